@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X SOR inversion engine.
+
+Metric (BASELINE.json): SOR grid-points x iterations per second, fp64, on the 3600 x 1800
+global lat-lon Poisson problem with a land/sea mask (configs[1]).  One *step* is one complete
+hot-path pass: `xinv_standard_2d_f64_dev` over one batch of synthetic input already resident in
+HBM, running a fixed number of sweeps (tolerance = 0, mxLoop = sweeps - 1), norm + stopping
+rule evaluated on the device after every sweep exactly as in production.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--sweeps S] [--spl 1|2] [--members M]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank solves its own
+member(s) of the batch axis (weak scaling, no data-path collective) and the per-slice flags
+are all-gathered over RCCL after each step.  Rank 0 prints ONE JSON line.
+
+Extra objects in the JSON line:
+  roofline      achieved = algorithmic bytes per sweep launch (48 B x grid points x sweeps per
+                launch) / mean launch duration, measured live with HIP events
+                on the solve's stream over the timed region (xinv_stats.sweep_ms).
+  cpu_baseline  the lexicographic C restatement of the reference (oracle/, 1 core) timed on
+                this box's host on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES = {'std2d': 48, 'gen2d': 72, 'std3d': 48}
+HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--sweeps', type=int, default=200, help='SOR sweeps per step')
+    ap.add_argument('--spl', type=int, default=0, help='sweeps fused per launch (0 = engine default)')
+    ap.add_argument('--rows', type=int, default=0, help='rows per tile (0 = engine default)')
+    ap.add_argument('--members', type=int, default=1, help='batch members per GPU')
+    ap.add_argument('--ny', type=int, default=1800)
+    ap.add_argument('--nx', type=int, default=3600)
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(p, budget_s):
+    """Time the oracle's lexicographic sweep (the reference's execution model: one slice, one
+    core) on member 0 of the same workload for about `budget_s` seconds."""
+    import oracle as orc
+    from xinvert_amd import synthetic
+    orc.build()
+    q = synthetic.member(p, 0)
+    c = [np.ascontiguousarray(a, dtype=np.float64) for a in q['coefs']]
+    npts = q['yc'] * q['xc']
+
+    def run(nsweeps):
+        S = np.array(q['S0'], dtype=np.float64, copy=True)
+        fl = np.array([0., 1., 0.])
+        t = time.perf_counter()
+        orc.standard_2d(S, *c, q['yc'], q['xc'], q['dely'], q['delx'], q['BCy'], q['BCx'],
+                        q['delxSqr'], q['ratioQtr'], q['ratioSqr'], q['optArg'], q['undef'], fl,
+                        nsweeps - 1, 0.0, orc.LEX)
+        return time.perf_counter() - t
+
+    t2 = run(2)
+    n = int(max(4, min(400, budget_s / max(t2 / 2, 1e-6))))
+    t = run(n)
+    return {'value': npts * n / t, 'unit': 'point-sweeps/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d lexicographic sweeps of the full %dx%d slice (%.1f s), oracle/xinv_oracle.c '
+                      'gcc -O3 -ffp-contract=off' % (n, q['yc'], q['xc'], t)}
+
+
+def main():
+    a = parse()
+    import torch
+    from xinvert_amd import _lib, synthetic
+    from xinvert_amd import dist as xdist
+
+    rank, local, world = xdist.init_process_group()
+    if world != a.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, a.gpus))
+    L = _lib.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    # synthetic workload: same grid on every rank, rank-dependent seed (independent members)
+    p = synthetic.poisson_latlon(a.ny, a.nx, mask=True, seed=synthetic.SEED + rank, members=a.members)
+    n = a.ny * a.nx
+    nb = a.members
+    S0 = torch.from_numpy(np.ascontiguousarray(p['S0'])).to(dev)
+    S = S0.clone()
+    coefs = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.float64)).to(dev) for c in p['coefs']]
+    strides = [n] + [0 if k in p['shared'] else n for k in range(len(coefs))]
+    st = _lib.strides_arg(strides)
+    flags = np.tile(np.array([0., 1., 0.]), (nb, 1))
+    opt = _lib.options(device=local, sweeps_per_launch=a.spl, rows_per_tile=a.rows, timing=1)
+    stream = torch.cuda.current_stream()
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    b = _lib.bc
+
+    def step():
+        rc = L.xinv_standard_2d_f64_dev(
+            ctypes.c_void_p(S.data_ptr()), *[ctypes.c_void_p(c.data_ptr()) for c in coefs],
+            nb, st, a.ny, a.nx, p['dely'], p['delx'], b(p['BCy']), b(p['BCx']), p['delxSqr'],
+            p['ratioQtr'], p['ratioSqr'], p['optArg'], p['undef'], _lib.hptr(flags),
+            a.sweeps - 1, 0.0, ctypes.byref(opt), sp)
+        _lib.check(rc)
+        s = _lib.last_stats()
+        allf = xdist.gather_flags(flags, nb * world) if world > 1 else flags
+        return s, allf
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        S.copy_(S0)
+        step()
+    S.copy_(S0)
+    barrier()
+    t0 = time.perf_counter()
+    ms_sweeps, launches = 0.0, 0
+    for _ in range(a.steps):
+        s, allf = step()
+        ms_sweeps += s['sweep_ms']; launches += s['sweep_launches']
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert int(allf[0, 2]) == a.sweeps - 1, allf[0]
+
+    if rank == 0:
+        total_ps = float(world) * nb * n * a.sweeps * a.steps
+        spl = s['sweeps_per_launch']
+        avg_ms = ms_sweeps / max(launches, 1)
+        alg_bytes = ALG_BYTES['std2d'] * n * nb * spl
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get('std2d_spl%d' % spl)
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'SOR grid-points*iters/sec (fp64) at %dx%d' % (a.nx, a.ny),
+            'value': total_ps / dt, 'unit': 'point-sweeps/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'invert_Poisson %dx%d lat-lon, land/sea mask, periodic-x, fixed-y '
+                                   '(BASELINE configs[1])' % (a.nx, a.ny),
+                       'sweeps_per_step': a.sweeps, 'members_per_gpu': nb,
+                       'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'],
+                       'path': {1: 'colour', 2: 'fused'}.get(s['path'], '?'),
+                       'parallelism': 'batch-axis shard x%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'k_fused2d<FusedStd2D,%d>' % spl,
+                         'avg_launch_ms': avg_ms, 'alg_bytes_per_launch': alg_bytes},
+        }
+        if world == 1 and not a.no_cpu:
+            out['cpu_baseline'] = cpu_baseline(p, a.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,165 @@
+/*
+ * xinv.h -- C-ABI of the MI355X SOR inversion engine (libxinv_hip.so).
+ *
+ * Drop-in boundary for the reference's hot path: every entry point replaces one call site of
+ * the numba kernels in the reference's xinvert/core.py (file:line cited per function, relative
+ * to the reference tree).  Plain pointers and sizes only; no C++/torch types cross this line.
+ * Implemented in xinvert_amd/csrc/xinv_hip.hip (hand-written HIP for gfx950).
+ *
+ * Conventions
+ *   - arrays are C-contiguous float64, x fastest: [yc][xc] or [zc][yc][xc]; a batch is
+ *     [nbatch] of those with a per-array batch stride in ELEMENTS (0 = one copy shared by all
+ *     members, kept once in HBM);
+ *   - S is read (initial guess / boundary values) and written in place, as the reference does;
+ *   - BC codes: XINV_BC_FIXED 0, XINV_BC_EXTEND 1, XINV_BC_PERIODIC 2 (the reference passes the
+ *     strings 'fixed' / 'extend' / 'periodic'; 'extend' on x or z is a no-op there and here);
+ *   - flags[3] per member = {overflow, last relative change of mean|S|, last loop index}
+ *     (reference numbas.py:401-414): flags[0] is written only on overflow, sweeps executed =
+ *     flags[2] + 1;
+ *   - return 0 on success, negative XINV_ERR_* otherwise; nothing throws across the ABI.
+ *
+ * Sweep ordering.  The reference sweeps lexicographically (serial Gauss-Seidel).  The engine
+ * sweeps red-black on (j+i)&1 when the cross coefficient B is identically zero and 4-colour on
+ * (j&1, i&1) otherwise (3-D: (k+j+i)&1); with periodic x and odd xc the last column is its own
+ * pair of colours.  Point arithmetic, masking predicate, 'extend' pre-pass, norm (mean |S| over
+ * S != undef) and the stopping rule are the reference's.
+ */
+#ifndef XINV_H
+#define XINV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XINV_BC_FIXED    0
+#define XINV_BC_EXTEND   1
+#define XINV_BC_PERIODIC 2
+
+#define XINV_OK          0
+#define XINV_ERR_ARG    -1   /* bad argument (sizes < 3, null pointer, unknown BC code, ...) */
+#define XINV_ERR_HIP    -2   /* a HIP runtime call failed; xinv_last_error() has the text     */
+#define XINV_ERR_NODEV  -3   /* no usable GPU                                                   */
+#define XINV_ERR_NOMEM  -4   /* device allocation failed                                        */
+
+/* kernel paths (xinv_options.path / xinv_stats.path) */
+#define XINV_PATH_AUTO   0
+#define XINV_PATH_COLOUR 1   /* one launch per colour, in place (general fallback)              */
+#define XINV_PATH_FUSED  2   /* streaming fused red+black sweep(s), ping-pong buffers (2-D)     */
+
+typedef struct xinv_options {
+    int32_t device;             /* HIP device ordinal; -1 = current device                      */
+    int32_t path;               /* XINV_PATH_*                                                   */
+    int32_t sweeps_per_launch;  /* fused path: sweeps fused in one launch (1..4); 0 = auto      */
+    int32_t check_every;        /* launches between host polls of the device stop flags; 0=auto */
+    int32_t rows_per_tile;      /* fused path: rows marched by one wavefront; 0 = auto          */
+    int32_t timing;             /* 1: bracket launch chunks with HIP events (xinv_last_stats)   */
+    int32_t reserved[2];
+} xinv_options;
+
+typedef struct xinv_stats {
+    int32_t path;               /* path actually used                                           */
+    int32_t colours;            /* colours per sweep (2, 4, or +2 with the odd-periodic seam)   */
+    int32_t sweeps_per_launch;
+    int32_t rows_per_tile;
+    int64_t sweep_launches;     /* sweep-kernel launches issued (incl. no-op tail launches)     */
+    int64_t sweeps_max;         /* max over members of sweeps executed                          */
+    double  sweep_ms;           /* HIP-event time over all launch chunks (timing=1), ms         */
+    double  h2d_ms, d2h_ms;     /* host-pointer entry points only                               */
+} xinv_stats;
+
+void        xinv_default_options(xinv_options *opt);
+int         xinv_last_stats(xinv_stats *out);       /* stats of the calling thread's last solve */
+const char *xinv_last_error(void);
+int         xinv_device_count(void);
+int         xinv_version(void);
+
+/* ---- single slice, HOST pointers: positional twins of the numba kernels -------------------
+ * xinv_standard_2d_f64  replaces numbas.invert_standard_2D  called at core.py:130-139
+ * xinv_general_2d_f64   replaces numbas.invert_general_2D   called at core.py:419-428
+ * xinv_standard_3d_f64  replaces numbas.invert_standard_3D  called at core.py:60-69
+ * Upload, solve on the current device, download S and flags. */
+int xinv_standard_2d_f64(double *S, const double *A, const double *B, const double *C,
+                         const double *F, int64_t yc, int64_t xc, double dely, double delx,
+                         int BCy, int BCx, double delxSqr, double ratioQtr, double ratioSqr,
+                         double optArg, double undef, double *flags, int64_t mxLoop,
+                         double tolerance);
+
+int xinv_general_2d_f64(double *S, const double *A, const double *B, const double *C,
+                        const double *D, const double *E, const double *F, const double *G,
+                        int64_t yc, int64_t xc, double dely, double delx, int BCy, int BCx,
+                        double delxSqr, double ratio, double ratioQtr, double ratioSqr,
+                        double optArg, double undef, double *flags, int64_t mxLoop,
+                        double tolerance);
+
+int xinv_standard_3d_f64(double *S, const double *A, const double *B, const double *C,
+                         const double *F, int64_t zc, int64_t yc, int64_t xc, double delz,
+                         double dely, double delx, int BCz, int BCy, int BCx, double delxSqr,
+                         double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                         double *flags, int64_t mxLoop, double tolerance);
+
+/* ---- batched over the outer (time / level / member) axis ----------------------------------
+ * The loop `for selDict in loop_noncore(F, dims)` of core.py:129 / 418 / 59 becomes ONE call.
+ * strides[]: batch stride in elements for each array, in argument order
+ *            (2-D standard / 3-D: S,A,B,C,F ; 2-D general: S,A,B,C,D,E,F,G); 0 = shared.
+ * flags:     [nbatch*3], caller-initialised (the reference passes {0,1,0}).
+ * opt:       may be NULL (defaults).
+ * *_batched  take HOST pointers (staged through pinned buffers, coefficients with stride 0
+ *            uploaded once); *_dev take DEVICE pointers already resident in HBM on opt->device
+ *            and run on `stream` (a hipStream_t, NULL = default stream); flags stays a HOST
+ *            pointer.  Both return after the solve has completed. */
+int xinv_standard_2d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                 const double *F, int64_t nbatch, const int64_t *strides,
+                                 int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                                 int BCx, double delxSqr, double ratioQtr, double ratioSqr,
+                                 double optArg, double undef, double *flags, int64_t mxLoop,
+                                 double tolerance, const xinv_options *opt);
+
+int xinv_general_2d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                const double *D, const double *E, const double *F,
+                                const double *G, int64_t nbatch, const int64_t *strides,
+                                int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                                int BCx, double delxSqr, double ratio, double ratioQtr,
+                                double ratioSqr, double optArg, double undef, double *flags,
+                                int64_t mxLoop, double tolerance, const xinv_options *opt);
+
+int xinv_standard_3d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                 const double *F, int64_t nbatch, const int64_t *strides,
+                                 int64_t zc, int64_t yc, int64_t xc, double delz, double dely,
+                                 double delx, int BCz, int BCy, int BCx, double delxSqr,
+                                 double ratio2Sqr, double ratio1Sqr, double optArg,
+                                 double undef, double *flags, int64_t mxLoop, double tolerance,
+                                 const xinv_options *opt);
+
+int xinv_standard_2d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                             const double *F, int64_t nbatch, const int64_t *strides,
+                             int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                             int BCx, double delxSqr, double ratioQtr, double ratioSqr,
+                             double optArg, double undef, double *flags, int64_t mxLoop,
+                             double tolerance, const xinv_options *opt, void *stream);
+
+int xinv_general_2d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                            const double *D, const double *E, const double *F, const double *G,
+                            int64_t nbatch, const int64_t *strides, int64_t yc, int64_t xc,
+                            double dely, double delx, int BCy, int BCx, double delxSqr,
+                            double ratio, double ratioQtr, double ratioSqr, double optArg,
+                            double undef, double *flags, int64_t mxLoop, double tolerance,
+                            const xinv_options *opt, void *stream);
+
+int xinv_standard_3d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                             const double *F, int64_t nbatch, const int64_t *strides,
+                             int64_t zc, int64_t yc, int64_t xc, double delz, double dely,
+                             double delx, int BCz, int BCy, int BCx, double delxSqr,
+                             double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                             double *flags, int64_t mxLoop, double tolerance,
+                             const xinv_options *opt, void *stream);
+
+/* mean |S| over S != undef of one device-resident slab of n elements (reference
+ * numbas.absNorm2D/3D, numbas.py:1710-1728 / 1689-1708); *out is a host double. */
+int xinv_abs_norm_f64_dev(const double *S, int64_t n, double undef, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XINV_H */

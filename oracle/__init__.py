@@ -1,0 +1,9 @@
+"""CPU oracle for the SOR hot path -- TEST INFRASTRUCTURE, never the product.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  See oracle/xinv_oracle.c for what is restated and how it is pinned.
+"""
+from .oracle import (  # noqa: F401
+    LEX, COLOUR_AUTO, COLOUR_2, COLOUR_4, BC_CODES,
+    build, lib, standard_2d, general_2d, standard_3d, abs_norm,
+)

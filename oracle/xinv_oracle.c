@@ -1,0 +1,425 @@
+/*
+ * xinv_oracle.c -- CPU restatement of the reference SOR kernels.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker for the HIP path, never the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library built
+ * from it.  The product (xinvert_amd/) never links, imports or calls it.
+ *
+ * What it restates (all file:line relative to /root/reference):
+ *   xo_standard_2d  <- xinvert/numbas.py:215-416   invert_standard_2D
+ *   xo_general_2d   <- xinvert/numbas.py:987-1201  invert_general_2D
+ *   xo_standard_3d  <- xinvert/numbas.py:15-212    invert_standard_3D
+ *   norm2d / norm3d <- xinvert/numbas.py:1710-1728 / 1689-1708  absNorm2D / absNorm3D
+ *
+ * Two orderings of the same point update:
+ *   order == XO_LEX       the reference's lexicographic Gauss-Seidel SOR (row-major, in place).
+ *                         Pinned bit-for-bit (S and flags) against the reference's own numbas.py
+ *                         imported as plain Python in the build container
+ *                         (tests/golden/gen_golden.py -> tests/golden/ fixtures) and against the
+ *                         loop counts / known answers the reference's tests and notebooks print.
+ *   order == XO_COLOUR_*  the coloured (red-black / 4-colour) ordering the HIP kernels use.
+ *                         Same per-point arithmetic, same boundary pre-pass, same norm and
+ *                         stopping rule; only the visiting order of the points inside one sweep
+ *                         changes.  Parity of the HIP path is bitwise (S) against this ordering;
+ *                         converged fields agree with XO_LEX to <= 1e-6 rel-L2 (tests).
+ *
+ * Arithmetic notes.  Every expression keeps the reference's association order; build with
+ * -ffp-contract=off (no FMA), no fast-math.  BC codes: 0 fixed, 1 extend, 2 periodic.
+ *
+ * Deliberate, documented deviation: the 'extend' pre-pass second loop (numbas.py:297-301) runs
+ * `for i in range(1, yc-1)` over a COLUMN index; for yc > xc the reference indexes out of bounds
+ * (undefined under numba's unchecked indexing).  Here the index is clamped to i < xc.
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#define XO_LEX 0
+#define XO_COLOUR_AUTO 1
+#define XO_COLOUR_2 2
+#define XO_COLOUR_4 4
+
+#define BC_FIXED 0
+#define BC_EXTEND 1
+#define BC_PERIODIC 2
+
+/* ---------------------------------------------------------------- norms */
+/* numbas.py:1710-1728 */
+static double norm2d(const double *S, int64_t yc, int64_t xc, double undef)
+{
+    double norm = 0.0;
+    int64_t count = 0;
+    for (int64_t j = 0; j < yc; j++)
+        for (int64_t i = 0; i < xc; i++) {
+            double v = S[j * xc + i];
+            if (v != undef) { norm += fabs(v); count++; }
+        }
+    if (count != 0) norm /= (double)count; else norm = NAN;
+    return norm;
+}
+
+/* numbas.py:1689-1708 */
+static double norm3d(const double *S, int64_t zc, int64_t yc, int64_t xc, double undef)
+{
+    return norm2d(S, zc * yc, xc, undef);   /* same row-major serial order */
+}
+
+/* ------------------------------------------------- sweep-loop control (a5) */
+/* numbas.py:401-414 (std 2D), 1186-1199 (gen 2D), 197-210 (3D).  Returns 1 to stop. */
+typedef struct { int64_t loop; double normPrev; } xo_ctl;
+
+static int ctl_step(xo_ctl *c, double norm, double *flags, int64_t mxLoop, double tol,
+                    int stop_on_zero_norm)
+{
+    if (isnan(norm) || norm > 1e100) { flags[0] = 1.0; return 1; }
+    flags[1] = fabs(norm - c->normPrev) / c->normPrev;
+    flags[2] = (double)c->loop;
+    if (flags[1] < tol || c->loop >= mxLoop || (stop_on_zero_norm && norm == 0.0)) return 1;
+    c->normPrev = norm;
+    c->loop += 1;
+    return 0;
+}
+
+/* ------------------------------------------- 'extend' boundary pre-pass (a6) */
+/* numbas.py:284-310 / 1064-1090: one 2-D slab of yc x xc. */
+static void extend2d(double *S, int64_t yc, int64_t xc, int BCx, double undef)
+{
+    double *r0 = S, *r1 = S + xc, *rm2 = S + (yc - 2) * xc, *rm1 = S + (yc - 1) * xc;
+    if (BCx == BC_PERIODIC) {
+        for (int64_t i = 0; i < xc; i++) {
+            if (r1[i] != undef) r0[i] = r1[i];
+            if (rm2[i] != undef) rm1[i] = rm2[i];
+        }
+    } else {
+        for (int64_t i = 1; i < xc - 1; i++) {
+            if (r1[i] != undef) r0[i] = r1[i];
+            if (rm2[i] != undef) rm1[i] = rm2[i];
+        }
+        int64_t lim = yc - 1 < xc ? yc - 1 : xc;          /* clamp: see header */
+        for (int64_t i = 1; i < lim; i++) {
+            if (r1[i] != undef) r0[i] = r1[i];
+            if (rm2[i] != undef) rm1[i] = rm2[i];
+        }
+        if (r1[1] != undef) r0[0] = r1[1];
+        if (r1[xc - 2] != undef) r0[xc - 1] = r1[xc - 2];
+        if (rm2[1] != undef) rm1[0] = rm2[1];
+        if (rm2[xc - 2] != undef) rm1[xc - 1] = rm2[xc - 2];
+    }
+}
+
+/* numbas.py:87-115: planes k = 1 .. zc-2 only; the non-periodic branch repeats the same
+ * i-loop twice (idempotent) and fixes the four corners of each plane. */
+static void extend3d(double *S, int64_t zc, int64_t yc, int64_t xc, int BCx, double undef)
+{
+    for (int64_t k = 1; k < zc - 1; k++) {
+        double *P = S + k * yc * xc;
+        double *r0 = P, *r1 = P + xc, *rm2 = P + (yc - 2) * xc, *rm1 = P + (yc - 1) * xc;
+        if (BCx == BC_PERIODIC) {
+            for (int64_t i = 0; i < xc; i++) {
+                if (r1[i] != undef) r0[i] = r1[i];
+                if (rm2[i] != undef) rm1[i] = rm2[i];
+            }
+        } else {
+            for (int64_t i = 1; i < xc - 1; i++) {
+                if (r1[i] != undef) r0[i] = r1[i];
+                if (rm2[i] != undef) rm1[i] = rm2[i];
+            }
+            if (r1[1] != undef) r0[0] = r1[1];
+            if (r1[xc - 2] != undef) r0[xc - 1] = r1[xc - 2];
+            if (rm2[1] != undef) rm1[0] = rm2[1];
+            if (rm2[xc - 2] != undef) rm1[xc - 1] = rm2[xc - 2];
+        }
+    }
+}
+
+/* ------------------------------------------------------------ point updates */
+/* numbas.py:343-369 (inner), 314-340 (west, im = xc-1, ip = 1), 373-399 (east, im = xc-2,
+ * ip = 0).  `west` reproduces the two irregularities of the reference's i == 0 branch
+ * (numbas.py:327-328): it multiplies by B[j+1,1] where it tested B[j+1,0], and it differences
+ * S[j-1,0] - S[j-1,-1] where the inner loop has S[j-1,i+1] - S[j-1,i-1]. */
+static inline void upd_std2d(double *S, const double *A, const double *B, const double *C,
+                             const double *F, int64_t xc, int64_t j, int64_t i, int64_t im,
+                             int64_t ip, int west, double delxSqr, double ratioQtr,
+                             double ratioSqr, double optArg, double undef)
+{
+    const int64_t r = j * xc, rp = (j + 1) * xc, rm = (j - 1) * xc;
+    const int64_t bn = west ? ip : i, sq = west ? i : ip;
+    int cond = (F[r + i] != undef &&
+                A[rp + i] != undef && A[r + i] != undef &&
+                B[r + ip] != undef && B[r + im] != undef &&
+                B[rp + i] != undef && B[rm + i] != undef &&
+                C[r + ip] != undef && C[r + i] != undef);
+    if (!cond) return;
+    double temp = (
+        (
+            A[rp + i] * (S[rp + i] - S[r + i]) -
+            A[r + i] * (S[r + i] - S[rm + i])
+        ) * ratioSqr + (
+            B[rp + bn] * (S[rp + ip] - S[rp + im]) -
+            B[rm + i] * (S[rm + sq] - S[rm + im])
+        ) * ratioQtr + (
+            B[r + ip] * (S[rp + ip] - S[rm + ip]) -
+            B[r + im] * (S[rp + im] - S[rm + im])
+        ) * ratioQtr + (
+            C[r + ip] * (S[r + ip] - S[r + i]) -
+            C[r + i] * (S[r + i] - S[r + im])
+        )
+    ) - F[r + i] * delxSqr;
+    temp *= optArg / ((A[rp + i] + A[r + i]) * ratioSqr + (C[r + ip] + C[r + i]));
+    S[r + i] += temp;
+}
+
+/* numbas.py:1125-1153 (inner), 1094-1122 (west), 1156-1184 (east). */
+static inline void upd_gen2d(double *S, const double *A, const double *B, const double *C,
+                             const double *D, const double *E, const double *F, const double *G,
+                             int64_t xc, int64_t j, int64_t i, int64_t im, int64_t ip,
+                             double delx, double delxSqr, double ratio, double ratioQtr,
+                             double ratioSqr, double optArg, double undef)
+{
+    const int64_t r = j * xc, rp = (j + 1) * xc, rm = (j - 1) * xc;
+    int cond = (G[r + i] != undef &&
+                A[r + i] != undef && B[r + i] != undef &&
+                C[r + i] != undef && D[r + i] != undef &&
+                E[r + i] != undef && F[r + i] != undef);
+    if (!cond) return;
+    double temp = (
+        A[r + i] * (
+            (S[rp + i] - S[r + i]) - (S[r + i] - S[rm + i])
+        ) * ratioSqr +
+        B[r + i] * (
+            (S[rp + ip] - S[rm + ip]) - (S[rp + im] - S[rm + im])
+        ) * ratioQtr +
+        C[r + i] * (
+            (S[r + ip] - S[r + i]) - (S[r + i] - S[r + im])
+        ) + (
+        D[r + i] * (
+            (S[rp + i] - S[rm + i])
+        ) * ratio +
+        E[r + i] * (
+            (S[r + ip] - S[r + im])
+        )) * delx / 2.0 + (
+        F[r + i] * S[r + i] - G[r + i]) * delxSqr
+    );
+    temp *= optArg / ((A[r + i] * ratioSqr + C[r + i]) * 2.0
+                      - F[r + i] * delxSqr);
+    S[r + i] += temp;
+}
+
+/* numbas.py:146-169 (inner), 120-143 (west), 172-195 (east).  P = yc*xc plane stride. */
+static inline void upd_std3d(double *S, const double *A, const double *B, const double *C,
+                             const double *F, int64_t P, int64_t xc, int64_t k, int64_t j,
+                             int64_t i, int64_t im, int64_t ip, double delxSqr,
+                             double ratio2Sqr, double ratio1Sqr, double optArg, double undef)
+{
+    const int64_t r = k * P + j * xc;
+    const int64_t c = r + i;
+    int cond = (F[c] != undef &&
+                A[c + P] != undef && A[c] != undef &&
+                B[c + xc] != undef && B[c] != undef &&
+                C[r + ip] != undef && C[c] != undef);
+    if (!cond) return;
+    double temp = (
+        (
+            A[c + P] * (S[c + P] - S[c]) -
+            A[c] * (S[c] - S[c - P])
+        ) * ratio2Sqr + (
+            B[c + xc] * (S[c + xc] - S[c]) -
+            B[c] * (S[c] - S[c - xc])
+        ) * ratio1Sqr + (
+            C[r + ip] * (S[r + ip] - S[c]) -
+            C[c] * (S[c] - S[r + im])
+        )
+    ) - F[c] * delxSqr;
+    temp *= optArg / ((A[c + P] + A[c]) * ratio2Sqr +
+                      (B[c + xc] + B[c]) * ratio1Sqr +
+                      (C[r + ip] + C[c]));
+    S[c] += temp;
+}
+
+/* ------------------------------------------------------------------ colours */
+/* Colour of point (j,i) (2-D) for the coloured ordering.  base = 2: red-black on (j+i)&1,
+ * valid when the cross coefficient B is identically zero (5-point coupling); base = 4:
+ * (j&1, i&1), valid for the full 9-point coupling.  With periodic x and odd xc, columns 0 and
+ * xc-1 are neighbours of equal base colour, so column xc-1 forms two extra colours by row
+ * parity (a "seam").  The HIP kernels use exactly this function. */
+static inline int colour2d(int64_t j, int64_t i, int64_t xc, int base, int seam)
+{
+    if (seam && i == xc - 1) return base + (int)(j & 1);
+    if (base == 2) return (int)((j + i) & 1);
+    return (int)(2 * (j & 1) + (i & 1));
+}
+
+static int all_zero(const double *B, int64_t n)
+{
+    for (int64_t t = 0; t < n; t++) if (B[t] != 0.0) return 0;
+    return 1;
+}
+
+/* ---------------------------------------------------------------- kernels */
+int xo_standard_2d(double *S, const double *A, const double *B, const double *C,
+                   const double *F, int64_t yc, int64_t xc, double dely, double delx,
+                   int BCy, int BCx, double delxSqr, double ratioQtr, double ratioSqr,
+                   double optArg, double undef, double *flags, int64_t mxLoop,
+                   double tolerance, int order)
+{
+    (void)dely; (void)delx;
+    if (yc < 3 || xc < 3) return -1;
+    xo_ctl ctl = { 0, DBL_MAX };
+    const int per = (BCx == BC_PERIODIC);
+    int base = 0, seam = 0;
+    if (order != XO_LEX) {
+        base = order == XO_COLOUR_AUTO ? (all_zero(B, yc * xc) ? 2 : 4) : order;
+        seam = per && (xc & 1);
+    }
+    const int ncol = base + (seam ? 2 : 0);
+    const int64_t i0 = per ? 0 : 1, i1 = per ? xc : xc - 1;
+
+    for (;;) {
+        if (BCy == BC_EXTEND) extend2d(S, yc, xc, BCx, undef);
+
+        if (order == XO_LEX) {
+            for (int64_t j = 1; j < yc - 1; j++) {
+                if (per)
+                    upd_std2d(S, A, B, C, F, xc, j, 0, xc - 1, 1, 1,
+                              delxSqr, ratioQtr, ratioSqr, optArg, undef);
+                for (int64_t i = 1; i < xc - 1; i++)
+                    upd_std2d(S, A, B, C, F, xc, j, i, i - 1, i + 1, 0,
+                              delxSqr, ratioQtr, ratioSqr, optArg, undef);
+                if (per)
+                    upd_std2d(S, A, B, C, F, xc, j, xc - 1, xc - 2, 0, 0,
+                              delxSqr, ratioQtr, ratioSqr, optArg, undef);
+            }
+        } else {
+            for (int c = 0; c < ncol; c++)
+                for (int64_t j = 1; j < yc - 1; j++)
+                    for (int64_t i = i0; i < i1; i++) {
+                        if (colour2d(j, i, xc, base, seam) != c) continue;
+                        int64_t im = i == 0 ? xc - 1 : i - 1;
+                        int64_t ip = i == xc - 1 ? 0 : i + 1;
+                        upd_std2d(S, A, B, C, F, xc, j, i, im, ip, i == 0,
+                                  delxSqr, ratioQtr, ratioSqr, optArg, undef);
+                    }
+        }
+
+        double norm = norm2d(S, yc, xc, undef);
+        if (ctl_step(&ctl, norm, flags, mxLoop, tolerance, 1)) break;
+    }
+    return 0;
+}
+
+int xo_general_2d(double *S, const double *A, const double *B, const double *C,
+                  const double *D, const double *E, const double *F, const double *G,
+                  int64_t yc, int64_t xc, double dely, double delx, int BCy, int BCx,
+                  double delxSqr, double ratio, double ratioQtr, double ratioSqr,
+                  double optArg, double undef, double *flags, int64_t mxLoop,
+                  double tolerance, int order)
+{
+    (void)dely;
+    if (yc < 3 || xc < 3) return -1;
+    xo_ctl ctl = { 0, DBL_MAX };
+    const int per = (BCx == BC_PERIODIC);
+    int base = 0, seam = 0;
+    if (order != XO_LEX) {
+        base = order == XO_COLOUR_AUTO ? (all_zero(B, yc * xc) ? 2 : 4) : order;
+        seam = per && (xc & 1);
+    }
+    const int ncol = base + (seam ? 2 : 0);
+    const int64_t i0 = per ? 0 : 1, i1 = per ? xc : xc - 1;
+
+    for (;;) {
+        if (BCy == BC_EXTEND) extend2d(S, yc, xc, BCx, undef);
+
+        if (order == XO_LEX) {
+            for (int64_t j = 1; j < yc - 1; j++) {
+                if (per)
+                    upd_gen2d(S, A, B, C, D, E, F, G, xc, j, 0, xc - 1, 1,
+                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+                for (int64_t i = 1; i < xc - 1; i++)
+                    upd_gen2d(S, A, B, C, D, E, F, G, xc, j, i, i - 1, i + 1,
+                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+                if (per)
+                    upd_gen2d(S, A, B, C, D, E, F, G, xc, j, xc - 1, xc - 2, 0,
+                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+            }
+        } else {
+            for (int c = 0; c < ncol; c++)
+                for (int64_t j = 1; j < yc - 1; j++)
+                    for (int64_t i = i0; i < i1; i++) {
+                        if (colour2d(j, i, xc, base, seam) != c) continue;
+                        int64_t im = i == 0 ? xc - 1 : i - 1;
+                        int64_t ip = i == xc - 1 ? 0 : i + 1;
+                        upd_gen2d(S, A, B, C, D, E, F, G, xc, j, i, im, ip,
+                                  delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+                    }
+        }
+
+        double norm = norm2d(S, yc, xc, undef);
+        if (ctl_step(&ctl, norm, flags, mxLoop, tolerance, 0)) break;
+    }
+    return 0;
+}
+
+/* BCz is accepted and never read, exactly as numbas.py:16-19. */
+int xo_standard_3d(double *S, const double *A, const double *B, const double *C,
+                   const double *F, int64_t zc, int64_t yc, int64_t xc, double delz,
+                   double dely, double delx, int BCz, int BCy, int BCx, double delxSqr,
+                   double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                   double *flags, int64_t mxLoop, double tolerance, int order)
+{
+    (void)delz; (void)dely; (void)delx; (void)BCz;
+    if (zc < 3 || yc < 3 || xc < 3) return -1;
+    xo_ctl ctl = { 0, DBL_MAX };
+    const int per = (BCx == BC_PERIODIC);
+    const int seam = (order != XO_LEX) && per && (xc & 1);
+    const int ncol = 2 + (seam ? 2 : 0);
+    const int64_t i0 = per ? 0 : 1, i1 = per ? xc : xc - 1;
+    const int64_t P = yc * xc;
+
+    for (;;) {
+        if (BCy == BC_EXTEND) extend3d(S, zc, yc, xc, BCx, undef);
+
+        if (order == XO_LEX) {
+            for (int64_t k = 1; k < zc - 1; k++)
+                for (int64_t j = 1; j < yc - 1; j++) {
+                    if (per)
+                        upd_std3d(S, A, B, C, F, P, xc, k, j, 0, xc - 1, 1,
+                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                    for (int64_t i = 1; i < xc - 1; i++)
+                        upd_std3d(S, A, B, C, F, P, xc, k, j, i, i - 1, i + 1,
+                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                    if (per)
+                        upd_std3d(S, A, B, C, F, P, xc, k, j, xc - 1, xc - 2, 0,
+                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                }
+        } else {
+            for (int c = 0; c < ncol; c++)
+                for (int64_t k = 1; k < zc - 1; k++)
+                    for (int64_t j = 1; j < yc - 1; j++)
+                        for (int64_t i = i0; i < i1; i++) {
+                            int col = (seam && i == xc - 1) ? 2 + (int)((k + j) & 1)
+                                                             : (int)((k + j + i) & 1);
+                            if (col != c) continue;
+                            int64_t im = i == 0 ? xc - 1 : i - 1;
+                            int64_t ip = i == xc - 1 ? 0 : i + 1;
+                            upd_std3d(S, A, B, C, F, P, xc, k, j, i, im, ip,
+                                      delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                        }
+        }
+
+        double norm = norm3d(S, zc, yc, xc, undef);
+        if (ctl_step(&ctl, norm, flags, mxLoop, tolerance, 0)) break;
+    }
+    return 0;
+}
+
+/* Standalone norm entry points (for tests of the fused device-side norm). */
+double xo_abs_norm_2d(const double *S, int64_t yc, int64_t xc, double undef)
+{
+    return norm2d(S, yc, xc, undef);
+}
+
+double xo_abs_norm_3d(const double *S, int64_t zc, int64_t yc, int64_t xc, double undef)
+{
+    return norm3d(S, zc, yc, xc, undef);
+}

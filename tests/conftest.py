@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _gpu_count():
+    try:
+        from xinvert_amd import _lib
+        return _lib.load().xinv_device_count()
+    except Exception:
+        return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests never fall back: without a visible device they are skipped (CPU container),
+    # with one they run through the HIP library or fail.
+    if _gpu_count() > 0:
+        return
+    skip = pytest.mark.skip(reason='no HIP device visible (GPU parity tests run on the MI355X box)')
+    for it in items:
+        if 'gpu' in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    import oracle as orc
+    orc.build()
+    return orc

@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the C-ABI) against the coloured-ordering oracle.
+
+Bar: S bit-exact (same ordering, same arithmetic, no FMA contraction on either side); the
+norm-derived flags[1] to 1e-10 relative (the device adds the mean|S| partials in a different,
+but fixed, order); flags[2] (loop index) equal.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+from util import rand2d, rand3d, run_oracle, run_hip_single, run_hip_batched, run_hip_dev
+
+pytestmark = pytest.mark.gpu
+
+def _seed(key):
+    return zlib.crc32(repr(key).encode()) & 0x7fffffff
+
+
+COLOUR_AUTO, COLOUR_2 = 1, 2
+PATH_COLOUR, PATH_FUSED = 1, 2
+
+
+def assert_same(S, fl, So, flo, what=''):
+    assert np.array_equal(S, So), '%s: S differs, max |d| = %g at %d points' % (
+        what, np.nanmax(np.abs(S - So)), int((S != So).sum()))
+    assert fl[2] == flo[2], '%s: loop index %r vs oracle %r' % (what, fl[2], flo[2])
+    assert fl[0] == flo[0]
+    assert np.isclose(fl[1], flo[1], rtol=1e-10, atol=0), (what, fl, flo)
+
+
+BCS = [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'fixed'), ('extend', 'periodic'),
+       ('fixed', 'extend')]
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+@pytest.mark.parametrize('BCy,BCx', BCS)
+@pytest.mark.parametrize('bnz', [0, 1])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', [(17, 24), (12, 19), (21, 70)])
+def test_colour_path_2d(kind, BCy, BCx, bnz, msk, shape):
+    p = rand2d(kind, shape[0], shape[1], BCy, BCx, bnz, msk, seed=_seed((kind, BCy, BCx, bnz, msk, shape)))
+    So, flo = run_oracle(p, 25, 1e-9, COLOUR_AUTO)
+    S, fl, st = run_hip_batched([p], 25, 1e-9, path=PATH_COLOUR)
+    assert st['path'] == PATH_COLOUR
+    assert_same(S[0], fl[0], So, flo, 'colour path %s' % kind)
+
+
+@pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'), ('extend', 'fixed')])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', [(6, 9, 12), (5, 7, 9), (7, 10, 66)])
+def test_colour_path_3d(BCy, BCx, msk, shape):
+    p = rand3d(shape[0], shape[1], shape[2], BCy, BCx, msk, seed=_seed((BCy, BCx, msk, shape)))
+    So, flo = run_oracle(p, 15, 1e-9, COLOUR_AUTO)
+    S, fl, st = run_hip_batched([p], 15, 1e-9)
+    assert_same(S[0], fl[0], So, flo, '3d')
+
+
+FUSED_SHAPES = [(17, 24), (12, 20), (40, 300), (70, 130), (33, 257), (8, 4), (3, 3), (64, 512)]
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+@pytest.mark.parametrize('BCy,BCx', BCS)
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', FUSED_SHAPES)
+@pytest.mark.parametrize('K', [1, 2])
+def test_fused_path(kind, BCy, BCx, msk, shape, K):
+    yc, xc = shape
+    if BCx == 'periodic' and xc % 2:
+        pytest.skip('odd-xc periodic seam goes through the colour path (covered there)')
+    p = rand2d(kind, yc, xc, BCy, BCx, 0, msk, seed=_seed((kind, BCy, BCx, msk, shape)))
+    So, flo = run_oracle(p, 24, 1e-9, COLOUR_2)
+    S, fl, st = run_hip_batched([p], 24, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=16)
+    assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == K
+    assert_same(S[0], fl[0], So, flo, 'fused K=%d %s %r' % (K, kind, shape))
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+@pytest.mark.parametrize('K', [1, 2])
+@pytest.mark.parametrize('tol', [3e-3, 1e-3, 2e-4])
+def test_fused_early_stop_exact_sweep(kind, K, tol):
+    """Stopping inside a K-sweep launch must return the state of exactly the stopping sweep."""
+    p = rand2d(kind, 40, 300, 'fixed', 'periodic', 0, 1, seed=7)
+    So, flo = run_oracle(p, 500, tol, COLOUR_2)
+    assert 2 < flo[2] < 499
+    S, fl, st = run_hip_batched([p], 500, tol, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=8,
+                                check_every=5)
+    assert_same(S[0], fl[0], So, flo, 'early stop')
+    assert st['sweeps_max'] == flo[2] + 1
+
+
+def test_fused_equals_colour_path():
+    p = rand2d('gen2d', 50, 260, 'extend', 'periodic', 0, 1, seed=11)
+    S1, f1, _ = run_hip_batched([p], 30, 0.0, path=PATH_FUSED)
+    S2, f2, _ = run_hip_batched([p], 30, 0.0, path=PATH_COLOUR)
+    assert np.array_equal(S1, S2)
+    assert np.allclose(f1, f2, rtol=1e-10)
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+def test_batched_shared_coefficients_and_per_member_stop(kind):
+    """Members stop at different sweeps; coefficients shared with batch stride 0."""
+    base = rand2d(kind, 36, 200, 'fixed', 'periodic', 0, 0, seed=3)
+    ps = []
+    rng = np.random.default_rng(5)
+    for m in range(5):
+        q = dict(base)
+        q['coefs'] = list(base['coefs'])
+        q['coefs'][-1] = base['coefs'][-1] * (1.0 + m) + rng.standard_normal(base['S0'].shape) * 0.01 * m
+        q['S0'] = base['S0'] * (m + 1)
+        ps.append(q)
+    shared = tuple(range(len(base['coefs']) - 1))
+    S, fl, st = run_hip_batched(ps, 400, 5e-4, shared=shared, sweeps_per_launch=2)
+    loops = set()
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 400, 5e-4, COLOUR_2)
+        assert_same(S[m], fl[m], So, flo, 'member %d' % m)
+        loops.add(flo[2])
+    assert len(loops) > 1, 'test should exercise different stopping sweeps'
+
+
+def test_dev_api_matches_host_api():
+    ps = [rand2d('std2d', 48, 280, 'fixed', 'periodic', 0, 1, seed=s) for s in (1, 2, 3)]
+    S1, f1, _ = run_hip_batched(ps, 40, 1e-7)
+    S2, f2, st = run_hip_dev(ps, 40, 1e-7, timing=1)
+    assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
+    assert st['sweep_ms'] > 0
+
+
+def test_single_slice_positional_twins():
+    for p in (rand2d('std2d', 30, 64, 'extend', 'periodic', 1, 1, seed=4),
+              rand2d('gen2d', 30, 64, 'fixed', 'fixed', 0, 1, seed=5),
+              rand3d(6, 12, 20, 'fixed', 'periodic', 1, seed=6)):
+        So, flo = run_oracle(p, 20, 1e-9, COLOUR_AUTO)
+        S, fl = run_hip_single(p, 20, 1e-9)
+        assert_same(S, fl, So, flo, 'single ' + p['kind'])
+
+
+def test_overflow_flag():
+    """omega far outside (0,2) diverges: flags[0] set, as numbas.py:403-405."""
+    p = rand2d('gen2d', 20, 40, 'fixed', 'fixed', 0, 0, seed=9, omega=40.0)
+    So, flo = run_oracle(p, 2000, 1e-12, COLOUR_2)
+    S, fl, _ = run_hip_batched([p], 2000, 1e-12)
+    assert flo[0] == 1.0 and fl[0][0] == 1.0
+    assert fl[0][2] == flo[2]
+
+
+def test_restartable_in_place():
+    """animate_iteration's contract (apps.py:1031-1044): two calls of n sweeps == one of 2n."""
+    p = rand2d('std2d', 40, 140, 'fixed', 'periodic', 0, 1, seed=21)
+    S_a, _, _ = run_hip_batched([p], 19, 0.0)          # 20 sweeps
+    q = dict(p); q['S0'] = S_a[0]
+    S_b, _, _ = run_hip_batched([q], 19, 0.0)          # 20 more
+    S_c, _, _ = run_hip_batched([p], 39, 0.0)          # 40 at once
+    assert np.array_equal(S_b, S_c)
+
+
+def test_bad_arguments():
+    from xinvert_amd import _lib
+    p = rand2d('std2d', 2, 10, 'fixed', 'fixed', 0, 0)
+    with pytest.raises(_lib.XinvError):
+        run_hip_single(p, 10, 1e-9)

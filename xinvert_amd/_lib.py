@@ -1,0 +1,140 @@
+"""ctypes binding of libxinv_hip.so (C-ABI declared in include/xinv.h).
+
+This is the ONLY compute path of the package: if the HIP library cannot be loaded, or it
+reports no GPU, every solve raises -- there is no CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, 'libxinv_hip.so')
+
+BC_CODES = {'fixed': 0, 'extend': 1, 'periodic': 2}
+PATH_AUTO, PATH_COLOUR, PATH_FUSED = 0, 1, 2
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int64)
+_i64, _f64, _int, _vp = ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_void_p
+
+
+class XinvOptions(ctypes.Structure):
+    _fields_ = [('device', ctypes.c_int32), ('path', ctypes.c_int32),
+                ('sweeps_per_launch', ctypes.c_int32), ('check_every', ctypes.c_int32),
+                ('rows_per_tile', ctypes.c_int32), ('timing', ctypes.c_int32),
+                ('reserved', ctypes.c_int32 * 2)]
+
+
+class XinvStats(ctypes.Structure):
+    _fields_ = [('path', ctypes.c_int32), ('colours', ctypes.c_int32),
+                ('sweeps_per_launch', ctypes.c_int32), ('rows_per_tile', ctypes.c_int32),
+                ('sweep_launches', ctypes.c_int64), ('sweeps_max', ctypes.c_int64),
+                ('sweep_ms', ctypes.c_double), ('h2d_ms', ctypes.c_double),
+                ('d2h_ms', ctypes.c_double)]
+
+
+class XinvError(RuntimeError):
+    pass
+
+
+# every symbol include/xinv.h declares (tests check the library exports all of them)
+EXPORTS = [
+    'xinv_default_options', 'xinv_last_stats', 'xinv_last_error', 'xinv_device_count',
+    'xinv_version',
+    'xinv_standard_2d_f64', 'xinv_general_2d_f64', 'xinv_standard_3d_f64',
+    'xinv_standard_2d_f64_batched', 'xinv_general_2d_f64_batched',
+    'xinv_standard_3d_f64_batched',
+    'xinv_standard_2d_f64_dev', 'xinv_general_2d_f64_dev', 'xinv_standard_3d_f64_dev',
+    'xinv_abs_norm_f64_dev',
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (raises XinvError with a build hint when it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise XinvError('HIP extension %s is missing: run `python -m xinvert_amd.build` '
+                        '(there is no CPU fallback)' % SO)
+    try:
+        L = ctypes.CDLL(SO)
+    except OSError as e:
+        raise XinvError('cannot load %s: %s' % (SO, e))
+    _opt = ctypes.POINTER(XinvOptions)
+    std2d_scal = [_i64, _i64, _f64, _f64, _int, _int, _f64, _f64, _f64, _f64, _f64, _dp, _i64, _f64]
+    gen2d_scal = [_i64, _i64, _f64, _f64, _int, _int, _f64, _f64, _f64, _f64, _f64, _f64, _dp, _i64, _f64]
+    std3d_scal = [_i64, _i64, _i64, _f64, _f64, _f64, _int, _int, _int, _f64, _f64, _f64, _f64,
+                  _f64, _dp, _i64, _f64]
+    L.xinv_standard_2d_f64.argtypes = [_dp] * 5 + std2d_scal
+    L.xinv_general_2d_f64.argtypes = [_dp] * 8 + gen2d_scal
+    L.xinv_standard_3d_f64.argtypes = [_dp] * 5 + std3d_scal
+    L.xinv_standard_2d_f64_batched.argtypes = [_dp] * 5 + [_i64, _ip] + std2d_scal + [_opt]
+    L.xinv_general_2d_f64_batched.argtypes = [_dp] * 8 + [_i64, _ip] + gen2d_scal + [_opt]
+    L.xinv_standard_3d_f64_batched.argtypes = [_dp] * 5 + [_i64, _ip] + std3d_scal + [_opt]
+    # *_dev: array arguments are device addresses (integers), flags is a host pointer
+    std2d_dev = [_i64, _i64, _f64, _f64, _int, _int, _f64, _f64, _f64, _f64, _f64, _dp, _i64, _f64]
+    L.xinv_standard_2d_f64_dev.argtypes = [_vp] * 5 + [_i64, _ip] + std2d_dev + [_opt, _vp]
+    L.xinv_general_2d_f64_dev.argtypes = [_vp] * 8 + [_i64, _ip] + gen2d_scal + [_opt, _vp]
+    L.xinv_standard_3d_f64_dev.argtypes = [_vp] * 5 + [_i64, _ip] + std3d_scal + [_opt, _vp]
+    L.xinv_abs_norm_f64_dev.argtypes = [_vp, _i64, _f64, _dp, _vp]
+    for name in EXPORTS:
+        getattr(L, name).restype = _int
+    L.xinv_last_error.restype = ctypes.c_char_p
+    L.xinv_default_options.restype = None
+    L.xinv_default_options.argtypes = [_opt]
+    L.xinv_last_stats.argtypes = [ctypes.POINTER(XinvStats)]
+    _lib = L
+    return L
+
+
+def require_gpu():
+    L = load()
+    if L.xinv_device_count() < 1:
+        raise XinvError('libxinv_hip.so loaded but no MI355X/HIP device is visible '
+                        '(there is no CPU fallback)')
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise XinvError('xinv call failed (rc=%d): %s' % (rc, load().xinv_last_error().decode()))
+
+
+def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
+            timing=0):
+    o = XinvOptions()
+    load().xinv_default_options(ctypes.byref(o))
+    o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
+    o.check_every, o.rows_per_tile, o.timing = check_every, rows_per_tile, timing
+    return o
+
+
+def last_stats():
+    s = XinvStats()
+    load().xinv_last_stats(ctypes.byref(s))
+    return {f: getattr(s, f) for f, _ in XinvStats._fields_}
+
+
+def bc(b):
+    if isinstance(b, str):
+        if b not in BC_CODES:
+            raise XinvError('unknown boundary condition %r' % (b,))
+        return BC_CODES[b]
+    return int(b)
+
+
+def hptr(a):
+    """Host pointer of a C-contiguous float64 ndarray (None -> NULL)."""
+    if a is None:
+        return None
+    if a.dtype != np.float64 or not a.flags.c_contiguous:
+        raise XinvError('need C-contiguous float64 arrays at the C-ABI')
+    return a.ctypes.data_as(_dp)
+
+
+def strides_arg(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])

@@ -1,0 +1,457 @@
+"""Application front end: invert_Poisson / invert_Stommel / invert_GillMatsuno / invert_omega.
+
+Host-side mirror of the reference's callers of the SOR hot path (reference
+xinvert/apps.py:67-100, 443-488, 351-394, 766-827) with the same names, argument meaning,
+defaults and error behaviour, restated on numpy (`Field`) because xarray is not available in
+the build/test image.  xarray.DataArray inputs are accepted and returned when xarray exists.
+
+The call shape is the reference's:  invert_*() -> _template() -> _coeffs_*() ->
+_cal_params{2,3}D() -> core.inv_*() -> HIP kernels (xinvert_amd/csrc) through the C-ABI.
+No arithmetic here runs on the GPU and none of it falls back to a CPU solver: core.inv_*
+raises if the HIP library is missing.
+
+Differences from the reference that a user can observe (all documented in DESIGN.md):
+  * the solver is fp64; float32 inputs/coordinates are promoted to float64 on entry
+    (the reference's mixed f32/f64 rounding is not reproduced);
+  * sweeps are red-black / 4-colour ordered, so iterates (and loop counts) differ from the
+    reference's lexicographic sweep while converged fields agree to <= 1e-6 rel-L2;
+  * `flags` are reported per slice (iParams['flags'] has shape [nslice, 3]).
+"""
+import copy
+
+import numpy as np
+
+from . import core
+from .field import Field, along, from_any, to_like
+
+# default undefined value (reference apps.py:18, core.py:15)
+_undeftmp = -9.99e8
+
+# reference apps.py:21-38
+default_iParams = copy.deepcopy({
+    'BCs'      : ['fixed', 'fixed'],
+    'undef'    : np.nan,
+    'mxLoop'   : 5000,
+    'tolerance': 1e-8,
+    'optArg'   : None,
+    'printInfo': True,
+    'debug'    : False,
+})
+
+# reference apps.py:42-60
+default_mParams = copy.deepcopy({
+    'f0'     : 1e-5,
+    'beta'   : 2e-11,
+    'Phi'    : 1e4,
+    'epsilon': 7e-6,
+    'N2'     : 2e-4,
+    'A'      : 1e5,
+    'R'      : 5e-5,
+    'depth'  : 100,
+    'rho0'   : 1027,
+    'ang0'   : 2e5,
+    'lambda' : 1e-8,
+    'c0'     : 8e-9,
+    'c1'     : 8e-5,
+    'Rearth' : 6371200.0,
+    'Omega'  : 7.292e-5,
+    'g'      : 9.80665,
+})
+
+
+# --------------------------------------------------------------------- entry points
+def invert_Poisson(F, dims, coords='lat-lon', icbc=None,
+                   mParams=default_mParams, iParams=default_iParams):
+    """psi from F:  d2psi/dy2 + d2psi/dx2 = F   (reference apps.py:67-100)."""
+    return _template(_coeffs_Poisson, core.inv_standard2D, 2, F, dims, coords,
+                     icbc, ['g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_Stommel(curl, dims, coords='lat-lon', icbc=None,
+                   mParams=default_mParams, iParams=default_iParams):
+    """Stommel wind-driven gyre, general 2-D form (reference apps.py:443-488)."""
+    return _template(_coeffs_Stommel, core.inv_general2D, 2, curl, dims, coords,
+                     icbc, ['beta', 'R', 'D', 'rho0', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_GillMatsuno(Q, dims, coords='lat-lon', icbc=None,
+                       mParams=default_mParams, iParams=default_iParams):
+    """Gill-Matsuno mass field phi from heating Q (reference apps.py:351-394)."""
+    return _template(_coeffs_GillMatsuno, core.inv_general2D, 2, Q, dims, coords,
+                     icbc, ['f0', 'beta', 'epsilon', 'Phi', 'g', 'Omega', 'Rearth'],
+                     mParams, iParams)
+
+
+def invert_omega(F, dims, coords='lat-lon', icbc=None,
+                 mParams=default_mParams, iParams=default_iParams):
+    """QG omega equation, standard 3-D form (reference apps.py:766-827)."""
+    N2 = mParams['N2'] if 'N2' in mParams else None
+    if N2 is not None and not np.isscalar(N2):
+        n2 = np.asarray(N2.values if hasattr(N2, 'values') else N2)
+        if n2.ndim >= 1 and n2.shape[0] > 1:
+            tail = n2[1:]
+            if not np.isfinite(tail).all():
+                raise Exception('inifinite stratification coefficient A')
+            if np.isnan(tail).any():
+                raise Exception('nan in coefficient A')
+            if (tail <= 0).any():
+                raise Exception('unstable stratification in coefficient A')
+    return _template(_coeffs_omega, core.inv_standard3D, 3, F, dims, coords,
+                     icbc, ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def cal_flow(S, dims, coords='lat-lon', BCs=('fixed', 'fixed'), vtype='GillMatsuno',
+             mParams=default_mParams):
+    """(u, v) from the Gill-Matsuno mass field (reference apps.py:1277-1317).
+
+    Only vtype='GillMatsuno' is restated (it completes config 4's "3-field" output);
+    the streamfunction / velocity-potential branches need the reference's FiniteDiff class,
+    which is outside the hot path.
+    """
+    if vtype.lower() != 'gillmatsuno':
+        raise Exception('unsupported vtype: ' + vtype + ' (only GillMatsuno is provided)')
+    tmpl = S
+    S = from_any(S)
+    mParams = _update(default_mParams, mParams,
+                      ['f0', 'beta', 'epsilon', 'Phi', 'Omega', 'Rearth'])
+    eps, f0, beta = mParams['epsilon'], mParams['f0'], mParams['beta']
+    Omega, Rearth = mParams['Omega'], mParams['Rearth']
+    vals = np.asarray(S.values, dtype=np.float64)
+    ay, ax = S.axis(dims[0]), S.axis(dims[1])
+    yv = np.asarray(S[dims[0]], dtype=np.float64)
+    xv = np.asarray(S[dims[1]], dtype=np.float64)
+    Sy = np.gradient(vals, yv, axis=ay)       # == xarray .differentiate (edge_order=1)
+    Sx = np.gradient(vals, xv, axis=ax)
+    if coords.lower() == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosLat = along(np.cos(lats), S, dims[0])
+        f = 2.0 * Omega * np.sin(lats)
+        deg2m = np.deg2rad(1.0) * Rearth
+        coef1 = along(eps / (eps**2.0 + f**2.0), S, dims[0])
+        coef2 = along(f / (eps**2.0 + f**2.0), S, dims[0])
+        c1 = - coef1 * Sx / deg2m / cosLat - coef2 * Sy / deg2m
+        c2 = - coef1 * Sy / deg2m + coef2 * Sx / deg2m / cosLat
+    elif coords.lower() == 'cartesian':
+        f = f0 + beta * yv
+        coef1 = along(eps / (eps**2.0 + f**2.0), S, dims[0])
+        coef2 = along(f / (eps**2.0 + f**2.0), S, dims[0])
+        c1 = - coef1 * Sx - coef2 * Sy
+        c2 = - coef1 * Sy + coef2 * Sx
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be [lat-lon, cartesian]')
+    return to_like(S.like(c1, 'u'), tmpl), to_like(S.like(c2, 'v'), tmpl)
+
+
+# ------------------------------------------------------------------------- helpers
+def _template(coef_func, inv_func, dimLen, F, dims, coords='lat-lon', icbc=None,
+              validParams=(), mParams=default_mParams, iParams=default_iParams):
+    """Whole inverting process (reference apps.py:1324-1394)."""
+    if len(dims) != dimLen:
+        raise Exception('{0:2d} dimensional forcing are needed'.format(dimLen))
+
+    tmpl = F
+    F = from_any(F)
+    if icbc is not None:
+        icbc = from_any(icbc)
+
+    iParams = _update(default_iParams, iParams)
+    mParams = _update(default_mParams, mParams, list(validParams))
+
+    # 1. coefficients
+    maskF, initS, coeffs = coef_func(F, dims, coords, mParams, iParams, icbc)
+
+    # 2. parameters
+    if dimLen == 2:
+        ps = _cal_params2D(maskF[dims[0]], maskF[dims[1]], coords, Rearth=mParams['Rearth'])
+    elif dimLen == 3:
+        ps = _cal_params3D(maskF[dims[0]], maskF[dims[1]], maskF[dims[2]], coords,
+                           Rearth=mParams['Rearth'])
+    else:
+        raise Exception('dimension length should be one of [2, 3]')
+
+    iParams = _update(ps, iParams)
+
+    if iParams['debug']:
+        print({k: v for k, v in iParams.items() if k != 'flags'})
+
+    # 3. invert (HIP kernels; in place on initS)
+    S = inv_func(*coeffs, maskF, initS, dims, iParams)
+
+    # 4. de-mask
+    if icbc is None:
+        out = np.where(maskF.values != _undeftmp, S.values, iParams['undef'])
+        S = S.like(out, 'inverted')
+    else:
+        S = S.like(S.values, 'inverted')
+    S.iParams = iParams            # per-slice flags etc. for callers that want them
+    return to_like(S, tmpl) if not isinstance(tmpl, Field) else S
+
+
+def _mask_FS(F, dims, iParams, icbc):
+    """Mask forcing with _undeftmp, build the initial guess (reference apps.py:2112-2159)."""
+    vals = np.asarray(F.values, dtype=np.float64)
+    undef = iParams['undef']
+    if np.isnan(undef):
+        mvals = np.where(np.isnan(vals), _undeftmp, vals)
+    else:
+        mvals = np.where(vals != undef, vals, _undeftmp)
+    maskF = F.like(mvals)
+    zero = mvals - mvals
+
+    if icbc is None:
+        initS = F.like(zero.copy())
+    else:
+        mask = mvals == _undeftmp
+        for dim, BC in zip(dims, iParams['BCs']):
+            if BC != 'periodic':
+                dv = np.asarray(F[dim])
+                cond = along(np.isin(dv, [dv[0], dv[-1]]), F, dim)
+                mask = np.logical_or(mask, cond)
+        ic = np.broadcast_to(np.asarray(icbc.values, dtype=np.float64), vals.shape)
+        initS = F.like(np.where(mask, ic, 0.0))
+    return maskF, initS, zero
+
+
+def _remask(values, maskF):
+    return np.where(maskF.values != _undeftmp, values, _undeftmp)
+
+
+def _coeffs_Poisson(force, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1397-1437.  Returns core-shaped (batch-shared) coefficients."""
+    maskF, initS, zero = _mask_FS(force, dims, iParams, icbc)
+    z2 = _core_zero(maskF, dims)
+    c = coords.lower()
+    if c == 'lat-lon':
+        latd = np.asarray(maskF[dims[0]], dtype=np.float64)
+        lats = np.deg2rad(latd)
+        cosG = np.cos(lats)
+        shifted = np.concatenate(([np.nan], lats[:-1]))
+        cosH = np.cos((lats + shifted) / 2.0)
+        A = z2 + cosH[:, None]
+        B = z2
+        C = z2 + (1.0 / cosG)[:, None]
+        Fv = _remask(maskF.values * along(cosG, maskF, dims[0]), maskF)
+    elif c == 'z-lat':
+        cosG = np.cos(np.deg2rad(np.asarray(maskF[dims[1]], dtype=np.float64)))
+        A = z2 + 1.0
+        B = z2
+        C = z2 + 1.0
+        Fv = _remask(maskF.values * along(cosG, maskF, dims[1]), maskF)
+    elif c in ('z-lon', 'cartesian'):
+        A = z2 + 1.0
+        B = z2
+        C = z2 + 1.0
+        Fv = maskF.values
+    else:
+        raise Exception('unsupported coords ' + coords +
+                        ', should be in [lat-lon, z-lat, z-lon, cartesian]')
+    return maskF.like(Fv), initS, (A, B, C)
+
+
+def _coeffs_Stommel(curl, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1712-1748."""
+    beta, R, depth = mParams['beta'], mParams['R'], mParams['D']
+    rho0, Rearth, Omega = mParams['rho0'], mParams['Rearth'], mParams['Omega']
+    maskF, initS, zero = _mask_FS(curl, dims, iParams, icbc)
+    z2 = _core_zero(maskF, dims)
+    R2 = _core_param(R, maskF, dims)          # scalar, or a field varying over the core dims
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(np.asarray(curl[dims[0]], dtype=np.float64))
+        cosL = np.cos(lats)
+        A = z2 - R2 / depth
+        B = z2
+        C = z2 - R2 / depth / (cosL**2.)[:, None]
+        D = z2
+        E = z2 - 2. * Omega / Rearth
+        Fc = z2
+    elif c == 'cartesian':
+        A = z2 - R2 / depth
+        B = z2
+        C = z2 - R2 / depth
+        D = z2
+        E = z2 - beta
+        Fc = z2
+    else:
+        raise Exception('unsupported coords ' + coords +
+                        ', should be in [lat-lon, z-lat, z-lon, cartesian]')
+    G = _remask(-maskF.values / depth / rho0, maskF)
+    return maskF.like(G), initS, (A, B, C, D, E, Fc)
+
+
+def _coeffs_GillMatsuno(Q, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1609-1657."""
+    Phi, epsilon = mParams['Phi'], mParams['epsilon']
+    f0, beta = mParams['f0'], mParams['beta']
+    Omega, Rearth = mParams['Omega'], mParams['Rearth']
+    maskF, initS, zero = _mask_FS(Q, dims, iParams, icbc)
+    z2 = _core_zero(maskF, dims)
+    yv = np.asarray(Q[dims[0]], dtype=np.float64)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosL = np.cos(lats)
+        f = 2.0 * Omega * np.sin(lats)
+        c1 = epsilon / (epsilon**2. + f**2.)
+        c2 = f / (epsilon**2. + f**2.)
+        deg2m = Rearth / 180. * np.pi
+        A = z2 + (c1 * Phi)[:, None]
+        B = z2
+        C = z2 + (c1 * Phi / cosL**2.)[:, None]
+        D = z2 + (Phi * (np.gradient(c1, yv) / deg2m + c1 * np.tan(lats) / Rearth))[:, None]
+        E = z2 - (Phi * np.gradient(c2, yv) / deg2m / cosL)[:, None]
+        Fc = z2 - epsilon
+    elif c == 'cartesian':
+        f = f0 + beta * yv
+        c1 = epsilon / (epsilon**2. + f**2.)
+        c2 = f / (epsilon**2. + f**2.)
+        A = z2 + (c1 * Phi)[:, None]
+        B = z2
+        C = z2 + (c1 * Phi)[:, None]
+        D = z2 + (Phi * np.gradient(c1, yv))[:, None]
+        E = z2 - (Phi * np.gradient(c2, yv))[:, None]
+        Fc = z2 - epsilon
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    return maskF.like(maskF.values), initS, (A, B, C, D, E, Fc)
+
+
+def _coeffs_omega(force, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:2016-2052.  N2 may be a scalar or a profile over dims[0] (lev)."""
+    f0, beta, N2, Omega = mParams['f0'], mParams['beta'], mParams['N2'], mParams['Omega']
+    maskF, initS, zero = _mask_FS(force, dims, iParams, icbc)
+    zc, yc, xc = (maskF.shape[maskF.axis(d)] for d in dims)
+    z3 = np.zeros((zc, yc, xc))
+    if np.isscalar(N2):
+        n2 = N2
+    else:
+        n2 = np.asarray(N2.values if hasattr(N2, 'values') else N2, dtype=np.float64)
+        if n2.ndim == 1:
+            n2 = n2[:, None, None]
+    yv = np.asarray(force[dims[1]], dtype=np.float64)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        shifted = np.concatenate(([np.nan], lats[:-1]))
+        cosH = np.cos((lats + shifted) / 2.)
+        cosG = np.cos(lats)
+        f = 2. * Omega * np.sin(lats)
+        A = z3 + (f**2 * cosG)[None, :, None]
+        B = z3 + n2 * cosH[None, :, None]
+        C = z3 + n2 / cosG[None, :, None]
+        Fv = _remask(maskF.values * along(cosG, maskF, dims[1]), maskF)
+    elif c == 'cartesian':
+        f = f0 + beta * yv
+        A = z3 + (f**2.)[None, :, None]
+        B = z3 + n2
+        C = z3 + n2
+        Fv = maskF.values
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    return maskF.like(Fv), initS, (A, B, C)
+
+
+def _core_zero(maskF, dims):
+    """`zero` restricted to the core dims: coefficients that do not depend on the batch axis
+    are built once and shared by every slice (batch stride 0 at the C-ABI), instead of the
+    reference's broadcast to F's full shape (apps.py:2141)."""
+    return np.zeros(tuple(maskF.shape[maskF.axis(d)] for d in dims))
+
+
+def _core_param(p, maskF, dims):
+    if np.isscalar(p):
+        return p
+    p = np.asarray(p.values if hasattr(p, 'values') else p, dtype=np.float64)
+    want = tuple(maskF.shape[maskF.axis(d)] for d in dims)
+    if p.shape != want:
+        raise Exception('field-valued parameter must have the core shape %r' % (want,))
+    return p
+
+
+def _cal_params2D(dim2_var, dim1_var, coords, Rearth=default_mParams['Rearth']):
+    """reference apps.py:2245-2313."""
+    dim2_var = np.asarray(dim2_var, dtype=np.float64)
+    dim1_var = np.asarray(dim1_var, dtype=np.float64)
+    gc2, gc1 = len(dim2_var), len(dim1_var)
+    del2 = np.diff(dim2_var)[0]
+    del1 = np.diff(dim1_var)[0]
+    _uniform_interval(dim2_var, del2, 'dim2')
+    _uniform_interval(dim1_var, del1, 'dim1')
+    c = coords.lower()
+    if c == 'lat-lon':
+        del2 = np.deg2rad(del2) * Rearth
+        del1 = np.deg2rad(del1) * Rearth
+    elif c in ('z-lat', 'z-lon'):
+        del1 = np.deg2rad(del1) * Rearth
+    elif c == 'cartesian':
+        pass
+    else:
+        raise Exception('unsupported coords for 2D case: ' + coords +
+                        ', should be [lat-lon, cartesian]')
+    ratio = del1 / del2
+    epsilon = np.sin(np.pi/(2.0*gc1+2.0))**2 + np.sin(np.pi/(2.0*gc2+2.0))**2
+    re = {
+        'gc2': gc2, 'gc1': gc1, 'del2': del2, 'del1': del1,
+        'ratio': ratio, 'ratioSSr': ratio ** 4.0, 'ratioSqr': ratio ** 2.0,
+        'ratioQtr': ratio / 4.0, 'del1Sqr': del1 ** 2.0, 'del1Tr': del1 ** 3.0,
+        'del1SSr': del1 ** 4.0,
+        'optArg': 2.0 / (1.0 + np.sqrt((2.0 - epsilon) * epsilon)),
+        'flags': np.array([0.0, 1.0, 0.0]),
+    }
+    return re
+
+
+def _cal_params3D(dim3_var, dim2_var, dim1_var, coords, Rearth=default_mParams['Rearth']):
+    """reference apps.py:2162-2242 (note the 2*gc3+3 in the z term, :2208)."""
+    dim3_var = np.asarray(dim3_var, dtype=np.float64)
+    dim2_var = np.asarray(dim2_var, dtype=np.float64)
+    dim1_var = np.asarray(dim1_var, dtype=np.float64)
+    gc3, gc2, gc1 = len(dim3_var), len(dim2_var), len(dim1_var)
+    del3 = np.diff(dim3_var)[0]
+    del2 = np.diff(dim2_var)[0]
+    del1 = np.diff(dim1_var)[0]
+    _uniform_interval(dim3_var, del3, 'dim3')
+    _uniform_interval(dim2_var, del2, 'dim2')
+    _uniform_interval(dim1_var, del1, 'dim1')
+    c = coords.lower()
+    if c == 'lat-lon':
+        del2 = np.deg2rad(del2) * Rearth
+        del1 = np.deg2rad(del1) * Rearth
+    elif c == 'cartesian':
+        pass
+    else:
+        raise Exception('unsupported coords for 3D case: ' + coords +
+                        ', should be in [\'lat-lon\', \'cartesian\']')
+    ratio1 = del1 / del2
+    ratio2 = del1 / del3
+    epsilon = (np.sin(np.pi/(2.0*gc1+2.0)) ** 2.0 +
+               np.sin(np.pi/(2.0*gc2+2.0)) ** 2.0 +
+               np.sin(np.pi/(2.0*gc3+3.0)) ** 2.0)
+    re = {
+        'gc3': gc3, 'gc2': gc2, 'gc1': gc1, 'del3': del3, 'del2': del2, 'del1': del1,
+        'ratio1': ratio1, 'ratio2': ratio2,
+        'ratio1Sqr': ratio1 ** 2.0, 'ratio2Sqr': ratio2 ** 2.0, 'del1Sqr': del1 ** 2.0,
+        'optArg': 2.0 / (1.0 + np.sqrt((2.0 - epsilon) * epsilon)),
+        'flags': np.array([0.0, 1.0, 0.0]),
+    }
+    return re
+
+
+def _update(default, users, valid=None):
+    """Merge user parameters over defaults (reference apps.py:2361-2375): None values are
+    ignored; unknown mParams keys raise."""
+    if valid is not None and users != default:
+        for k in users:
+            if k not in valid:
+                raise Exception(f'mParams[\'{k}\'] is not used, valid are {valid}')
+    out = copy.deepcopy(default)
+    for k, v in users.items():
+        if v is not None:
+            out[k] = v
+    return out
+
+
+def _uniform_interval(coord1D, value, name='coordinate'):
+    """reference apps.py:2377-2379."""
+    if not np.isclose(np.diff(coord1D), value).all():
+        raise Exception(f'coordinate {name} is non-uniform:\n{coord1D}')

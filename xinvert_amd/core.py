@@ -1,0 +1,160 @@
+"""Core inversion wrappers: inv_standard2D / inv_general2D / inv_standard3D.
+
+Host-side mirror of the reference's xinvert/core.py:20-155, 374-444 -- same names, argument
+order and error behaviour -- with one structural change: the reference's Python loop over the
+non-core (time / level / member) axis (`for selDict in loop_noncore(F, dims)`, core.py:59,
+129, 418) becomes ONE batched call into the HIP library, which keeps coefficient arrays that
+do not vary along the batch axis resident once in HBM (batch stride 0) and solves every slice
+concurrently.  There is no CPU fallback: a missing library or GPU raises.
+
+Arrays may be `Field`s or ndarrays.  Coefficients are either core-shaped ([yc, xc] or
+[zc, yc, xc]: shared by all slices) or shaped like F (one per slice).
+"""
+import itertools
+
+import numpy as np
+
+from . import _lib
+from .field import Field
+
+# default undefined value (reference core.py:15)
+_undeftmp = -9.99e8
+
+
+def inv_standard2D(A, B, C, F, S, dims, iParams):
+    """d/dy(A dS/dy + B dS/dx) + d/dx(B dS/dy + C dS/dx) = F   (reference core.py:88-155)."""
+    if len(dims) != 2:
+        raise Exception('2 dimensions are needed for inversion')
+    return _solve('std2d', (A, B, C), F, S, dims, iParams)
+
+
+def inv_general2D(A, B, C, D, E, F, G, S, dims, iParams):
+    """A Syy + B Syx + C Sxx + D Sy + E Sx + F S = G   (reference core.py:374-444)."""
+    if len(dims) != 2:
+        raise Exception('2 dimensions are needed for inversion')
+    return _solve('gen2d', (A, B, C, D, E, F), G, S, dims, iParams)
+
+
+def inv_standard3D(A, B, C, F, S, dims, iParams):
+    """d/dz(A dS/dz) + d/dy(B dS/dy) + d/dx(C dS/dx) = F   (reference core.py:20-85)."""
+    if len(dims) != 3:
+        raise Exception('3 dimensions are needed for inversion')
+    return _solve('std3d', (A, B, C), F, S, dims, iParams)
+
+
+# ------------------------------------------------------------------------------ internals
+def _vals(a):
+    return a.values if isinstance(a, Field) or hasattr(a, 'values') else np.asarray(a)
+
+
+def _batch_layout(F, dims):
+    """Permutation putting the non-core axes first (in F's order) and the core axes last
+    (in the order given by `dims`), plus the batch selectors for the info lines."""
+    core_ax = [F.axis(d) for d in dims]
+    batch_ax = [ax for ax in range(len(F.dims)) if ax not in core_ax]
+    perm = batch_ax + core_ax
+    bdims = [F.dims[ax] for ax in batch_ax]
+    bshape = [F.shape[ax] for ax in batch_ax]
+    return perm, bdims, bshape
+
+
+def _prep_coef(c, F, perm, core_shape, nbatch):
+    """-> (contiguous float64 array, batch stride in elements)."""
+    v = np.asarray(_vals(c), dtype=np.float64)
+    n = int(np.prod(core_shape))
+    if v.shape == tuple(core_shape):
+        return np.ascontiguousarray(v), 0
+    if v.shape == F.shape:
+        # a broadcast view over the batch axes (zero strides) is one shared slice
+        t = np.transpose(v, perm)
+        nb_axes = len(perm) - len(core_shape)
+        if all(t.strides[ax] == 0 or t.shape[ax] == 1 for ax in range(nb_axes)):
+            idx = (0,) * nb_axes
+            return np.ascontiguousarray(t[idx]), 0
+        return np.ascontiguousarray(t).reshape((nbatch,) + tuple(core_shape)), n
+    try:
+        t = np.broadcast_to(v, F.shape)
+    except ValueError:
+        raise Exception('coefficient shape %r matches neither the core shape %r nor F %r'
+                        % (v.shape, tuple(core_shape), F.shape))
+    return _prep_coef(t, F, perm, core_shape, nbatch)
+
+
+def _info(sel):
+    """Selector text of the reference's per-slice line (core.py:141-145)."""
+    return (str(sel).replace('numpy.datetime64(', '').replace('numpy.timedelta64(', '')
+            .replace('np.float64(', '').replace('np.int64(', '').replace('np.float32(', '')
+            .replace(')', '').replace('\'', '').replace('.000000000', ''))
+
+
+def _solve(kind, coefs, F, S, dims, iParams):
+    L = _lib.require_gpu()
+    if not isinstance(F, Field) or not isinstance(S, Field):
+        raise Exception('forcing and solution must be Field objects (see xinvert_amd.field)')
+    perm, bdims, bshape = _batch_layout(F, dims)
+    core_shape = tuple(F.shape[F.axis(d)] for d in dims)
+    nbatch = int(np.prod(bshape)) if bshape else 1
+    n = int(np.prod(core_shape))
+
+    Sv = np.ascontiguousarray(np.transpose(np.asarray(S.values, dtype=np.float64), perm)
+                              ).reshape((nbatch,) + core_shape)
+    Fv = np.ascontiguousarray(np.transpose(np.asarray(F.values, dtype=np.float64), perm)
+                              ).reshape((nbatch,) + core_shape)
+    arrs, strides = [Sv], [n]
+    for c in coefs:
+        a, st = _prep_coef(c, F, perm, core_shape, nbatch)
+        arrs.append(a)
+        strides.append(st)
+    arrs.append(Fv)
+    strides.append(n)
+
+    flags = np.tile(np.array([0.0, 1.0, 0.0]), (nbatch, 1))
+    BCs = [_lib.bc(b) for b in iParams['BCs']]
+    opt = _lib.options(device=int(iParams.get('device', -1)),
+                       path=int(iParams.get('engine_path', 0)),
+                       sweeps_per_launch=int(iParams.get('sweeps_per_launch', 0)),
+                       check_every=int(iParams.get('check_every', 0)))
+    st = _lib.strides_arg(strides)
+    ptrs = [_lib.hptr(a) for a in arrs]
+    mx, tol = int(iParams['mxLoop']), float(iParams['tolerance'])
+    if kind == 'std2d':
+        rc = L.xinv_standard_2d_f64_batched(
+            *ptrs, nbatch, st, iParams['gc2'], iParams['gc1'],
+            float(iParams['del2']), float(iParams['del1']), BCs[0], BCs[1],
+            float(iParams['del1Sqr']), float(iParams['ratioQtr']), float(iParams['ratioSqr']),
+            float(iParams['optArg']), _undeftmp, _lib.hptr(flags), mx, tol, opt)
+    elif kind == 'gen2d':
+        rc = L.xinv_general_2d_f64_batched(
+            *ptrs, nbatch, st, iParams['gc2'], iParams['gc1'],
+            float(iParams['del2']), float(iParams['del1']), BCs[0], BCs[1],
+            float(iParams['del1Sqr']), float(iParams['ratio']), float(iParams['ratioQtr']),
+            float(iParams['ratioSqr']), float(iParams['optArg']), _undeftmp,
+            _lib.hptr(flags), mx, tol, opt)
+    else:
+        rc = L.xinv_standard_3d_f64_batched(
+            *ptrs, nbatch, st, iParams['gc3'], iParams['gc2'], iParams['gc1'],
+            float(iParams['del3']), float(iParams['del2']), float(iParams['del1']),
+            BCs[0], BCs[1], BCs[2], float(iParams['del1Sqr']),
+            float(iParams['ratio2Sqr']), float(iParams['ratio1Sqr']),
+            float(iParams['optArg']), _undeftmp, _lib.hptr(flags), mx, tol, opt)
+    _lib.check(rc)
+
+    # in place on S, as the reference (S.loc[sel].values are views of initS, apps.py:2159)
+    inv = np.argsort(perm)
+    out = np.transpose(Sv.reshape(tuple(bshape) + core_shape), inv)
+    if S.values.dtype == np.float64 and S.values.flags.writeable:
+        S.values[...] = out
+    else:
+        S.values = np.ascontiguousarray(out)
+
+    iParams['flags'] = flags if nbatch > 1 else flags[0]
+    iParams['stats'] = _lib.last_stats()
+    if iParams.get('printInfo', True):
+        coords = [np.asarray(F[d]) for d in bdims]
+        sels = itertools.product(*coords) if bdims else [()]
+        for m, idx in enumerate(sels):
+            info = _info(dict(zip(bdims, idx)))
+            tail = ' (overflows!)' if flags[m, 0] else ''
+            print(info + ' loops {0:4.0f} and tolerance is {1:e}'.format(flags[m, 2], flags[m, 1])
+                  + tail)
+    return S

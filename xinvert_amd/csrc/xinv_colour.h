@@ -1,0 +1,304 @@
+// xinv_colour.h -- colour-pass kernels: one launch per colour, in place on S.
+//
+// General path of the engine: every model, every BC combination, the 9-point forms and the
+// odd-xc periodic seam.  Each thread owns one point of the launch's colour; points of one
+// colour never read each other, so the in-place update is race free and its result is
+// independent of scheduling (bitwise equal to the CPU restatement of the same ordering).
+// Companion kernels: the 'extend' boundary pre-pass, the mean|S| norm (two deterministic
+// stages) with the device-side stopping rule.
+#pragma once
+#include "xinv_device.h"
+
+struct ColourArgs2D {
+    double *S;
+    const double *c[7];        // std: A,B,C,F ; gen: A,B,C,D,E,F,G
+    int64_t sS, sc[7];         // batch strides (elements)
+    int64_t yc, xc;
+    int per;                   // periodic x
+    int base;                  // 2 or 4
+    int seam;                  // odd xc with periodic x
+    int colour;                // colour of this launch
+    int force;                 // ignore ctl.done (never set in production)
+    XinvScal sc_;
+    const XinvCtl *ctl;
+};
+
+// Row / column of the thread's point for `colour`; returns false when the thread has none.
+__device__ __forceinline__ bool xinv_colour_point(const ColourArgs2D &a, int64_t tj, int64_t ti,
+                                                  int64_t &j, int64_t &i)
+{
+    const int cc = a.colour;
+    if (cc >= a.base) {                          // seam colours: column xc-1, row parity cc-base
+        if (ti != 0) return false;
+        int par = cc - a.base;
+        j = ((par == 1) ? 1 : 2) + 2 * tj;
+        i = a.xc - 1;
+        return j <= a.yc - 2;
+    }
+    if (a.base == 2) {
+        j = 1 + tj;
+        if (j > a.yc - 2) return false;
+        i = 2 * ti + ((j + cc) & 1);
+    } else {
+        int pj = cc >> 1, pi = cc & 1;
+        j = ((pj == 1) ? 1 : 2) + 2 * tj;
+        if (j > a.yc - 2) return false;
+        i = 2 * ti + pi;
+    }
+    const int64_t ilo = a.per ? 0 : 1;
+    const int64_t ihi = a.per ? a.xc - 1 : a.xc - 2;
+    if (i < ilo || i > ihi) return false;
+    if (a.seam && i == a.xc - 1) return false;   // belongs to the seam colours
+    return true;
+}
+
+template <bool NINE>
+__global__ __launch_bounds__(256) void k_colour_std2d(ColourArgs2D a)
+{
+    const int64_t m = blockIdx.z;
+    if (!a.force && a.ctl[m].done) return;
+    const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    int64_t j, i;
+    if (!xinv_colour_point(a, tj, ti, j, i)) return;
+    const int64_t xc = a.xc;
+    double *S = a.S + m * a.sS;
+    const double *A = a.c[0] + m * a.sc[0];
+    const double *B = a.c[1] + m * a.sc[1];
+    const double *C = a.c[2] + m * a.sc[2];
+    const double *F = a.c[3] + m * a.sc[3];
+    const int64_t im = (i == 0) ? xc - 1 : i - 1;
+    const int64_t ip = (i == xc - 1) ? 0 : i + 1;
+    const int64_t r = j * xc, rp = r + xc, rm = r - xc;
+    const double sC = S[r + i];
+    double v;
+    if (NINE) {
+        const bool west = (i == 0);
+        const int64_t bn = west ? ip : i, sq = west ? i : ip;
+        v = xinv_upd_std2d_9(sC, S[rp + i], S[rm + i], S[r + im], S[r + ip],
+                             S[rp + ip], S[rp + im], S[rm + ip], S[rm + im], S[rm + sq],
+                             A[rp + i], A[r + i], B[r + ip], B[r + im], B[rp + i], B[rp + bn],
+                             B[rm + i], C[r + ip], C[r + i], F[r + i], a.sc_);
+    } else {
+        v = xinv_upd_std2d_5(sC, S[rp + i], S[rm + i], S[r + im], S[r + ip],
+                             A[rp + i], A[r + i], C[r + ip], C[r + i], F[r + i], true, a.sc_);
+    }
+    S[r + i] = v;
+}
+
+template <bool NINE>
+__global__ __launch_bounds__(256) void k_colour_gen2d(ColourArgs2D a)
+{
+    const int64_t m = blockIdx.z;
+    if (!a.force && a.ctl[m].done) return;
+    const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    int64_t j, i;
+    if (!xinv_colour_point(a, tj, ti, j, i)) return;
+    const int64_t xc = a.xc;
+    double *S = a.S + m * a.sS;
+    const int64_t im = (i == 0) ? xc - 1 : i - 1;
+    const int64_t ip = (i == xc - 1) ? 0 : i + 1;
+    const int64_t r = j * xc, rp = r + xc, rm = r - xc;
+    const int64_t p = r + i;
+    const double cA = a.c[0][m * a.sc[0] + p], cC = a.c[2][m * a.sc[2] + p];
+    const double cD = a.c[3][m * a.sc[3] + p], cE = a.c[4][m * a.sc[4] + p];
+    const double cF = a.c[5][m * a.sc[5] + p], cG = a.c[6][m * a.sc[6] + p];
+    const double sC = S[p];
+    double v;
+    if (NINE) {
+        const double cB = a.c[1][m * a.sc[1] + p];
+        v = xinv_upd_gen2d_9(sC, S[rp + i], S[rm + i], S[r + im], S[r + ip],
+                             S[rp + ip], S[rp + im], S[rm + ip], S[rm + im],
+                             cA, cB, cC, cD, cE, cF, cG, a.sc_);
+    } else {
+        v = xinv_upd_gen2d_5(sC, S[rp + i], S[rm + i], S[r + im], S[r + ip],
+                             cA, cC, cD, cE, cF, cG, true, a.sc_);
+    }
+    S[p] = v;
+}
+
+// ------------------------------------------------------------------------------- 3-D
+struct ColourArgs3D {
+    double *S;
+    const double *c[4];        // A,B,C,F
+    int64_t sS, sc[4];
+    int64_t zc, yc, xc;
+    int per, seam, colour, force;
+    XinvScal sc_;
+    const XinvCtl *ctl;
+    int64_t nbatch;
+};
+
+// grid: x over column pairs, y over rows 1..yc-2, z over (member, plane 1..zc-2).
+__global__ __launch_bounds__(256) void k_colour_std3d(ColourArgs3D a)
+{
+    const int64_t nk = a.zc - 2;
+    const int64_t m = blockIdx.z / nk;
+    const int64_t k = 1 + blockIdx.z % nk;
+    if (!a.force && a.ctl[m].done) return;
+    const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = 1 + (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    if (j > a.yc - 2) return;
+    const int64_t xc = a.xc;
+    int64_t i;
+    if (a.colour >= 2) {                           // seam: column xc-1, parity of (k+j)
+        if (ti != 0 || ((k + j) & 1) != a.colour - 2) return;
+        i = xc - 1;
+    } else {
+        i = 2 * ti + ((k + j + a.colour) & 1);
+        const int64_t ilo = a.per ? 0 : 1;
+        const int64_t ihi = a.per ? xc - 1 : xc - 2;
+        if (i < ilo || i > ihi) return;
+        if (a.seam && i == xc - 1) return;
+    }
+    const int64_t P = a.yc * xc;
+    double *S = a.S + m * a.sS;
+    const double *A = a.c[0] + m * a.sc[0];
+    const double *B = a.c[1] + m * a.sc[1];
+    const double *C = a.c[2] + m * a.sc[2];
+    const double *F = a.c[3] + m * a.sc[3];
+    const int64_t im = (i == 0) ? xc - 1 : i - 1;
+    const int64_t ip = (i == xc - 1) ? 0 : i + 1;
+    const int64_t r = k * P + j * xc;
+    const int64_t p = r + i;
+    S[p] = xinv_upd_std3d(S[p], S[p + P], S[p - P], S[p + xc], S[p - xc], S[r + ip], S[r + im],
+                          A[p + P], A[p], B[p + xc], B[p], C[r + ip], C[p], F[p], a.sc_);
+}
+
+// ---------------------------------------------------------------- 'extend' pre-pass
+// numbas.py:284-310 (2-D) / 87-115 (3-D, planes 1..zc-2).  One thread per column; reads rows
+// 1 and yc-2, writes rows 0 and yc-1.  `tall` (2-D, yc > xc) reproduces what the reference's
+// second loop does inside the array bounds (see oracle/xinv_oracle.c header).
+struct ExtendArgs {
+    double *S;
+    int64_t sS, yc, xc;
+    int64_t kfirst, nk;        // planes kfirst .. kfirst+nk-1 of each member (2-D: 0, 1)
+    int per, tall, force;
+    double undef;
+    const XinvCtl *ctl;
+};
+
+__global__ __launch_bounds__(256) void k_extend(ExtendArgs a)
+{
+    const int64_t m = blockIdx.z;
+    if (!a.force && a.ctl[m].done) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.xc) return;
+    const int64_t k = a.kfirst + blockIdx.y;
+    const int64_t xc = a.xc, yc = a.yc;
+    double *P = a.S + m * a.sS + k * yc * xc;
+    double *r0 = P, *r1 = P + xc, *rm2 = P + (yc - 2) * xc, *rm1 = P + (yc - 1) * xc;
+    const double u = a.undef;
+    if (a.per || (i >= 1 && i <= xc - 2)) {
+        double t = r1[i], b = rm2[i];
+        if (t != u) r0[i] = t;
+        if (b != u) rm1[i] = b;
+    } else if (i == 0) {
+        double t = r1[1], b = rm2[1];
+        if (t != u) r0[0] = t;
+        if (b != u) rm1[0] = b;
+    } else {                                       // i == xc-1
+        if (a.tall) {
+            double t = r1[i], b = rm2[i];
+            if (t != u) r0[i] = t;
+            if (b != u) rm1[i] = b;
+        }
+        double t = r1[xc - 2], b = rm2[xc - 2];
+        if (t != u) r0[i] = t;
+        if (b != u) rm1[i] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------ norm
+// Stage 1: per-workgroup (sum |S|, count) over S != undef in a fixed element -> thread map.
+// Stage 2: one workgroup per member adds the partials in index order and applies the
+// stopping rule.  Both stages are order-deterministic (no floating-point atomics).
+#define XINV_NORM_BLOCKS 512
+
+struct NormArgs {
+    const double *S;
+    int64_t sS, n;
+    double undef;
+    double *psum;              // [nbatch][XINV_NORM_BLOCKS]
+    long long *pcnt;
+    XinvCtl *ctl;
+    XinvStop stop;
+    int force;
+};
+
+__global__ __launch_bounds__(256) void k_norm_partial(NormArgs a)
+{
+    const int64_t m = blockIdx.y;
+    if (!a.force && a.ctl[m].done) return;
+    const double *S = a.S + m * a.sS;
+    double s = 0.0;
+    long long c = 0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.n;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        double v = S[t];
+        if (v != a.undef) { s += fabs(v); c += 1; }
+    }
+    s = xinv_wave_sum(s);
+    c = xinv_wave_sum_ll(c);
+    __shared__ double ls[4];
+    __shared__ long long lc[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { ls[w] = s; lc[w] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0; long long tc = 0;
+        for (int q = 0; q < 4; q++) { ts += ls[q]; tc += lc[q]; }
+        a.psum[m * XINV_NORM_BLOCKS + blockIdx.x] = ts;
+        a.pcnt[m * XINV_NORM_BLOCKS + blockIdx.x] = tc;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_norm_final(NormArgs a, int nblocks)
+{
+    const int64_t m = blockIdx.x;
+    if (!a.force && a.ctl[m].done) return;
+    double s = 0.0;
+    long long c = 0;
+    for (int t = threadIdx.x; t < nblocks; t += 64) {
+        s += a.psum[m * XINV_NORM_BLOCKS + t];
+        c += a.pcnt[m * XINV_NORM_BLOCKS + t];
+    }
+    s = xinv_wave_sum(s);
+    c = xinv_wave_sum_ll(c);
+    if (threadIdx.x == 0) xinv_ctl_update(&a.ctl[m], s, c, a.stop);
+}
+
+// Stand-alone mean|S| (xinv_abs_norm_f64_dev): same two stages, result written to out[0..1].
+__global__ __launch_bounds__(64) void k_norm_out(const double *psum, const long long *pcnt,
+                                                 int nblocks, double *out)
+{
+    double s = 0.0;
+    long long c = 0;
+    for (int t = threadIdx.x; t < nblocks; t += 64) { s += psum[t]; c += pcnt[t]; }
+    s = xinv_wave_sum(s);
+    c = xinv_wave_sum_ll(c);
+    if (threadIdx.x == 0) out[0] = (c != 0) ? s / (double)c : NAN;
+}
+
+// any(B != 0) over n elements -> *flag (int), used once per solve to pick the colouring.
+__global__ __launch_bounds__(256) void k_any_nonzero(const double *B, int64_t n, int *flag)
+{
+    bool nz = false;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (int64_t)gridDim.x * blockDim.x)
+        nz |= (B[t] != 0.0);
+    if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ void k_ctl_init(XinvCtl *ctl, int64_t nbatch)
+{
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nbatch) return;
+    XinvCtl c;
+    c.normPrev = DBL_MAX;
+    c.flag1 = 0.0; c.flag2 = 0.0;
+    c.loop = 0; c.sweeps = 0;
+    c.done = 0; c.overflow = 0; c.wrote = 0; c.ticket = 0;
+    ctl[m] = c;
+}

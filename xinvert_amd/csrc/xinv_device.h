@@ -1,0 +1,224 @@
+// xinv_device.h -- device-side helpers shared by the colour-pass and fused kernels (gfx950).
+//
+// Point arithmetic follows the reference expression by expression (reference
+// xinvert/numbas.py:343-369, 1125-1153, 146-169); the translation unit is compiled with
+// -ffp-contract=off so that no FMA is formed and results are bitwise those of the
+// CPU restatement of the same ordering.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <math.h>
+
+#define XINV_WAVE 64
+
+// One control block per batch member, resident in HBM for the whole solve.  Written only by
+// the last-arriving workgroup of a sweep launch (fused path) or by k_norm_final (colour path);
+// read by every later launch (`done` => the launch is a no-op for that member) and by the host
+// every `check_every` launches.  Mirrors the reference's loop variables (numbas.py:278-283,
+// 401-414): loop, normPrev, flags[1], flags[2], overflow.
+struct XinvCtl {
+    double normPrev;
+    double flag1;          // last relative change of mean|S|
+    double flag2;          // last loop index
+    long long loop;
+    long long sweeps;      // valid once done: sweeps the returned S must contain (= loop + 1)
+    int done;
+    int overflow;
+    int wrote;             // flag1/flag2 have been written at least once
+    unsigned ticket;       // fused path: workgroup arrival counter of the current launch
+};
+
+struct XinvStop {
+    long long mxLoop;
+    double tolerance;
+    int stop_on_zero_norm;  // standard_2D only (numbas.py:410)
+};
+
+// numbas.py:401-414 / 1186-1199 / 197-210, one sweep's worth.
+__device__ __forceinline__ void xinv_ctl_update(XinvCtl *c, double sum, long long count,
+                                                const XinvStop &st)
+{
+    if (c->done) return;
+    double norm = (count != 0) ? sum / (double)count : NAN;
+    if (isnan(norm) || norm > 1e100) {
+        c->overflow = 1;
+        c->done = 1;
+        c->sweeps = c->loop + 1;
+        return;
+    }
+    c->flag1 = fabs(norm - c->normPrev) / c->normPrev;
+    c->flag2 = (double)c->loop;
+    c->wrote = 1;
+    if (c->flag1 < st.tolerance || c->loop >= st.mxLoop ||
+        (st.stop_on_zero_norm && norm == 0.0)) {
+        c->done = 1;
+        c->sweeps = c->loop + 1;
+        return;
+    }
+    c->normPrev = norm;
+    c->loop += 1;
+}
+
+// Deterministic butterfly sum over the 64 lanes of a wavefront.
+__device__ __forceinline__ double xinv_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, XINV_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ long long xinv_wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, XINV_WAVE);
+    return v;
+}
+
+// Scalars of one solve (same for every member), passed by value to the kernels.
+struct XinvScal {
+    double delx, delxSqr, ratio, ratioQtr, ratioSqr;   // 2-D
+    double ratio2Sqr, ratio1Sqr;                       // 3-D
+    double optArg, undef;
+};
+
+// ---- point updates: return the new value of S at the point, or sC when masked -----------
+
+// standard 2-D, full 9-point form (numbas.py:343-369).  `west` selects the two irregular
+// operands of the reference's i == 0 periodic branch (numbas.py:327-328).
+__device__ __forceinline__ double xinv_upd_std2d_9(
+    double sC, double sP, double sM, double sW, double sE,
+    double sPE, double sPW, double sME, double sMW, double sM_q,
+    double aP, double a0, double bE, double bW, double bP_chk, double bP_use, double bM,
+    double cE, double c0, double f, const XinvScal &sc)
+{
+    const double u = sc.undef;
+    bool cond = (f != u) && (aP != u) && (a0 != u) && (bE != u) && (bW != u) &&
+                (bP_chk != u) && (bM != u) && (cE != u) && (c0 != u);
+    if (!cond) return sC;
+    double temp = (
+        (
+            aP * (sP - sC) -
+            a0 * (sC - sM)
+        ) * sc.ratioSqr + (
+            bP_use * (sPE - sPW) -
+            bM * (sM_q - sMW)
+        ) * sc.ratioQtr + (
+            bE * (sPE - sME) -
+            bW * (sPW - sMW)
+        ) * sc.ratioQtr + (
+            cE * (sE - sC) -
+            c0 * (sC - sW)
+        )
+    ) - f * sc.delxSqr;
+    temp *= sc.optArg / ((aP + a0) * sc.ratioSqr + (cE + c0));
+    return sC + temp;
+}
+
+// standard 2-D with B == 0 everywhere (5-point coupling).
+__device__ __forceinline__ double xinv_upd_std2d_5(
+    double sC, double sP, double sM, double sW, double sE,
+    double aP, double a0, double cE, double c0, double f, bool inrange, const XinvScal &sc)
+{
+    const double u = sc.undef;
+    bool cond = inrange && (f != u) && (aP != u) && (a0 != u) && (cE != u) && (c0 != u);
+    double temp = (
+        (
+            aP * (sP - sC) -
+            a0 * (sC - sM)
+        ) * sc.ratioSqr + (
+            cE * (sE - sC) -
+            c0 * (sC - sW)
+        )
+    ) - f * sc.delxSqr;
+    temp *= sc.optArg / ((aP + a0) * sc.ratioSqr + (cE + c0));
+    return cond ? sC + temp : sC;
+}
+
+// general 2-D, full 9-point form (numbas.py:1125-1153).
+__device__ __forceinline__ double xinv_upd_gen2d_9(
+    double sC, double sP, double sM, double sW, double sE,
+    double sPE, double sPW, double sME, double sMW,
+    double A, double B, double C, double D, double E, double F, double G, const XinvScal &sc)
+{
+    const double u = sc.undef;
+    bool cond = (G != u) && (A != u) && (B != u) && (C != u) && (D != u) && (E != u) && (F != u);
+    if (!cond) return sC;
+    double temp = (
+        A * (
+            (sP - sC) - (sC - sM)
+        ) * sc.ratioSqr +
+        B * (
+            (sPE - sME) - (sPW - sMW)
+        ) * sc.ratioQtr +
+        C * (
+            (sE - sC) - (sC - sW)
+        ) + (
+        D * (
+            (sP - sM)
+        ) * sc.ratio +
+        E * (
+            (sE - sW)
+        )) * sc.delx / 2.0 + (
+        F * sC - G) * sc.delxSqr
+    );
+    temp *= sc.optArg / ((A * sc.ratioSqr + C) * 2.0
+                         - F * sc.delxSqr);
+    return sC + temp;
+}
+
+// general 2-D with B == 0 everywhere (5-point coupling).
+__device__ __forceinline__ double xinv_upd_gen2d_5(
+    double sC, double sP, double sM, double sW, double sE,
+    double A, double C, double D, double E, double F, double G, bool inrange,
+    const XinvScal &sc)
+{
+    const double u = sc.undef;
+    bool cond = inrange && (G != u) && (A != u) && (C != u) && (D != u) && (E != u) && (F != u);
+    double temp = (
+        A * (
+            (sP - sC) - (sC - sM)
+        ) * sc.ratioSqr +
+        C * (
+            (sE - sC) - (sC - sW)
+        ) + (
+        D * (
+            (sP - sM)
+        ) * sc.ratio +
+        E * (
+            (sE - sW)
+        )) * sc.delx / 2.0 + (
+        F * sC - G) * sc.delxSqr
+    );
+    temp *= sc.optArg / ((A * sc.ratioSqr + C) * 2.0
+                         - F * sc.delxSqr);
+    return cond ? sC + temp : sC;
+}
+
+// standard 3-D, 7-point (numbas.py:146-169).  P/M = k+1/k-1, N/S = j+1/j-1, E/W = i+1/i-1.
+__device__ __forceinline__ double xinv_upd_std3d(
+    double sC, double sKP, double sKM, double sJP, double sJM, double sE, double sW,
+    double aP, double a0, double bP, double b0, double cE, double c0, double f,
+    const XinvScal &sc)
+{
+    const double u = sc.undef;
+    bool cond = (f != u) && (aP != u) && (a0 != u) && (bP != u) && (b0 != u) &&
+                (cE != u) && (c0 != u);
+    if (!cond) return sC;
+    double temp = (
+        (
+            aP * (sKP - sC) -
+            a0 * (sC - sKM)
+        ) * sc.ratio2Sqr + (
+            bP * (sJP - sC) -
+            b0 * (sC - sJM)
+        ) * sc.ratio1Sqr + (
+            cE * (sE - sC) -
+            c0 * (sC - sW)
+        )
+    ) - f * sc.delxSqr;
+    temp *= sc.optArg / ((aP + a0) * sc.ratio2Sqr +
+                         (bP + b0) * sc.ratio1Sqr +
+                         (cE + c0));
+    return sC + temp;
+}

@@ -1,0 +1,342 @@
+// xinv_fused.h -- streaming fused red-black SOR sweep(s) for the 2-D 5-point forms (gfx950).
+//
+// The hot kernel of the engine (configs: Poisson / Stommel / Gill-Matsuno, B == 0).
+//
+// Decomposition.  One wavefront owns a tile: a strip of 128 columns (two adjacent columns per
+// lane, one of each colour, so every lane works in every half-sweep) marched top to bottom over
+// RY rows.  A 256-thread workgroup is four independent wavefronts on four adjacent strips; the
+// only workgroup-level step is the final reduction of the norm partials.  Neighbouring tiles
+// overlap by a halo of 2K columns / 2K rows that is recomputed (never exchanged), so a launch
+// needs no inter-workgroup synchronisation and S ping-pongs between two buffers.
+//
+// Pipeline.  Rows stream through a register window.  With `r` the row just loaded, sweep s
+// (s = 1..K) updates its red points on row r-2s+1 and its black points on row r-2s; row r-2K
+// leaves the window with K complete sweeps applied.  All stages of one step update the same
+// lane component ((r+1)&1), and each needs exactly one cross-lane operand (the other colour's
+// value one column over), taken with a wave shuffle.  HBM traffic per launch is one read of S
+// and of each coefficient array plus one write of S (+ halo re-reads served by L2), for K sweeps.
+//
+// Loads are 16 B per lane (1 KiB per wavefront per array row), issued two rows ahead of use.
+//
+// Norm.  mean|S| of the reference (numbas.py:1710-1728) is accumulated per sweep for the rows
+// and columns a tile owns, reduced wave -> workgroup -> partials[] in a fixed order, and the
+// last-arriving workgroup of the launch (agent-scope ticket) adds the partials in index order
+// and applies the stopping rule (numbas.py:401-414) on the device.  No floating-point atomics:
+// the norm is run-to-run reproducible.
+#pragma once
+#include "xinv_device.h"
+#include <type_traits>
+
+#define XINV_KMAX 4
+
+struct FusedArgs {
+    const double *src;
+    double *dst;
+    const double *c[6];        // std: A, C, F ; gen: A, C, D, E, F, G   (B is identically 0)
+    int64_t sS, sc[6];         // batch strides (elements)
+    int64_t yc, xc;
+    int per, ext, tall;
+    int nsg, nrb, RY;          // strip groups (4 strips each), row blocks, rows per tile
+    int force, no_ctl;
+    int64_t member0;
+    XinvScal sc_;
+    XinvCtl *ctl;
+    XinvStop stop;
+    unsigned long long *psum;  // [nbatch][XINV_KMAX][NB]  (bit patterns of doubles)
+    long long *pcnt;
+};
+
+template <int X> __device__ __forceinline__ double comp(const double2 &v) { return X ? v.y : v.x; }
+template <int X> __device__ __forceinline__ void setc(double2 &v, double t) { if (X) v.y = t; else v.x = t; }
+
+// value of the neighbouring column: X == 0 -> west neighbour lives in lane-1's .y, east is own .y
+//                                   X == 1 -> west is own .x, east neighbour lives in lane+1's .x
+template <int X> __device__ __forceinline__ void row_neighbours(const double2 &row, double &w, double &e)
+{
+    if (X == 0) { w = __shfl_up(row.y, 1, XINV_WAVE); e = row.y; }
+    else        { w = row.x; e = __shfl_down(row.x, 1, XINV_WAVE); }
+}
+
+// ---- models: which coefficient streams exist and how a point is updated -------------------
+struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
+    static constexpr int NC = 3;    // A, C, F
+    // jw = window index of row j; row j+1 is jw-1.
+    template <int X, int DC>
+    static __device__ __forceinline__ double upd(const double2 (&cw)[NC][DC], int jw, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 bool inr, const XinvScal &sc)
+    {
+        const double aP = comp<X>(cw[0][jw - 1]);
+        const double a0 = comp<X>(cw[0][jw]);
+        const double c0 = comp<X>(cw[1][jw]);
+        double cE;
+        if (X == 0) cE = cw[1][jw].y;
+        else        cE = __shfl_down(cw[1][jw].x, 1, XINV_WAVE);
+        const double f = comp<X>(cw[2][jw]);
+        return xinv_upd_std2d_5(sC, sP, sM, sW, sE, aP, a0, cE, c0, f, inr, sc);
+    }
+};
+
+struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
+    static constexpr int NC = 6;    // A, C, D, E, F, G
+    template <int X, int DC>
+    static __device__ __forceinline__ double upd(const double2 (&cw)[NC][DC], int jw, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 bool inr, const XinvScal &sc)
+    {
+        return xinv_upd_gen2d_5(sC, sP, sM, sW, sE,
+                                comp<X>(cw[0][jw]), comp<X>(cw[1][jw]), comp<X>(cw[2][jw]),
+                                comp<X>(cw[3][jw]), comp<X>(cw[4][jw]), comp<X>(cw[5][jw]),
+                                inr, sc);
+    }
+};
+
+template <int NC> struct RowPack { double2 s; double2 c[NC]; };
+
+struct LaneCols {
+    int64_t l0, l1;            // load columns of .x / .y (wrapped or clamped)
+    bool ok_x, ok_y;           // column may be updated (interior, or any column when periodic)
+    bool use_x, use_y;         // column is owned (stored / counted) by this lane
+    int cls_x, cls_y;          // extend fix: 0 none, 1 straight copy, 2 column 0, 3 column xc-1
+};
+
+template <bool AL>
+__device__ __forceinline__ double2 ld2(const double *p, int64_t row_off, const LaneCols &lc)
+{
+    if (AL) return *reinterpret_cast<const double2 *>(p + row_off + lc.l0);
+    double2 v; v.x = p[row_off + lc.l0]; v.y = p[row_off + lc.l1]; return v;
+}
+
+// 'extend' pre-pass for one boundary row held in the window (numbas.py:284-310).
+// edge = row 0 (or yc-1), inner = row 1 (or yc-2), both in their state at the start of sweep s.
+__device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &inner,
+                                                 const LaneCols &lc, bool tall, double u)
+{
+    const double inner_w = __shfl_up(inner.y, 1, XINV_WAVE);   // column c0-1
+    // component x (column c0)
+    if (lc.cls_x == 1) { if (inner.x != u) edge.x = inner.x; }
+    else if (lc.cls_x == 2) { if (inner.y != u) edge.x = inner.y; }           // (0,0) <- (1,1)
+    else if (lc.cls_x == 3) {
+        if (tall && inner.x != u) edge.x = inner.x;
+        if (inner_w != u) edge.x = inner_w;                                    // <- column xc-2
+    }
+    // component y (column c0+1)
+    if (lc.cls_y == 1) { if (inner.y != u) edge.y = inner.y; }
+    else if (lc.cls_y == 3) {
+        if (tall && inner.y != u) edge.y = inner.y;
+        if (inner.x != u) edge.y = inner.x;                                    // <- column xc-2
+    }
+}
+
+template <class M, int K, bool AL>
+__global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
+{
+    constexpr int NC = M::NC;
+    constexpr int H = 2 * K;            // halo (rows and columns) consumed by K sweeps
+    constexpr int UW = 128 - 2 * H;     // columns owned by one wavefront
+    constexpr int DS = 2 * K + 2;       // S window depth
+    constexpr int DC = 2 * K + 1;       // coefficient window depth
+
+    const int64_t m = a.member0 + blockIdx.y;
+    XinvCtl *ctl = a.ctl + m;
+    if (!a.force && ctl->done) return;
+
+    // ---- tile of this wavefront; workgroup -> tile map keeps each XCD on a band of rows ----
+    const int NB = a.nsg * a.nrb;
+    int T;
+    {
+        const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
+        T = xcd * q + (xcd < rem ? xcd : rem) + idx;
+    }
+    const int rb = T / a.nsg, sg = T - rb * a.nsg;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t xc = a.xc, yc = a.yc;
+    const int64_t xu0 = (int64_t)(sg * 4 + wave) * UW;
+    const int64_t yu0 = (int64_t)rb * a.RY;
+    const int64_t yu1 = (yu0 + a.RY < yc) ? yu0 + a.RY : yc;
+    const bool active = xu0 < xc;
+    const double u = a.sc_.undef;
+
+    LaneCols lc;
+    {
+        const int64_t c0 = xu0 - H + 2 * lane, c1 = c0 + 1;
+        if (a.per) {
+            int64_t w0 = c0 % xc; if (w0 < 0) w0 += xc;
+            int64_t w1 = c1 % xc; if (w1 < 0) w1 += xc;
+            lc.l0 = w0; lc.l1 = w1;
+            lc.ok_x = lc.ok_y = true;
+            lc.cls_x = lc.cls_y = 1;
+        } else {
+            if (AL) {
+                int64_t p = c0 < 0 ? 0 : (c0 > xc - 2 ? xc - 2 : c0);
+                lc.l0 = p; lc.l1 = p + 1;
+            } else {
+                lc.l0 = c0 < 0 ? 0 : (c0 > xc - 1 ? xc - 1 : c0);
+                lc.l1 = c1 < 0 ? 0 : (c1 > xc - 1 ? xc - 1 : c1);
+            }
+            lc.ok_x = (c0 >= 1 && c0 <= xc - 2);
+            lc.ok_y = (c1 >= 1 && c1 <= xc - 2);
+            lc.cls_x = lc.ok_x ? 1 : (c0 == 0 ? 2 : (c0 == xc - 1 ? 3 : 0));
+            lc.cls_y = lc.ok_y ? 1 : (c1 == xc - 1 ? 3 : 0);
+        }
+        lc.use_x = (c0 >= xu0 && c0 < xu0 + UW && c0 < xc);
+        lc.use_y = (c1 >= xu0 && c1 < xu0 + UW && c1 < xc);
+    }
+    const int64_t st0 = xu0 - H + 2 * lane;          // unwrapped store column of .x
+
+    const double *srcS = a.src + m * a.sS;
+    double *dstS = a.dst + m * a.sS;
+    const double *cp[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++) cp[q] = a.c[q] + m * a.sc[q];
+
+    double acc[K];
+    int cnt[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) { acc[s] = 0.0; cnt[s] = 0; }
+
+    if (active) {
+        auto load = [&](int64_t r) {
+            RowPack<NC> p;
+            const int64_t rr = r < 0 ? 0 : (r > yc - 1 ? yc - 1 : r);
+            const int64_t off = rr * xc;
+            p.s = ld2<AL>(srcS, off, lc);
+#pragma unroll
+            for (int q = 0; q < NC; q++) p.c[q] = ld2<AL>(cp[q], off, lc);
+            return p;
+        };
+
+        double2 sw[DS];
+        double2 cw[NC][DC];
+#pragma unroll
+        for (int t = 0; t < DS; t++) sw[t] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+#pragma unroll
+            for (int t = 0; t < DC; t++) cw[q][t] = make_double2(0.0, 0.0);
+
+        // one pipeline step: row r enters; X = component updated by every stage of this step
+        auto step = [&](int64_t r, const RowPack<NC> &p, auto xtag) {
+            constexpr int X = decltype(xtag)::value;
+#pragma unroll
+            for (int t = DS - 1; t > 0; t--) sw[t] = sw[t - 1];
+            sw[0] = p.s;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+#pragma unroll
+                for (int t = DC - 1; t > 0; t--) cw[q][t] = cw[q][t - 1];
+                cw[q][0] = p.c[q];
+            }
+            const bool okc = X ? lc.ok_y : lc.ok_x;
+#pragma unroll
+            for (int s = 1; s <= K; s++) {
+                {   // red half-sweep of sweep s on row ja (window index 2s-1)
+                    const int64_t ja = r - 2 * s + 1;
+                    const int jw = 2 * s - 1;
+                    if (a.ext) {
+                        if (ja == 1) fused_extend_fix(sw[jw + 1], sw[jw], lc, a.tall, u);
+                        if (ja == yc - 2) fused_extend_fix(sw[jw - 1], sw[jw], lc, a.tall, u);
+                    }
+                    double w, e;
+                    row_neighbours<X>(sw[jw], w, e);
+                    const bool inr = okc && (ja >= 1) && (ja <= yc - 2);
+                    const double v = M::template upd<X, DC>(cw, jw, comp<X>(sw[jw]),
+                                                            comp<X>(sw[jw - 1]), comp<X>(sw[jw + 1]),
+                                                            w, e, inr, a.sc_);
+                    setc<X>(sw[jw], v);
+                }
+                {   // black half-sweep of sweep s on row jb (window index 2s)
+                    const int64_t jb = r - 2 * s;
+                    const int jw = 2 * s;
+                    double w, e;
+                    row_neighbours<X>(sw[jw], w, e);
+                    const bool inr = okc && (jb >= 1) && (jb <= yc - 2);
+                    const double v = M::template upd<X, DC>(cw, jw, comp<X>(sw[jw]),
+                                                            comp<X>(sw[jw - 1]), comp<X>(sw[jw + 1]),
+                                                            w, e, inr, a.sc_);
+                    setc<X>(sw[jw], v);
+                    if (jb >= yu0 && jb < yu1) {          // row jb now holds sweep s: norm
+                        const double2 t = sw[jw];
+                        if (lc.use_x && t.x != u) { acc[s - 1] += fabs(t.x); cnt[s - 1] += 1; }
+                        if (lc.use_y && t.y != u) { acc[s - 1] += fabs(t.y); cnt[s - 1] += 1; }
+                    }
+                }
+            }
+            const int64_t jo = r - 2 * K;                  // row leaving the pipeline
+            if (jo >= yu0 && jo < yu1) {
+                const double2 t = sw[2 * K];
+                if (AL) {
+                    if (lc.use_x) *reinterpret_cast<double2 *>(dstS + jo * xc + st0) = t;
+                } else {
+                    if (lc.use_x) dstS[jo * xc + st0] = t.x;
+                    if (lc.use_y) dstS[jo * xc + st0 + 1] = t.y;
+                }
+            }
+        };
+
+        const int64_t r0 = yu0 - H;                        // even: RY and H are even
+        const int64_t rlast = yu1 - 1 + H;
+        RowPack<NC> p0 = load(r0), p1 = load(r0 + 1);
+        for (int64_t r = r0; r <= rlast; r += 2) {
+            step(r, p0, std::integral_constant<int, 1>{});       // r even   -> update .y
+            p0 = load(r + 2);
+            step(r + 1, p1, std::integral_constant<int, 0>{});   // r+1 odd  -> update .x
+            p1 = load(r + 3);
+        }
+    }
+
+    if (a.no_ctl) return;
+
+    // ---- norm partials: wave -> workgroup -> global, then last-arriver finalises ----------
+    __shared__ double ls[4][K];
+    __shared__ long long lcn[4][K];
+    __shared__ unsigned s_last;
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        double ws = xinv_wave_sum(acc[s]);
+        long long wc = xinv_wave_sum_ll((long long)cnt[s]);
+        if (lane == 0) { ls[wave][s] = ws; lcn[wave][s] = wc; }
+    }
+    __syncthreads();
+    unsigned long long *psum = a.psum + (size_t)m * XINV_KMAX * NB;
+    long long *pcnt = a.pcnt + (size_t)m * XINV_KMAX * NB;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            double ts = 0.0; long long tc = 0;
+            for (int q = 0; q < 4; q++) { ts += ls[q][s]; tc += lcn[q][s]; }
+            __hip_atomic_store(&psum[s * NB + T], (unsigned long long)__double_as_longlong(ts),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pcnt[s * NB + T], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
+        unsigned old = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == (unsigned)(NB - 1)) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || wave != 0) return;
+
+    // last workgroup of this member's launch: every partial is in memory (write-through);
+    // read them with agent-scope loads (bypass this CU's L1), sum in index order.
+    double tot[K];
+    long long tcn[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        double ps = 0.0; long long pc = 0;
+        for (int t = lane; t < NB; t += XINV_WAVE) {
+            unsigned long long bits = __hip_atomic_load(&psum[s * NB + t], __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+            ps += __longlong_as_double((long long)bits);
+            pc += __hip_atomic_load(&pcnt[s * NB + t], __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+        }
+        tot[s] = xinv_wave_sum(ps);
+        tcn[s] = xinv_wave_sum_ll(pc);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < K; s++) xinv_ctl_update(ctl, tot[s], tcn[s], a.stop);
+        __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}

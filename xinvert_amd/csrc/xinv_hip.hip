@@ -1,0 +1,759 @@
+// xinv_hip.hip -- host driver and C-ABI of the MI355X SOR inversion engine (include/xinv.h).
+//
+// Replaces the reference's numba kernels behind the call boundary of xinvert/core.py
+// (core.py:60-69, 130-139, 419-428).  Built for gfx950 only:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+//
+// Control flow of one solve (all batch members together, one stream):
+//   k_ctl_init -> [ sweep launches ... ] x check_every -> async read-back of the per-member
+//   control blocks -> repeat until every member has stopped.  The stopping rule runs on the
+//   device after every sweep (last-arriving workgroup / k_norm_final); once a member is done
+//   every later launch is a no-op for it, so S holds exactly the sweep the reference stops at.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <exception>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/xinv.h"
+#include "xinv_device.h"
+#include "xinv_colour.h"
+#include "xinv_fused.h"
+
+#define XINV_VERSION 100
+
+// ------------------------------------------------------------------ errors / thread state
+static thread_local std::string t_err;
+static thread_local xinv_stats t_stats;
+
+#define HIPCHK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            char b_[512];                                                              \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                              \
+            t_err = b_;                                                                \
+            return (e_ == hipErrorOutOfMemory) ? XINV_ERR_NOMEM : XINV_ERR_HIP;        \
+        }                                                                              \
+    } while (0)
+
+static int fail_arg(const char *msg) { t_err = msg; return XINV_ERR_ARG; }
+
+// ------------------------------------------------------------------ per-device workspace
+// Grown on demand, reused across solves (no hipMalloc in steady state).
+struct Workspace {
+    int device = -1;
+    double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
+    XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
+    void *partials = nullptr; size_t partials_cap = 0;  // psum + pcnt
+    int *dflag = nullptr;
+    XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
+    int *hflag = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *stage = nullptr; size_t stage_cap = 0;      // device staging for host-pointer API
+};
+
+static std::mutex g_ws_mutex;
+static std::vector<Workspace *> g_ws;
+
+static Workspace *get_ws(int device)
+{
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    for (auto *w : g_ws) if (w->device == device) return w;
+    Workspace *w = new Workspace();
+    w->device = device;
+    g_ws.push_back(w);
+    return w;
+}
+
+template <class T>
+static int ensure_dev(T **p, size_t *cap, size_t need_bytes)
+{
+    if (*cap >= need_bytes && *p) return XINV_OK;
+    if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIPCHK(hipMalloc((void **)p, need_bytes));
+    *cap = need_bytes;
+    return XINV_OK;
+}
+
+// ------------------------------------------------------------------ problem description
+enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2 };
+
+struct Problem {
+    int kind;
+    int64_t nbatch, zc, yc, xc;
+    double *S;
+    const double *c[7];          // std2d/std3d: A,B,C,F ; gen2d: A,B,C,D,E,F,G
+    int64_t sS, sc[7];
+    int ncoef;
+    int BCz, BCy, BCx;
+    XinvScal sc_;
+    XinvStop stop;
+};
+
+static int bc_ok(int b) { return b == XINV_BC_FIXED || b == XINV_BC_EXTEND || b == XINV_BC_PERIODIC; }
+
+static int validate(const Problem &p, const double *flags)
+{
+    if (!p.S || !flags) return fail_arg("null S or flags");
+    for (int q = 0; q < p.ncoef; q++)
+        if (!p.c[q] && !(q == 1 && p.kind != KIND_STD3D))   // B may be NULL in 2-D: identically 0
+            return fail_arg("null coefficient array");
+    if (p.nbatch < 1) return fail_arg("nbatch < 1");
+    if (p.yc < 3 || p.xc < 3 || (p.kind == KIND_STD3D && p.zc < 3))
+        return fail_arg("every core dimension needs at least 3 points");
+    if (!bc_ok(p.BCy) || !bc_ok(p.BCx) || (p.kind == KIND_STD3D && !bc_ok(p.BCz)))
+        return fail_arg("unknown boundary-condition code");
+    if (p.stop.mxLoop < 0) return fail_arg("mxLoop < 0");
+    const int64_t n = p.zc * p.yc * p.xc;
+    if (p.nbatch > 1 && p.sS < n) return fail_arg("S batch stride smaller than one slice");
+    for (int q = 0; q < p.ncoef; q++)
+        if (p.c[q] && p.sc[q] != 0 && p.sc[q] < n)
+            return fail_arg("coefficient batch stride must be 0 (shared) or >= slice size");
+    return XINV_OK;
+}
+
+static void fill_options(xinv_options &o, const xinv_options *in)
+{
+    xinv_default_options(&o);
+    if (in) o = *in;
+}
+
+// ------------------------------------------------------------------ launch helpers
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+struct Plan {
+    int path, base, seam, ncol;
+    int K, RY, nsg, nrb;
+    bool aligned;
+};
+
+static bool ptr_al16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
+
+static int launch_fused(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
+                        Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
+                        int no_ctl)
+{
+    FusedArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = src; a.dst = dst;
+    a.sS = p.sS;
+    if (p.kind == KIND_STD2D) {
+        a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
+        a.c[1] = p.c[2]; a.sc[1] = p.sc[2];      // C
+        a.c[2] = p.c[3]; a.sc[2] = p.sc[3];      // F
+    } else {
+        a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
+        for (int q = 2; q < 7; q++) { a.c[q - 1] = p.c[q]; a.sc[q - 1] = p.sc[q]; }   // C..G
+    }
+    a.yc = p.yc; a.xc = p.xc;
+    a.per = (p.BCx == XINV_BC_PERIODIC);
+    a.ext = (p.BCy == XINV_BC_EXTEND);
+    a.tall = (p.yc > p.xc);
+    a.RY = pl.RY;
+    const int UW = 128 - 4 * K;
+    a.nsg = (int)cdiv(cdiv(p.xc, UW), 4);
+    a.nrb = (int)cdiv(p.yc, pl.RY);
+    a.force = force; a.no_ctl = no_ctl;
+    a.member0 = member0;
+    a.sc_ = p.sc_;
+    a.ctl = ws->ctl;
+    a.stop = p.stop;
+    const size_t NBmax = (size_t)pl.nsg * pl.nrb;   // partials are sized for the narrowest strips (K = XINV_KMAX)
+    a.psum = (unsigned long long *)ws->partials;
+    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
+    dim3 grid((unsigned)(a.nsg * a.nrb), (unsigned)nmem, 1), block(256, 1, 1);
+    const bool gen = (p.kind == KIND_GEN2D);
+#define LAUNCH(M, KK, AL) hipLaunchKernelGGL((k_fused2d<M, KK, AL>), grid, block, 0, st, a)
+#define PICK_K(M, AL)                                    \
+    switch (K) {                                         \
+    case 1: LAUNCH(M, 1, AL); break;                     \
+    case 2: LAUNCH(M, 2, AL); break;                     \
+    default: return fail_arg("unsupported sweeps_per_launch"); }
+    if (gen) { if (pl.aligned) { PICK_K(FusedGen2D, true) } else { PICK_K(FusedGen2D, false) } }
+    else     { if (pl.aligned) { PICK_K(FusedStd2D, true) } else { PICK_K(FusedStd2D, false) } }
+#undef PICK_K
+#undef LAUNCH
+    HIPCHK(hipGetLastError());
+    return XINV_OK;
+}
+
+// one full coloured sweep (+ norm + stop rule) in place on p.S
+static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st)
+{
+    const int per = (p.BCx == XINV_BC_PERIODIC);
+    if (p.BCy == XINV_BC_EXTEND) {
+        ExtendArgs e;
+        e.S = p.S; e.sS = p.sS; e.yc = p.yc; e.xc = p.xc;
+        e.kfirst = (p.kind == KIND_STD3D) ? 1 : 0;
+        e.nk = (p.kind == KIND_STD3D) ? p.zc - 2 : 1;
+        e.per = per; e.tall = (p.kind != KIND_STD3D) && (p.yc > p.xc); e.force = 0;
+        e.undef = p.sc_.undef; e.ctl = ws->ctl;
+        dim3 g(cdiv(p.xc, 256), (unsigned)e.nk, (unsigned)p.nbatch), b(256, 1, 1);
+        hipLaunchKernelGGL(k_extend, g, b, 0, st, e);
+    }
+    if (p.kind == KIND_STD3D) {
+        ColourArgs3D a;
+        memset(&a, 0, sizeof a);
+        a.S = p.S; a.sS = p.sS;
+        for (int q = 0; q < 4; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
+        a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
+        a.per = per; a.seam = pl.seam; a.force = 0; a.sc_ = p.sc_; a.ctl = ws->ctl;
+        a.nbatch = p.nbatch;
+        dim3 b(64, 4, 1);
+        dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)(p.nbatch * (p.zc - 2)));
+        for (int cc = 0; cc < pl.ncol; cc++) {
+            a.colour = cc;
+            hipLaunchKernelGGL(k_colour_std3d, g, b, 0, st, a);
+        }
+    } else {
+        ColourArgs2D a;
+        memset(&a, 0, sizeof a);
+        a.S = p.S; a.sS = p.sS;
+        for (int q = 0; q < p.ncoef; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
+        a.yc = p.yc; a.xc = p.xc;
+        a.per = per; a.base = pl.base; a.seam = pl.seam; a.force = 0;
+        a.sc_ = p.sc_; a.ctl = ws->ctl;
+        dim3 b(64, 4, 1);
+        dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)p.nbatch);
+        const bool nine = (pl.base == 4);
+        for (int cc = 0; cc < pl.ncol; cc++) {
+            a.colour = cc;
+            if (p.kind == KIND_STD2D) {
+                if (nine) hipLaunchKernelGGL(k_colour_std2d<true>, g, b, 0, st, a);
+                else      hipLaunchKernelGGL(k_colour_std2d<false>, g, b, 0, st, a);
+            } else {
+                if (nine) hipLaunchKernelGGL(k_colour_gen2d<true>, g, b, 0, st, a);
+                else      hipLaunchKernelGGL(k_colour_gen2d<false>, g, b, 0, st, a);
+            }
+        }
+    }
+    NormArgs n;
+    n.S = p.S; n.sS = p.sS; n.n = p.zc * p.yc * p.xc; n.undef = p.sc_.undef;
+    n.psum = (double *)ws->partials;
+    n.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_NORM_BLOCKS * sizeof(double));
+    n.ctl = ws->ctl; n.stop = p.stop; n.force = 0;
+    int nblk = (int)std::min<int64_t>(XINV_NORM_BLOCKS, std::max<int64_t>(1, n.n / 2048));
+    hipLaunchKernelGGL(k_norm_partial, dim3(nblk, (unsigned)p.nbatch, 1), dim3(256, 1, 1), 0, st, n);
+    hipLaunchKernelGGL(k_norm_final, dim3((unsigned)p.nbatch, 1, 1), dim3(64, 1, 1), 0, st, n, nblk);
+    HIPCHK(hipGetLastError());
+    return XINV_OK;
+}
+
+// ------------------------------------------------------------------ the solve (device ptrs)
+static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st)
+{
+    int rc = validate(p, flags);
+    if (rc) return rc;
+    xinv_options opt;
+    fill_options(opt, opt_in);
+
+    int device = opt.device;
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    else HIPCHK(hipSetDevice(device));
+    Workspace *ws = get_ws(device);
+    if (!ws->ev0) { HIPCHK(hipEventCreate(&ws->ev0)); HIPCHK(hipEventCreate(&ws->ev1)); }
+    if (!ws->dflag) {
+        HIPCHK(hipMalloc((void **)&ws->dflag, sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&ws->hflag, sizeof(int), hipHostMallocDefault));
+    }
+
+    const int64_t n = p.zc * p.yc * p.xc;
+    memset(&t_stats, 0, sizeof t_stats);
+
+    // ---- colouring: red-black when the cross coefficient vanishes, else 4 colours ----------
+    Plan pl;
+    memset(&pl, 0, sizeof pl);
+    if (p.kind == KIND_STD3D) {
+        pl.base = 2;
+    } else {
+        bool bzero = (p.c[1] == nullptr);
+        if (!bzero && p.sc_.undef != 0.0) {
+            HIPCHK(hipMemsetAsync(ws->dflag, 0, sizeof(int), st));
+            const int64_t nb = (p.sc[1] == 0) ? n : (p.nbatch - 1) * p.sc[1] + n;
+            hipLaunchKernelGGL(k_any_nonzero, dim3(1024), dim3(256), 0, st, p.c[1], nb, ws->dflag);
+            HIPCHK(hipMemcpyAsync(ws->hflag, ws->dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            bzero = (*ws->hflag == 0);
+        }
+        pl.base = bzero ? 2 : 4;
+    }
+    pl.seam = (p.BCx == XINV_BC_PERIODIC) && (p.xc & 1);
+    pl.ncol = pl.base + (pl.seam ? 2 : 0);
+
+    // ---- path ------------------------------------------------------------------------------
+    const bool fused_ok = (p.kind != KIND_STD3D) && pl.base == 2 && !pl.seam;
+    pl.path = XINV_PATH_COLOUR;
+    if (fused_ok && opt.path != XINV_PATH_COLOUR) pl.path = XINV_PATH_FUSED;
+    if (opt.path == XINV_PATH_FUSED && !fused_ok)
+        return fail_arg("fused path needs a 2-D problem with B == 0 and no odd-xc periodic seam");
+    if (pl.path == XINV_PATH_COLOUR && p.kind != KIND_STD3D && !p.c[1] && pl.base == 4)
+        return fail_arg("internal: 9-point form without B");
+
+    if (pl.path == XINV_PATH_FUSED) {
+        pl.K = opt.sweeps_per_launch > 0 ? opt.sweeps_per_launch : 1;
+        if (pl.K > 2) return fail_arg("sweeps_per_launch must be 1 or 2");
+        pl.RY = opt.rows_per_tile > 0 ? (opt.rows_per_tile + 1) & ~1 : 32;
+        pl.nsg = (int)cdiv(cdiv(p.xc, 128 - 4 * XINV_KMAX), 4);   // most strips any K needs: sizes the partials
+        pl.nrb = (int)cdiv(p.yc, pl.RY);
+        pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
+        const int cmap3[3] = {0, 2, 3}, cmap6[6] = {0, 2, 3, 4, 5, 6};
+        const int nc = (p.kind == KIND_STD2D) ? 3 : 6;
+        for (int q = 0; q < nc; q++) {
+            const int s = (p.kind == KIND_STD2D) ? cmap3[q] : cmap6[q];
+            pl.aligned = pl.aligned && ptr_al16(p.c[s]) && !(p.sc[s] & 1);
+        }
+    }
+
+    // ---- workspace ---------------------------------------------------------------------------
+    rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)p.nbatch * sizeof(XinvCtl));
+    if (rc) return rc;
+    if (ws->hctl_cap < (size_t)p.nbatch) {
+        if (ws->hctl) HIPCHK(hipHostFree(ws->hctl));
+        HIPCHK(hipHostMalloc((void **)&ws->hctl, (size_t)p.nbatch * sizeof(XinvCtl), hipHostMallocDefault));
+        ws->hctl_cap = (size_t)p.nbatch;
+    }
+    size_t pbytes;
+    if (pl.path == XINV_PATH_FUSED)
+        pbytes = (size_t)p.nbatch * XINV_KMAX * pl.nsg * pl.nrb * (sizeof(double) + sizeof(long long));
+    else
+        pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
+    rc = ensure_dev(&ws->partials, &ws->partials_cap, pbytes);
+    if (rc) return rc;
+    double *S2 = nullptr;
+    if (pl.path == XINV_PATH_FUSED) {
+        const size_t need = (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double);
+        rc = ensure_dev(&ws->S2, &ws->S2_cap, need);
+        if (rc) return rc;
+        S2 = ws->S2;
+    }
+
+    hipLaunchKernelGGL(k_ctl_init, dim3(cdiv(p.nbatch, 256)), dim3(256), 0, st, ws->ctl, p.nbatch);
+
+    // ---- sweep loop ----------------------------------------------------------------------------
+    const int64_t max_sweeps = p.stop.mxLoop + 1;       // numbas.py:410: loop >= mxLoop stops
+    const int Kf = (pl.path == XINV_PATH_FUSED) ? pl.K : 1;
+    int check_every = opt.check_every;
+    if (check_every <= 0) {
+        double est_us = std::max(6.0, (double)p.nbatch * (double)n * Kf / 30e3);
+        check_every = (int)std::min(256.0, std::max(4.0, 2000.0 / est_us));
+    }
+    double *buf[2] = { p.S, S2 };
+    std::vector<int64_t> bound;                          // bound[i] = sweeps before launch i
+    int64_t launched = 0;
+    bool all_done = false;
+    double ms_total = 0.0;
+    int64_t nlaunch = 0;
+    while (launched < max_sweeps && !all_done) {
+        if (opt.timing) HIPCHK(hipEventRecord(ws->ev0, st));
+        for (int i = 0; i < check_every && launched < max_sweeps; i++) {
+            if (pl.path == XINV_PATH_FUSED) {
+                const int k = (max_sweeps - launched >= Kf) ? Kf : 1;
+                const int cur = (int)(bound.size() & 1);
+                rc = launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0);
+                if (rc) return rc;
+                bound.push_back(launched);
+                launched += k;
+            } else {
+                rc = launch_colour_sweep(p, pl, ws, st);
+                if (rc) return rc;
+                launched += 1;
+            }
+            nlaunch++;
+        }
+        if (opt.timing) HIPCHK(hipEventRecord(ws->ev1, st));
+        HIPCHK(hipMemcpyAsync(ws->hctl, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl),
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (opt.timing) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
+            ms_total += ms;
+        }
+        all_done = true;
+        for (int64_t m = 0; m < p.nbatch; m++) all_done = all_done && ws->hctl[m].done;
+    }
+    if (!all_done) { t_err = "internal: sweep budget exhausted before the stop rule fired"; return XINV_ERR_HIP; }
+
+    // ---- fused path: put each member's final state into S ------------------------------------
+    int64_t sweeps_max = 0;
+    if (pl.path == XINV_PATH_FUSED) {
+        bound.push_back(launched);
+        for (int64_t m = 0; m < p.nbatch; m++) {
+            const int64_t sw = ws->hctl[m].sweeps;
+            // launch i covers sweeps (bound[i], bound[i+1]]; find the one holding sweep `sw`
+            size_t i = std::upper_bound(bound.begin(), bound.end(), sw - 1) - bound.begin() - 1;
+            int where;                                   // buffer index holding the final state
+            if (bound[i + 1] == sw) {
+                where = (int)((i + 1) & 1);
+            } else {                                     // stopped inside a K-sweep launch: redo
+                int cur = (int)(i & 1);
+                for (int64_t s = bound[i]; s < sw; s++) {
+                    rc = launch_fused(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1);
+                    if (rc) return rc;
+                    cur ^= 1;
+                }
+                where = cur;
+            }
+            if (where == 1)
+                HIPCHK(hipMemcpyAsync(p.S + m * p.sS, S2 + m * p.sS, (size_t)n * sizeof(double),
+                                      hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    for (int64_t m = 0; m < p.nbatch; m++) {
+        const XinvCtl &c = ws->hctl[m];
+        if (c.overflow) flags[3 * m + 0] = 1.0;
+        if (c.wrote) { flags[3 * m + 1] = c.flag1; flags[3 * m + 2] = c.flag2; }
+        sweeps_max = std::max<int64_t>(sweeps_max, c.sweeps);
+    }
+    t_stats.path = pl.path;
+    t_stats.colours = pl.ncol;
+    t_stats.sweeps_per_launch = Kf;
+    t_stats.rows_per_tile = pl.RY;
+    t_stats.sweep_launches = nlaunch;
+    t_stats.sweeps_max = sweeps_max;
+    t_stats.sweep_ms = ms_total;
+    return XINV_OK;
+}
+
+// ------------------------------------------------------------------ host-pointer staging
+struct Staged {
+    std::vector<void *> dev;
+    ~Staged() { for (void *p : dev) if (p) (void)hipFree(p); }
+};
+
+static int upload(Staged &sg, const double *h, int64_t nbatch, int64_t stride, int64_t n,
+                  double **out, int64_t *dstride)
+{
+    if (!h) { *out = nullptr; *dstride = 0; return XINV_OK; }
+    const int64_t members = (stride == 0) ? 1 : nbatch;
+    double *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, (size_t)members * n * sizeof(double)));
+    sg.dev.push_back(d);
+    if (members == 1 || stride == n) {
+        HIPCHK(hipMemcpy(d, h, (size_t)members * n * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        for (int64_t m = 0; m < members; m++)
+            HIPCHK(hipMemcpy(d + m * n, h + m * stride, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    *out = d;
+    *dstride = (stride == 0) ? 0 : n;
+    return XINV_OK;
+}
+
+static int solve_host(Problem &p, double *flags, const xinv_options *opt)
+{
+    int rc = validate(p, flags);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        t_err = "no HIP device available";
+        return XINV_ERR_NODEV;
+    }
+    if (opt && opt->device >= 0) HIPCHK(hipSetDevice(opt->device));
+    const int64_t n = p.zc * p.yc * p.xc;
+    Staged sg;
+    Problem d = p;
+    double *hS = p.S;
+    const int64_t hsS = p.sS;
+    hipEvent_t e0, e1, e2, e3;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
+    HIPCHK(hipEventRecord(e0, 0));
+    int64_t ds;
+    rc = upload(sg, p.S, p.nbatch, p.nbatch > 1 ? p.sS : n, n, &d.S, &ds);
+    if (rc) return rc;
+    d.sS = n;
+    for (int q = 0; q < p.ncoef; q++) {
+        double *dc;
+        rc = upload(sg, p.c[q], p.nbatch, p.nbatch > 1 ? p.sc[q] : 0, n, &dc, &d.sc[q]);
+        if (rc) return rc;
+        d.c[q] = dc;
+    }
+    HIPCHK(hipEventRecord(e1, 0));
+    rc = solve_dev(d, flags, opt, 0);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e2, 0));
+    if (p.nbatch == 1 || hsS == n) {
+        HIPCHK(hipMemcpy(hS, d.S, (size_t)p.nbatch * n * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        for (int64_t m = 0; m < p.nbatch; m++)
+            HIPCHK(hipMemcpy(hS + m * hsS, d.S + m * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipEventRecord(e3, 0));
+    HIPCHK(hipEventSynchronize(e3));
+    float a = 0.f, b = 0.f;
+    HIPCHK(hipEventElapsedTime(&a, e0, e1));
+    HIPCHK(hipEventElapsedTime(&b, e2, e3));
+    t_stats.h2d_ms = a; t_stats.d2h_ms = b;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
+    return XINV_OK;
+}
+
+// ------------------------------------------------------------------ problem builders
+static void set_scal2d(Problem &p, double delx, double delxSqr, double ratio, double ratioQtr,
+                       double ratioSqr, double optArg, double undef)
+{
+    memset(&p.sc_, 0, sizeof p.sc_);
+    p.sc_.delx = delx; p.sc_.delxSqr = delxSqr; p.sc_.ratio = ratio;
+    p.sc_.ratioQtr = ratioQtr; p.sc_.ratioSqr = ratioSqr; p.sc_.optArg = optArg;
+    p.sc_.undef = undef;
+}
+
+static Problem mk_std2d(double *S, const double *A, const double *B, const double *C,
+                        const double *F, int64_t nbatch, const int64_t *st, int64_t yc,
+                        int64_t xc, double delx, int BCy, int BCx, double delxSqr,
+                        double ratioQtr, double ratioSqr, double optArg, double undef,
+                        int64_t mxLoop, double tol)
+{
+    Problem p;
+    memset(&p, 0, sizeof p);
+    p.kind = KIND_STD2D; p.nbatch = nbatch; p.zc = 1; p.yc = yc; p.xc = xc;
+    p.S = S; p.c[0] = A; p.c[1] = B; p.c[2] = C; p.c[3] = F; p.ncoef = 4;
+    const int64_t n = yc * xc;
+    p.sS = st ? st[0] : n;
+    for (int q = 0; q < 4; q++) p.sc[q] = st ? st[1 + q] : n;
+    p.BCz = 0; p.BCy = BCy; p.BCx = BCx;
+    set_scal2d(p, delx, delxSqr, 0.0, ratioQtr, ratioSqr, optArg, undef);
+    p.stop.mxLoop = mxLoop; p.stop.tolerance = tol; p.stop.stop_on_zero_norm = 1;
+    return p;
+}
+
+static Problem mk_gen2d(double *S, const double *A, const double *B, const double *C,
+                        const double *D, const double *E, const double *F, const double *G,
+                        int64_t nbatch, const int64_t *st, int64_t yc, int64_t xc, double delx,
+                        int BCy, int BCx, double delxSqr, double ratio, double ratioQtr,
+                        double ratioSqr, double optArg, double undef, int64_t mxLoop, double tol)
+{
+    Problem p;
+    memset(&p, 0, sizeof p);
+    p.kind = KIND_GEN2D; p.nbatch = nbatch; p.zc = 1; p.yc = yc; p.xc = xc;
+    p.S = S;
+    p.c[0] = A; p.c[1] = B; p.c[2] = C; p.c[3] = D; p.c[4] = E; p.c[5] = F; p.c[6] = G;
+    p.ncoef = 7;
+    const int64_t n = yc * xc;
+    p.sS = st ? st[0] : n;
+    for (int q = 0; q < 7; q++) p.sc[q] = st ? st[1 + q] : n;
+    p.BCz = 0; p.BCy = BCy; p.BCx = BCx;
+    set_scal2d(p, delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+    p.stop.mxLoop = mxLoop; p.stop.tolerance = tol; p.stop.stop_on_zero_norm = 0;
+    return p;
+}
+
+static Problem mk_std3d(double *S, const double *A, const double *B, const double *C,
+                        const double *F, int64_t nbatch, const int64_t *st, int64_t zc,
+                        int64_t yc, int64_t xc, int BCz, int BCy, int BCx, double delxSqr,
+                        double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                        int64_t mxLoop, double tol)
+{
+    Problem p;
+    memset(&p, 0, sizeof p);
+    p.kind = KIND_STD3D; p.nbatch = nbatch; p.zc = zc; p.yc = yc; p.xc = xc;
+    p.S = S; p.c[0] = A; p.c[1] = B; p.c[2] = C; p.c[3] = F; p.ncoef = 4;
+    const int64_t n = zc * yc * xc;
+    p.sS = st ? st[0] : n;
+    for (int q = 0; q < 4; q++) p.sc[q] = st ? st[1 + q] : n;
+    p.BCz = BCz; p.BCy = BCy; p.BCx = BCx;
+    memset(&p.sc_, 0, sizeof p.sc_);
+    p.sc_.delxSqr = delxSqr; p.sc_.ratio2Sqr = ratio2Sqr; p.sc_.ratio1Sqr = ratio1Sqr;
+    p.sc_.optArg = optArg; p.sc_.undef = undef;
+    p.stop.mxLoop = mxLoop; p.stop.tolerance = tol; p.stop.stop_on_zero_norm = 0;
+    return p;
+}
+
+// ------------------------------------------------------------------ C-ABI
+extern "C" {
+
+void xinv_default_options(xinv_options *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->device = -1;
+    o->path = XINV_PATH_AUTO;
+}
+
+int xinv_last_stats(xinv_stats *out)
+{
+    if (!out) return XINV_ERR_ARG;
+    *out = t_stats;
+    return XINV_OK;
+}
+
+const char *xinv_last_error(void) { return t_err.c_str(); }
+
+int xinv_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int xinv_version(void) { return XINV_VERSION; }
+
+#define GUARD(expr) try { return (expr); } catch (const std::exception &e) { t_err = e.what(); return XINV_ERR_HIP; } catch (...) { t_err = "unknown C++ exception"; return XINV_ERR_HIP; }
+
+int xinv_standard_2d_f64(double *S, const double *A, const double *B, const double *C,
+                         const double *F, int64_t yc, int64_t xc, double dely, double delx,
+                         int BCy, int BCx, double delxSqr, double ratioQtr, double ratioSqr,
+                         double optArg, double undef, double *flags, int64_t mxLoop,
+                         double tolerance)
+{
+    (void)dely;
+    Problem p = mk_std2d(S, A, B, C, F, 1, nullptr, yc, xc, delx, BCy, BCx, delxSqr, ratioQtr,
+                         ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, nullptr))
+}
+
+int xinv_general_2d_f64(double *S, const double *A, const double *B, const double *C,
+                        const double *D, const double *E, const double *F, const double *G,
+                        int64_t yc, int64_t xc, double dely, double delx, int BCy, int BCx,
+                        double delxSqr, double ratio, double ratioQtr, double ratioSqr,
+                        double optArg, double undef, double *flags, int64_t mxLoop,
+                        double tolerance)
+{
+    (void)dely;
+    Problem p = mk_gen2d(S, A, B, C, D, E, F, G, 1, nullptr, yc, xc, delx, BCy, BCx, delxSqr,
+                         ratio, ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, nullptr))
+}
+
+int xinv_standard_3d_f64(double *S, const double *A, const double *B, const double *C,
+                         const double *F, int64_t zc, int64_t yc, int64_t xc, double delz,
+                         double dely, double delx, int BCz, int BCy, int BCx, double delxSqr,
+                         double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                         double *flags, int64_t mxLoop, double tolerance)
+{
+    (void)delz; (void)dely; (void)delx;
+    Problem p = mk_std3d(S, A, B, C, F, 1, nullptr, zc, yc, xc, BCz, BCy, BCx, delxSqr,
+                         ratio2Sqr, ratio1Sqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, nullptr))
+}
+
+int xinv_standard_2d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                 const double *F, int64_t nbatch, const int64_t *strides,
+                                 int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                                 int BCx, double delxSqr, double ratioQtr, double ratioSqr,
+                                 double optArg, double undef, double *flags, int64_t mxLoop,
+                                 double tolerance, const xinv_options *opt)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_std2d(S, A, B, C, F, nbatch, strides, yc, xc, delx, BCy, BCx, delxSqr,
+                         ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, opt))
+}
+
+int xinv_general_2d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                const double *D, const double *E, const double *F,
+                                const double *G, int64_t nbatch, const int64_t *strides,
+                                int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                                int BCx, double delxSqr, double ratio, double ratioQtr,
+                                double ratioSqr, double optArg, double undef, double *flags,
+                                int64_t mxLoop, double tolerance, const xinv_options *opt)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_gen2d(S, A, B, C, D, E, F, G, nbatch, strides, yc, xc, delx, BCy, BCx,
+                         delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, opt))
+}
+
+int xinv_standard_3d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                 const double *F, int64_t nbatch, const int64_t *strides,
+                                 int64_t zc, int64_t yc, int64_t xc, double delz, double dely,
+                                 double delx, int BCz, int BCy, int BCx, double delxSqr,
+                                 double ratio2Sqr, double ratio1Sqr, double optArg,
+                                 double undef, double *flags, int64_t mxLoop, double tolerance,
+                                 const xinv_options *opt)
+{
+    (void)delz; (void)dely; (void)delx;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_std3d(S, A, B, C, F, nbatch, strides, zc, yc, xc, BCz, BCy, BCx, delxSqr,
+                         ratio2Sqr, ratio1Sqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, opt))
+}
+
+int xinv_standard_2d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                             const double *F, int64_t nbatch, const int64_t *strides,
+                             int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                             int BCx, double delxSqr, double ratioQtr, double ratioSqr,
+                             double optArg, double undef, double *flags, int64_t mxLoop,
+                             double tolerance, const xinv_options *opt, void *stream)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_std2d(S, A, B, C, F, nbatch, strides, yc, xc, delx, BCy, BCx, delxSqr,
+                         ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
+}
+
+int xinv_general_2d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                            const double *D, const double *E, const double *F, const double *G,
+                            int64_t nbatch, const int64_t *strides, int64_t yc, int64_t xc,
+                            double dely, double delx, int BCy, int BCx, double delxSqr,
+                            double ratio, double ratioQtr, double ratioSqr, double optArg,
+                            double undef, double *flags, int64_t mxLoop, double tolerance,
+                            const xinv_options *opt, void *stream)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_gen2d(S, A, B, C, D, E, F, G, nbatch, strides, yc, xc, delx, BCy, BCx,
+                         delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
+}
+
+int xinv_standard_3d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                             const double *F, int64_t nbatch, const int64_t *strides,
+                             int64_t zc, int64_t yc, int64_t xc, double delz, double dely,
+                             double delx, int BCz, int BCy, int BCx, double delxSqr,
+                             double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                             double *flags, int64_t mxLoop, double tolerance,
+                             const xinv_options *opt, void *stream)
+{
+    (void)delz; (void)dely; (void)delx;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_std3d(S, A, B, C, F, nbatch, strides, zc, yc, xc, BCz, BCy, BCx, delxSqr,
+                         ratio2Sqr, ratio1Sqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
+}
+
+static int abs_norm_dev(const double *S, int64_t n, double undef, double *out, hipStream_t st)
+{
+    if (!S || !out || n < 1) return fail_arg("bad arguments to xinv_abs_norm_f64_dev");
+    int device;
+    HIPCHK(hipGetDevice(&device));
+    Workspace *ws = get_ws(device);
+    int rc = ensure_dev(&ws->partials, &ws->partials_cap,
+                        (size_t)XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long)) + 64);
+    if (rc) return rc;
+    rc = ensure_dev(&ws->ctl, &ws->ctl_cap, sizeof(XinvCtl));
+    if (rc) return rc;
+    NormArgs a;
+    memset(&a, 0, sizeof a);
+    a.S = S; a.sS = 0; a.n = n; a.undef = undef;
+    a.psum = (double *)ws->partials;
+    a.pcnt = (long long *)((char *)ws->partials + XINV_NORM_BLOCKS * sizeof(double));
+    a.ctl = ws->ctl; a.force = 1;
+    int nblk = (int)std::min<int64_t>(XINV_NORM_BLOCKS, std::max<int64_t>(1, n / 2048));
+    double *dout = (double *)((char *)ws->partials + XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long)));
+    hipLaunchKernelGGL(k_norm_partial, dim3(nblk, 1, 1), dim3(256, 1, 1), 0, st, a);
+    hipLaunchKernelGGL(k_norm_out, dim3(1), dim3(64), 0, st, a.psum, a.pcnt, nblk, dout);
+    HIPCHK(hipMemcpyAsync(out, dout, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return XINV_OK;
+}
+
+int xinv_abs_norm_f64_dev(const double *S, int64_t n, double undef, double *out, void *stream)
+{
+    GUARD(abs_norm_dev(S, n, undef, out, (hipStream_t)stream))
+}
+
+} // extern "C"

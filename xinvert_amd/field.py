@@ -1,0 +1,76 @@
+"""Minimal labelled array used where the reference uses xarray.DataArray.
+
+The reference front end (xinvert/apps.py) takes xarray.DataArray forcings.  xarray is not
+installed in the build/test image, so the host layer works on this small container and
+converts real xarray objects at the boundary when xarray is importable (`from_any`/`to_like`).
+Only what the hot path's callers need is implemented: values, ordered dims, 1-D coordinate
+vectors per dim.
+"""
+import numpy as np
+
+
+class Field:
+    """values + ordered dim names + one 1-D coordinate vector per dim."""
+
+    def __init__(self, values, dims, coords=None, name=None):
+        self.values = np.asarray(values)
+        self.dims = tuple(dims)
+        if self.values.ndim != len(self.dims):
+            raise ValueError('values.ndim %d != len(dims) %d' % (self.values.ndim, len(self.dims)))
+        coords = {} if coords is None else dict(coords)
+        self.coords = {}
+        for ax, d in enumerate(self.dims):
+            c = coords.get(d)
+            c = np.arange(self.values.shape[ax], dtype=np.float64) if c is None else np.asarray(c)
+            if c.ndim != 1 or c.shape[0] != self.values.shape[ax]:
+                raise ValueError('coordinate %r does not match axis length' % d)
+            self.coords[d] = c
+        self.name = name
+
+    @property
+    def shape(self):
+        return self.values.shape
+
+    def axis(self, dim):
+        return self.dims.index(dim)
+
+    def like(self, values, name=None):
+        return Field(values, self.dims, self.coords, name=name if name is not None else self.name)
+
+    def __getitem__(self, dim):
+        """F['lat'] -> coordinate vector, as xarray does."""
+        return self.coords[dim]
+
+    def __repr__(self):
+        return 'Field(name=%r, dims=%r, shape=%r)' % (self.name, self.dims, self.shape)
+
+
+def along(vec, field, dim):
+    """Broadcast a 1-D per-`dim` vector against `field` (xarray's alignment by dim name)."""
+    shape = [1] * len(field.dims)
+    shape[field.axis(dim)] = -1
+    return np.asarray(vec).reshape(shape)
+
+
+def from_any(obj, dims=None):
+    """Field from a Field, an xarray.DataArray (if xarray is importable) or (ndarray, dims)."""
+    if isinstance(obj, Field):
+        return obj
+    if hasattr(obj, 'dims') and hasattr(obj, 'coords') and hasattr(obj, 'values'):
+        coords = {d: np.asarray(obj.coords[d].values) for d in obj.dims if d in obj.coords}
+        return Field(np.asarray(obj.values), obj.dims, coords, name=getattr(obj, 'name', None))
+    if dims is None:
+        raise TypeError('need a Field, an xarray.DataArray or an ndarray with dims')
+    return Field(np.asarray(obj), dims)
+
+
+def to_like(field, template):
+    """Return `field` in the caller's container type (xarray in -> xarray out)."""
+    if isinstance(template, Field) or not hasattr(template, 'coords'):
+        return field
+    try:
+        import xarray as xr
+    except ImportError:                      # pragma: no cover - xarray absent in this image
+        return field
+    return xr.DataArray(field.values, dims=field.dims,
+                        coords={d: field.coords[d] for d in field.dims}, name=field.name)
