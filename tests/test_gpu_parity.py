@@ -1,8 +1,10 @@
 """GPU parity: the HIP path (through the C-ABI) against the coloured-ordering oracle.
 
-Bar: S bit-exact (same ordering, same arithmetic, no FMA contraction on either side); the
-norm-derived flags[1] to 1e-10 relative (the device adds the mean|S| partials in a different,
-but fixed, order); flags[2] (loop index) equal.
+Bar: S bit-exact (same ordering, same arithmetic, no FMA contraction on either side);
+flags[2] (loop index) equal; flags[1] = |norm - normPrev| / normPrev to 1e-12 ABSOLUTE: the
+device adds the mean|S| partials in a different (fixed) order than the serial oracle, which
+perturbs each norm by a few ulp (~1e-16 relative) and therefore their relative DIFFERENCE by
+~1e-15 absolute, whatever its size.
 """
 import zlib
 
@@ -27,7 +29,7 @@ def assert_same(S, fl, So, flo, what=''):
         what, np.nanmax(np.abs(S - So)), int((S != So).sum()))
     assert fl[2] == flo[2], '%s: loop index %r vs oracle %r' % (what, fl[2], flo[2])
     assert fl[0] == flo[0]
-    assert np.isclose(fl[1], flo[1], rtol=1e-10, atol=0), (what, fl, flo)
+    assert abs(fl[1] - flo[1]) <= 1e-12 + 1e-9 * abs(flo[1]), (what, fl, flo)
 
 
 BCS = [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'fixed'), ('extend', 'periodic'),
@@ -95,7 +97,7 @@ def test_fused_equals_colour_path():
     S1, f1, _ = run_hip_batched([p], 30, 0.0, path=PATH_FUSED)
     S2, f2, _ = run_hip_batched([p], 30, 0.0, path=PATH_COLOUR)
     assert np.array_equal(S1, S2)
-    assert np.allclose(f1, f2, rtol=1e-10)
+    assert np.allclose(f1, f2, rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
@@ -107,8 +109,8 @@ def test_batched_shared_coefficients_and_per_member_stop(kind):
     for m in range(5):
         q = dict(base)
         q['coefs'] = list(base['coefs'])
-        q['coefs'][-1] = base['coefs'][-1] * (1.0 + m) + rng.standard_normal(base['S0'].shape) * 0.01 * m
-        q['S0'] = base['S0'] * (m + 1)
+        q['coefs'][-1] = rng.standard_normal(base['S0'].shape) * (0.2 + m)
+        q['S0'] = rng.standard_normal(base['S0'].shape) * 10.0 ** (m - 2)
         ps.append(q)
     shared = tuple(range(len(base['coefs']) - 1))
     S, fl, st = run_hip_batched(ps, 400, 5e-4, shared=shared, sweeps_per_launch=2)

@@ -60,6 +60,14 @@ def load():
     if not os.path.exists(SO):
         raise XinvError('HIP extension %s is missing: run `python -m xinvert_amd.build` '
                         '(there is no CPU fallback)' % SO)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64.
+    # If this library pulled in /opt/rocm's copy first, a later `import torch` would bring a
+    # second runtime that finds no GPU.  Importing torch first (when present) makes the
+    # dynamic linker resolve our dependency to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         L = ctypes.CDLL(SO)
     except OSError as e:
