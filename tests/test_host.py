@@ -1,0 +1,177 @@
+"""Host logic (no GPU): the front-end restatement, the boundary wrappers' marshalling and
+error behaviour, and the C-ABI library's exports.  No compute call is made here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from xinvert_amd import _lib, apps, core
+from xinvert_amd.field import Field
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C-ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'xinv.h')).read()
+    declared = set(re.findall(r'\b(xinv_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.load()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.xinv_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    L = _lib.load()
+    if L.xinv_device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(_lib.XinvError):
+        _lib.require_gpu()
+    F = Field(np.zeros((5, 8)), ('lat', 'lon'), {'lat': np.linspace(-10, 10, 5), 'lon': np.linspace(0, 70, 8)})
+    with pytest.raises(_lib.XinvError):
+        apps.invert_Poisson(F, ['lat', 'lon'], iParams={'printInfo': False})
+    # the host-pointer entry points report the missing device instead of computing anything
+    S = np.zeros((5, 8)); fl = np.array([0., 1., 0.])
+    rc = L.xinv_standard_2d_f64(_lib.hptr(S), _lib.hptr(S), None, _lib.hptr(S), _lib.hptr(S),
+                                5, 8, 1., 1., 0, 0, 1., .25, 1., 1., -9.99e8, _lib.hptr(fl), 3, 1e-8)
+    assert rc == -3 and b'no HIP device' in L.xinv_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, 'xinvert_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(root, f)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt, f
+                assert 'xinv_oracle' not in txt, f
+
+
+# ------------------------------------------------------------------ parameters (a8)
+OMEGA_2D = {(73, 144): 1.934805014448645, (180, 360): 1.972913967488753,
+            (1800, 3600): 1.997245570836297, (2000, 2000): 1.996864900786959,
+            (720, 1440): 1.993133264690061, (151, 201): 1.964078724984458}
+
+
+def test_optimal_omega_goldens():
+    for (gy, gx), w in OMEGA_2D.items():
+        p = apps._cal_params2D(np.linspace(0, 1, gy), np.linspace(0, 1, gx), 'cartesian')
+        assert abs(p['optArg'] - w) < 2e-15
+        assert 1.0 <= p['optArg'] <= 2.0                 # reference tests/test_OptArg.py:24
+    p = apps._cal_params3D(np.linspace(0, 1, 50), np.linspace(0, 1, 360), np.linspace(0, 1, 720), 'cartesian')
+    assert abs(p['optArg'] - 1.916326873236605) < 2e-15  # uses 2*gc3+3 (apps.py:2208)
+
+
+def test_cal_params2d_metrics():
+    lat = np.linspace(-90, 90, 73); lon = np.linspace(0, 357.5, 144)
+    p = apps._cal_params2D(lat, lon, 'lat-lon')
+    R = 6371200.0
+    assert p['del2'] == np.deg2rad(2.5) * R and p['del1'] == np.deg2rad(2.5) * R
+    assert p['ratio'] == 1.0 and p['ratioQtr'] == 0.25 and p['del1Sqr'] == p['del1'] ** 2.0
+    assert list(p['flags']) == [0.0, 1.0, 0.0]
+    q = apps._cal_params2D(np.linspace(0, 10, 11), lat, 'z-lat')
+    assert q['del2'] == 1.0 and q['del1'] == np.deg2rad(2.5) * R
+    with pytest.raises(Exception, match='unsupported coords'):
+        apps._cal_params2D(lat, lon, 'polar')
+    with pytest.raises(Exception, match='non-uniform'):
+        apps._cal_params2D(np.array([0., 1., 3.]), lon, 'cartesian')
+
+
+def test_update_semantics():
+    d = apps._update(apps.default_iParams, {'optArg': None, 'mxLoop': 7})
+    assert d['optArg'] is None and d['mxLoop'] == 7 and d['tolerance'] == 1e-8
+    with pytest.raises(Exception, match='is not used'):
+        apps._update(apps.default_mParams, {'bogus': 1}, ['g'])
+    ps = {'optArg': 1.7, 'mxLoop': 1}
+    assert apps._update(ps, d)['optArg'] == 1.7          # user None does not override computed
+    assert apps._update(ps, d)['mxLoop'] == 7
+
+
+def test_mask_fs_nan_and_value_undef():
+    v = np.array([[1.0, np.nan, 3.0], [4.0, 5.0, -9999.0], [7.0, 8.0, 9.0]])
+    F = Field(v, ('y', 'x'))
+    m, s, z = apps._mask_FS(F, ['y', 'x'], {'undef': np.nan, 'BCs': ['fixed', 'fixed']}, None)
+    assert m.values[0, 1] == -9.99e8 and m.values[1, 2] == -9999.0 and (s.values == 0).all()
+    m, s, z = apps._mask_FS(F, ['y', 'x'], {'undef': -9999.0, 'BCs': ['fixed', 'fixed']}, None)
+    assert m.values[1, 2] == -9.99e8 and np.isnan(m.values[0, 1])
+    # icbc: kept on masked points and on the first/last index of non-periodic dims (apps.py:2144-2156)
+    ic = Field(np.full((3, 3), 2.5), ('y', 'x'))
+    m, s, z = apps._mask_FS(F, ['y', 'x'], {'undef': np.nan, 'BCs': ['fixed', 'periodic']}, ic)
+    assert (s.values[0] == 2.5).all() and (s.values[2] == 2.5).all()
+    assert s.values[1, 0] == 0 and s.values[1, 1] == 0
+
+
+def test_poisson_coefficients_latlon():
+    lat = np.linspace(-80, 80, 9); lon = np.linspace(0, 315, 8)
+    z = np.ones((2, 9, 8)); z[1, 4, 3] = np.nan
+    F = Field(z, ('time', 'lat', 'lon'), {'lat': lat, 'lon': lon})
+    Fm, S, (A, B, C) = apps._coeffs_Poisson(F, ['lat', 'lon'], 'lat-lon', apps.default_mParams,
+                                            apps.default_iParams, None)
+    assert A.shape == (9, 8) and np.isnan(A[0]).all()            # shifted half grid: row 0 never read
+    assert np.allclose(A[1], np.cos(np.deg2rad((lat[1] + lat[0]) / 2)))
+    assert (B == 0).all() and np.allclose(C[:, 0], 1 / np.cos(np.deg2rad(lat)))
+    assert Fm.values[1, 4, 3] == -9.99e8 and Fm.values[0, 4, 3] == np.cos(np.deg2rad(lat[4]))
+
+
+def test_dims_length_errors():
+    F = Field(np.zeros((4, 5)), ('y', 'x'))
+    with pytest.raises(Exception, match='2 dimensions are needed for inversion'):
+        core.inv_standard2D(0, 0, 0, F, F, ['y'], {})
+    with pytest.raises(Exception, match='2 dimensions are needed for inversion'):
+        core.inv_general2D(0, 0, 0, 0, 0, 0, F, F, ['y', 'x', 'z'], {})
+    with pytest.raises(Exception, match='3 dimensions are needed for inversion'):
+        core.inv_standard3D(0, 0, 0, F, F, ['y', 'x'], {})
+    with pytest.raises(Exception, match='dimensional forcing are needed'):
+        apps.invert_Poisson(F, ['y'])
+    with pytest.raises(Exception, match='is not used'):
+        apps.invert_Poisson(F, ['y', 'x'], mParams={'Phi': 1.0})
+
+
+def test_omega_validates_stratification():
+    F = Field(np.zeros((3, 4, 5)), ('lev', 'lat', 'lon'))
+    with pytest.raises(Exception, match='unstable stratification'):
+        apps.invert_omega(F, ['lev', 'lat', 'lon'], mParams={'N2': np.array([1e-4, -1e-4, 1e-4])})
+    with pytest.raises(Exception, match='inifinite stratification'):
+        apps.invert_omega(F, ['lev', 'lat', 'lon'], mParams={'N2': np.array([1e-4, np.inf, 1e-4])})
+
+
+# ------------------------------------------------------------------ batching / marshalling
+def test_batch_layout_and_shared_coefficients():
+    F = Field(np.zeros((3, 4, 2, 5)), ('time', 'lat', 'mem', 'lon'))
+    perm, bdims, bshape = core._batch_layout(F, ['lat', 'lon'])
+    assert perm == [0, 2, 1, 3] and bdims == ['time', 'mem'] and bshape == [3, 2]
+    core2 = np.arange(20.0).reshape(4, 5)
+    a, st = core._prep_coef(core2, F, perm, (4, 5), 6)
+    assert st == 0 and a.shape == (4, 5)
+    full = np.broadcast_to(core2[None, :, None, :], F.shape)      # zero batch strides -> shared
+    a, st = core._prep_coef(full, F, perm, (4, 5), 6)
+    assert st == 0 and np.array_equal(a, core2)
+    per = np.arange(120.0).reshape(3, 4, 2, 5)
+    a, st = core._prep_coef(per, F, perm, (4, 5), 6)
+    assert st == 20 and a.shape == (6, 4, 5) and np.array_equal(a[1], per[0, :, 1, :])
+    with pytest.raises(Exception, match='matches neither'):
+        core._prep_coef(np.zeros((7, 7)), F, perm, (4, 5), 6)
+
+
+def test_info_line_format():
+    assert core._info({'time': np.float64(3.0)}) == '{time: 3.0}'
+    assert core._info({}) == '{}'
+    line = core._info({'lev': 500}) + ' loops {0:4.0f} and tolerance is {1:e}'.format(87.0, 4.905623e-06)
+    assert line == '{lev: 500} loops   87 and tolerance is 4.905623e-06'
+
+
+def test_cal_flow_gill_matsuno_matches_reference_formula():
+    lat = np.linspace(-90, 90, 19); lon = np.linspace(0, 360, 24)
+    rng = np.random.default_rng(0)
+    S = Field(rng.standard_normal((19, 24)), ('lat', 'lon'), {'lat': lat, 'lon': lon})
+    u, v = apps.cal_flow(S, ['lat', 'lon'], mParams={'epsilon': 1e-5, 'Phi': 5000})
+    f = 2 * 7.292e-5 * np.sin(np.deg2rad(lat)); eps = 1e-5
+    c1 = (eps / (eps**2 + f**2))[:, None]; c2 = (f / (eps**2 + f**2))[:, None]
+    d = np.deg2rad(1.0) * 6371200.0
+    Sx = np.gradient(S.values, lon, axis=1); Sy = np.gradient(S.values, lat, axis=0)
+    cosL = np.cos(np.deg2rad(lat))[:, None]
+    assert np.array_equal(u.values, -c1 * Sx / d / cosL - c2 * Sy / d)
+    assert np.array_equal(v.values, -c1 * Sy / d + c2 * Sx / d / cosL)
+    with pytest.raises(Exception, match='unsupported vtype'):
+        apps.cal_flow(S, ['lat', 'lon'], vtype='streamfunction')

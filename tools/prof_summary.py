@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) runs into small text/JSON files.
+
+  python tools/prof_summary.py kernels  <results.db> [out.txt]     per-kernel calls / avg / min / max us
+  python tools/prof_summary.py counters <results.db> [out.txt]     per-kernel mean of each PMC counter
+  python tools/prof_summary.py traffic  <fetch.db> <write.db> <kernel-substring> <key> [traffic.json]
+        HBM-side bytes per launch of one kernel = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes).
+        The factor 2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM section):
+        this rocprofv3 tallies 128-B read requests at 64 B.  It is re-checked in every profile by
+        k_any_nonzero, which streams exactly one coefficient array (known byte count).
+"""
+import json
+import os
+import sqlite3
+import sys
+
+
+def kernels(db):
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, count(*), avg(duration), min(duration), max(duration), sum(duration), "
+                     "max(vgpr_count), max(sgpr_count), max(grid_x), max(workgroup_x) "
+                     "from kernels group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[5] for r in rows) or 1
+    out = ['%-64s %7s %10s %10s %10s %7s %5s %5s %9s' % ('kernel', 'calls', 'avg_us', 'min_us', 'max_us', 'pct', 'vgpr', 'sgpr', 'grid_x')]
+    for r in rows:
+        out.append('%-64s %7d %10.2f %10.2f %10.2f %6.2f%% %5d %5d %9d' % (
+            r[0][:64], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, 100.0 * r[5] / tot, r[6], r[7], r[8]))
+    return '\n'.join(out)
+
+
+def counters(db):
+    c = sqlite3.connect(db)
+    rows = c.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
+                     "from counters_collection group by kernel_name, counter_name order by kernel_name").fetchall()
+    out = ['%-64s %-18s %7s %16s %16s %16s' % ('kernel', 'counter', 'n', 'mean', 'min', 'max')]
+    for r in rows:
+        out.append('%-64s %-18s %7d %16.3f %16.3f %16.3f' % (r[0][:64], r[1], r[2], r[3], r[4], r[5]))
+    return '\n'.join(out)
+
+
+def mean_counter(db, name, kernel_sub):
+    c = sqlite3.connect(db)
+    r = c.execute("select avg(value), count(*) from counters_collection where counter_name=? and kernel_name like ?",
+                  (name, '%' + kernel_sub + '%')).fetchone()
+    return r[0], r[1]
+
+
+def main():
+    cmd = sys.argv[1]
+    if cmd in ('kernels', 'counters'):
+        txt = kernels(sys.argv[2]) if cmd == 'kernels' else counters(sys.argv[2])
+        if len(sys.argv) > 3:
+            open(sys.argv[3], 'w').write(txt + '\n')
+        print(txt)
+    elif cmd == 'traffic':
+        fdb, wdb, ksub, key = sys.argv[2:6]
+        f, nf = mean_counter(fdb, 'FETCH_SIZE', ksub)
+        w, nw = mean_counter(wdb, 'WRITE_SIZE', ksub)
+        cal, _ = mean_counter(fdb, 'FETCH_SIZE', 'k_any_nonzero')
+        traffic = (2.0 * f + w) * 1024.0
+        print('%s: FETCH_SIZE %.1f KiB (n=%d) x2, WRITE_SIZE %.1f KiB (n=%d) -> %.4e B per launch'
+              % (ksub, f, nf, w, nw, traffic))
+        if cal:
+            print('calibration: k_any_nonzero FETCH_SIZE %.1f KiB (streams one coefficient array)' % cal)
+        if len(sys.argv) > 6:
+            path = sys.argv[6]
+            d = json.load(open(path)) if os.path.exists(path) else {}
+            d[key] = traffic
+            d[key + '_detail'] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'fetch_correction': 2.0,
+                                  'calibration_any_nonzero_FETCH_KiB': cal}
+            json.dump(d, open(path, 'w'), indent=1, sort_keys=True)
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == '__main__':
+    main()

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_colour_std3d(ColourArgs3D a)
 // ---------------------------------------------------------------- 'extend' pre-pass
 // numbas.py:284-310 (2-D) / 87-115 (3-D, planes 1..zc-2).  One thread per column; reads rows
 // 1 and yc-2, writes rows 0 and yc-1.  `tall` (2-D, yc > xc) reproduces what the reference's
-// second loop does inside the array bounds (see oracle/xinv_oracle.c header).
+// second loop does inside the array bounds ("extend pre-pass").
 struct ExtendArgs {
     double *S;
     int64_t sS, yc, xc;
