@@ -1,0 +1,220 @@
+"""GPU: the reference-shaped front end (invert_* -> core.inv_* -> C-ABI -> HIP) on the
+reference's own test cases and the committed golden fixtures, plus size-independent properties
+at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+
+import util
+from util import golden, U
+
+pytestmark = pytest.mark.gpu
+
+LEX, AUTO, C2 = 0, 1, 2
+
+
+def _gm_fields():
+    d = golden('gill_matsuno.npz')
+    return d, d['lat'], d['lon']
+
+
+def test_invert_gill_matsuno_known_answers(capsys):
+    """reference tests/test_GillMatsuno.py:14-57 through xinvert_amd.invert_GillMatsuno:
+    same asserts as the reference test (KE sums with np.isclose), batched over the 3 forcings."""
+    import xinvert_amd as xa
+    d, lat, lon = _gm_fields()
+    Q = xa.Field(np.stack([d['Q1'], d['Q2'], d['Q3']]), ('case', 'lat', 'lon'),
+                 {'case': np.arange(3), 'lat': lat, 'lon': lon})
+    iParams = {'BCs': ['fixed', 'periodic'], 'mxLoop': 2000, 'tolerance': 1e-8, 'optArg': 1.4}
+    mParams = {'epsilon': 1e-5, 'Phi': 5000}
+    h = xa.invert_GillMatsuno(Q, dims=['lat', 'lon'], iParams=iParams, mParams=mParams)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 3 and out[0].startswith('{case: 0} loops ') and 'tolerance is' in out[0]
+    u, v = xa.cal_flow(h, dims=['lat', 'lon'], BCs=['fixed', 'periodic'], mParams=mParams, vtype='GillMatsuno')
+    ke = ((u.values**2 + v.values**2) / 2).sum(axis=(1, 2))
+    assert (h.values[0] <= 0).all() and (np.abs(h.values[1]) <= 370).all() and (h.values[2] <= 0).all()
+    assert np.isclose(ke[0], 4351.62244687) and np.isclose(ke[1], 5833.33192343) and np.isclose(ke[2], 5100.85325027)
+    fl = h.iParams['flags']
+    assert fl.shape == (3, 3) and (fl[:, 0] == 0).all() and (fl[:, 1] < 1e-8).all()
+    assert h.iParams['stats']['path'] == 2
+
+
+def test_gill_matsuno_converged_vs_reference_fields():
+    """Converged HIP field vs the converged lexicographic (reference-ordering) oracle: <= 1e-6."""
+    from test_oracle_golden import _gm_problem
+    d, lat, lon = _gm_fields()
+    for name in ('Q1', 'Q2', 'Q3'):
+        p, _ = _gm_problem(d[name], lat, lon, 4000, 1e-13)
+        Sl, _ = util.run_oracle(p, 4000, 1e-13, LEX)
+        Sh, fl, _ = util.run_hip_batched([p], 4000, 1e-13)
+        assert util.rel_l2(Sh[0], Sl) < 1e-6
+
+
+def test_invert_stommel_reference_case():
+    """reference tests/test_StommelWBC.py:14-55 (S1, S2): converged streamfunction within 1e-6
+    of the stored reference field (S2) and of the survey-time scalar pins (S1)."""
+    import xinvert_amd as xa
+    d = golden('stommel.npz')
+    curl = xa.Field(d['curl'], ('ydef', 'xdef'), {'ydef': d['ydef'], 'xdef': d['xdef']})
+    iParams = {'BCs': ['fixed', 'fixed'], 'mxLoop': 5000, 'optArg': 1.9, 'tolerance': 1e-12,
+               'printInfo': False}
+    S2 = xa.invert_Stommel(curl, dims=['ydef', 'xdef'], coords='cartesian', iParams=iParams,
+                           mParams={'beta': 1.8e-11, 'R': 0.0008, 'D': 200})
+    assert util.rel_l2(S2.values, d['S2']) < 1e-6
+    S1 = xa.invert_Stommel(curl, dims=['ydef', 'xdef'], coords='cartesian', iParams=iParams,
+                           mParams={'beta': 0, 'R': 0.0008, 'D': 200})
+    assert abs(S1.values.max() / 6.1120365308e+05 - 1) < 1e-6
+    assert abs(np.abs(S1.values).mean() / 2.7816492185e+05 - 1) < 1e-6
+
+
+def test_invert_ishida_mask_periodic_odd_width():
+    """reference tests/test_Ishida.py:13-63 (h1, h2): value-undef mask, periodic x, xc = 251."""
+    import xinvert_amd as xa
+    xnum, ynum = 251, 151
+    Lx, Ly = 1e7, 2 * np.pi * 1e6
+    x = np.linspace(0, Lx, xnum); y = np.linspace(0, Ly, ynum)
+    curl = -np.pi * np.sin(2. * np.pi * (y[:, None] + 0 * x[None, :]) / Ly) / Ly
+    curl[65:, 100:104] = -9999
+    curl[:75, 130:134] = -9999
+    F = xa.Field(curl, ('ydef', 'xdef'), {'ydef': y, 'xdef': x})
+    iParams = {'BCs': ['fixed', 'periodic'], 'mxLoop': 3000, 'tolerance': 1e-9, 'optArg': 1.4,
+               'undef': -9999, 'printInfo': False}
+    h1 = xa.invert_Stommel(F, dims=['ydef', 'xdef'], coords='cartesian', iParams=iParams,
+                           mParams={'beta': 2.2e-11, 'R': 0.0009, 'D': 200})
+    h2 = xa.invert_Stommel(F, dims=['ydef', 'xdef'], coords='cartesian', iParams=iParams,
+                           mParams={'beta': 2.2e-11, 'R': 0.0009 * 20, 'D': 200})
+    land = curl == -9999
+    assert (h1.values[land] == -9999).all()                     # de-masked with iParams['undef']
+    assert (np.abs(h1.values[~land]) <= 5.5e5).all() and (np.abs(h2.values[~land]) <= 2.8e4).all()
+    assert h1.iParams['stats']['colours'] == 4                   # red-black + the odd-width seam
+
+
+def test_invert_poisson_real_data_both_times():
+    """Data/Helmholtz_atmos.nc vorticity (2 x 73 x 144 f32), reference tests/test_Poisson.py:14-24
+    parameters; converged HIP vs converged reference-ordering oracle after removing the mean
+    (pure-Neumann/periodic problem: SURVEY N10)."""
+    import xinvert_amd as xa
+    from xinvert_amd import apps
+    d = golden('poisson_atmos.npz')
+    lat, lon = d['lat'].astype(np.float64), d['lon'].astype(np.float64)
+    vor = xa.Field(d['vor_f32'], ('time', 'lat', 'lon'), {'time': np.arange(2), 'lat': lat, 'lon': lon})
+    sf = xa.invert_Poisson(vor, dims=['lat', 'lon'],
+                           iParams={'BCs': ['fixed', 'periodic'], 'mxLoop': 5000, 'tolerance': 1e-13,
+                                    'printInfo': False})
+    assert sf.values.shape == (2, 73, 144)
+    iP = apps._update(apps.default_iParams, {'BCs': ['fixed', 'periodic']})
+    Fv = xa.Field(d['vor_f32'].astype(np.float64), ('time', 'lat', 'lon'), {'lat': lat, 'lon': lon})
+    F, initS, (A, B, C) = apps._coeffs_Poisson(Fv, ['lat', 'lon'], 'lat-lon', apps.default_mParams, iP, None)
+    ps = apps._cal_params2D(lat, lon, 'lat-lon')
+    for t in range(2):
+        p = dict(kind='std2d', yc=73, xc=144, BCy='fixed', BCx='periodic', dely=ps['del2'], delx=ps['del1'],
+                 delxSqr=ps['del1Sqr'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'],
+                 optArg=ps['optArg'], undef=U, S0=np.zeros((73, 144)),
+                 coefs=[A, B, C, np.ascontiguousarray(F.values[t])])
+        Sl, _ = util.run_oracle(p, 5000, 1e-13, LEX)
+        assert util.rel_l2(sf.values[t], Sl) < 1e-6
+
+
+def test_invert_omega_3d_small():
+    import xinvert_amd as xa
+    from xinvert_amd import synthetic
+    p = synthetic.omega_latlon(8, 24, 36, 2)
+    S, fl, st = util.run_hip_batched([synthetic.member(p, m) for m in range(2)], 3000, 1e-14, shared=p['shared'])
+    for m in range(2):
+        Sl, _ = util.run_oracle(synthetic.member(p, m), 3000, 1e-14, LEX)
+        assert util.rel_l2(S[m], Sl) < 1e-6
+
+
+def test_non_trailing_core_dims_and_inplace():
+    """Core dims anywhere in F (the reference's .loc[sel].values views): result lands in place."""
+    import xinvert_amd as xa
+    from xinvert_amd import core, apps
+    rng = np.random.default_rng(0)
+    y = np.linspace(0, 1e6, 20); x = np.linspace(0, 2e6, 34)
+    G = rng.standard_normal((20, 3, 34)) * 1e-10
+    F = xa.Field(G, ('y', 'mem', 'x'), {'y': y, 'x': x})
+    S = xa.Field(np.zeros_like(G), ('y', 'mem', 'x'), {'y': y, 'x': x})
+    ps = apps._cal_params2D(y, x, 'cartesian')
+    iP = apps._update(apps._update(apps.default_iParams, {'BCs': ['fixed', 'fixed'], 'mxLoop': 30,
+                                                         'tolerance': 0.0, 'printInfo': False}), {})
+    iP = apps._update(ps, iP)
+    one = np.ones((20, 34)); zero = np.zeros((20, 34))
+    buf = S.values
+    out = core.inv_general2D(one, zero, one, zero, zero, zero, F, S, ['y', 'x'], iP)
+    assert out is S and S.values is buf and np.abs(buf).max() > 0
+    for m in range(3):
+        p = dict(kind='gen2d', yc=20, xc=34, BCy='fixed', BCx='fixed', dely=ps['del2'], delx=ps['del1'],
+                 delxSqr=ps['del1Sqr'], ratio=ps['ratio'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'],
+                 optArg=ps['optArg'], undef=U, S0=np.zeros((20, 34)),
+                 coefs=[one, zero, one, zero, zero, zero, np.ascontiguousarray(G[:, m, :])])
+        So, flo = util.run_oracle(p, 30, 0.0, C2)
+        assert np.array_equal(buf[:, m, :], So)
+
+
+# ------------------------------------------------------------------ full-size properties
+def _full_c2():
+    from xinvert_amd import synthetic
+    return synthetic.poisson_latlon(1800, 3600, mask=True)
+
+
+def test_full_size_c2_properties():
+    """BASELINE configs[1] (3600 x 1800, land mask).  The oracle cannot finish this size in test
+    time, so check size-independent properties: (i) K=2 fused launches == K=1 launches == colour
+    path, bit for bit; (ii) land points never change; (iii) the device norm equals a host
+    recomputation; (iv) restart: 10 + 10 sweeps == 20 sweeps."""
+    from xinvert_amd import synthetic
+    p = _full_c2()
+    q = synthetic.member(p, 0)
+    S1, f1, s1 = util.run_hip_dev([q], 19, 0.0, sweeps_per_launch=1)
+    S2, f2, s2 = util.run_hip_dev([q], 19, 0.0, sweeps_per_launch=2)
+    S3, f3, s3 = util.run_hip_dev([q], 19, 0.0, path=1)
+    assert s1['path'] == 2 and s2['sweeps_per_launch'] == 2 and s3['path'] == 1
+    assert np.array_equal(S1, S2) and np.array_equal(S1, S3)
+    assert np.allclose(f1, f2, rtol=1e-9, atol=1e-12) and np.allclose(f1, f3, rtol=1e-9, atol=1e-12)
+    land = q['coefs'][3] == U
+    assert land.mean() > 0.2 and (S1[0][land] == 0).all()
+    assert np.abs(S1[0][~land]).max() > 0
+    Sa, _, _ = util.run_hip_dev([q], 9, 0.0)
+    r = dict(q); r['S0'] = Sa[0]
+    Sb, _, _ = util.run_hip_dev([r], 9, 0.0)
+    assert np.array_equal(Sb, S1)
+
+
+def test_full_size_c2_sample_rows_against_oracle():
+    """A 64-row band of the full problem with frozen ('fixed') band edges is itself a valid SOR
+    problem: the HIP result on the band must equal the oracle's, bit for bit."""
+    from xinvert_amd import synthetic
+    p = _full_c2()
+    q = synthetic.member(p, 0)
+    j0, j1 = 700, 764
+    band = dict(q)
+    band['yc'] = j1 - j0
+    band['S0'] = np.ascontiguousarray(q['S0'][j0:j1])
+    band['coefs'] = [np.ascontiguousarray(c[j0:j1]) for c in q['coefs']]
+    So, flo = util.run_oracle(band, 11, 0.0, C2)
+    Sh, fl, _ = util.run_hip_batched([band], 11, 0.0, sweeps_per_launch=2)
+    assert np.array_equal(Sh[0], So) and fl[0][2] == flo[2]
+
+
+def test_full_size_c3_stommel_bitwise_paths():
+    from xinvert_amd import synthetic
+    p = synthetic.stommel_cartesian(2000, 2000)
+    q = synthetic.member(p, 0)
+    S1, f1, _ = util.run_hip_dev([q], 9, 0.0, sweeps_per_launch=2)
+    S2, f2, _ = util.run_hip_dev([q], 9, 0.0, path=1)
+    assert np.array_equal(S1, S2)
+    assert (S1[0][0] == 0).all() and (S1[0][:, 0] == 0).all() and (S1[0][-1] == 0).all()
+
+
+def test_abs_norm_dev():
+    import ctypes
+    import torch
+    import oracle as orc
+    from xinvert_amd import _lib
+    L = _lib.require_gpu()
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((300, 401)); a[rng.random(a.shape) < 0.2] = U
+    t = torch.from_numpy(a).cuda()
+    out = ctypes.c_double(0)
+    rc = L.xinv_abs_norm_f64_dev(ctypes.c_void_p(t.data_ptr()), a.size, U, ctypes.byref(out), None)
+    _lib.check(rc)
+    assert abs(out.value / orc.abs_norm(a, U) - 1) < 1e-13
