@@ -1,0 +1,67 @@
+"""Build container only: the C oracle against the reference's own numbas.py run live.
+
+/root/reference does not exist on the GPU box; there this module is skipped and the committed
+fixtures (test_oracle_golden.py) carry the same check.  Fresh random inputs on every cell of
+kernel x BCy x BCx x mask x (B == 0 | B != 0), bit-exact S and flags."""
+import numpy as np
+import pytest
+
+from oracle import ref_import
+from util import U
+
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason='reference tree not present')
+
+
+def test_lexicographic_oracle_equals_reference_live(oracle):
+    ref = ref_import.load_reference_numbas()
+    rng = np.random.default_rng(424242)
+    mk = lambda sh: rng.uniform(0.5, 1.5, sh)
+    n = 0
+    for (yc, xc) in [(11, 14), (9, 9), (8, 21)]:
+        for BCy in ('fixed', 'extend'):
+            for BCx in ('fixed', 'periodic', 'extend'):
+                for bnz in (0, 1):
+                    for msk in (0, 1):
+                        sh = (yc, xc)
+                        A, C = mk(sh), mk(sh)
+                        B = rng.uniform(-.2, .2, sh) if bnz else np.zeros(sh)
+                        F = rng.standard_normal(sh)
+                        if msk:
+                            F[rng.random(sh) < 0.15] = U
+                            A[rng.random(sh) < 0.03] = U
+                            if bnz:
+                                B[rng.random(sh) < 0.03] = U
+                        S0 = rng.standard_normal(sh) * 0.1
+                        if msk:
+                            S0[rng.random(sh) < 0.05] = U
+                        a2 = (yc, xc, 1.3, 1.1, BCy, BCx, 1.21, 1.1 / 1.3 / 4, (1.1 / 1.3)**2, 1.3, U)
+                        S1 = S0.copy(); f1 = np.array([0., 1., 0.])
+                        ref.invert_standard_2D(S1, A, B, C, F, *a2, f1, 12, 1e-9)
+                        S2 = S0.copy(); f2 = np.array([0., 1., 0.])
+                        oracle.standard_2d(S2, A, B, C, F, *a2, f2, 12, 1e-9)
+                        assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
+                        D, E, Fc = mk(sh) * 0.1, mk(sh) * 0.1, -mk(sh) * 0.01
+                        ag = (yc, xc, 1.3, 1.1, BCy, BCx, 1.21, 1.1 / 1.3, 1.1 / 1.3 / 4, (1.1 / 1.3)**2, 1.3, U)
+                        S1 = S0.copy(); f1 = np.array([0., 1., 0.])
+                        ref.invert_general_2D(S1, A, B, C, D, E, Fc, F, *ag, f1, 12, 1e-9)
+                        S2 = S0.copy(); f2 = np.array([0., 1., 0.])
+                        oracle.general_2d(S2, A, B, C, D, E, Fc, F, *ag, f2, 12, 1e-9)
+                        assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
+                        n += 2
+    for sh in [(5, 7, 9), (4, 6, 8)]:
+        for BCy in ('fixed', 'extend'):
+            for BCx in ('fixed', 'periodic'):
+                for msk in (0, 1):
+                    A, B, C, F = mk(sh), mk(sh), mk(sh), rng.standard_normal(sh)
+                    if msk:
+                        F[rng.random(sh) < 0.15] = U
+                        B[rng.random(sh) < 0.03] = U
+                    S0 = rng.standard_normal(sh) * 0.1
+                    a3 = (*sh, 2., 1.3, 1.1, 'fixed', BCy, BCx, 1.21, (1.1 / 2)**2, (1.1 / 1.3)**2, 1.2, U)
+                    S1 = S0.copy(); f1 = np.array([0., 1., 0.])
+                    ref.invert_standard_3D(S1, A, B, C, F, *a3, f1, 8, 1e-9)
+                    S2 = S0.copy(); f2 = np.array([0., 1., 0.])
+                    oracle.standard_3d(S2, A, B, C, F, *a3, f2, 8, 1e-9)
+                    assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
+                    n += 1
+    assert n == 160

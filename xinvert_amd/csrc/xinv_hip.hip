@@ -297,7 +297,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         return fail_arg("internal: 9-point form without B");
 
     if (pl.path == XINV_PATH_FUSED) {
-        pl.K = opt.sweeps_per_launch > 0 ? opt.sweeps_per_launch : 1;
+        pl.K = opt.sweeps_per_launch > 0 ? opt.sweeps_per_launch : 2;   // 2 sweeps per pass over HBM
         if (pl.K > 2) return fail_arg("sweeps_per_launch must be 1 or 2");
         pl.RY = opt.rows_per_tile > 0 ? (opt.rows_per_tile + 1) & ~1 : 32;
         pl.nsg = (int)cdiv(cdiv(p.xc, 128 - 4 * XINV_KMAX), 4);   // most strips any K needs: sizes the partials
