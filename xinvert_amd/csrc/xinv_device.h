@@ -75,6 +75,25 @@ __device__ __forceinline__ long long xinv_wave_sum_ll(long long v)
     return v;
 }
 
+// Neighbour-lane moves on the VALU (DPP wave shifts, gfx9 family): no LDS round trip, unlike
+// __shfl_up/__shfl_down (ds_bpermute_b32).  Edge lanes keep their own value, as __shfl does.
+// Verified on gfx950: wave_shr:1 == __shfl_up(v, 1), wave_shl:1 == __shfl_down(v, 1).
+__device__ __forceinline__ double xinv_lane_up(double v)       // lane i <- lane i-1
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double xinv_lane_down(double v)     // lane i <- lane i+1
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // Scalars of one solve (same for every member), passed by value to the kernels.
 struct XinvScal {
     double delx, delxSqr, ratio, ratioQtr, ratioSqr;   // 2-D

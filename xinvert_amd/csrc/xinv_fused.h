@@ -26,6 +26,7 @@
 #pragma once
 #include "xinv_device.h"
 #include <type_traits>
+#include <utility>
 
 #define XINV_KMAX 4
 
@@ -46,6 +47,12 @@ struct FusedArgs {
     long long *pcnt;
 };
 
+template <class F, int... U>
+__device__ __forceinline__ void xinv_unroll_steps(F &&f, std::integer_sequence<int, U...>)
+{
+    (f(std::integral_constant<int, U>{}), ...);
+}
+
 template <int X> __device__ __forceinline__ double comp(const double2 &v) { return X ? v.y : v.x; }
 template <int X> __device__ __forceinline__ void setc(double2 &v, double t) { if (X) v.y = t; else v.x = t; }
 
@@ -53,40 +60,40 @@ template <int X> __device__ __forceinline__ void setc(double2 &v, double t) { if
 //                                   X == 1 -> west is own .x, east neighbour lives in lane+1's .x
 template <int X> __device__ __forceinline__ void row_neighbours(const double2 &row, double &w, double &e)
 {
-    if (X == 0) { w = __shfl_up(row.y, 1, XINV_WAVE); e = row.y; }
-    else        { w = row.x; e = __shfl_down(row.x, 1, XINV_WAVE); }
+    if (X == 0) { w = xinv_lane_up(row.y); e = row.y; }
+    else        { w = row.x; e = xinv_lane_down(row.x); }
 }
 
 // ---- models: which coefficient streams exist and how a point is updated -------------------
 struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
     static constexpr int NC = 3;    // A, C, F
-    // jw = window index of row j; row j+1 is jw-1.
-    template <int X, int DC>
-    static __device__ __forceinline__ double upd(const double2 (&cw)[NC][DC], int jw, double sC,
-                                                 double sP, double sM, double sW, double sE,
-                                                 bool inr, const XinvScal &sc)
+    // sj = register slot of row j, sjp = slot of row j+1.
+    template <int X, int D>
+    static __device__ __forceinline__ double upd(const double2 (&cw)[NC][D], int sj, int sjp,
+                                                 double sC, double sP, double sM, double sW,
+                                                 double sE, bool inr, const XinvScal &sc)
     {
-        const double aP = comp<X>(cw[0][jw - 1]);
-        const double a0 = comp<X>(cw[0][jw]);
-        const double c0 = comp<X>(cw[1][jw]);
+        const double aP = comp<X>(cw[0][sjp]);
+        const double a0 = comp<X>(cw[0][sj]);
+        const double c0 = comp<X>(cw[1][sj]);
         double cE;
-        if (X == 0) cE = cw[1][jw].y;
-        else        cE = __shfl_down(cw[1][jw].x, 1, XINV_WAVE);
-        const double f = comp<X>(cw[2][jw]);
+        if (X == 0) cE = cw[1][sj].y;
+        else        cE = xinv_lane_down(cw[1][sj].x);
+        const double f = comp<X>(cw[2][sj]);
         return xinv_upd_std2d_5(sC, sP, sM, sW, sE, aP, a0, cE, c0, f, inr, sc);
     }
 };
 
 struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     static constexpr int NC = 6;    // A, C, D, E, F, G
-    template <int X, int DC>
-    static __device__ __forceinline__ double upd(const double2 (&cw)[NC][DC], int jw, double sC,
-                                                 double sP, double sM, double sW, double sE,
-                                                 bool inr, const XinvScal &sc)
+    template <int X, int D>
+    static __device__ __forceinline__ double upd(const double2 (&cw)[NC][D], int sj, int,
+                                                 double sC, double sP, double sM, double sW,
+                                                 double sE, bool inr, const XinvScal &sc)
     {
         return xinv_upd_gen2d_5(sC, sP, sM, sW, sE,
-                                comp<X>(cw[0][jw]), comp<X>(cw[1][jw]), comp<X>(cw[2][jw]),
-                                comp<X>(cw[3][jw]), comp<X>(cw[4][jw]), comp<X>(cw[5][jw]),
+                                comp<X>(cw[0][sj]), comp<X>(cw[1][sj]), comp<X>(cw[2][sj]),
+                                comp<X>(cw[3][sj]), comp<X>(cw[4][sj]), comp<X>(cw[5][sj]),
                                 inr, sc);
     }
 };
@@ -112,7 +119,7 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t row_off, const L
 __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &inner,
                                                  const LaneCols &lc, bool tall, double u)
 {
-    const double inner_w = __shfl_up(inner.y, 1, XINV_WAVE);   // column c0-1
+    const double inner_w = xinv_lane_up(inner.y);              // column c0-1
     // component x (column c0)
     if (lc.cls_x == 1) { if (inner.x != u) edge.x = inner.x; }
     else if (lc.cls_x == 2) { if (inner.y != u) edge.x = inner.y; }           // (0,0) <- (1,1)
@@ -134,8 +141,7 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
     constexpr int NC = M::NC;
     constexpr int H = 2 * K;            // halo (rows and columns) consumed by K sweeps
     constexpr int UW = 128 - 2 * H;     // columns owned by one wavefront
-    constexpr int DS = 2 * K + 2;       // S window depth
-    constexpr int DC = 2 * K + 1;       // coefficient window depth
+    constexpr int D = 2 * K + 2;        // rows held in the register window
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -206,65 +212,67 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
             return p;
         };
 
-        double2 sw[DS];
-        double2 cw[NC][DC];
+        // Register window: row r lives in slot (r - r0) mod D.  The march is unrolled D steps so
+        // that every slot index below is a compile-time constant: rows never move between
+        // registers, a new row simply overwrites the slot of the row that left the pipeline.
+        double2 sw[D];
+        double2 cw[NC][D];
 #pragma unroll
-        for (int t = 0; t < DS; t++) sw[t] = make_double2(0.0, 0.0);
+        for (int t = 0; t < D; t++) sw[t] = make_double2(0.0, 0.0);
 #pragma unroll
         for (int q = 0; q < NC; q++)
 #pragma unroll
-            for (int t = 0; t < DC; t++) cw[q][t] = make_double2(0.0, 0.0);
+            for (int t = 0; t < D; t++) cw[q][t] = make_double2(0.0, 0.0);
 
-        // one pipeline step: row r enters; X = component updated by every stage of this step
-        auto step = [&](int64_t r, const RowPack<NC> &p, auto xtag) {
-            constexpr int X = decltype(xtag)::value;
+        // one pipeline step: row r (= rbase + U) enters slot U
+        auto step = [&](int64_t r, const RowPack<NC> &p, auto utag) {
+            constexpr int U = decltype(utag)::value;
+            constexpr int X = (U & 1) ? 0 : 1;       // r even -> .y ; all stages of a step share it
+#define SLOT(w) ((U - (w) + 4 * D) % D)              /* slot of row r - w */
+            sw[U] = p.s;
 #pragma unroll
-            for (int t = DS - 1; t > 0; t--) sw[t] = sw[t - 1];
-            sw[0] = p.s;
-#pragma unroll
-            for (int q = 0; q < NC; q++) {
-#pragma unroll
-                for (int t = DC - 1; t > 0; t--) cw[q][t] = cw[q][t - 1];
-                cw[q][0] = p.c[q];
-            }
+            for (int q = 0; q < NC; q++) cw[q][U] = p.c[q];
             const bool okc = X ? lc.ok_y : lc.ok_x;
 #pragma unroll
             for (int s = 1; s <= K; s++) {
-                {   // red half-sweep of sweep s on row ja (window index 2s-1)
+                {   // red half-sweep of sweep s on row ja = r-2s+1
                     const int64_t ja = r - 2 * s + 1;
-                    const int jw = 2 * s - 1;
+                    const int sj = SLOT(2 * s - 1), sjp = SLOT(2 * s - 2), sjm = SLOT(2 * s);
                     if (a.ext) {
-                        if (ja == 1) fused_extend_fix(sw[jw + 1], sw[jw], lc, a.tall, u);
-                        if (ja == yc - 2) fused_extend_fix(sw[jw - 1], sw[jw], lc, a.tall, u);
+                        if (ja == 1) fused_extend_fix(sw[sjm], sw[sj], lc, a.tall, u);
+                        if (ja == yc - 2) fused_extend_fix(sw[sjp], sw[sj], lc, a.tall, u);
                     }
                     double w, e;
-                    row_neighbours<X>(sw[jw], w, e);
+                    row_neighbours<X>(sw[sj], w, e);
                     const bool inr = okc && (ja >= 1) && (ja <= yc - 2);
-                    const double v = M::template upd<X, DC>(cw, jw, comp<X>(sw[jw]),
-                                                            comp<X>(sw[jw - 1]), comp<X>(sw[jw + 1]),
-                                                            w, e, inr, a.sc_);
-                    setc<X>(sw[jw], v);
+                    const double v = M::template upd<X, D>(cw, sj, sjp, comp<X>(sw[sj]),
+                                                           comp<X>(sw[sjp]), comp<X>(sw[sjm]),
+                                                           w, e, inr, a.sc_);
+                    setc<X>(sw[sj], v);
                 }
-                {   // black half-sweep of sweep s on row jb (window index 2s)
+                {   // black half-sweep of sweep s on row jb = r-2s
                     const int64_t jb = r - 2 * s;
-                    const int jw = 2 * s;
+                    const int sj = SLOT(2 * s), sjp = SLOT(2 * s - 1), sjm = SLOT(2 * s + 1);
                     double w, e;
-                    row_neighbours<X>(sw[jw], w, e);
+                    row_neighbours<X>(sw[sj], w, e);
                     const bool inr = okc && (jb >= 1) && (jb <= yc - 2);
-                    const double v = M::template upd<X, DC>(cw, jw, comp<X>(sw[jw]),
-                                                            comp<X>(sw[jw - 1]), comp<X>(sw[jw + 1]),
-                                                            w, e, inr, a.sc_);
-                    setc<X>(sw[jw], v);
-                    if (jb >= yu0 && jb < yu1) {          // row jb now holds sweep s: norm
-                        const double2 t = sw[jw];
-                        if (lc.use_x && t.x != u) { acc[s - 1] += fabs(t.x); cnt[s - 1] += 1; }
-                        if (lc.use_y && t.y != u) { acc[s - 1] += fabs(t.y); cnt[s - 1] += 1; }
-                    }
+                    const double v = M::template upd<X, D>(cw, sj, sjp, comp<X>(sw[sj]),
+                                                           comp<X>(sw[sjp]), comp<X>(sw[sjm]),
+                                                           w, e, inr, a.sc_);
+                    setc<X>(sw[sj], v);
+                    // row jb now holds sweep s: its share of mean|S| (branch-free)
+                    const bool rowin = (jb >= yu0) && (jb < yu1);
+                    const double2 t = sw[sj];
+                    const bool cx = rowin && lc.use_x && (t.x != u);
+                    const bool cy = rowin && lc.use_y && (t.y != u);
+                    acc[s - 1] += (cx ? fabs(t.x) : 0.0);
+                    acc[s - 1] += (cy ? fabs(t.y) : 0.0);
+                    cnt[s - 1] += (cx ? 1 : 0) + (cy ? 1 : 0);
                 }
             }
             const int64_t jo = r - 2 * K;                  // row leaving the pipeline
             if (jo >= yu0 && jo < yu1) {
-                const double2 t = sw[2 * K];
+                const double2 t = sw[SLOT(2 * K)];
                 if (AL) {
                     if (lc.use_x) *reinterpret_cast<double2 *>(dstS + jo * xc + st0) = t;
                 } else {
@@ -272,16 +280,18 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
                     if (lc.use_y) dstS[jo * xc + st0 + 1] = t.y;
                 }
             }
+#undef SLOT
         };
 
         const int64_t r0 = yu0 - H;                        // even: RY and H are even
         const int64_t rlast = yu1 - 1 + H;
         RowPack<NC> p0 = load(r0), p1 = load(r0 + 1);
-        for (int64_t r = r0; r <= rlast; r += 2) {
-            step(r, p0, std::integral_constant<int, 1>{});       // r even   -> update .y
-            p0 = load(r + 2);
-            step(r + 1, p1, std::integral_constant<int, 0>{});   // r+1 odd  -> update .x
-            p1 = load(r + 3);
+        for (int64_t rb_ = r0; rb_ <= rlast; rb_ += D) {
+            xinv_unroll_steps([&](auto utag) {
+                constexpr int U = decltype(utag)::value;
+                if (U & 1) { step(rb_ + U, p1, utag); p1 = load(rb_ + U + 2); }
+                else       { step(rb_ + U, p0, utag); p0 = load(rb_ + U + 2); }
+            }, std::make_integer_sequence<int, D>{});
         }
     }
 

@@ -299,7 +299,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (pl.path == XINV_PATH_FUSED) {
         pl.K = opt.sweeps_per_launch > 0 ? opt.sweeps_per_launch : 2;   // 2 sweeps per pass over HBM
         if (pl.K > 2) return fail_arg("sweeps_per_launch must be 1 or 2");
-        pl.RY = opt.rows_per_tile > 0 ? (opt.rows_per_tile + 1) & ~1 : 32;
+        // default rows per tile: RY + 4K is a multiple of the window depth 2K+2 (no idle steps)
+        pl.RY = opt.rows_per_tile > 0 ? (opt.rows_per_tile + 1) & ~1 : (pl.K == 1 ? 64 : 34);
         pl.nsg = (int)cdiv(cdiv(p.xc, 128 - 4 * XINV_KMAX), 4);   // most strips any K needs: sizes the partials
         pl.nrb = (int)cdiv(p.yc, pl.RY);
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
