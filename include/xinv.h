@@ -51,11 +51,11 @@ extern "C" {
 typedef struct xinv_options {
     int32_t device;             /* HIP device ordinal; -1 = current device                      */
     int32_t path;               /* XINV_PATH_*                                                   */
-    int32_t sweeps_per_launch;  /* fused path: sweeps fused in one launch (1..4); 0 = auto      */
+    int32_t sweeps_per_launch;  /* fused path: sweeps fused in one launch (1 or 2); 0 = auto    */
     int32_t check_every;        /* launches between host polls of the device stop flags; 0=auto */
     int32_t rows_per_tile;      /* fused path: rows marched by one wavefront; 0 = auto          */
     int32_t timing;             /* 1: bracket launch chunks with HIP events (xinv_last_stats)   */
-    int32_t reserved[2];
+    int32_t reserved[2];        /* reserved[0] bit 0: do not look for x-uniform coefficient rows */
 } xinv_options;
 
 typedef struct xinv_stats {
@@ -63,6 +63,8 @@ typedef struct xinv_stats {
     int32_t colours;            /* colours per sweep (2, 4, or +2 with the odd-periodic seam)   */
     int32_t sweeps_per_launch;
     int32_t rows_per_tile;
+    int32_t xuniform_mask;      /* fused path: coefficient streams read as one scalar per row    */
+    int32_t pad_;
     int64_t sweep_launches;     /* sweep-kernel launches issued (incl. no-op tail launches)     */
     int64_t sweeps_max;         /* max over members of sweeps executed                          */
     double  sweep_ms;           /* HIP-event time over all launch chunks (timing=1), ms         */

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, 'libxinv_hip.so')
+SO = os.environ.get('XINV_SO') or os.path.join(HERE, 'libxinv_hip.so')
 
 BC_CODES = {'fixed': 0, 'extend': 1, 'periodic': 2}
 PATH_AUTO, PATH_COLOUR, PATH_FUSED = 0, 1, 2
@@ -29,6 +29,7 @@ class XinvOptions(ctypes.Structure):
 class XinvStats(ctypes.Structure):
     _fields_ = [('path', ctypes.c_int32), ('colours', ctypes.c_int32),
                 ('sweeps_per_launch', ctypes.c_int32), ('rows_per_tile', ctypes.c_int32),
+                ('xuniform_mask', ctypes.c_int32), ('pad_', ctypes.c_int32),
                 ('sweep_launches', ctypes.c_int64), ('sweeps_max', ctypes.c_int64),
                 ('sweep_ms', ctypes.c_double), ('h2d_ms', ctypes.c_double),
                 ('d2h_ms', ctypes.c_double)]
@@ -113,11 +114,12 @@ def check(rc):
 
 
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
-            timing=0):
+            timing=0, no_xuniform=0):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
     o.check_every, o.rows_per_tile, o.timing = check_every, rows_per_tile, timing
+    o.reserved[0] = 1 if no_xuniform else 0
     return o
 
 

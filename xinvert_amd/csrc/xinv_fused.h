@@ -9,14 +9,24 @@
 // overlap by a halo of 2K columns / 2K rows that is recomputed (never exchanged), so a launch
 // needs no inter-workgroup synchronisation and S ping-pongs between two buffers.
 //
-// Pipeline.  Rows stream through a register window.  With `r` the row just loaded, sweep s
-// (s = 1..K) updates its red points on row r-2s+1 and its black points on row r-2s; row r-2K
-// leaves the window with K complete sweeps applied.  All stages of one step update the same
+// Pipeline.  Rows stream through a register window (no LDS).  With `r` the row just loaded,
+// sweep s (s = 1..K) updates its red points on row r-2s+1 and its black points on row r-2s; row
+// r-2K leaves the window with K complete sweeps applied.  All stages of one step update the same
 // lane component ((r+1)&1), and each needs exactly one cross-lane operand (the other colour's
-// value one column over), taken with a wave shuffle.  HBM traffic per launch is one read of S
-// and of each coefficient array plus one write of S (+ halo re-reads served by L2), for K sweeps.
+// value one column over), taken with a DPP wave shift.  The window rotates: the march is unrolled
+// 2K+2 steps so every register index is a compile-time constant and rows never move.  HBM traffic
+// per launch is one read of S and of each streamed coefficient array plus one write of S
+// (+ halo re-reads), for K sweeps.  Loads are 16 B per lane (1 KiB per wavefront per array row),
+// issued two rows ahead of use.
 //
-// Loads are 16 B per lane (1 KiB per wavefront per array row), issued two rows ahead of use.
+// x-uniform coefficients (template mask UM).  On lat-lon grids the reference materialises
+// coefficient fields that depend on latitude only as full 2-D arrays (`zero + cos(lat)`,
+// apps.py:1406-1408, 1630-1635).  The host detects arrays whose rows are constant along x
+// (bitwise, one pass per solve) and the kernel then reads ONE value per row through the scalar
+// unit instead of a 1 KiB vector row: no HBM stream, no vector registers, and the per-point
+// divide `optArg / denom` -- now uniform along the row -- is evaluated once per row.  The
+// arithmetic applied to each point is unchanged (same operands, same order), so results stay
+// bitwise equal to the full-array path and to the oracle.
 //
 // Norm.  mean|S| of the reference (numbas.py:1710-1728) is accumulated per sweep for the rows
 // and columns a tile owns, reduced wave -> workgroup -> partials[] in a fixed order, and the
@@ -28,7 +38,7 @@
 #include <type_traits>
 #include <utility>
 
-#define XINV_KMAX 4
+#define XINV_KMAX 2
 
 struct FusedArgs {
     const double *src;
@@ -64,41 +74,125 @@ template <int X> __device__ __forceinline__ void row_neighbours(const double2 &r
     else        { w = row.x; e = xinv_lane_down(row.x); }
 }
 
+// Per-row register window of the coefficient streams.  Stream q is either a vector row
+// (v[q][slot], two columns per lane) or, when bit q of UM is set, one scalar per row (s[q][slot]).
+// rq / rok: per-row relaxation factor optArg/denom and uniform part of the mask predicate, used
+// when the model's denominator is x-uniform (M::hoist<UM>()).
+template <int NC, int D> struct CoefWin {
+    double2 v[NC][D];
+    double s[NC][D];
+    double rq[D];
+    bool rok[D];
+};
+
+template <int X, unsigned UM, int Q, int NC, int D>
+__device__ __forceinline__ double cget(const CoefWin<NC, D> &w, int slot)
+{
+    if ((UM >> Q) & 1u) return w.s[Q][slot];
+    return comp<X>(w.v[Q][slot]);
+}
+
 // ---- models: which coefficient streams exist and how a point is updated -------------------
 struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
     static constexpr int NC = 3;    // A, C, F
-    // sj = register slot of row j, sjp = slot of row j+1.
-    template <int X, int D>
-    static __device__ __forceinline__ double upd(const double2 (&cw)[NC][D], int sj, int sjp,
-                                                 double sC, double sP, double sM, double sW,
-                                                 double sE, bool inr, const XinvScal &sc)
+    template <unsigned UM> static constexpr bool hoist() { return (UM & 3u) == 3u; }   // A and C uniform
+
+    // called once per step after row r entered slot `sr`; `s1` = slot of row r-1.
+    template <unsigned UM, int D>
+    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int s1, const XinvScal &sc)
     {
-        const double aP = comp<X>(cw[0][sjp]);
-        const double a0 = comp<X>(cw[0][sj]);
-        const double c0 = comp<X>(cw[1][sj]);
+        if (hoist<UM>()) {          // row r-1: A[r], A[r-1], C[r-1] are all known now
+            const double aP = w.s[0][sr], a0 = w.s[0][s1], c = w.s[1][s1];
+            w.rq[s1] = sc.optArg / ((aP + a0) * sc.ratioSqr + (c + c));
+            w.rok[s1] = (aP != sc.undef) && (a0 != sc.undef) && (c != sc.undef);
+        }
+    }
+
+    // sj = slot of row j, sjp = slot of row j+1.
+    template <int X, unsigned UM, int D>
+    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 bool inr, const XinvScal &sc)
+    {
+        const double aP = cget<X, UM, 0>(w, sjp);
+        const double a0 = cget<X, UM, 0>(w, sj);
+        const double c0 = cget<X, UM, 1>(w, sj);
         double cE;
-        if (X == 0) cE = cw[1][sj].y;
-        else        cE = xinv_lane_down(cw[1][sj].x);
-        const double f = comp<X>(cw[2][sj]);
+        if ((UM >> 1) & 1u) cE = w.s[1][sj];
+        else if (X == 0)    cE = w.v[1][sj].y;
+        else                cE = xinv_lane_down(w.v[1][sj].x);
+        const double f = cget<X, UM, 2>(w, sj);
+        if (hoist<UM>()) {
+            const bool cond = inr && w.rok[sj] && (f != sc.undef);
+            double temp = (
+                (
+                    aP * (sP - sC) -
+                    a0 * (sC - sM)
+                ) * sc.ratioSqr + (
+                    cE * (sE - sC) -
+                    c0 * (sC - sW)
+                )
+            ) - f * sc.delxSqr;
+            temp *= w.rq[sj];
+            return cond ? sC + temp : sC;
+        }
         return xinv_upd_std2d_5(sC, sP, sM, sW, sE, aP, a0, cE, c0, f, inr, sc);
     }
 };
 
 struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     static constexpr int NC = 6;    // A, C, D, E, F, G
-    template <int X, int D>
-    static __device__ __forceinline__ double upd(const double2 (&cw)[NC][D], int sj, int,
-                                                 double sC, double sP, double sM, double sW,
-                                                 double sE, bool inr, const XinvScal &sc)
+    template <unsigned UM> static constexpr bool hoist() { return (UM & 0x13u) == 0x13u; }  // A, C, F uniform
+
+    template <unsigned UM, int D>
+    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int, const XinvScal &sc)
     {
-        return xinv_upd_gen2d_5(sC, sP, sM, sW, sE,
-                                comp<X>(cw[0][sj]), comp<X>(cw[1][sj]), comp<X>(cw[2][sj]),
-                                comp<X>(cw[3][sj]), comp<X>(cw[4][sj]), comp<X>(cw[5][sj]),
-                                inr, sc);
+        if (hoist<UM>()) {
+            const double A = w.s[0][sr], C = w.s[1][sr], F = w.s[4][sr];
+            w.rq[sr] = sc.optArg / ((A * sc.ratioSqr + C) * 2.0
+                                    - F * sc.delxSqr);
+            bool ok = (A != sc.undef) && (C != sc.undef) && (F != sc.undef);
+            if ((UM >> 2) & 1u) ok = ok && (w.s[2][sr] != sc.undef);
+            if ((UM >> 3) & 1u) ok = ok && (w.s[3][sr] != sc.undef);
+            w.rok[sr] = ok;
+        }
+    }
+
+    template <int X, unsigned UM, int D>
+    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 bool inr, const XinvScal &sc)
+    {
+        const double A = cget<X, UM, 0>(w, sj), C = cget<X, UM, 1>(w, sj);
+        const double Dd = cget<X, UM, 2>(w, sj), E = cget<X, UM, 3>(w, sj);
+        const double F = cget<X, UM, 4>(w, sj), G = cget<X, UM, 5>(w, sj);
+        if (hoist<UM>()) {
+            bool cond = inr && w.rok[sj] && (G != sc.undef);
+            if (!((UM >> 2) & 1u)) cond = cond && (Dd != sc.undef);
+            if (!((UM >> 3) & 1u)) cond = cond && (E != sc.undef);
+            double temp = (
+                A * (
+                    (sP - sC) - (sC - sM)
+                ) * sc.ratioSqr +
+                C * (
+                    (sE - sC) - (sC - sW)
+                ) + (
+                Dd * (
+                    (sP - sM)
+                ) * sc.ratio +
+                E * (
+                    (sE - sW)
+                )) * sc.delx / 2.0 + (
+                F * sC - G) * sc.delxSqr
+            );
+            temp *= w.rq[sj];
+            return cond ? sC + temp : sC;
+        }
+        return xinv_upd_gen2d_5(sC, sP, sM, sW, sE, A, C, Dd, E, F, G, inr, sc);
     }
 };
 
-template <int NC> struct RowPack { double2 s; double2 c[NC]; };
+template <int NC> struct RowPack { double2 s; double2 c[NC]; double cs[NC]; };
 
 struct LaneCols {
     int64_t l0, l1;            // load columns of .x / .y (wrapped or clamped)
@@ -135,13 +229,21 @@ __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &i
     }
 }
 
-template <class M, int K, bool AL>
+template <class M, int K, bool AL, unsigned UM, bool EXT, int PFD = 0>
 __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
 {
     constexpr int NC = M::NC;
     constexpr int H = 2 * K;            // halo (rows and columns) consumed by K sweeps
     constexpr int UW = 128 - 2 * H;     // columns owned by one wavefront
     constexpr int D = 2 * K + 2;        // rows held in the register window
+#ifndef XINV_PF_MODE
+#define XINV_PF_MODE 0
+#endif
+#ifndef XINV_FORCE_VGPR
+#define XINV_FORCE_VGPR 0
+#endif
+    constexpr int PF = PFD > 0 ? PFD : (XINV_PF_MODE == 0 ? 2 : ((UM != 0u) ? D : (K == 1 ? 4 : 3)));
+    static_assert(D % PF == 0, "prefetch depth must divide the window depth");
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -208,7 +310,16 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
             const int64_t off = rr * xc;
             p.s = ld2<AL>(srcS, off, lc);
 #pragma unroll
-            for (int q = 0; q < NC; q++) p.c[q] = ld2<AL>(cp[q], off, lc);
+            for (int q = 0; q < NC; q++) {
+                if ((UM >> q) & 1u) {
+                    double t = cp[q][off];               // scalar load: one value per row
+#if XINV_FORCE_VGPR
+                    asm volatile("" : "+v"(t));          // held in a VGPR pair: SGPRs are scarcer here
+#endif
+                    p.cs[q] = t; p.c[q] = make_double2(0.0, 0.0);
+                }
+                else                { p.c[q] = ld2<AL>(cp[q], off, lc); p.cs[q] = 0.0; }
+            }
             return p;
         };
 
@@ -216,13 +327,14 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
         // that every slot index below is a compile-time constant: rows never move between
         // registers, a new row simply overwrites the slot of the row that left the pipeline.
         double2 sw[D];
-        double2 cw[NC][D];
+        CoefWin<NC, D> cw;
 #pragma unroll
-        for (int t = 0; t < D; t++) sw[t] = make_double2(0.0, 0.0);
+        for (int t = 0; t < D; t++) {
+            sw[t] = make_double2(0.0, 0.0);
+            cw.rq[t] = 0.0; cw.rok[t] = false;
 #pragma unroll
-        for (int q = 0; q < NC; q++)
-#pragma unroll
-            for (int t = 0; t < D; t++) cw[q][t] = make_double2(0.0, 0.0);
+            for (int q = 0; q < NC; q++) { cw.v[q][t] = make_double2(0.0, 0.0); cw.s[q][t] = 0.0; }
+        }
 
         // one pipeline step: row r (= rbase + U) enters slot U
         auto step = [&](int64_t r, const RowPack<NC> &p, auto utag) {
@@ -231,23 +343,24 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
 #define SLOT(w) ((U - (w) + 4 * D) % D)              /* slot of row r - w */
             sw[U] = p.s;
 #pragma unroll
-            for (int q = 0; q < NC; q++) cw[q][U] = p.c[q];
+            for (int q = 0; q < NC; q++) { cw.v[q][U] = p.c[q]; cw.s[q][U] = p.cs[q]; }
+            M::template derive<UM, D>(cw, U, SLOT(1), a.sc_);
             const bool okc = X ? lc.ok_y : lc.ok_x;
 #pragma unroll
             for (int s = 1; s <= K; s++) {
                 {   // red half-sweep of sweep s on row ja = r-2s+1
                     const int64_t ja = r - 2 * s + 1;
                     const int sj = SLOT(2 * s - 1), sjp = SLOT(2 * s - 2), sjm = SLOT(2 * s);
-                    if (a.ext) {
+                    if (EXT) {           // BCy == 'extend': compiled out otherwise
                         if (ja == 1) fused_extend_fix(sw[sjm], sw[sj], lc, a.tall, u);
                         if (ja == yc - 2) fused_extend_fix(sw[sjp], sw[sj], lc, a.tall, u);
                     }
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
                     const bool inr = okc && (ja >= 1) && (ja <= yc - 2);
-                    const double v = M::template upd<X, D>(cw, sj, sjp, comp<X>(sw[sj]),
-                                                           comp<X>(sw[sjp]), comp<X>(sw[sjm]),
-                                                           w, e, inr, a.sc_);
+                    const double v = M::template upd<X, UM, D>(cw, sj, sjp, comp<X>(sw[sj]),
+                                                               comp<X>(sw[sjp]), comp<X>(sw[sjm]),
+                                                               w, e, inr, a.sc_);
                     setc<X>(sw[sj], v);
                 }
                 {   // black half-sweep of sweep s on row jb = r-2s
@@ -256,9 +369,9 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
                     const bool inr = okc && (jb >= 1) && (jb <= yc - 2);
-                    const double v = M::template upd<X, D>(cw, sj, sjp, comp<X>(sw[sj]),
-                                                           comp<X>(sw[sjp]), comp<X>(sw[sjm]),
-                                                           w, e, inr, a.sc_);
+                    const double v = M::template upd<X, UM, D>(cw, sj, sjp, comp<X>(sw[sj]),
+                                                               comp<X>(sw[sjp]), comp<X>(sw[sjm]),
+                                                               w, e, inr, a.sc_);
                     setc<X>(sw[sj], v);
                     // row jb now holds sweep s: its share of mean|S| (branch-free)
                     const bool rowin = (jb >= yu0) && (jb < yu1);
@@ -283,14 +396,19 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
 #undef SLOT
         };
 
+        // Prefetch ring: PF rows in flight per wavefront (PF divides D so ring indices are
+        // compile-time constants).  Bytes in flight, not issue rate, bound this kernel: a wave
+        // keeps PF x (1 + vector streams) KiB outstanding.
         const int64_t r0 = yu0 - H;                        // even: RY and H are even
         const int64_t rlast = yu1 - 1 + H;
-        RowPack<NC> p0 = load(r0), p1 = load(r0 + 1);
+        RowPack<NC> pf[PF];
+#pragma unroll
+        for (int t = 0; t < PF; t++) pf[t] = load(r0 + t);
         for (int64_t rb_ = r0; rb_ <= rlast; rb_ += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
-                if (U & 1) { step(rb_ + U, p1, utag); p1 = load(rb_ + U + 2); }
-                else       { step(rb_ + U, p0, utag); p0 = load(rb_ + U + 2); }
+                step(rb_ + U, pf[U % PF], utag);
+                pf[U % PF] = load(rb_ + U + PF);
             }, std::make_integer_sequence<int, D>{});
         }
     }
@@ -349,4 +467,36 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
         for (int s = 0; s < K; s++) xinv_ctl_update(ctl, tot[s], tcn[s], a.stop);
         __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ---- detection of x-uniform coefficient rows (once per solve) -----------------------------
+// flag[q] |= 1 when array q has a row whose elements are not all bitwise equal to its first.
+struct XUniArgs {
+    const double *c[6];
+    int64_t stride[6];         // batch stride; 0 = shared (checked once)
+    int64_t nbatch, yc, xc;
+    int nstream;
+    int *flag;                 // [8]
+};
+
+__global__ __launch_bounds__(256) void k_xuniform(XUniArgs a)
+{
+    const int q = blockIdx.y;
+    if (q >= a.nstream) return;
+    volatile int *fl = a.flag + q;
+    const int64_t nm = (a.stride[q] == 0) ? 1 : a.nbatch;
+    const int64_t nrow = nm * a.yc;
+    const unsigned long long *base = reinterpret_cast<const unsigned long long *>(a.c[q]);
+    bool bad = false;
+    // one wavefront per row at a time, grid-stride over rows
+    const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * wpb + wave; row < nrow; row += (int64_t)gridDim.x * wpb) {
+        if (*fl) break;                                  // someone already found a varying row
+        const int64_t mm = row / a.yc, j = row - mm * a.yc;
+        const unsigned long long *p = base + mm * a.stride[q] + j * a.xc;
+        const unsigned long long first = p[0];
+        for (int64_t i = lane; i < a.xc; i += 64) bad |= (p[i] != first);
+        if (__any(bad)) break;
+    }
+    if (__any(bad) && lane == 0) atomicOr(a.flag + q, 1);
 }

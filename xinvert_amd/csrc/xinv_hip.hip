@@ -18,6 +18,7 @@
 #include <exception>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/xinv.h"
@@ -53,6 +54,7 @@ struct Workspace {
     XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
     void *partials = nullptr; size_t partials_cap = 0;  // psum + pcnt
     int *dflag = nullptr;
+    int *dflags8 = nullptr, *hflags8 = nullptr;
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
     int *hflag = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -132,7 +134,51 @@ struct Plan {
     int path, base, seam, ncol;
     int K, RY, nsg, nrb;
     bool aligned;
+    unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
+    unsigned um;             // the kernel variant's mask (subset of umask)
 };
+
+// kernel variants instantiated per model: mask of streams read as one scalar per row
+static unsigned pick_um(int kind, unsigned umask)
+{
+    if (kind == KIND_STD2D) return ((umask & 3u) == 3u) ? 3u : 0u;            // A, C
+    if ((umask & 0x1fu) == 0x1fu) return 0x1fu;                                // A, C, D, E, F
+    if ((umask & 0x1cu) == 0x1cu) return 0x1cu;                                // D, E, F
+    return 0u;
+}
+
+template <class M, bool AL, unsigned UM, bool EXT>
+static int launch_fused_k(int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a)
+{
+    switch (K) {
+    case 1: hipLaunchKernelGGL((k_fused2d<M, 1, AL, UM, EXT>), grid, block, 0, st, a); return 0;
+    case 2: hipLaunchKernelGGL((k_fused2d<M, 2, AL, UM, EXT>), grid, block, 0, st, a); return 0;
+    default: break;
+    }
+    return 1;
+}
+
+template <class M, bool AL, bool EXT>
+static int launch_fused_um(unsigned um, int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a)
+{
+    if constexpr (std::is_same<M, FusedStd2D>::value) {
+        if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a);
+    } else {
+        if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a);
+        if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a);
+    }
+    return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a);
+}
+
+template <class M>
+static int launch_fused_m(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
+                          const FusedArgs &a)
+{
+    if (al) return ext ? launch_fused_um<M, true, true>(um, K, grid, block, st, a)
+                       : launch_fused_um<M, true, false>(um, K, grid, block, st, a);
+    return ext ? launch_fused_um<M, false, true>(um, K, grid, block, st, a)
+               : launch_fused_um<M, false, false>(um, K, grid, block, st, a);
+}
 
 static bool ptr_al16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
@@ -170,16 +216,9 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
     dim3 grid((unsigned)(a.nsg * a.nrb), (unsigned)nmem, 1), block(256, 1, 1);
     const bool gen = (p.kind == KIND_GEN2D);
-#define LAUNCH(M, KK, AL) hipLaunchKernelGGL((k_fused2d<M, KK, AL>), grid, block, 0, st, a)
-#define PICK_K(M, AL)                                    \
-    switch (K) {                                         \
-    case 1: LAUNCH(M, 1, AL); break;                     \
-    case 2: LAUNCH(M, 2, AL); break;                     \
-    default: return fail_arg("unsupported sweeps_per_launch"); }
-    if (gen) { if (pl.aligned) { PICK_K(FusedGen2D, true) } else { PICK_K(FusedGen2D, false) } }
-    else     { if (pl.aligned) { PICK_K(FusedStd2D, true) } else { PICK_K(FusedStd2D, false) } }
-#undef PICK_K
-#undef LAUNCH
+    const int bad = gen ? launch_fused_m<FusedGen2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a)
+                        : launch_fused_m<FusedStd2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a);
+    if (bad) return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     HIPCHK(hipGetLastError());
     return XINV_OK;
 }
@@ -297,10 +336,38 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         return fail_arg("internal: 9-point form without B");
 
     if (pl.path == XINV_PATH_FUSED) {
+        // which coefficient streams are constant along x (lat-lon grids: functions of latitude)
+        {
+            XUniArgs xa;
+            memset(&xa, 0, sizeof xa);
+            const int cmapS[3] = {0, 2, 3}, cmapG[6] = {0, 2, 3, 4, 5, 6};
+            xa.nstream = (p.kind == KIND_STD2D) ? 3 : 6;
+            for (int q = 0; q < xa.nstream; q++) {
+                const int sidx = (p.kind == KIND_STD2D) ? cmapS[q] : cmapG[q];
+                xa.c[q] = p.c[sidx]; xa.stride[q] = p.sc[sidx];
+            }
+            xa.nbatch = p.nbatch; xa.yc = p.yc; xa.xc = p.xc;
+            if (!ws->dflags8) {
+                HIPCHK(hipMalloc((void **)&ws->dflags8, 8 * sizeof(int)));
+                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 8 * sizeof(int), hipHostMallocDefault));
+            }
+            xa.flag = ws->dflags8;
+            pl.umask = 0;
+            if (!(opt.reserved[0] & 1)) {               // reserved[0] bit 0: disable the detection
+                HIPCHK(hipMemsetAsync(ws->dflags8, 0, 8 * sizeof(int), st));
+                hipLaunchKernelGGL(k_xuniform, dim3(512, (unsigned)xa.nstream, 1), dim3(256), 0, st, xa);
+                HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (int q = 0; q < xa.nstream; q++) if (!ws->hflags8[q]) pl.umask |= (1u << q);
+            }
+            pl.um = pick_um(p.kind, pl.umask);
+        }
+        const int kmax = XINV_KMAX;
         pl.K = opt.sweeps_per_launch > 0 ? opt.sweeps_per_launch : 2;   // 2 sweeps per pass over HBM
-        if (pl.K > 2) return fail_arg("sweeps_per_launch must be 1 or 2");
+        if (pl.K > kmax) return fail_arg("sweeps_per_launch must be 1 or 2");
         // default rows per tile: RY + 4K is a multiple of the window depth 2K+2 (no idle steps)
-        pl.RY = opt.rows_per_tile > 0 ? (opt.rows_per_tile + 1) & ~1 : (pl.K == 1 ? 64 : 34);
+        static const int ry_default[3] = {0, 32, 34};
+        pl.RY = opt.rows_per_tile > 0 ? (opt.rows_per_tile + 1) & ~1 : ry_default[pl.K];
         pl.nsg = (int)cdiv(cdiv(p.xc, 128 - 4 * XINV_KMAX), 4);   // most strips any K needs: sizes the partials
         pl.nrb = (int)cdiv(p.yc, pl.RY);
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
@@ -418,6 +485,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     t_stats.colours = pl.ncol;
     t_stats.sweeps_per_launch = Kf;
     t_stats.rows_per_tile = pl.RY;
+    t_stats.xuniform_mask = (pl.path == XINV_PATH_FUSED) ? (int32_t)pl.um : 0;
     t_stats.sweep_launches = nlaunch;
     t_stats.sweeps_max = sweeps_max;
     t_stats.sweep_ms = ms_total;
