@@ -365,9 +365,21 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         const int kmax = XINV_KMAX;
         pl.K = opt.sweeps_per_launch > 0 ? opt.sweeps_per_launch : 2;   // 2 sweeps per pass over HBM
         if (pl.K > kmax) return fail_arg("sweeps_per_launch must be 1 or 2");
-        // default rows per tile: RY + 4K is a multiple of the window depth 2K+2 (no idle steps)
-        static const int ry_default[3] = {0, 32, 34};
-        pl.RY = opt.rows_per_tile > 0 ? (opt.rows_per_tile + 1) & ~1 : ry_default[pl.K];
+        // Rows per tile.  RY + 4K is kept a multiple of the window depth 2K+2 (no idle steps).
+        // Tall tiles amortise the 4K recomputed halo rows, but a launch needs ~1500 wavefronts
+        // to occupy 1024 SIMDs, so small problems get short tiles (measured: 180x360 is best at
+        // RY = 4, 1800x3600 at 34, large batches are flat from 34 to 94).
+        if (opt.rows_per_tile > 0) {
+            pl.RY = (opt.rows_per_tile + 1) & ~1;
+        } else {
+            const int ry_max = (pl.K == 1) ? 32 : 34, period = 2 * pl.K + 2;
+            const double slots = (double)cdiv(cdiv(p.xc, 128 - 4 * pl.K), 4) * 4.0 * (double)p.nbatch;
+            int want = (int)((double)p.yc * slots / 1536.0);
+            want = std::max(4, std::min(ry_max, want));
+            int ry = ry_max;
+            while (ry - period >= 4 && ry - period >= want) ry -= period;     // smallest valid >= want
+            pl.RY = ry;
+        }
         pl.nsg = (int)cdiv(cdiv(p.xc, 128 - 4 * XINV_KMAX), 4);   // most strips any K needs: sizes the partials
         pl.nrb = (int)cdiv(p.yc, pl.RY);
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
