@@ -59,6 +59,44 @@ def test_colour_path_3d(BCy, BCx, msk, shape):
     assert_same(S[0], fl[0], So, flo, '3d')
 
 
+def _uniform3d(p, rng):
+    """Make A, B, C constant along x (what every lat-lon omega coefficient looks like)."""
+    q = dict(p)
+    q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[..., :1], c.shape)) if k < 3 else c
+                  for k, c in enumerate(p['coefs'])]
+    return q
+
+
+@pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'), ('extend', 'fixed')])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('uni', [0, 1])
+@pytest.mark.parametrize('nw', [8, 12, 16])
+@pytest.mark.parametrize('shape', [(6, 9, 12), (5, 30, 130), (9, 21, 260), (4, 14, 11), (3, 3, 3)])
+def test_fused_path_3d(BCy, BCx, msk, uni, nw, shape):
+    if BCx == 'periodic' and shape[2] % 2:
+        pytest.skip('odd-xc periodic seam goes through the colour path')
+    p = rand3d(shape[0], shape[1], shape[2], BCy, BCx, msk, seed=_seed((BCy, BCx, msk, uni, shape)))
+    if uni:
+        p = _uniform3d(p, None)
+    So, flo = run_oracle(p, 12, 1e-9, COLOUR_2)
+    S, fl, st = run_hip_batched([p], 12, 1e-9, path=PATH_FUSED, rows_per_tile=nw)
+    assert st['path'] == PATH_FUSED and st['rows_per_tile'] == nw
+    assert st['xuniform_mask'] == (7 if uni else 0)
+    assert_same(S[0], fl[0], So, flo, 'fused 3d %r' % (shape,))
+
+
+def test_fused_3d_batched_early_stop():
+    ps = [rand3d(7, 20, 140, 'fixed', 'periodic', 1, seed=s) for s in (1, 2, 3)]
+    S, fl, st = run_hip_batched(ps, 300, 2e-4)
+    assert st['path'] == PATH_FUSED
+    loops = set()
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 300, 2e-4, COLOUR_2)
+        assert_same(S[m], fl[m], So, flo, '3d member %d' % m)
+        loops.add(flo[2])
+    assert len(loops) > 1
+
+
 FUSED_SHAPES = [(17, 24), (12, 20), (40, 300), (70, 130), (33, 257), (8, 4), (3, 3), (64, 512)]
 
 

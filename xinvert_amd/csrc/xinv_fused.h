@@ -208,6 +208,37 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t row_off, const L
     double2 v; v.x = p[row_off + lc.l0]; v.y = p[row_off + lc.l1]; return v;
 }
 
+// Lane -> column map of one wavefront's strip: lane owns columns c0 = xu0 - H + 2*lane and c0+1.
+template <bool AL>
+__device__ __forceinline__ LaneCols make_lanecols(int64_t xu0, int H, int UW, int lane, int64_t xc,
+                                                  bool per)
+{
+    LaneCols lc;
+    const int64_t c0 = xu0 - H + 2 * lane, c1 = c0 + 1;
+    if (per) {
+        int64_t w0 = c0 % xc; if (w0 < 0) w0 += xc;
+        int64_t w1 = c1 % xc; if (w1 < 0) w1 += xc;
+        lc.l0 = w0; lc.l1 = w1;
+        lc.ok_x = lc.ok_y = true;
+        lc.cls_x = lc.cls_y = 1;
+    } else {
+        if (AL) {
+            int64_t p = c0 < 0 ? 0 : (c0 > xc - 2 ? xc - 2 : c0);
+            lc.l0 = p; lc.l1 = p + 1;
+        } else {
+            lc.l0 = c0 < 0 ? 0 : (c0 > xc - 1 ? xc - 1 : c0);
+            lc.l1 = c1 < 0 ? 0 : (c1 > xc - 1 ? xc - 1 : c1);
+        }
+        lc.ok_x = (c0 >= 1 && c0 <= xc - 2);
+        lc.ok_y = (c1 >= 1 && c1 <= xc - 2);
+        lc.cls_x = lc.ok_x ? 1 : (c0 == 0 ? 2 : (c0 == xc - 1 ? 3 : 0));
+        lc.cls_y = lc.ok_y ? 1 : (c1 == xc - 1 ? 3 : 0);
+    }
+    lc.use_x = (c0 >= xu0 && c0 < xu0 + UW && c0 < xc);
+    lc.use_y = (c1 >= xu0 && c1 < xu0 + UW && c1 < xc);
+    return lc;
+}
+
 // 'extend' pre-pass for one boundary row held in the window (numbas.py:284-310).
 // edge = row 0 (or yc-1), inner = row 1 (or yc-2), both in their state at the start of sweep s.
 __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &inner,
@@ -265,31 +296,7 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
     const bool active = xu0 < xc;
     const double u = a.sc_.undef;
 
-    LaneCols lc;
-    {
-        const int64_t c0 = xu0 - H + 2 * lane, c1 = c0 + 1;
-        if (a.per) {
-            int64_t w0 = c0 % xc; if (w0 < 0) w0 += xc;
-            int64_t w1 = c1 % xc; if (w1 < 0) w1 += xc;
-            lc.l0 = w0; lc.l1 = w1;
-            lc.ok_x = lc.ok_y = true;
-            lc.cls_x = lc.cls_y = 1;
-        } else {
-            if (AL) {
-                int64_t p = c0 < 0 ? 0 : (c0 > xc - 2 ? xc - 2 : c0);
-                lc.l0 = p; lc.l1 = p + 1;
-            } else {
-                lc.l0 = c0 < 0 ? 0 : (c0 > xc - 1 ? xc - 1 : c0);
-                lc.l1 = c1 < 0 ? 0 : (c1 > xc - 1 ? xc - 1 : c1);
-            }
-            lc.ok_x = (c0 >= 1 && c0 <= xc - 2);
-            lc.ok_y = (c1 >= 1 && c1 <= xc - 2);
-            lc.cls_x = lc.ok_x ? 1 : (c0 == 0 ? 2 : (c0 == xc - 1 ? 3 : 0));
-            lc.cls_y = lc.ok_y ? 1 : (c1 == xc - 1 ? 3 : 0);
-        }
-        lc.use_x = (c0 >= xu0 && c0 < xu0 + UW && c0 < xc);
-        lc.use_y = (c1 >= xu0 && c1 < xu0 + UW && c1 < xc);
-    }
+    const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
     const int64_t st0 = xu0 - H + 2 * lane;          // unwrapped store column of .x
 
     const double *srcS = a.src + m * a.sS;

@@ -25,6 +25,7 @@
 #include "xinv_device.h"
 #include "xinv_colour.h"
 #include "xinv_fused.h"
+#include "xinv_fused3d.h"
 
 #define XINV_VERSION 100
 
@@ -223,6 +224,48 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     return XINV_OK;
 }
 
+// ---- 3-D fused launch ------------------------------------------------------------------------
+template <int NW>
+static int launch_fused3d_nw(bool al, bool uni, bool ext, dim3 grid, hipStream_t st, const Fused3Args &a)
+{
+    dim3 block(NW * 64, 1, 1);
+#define L3(AL, UNI, EXT) hipLaunchKernelGGL((k_fused3d<NW, AL, UNI, EXT>), grid, block, 0, st, a)
+    if (al) {
+        if (uni) { if (ext) L3(true, true, true); else L3(true, true, false); }
+        else     { if (ext) L3(true, false, true); else L3(true, false, false); }
+    } else {
+        if (uni) { if (ext) L3(false, true, true); else L3(false, true, false); }
+        else     { if (ext) L3(false, false, true); else L3(false, false, false); }
+    }
+#undef L3
+    return 0;
+}
+
+static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, double *dst,
+                          Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
+                          int no_ctl)
+{
+    Fused3Args a;
+    memset(&a, 0, sizeof a);
+    a.src = src; a.dst = dst; a.sS = p.sS;
+    for (int q = 0; q < 4; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
+    a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
+    a.per = (p.BCx == XINV_BC_PERIODIC);
+    a.nstrip = pl.nsg; a.njb = pl.nrb;
+    a.force = force; a.no_ctl = no_ctl; a.member0 = member0;
+    a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
+    const size_t NB = (size_t)pl.nsg * pl.nrb;
+    a.psum = (unsigned long long *)ws->partials;
+    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * NB * sizeof(double));
+    dim3 grid((unsigned)NB, (unsigned)nmem, 1);
+    const bool ext = (p.BCy == XINV_BC_EXTEND), uni = (pl.um == 7u);
+    if (pl.RY == 8) launch_fused3d_nw<8>(pl.aligned, uni, ext, grid, st, a);
+    else if (pl.RY == 12) launch_fused3d_nw<12>(pl.aligned, uni, ext, grid, st, a);
+    else launch_fused3d_nw<16>(pl.aligned, uni, ext, grid, st, a);
+    HIPCHK(hipGetLastError());
+    return XINV_OK;
+}
+
 // one full coloured sweep (+ norm + stop rule) in place on p.S
 static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st)
 {
@@ -327,14 +370,46 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     pl.ncol = pl.base + (pl.seam ? 2 : 0);
 
     // ---- path ------------------------------------------------------------------------------
-    const bool fused_ok = (p.kind != KIND_STD3D) && pl.base == 2 && !pl.seam;
+    const bool fused_ok = pl.base == 2 && !pl.seam;
     pl.path = XINV_PATH_COLOUR;
     if (fused_ok && opt.path != XINV_PATH_COLOUR) pl.path = XINV_PATH_FUSED;
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("fused path needs a 2-D problem with B == 0 and no odd-xc periodic seam");
+        return fail_arg("fused path needs B == 0 (2-D) and no odd-xc periodic seam");
     if (pl.path == XINV_PATH_COLOUR && p.kind != KIND_STD3D && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 
+    if (pl.path == XINV_PATH_FUSED && p.kind == KIND_STD3D) {
+        // 3-D: one sweep per launch; cross-section of NW rows per workgroup (rows_per_tile = NW)
+        pl.K = 1;
+        pl.RY = (opt.rows_per_tile == 8 || opt.rows_per_tile == 12 || opt.rows_per_tile == 16)
+                    ? opt.rows_per_tile : 0;     // 0: decided below, once the variant is known
+        pl.nsg = (int)cdiv(p.xc, 124);                      // x strips
+        pl.nrb = (int)cdiv(p.yc, pl.RY - 4);                // j blocks
+        pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
+        for (int q = 0; q < 4; q++) pl.aligned = pl.aligned && ptr_al16(p.c[q]) && !(p.sc[q] & 1);
+        pl.umask = 0;
+        if (!(opt.reserved[0] & 1)) {
+            XUniArgs xa;
+            memset(&xa, 0, sizeof xa);
+            xa.nstream = 3;
+            for (int q = 0; q < 3; q++) { xa.c[q] = p.c[q]; xa.stride[q] = p.sc[q]; }
+            xa.nbatch = p.nbatch; xa.yc = p.zc * p.yc; xa.xc = p.xc;
+            if (!ws->dflags8) {
+                HIPCHK(hipMalloc((void **)&ws->dflags8, 8 * sizeof(int)));
+                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 8 * sizeof(int), hipHostMallocDefault));
+            }
+            xa.flag = ws->dflags8;
+            HIPCHK(hipMemsetAsync(ws->dflags8, 0, 8 * sizeof(int), st));
+            hipLaunchKernelGGL(k_xuniform, dim3(512, 3, 1), dim3(256), 0, st, xa);
+            HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int q = 0; q < 3; q++) if (!ws->hflags8[q]) pl.umask |= (1u << q);
+        }
+        pl.um = (pl.umask == 7u) ? 7u : 0u;
+        // 16 waves x 64 lanes leaves 128 VGPRs per lane: enough only for the x-uniform variant
+        if (pl.RY == 0) pl.RY = (pl.um == 7u && p.BCy != XINV_BC_EXTEND) ? 16 : 12;
+        pl.nrb = (int)cdiv(p.yc, pl.RY - 4);
+    } else
     if (pl.path == XINV_PATH_FUSED) {
         // which coefficient streams are constant along x (lat-lon grids: functions of latitude)
         {
@@ -401,7 +476,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     }
     size_t pbytes;
     if (pl.path == XINV_PATH_FUSED)
-        pbytes = (size_t)p.nbatch * XINV_KMAX * pl.nsg * pl.nrb * (sizeof(double) + sizeof(long long));
+        pbytes = (size_t)p.nbatch * XINV_KMAX * pl.nsg * pl.nrb * (sizeof(double) + sizeof(long long));   // (3-D uses a 1/KMAX prefix)
     else
         pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
     rc = ensure_dev(&ws->partials, &ws->partials_cap, pbytes);
@@ -436,7 +511,9 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             if (pl.path == XINV_PATH_FUSED) {
                 const int k = (max_sweeps - launched >= Kf) ? Kf : 1;
                 const int cur = (int)(bound.size() & 1);
-                rc = launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0);
+                rc = (p.kind == KIND_STD3D)
+                         ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
+                         : launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0);
                 if (rc) return rc;
                 bound.push_back(launched);
                 launched += k;
@@ -475,7 +552,9 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             } else {                                     // stopped inside a K-sweep launch: redo
                 int cur = (int)(i & 1);
                 for (int64_t s = bound[i]; s < sw; s++) {
-                    rc = launch_fused(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1);
+                    rc = (p.kind == KIND_STD3D)
+                             ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
+                             : launch_fused(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1);
                     if (rc) return rc;
                     cur ^= 1;
                 }
