@@ -151,7 +151,7 @@ def main():
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get('std2d_spl%d' % spl)
+                traffic = json.load(open(tfile)).get('std2d_spl%d_um%d' % (spl, s['xuniform_mask']))
             except Exception:
                 traffic = None
         out = {
@@ -164,11 +164,12 @@ def main():
                                    '(BASELINE configs[1])' % (a.nx, a.ny),
                        'sweeps_per_step': a.sweeps, 'members_per_gpu': nb,
                        'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'],
+                       'xuniform_mask': s['xuniform_mask'],
                        'path': {1: 'colour', 2: 'fused'}.get(s['path'], '?'),
                        'parallelism': 'batch-axis shard x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'k_fused2d<FusedStd2D,%d>' % spl,
+                         'kernel': 'k_fused2d<FusedStd2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask']),
                          'avg_launch_ms': avg_ms, 'alg_bytes_per_launch': alg_bytes},
         }
         if world == 1 and not a.no_cpu:
