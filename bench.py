@@ -89,6 +89,8 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, a.gpus))
     L = _lib.require_gpu()
+    # XINV_FORCE_DEVICE: testing aid (several ranks on one GPU with the gloo backend)
+    local = int(os.environ.get('XINV_FORCE_DEVICE', local))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -136,7 +138,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdev = dev if torch.distributed.get_backend() == 'nccl' else torch.device('cpu')
+        tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert int(allf[0, 2]) == a.sweeps - 1, allf[0]

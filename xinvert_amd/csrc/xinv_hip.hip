@@ -496,7 +496,11 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     const int Kf = (pl.path == XINV_PATH_FUSED) ? pl.K : 1;
     int check_every = opt.check_every;
     if (check_every <= 0) {
-        double est_us = std::max(6.0, (double)p.nbatch * (double)n * Kf / 30e3);
+        // poll the device stop flags about every 2 ms of sweeping (fused kernels run at roughly
+        // 2e5 points per microsecond, the colour path at a quarter of that); launches issued after
+        // a member has stopped are no-ops of a few microseconds each
+        const double rate = (pl.path == XINV_PATH_FUSED) ? 2.0e5 : 4.0e4;
+        const double est_us = std::max(4.0, (double)p.nbatch * (double)n * Kf / rate);
         check_every = (int)std::min(256.0, std::max(4.0, 2000.0 / est_us));
     }
     double *buf[2] = { p.S, S2 };
