@@ -59,7 +59,6 @@ struct Workspace {
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
     int *hflag = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double *stage = nullptr; size_t stage_cap = 0;      // device staging for host-pointer API
 };
 
 static std::mutex g_ws_mutex;
@@ -588,24 +587,83 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
 }
 
 // ------------------------------------------------------------------ host-pointer staging
-struct Staged {
-    std::vector<void *> dev;
-    ~Staged() { for (void *p : dev) if (p) (void)hipFree(p); }
+// Host <-> HBM path of the *_f64 / *_batched entry points.  Device buffers come from a
+// per-device pool that is kept across calls (the coefficient stack of a repeated solve is
+// re-uploaded but never re-allocated).  Large host arrays are pinned IN PLACE for the duration
+// of the call (hipHostRegister) so the DMA engines read them directly at PCIe rate and all
+// uploads are queued asynchronously on one stream; small arrays, or hosts where registration
+// fails, take the runtime's staged copy.
+struct DevPool {
+    std::vector<std::pair<void *, size_t>> bufs;   // (ptr, capacity)
+    size_t next = 0;
+    void reset() { next = 0; }
+};
+static std::mutex g_pool_mutex;
+static std::vector<std::pair<int, DevPool *>> g_pools;
+
+static DevPool *get_pool(int device)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    for (auto &e : g_pools) if (e.first == device) return e.second;
+    DevPool *p = new DevPool();
+    g_pools.push_back({device, p});
+    return p;
+}
+
+static int pool_alloc(DevPool *pool, size_t bytes, double **out)
+{
+    if (pool->next < pool->bufs.size()) {
+        auto &b = pool->bufs[pool->next];
+        if (b.second < bytes) {
+            HIPCHK(hipFree(b.first));
+            b.first = nullptr; b.second = 0;
+            HIPCHK(hipMalloc(&b.first, bytes));
+            b.second = bytes;
+        }
+        *out = (double *)b.first;
+        pool->next++;
+        return XINV_OK;
+    }
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, bytes));
+    pool->bufs.push_back({d, bytes});
+    pool->next++;
+    *out = (double *)d;
+    return XINV_OK;
+}
+
+struct Pinned {                                     // host ranges registered for this call
+    std::vector<void *> regs;
+    bool try_pin(const void *h, size_t bytes)
+    {
+        if (bytes < (1u << 20)) return false;
+        if (hipHostRegister((void *)h, bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        regs.push_back((void *)h);
+        return true;
+    }
+    ~Pinned() { for (void *h : regs) (void)hipHostUnregister(h); }
 };
 
-static int upload(Staged &sg, const double *h, int64_t nbatch, int64_t stride, int64_t n,
-                  double **out, int64_t *dstride)
+static int upload(DevPool *pool, Pinned &pin, hipStream_t st, const double *h, int64_t nbatch,
+                  int64_t stride, int64_t n, double **out, int64_t *dstride)
 {
     if (!h) { *out = nullptr; *dstride = 0; return XINV_OK; }
     const int64_t members = (stride == 0) ? 1 : nbatch;
     double *d = nullptr;
-    HIPCHK(hipMalloc((void **)&d, (size_t)members * n * sizeof(double)));
-    sg.dev.push_back(d);
+    int rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &d);
+    if (rc) return rc;
     if (members == 1 || stride == n) {
-        HIPCHK(hipMemcpy(d, h, (size_t)members * n * sizeof(double), hipMemcpyHostToDevice));
+        const size_t bytes = (size_t)members * n * sizeof(double);
+        pin.try_pin(h, bytes);
+        HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
     } else {
+        pin.try_pin(h, (size_t)((members - 1) * stride + n) * sizeof(double));
         for (int64_t m = 0; m < members; m++)
-            HIPCHK(hipMemcpy(d + m * n, h + m * stride, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpyAsync(d + m * n, h + m * stride, (size_t)n * sizeof(double),
+                                  hipMemcpyHostToDevice, st));
     }
     *out = d;
     *dstride = (stride == 0) ? 0 : n;
@@ -622,36 +680,42 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt)
         return XINV_ERR_NODEV;
     }
     if (opt && opt->device >= 0) HIPCHK(hipSetDevice(opt->device));
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
     const int64_t n = p.zc * p.yc * p.xc;
-    Staged sg;
+    DevPool *pool = get_pool(device);
+    pool->reset();
+    Pinned pin;
     Problem d = p;
     double *hS = p.S;
-    const int64_t hsS = p.sS;
+    const int64_t hsS = p.nbatch > 1 ? p.sS : n;
+    hipStream_t st = 0;
     hipEvent_t e0, e1, e2, e3;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
-    HIPCHK(hipEventRecord(e0, 0));
+    HIPCHK(hipEventRecord(e0, st));
     int64_t ds;
-    rc = upload(sg, p.S, p.nbatch, p.nbatch > 1 ? p.sS : n, n, &d.S, &ds);
+    rc = upload(pool, pin, st, p.S, p.nbatch, hsS, n, &d.S, &ds);
     if (rc) return rc;
     d.sS = n;
     for (int q = 0; q < p.ncoef; q++) {
         double *dc;
-        rc = upload(sg, p.c[q], p.nbatch, p.nbatch > 1 ? p.sc[q] : 0, n, &dc, &d.sc[q]);
+        rc = upload(pool, pin, st, p.c[q], p.nbatch, p.nbatch > 1 ? p.sc[q] : 0, n, &dc, &d.sc[q]);
         if (rc) return rc;
         d.c[q] = dc;
     }
-    HIPCHK(hipEventRecord(e1, 0));
-    rc = solve_dev(d, flags, opt, 0);
+    HIPCHK(hipEventRecord(e1, st));
+    rc = solve_dev(d, flags, opt, st);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(e2, 0));
+    HIPCHK(hipEventRecord(e2, st));
     if (p.nbatch == 1 || hsS == n) {
-        HIPCHK(hipMemcpy(hS, d.S, (size_t)p.nbatch * n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(hS, d.S, (size_t)p.nbatch * n * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {
         for (int64_t m = 0; m < p.nbatch; m++)
-            HIPCHK(hipMemcpy(hS + m * hsS, d.S + m * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpyAsync(hS + m * hsS, d.S + m * n, (size_t)n * sizeof(double),
+                                  hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(hipEventRecord(e3, 0));
+    HIPCHK(hipEventRecord(e3, st));
     HIPCHK(hipEventSynchronize(e3));
     float a = 0.f, b = 0.f;
     HIPCHK(hipEventElapsedTime(&a, e0, e1));
