@@ -201,3 +201,21 @@ def test_bad_arguments():
     p = rand2d('std2d', 2, 10, 'fixed', 'fixed', 0, 0)
     with pytest.raises(_lib.XinvError):
         run_hip_single(p, 10, 1e-9)
+
+
+@pytest.mark.parametrize('path', [PATH_COLOUR, PATH_FUSED])
+def test_more_members_than_one_grid_dimension(path):
+    """33 000 tiny slices in one call: launches are chunked over the member axis."""
+    base = rand2d('gen2d', 6, 8, 'fixed', 'periodic', 0, 0, seed=1)
+    nb = 33000
+    rng = np.random.default_rng(2)
+    G = rng.standard_normal((nb, 6, 8))
+    ps = []
+    for m in range(nb):
+        q = dict(base); q['coefs'] = list(base['coefs']); q['coefs'][-1] = G[m]
+        ps.append(q)
+    S, fl, st = run_hip_batched(ps, 6, 0.0, shared=tuple(range(6)), path=path)
+    assert st['path'] == path
+    for m in (0, 1, 32767, 32768, 32999):
+        So, flo = run_oracle(ps[m], 6, 0.0, COLOUR_2)
+        assert_same(S[m], fl[m], So, flo, 'member %d' % m)

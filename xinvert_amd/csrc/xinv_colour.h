@@ -19,6 +19,7 @@ struct ColourArgs2D {
     int seam;                  // odd xc with periodic x
     int colour;                // colour of this launch
     int force;                 // ignore ctl.done (never set in production)
+    int64_t member0;           // first member of this launch (grids are chunked to <= 32768 members)
     XinvScal sc_;
     const XinvCtl *ctl;
 };
@@ -55,7 +56,7 @@ __device__ __forceinline__ bool xinv_colour_point(const ColourArgs2D &a, int64_t
 template <bool NINE>
 __global__ __launch_bounds__(256) void k_colour_std2d(ColourArgs2D a)
 {
-    const int64_t m = blockIdx.z;
+    const int64_t m = a.member0 + blockIdx.z;
     if (!a.force && a.ctl[m].done) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k_colour_std2d(ColourArgs2D a)
 template <bool NINE>
 __global__ __launch_bounds__(256) void k_colour_gen2d(ColourArgs2D a)
 {
-    const int64_t m = blockIdx.z;
+    const int64_t m = a.member0 + blockIdx.z;
     if (!a.force && a.ctl[m].done) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
@@ -127,14 +128,14 @@ struct ColourArgs3D {
     int per, seam, colour, force;
     XinvScal sc_;
     const XinvCtl *ctl;
-    int64_t nbatch;
+    int64_t nbatch, member0;
 };
 
 // grid: x over column pairs, y over rows 1..yc-2, z over (member, plane 1..zc-2).
 __global__ __launch_bounds__(256) void k_colour_std3d(ColourArgs3D a)
 {
     const int64_t nk = a.zc - 2;
-    const int64_t m = blockIdx.z / nk;
+    const int64_t m = a.member0 + blockIdx.z / nk;
     const int64_t k = 1 + blockIdx.z % nk;
     if (!a.force && a.ctl[m].done) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,11 +178,12 @@ struct ExtendArgs {
     int per, tall, force;
     double undef;
     const XinvCtl *ctl;
+    int64_t member0;
 };
 
 __global__ __launch_bounds__(256) void k_extend(ExtendArgs a)
 {
-    const int64_t m = blockIdx.z;
+    const int64_t m = a.member0 + blockIdx.z;
     if (!a.force && a.ctl[m].done) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.xc) return;
@@ -225,11 +227,12 @@ struct NormArgs {
     XinvCtl *ctl;
     XinvStop stop;
     int force;
+    int64_t member0;
 };
 
 __global__ __launch_bounds__(256) void k_norm_partial(NormArgs a)
 {
-    const int64_t m = blockIdx.y;
+    const int64_t m = a.member0 + blockIdx.y;
     if (!a.force && a.ctl[m].done) return;
     const double *S = a.S + m * a.sS;
     double s = 0.0;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void k_norm_partial(NormArgs a)
 
 __global__ __launch_bounds__(64) void k_norm_final(NormArgs a, int nblocks)
 {
-    const int64_t m = blockIdx.x;
+    const int64_t m = a.member0 + blockIdx.x;
     if (!a.force && a.ctl[m].done) return;
     double s = 0.0;
     long long c = 0;

@@ -28,6 +28,7 @@
 #include "xinv_fused3d.h"
 
 #define XINV_VERSION 100
+#define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
 
 // ------------------------------------------------------------------ errors / thread state
 static thread_local std::string t_err;
@@ -214,11 +215,15 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     const size_t NBmax = (size_t)pl.nsg * pl.nrb;   // partials are sized for the narrowest strips (K = XINV_KMAX)
     a.psum = (unsigned long long *)ws->partials;
     a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
-    dim3 grid((unsigned)(a.nsg * a.nrb), (unsigned)nmem, 1), block(256, 1, 1);
     const bool gen = (p.kind == KIND_GEN2D);
-    const int bad = gen ? launch_fused_m<FusedGen2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a)
-                        : launch_fused_m<FusedStd2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a);
-    if (bad) return fail_arg("unsupported sweeps_per_launch for this kernel variant");
+    for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {      // grid.y is limited to 65535
+        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
+        a.member0 = member0 + m0;
+        dim3 grid((unsigned)(a.nsg * a.nrb), (unsigned)nm, 1), block(256, 1, 1);
+        const int bad = gen ? launch_fused_m<FusedGen2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a)
+                            : launch_fused_m<FusedStd2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a);
+        if (bad) return fail_arg("unsupported sweeps_per_launch for this kernel variant");
+    }
     HIPCHK(hipGetLastError());
     return XINV_OK;
 }
@@ -256,17 +261,22 @@ static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, d
     const size_t NB = (size_t)pl.nsg * pl.nrb;
     a.psum = (unsigned long long *)ws->partials;
     a.pcnt = (long long *)((char *)ws->partials + p.nbatch * NB * sizeof(double));
-    dim3 grid((unsigned)NB, (unsigned)nmem, 1);
     const bool ext = (p.BCy == XINV_BC_EXTEND), uni = (pl.um == 7u);
-    if (pl.RY == 8) launch_fused3d_nw<8>(pl.aligned, uni, ext, grid, st, a);
-    else if (pl.RY == 12) launch_fused3d_nw<12>(pl.aligned, uni, ext, grid, st, a);
-    else launch_fused3d_nw<16>(pl.aligned, uni, ext, grid, st, a);
+    for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
+        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
+        a.member0 = member0 + m0;
+        dim3 grid((unsigned)NB, (unsigned)nm, 1);
+        if (pl.RY == 8) launch_fused3d_nw<8>(pl.aligned, uni, ext, grid, st, a);
+        else if (pl.RY == 12) launch_fused3d_nw<12>(pl.aligned, uni, ext, grid, st, a);
+        else launch_fused3d_nw<16>(pl.aligned, uni, ext, grid, st, a);
+    }
     HIPCHK(hipGetLastError());
     return XINV_OK;
 }
 
 // one full coloured sweep (+ norm + stop rule) in place on p.S
-static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st)
+static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st,
+                               int64_t m0, int64_t nm)
 {
     const int per = (p.BCx == XINV_BC_PERIODIC);
     if (p.BCy == XINV_BC_EXTEND) {
@@ -275,8 +285,8 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
         e.kfirst = (p.kind == KIND_STD3D) ? 1 : 0;
         e.nk = (p.kind == KIND_STD3D) ? p.zc - 2 : 1;
         e.per = per; e.tall = (p.kind != KIND_STD3D) && (p.yc > p.xc); e.force = 0;
-        e.undef = p.sc_.undef; e.ctl = ws->ctl;
-        dim3 g(cdiv(p.xc, 256), (unsigned)e.nk, (unsigned)p.nbatch), b(256, 1, 1);
+        e.undef = p.sc_.undef; e.ctl = ws->ctl; e.member0 = m0;
+        dim3 g(cdiv(p.xc, 256), (unsigned)e.nk, (unsigned)nm), b(256, 1, 1);
         hipLaunchKernelGGL(k_extend, g, b, 0, st, e);
     }
     if (p.kind == KIND_STD3D) {
@@ -286,9 +296,9 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
         for (int q = 0; q < 4; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
         a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
         a.per = per; a.seam = pl.seam; a.force = 0; a.sc_ = p.sc_; a.ctl = ws->ctl;
-        a.nbatch = p.nbatch;
+        a.nbatch = p.nbatch; a.member0 = m0;
         dim3 b(64, 4, 1);
-        dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)(p.nbatch * (p.zc - 2)));
+        dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)(nm * (p.zc - 2)));
         for (int cc = 0; cc < pl.ncol; cc++) {
             a.colour = cc;
             hipLaunchKernelGGL(k_colour_std3d, g, b, 0, st, a);
@@ -300,9 +310,9 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
         for (int q = 0; q < p.ncoef; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
         a.yc = p.yc; a.xc = p.xc;
         a.per = per; a.base = pl.base; a.seam = pl.seam; a.force = 0;
-        a.sc_ = p.sc_; a.ctl = ws->ctl;
+        a.sc_ = p.sc_; a.ctl = ws->ctl; a.member0 = m0;
         dim3 b(64, 4, 1);
-        dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)p.nbatch);
+        dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)nm);
         const bool nine = (pl.base == 4);
         for (int cc = 0; cc < pl.ncol; cc++) {
             a.colour = cc;
@@ -319,11 +329,23 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
     n.S = p.S; n.sS = p.sS; n.n = p.zc * p.yc * p.xc; n.undef = p.sc_.undef;
     n.psum = (double *)ws->partials;
     n.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_NORM_BLOCKS * sizeof(double));
-    n.ctl = ws->ctl; n.stop = p.stop; n.force = 0;
+    n.ctl = ws->ctl; n.stop = p.stop; n.force = 0; n.member0 = m0;
     int nblk = (int)std::min<int64_t>(XINV_NORM_BLOCKS, std::max<int64_t>(1, n.n / 2048));
-    hipLaunchKernelGGL(k_norm_partial, dim3(nblk, (unsigned)p.nbatch, 1), dim3(256, 1, 1), 0, st, n);
-    hipLaunchKernelGGL(k_norm_final, dim3((unsigned)p.nbatch, 1, 1), dim3(64, 1, 1), 0, st, n, nblk);
+    hipLaunchKernelGGL(k_norm_partial, dim3(nblk, (unsigned)nm, 1), dim3(256, 1, 1), 0, st, n);
+    hipLaunchKernelGGL(k_norm_final, dim3((unsigned)nm, 1, 1), dim3(64, 1, 1), 0, st, n, nblk);
     HIPCHK(hipGetLastError());
+    return XINV_OK;
+}
+
+static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st)
+{
+    // grid.z carries members (x planes in 3-D) and is limited to 65535
+    int64_t chunk = XINV_MEMBER_CHUNK;
+    if (p.kind == KIND_STD3D) chunk = std::max<int64_t>(1, 65535 / std::max<int64_t>(1, p.zc - 2));
+    for (int64_t m0 = 0; m0 < p.nbatch; m0 += chunk) {
+        int rc = launch_colour_chunk(p, pl, ws, st, m0, std::min<int64_t>(chunk, p.nbatch - m0));
+        if (rc) return rc;
+    }
     return XINV_OK;
 }
 
@@ -969,7 +991,7 @@ static int abs_norm_dev(const double *S, int64_t n, double undef, double *out, h
     a.S = S; a.sS = 0; a.n = n; a.undef = undef;
     a.psum = (double *)ws->partials;
     a.pcnt = (long long *)((char *)ws->partials + XINV_NORM_BLOCKS * sizeof(double));
-    a.ctl = ws->ctl; a.force = 1;
+    a.ctl = ws->ctl; a.force = 1; a.member0 = 0;
     int nblk = (int)std::min<int64_t>(XINV_NORM_BLOCKS, std::max<int64_t>(1, n / 2048));
     double *dout = (double *)((char *)ws->partials + XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long)));
     hipLaunchKernelGGL(k_norm_partial, dim3(nblk, 1, 1), dim3(256, 1, 1), 0, st, a);
