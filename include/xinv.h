@@ -157,6 +157,40 @@ int xinv_standard_3d_f64_dev(double *S, const double *A, const double *B, const 
                              double *flags, int64_t mxLoop, double tolerance,
                              const xinv_options *opt, void *stream);
 
+/* ---- biharmonic 2-D form (Munk / Stommel-Munk), SURVEY 8(f) rank 1 ----------------------------
+ * xinv_general_bih_2d_f64 replaces numbas.invert_general_bih_2D called at core.py:503-516.
+ * strides[]: S,A,B,C,D,E,F,G,H,I,J.  Radius-2 stencil, 9 colours (j%3, i%3) (+3 per trailing
+ * column when x is periodic and xc % 3 != 0); colour-pass kernels; yc >= 5, xc >= 7.  The
+ * reference's east-periodic branches index the B term with a stale loop variable
+ * (numbas.py:1495-1497, 1540-1542); that behaviour is reproduced. */
+int xinv_general_bih_2d_f64(double *S, const double *A, const double *B, const double *C,
+                            const double *D, const double *E, const double *F, const double *G,
+                            const double *H, const double *I, const double *J, int64_t yc,
+                            int64_t xc, double dely, double delx, int BCy, int BCx,
+                            double delxSSr, double delxTr, double delxSqr, double ratio,
+                            double ratioSSr, double ratioQtr, double ratioSqr, double optArg,
+                            double undef, double *flags, int64_t mxLoop, double tolerance);
+
+int xinv_general_bih_2d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                    const double *D, const double *E, const double *F,
+                                    const double *G, const double *H, const double *I,
+                                    const double *J, int64_t nbatch, const int64_t *strides,
+                                    int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                                    int BCx, double delxSSr, double delxTr, double delxSqr,
+                                    double ratio, double ratioSSr, double ratioQtr,
+                                    double ratioSqr, double optArg, double undef, double *flags,
+                                    int64_t mxLoop, double tolerance, const xinv_options *opt);
+
+int xinv_general_bih_2d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                                const double *D, const double *E, const double *F,
+                                const double *G, const double *H, const double *I,
+                                const double *J, int64_t nbatch, const int64_t *strides,
+                                int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                                int BCx, double delxSSr, double delxTr, double delxSqr,
+                                double ratio, double ratioSSr, double ratioQtr, double ratioSqr,
+                                double optArg, double undef, double *flags, int64_t mxLoop,
+                                double tolerance, const xinv_options *opt, void *stream);
+
 /* mean |S| over S != undef of one device-resident slab of n elements (reference
  * numbas.absNorm2D/3D, numbas.py:1710-1728 / 1689-1708); *out is a host double. */
 int xinv_abs_norm_f64_dev(const double *S, int64_t n, double undef, double *out, void *stream);

@@ -47,6 +47,9 @@ def lib():
         L.xo_standard_3d.argtypes = [_dp] * 5 + [_i64, _i64, _i64, _f64, _f64, _f64,
                                                  _int, _int, _int, _f64, _f64, _f64, _f64,
                                                  _f64, _dp, _i64, _f64, _int]
+        L.xo_general_bih_2d.restype = _int
+        L.xo_general_bih_2d.argtypes = [_dp] * 11 + [_i64, _i64, _f64, _f64, _int, _int] + \
+            [_f64] * 9 + [_dp, _i64, _f64, _int]
         L.xo_abs_norm_2d.restype = _f64
         L.xo_abs_norm_2d.argtypes = [_dp, _i64, _i64, _f64]
         L.xo_abs_norm_3d.restype = _f64
@@ -102,6 +105,20 @@ def standard_3d(S, A, B, C, F, zc, yc, xc, delz, dely, delx, BCz, BCy, BCx, delx
     rc = lib().xo_standard_3d(_p(S), _p(A), _p(B), _p(C), _p(F), zc, yc, xc, delz, dely,
                               delx, _bc(BCz), _bc(BCy), _bc(BCx), delxSqr, ratio2Sqr,
                               ratio1Sqr, optArg, undef, _p(flags), mxLoop, tolerance, order)
+    if rc:
+        raise ValueError('oracle: bad arguments (rc=%d)' % rc)
+    return S
+
+
+def general_bih_2d(S, A, B, C, D, E, F, G, H, I, J, yc, xc, dely, delx, BCy, BCx, delxSSr,
+                   delxTr, delxSqr, ratio, ratioSSr, ratioQtr, ratioSqr, optArg, undef, flags,
+                   mxLoop, tolerance, order=LEX):
+    sh = (yc, xc)
+    _chk(S, sh, True); [_chk(a, sh) for a in (A, B, C, D, E, F, G, H, I, J)]
+    rc = lib().xo_general_bih_2d(_p(S), *[_p(a) for a in (A, B, C, D, E, F, G, H, I, J)], yc, xc,
+                                 dely, delx, _bc(BCy), _bc(BCx), delxSSr, delxTr, delxSqr, ratio,
+                                 ratioSSr, ratioQtr, ratioSqr, optArg, undef, _p(flags), mxLoop,
+                                 tolerance, order)
     if rc:
         raise ValueError('oracle: bad arguments (rc=%d)' % rc)
     return S

@@ -9,6 +9,7 @@
  *   xo_standard_2d  <- xinvert/numbas.py:215-416   invert_standard_2D
  *   xo_general_2d   <- xinvert/numbas.py:987-1201  invert_general_2D
  *   xo_standard_3d  <- xinvert/numbas.py:15-212    invert_standard_3D
+ *   xo_general_bih_2d <- xinvert/numbas.py:1204-1586 invert_general_bih_2D (radius-2, Munk)
  *   norm2d / norm3d <- xinvert/numbas.py:1710-1728 / 1689-1708  absNorm2D / absNorm3D
  *
  * Two orderings of the same point update:
@@ -408,6 +409,161 @@ int xo_standard_3d(double *S, const double *A, const double *B, const double *C,
         }
 
         double norm = norm3d(S, zc, yc, xc, undef);
+        if (ctl_step(&ctl, norm, flags, mxLoop, tolerance, 0)) break;
+    }
+    return 0;
+}
+
+
+/* ===================================================================== biharmonic 2-D
+ * numbas.py:1204-1586.  Radius-2 stencil; rows 2..yc-3 and columns 2..xc-3 are updated, plus
+ * columns 0, 1, xc-2, xc-1 when x is periodic.  Irregularities of the reference reproduced here:
+ *   - the periodic branches write the G term as `* delxTr / 2.0 * ratio`, the inner loop as
+ *     `* delxTr * ratio / 2.0` (different rounding) -> `edge`;
+ *   - the two east branches (numbas.py:1495-1497, 1540-1542) index the B term with the STALE inner
+ *     loop variable: `S[.., i-4]` / `S[.., i-3]` with i == xc-3, i.e. columns xc-7 / xc-6 instead
+ *     of xc-4 / xc-3 -> `bm2`;
+ *   - the 'extend' pre-pass differs between periodic (row 0 <- old row 1, row 1 <- row 2) and
+ *     non-periodic (rows 0, 1 <- row 2) x (numbas.py:1299-1343); its second loop is clamped to the
+ *     array bounds as in extend2d. */
+static inline void upd_bih2d(double *S, const double *const *c, int64_t xc, int64_t j,
+                             int64_t i, int64_t im2, int64_t im1, int64_t ip1, int64_t ip2,
+                             int64_t bm2, int edge, double delxSSr, double delxTr,
+                             double delxSqr, double ratio, double ratioSSr, double ratioQtr,
+                             double ratioSqr, double optArg, double undef)
+{
+    const int64_t r = j * xc, p = r + i;
+    const double A = c[0][p], B = c[1][p], C = c[2][p], D = c[3][p], E = c[4][p];
+    const double F = c[5][p], G = c[6][p], H = c[7][p], I = c[8][p], J = c[9][p];
+    int cond = (A != undef && B != undef && C != undef && D != undef && E != undef &&
+                F != undef && G != undef && H != undef && I != undef && J != undef);
+    if (!cond) return;
+    const double *r0 = S + r, *p1 = r0 + xc, *p2 = r0 + 2 * xc, *m1 = r0 - xc, *m2 = r0 - 2 * xc;
+    double gterm = G * (
+                       (p1[i] - m1[i])
+                   );
+    if (edge) gterm = gterm * delxTr / 2.0 * ratio;
+    else      gterm = gterm * delxTr * ratio / 2.0;
+    double temp = (
+        A * (
+            (p2[i] - 4.0*p1[i] + 6.0*r0[i] - 4.0*m1[i] + m2[i])
+        ) * ratioSSr +
+        B * (
+            (    p2[ip2] - 2.0*p2[i] +     p2[bm2] +
+            -2.0*r0[ip2] + 4.0*r0[i] - 2.0*r0[bm2] +
+                 m2[ip2] - 2.0*m2[i] +     m2[bm2])
+        ) * ratioSqr / 16.0 +
+        C * (
+            (r0[ip2] - 4.0*r0[ip1] + 6.0*r0[i] - 4.0*r0[im1] + r0[im2])
+        ) +
+        D * (
+            (p1[i] - r0[i])-(r0[i] - m1[i])
+        ) * ratioSqr * delxSqr +
+        E * (
+            (p1[ip1] - m1[ip1])-(p1[im1] - m1[im1])
+        ) * ratioQtr * delxSqr +
+        F * (
+            (r0[ip1] - r0[i])-(r0[i] - r0[im1])
+        ) * delxSqr +
+        gterm +
+        H * (
+            (r0[ip1] - r0[im1])
+        ) * delxTr / 2.0 + (
+        I * r0[i] - J) * delxSSr
+    );
+    temp *= -optArg / ((A*ratioSSr + C) * 6.0 +
+                        B*ratioSqr / 4.0 +
+                      -(D*ratioSqr + F) * 2.0 * delxSqr +
+                        I*delxSSr);
+    S[p] += temp;
+}
+
+static void extend_bih(double *S, int64_t yc, int64_t xc, int BCx, double undef)
+{
+    double *r0 = S, *r1 = S + xc, *r2 = S + 2 * xc;
+    double *b1 = S + (yc - 1) * xc, *b2 = S + (yc - 2) * xc, *b3 = S + (yc - 3) * xc;
+    if (BCx == BC_PERIODIC) {
+        for (int64_t i = 0; i < xc; i++) {
+            if (r2[i] != undef) { r0[i] = r1[i]; r1[i] = r2[i]; }
+            if (b3[i] != undef) { b1[i] = b3[i]; b2[i] = b3[i]; }
+        }
+    } else {
+        for (int64_t i = 1; i < xc - 1; i++) {
+            if (r2[i] != undef) { r0[i] = r2[i]; r1[i] = r2[i]; }
+            if (b3[i] != undef) { b1[i] = b3[i]; b2[i] = b3[i]; }
+        }
+        int64_t lim = yc - 1 < xc ? yc - 1 : xc;
+        for (int64_t i = 1; i < lim; i++) {
+            if (r2[i] != undef) { r0[i] = r2[i]; r1[i] = r2[i]; }
+            if (b3[i] != undef) { b1[i] = b3[i]; b2[i] = b3[i]; }
+        }
+        if (r2[2] != undef) { r0[0] = r2[2]; r0[1] = r2[2]; r1[0] = r2[2]; r1[1] = r2[2]; }
+        if (r2[xc - 3] != undef) { r0[xc - 1] = r2[xc - 3]; r0[xc - 2] = r2[xc - 3];
+                                   r1[xc - 1] = r2[xc - 3]; r1[xc - 2] = r2[xc - 3]; }
+        if (b3[2] != undef) { b1[0] = b3[2]; b2[0] = b3[2]; b1[1] = b3[2]; b2[1] = b3[2]; }
+        if (b3[xc - 3] != undef) { b1[xc - 1] = b3[xc - 3]; b1[xc - 2] = b3[xc - 3];
+                                   b2[xc - 1] = b3[xc - 3]; b2[xc - 2] = b3[xc - 3]; }
+    }
+}
+
+/* Colour of (j,i) for the radius-2 stencil: (j%3, i%3) -> 9 colours; with periodic x and
+ * xc % 3 != 0 the trailing xc%3 columns get 3 colours each (by j%3). */
+static inline int colour_bih(int64_t j, int64_t i, int64_t xc, int trail)
+{
+    if (trail && i >= xc - trail) return 9 + 3 * (int)(i - (xc - trail)) + (int)(j % 3);
+    return 3 * (int)(j % 3) + (int)(i % 3);
+}
+
+/* operands of the reference's five x-branches for column i */
+static inline void bih_cols(int64_t i, int64_t xc, int per, int64_t *im2, int64_t *im1,
+                            int64_t *ip1, int64_t *ip2, int64_t *bm2, int *edge)
+{
+    *im2 = i - 2; *im1 = i - 1; *ip1 = i + 1; *ip2 = i + 2; *edge = 0;
+    if (per) {
+        if (*im2 < 0) *im2 += xc;
+        if (*im1 < 0) *im1 += xc;
+        if (*ip1 >= xc) *ip1 -= xc;
+        if (*ip2 >= xc) *ip2 -= xc;
+        if (i < 2 || i >= xc - 2) *edge = 1;
+    }
+    *bm2 = *im2;
+    if (per && i >= xc - 2) {                 /* stale loop variable: (xc-3) - 4 or - 3 */
+        int64_t b = (i == xc - 2) ? xc - 7 : xc - 6;
+        if (b < 0) b += xc;                   /* Python negative index */
+        *bm2 = b;
+    }
+}
+
+int xo_general_bih_2d(double *S, const double *A, const double *B, const double *C,
+                      const double *D, const double *E, const double *F, const double *G,
+                      const double *H, const double *I, const double *J,
+                      int64_t yc, int64_t xc, double dely, double delx, int BCy, int BCx,
+                      double delxSSr, double delxTr, double delxSqr, double ratio,
+                      double ratioSSr, double ratioQtr, double ratioSqr, double optArg,
+                      double undef, double *flags, int64_t mxLoop, double tolerance, int order)
+{
+    (void)dely; (void)delx;
+    if (yc < 5 || xc < 7) return -1;
+    const double *c[10] = { A, B, C, D, E, F, G, H, I, J };
+    xo_ctl ctl = { 0, DBL_MAX };
+    const int per = (BCx == BC_PERIODIC);
+    const int trail = (order != XO_LEX && per) ? (int)(xc % 3) : 0;
+    const int ncol = 9 + 3 * trail;
+    const int64_t i0 = per ? 0 : 2, i1 = per ? xc : xc - 2;
+
+    for (;;) {
+        if (BCy == BC_EXTEND) extend_bih(S, yc, xc, BCx, undef);
+        const int npass = (order == XO_LEX) ? 1 : ncol;
+        for (int pass = 0; pass < npass; pass++)
+            for (int64_t j = 2; j < yc - 2; j++)
+                for (int64_t i = i0; i < i1; i++) {
+                    if (order != XO_LEX && colour_bih(j, i, xc, trail) != pass) continue;
+                    int64_t im2, im1, ip1, ip2, bm2; int edge;
+                    bih_cols(i, xc, per, &im2, &im1, &ip1, &ip2, &bm2, &edge);
+                    upd_bih2d(S, c, xc, j, i, im2, im1, ip1, ip2, bm2, edge, delxSSr, delxTr,
+                              delxSqr, ratio, ratioSSr, ratioQtr, ratioSqr, optArg, undef);
+                }
+        double norm = norm2d(S, yc, xc, undef);
         if (ctl_step(&ctl, norm, flags, mxLoop, tolerance, 0)) break;
     }
     return 0;

@@ -9,6 +9,7 @@ on the GPU box.  Re-run:  python tests/golden/gen_golden.py   (about 4 minutes).
 Fixtures written
   small_cases.npz   randomized tiny grids: every (kernel x BCy x BCx x mask x B==0/B!=0) cell,
                     inputs, S after the lexicographic sweeps, flags
+  bih_cases.npz     the same for the biharmonic kernel (numbas.invert_general_bih_2D)
   gill_matsuno.npz  the reference's Gill-Matsuno known-answer case (tests/test_GillMatsuno.py:
                     14-57 inputs; notebook 07 parameters mxLoop=600, tol=1e-5): fields + flags
   stommel.npz       tests/test_StommelWBC.py:14-55 case S2 (beta = 1.8e-11): field + flags
@@ -110,6 +111,46 @@ def small_cases():
     print('small_cases: %d cases' % cid)
 
 
+def bih_cases():
+    """numbas.invert_general_bih_2D (Munk / Stommel-Munk) on tiny random grids: every
+    BCy x BCx x mask x (B,E == 0 | != 0) cell, including the periodic east branches."""
+    rng = np.random.default_rng(20250510)
+    out, meta, cid = {}, [], 0
+    for (yc, xc) in [(9, 12), (8, 9), (11, 16), (7, 7)]:
+        for BCy in ('fixed', 'extend'):
+            for BCx in ('fixed', 'periodic', 'extend'):
+                if yc > xc and BCy == 'extend' and BCx != 'periodic':
+                    continue
+                for bnz in (0, 1):
+                    for msk in (0, 1):
+                        sh = (yc, xc)
+                        mk = lambda s=1.0: rng.uniform(0.5, 1.5, sh) * s
+                        A, C = mk(), mk()
+                        B = mk(0.3) if bnz else np.zeros(sh)
+                        D, E, F = -mk(0.5), (mk(0.1) if bnz else np.zeros(sh)), -mk(0.5)
+                        G, H, I = mk(0.05), mk(0.05), mk(0.01)
+                        J = rng.standard_normal(sh)
+                        if msk:
+                            J[rng.random(sh) < 0.15] = U
+                            A[rng.random(sh) < 0.03] = U
+                        S0 = rng.standard_normal(sh) * 0.1
+                        if msk:
+                            S0[rng.random(sh) < 0.05] = U
+                        dely, delx = 1.3, 1.1
+                        r = delx / dely
+                        S = S0.copy(); fl = np.array([0., 1., 0.])
+                        ref.invert_general_bih_2D(S, A, B, C, D, E, F, G, H, I, J, yc, xc, dely, delx,
+                                                  BCy, BCx, delx**4, delx**3, delx**2, r, r**4, r / 4,
+                                                  r**2, 0.9, U, fl, 12, 1e-9)
+                        k = 'b%03d' % cid; cid += 1
+                        out[k + '_in'] = np.stack([S0, A, B, C, D, E, F, G, H, I, J])
+                        out[k + '_S'] = S; out[k + '_flags'] = fl
+                        meta.append((k, yc, xc, BCy, BCx, dely, delx, 0.9, 12, 1e-9))
+    out['meta'] = np.array([repr(m) for m in meta])
+    np.savez_compressed(os.path.join(HERE, 'bih_cases.npz'), **out)
+    print('bih_cases: %d cases' % cid)
+
+
 def gill_matsuno():
     """Inputs as reference tests/test_GillMatsuno.py:14-40; iteration parameters as the executed
     notebook docs/source/notebooks/07_Gill_Matsuno_model.ipynb (mxLoop 600, tolerance 1e-5), whose
@@ -200,7 +241,8 @@ def real_data():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['small', 'real', 'gm', 'stommel']
+    which = sys.argv[1:] or ['small', 'bih', 'real', 'gm', 'stommel']
+    if 'bih' in which: bih_cases()
     if 'small' in which: small_cases()
     if 'real' in which: real_data()
     if 'gm' in which: gill_matsuno()

@@ -66,6 +66,29 @@ def test_invert_stommel_reference_case():
     assert abs(np.abs(S1.values).mean() / 2.7816492185e+05 - 1) < 1e-6
 
 
+def test_invert_stommel_munk_reference_case():
+    """reference tests/test_MunkWBC.py:14-58 through invert_StommelMunk.  h2 (A4 = 5e2) converges:
+    the reference's own assert holds.  h1's pin is an un-converged lexicographic iterate (see
+    tests/test_oracle_golden.py::test_munk_known_answers); for it the HIP result is checked bit for
+    bit against the oracle's 9-colour ordering at the same loop count."""
+    import xinvert_amd as xa
+    from test_oracle_golden import munk_problem
+    p, curl, x, y = munk_problem(5e2)
+    F = xa.Field(curl, ('ydef', 'xdef'), {'ydef': y, 'xdef': x})
+    iParams = {'BCs': ['fixed', 'fixed'], 'mxLoop': 4000, 'tolerance': 1e-14, 'optArg': 1.0,
+               'undef': np.nan, 'printInfo': False}
+    h2 = xa.invert_StommelMunk(F, dims=['ydef', 'xdef'], coords='cartesian', iParams=iParams,
+                               mParams={'A4': 5e2, 'beta': 1.8e-11, 'R': 0.0001, 'D': 200})
+    assert h2.values.shape == curl.shape and np.isclose(h2.values.max(), 399667.8611556)
+    Sl, _ = util.run_oracle(p, 4000, 1e-14, LEX)
+    assert util.rel_l2(h2.values, Sl) < 1e-6
+    p1, _, _, _ = munk_problem(5e3)
+    So, flo = util.run_oracle(p1, 4000, 1e-14, AUTO)
+    h1 = xa.invert_StommelMunk(F, dims=['ydef', 'xdef'], coords='cartesian', iParams=iParams,
+                               mParams={'A4': 5e3, 'beta': 1.8e-11, 'R': 0.0001, 'D': 200})
+    assert np.array_equal(h1.values, So) and h1.iParams['flags'][2] == flo[2]
+
+
 def test_invert_ishida_mask_periodic_odd_width():
     """reference tests/test_Ishida.py:13-63 (h1, h2): value-undef mask, periodic x, xc = 251."""
     import xinvert_amd as xa

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import util
-from util import rand2d, rand3d, run_oracle, run_hip_single, run_hip_batched, run_hip_dev
+from util import rand2d, rand3d, randbih, run_oracle, run_hip_single, run_hip_batched, run_hip_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -219,3 +219,30 @@ def test_more_members_than_one_grid_dimension(path):
     for m in (0, 1, 32767, 32768, 32999):
         So, flo = run_oracle(ps[m], 6, 0.0, COLOUR_2)
         assert_same(S[m], fl[m], So, flo, 'member %d' % m)
+
+
+@pytest.mark.parametrize('BCy,BCx', BCS)
+@pytest.mark.parametrize('bnz', [0, 1])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', [(9, 12), (11, 16), (7, 7), (20, 70), (14, 17)])
+def test_biharmonic_colour_path(BCy, BCx, bnz, msk, shape):
+    """numbas.invert_general_bih_2D: 9 colours (+ trailing-column colours when xc % 3 != 0 and
+    x is periodic), including the reference's stale-index east branches."""
+    p = randbih(shape[0], shape[1], BCy, BCx, bnz, msk, seed=_seed((BCy, BCx, bnz, msk, shape)))
+    So, flo = run_oracle(p, 15, 1e-9, COLOUR_AUTO)
+    S, fl, st = run_hip_batched([p], 15, 1e-9)
+    assert st['path'] == PATH_COLOUR
+    assert st['colours'] == 9 + (3 * (shape[1] % 3) if BCx == 'periodic' else 0)
+    assert_same(S[0], fl[0], So, flo, 'bih')
+    S1, f1 = run_hip_single(p, 15, 1e-9)
+    assert np.array_equal(S1, S[0])
+
+
+def test_biharmonic_batched_dev():
+    ps = [randbih(16, 33, 'extend', 'periodic', 1, 1, seed=s) for s in (3, 4)]
+    S1, f1, _ = run_hip_batched(ps, 20, 1e-7)
+    S2, f2, _ = run_hip_dev(ps, 20, 1e-7)
+    assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 20, 1e-7, COLOUR_AUTO)
+        assert_same(S1[m], f1[m], So, flo, 'bih member %d' % m)

@@ -112,3 +112,18 @@ def test_linearity_of_one_sweep(oracle):
     S2, _ = util.run_oracle(p2, 0, 0.0, C2)
     S3, _ = util.run_oracle(p3, 0, 0.0, C2)
     assert np.allclose(S3, 2.0 * S1 - 0.5 * S2, rtol=1e-11, atol=1e-11)
+
+
+def test_converged_munk_nine_colours(oracle):
+    """Biharmonic form, 9-colour ordering: the converged case of tests/test_MunkWBC.py."""
+    from test_oracle_golden import munk_problem
+    p, _, _, _ = munk_problem(5e2)
+    Sl, fl = util.run_oracle(p, 4000, 1e-14, LEX)
+    Sc, fc = util.run_oracle(p, 4000, 1e-14, AUTO)
+    assert fl[2] < 4000 and fc[2] < 4000
+    assert util.rel_l2(Sc, Sl) < 1e-6
+    assert np.isclose(Sc.max(), 399667.8611556)
+    q = util.randbih(14, 17, 'fixed', 'periodic', bnz=True, msk=True, seed=5)   # xc % 3 = 2: trailing colours
+    Sl, _ = util.run_oracle(q, 20000, 1e-15, LEX)
+    Sc, _ = util.run_oracle(q, 20000, 1e-15, AUTO)
+    assert util.rel_l2(Sc, Sl, Sl != U) < 1e-6

@@ -65,3 +65,22 @@ def test_lexicographic_oracle_equals_reference_live(oracle):
                     assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
                     n += 1
     assert n == 160
+    for (yc, xc) in [(8, 10), (7, 8)]:
+        for BCy in ('fixed', 'extend'):
+            for BCx in ('fixed', 'periodic'):
+                for bnz in (0, 1):
+                    sh = (yc, xc)
+                    mkb = lambda s=1.0: rng.uniform(0.5, 1.5, sh) * s
+                    A, C = mkb(), mkb()
+                    B = mkb(0.3) if bnz else np.zeros(sh)
+                    D, E, F = -mkb(0.5), (mkb(0.1) if bnz else np.zeros(sh)), -mkb(0.5)
+                    G, H, I = mkb(0.05), mkb(0.05), mkb(0.01)
+                    J = rng.standard_normal(sh); J[rng.random(sh) < 0.1] = U
+                    S0 = rng.standard_normal(sh) * 0.1
+                    r = 1.1 / 1.3
+                    ab = (yc, xc, 1.3, 1.1, BCy, BCx, 1.1**4, 1.1**3, 1.1**2, r, r**4, r / 4, r**2, 0.9, U)
+                    S1 = S0.copy(); f1 = np.array([0., 1., 0.])
+                    ref.invert_general_bih_2D(S1, A, B, C, D, E, F, G, H, I, J, *ab, f1, 8, 1e-9)
+                    S2 = S0.copy(); f2 = np.array([0., 1., 0.])
+                    oracle.general_bih_2d(S2, A, B, C, D, E, F, G, H, I, J, *ab, f2, 8, 1e-9)
+                    assert np.array_equal(S1, S2) and np.array_equal(f1, f2)

@@ -40,6 +40,29 @@ def rand2d(kind, yc, xc, BCy, BCx, bnz=False, msk=False, seed=0, dely=1.3, delx=
     return p
 
 
+def randbih(yc, xc, BCy, BCx, bnz=False, msk=False, seed=0, dely=1.3, delx=1.1, omega=0.9):
+    """Random biharmonic problem (10 coefficient arrays A..J)."""
+    rng = np.random.default_rng(seed)
+    sh = (yc, xc)
+    mk = lambda s=1.0: rng.uniform(0.5, 1.5, sh) * s
+    A, C = mk(), mk()
+    B = mk(0.3) if bnz else np.zeros(sh)
+    D, E, F = -mk(0.5), (mk(0.1) if bnz else np.zeros(sh)), -mk(0.5)
+    G, H, I = mk(0.05), mk(0.05), mk(0.01)
+    J = rng.standard_normal(sh)
+    if msk:
+        J[rng.random(sh) < 0.15] = U
+        A[rng.random(sh) < 0.03] = U
+    S0 = rng.standard_normal(sh) * 0.1
+    if msk:
+        S0[rng.random(sh) < 0.05] = U
+    r = delx / dely
+    return dict(kind='bih2d', yc=yc, xc=xc, BCy=BCy, BCx=BCx, dely=dely, delx=delx,
+                delxSSr=delx**4, delxTr=delx**3, delxSqr=delx**2, ratio=r, ratioSSr=r**4,
+                ratioQtr=r / 4, ratioSqr=r**2, optArg=omega, undef=U, S0=S0,
+                coefs=[A, B, C, D, E, F, G, H, I, J])
+
+
 def rand3d(zc, yc, xc, BCy, BCx, msk=False, seed=0, delz=2.0, dely=1.3, delx=1.1, omega=1.2):
     rng = np.random.default_rng(seed)
     sh = (zc, yc, xc)
@@ -71,6 +94,11 @@ def run_oracle(p, mxLoop, tol, order):
         orc.general_2d(S, *c, p['yc'], p['xc'], p['dely'], p['delx'], p['BCy'], p['BCx'],
                        p['delxSqr'], p['ratio'], p['ratioQtr'], p['ratioSqr'], p['optArg'],
                        p['undef'], fl, mxLoop, tol, order)
+    elif p['kind'] == 'bih2d':
+        orc.general_bih_2d(S, *c, p['yc'], p['xc'], p['dely'], p['delx'], p['BCy'], p['BCx'],
+                           p['delxSSr'], p['delxTr'], p['delxSqr'], p['ratio'], p['ratioSSr'],
+                           p['ratioQtr'], p['ratioSqr'], p['optArg'], p['undef'], fl, mxLoop, tol,
+                           order)
     else:
         orc.standard_3d(S, *c, p['zc'], p['yc'], p['xc'], p['delz'], p['dely'], p['delx'],
                         p['BCz'], p['BCy'], p['BCx'], p['delxSqr'], p['ratio2Sqr'], p['ratio1Sqr'],
@@ -89,12 +117,17 @@ def _scal(p, flags, mxLoop, tol):
     if p['kind'] == 'gen2d':
         return [p['yc'], p['xc'], p['dely'], p['delx'], b(p['BCy']), b(p['BCx']), p['delxSqr'],
                 p['ratio'], p['ratioQtr'], p['ratioSqr'], p['optArg'], p['undef'], fp, mxLoop, tol]
+    if p['kind'] == 'bih2d':
+        return [p['yc'], p['xc'], p['dely'], p['delx'], b(p['BCy']), b(p['BCx']), p['delxSSr'],
+                p['delxTr'], p['delxSqr'], p['ratio'], p['ratioSSr'], p['ratioQtr'], p['ratioSqr'],
+                p['optArg'], p['undef'], fp, mxLoop, tol]
     return [p['zc'], p['yc'], p['xc'], p['delz'], p['dely'], p['delx'], b(p['BCz']), b(p['BCy']),
             b(p['BCx']), p['delxSqr'], p['ratio2Sqr'], p['ratio1Sqr'], p['optArg'], p['undef'],
             fp, mxLoop, tol]
 
 
-_FN = {'std2d': 'xinv_standard_2d_f64', 'gen2d': 'xinv_general_2d_f64', 'std3d': 'xinv_standard_3d_f64'}
+_FN = {'std2d': 'xinv_standard_2d_f64', 'gen2d': 'xinv_general_2d_f64', 'std3d': 'xinv_standard_3d_f64',
+       'bih2d': 'xinv_general_bih_2d_f64'}
 
 
 def run_hip_single(p, mxLoop, tol):

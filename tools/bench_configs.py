@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-ALG = {'std2d': 48, 'gen2d': 72, 'std3d': 48}
+ALG = {'std2d': 48, 'gen2d': 72, 'std3d': 48, 'bih2d': 96}
 
 
 def main():
@@ -43,6 +43,8 @@ def main():
             p = synthetic.poisson_latlon(1800, 3600, mask=True, members=a.members or 1); sw = a.sweeps or 200
         elif name == 'c3':
             p = synthetic.stommel_cartesian(2000, 2000); sw = a.sweeps or 200
+        elif name == 'c3m':
+            p = synthetic.munk_cartesian(2000, 2000); sw = a.sweeps or 100
         elif name == 'c4':
             p = synthetic.gill_matsuno(720, 1440, a.members or 8); sw = a.sweeps or 200
         elif name == 'c5':

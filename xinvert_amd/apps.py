@@ -1,7 +1,8 @@
-"""Application front end: invert_Poisson / invert_Stommel / invert_GillMatsuno / invert_omega.
+"""Application front end: invert_Poisson / invert_Stommel / invert_StommelMunk /
+invert_GillMatsuno / invert_omega.
 
 Host-side mirror of the reference's callers of the SOR hot path (reference
-xinvert/apps.py:67-100, 443-488, 351-394, 766-827) with the same names, argument meaning,
+xinvert/apps.py:67-100, 443-488, 535-582, 351-394, 766-827) with the same names, argument meaning,
 defaults and error behaviour, restated on numpy (`Field`) because xarray is not available in
 the build/test image.  xarray.DataArray inputs are accepted and returned when xarray exists.
 
@@ -72,6 +73,13 @@ def invert_Stommel(curl, dims, coords='lat-lon', icbc=None,
     """Stommel wind-driven gyre, general 2-D form (reference apps.py:443-488)."""
     return _template(_coeffs_Stommel, core.inv_general2D, 2, curl, dims, coords,
                      icbc, ['beta', 'R', 'D', 'rho0', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_StommelMunk(curl, dims, coords='lat-lon', icbc=None,
+                       mParams=default_mParams, iParams=default_iParams):
+    """Stommel-Munk wind-driven gyre, biharmonic form (reference apps.py:535-582)."""
+    return _template(_coeffs_StommelMunk, core.inv_general2D_bih, 2, curl, dims, coords,
+                     icbc, ['A4', 'beta', 'R', 'D', 'rho0', 'g', 'Omega', 'Rearth'], mParams, iParams)
 
 
 def invert_GillMatsuno(Q, dims, coords='lat-lon', icbc=None,
@@ -277,6 +285,41 @@ def _coeffs_Stommel(curl, dims, coords, mParams, iParams, icbc):
                         ', should be in [lat-lon, z-lat, z-lon, cartesian]')
     G = _remask(-maskF.values / depth / rho0, maskF)
     return maskF.like(G), initS, (A, B, C, D, E, Fc)
+
+
+def _coeffs_StommelMunk(curl, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1793-1836."""
+    beta, A4, R, depth = mParams['beta'], mParams['A4'], mParams['R'], mParams['D']
+    rho0, Omega, Rearth = mParams['rho0'], mParams['Omega'], mParams['Rearth']
+    maskF, initS, zero = _mask_FS(curl, dims, iParams, icbc)
+    z2 = _core_zero(maskF, dims)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(np.asarray(curl[dims[0]], dtype=np.float64))
+        cosL = np.cos(lats)
+        A = z2 + A4
+        B = z2
+        C = z2 + (A4 / cosL**2.)[:, None]
+        D = z2 - R / depth
+        E = z2
+        F = z2 - (R / depth / cosL**2.)[:, None]
+        G = z2
+        H = z2 - 2. * Omega / Rearth
+        I = z2
+    elif c == 'cartesian':
+        A = z2 + A4
+        B = z2
+        C = z2 + A4
+        D = z2 - R / depth
+        E = z2
+        F = z2 - R / depth
+        G = z2
+        H = z2 - beta
+        I = z2
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    J = _remask(-maskF.values / depth / rho0, maskF)
+    return maskF.like(J), initS, (A, B, C, D, E, F, G, H, I)
 
 
 def _coeffs_GillMatsuno(Q, dims, coords, mParams, iParams, icbc):

@@ -35,6 +35,14 @@ def inv_general2D(A, B, C, D, E, F, G, S, dims, iParams):
     return _solve('gen2d', (A, B, C, D, E, F), G, S, dims, iParams)
 
 
+def inv_general2D_bih(A, B, C, D, E, F, G, H, I, J, S, dims, iParams):
+    """A Syyyy + B Syyxx + C Sxxxx + D Syy + E Syx + F Sxx + G Sy + H Sx + I S = J
+    (reference core.py:447-532; Munk / Stommel-Munk)."""
+    if len(dims) != 2:
+        raise Exception('2 dimensions are needed for inversion')
+    return _solve('bih2d', (A, B, C, D, E, F, G, H, I), J, S, dims, iParams)
+
+
 def inv_standard3D(A, B, C, F, S, dims, iParams):
     """d/dz(A dS/dz) + d/dy(B dS/dy) + d/dx(C dS/dx) = F   (reference core.py:20-85)."""
     if len(dims) != 3:
@@ -128,6 +136,14 @@ def _solve(kind, coefs, F, S, dims, iParams):
             *ptrs, nbatch, st, iParams['gc2'], iParams['gc1'],
             float(iParams['del2']), float(iParams['del1']), BCs[0], BCs[1],
             float(iParams['del1Sqr']), float(iParams['ratio']), float(iParams['ratioQtr']),
+            float(iParams['ratioSqr']), float(iParams['optArg']), _undeftmp,
+            _lib.hptr(flags), mx, tol, opt)
+    elif kind == 'bih2d':
+        rc = L.xinv_general_bih_2d_f64_batched(
+            *ptrs, nbatch, st, iParams['gc2'], iParams['gc1'],
+            float(iParams['del2']), float(iParams['del1']), BCs[0], BCs[1],
+            float(iParams['del1SSr']), float(iParams['del1Tr']), float(iParams['del1Sqr']),
+            float(iParams['ratio']), float(iParams['ratioSSr']), float(iParams['ratioQtr']),
             float(iParams['ratioSqr']), float(iParams['optArg']), _undeftmp,
             _lib.hptr(flags), mx, tol, opt)
     else:

@@ -212,6 +212,107 @@ __global__ __launch_bounds__(256) void k_extend(ExtendArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------- biharmonic 2-D (Munk)
+// numbas.invert_general_bih_2D (numbas.py:1204-1586).  Radius-2 stencil: 9 colours (j%3, i%3);
+// with periodic x and xc % 3 != 0 the trailing xc%3 columns are 3 extra colours each.
+struct ColourArgsBih {
+    double *S;
+    const double *c[10];       // A..J
+    int64_t sS, sc[10];
+    int64_t yc, xc;
+    int per, trail, colour, force;
+    int64_t member0;
+    XinvScal sc_;
+    const XinvCtl *ctl;
+};
+
+__global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
+{
+    const int64_t m = a.member0 + blockIdx.z;
+    if (!a.force && a.ctl[m].done) return;
+    const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    const int64_t xc = a.xc, yc = a.yc;
+    int64_t j, i;
+    const int cc = a.colour;
+    const int64_t ilo = a.per ? 0 : 2, ihi = a.per ? xc - 1 : xc - 3;
+    int cj;
+    if (cc >= 9) {                                     // trailing-column colours
+        if (ti != 0) return;
+        i = xc - a.trail + (cc - 9) / 3;
+        cj = (cc - 9) % 3;
+    } else {
+        cj = cc / 3;
+        const int ci = cc % 3;
+        const int64_t first = ilo + ((ci - ilo % 3) + 3) % 3;
+        i = first + 3 * ti;
+        if (i > ihi) return;
+        if (a.trail && i >= xc - a.trail) return;
+    }
+    j = 2 + ((cj - 2) % 3 + 3) % 3 + 3 * tj;           // first row >= 2 with j % 3 == cj
+    if (j > yc - 3) return;
+
+    int64_t im2 = i - 2, im1 = i - 1, ip1 = i + 1, ip2 = i + 2;
+    bool edge = false;
+    if (a.per) {
+        if (im2 < 0) im2 += xc;
+        if (im1 < 0) im1 += xc;
+        if (ip1 >= xc) ip1 -= xc;
+        if (ip2 >= xc) ip2 -= xc;
+        edge = (i < 2) || (i >= xc - 2);
+    }
+    int64_t bm2 = im2;
+    if (a.per && i >= xc - 2) {                        // numbas.py:1495-1497, 1540-1542
+        bm2 = (i == xc - 2) ? xc - 7 : xc - 6;
+        if (bm2 < 0) bm2 += xc;
+    }
+    double *S = a.S + m * a.sS;
+    const int64_t p = j * xc + i;
+    double cv[10];
+#pragma unroll
+    for (int q = 0; q < 10; q++) cv[q] = a.c[q][m * a.sc[q] + p];
+    const double *r0 = S + j * xc;
+    S[p] = xinv_upd_bih2d(r0, r0 + xc, r0 + 2 * xc, r0 - xc, r0 - 2 * xc, i, im2, im1, ip1, ip2,
+                          bm2, edge, cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7],
+                          cv[8], cv[9], a.sc_);
+}
+
+// 'extend' pre-pass of the biharmonic kernel (numbas.py:1299-1343): one thread per column.
+__global__ __launch_bounds__(256) void k_extend_bih(ExtendArgs a)
+{
+    const int64_t m = a.member0 + blockIdx.z;
+    if (!a.force && a.ctl[m].done) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.xc) return;
+    const int64_t xc = a.xc, yc = a.yc;
+    double *P = a.S + m * a.sS;
+    double *r0 = P, *r1 = P + xc, *r2 = P + 2 * xc;
+    double *b1 = P + (yc - 1) * xc, *b2 = P + (yc - 2) * xc, *b3 = P + (yc - 3) * xc;
+    const double u = a.undef;
+    if (a.per) {
+        if (r2[i] != u) { r0[i] = r1[i]; r1[i] = r2[i]; }
+        if (b3[i] != u) { b1[i] = b3[i]; b2[i] = b3[i]; }
+        return;
+    }
+    // non-periodic: loops over 1..xc-2 (and xc-1 when yc > xc), then the 2x2 corner blocks
+    double t0 = r0[i], t1 = r1[i], q1 = b1[i], q2 = b2[i];
+    const bool inloop = (i >= 1 && i <= xc - 2) || (i == xc - 1 && a.tall);
+    if (inloop) {
+        if (r2[i] != u) { t0 = r2[i]; t1 = r2[i]; }
+        if (b3[i] != u) { q1 = b3[i]; q2 = b3[i]; }
+    }
+    if (i <= 1) {
+        if (r2[2] != u) { t0 = r2[2]; t1 = r2[2]; }
+        if (b3[2] != u) { q1 = b3[2]; q2 = b3[2]; }
+    }
+    if (i >= xc - 2) {
+        if (r2[xc - 3] != u) { t0 = r2[xc - 3]; t1 = r2[xc - 3]; }
+        if (b3[xc - 3] != u) { q1 = b3[xc - 3]; q2 = b3[xc - 3]; }
+    }
+    r0[i] = t0; r1[i] = t1; b1[i] = q1; b2[i] = q2;
+}
+
 // ------------------------------------------------------------------------------ norm
 // Stage 1: per-workgroup (sum |S|, count) over S != undef in a fixed element -> thread map.
 // Stage 2: one workgroup per member adds the partials in index order and applies the

@@ -98,6 +98,7 @@ __device__ __forceinline__ double xinv_lane_down(double v)     // lane i <- lane
 struct XinvScal {
     double delx, delxSqr, ratio, ratioQtr, ratioSqr;   // 2-D
     double ratio2Sqr, ratio1Sqr;                       // 3-D
+    double delxSSr, delxTr, ratioSSr;                  // biharmonic 2-D
     double optArg, undef;
 };
 
@@ -239,5 +240,59 @@ __device__ __forceinline__ double xinv_upd_std3d(
     temp *= sc.optArg / ((aP + a0) * sc.ratio2Sqr +
                          (bP + b0) * sc.ratio1Sqr +
                          (cE + c0));
+    return sC + temp;
+}
+
+// biharmonic 2-D (numbas.py:1437-1479 inner loop; 1347-1434, 1482-1570 periodic branches).
+// r0/p1/p2/m1/m2 = rows j, j+1, j+2, j-1, j-2 of S.  `edge` and `bm2` carry the reference's
+// branch irregularities (see oracle header): the G-term association of the periodic branches
+// and the stale loop index in the east branches' B term.
+__device__ __forceinline__ double xinv_upd_bih2d(
+    const double *r0, const double *p1, const double *p2, const double *m1, const double *m2,
+    int64_t i, int64_t im2, int64_t im1, int64_t ip1, int64_t ip2, int64_t bm2, bool edge,
+    double A, double B, double C, double D, double E, double F, double G, double H, double I,
+    double J, const XinvScal &sc)
+{
+    const double u = sc.undef;
+    const double sC = r0[i];
+    bool cond = (A != u) && (B != u) && (C != u) && (D != u) && (E != u) && (F != u) &&
+                (G != u) && (H != u) && (I != u) && (J != u);
+    if (!cond) return sC;
+    double gterm = G * (
+                       (p1[i] - m1[i])
+                   );
+    if (edge) gterm = gterm * sc.delxTr / 2.0 * sc.ratio;
+    else      gterm = gterm * sc.delxTr * sc.ratio / 2.0;
+    double temp = (
+        A * (
+            (p2[i] - 4.0*p1[i] + 6.0*r0[i] - 4.0*m1[i] + m2[i])
+        ) * sc.ratioSSr +
+        B * (
+            (    p2[ip2] - 2.0*p2[i] +     p2[bm2] +
+            -2.0*r0[ip2] + 4.0*r0[i] - 2.0*r0[bm2] +
+                 m2[ip2] - 2.0*m2[i] +     m2[bm2])
+        ) * sc.ratioSqr / 16.0 +
+        C * (
+            (r0[ip2] - 4.0*r0[ip1] + 6.0*r0[i] - 4.0*r0[im1] + r0[im2])
+        ) +
+        D * (
+            (p1[i] - r0[i])-(r0[i] - m1[i])
+        ) * sc.ratioSqr * sc.delxSqr +
+        E * (
+            (p1[ip1] - m1[ip1])-(p1[im1] - m1[im1])
+        ) * sc.ratioQtr * sc.delxSqr +
+        F * (
+            (r0[ip1] - r0[i])-(r0[i] - r0[im1])
+        ) * sc.delxSqr +
+        gterm +
+        H * (
+            (r0[ip1] - r0[im1])
+        ) * sc.delxTr / 2.0 + (
+        I * r0[i] - J) * sc.delxSSr
+    );
+    temp *= -sc.optArg / ((A*sc.ratioSSr + C) * 6.0 +
+                           B*sc.ratioSqr / 4.0 +
+                         -(D*sc.ratioSqr + F) * 2.0 * sc.delxSqr +
+                           I*sc.delxSSr);
     return sC + temp;
 }

@@ -86,14 +86,14 @@ static int ensure_dev(T **p, size_t *cap, size_t need_bytes)
 }
 
 // ------------------------------------------------------------------ problem description
-enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2 };
+enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3 };
 
 struct Problem {
     int kind;
     int64_t nbatch, zc, yc, xc;
     double *S;
-    const double *c[7];          // std2d/std3d: A,B,C,F ; gen2d: A,B,C,D,E,F,G
-    int64_t sS, sc[7];
+    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J
+    int64_t sS, sc[10];
     int ncoef;
     int BCz, BCy, BCx;
     XinvScal sc_;
@@ -106,13 +106,15 @@ static int validate(const Problem &p, const double *flags)
 {
     if (!p.S || !flags) return fail_arg("null S or flags");
     for (int q = 0; q < p.ncoef; q++)
-        if (!p.c[q] && !(q == 1 && p.kind != KIND_STD3D))   // B may be NULL in 2-D: identically 0
+        if (!p.c[q] && !(q == 1 && (p.kind == KIND_STD2D || p.kind == KIND_GEN2D)))   // B may be NULL: identically 0
             return fail_arg("null coefficient array");
     if (p.nbatch < 1) return fail_arg("nbatch < 1");
     if (p.yc < 3 || p.xc < 3 || (p.kind == KIND_STD3D && p.zc < 3))
         return fail_arg("every core dimension needs at least 3 points");
     if (!bc_ok(p.BCy) || !bc_ok(p.BCx) || (p.kind == KIND_STD3D && !bc_ok(p.BCz)))
         return fail_arg("unknown boundary-condition code");
+    if (p.kind == KIND_BIH2D && (p.yc < 5 || p.xc < 7))
+        return fail_arg("the biharmonic form needs yc >= 5 and xc >= 7");
     if (p.stop.mxLoop < 0) return fail_arg("mxLoop < 0");
     const int64_t n = p.zc * p.yc * p.xc;
     if (p.nbatch > 1 && p.sS < n) return fail_arg("S batch stride smaller than one slice");
@@ -279,7 +281,27 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
                                int64_t m0, int64_t nm)
 {
     const int per = (p.BCx == XINV_BC_PERIODIC);
-    if (p.BCy == XINV_BC_EXTEND) {
+    if (p.kind == KIND_BIH2D) {
+        if (p.BCy == XINV_BC_EXTEND) {
+            ExtendArgs e;
+            e.S = p.S; e.sS = p.sS; e.yc = p.yc; e.xc = p.xc; e.kfirst = 0; e.nk = 1;
+            e.per = per; e.tall = (p.yc > p.xc); e.force = 0;
+            e.undef = p.sc_.undef; e.ctl = ws->ctl; e.member0 = m0;
+            hipLaunchKernelGGL(k_extend_bih, dim3(cdiv(p.xc, 256), 1, (unsigned)nm), dim3(256, 1, 1), 0, st, e);
+        }
+        ColourArgsBih a;
+        memset(&a, 0, sizeof a);
+        a.S = p.S; a.sS = p.sS;
+        for (int q = 0; q < 10; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
+        a.yc = p.yc; a.xc = p.xc; a.per = per; a.trail = pl.seam; a.force = 0; a.member0 = m0;
+        a.sc_ = p.sc_; a.ctl = ws->ctl;
+        dim3 b(64, 4, 1);
+        dim3 g(cdiv(cdiv(p.xc, 3) + 1, 64), cdiv(cdiv(p.yc, 3) + 1, 4), (unsigned)nm);
+        for (int cc = 0; cc < pl.ncol; cc++) {
+            a.colour = cc;
+            hipLaunchKernelGGL(k_colour_bih2d, g, b, 0, st, a);
+        }
+    } else if (p.BCy == XINV_BC_EXTEND) {
         ExtendArgs e;
         e.S = p.S; e.sS = p.sS; e.yc = p.yc; e.xc = p.xc;
         e.kfirst = (p.kind == KIND_STD3D) ? 1 : 0;
@@ -289,7 +311,9 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
         dim3 g(cdiv(p.xc, 256), (unsigned)e.nk, (unsigned)nm), b(256, 1, 1);
         hipLaunchKernelGGL(k_extend, g, b, 0, st, e);
     }
-    if (p.kind == KIND_STD3D) {
+    if (p.kind == KIND_BIH2D) {
+        // sweeps launched above
+    } else if (p.kind == KIND_STD3D) {
         ColourArgs3D a;
         memset(&a, 0, sizeof a);
         a.S = p.S; a.sS = p.sS;
@@ -375,6 +399,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     memset(&pl, 0, sizeof pl);
     if (p.kind == KIND_STD3D) {
         pl.base = 2;
+    } else if (p.kind == KIND_BIH2D) {
+        pl.base = 9;                                   // radius-2 stencil: (j%3, i%3)
     } else {
         bool bzero = (p.c[1] == nullptr);
         if (!bzero && p.sc_.undef != 0.0) {
@@ -387,11 +413,16 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         }
         pl.base = bzero ? 2 : 4;
     }
-    pl.seam = (p.BCx == XINV_BC_PERIODIC) && (p.xc & 1);
-    pl.ncol = pl.base + (pl.seam ? 2 : 0);
+    if (p.kind == KIND_BIH2D) {
+        pl.seam = (p.BCx == XINV_BC_PERIODIC) ? (int)(p.xc % 3) : 0;     // trailing columns
+        pl.ncol = 9 + 3 * pl.seam;
+    } else {
+        pl.seam = (p.BCx == XINV_BC_PERIODIC) && (p.xc & 1);
+        pl.ncol = pl.base + (pl.seam ? 2 : 0);
+    }
 
     // ---- path ------------------------------------------------------------------------------
-    const bool fused_ok = pl.base == 2 && !pl.seam;
+    const bool fused_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D;
     pl.path = XINV_PATH_COLOUR;
     if (fused_ok && opt.path != XINV_PATH_COLOUR) pl.path = XINV_PATH_FUSED;
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
@@ -798,6 +829,27 @@ static Problem mk_gen2d(double *S, const double *A, const double *B, const doubl
     return p;
 }
 
+static Problem mk_bih2d(double *S, const double *const *co, int64_t nbatch, const int64_t *st,
+                        int64_t yc, int64_t xc, int BCy, int BCx, double delxSSr, double delxTr,
+                        double delxSqr, double ratio, double ratioSSr, double ratioQtr,
+                        double ratioSqr, double optArg, double undef, int64_t mxLoop, double tol)
+{
+    Problem p;
+    memset(&p, 0, sizeof p);
+    p.kind = KIND_BIH2D; p.nbatch = nbatch; p.zc = 1; p.yc = yc; p.xc = xc;
+    p.S = S; p.ncoef = 10;
+    const int64_t n = yc * xc;
+    p.sS = st ? st[0] : n;
+    for (int q = 0; q < 10; q++) { p.c[q] = co[q]; p.sc[q] = st ? st[1 + q] : n; }
+    p.BCz = 0; p.BCy = BCy; p.BCx = BCx;
+    memset(&p.sc_, 0, sizeof p.sc_);
+    p.sc_.delxSSr = delxSSr; p.sc_.delxTr = delxTr; p.sc_.delxSqr = delxSqr; p.sc_.ratio = ratio;
+    p.sc_.ratioSSr = ratioSSr; p.sc_.ratioQtr = ratioQtr; p.sc_.ratioSqr = ratioSqr;
+    p.sc_.optArg = optArg; p.sc_.undef = undef;
+    p.stop.mxLoop = mxLoop; p.stop.tolerance = tol; p.stop.stop_on_zero_norm = 0;
+    return p;
+}
+
 static Problem mk_std3d(double *S, const double *A, const double *B, const double *C,
                         const double *F, int64_t nbatch, const int64_t *st, int64_t zc,
                         int64_t yc, int64_t xc, int BCz, int BCy, int BCx, double delxSqr,
@@ -972,6 +1024,57 @@ int xinv_standard_3d_f64_dev(double *S, const double *A, const double *B, const 
     if (!strides) return fail_arg("null strides");
     Problem p = mk_std3d(S, A, B, C, F, nbatch, strides, zc, yc, xc, BCz, BCy, BCx, delxSqr,
                          ratio2Sqr, ratio1Sqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
+}
+
+int xinv_general_bih_2d_f64(double *S, const double *A, const double *B, const double *C,
+                            const double *D, const double *E, const double *F, const double *G,
+                            const double *H, const double *I, const double *J, int64_t yc,
+                            int64_t xc, double dely, double delx, int BCy, int BCx,
+                            double delxSSr, double delxTr, double delxSqr, double ratio,
+                            double ratioSSr, double ratioQtr, double ratioSqr, double optArg,
+                            double undef, double *flags, int64_t mxLoop, double tolerance)
+{
+    (void)dely; (void)delx;
+    const double *co[10] = { A, B, C, D, E, F, G, H, I, J };
+    Problem p = mk_bih2d(S, co, 1, nullptr, yc, xc, BCy, BCx, delxSSr, delxTr, delxSqr, ratio,
+                         ratioSSr, ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, nullptr))
+}
+
+int xinv_general_bih_2d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                    const double *D, const double *E, const double *F,
+                                    const double *G, const double *H, const double *I,
+                                    const double *J, int64_t nbatch, const int64_t *strides,
+                                    int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                                    int BCx, double delxSSr, double delxTr, double delxSqr,
+                                    double ratio, double ratioSSr, double ratioQtr,
+                                    double ratioSqr, double optArg, double undef, double *flags,
+                                    int64_t mxLoop, double tolerance, const xinv_options *opt)
+{
+    (void)dely; (void)delx;
+    if (!strides) return fail_arg("null strides");
+    const double *co[10] = { A, B, C, D, E, F, G, H, I, J };
+    Problem p = mk_bih2d(S, co, nbatch, strides, yc, xc, BCy, BCx, delxSSr, delxTr, delxSqr,
+                         ratio, ratioSSr, ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, opt))
+}
+
+int xinv_general_bih_2d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                                const double *D, const double *E, const double *F,
+                                const double *G, const double *H, const double *I,
+                                const double *J, int64_t nbatch, const int64_t *strides,
+                                int64_t yc, int64_t xc, double dely, double delx, int BCy,
+                                int BCx, double delxSSr, double delxTr, double delxSqr,
+                                double ratio, double ratioSSr, double ratioQtr, double ratioSqr,
+                                double optArg, double undef, double *flags, int64_t mxLoop,
+                                double tolerance, const xinv_options *opt, void *stream)
+{
+    (void)dely; (void)delx;
+    if (!strides) return fail_arg("null strides");
+    const double *co[10] = { A, B, C, D, E, F, G, H, I, J };
+    Problem p = mk_bih2d(S, co, nbatch, strides, yc, xc, BCy, BCx, delxSSr, delxTr, delxSqr,
+                         ratio, ratioSSr, ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
     GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
 }
 

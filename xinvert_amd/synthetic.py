@@ -78,6 +78,26 @@ def stommel_cartesian(ny, nx, seed=SEED, varying_R=True):
                 S0=initS.values[None], coefs=list(cs) + [G.values[None]], shared=(0, 1, 2, 3, 4, 5))
 
 
+def munk_cartesian(ny, nx, seed=SEED):
+    """Config 3 (Munk branch): Stommel-Munk gyre, biharmonic form, Cartesian box."""
+    rng = np.random.default_rng(seed)
+    Lx, Ly = 1e7, 2 * np.pi * 1e6
+    x = np.linspace(0, Lx, nx); y = np.linspace(0, Ly, ny)
+    yg = y[:, None] + 0 * x[None, :]
+    curl = -0.3 * np.sin(np.pi * yg / Ly) * np.pi / Ly * (1.0 + 0.1 * rng.standard_normal((ny, nx)))
+    F = Field(curl, ('ydef', 'xdef'), {'ydef': y, 'xdef': x})
+    iP = apps._update(apps.default_iParams, {'BCs': ['fixed', 'fixed']})
+    mP = dict(apps.default_mParams); mP.update({'A4': 5e2 * (151.0 / ny) ** 0, 'beta': 1.8e-11, 'R': 1e-4, 'D': 200})
+    J, initS, cs = apps._coeffs_StommelMunk(F, ['ydef', 'xdef'], 'cartesian', mP, iP, None)
+    ps = apps._cal_params2D(y, x, 'cartesian')
+    return dict(kind='bih2d', yc=ny, xc=nx, BCy='fixed', BCx='fixed', dely=ps['del2'], delx=ps['del1'],
+                delxSSr=ps['del1SSr'], delxTr=ps['del1Tr'], delxSqr=ps['del1Sqr'], ratio=ps['ratio'],
+                ratioSSr=ps['ratioSSr'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'],
+                optArg=1.0, undef=apps._undeftmp, S0=initS.values[None],
+                coefs=[np.ascontiguousarray(c) for c in cs] + [J.values[None]],
+                shared=tuple(range(9)))
+
+
 def gill_matsuno(ny, nx, members, seed=SEED):
     """Config 4: Gill-Matsuno response to `members` Gaussian heat sources."""
     rng = np.random.default_rng(seed)
