@@ -191,6 +191,32 @@ int xinv_general_bih_2d_f64_dev(double *S, const double *A, const double *B, con
                                 double optArg, double undef, double *flags, int64_t mxLoop,
                                 double tolerance, const xinv_options *opt, void *stream);
 
+/* ---- standard 2-D "test" form (Fofonoff, Bretherton-Haidvogel), SURVEY 8(f) rank 2 -------------
+ * xinv_standard_2d_test_f64 replaces numbas.invert_standard_2D_test called at core.py:205-215:
+ * d/dy(A Sy + B Sx) + d/dx(C Sy + D Sx) + E S = F.  strides[]: S,A,B,C,D,E,F.  Red-black fused
+ * kernels when B and C are identically zero, 4-colour passes otherwise. */
+int xinv_standard_2d_test_f64(double *S, const double *A, const double *B, const double *C,
+                              const double *D, const double *E, const double *F, int64_t yc,
+                              int64_t xc, double dely, double delx, int BCy, int BCx,
+                              double delxSqr, double ratioQtr, double ratioSqr, double optArg,
+                              double undef, double *flags, int64_t mxLoop, double tolerance);
+
+int xinv_standard_2d_test_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                      const double *D, const double *E, const double *F,
+                                      int64_t nbatch, const int64_t *strides, int64_t yc,
+                                      int64_t xc, double dely, double delx, int BCy, int BCx,
+                                      double delxSqr, double ratioQtr, double ratioSqr,
+                                      double optArg, double undef, double *flags, int64_t mxLoop,
+                                      double tolerance, const xinv_options *opt);
+
+int xinv_standard_2d_test_f64_dev(double *S, const double *A, const double *B, const double *C,
+                                  const double *D, const double *E, const double *F,
+                                  int64_t nbatch, const int64_t *strides, int64_t yc, int64_t xc,
+                                  double dely, double delx, int BCy, int BCx, double delxSqr,
+                                  double ratioQtr, double ratioSqr, double optArg, double undef,
+                                  double *flags, int64_t mxLoop, double tolerance,
+                                  const xinv_options *opt, void *stream);
+
 /* mean |S| over S != undef of one device-resident slab of n elements (reference
  * numbas.absNorm2D/3D, numbas.py:1710-1728 / 1689-1708); *out is a host double. */
 int xinv_abs_norm_f64_dev(const double *S, int64_t n, double undef, double *out, void *stream);

@@ -50,6 +50,10 @@ def lib():
         L.xo_general_bih_2d.restype = _int
         L.xo_general_bih_2d.argtypes = [_dp] * 11 + [_i64, _i64, _f64, _f64, _int, _int] + \
             [_f64] * 9 + [_dp, _i64, _f64, _int]
+        L.xo_standard_2d_test.restype = _int
+        L.xo_standard_2d_test.argtypes = [_dp] * 7 + [_i64, _i64, _f64, _f64, _int, _int,
+                                                      _f64, _f64, _f64, _f64, _f64, _dp, _i64,
+                                                      _f64, _int]
         L.xo_abs_norm_2d.restype = _f64
         L.xo_abs_norm_2d.argtypes = [_dp, _i64, _i64, _f64]
         L.xo_abs_norm_3d.restype = _f64
@@ -119,6 +123,18 @@ def general_bih_2d(S, A, B, C, D, E, F, G, H, I, J, yc, xc, dely, delx, BCy, BCx
                                  dely, delx, _bc(BCy), _bc(BCx), delxSSr, delxTr, delxSqr, ratio,
                                  ratioSSr, ratioQtr, ratioSqr, optArg, undef, _p(flags), mxLoop,
                                  tolerance, order)
+    if rc:
+        raise ValueError('oracle: bad arguments (rc=%d)' % rc)
+    return S
+
+
+def standard_2d_test(S, A, B, C, D, E, F, yc, xc, dely, delx, BCy, BCx, delxSqr, ratioQtr,
+                     ratioSqr, optArg, undef, flags, mxLoop, tolerance, order=LEX):
+    sh = (yc, xc)
+    _chk(S, sh, True); [_chk(a, sh) for a in (A, B, C, D, E, F)]
+    rc = lib().xo_standard_2d_test(_p(S), *[_p(a) for a in (A, B, C, D, E, F)], yc, xc, dely, delx,
+                                   _bc(BCy), _bc(BCx), delxSqr, ratioQtr, ratioSqr, optArg, undef,
+                                   _p(flags), mxLoop, tolerance, order)
     if rc:
         raise ValueError('oracle: bad arguments (rc=%d)' % rc)
     return S

@@ -10,6 +10,7 @@
  *   xo_general_2d   <- xinvert/numbas.py:987-1201  invert_general_2D
  *   xo_standard_3d  <- xinvert/numbas.py:15-212    invert_standard_3D
  *   xo_general_bih_2d <- xinvert/numbas.py:1204-1586 invert_general_bih_2D (radius-2, Munk)
+ *   xo_standard_2d_test <- xinvert/numbas.py:420-629 invert_standard_2D_test (Fofonoff, Bretherton)
  *   norm2d / norm3d <- xinvert/numbas.py:1710-1728 / 1689-1708  absNorm2D / absNorm3D
  *
  * Two orderings of the same point update:
@@ -565,6 +566,81 @@ int xo_general_bih_2d(double *S, const double *A, const double *B, const double 
                 }
         double norm = norm2d(S, yc, xc, undef);
         if (ctl_step(&ctl, norm, flags, mxLoop, tolerance, 0)) break;
+    }
+    return 0;
+}
+
+/* ===================================================================== standard 2-D "test" form
+ * numbas.py:420-629:  d/dy(A Sy + B Sx) + d/dx(C Sy + D Sx) + E S = F.  Same sweep, pre-pass,
+ * stop rule (incl. norm == 0) and west-branch irregularities as invert_standard_2D. */
+static inline void upd_std2dt(double *S, const double *A, const double *B, const double *C,
+                              const double *D, const double *E, const double *F, int64_t xc,
+                              int64_t j, int64_t i, int64_t im, int64_t ip, int west,
+                              double delxSqr, double ratioQtr, double ratioSqr, double optArg,
+                              double undef)
+{
+    const int64_t r = j * xc, rp = (j + 1) * xc, rm = (j - 1) * xc;
+    const int64_t bn = west ? ip : i, sq = west ? i : ip;
+    int cond = (F[r + i] != undef &&
+                A[rp + i] != undef && A[r + i] != undef &&
+                B[rp + i] != undef && B[rm + i] != undef &&
+                C[r + ip] != undef && C[r + im] != undef &&
+                D[r + ip] != undef && D[r + i] != undef &&
+                E[r + i] != undef);
+    if (!cond) return;
+    double temp = (
+        (
+            A[rp + i] * (S[rp + i] - S[r + i]) -
+            A[r + i] * (S[r + i] - S[rm + i])
+        ) * ratioSqr + (
+            B[rp + bn] * (S[rp + ip] - S[rp + im]) -
+            B[rm + i] * (S[rm + sq] - S[rm + im])
+        ) * ratioQtr + (
+            C[r + ip] * (S[rp + ip] - S[rm + ip]) -
+            C[r + im] * (S[rp + im] - S[rm + im])
+        ) * ratioQtr + (
+            D[r + ip] * (S[r + ip] - S[r + i]) -
+            D[r + i] * (S[r + i] - S[r + im])
+        )
+    ) + (E[r + i] * S[r + i] - F[r + i]) * delxSqr;
+    temp *= optArg / ((A[rp + i] + A[r + i]) * ratioSqr +
+                      (D[r + ip] + D[r + i]) - E[r + i] * delxSqr);
+    S[r + i] += temp;
+}
+
+int xo_standard_2d_test(double *S, const double *A, const double *B, const double *C,
+                        const double *D, const double *E, const double *F, int64_t yc,
+                        int64_t xc, double dely, double delx, int BCy, int BCx, double delxSqr,
+                        double ratioQtr, double ratioSqr, double optArg, double undef,
+                        double *flags, int64_t mxLoop, double tolerance, int order)
+{
+    (void)dely; (void)delx;
+    if (yc < 3 || xc < 3) return -1;
+    xo_ctl ctl = { 0, DBL_MAX };
+    const int per = (BCx == BC_PERIODIC);
+    int base = 0, seam = 0;
+    if (order != XO_LEX) {
+        base = order == XO_COLOUR_AUTO
+                   ? ((all_zero(B, yc * xc) && all_zero(C, yc * xc)) ? 2 : 4) : order;
+        seam = per && (xc & 1);
+    }
+    const int ncol = base + (seam ? 2 : 0);
+    const int64_t i0 = per ? 0 : 1, i1 = per ? xc : xc - 1;
+
+    for (;;) {
+        if (BCy == BC_EXTEND) extend2d(S, yc, xc, BCx, undef);
+        const int npass = (order == XO_LEX) ? 1 : ncol;
+        for (int c = 0; c < npass; c++)
+            for (int64_t j = 1; j < yc - 1; j++)
+                for (int64_t i = i0; i < i1; i++) {
+                    if (order != XO_LEX && colour2d(j, i, xc, base, seam) != c) continue;
+                    int64_t im = i == 0 ? xc - 1 : i - 1;
+                    int64_t ip = i == xc - 1 ? 0 : i + 1;
+                    upd_std2dt(S, A, B, C, D, E, F, xc, j, i, im, ip, i == 0,
+                               delxSqr, ratioQtr, ratioSqr, optArg, undef);
+                }
+        double norm = norm2d(S, yc, xc, undef);
+        if (ctl_step(&ctl, norm, flags, mxLoop, tolerance, 1)) break;
     }
     return 0;
 }

@@ -10,6 +10,7 @@ Fixtures written
   small_cases.npz   randomized tiny grids: every (kernel x BCy x BCx x mask x B==0/B!=0) cell,
                     inputs, S after the lexicographic sweeps, flags
   bih_cases.npz     the same for the biharmonic kernel (numbas.invert_general_bih_2D)
+  std2dt_cases.npz  the same for numbas.invert_standard_2D_test
   gill_matsuno.npz  the reference's Gill-Matsuno known-answer case (tests/test_GillMatsuno.py:
                     14-57 inputs; notebook 07 parameters mxLoop=600, tol=1e-5): fields + flags
   stommel.npz       tests/test_StommelWBC.py:14-55 case S2 (beta = 1.8e-11): field + flags
@@ -151,6 +152,38 @@ def bih_cases():
     print('bih_cases: %d cases' % cid)
 
 
+def std2dt_cases():
+    """numbas.invert_standard_2D_test on tiny random grids."""
+    rng = np.random.default_rng(20250511)
+    out, meta, cid = {}, [], 0
+    for (yc, xc) in [(9, 12), (8, 9), (11, 16)]:
+        for BCy in ('fixed', 'extend'):
+            for BCx in ('fixed', 'periodic', 'extend'):
+                for bnz in (0, 1):
+                    for msk in (0, 1):
+                        sh = (yc, xc)
+                        mk = lambda s=1.0: rng.uniform(0.5, 1.5, sh) * s
+                        A, D = mk(), mk()
+                        B = rng.uniform(-.2, .2, sh) if bnz else np.zeros(sh)
+                        C = rng.uniform(-.2, .2, sh) if bnz else np.zeros(sh)
+                        E = -mk(0.05); F = rng.standard_normal(sh)
+                        if msk:
+                            F[rng.random(sh) < 0.15] = U
+                            A[rng.random(sh) < 0.03] = U
+                        S0 = rng.standard_normal(sh) * 0.1
+                        r = 1.1 / 1.3
+                        S = S0.copy(); fl = np.array([0., 1., 0.])
+                        ref.invert_standard_2D_test(S, A, B, C, D, E, F, yc, xc, 1.3, 1.1, BCy, BCx,
+                                                    1.1**2, r / 4, r**2, 1.3, U, fl, 12, 1e-9)
+                        k = 't%03d' % cid; cid += 1
+                        out[k + '_in'] = np.stack([S0, A, B, C, D, E, F])
+                        out[k + '_S'] = S; out[k + '_flags'] = fl
+                        meta.append((k, yc, xc, BCy, BCx, 1.3, 1.1, 1.3, 12, 1e-9))
+    out['meta'] = np.array([repr(m) for m in meta])
+    np.savez_compressed(os.path.join(HERE, 'std2dt_cases.npz'), **out)
+    print('std2dt_cases: %d cases' % cid)
+
+
 def gill_matsuno():
     """Inputs as reference tests/test_GillMatsuno.py:14-40; iteration parameters as the executed
     notebook docs/source/notebooks/07_Gill_Matsuno_model.ipynb (mxLoop 600, tolerance 1e-5), whose
@@ -241,8 +274,9 @@ def real_data():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['small', 'bih', 'real', 'gm', 'stommel']
+    which = sys.argv[1:] or ['small', 'bih', 'std2dt', 'real', 'gm', 'stommel']
     if 'bih' in which: bih_cases()
+    if 'std2dt' in which: std2dt_cases()
     if 'small' in which: small_cases()
     if 'real' in which: real_data()
     if 'gm' in which: gill_matsuno()

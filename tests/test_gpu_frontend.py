@@ -89,6 +89,54 @@ def test_invert_stommel_munk_reference_case():
     assert np.array_equal(h1.values, So) and h1.iParams['flags'][2] == flo[2]
 
 
+def test_invert_fofonoff_reference_case():
+    """reference tests/test_Fofonoff.py:13-44 through invert_Fofonoff (fused kernel, x-uniform
+    A, D, E): shape/dims asserts of the reference + converged field vs the reference ordering."""
+    import xinvert_amd as xa
+    from test_oracle_golden import fofonoff_problem
+    p, Fv, xc, yc = fofonoff_problem()
+    F = xa.Field(Fv, ('y', 'x'), {'y': yc, 'x': xc})
+    assert F.shape == (251, 301)
+    sf = xa.invert_Fofonoff(F, dims=['y', 'x'], coords='cartesian',
+                            iParams={'BCs': ['fixed', 'fixed'], 'mxLoop': 2000, 'tolerance': 1e-14,
+                                     'optArg': 1.2, 'printInfo': False},
+                            mParams={'f0': 1e-4, 'beta': 2e-11, 'c0': 8e-9, 'c1': 1e-4})
+    assert sf.dims == F.dims and sf.shape == F.shape
+    assert sf.iParams['stats']['path'] == 2 and sf.iParams['stats']['xuniform_mask'] == 7
+    Sl, _ = util.run_oracle(p, 4000, 1e-14, LEX)
+    assert util.rel_l2(sf.values, Sl) < 1e-6
+
+
+def test_invert_bretherton_synthetic_topography():
+    """invert_BrethertonHaidvogel (reference tests/test_Bretherton.py:13-31 call shape) on a
+    synthetic seamount: HIP bit-equal to the oracle's ordering, converged within 1e-6 of the
+    reference ordering."""
+    import xinvert_amd as xa
+    from xinvert_amd import apps
+    x = np.linspace(0, 3e5, 121); y = np.linspace(0, 2e5, 81)
+    topo = 300.0 * np.exp(-(((x[None, :] - 1.5e5) / 4e4) ** 2 + ((y[:, None] - 1e5) / 3e4) ** 2))
+    topo = topo - topo.mean()
+    h = xa.Field(topo, ('y', 'x'), {'y': y, 'x': x})
+    # fixed sweep count for the bitwise check: a stop test at 1e-14 sits in the rounding noise of
+    # the norm, whose summation order differs between the device and the serial oracle
+    iParams = {'BCs': ['fixed', 'fixed'], 'mxLoop': 300, 'tolerance': 0.0, 'undef': np.nan, 'printInfo': False}
+    mParams = {'f0': 1e-4, 'D': 1000, 'lambda': 1e-15}
+    S1 = xa.invert_BrethertonHaidvogel(h, dims=['y', 'x'], coords='cartesian', mParams=mParams, iParams=iParams)
+    iP = apps._update(apps.default_iParams, iParams)
+    mP = apps._update(apps.default_mParams, mParams)
+    Fm, initS, cs = apps._coeffs_Bretherton(h, ['y', 'x'], 'cartesian', mP, iP, None)
+    ps = apps._cal_params2D(y, x, 'cartesian')
+    p = dict(kind='std2dt', yc=81, xc=121, BCy='fixed', BCx='fixed', dely=ps['del2'], delx=ps['del1'],
+             delxSqr=ps['del1Sqr'], ratio=ps['ratio'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'],
+             optArg=ps['optArg'], undef=U, S0=np.zeros((81, 121)),
+             coefs=[np.ascontiguousarray(c) for c in cs] + [Fm.values])
+    So, flo = util.run_oracle(p, 300, 0.0, C2)
+    assert np.array_equal(S1.values, So) and S1.iParams['flags'][2] == flo[2] == 300
+    Sl, _ = util.run_oracle(p, 6000, 1e-15, LEX)
+    Sh, _, _ = util.run_hip_batched([p], 6000, 1e-15)
+    assert util.rel_l2(Sh[0], Sl) < 1e-6
+
+
 def test_invert_ishida_mask_periodic_odd_width():
     """reference tests/test_Ishida.py:13-63 (h1, h2): value-undef mask, periodic x, xc = 251."""
     import xinvert_amd as xa

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import util
-from util import rand2d, rand3d, randbih, run_oracle, run_hip_single, run_hip_batched, run_hip_dev
+from util import rand2d, rand2dt, rand3d, randbih, run_oracle, run_hip_single, run_hip_batched, run_hip_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -289,3 +289,29 @@ def test_mxloop_zero_does_one_sweep():
     S, fl, st = run_hip_batched([p], 0, 1e-9)
     assert_same(S[0], fl[0], So, flo, 'mxLoop=0')
     assert st['sweeps_max'] == 1
+
+
+@pytest.mark.parametrize('BCy,BCx', BCS)
+@pytest.mark.parametrize('bnz', [0, 1])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', [(9, 12), (12, 19), (30, 260)])
+def test_standard_2d_test_form(BCy, BCx, bnz, msk, shape):
+    """numbas.invert_standard_2D_test: colour path (5/9-point, seam) and, when B == C == 0,
+    the fused kernels (K = 1, 2; full-array and x-uniform variants)."""
+    p = rand2dt(shape[0], shape[1], BCy, BCx, bnz, msk, seed=_seed((BCy, BCx, bnz, msk, shape)))
+    So, flo = run_oracle(p, 20, 1e-9, COLOUR_AUTO)
+    S, fl, st = run_hip_batched([p], 20, 1e-9, path=PATH_COLOUR)
+    assert_same(S[0], fl[0], So, flo, 'std2dt colour')
+    if bnz == 0 and not (BCx == 'periodic' and shape[1] % 2):
+        for K in (1, 2):
+            S, fl, st = run_hip_batched([p], 20, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=10)
+            assert st['path'] == PATH_FUSED
+            assert_same(S[0], fl[0], So, flo, 'std2dt fused K=%d' % K)
+        if not msk:
+            q = dict(p)
+            q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k in (0, 3, 4) else c
+                          for k, c in enumerate(p['coefs'])]
+            So, flo = run_oracle(q, 20, 1e-9, COLOUR_AUTO)
+            S, fl, st = run_hip_batched([q], 20, 1e-9)
+            assert st['xuniform_mask'] == 7
+            assert_same(S[0], fl[0], So, flo, 'std2dt fused x-uniform')

@@ -127,3 +127,11 @@ def test_converged_munk_nine_colours(oracle):
     Sl, _ = util.run_oracle(q, 20000, 1e-15, LEX)
     Sc, _ = util.run_oracle(q, 20000, 1e-15, AUTO)
     assert util.rel_l2(Sc, Sl, Sl != U) < 1e-6
+
+
+def test_converged_fofonoff(oracle):
+    from test_oracle_golden import fofonoff_problem
+    p, _, _, _ = fofonoff_problem()
+    Sl, fl = util.run_oracle(p, 4000, 1e-14, LEX)
+    Sc, fc = util.run_oracle(p, 4000, 1e-14, AUTO)
+    assert fc[2] < 4000 and util.rel_l2(Sc, Sl) < 1e-6

@@ -222,3 +222,45 @@ def test_munk_known_answers(oracle, A4, pin):
     S, fl = util.run_oracle(p, 4000, 1e-14, LEX)
     assert np.isclose(S.max(), pin) and abs(S.max() / pin - 1) < 1e-11
     assert (fl[2] == 4000) == (A4 == 5e3)
+
+
+# ------------------------------------------------------------------ standard_2D_test, SURVEY 8(f)
+def test_std2dt_small_cases_bitwise(oracle):
+    d = golden('std2dt_cases.npz')
+    metas = [ast.literal_eval(str(m)) for m in d['meta']]
+    assert len(metas) == 72
+    for m in metas:
+        k, yc, xc, BCy, BCx, dely, delx, om, nsw, tol = m
+        arr = d[k + '_in']
+        S = np.ascontiguousarray(arr[0]).copy()
+        fl = np.array([0., 1., 0.])
+        c = [np.ascontiguousarray(a) for a in arr[1:]]
+        r = delx / dely
+        oracle.standard_2d_test(S, *c, yc, xc, dely, delx, BCy, BCx, delx**2, r / 4, r**2, om, U, fl,
+                                nsw, tol, LEX)
+        assert np.array_equal(S, d[k + '_S']) and np.array_equal(fl, d[k + '_flags']), m
+
+
+def fofonoff_problem():
+    """reference tests/test_Fofonoff.py:13-41 / docs notebook 09 cell 2."""
+    from xinvert_amd import apps
+    from xinvert_amd.field import Field
+    xc = np.linspace(0, 600000, 301); yc = np.linspace(0, 500000, 251)
+    Fv = yc[:, None] - xc[None, :]
+    iP = apps._update(apps.default_iParams, {'BCs': ['fixed', 'fixed'], 'optArg': 1.2})
+    mP = apps._update(apps.default_mParams, {'f0': 1e-4, 'beta': 2e-11, 'c0': 8e-9, 'c1': 1e-4})
+    F = Field(Fv, ('y', 'x'), {'y': yc, 'x': xc})
+    Fm, initS, cs = apps._coeffs_Fofonoff(F, ['y', 'x'], 'cartesian', mP, iP, None)
+    ps = apps._cal_params2D(yc, xc, 'cartesian')
+    return dict(kind='std2dt', yc=251, xc=301, BCy='fixed', BCx='fixed', dely=ps['del2'], delx=ps['del1'],
+                delxSqr=ps['del1Sqr'], ratio=ps['ratio'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'],
+                optArg=1.2, undef=U, S0=np.zeros((251, 301)),
+                coefs=[np.ascontiguousarray(c) for c in cs] + [Fm.values]), Fv, xc, yc
+
+
+def test_fofonoff_notebook_pin(oracle):
+    """docs/source/notebooks/09_Fofonoff_flow.ipynb:128 prints `loops 1174 and tolerance is
+    9.362824e-15` for this call (mxLoop 4000, tolerance 1e-14, optArg 1.2)."""
+    p, _, _, _ = fofonoff_problem()
+    S, fl = util.run_oracle(p, 4000, 1e-14, LEX)
+    assert '{0:4.0f} and tolerance is {1:e}'.format(fl[2], fl[1]) == '1174 and tolerance is 9.362824e-15'

@@ -65,6 +65,24 @@ def test_lexicographic_oracle_equals_reference_live(oracle):
                     assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
                     n += 1
     assert n == 160
+    for (yc, xc) in [(8, 10), (7, 9)]:
+        for BCy in ('fixed', 'extend'):
+            for BCx in ('fixed', 'periodic'):
+                for bnz in (0, 1):
+                    sh = (yc, xc)
+                    mkt = lambda s=1.0: rng.uniform(0.5, 1.5, sh) * s
+                    A, D = mkt(), mkt()
+                    B = rng.uniform(-.2, .2, sh) if bnz else np.zeros(sh)
+                    C = rng.uniform(-.2, .2, sh) if bnz else np.zeros(sh)
+                    E = -mkt(0.05); F = rng.standard_normal(sh); F[rng.random(sh) < 0.1] = U
+                    S0 = rng.standard_normal(sh) * 0.1
+                    r = 1.1 / 1.3
+                    at = (yc, xc, 1.3, 1.1, BCy, BCx, 1.21, r / 4, r**2, 1.3, U)
+                    S1 = S0.copy(); f1 = np.array([0., 1., 0.])
+                    ref.invert_standard_2D_test(S1, A, B, C, D, E, F, *at, f1, 8, 1e-9)
+                    S2 = S0.copy(); f2 = np.array([0., 1., 0.])
+                    oracle.standard_2d_test(S2, A, B, C, D, E, F, *at, f2, 8, 1e-9)
+                    assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
     for (yc, xc) in [(8, 10), (7, 8)]:
         for BCy in ('fixed', 'extend'):
             for BCx in ('fixed', 'periodic'):

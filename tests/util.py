@@ -40,6 +40,28 @@ def rand2d(kind, yc, xc, BCy, BCx, bnz=False, msk=False, seed=0, dely=1.3, delx=
     return p
 
 
+def rand2dt(yc, xc, BCy, BCx, bnz=False, msk=False, seed=0, dely=1.3, delx=1.1, omega=1.3):
+    """Random problem for the standard 2-D "test" form (A, B, C, D, E, F)."""
+    rng = np.random.default_rng(seed)
+    sh = (yc, xc)
+    mk = lambda s=1.0: rng.uniform(0.5, 1.5, sh) * s
+    A, D = mk(), mk()
+    B = rng.uniform(-.2, .2, sh) if bnz else np.zeros(sh)
+    C = rng.uniform(-.2, .2, sh) if bnz else np.zeros(sh)
+    E = -mk(0.05)
+    F = rng.standard_normal(sh)
+    if msk:
+        F[rng.random(sh) < 0.15] = U
+        A[rng.random(sh) < 0.03] = U
+    S0 = rng.standard_normal(sh) * 0.1
+    if msk:
+        S0[rng.random(sh) < 0.05] = U
+    r = delx / dely
+    return dict(kind='std2dt', yc=yc, xc=xc, BCy=BCy, BCx=BCx, dely=dely, delx=delx, delxSqr=delx**2,
+                ratio=r, ratioQtr=r / 4, ratioSqr=r**2, optArg=omega, undef=U, S0=S0,
+                coefs=[A, B, C, D, E, F])
+
+
 def randbih(yc, xc, BCy, BCx, bnz=False, msk=False, seed=0, dely=1.3, delx=1.1, omega=0.9):
     """Random biharmonic problem (10 coefficient arrays A..J)."""
     rng = np.random.default_rng(seed)
@@ -94,6 +116,10 @@ def run_oracle(p, mxLoop, tol, order):
         orc.general_2d(S, *c, p['yc'], p['xc'], p['dely'], p['delx'], p['BCy'], p['BCx'],
                        p['delxSqr'], p['ratio'], p['ratioQtr'], p['ratioSqr'], p['optArg'],
                        p['undef'], fl, mxLoop, tol, order)
+    elif p['kind'] == 'std2dt':
+        orc.standard_2d_test(S, *c, p['yc'], p['xc'], p['dely'], p['delx'], p['BCy'], p['BCx'],
+                             p['delxSqr'], p['ratioQtr'], p['ratioSqr'], p['optArg'], p['undef'], fl,
+                             mxLoop, tol, order)
     elif p['kind'] == 'bih2d':
         orc.general_bih_2d(S, *c, p['yc'], p['xc'], p['dely'], p['delx'], p['BCy'], p['BCx'],
                            p['delxSSr'], p['delxTr'], p['delxSqr'], p['ratio'], p['ratioSSr'],
@@ -111,7 +137,7 @@ def _scal(p, flags, mxLoop, tol):
     from xinvert_amd import _lib
     b = _lib.bc
     fp = _lib.hptr(flags)
-    if p['kind'] == 'std2d':
+    if p['kind'] in ('std2d', 'std2dt'):
         return [p['yc'], p['xc'], p['dely'], p['delx'], b(p['BCy']), b(p['BCx']), p['delxSqr'],
                 p['ratioQtr'], p['ratioSqr'], p['optArg'], p['undef'], fp, mxLoop, tol]
     if p['kind'] == 'gen2d':
@@ -127,7 +153,7 @@ def _scal(p, flags, mxLoop, tol):
 
 
 _FN = {'std2d': 'xinv_standard_2d_f64', 'gen2d': 'xinv_general_2d_f64', 'std3d': 'xinv_standard_3d_f64',
-       'bih2d': 'xinv_general_bih_2d_f64'}
+       'bih2d': 'xinv_general_bih_2d_f64', 'std2dt': 'xinv_standard_2d_test_f64'}
 
 
 def run_hip_single(p, mxLoop, tol):

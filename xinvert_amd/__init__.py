@@ -10,9 +10,10 @@ Layout (only what the hot path needs):
   field.py       minimal labelled array standing in for xarray.DataArray
 """
 from .field import Field                                           # noqa: F401
-from .core import inv_standard2D, inv_general2D, inv_general2D_bih, inv_standard3D    # noqa: F401
+from .core import (inv_standard2D, inv_standard2D_test, inv_general2D, inv_general2D_bih,    # noqa: F401
+                   inv_standard3D)
 from .apps import (invert_Poisson, invert_Stommel, invert_StommelMunk, invert_GillMatsuno,  # noqa: F401
-                   invert_omega,
+                   invert_Fofonoff, invert_BrethertonHaidvogel, invert_omega,
                    cal_flow, default_iParams, default_mParams)
 
 __version__ = '0.1.0'

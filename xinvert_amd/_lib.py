@@ -48,6 +48,7 @@ EXPORTS = [
     'xinv_standard_3d_f64_batched',
     'xinv_standard_2d_f64_dev', 'xinv_general_2d_f64_dev', 'xinv_standard_3d_f64_dev',
     'xinv_general_bih_2d_f64', 'xinv_general_bih_2d_f64_batched', 'xinv_general_bih_2d_f64_dev',
+    'xinv_standard_2d_test_f64', 'xinv_standard_2d_test_f64_batched', 'xinv_standard_2d_test_f64_dev',
     'xinv_abs_norm_f64_dev',
 ]
 
@@ -94,6 +95,9 @@ def load():
     L.xinv_general_bih_2d_f64.argtypes = [_dp] * 11 + bih_scal
     L.xinv_general_bih_2d_f64_batched.argtypes = [_dp] * 11 + [_i64, _ip] + bih_scal + [_opt]
     L.xinv_general_bih_2d_f64_dev.argtypes = [_vp] * 11 + [_i64, _ip] + bih_scal + [_opt, _vp]
+    L.xinv_standard_2d_test_f64.argtypes = [_dp] * 7 + std2d_scal
+    L.xinv_standard_2d_test_f64_batched.argtypes = [_dp] * 7 + [_i64, _ip] + std2d_scal + [_opt]
+    L.xinv_standard_2d_test_f64_dev.argtypes = [_vp] * 7 + [_i64, _ip] + std2d_scal + [_opt, _vp]
     L.xinv_abs_norm_f64_dev.argtypes = [_vp, _i64, _f64, _dp, _vp]
     for name in EXPORTS:
         getattr(L, name).restype = _int

@@ -82,6 +82,20 @@ def invert_StommelMunk(curl, dims, coords='lat-lon', icbc=None,
                      icbc, ['A4', 'beta', 'R', 'D', 'rho0', 'g', 'Omega', 'Rearth'], mParams, iParams)
 
 
+def invert_Fofonoff(F, dims, coords='cartesian', icbc=None,
+                    mParams=default_mParams, iParams=default_iParams):
+    """Fofonoff inertial gyre, standard 2-D "test" form (reference apps.py:721-763)."""
+    return _template(_coeffs_Fofonoff, core.inv_standard2D_test, 2, F, dims, coords,
+                     icbc, ['c0', 'c1', 'f0', 'beta', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_BrethertonHaidvogel(h, dims, coords='cartesian', icbc=None,
+                               mParams=default_mParams, iParams=default_iParams):
+    """Bretherton-Haidvogel minimum-enstrophy flow over topography (reference apps.py:676-718)."""
+    return _template(_coeffs_Bretherton, core.inv_standard2D_test, 2, h, dims, coords,
+                     icbc, ['f0', 'beta', 'D', 'lambda', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
 def invert_GillMatsuno(Q, dims, coords='lat-lon', icbc=None,
                        mParams=default_mParams, iParams=default_iParams):
     """Gill-Matsuno mass field phi from heating Q (reference apps.py:351-394)."""
@@ -285,6 +299,69 @@ def _coeffs_Stommel(curl, dims, coords, mParams, iParams, icbc):
                         ', should be in [lat-lon, z-lat, z-lon, cartesian]')
     G = _remask(-maskF.values / depth / rho0, maskF)
     return maskF.like(G), initS, (A, B, C, D, E, Fc)
+
+
+def _coeffs_Fofonoff(f, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1975-2013.  (The forcing argument only provides the grid and mask: the
+    right-hand side is c1 - f(y), as in the reference.)"""
+    f0, beta, c0, c1, Omega = (mParams[k] for k in ('f0', 'beta', 'c0', 'c1', 'Omega'))
+    maskF, initS, zero = _mask_FS(f, dims, iParams, icbc)
+    z2 = _core_zero(maskF, dims)
+    yv = np.asarray(maskF[dims[0]], dtype=np.float64)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosG = np.cos(lats)
+        cosH = np.cos((lats + np.concatenate(([np.nan], lats[:-1]))) / 2.0)
+        fc = 2. * Omega * np.sin(lats)
+        A = z2 + cosH[:, None]
+        B = z2
+        C = z2
+        D = z2 + (1.0 / cosG)[:, None]
+        E = z2 - (c0 * cosG)[:, None]
+        Fv = _remask((zero + c1 - along(fc, maskF, dims[0])) * along(cosG, maskF, dims[0]), maskF)
+    elif c == 'cartesian':
+        fc = f0 + beta * yv
+        A = z2 + 1.0
+        B = z2
+        C = z2
+        D = z2 + 1.0
+        E = z2 - c0
+        Fv = _remask(zero + c1 - along(fc, maskF, dims[0]), maskF)
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    return maskF.like(Fv), initS, (A, B, C, D, E)
+
+
+def _coeffs_Bretherton(h, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1934-1972."""
+    f0, beta, depth, lamb, Omega = (mParams[k] for k in ('f0', 'beta', 'D', 'lambda', 'Omega'))
+    maskF, initS, zero = _mask_FS(h, dims, iParams, icbc)
+    z2 = _core_zero(maskF, dims)
+    yv = np.asarray(maskF[dims[0]], dtype=np.float64)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosG = np.cos(lats)
+        cosH = np.cos((lats + np.concatenate(([np.nan], lats[:-1]))) / 2.0)
+        fc = 2. * Omega * np.sin(lats)
+        A = z2 + cosH[:, None]
+        B = z2
+        C = z2
+        D = z2 + (1.0 / cosG)[:, None]
+        E = z2 - (lamb * depth * cosG)[:, None]
+        Fv = _remask(-maskF.values * along(fc, maskF, dims[0]) / depth * along(cosG, maskF, dims[0]), maskF)
+    elif c == 'cartesian':
+        fc = f0 + beta * yv
+        A = z2 + 1.0
+        B = z2
+        C = z2
+        D = z2 + 1.0
+        E = z2 - lamb * depth
+        Fv = _remask(-maskF.values * along(fc, maskF, dims[0]) / depth, maskF)
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    return maskF.like(Fv), initS, (A, B, C, D, E)
 
 
 def _coeffs_StommelMunk(curl, dims, coords, mParams, iParams, icbc):

@@ -28,6 +28,14 @@ def inv_standard2D(A, B, C, F, S, dims, iParams):
     return _solve('std2d', (A, B, C), F, S, dims, iParams)
 
 
+def inv_standard2D_test(A, B, C, D, E, F, S, dims, iParams):
+    """d/dy(A dS/dy + B dS/dx) + d/dx(C dS/dy + D dS/dx) + E S = F   (reference core.py:159-231;
+    Fofonoff, Bretherton-Haidvogel)."""
+    if len(dims) != 2:
+        raise Exception('2 dimensions are needed for inversion')
+    return _solve('std2dt', (A, B, C, D, E), F, S, dims, iParams)
+
+
 def inv_general2D(A, B, C, D, E, F, G, S, dims, iParams):
     """A Syy + B Syx + C Sxx + D Sy + E Sx + F S = G   (reference core.py:374-444)."""
     if len(dims) != 2:
@@ -138,6 +146,12 @@ def _solve(kind, coefs, F, S, dims, iParams):
             float(iParams['del1Sqr']), float(iParams['ratio']), float(iParams['ratioQtr']),
             float(iParams['ratioSqr']), float(iParams['optArg']), _undeftmp,
             _lib.hptr(flags), mx, tol, opt)
+    elif kind == 'std2dt':
+        rc = L.xinv_standard_2d_test_f64_batched(
+            *ptrs, nbatch, st, iParams['gc2'], iParams['gc1'],
+            float(iParams['del2']), float(iParams['del1']), BCs[0], BCs[1],
+            float(iParams['del1Sqr']), float(iParams['ratioQtr']), float(iParams['ratioSqr']),
+            float(iParams['optArg']), _undeftmp, _lib.hptr(flags), mx, tol, opt)
     elif kind == 'bih2d':
         rc = L.xinv_general_bih_2d_f64_batched(
             *ptrs, nbatch, st, iParams['gc2'], iParams['gc1'],

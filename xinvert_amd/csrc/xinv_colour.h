@@ -119,6 +119,44 @@ __global__ __launch_bounds__(256) void k_colour_gen2d(ColourArgs2D a)
     S[p] = v;
 }
 
+
+// standard 2-D "test" form: c[] = A, B, C, D, E, F (numbas.invert_standard_2D_test).
+template <bool NINE>
+__global__ __launch_bounds__(256) void k_colour_std2dt(ColourArgs2D a)
+{
+    const int64_t m = a.member0 + blockIdx.z;
+    if (!a.force && a.ctl[m].done) return;
+    const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    int64_t j, i;
+    if (!xinv_colour_point(a, tj, ti, j, i)) return;
+    const int64_t xc = a.xc;
+    double *S = a.S + m * a.sS;
+    const double *A = a.c[0] + m * a.sc[0];
+    const double *B = a.c[1] + m * a.sc[1];
+    const double *C = a.c[2] + m * a.sc[2];
+    const double *D = a.c[3] + m * a.sc[3];
+    const double *E = a.c[4] + m * a.sc[4];
+    const double *F = a.c[5] + m * a.sc[5];
+    const int64_t im = (i == 0) ? xc - 1 : i - 1;
+    const int64_t ip = (i == xc - 1) ? 0 : i + 1;
+    const int64_t r = j * xc, rp = r + xc, rm = r - xc;
+    const double sC = S[r + i];
+    double v;
+    if (NINE) {
+        const bool west = (i == 0);
+        const int64_t bn = west ? ip : i, sq = west ? i : ip;
+        v = xinv_upd_std2dt_9(sC, S[rp + i], S[rm + i], S[r + im], S[r + ip],
+                              S[rp + ip], S[rp + im], S[rm + ip], S[rm + im], S[rm + sq],
+                              A[rp + i], A[r + i], B[rp + i], B[rp + bn], B[rm + i],
+                              C[r + ip], C[r + im], D[r + ip], D[r + i], E[r + i], F[r + i], a.sc_);
+    } else {
+        v = xinv_upd_std2dt_5(sC, S[rp + i], S[rm + i], S[r + im], S[r + ip],
+                              A[rp + i], A[r + i], D[r + ip], D[r + i], E[r + i], F[r + i], true, a.sc_);
+    }
+    S[r + i] = v;
+}
+
 // ------------------------------------------------------------------------------- 3-D
 struct ColourArgs3D {
     double *S;

@@ -296,3 +296,56 @@ __device__ __forceinline__ double xinv_upd_bih2d(
                            I*sc.delxSSr);
     return sC + temp;
 }
+
+// standard 2-D "test" form (numbas.py:563-589): d/dy(A Sy + B Sx) + d/dx(C Sy + D Sx) + E S = F.
+__device__ __forceinline__ double xinv_upd_std2dt_9(
+    double sC, double sP, double sM, double sW, double sE,
+    double sPE, double sPW, double sME, double sMW, double sM_q,
+    double aP, double a0, double bP_chk, double bP_use, double bM, double cE, double cW,
+    double dE, double d0, double e, double f, const XinvScal &sc)
+{
+    const double u = sc.undef;
+    bool cond = (f != u) && (aP != u) && (a0 != u) && (bP_chk != u) && (bM != u) &&
+                (cE != u) && (cW != u) && (dE != u) && (d0 != u) && (e != u);
+    if (!cond) return sC;
+    double temp = (
+        (
+            aP * (sP - sC) -
+            a0 * (sC - sM)
+        ) * sc.ratioSqr + (
+            bP_use * (sPE - sPW) -
+            bM * (sM_q - sMW)
+        ) * sc.ratioQtr + (
+            cE * (sPE - sME) -
+            cW * (sPW - sMW)
+        ) * sc.ratioQtr + (
+            dE * (sE - sC) -
+            d0 * (sC - sW)
+        )
+    ) + (e * sC - f) * sc.delxSqr;
+    temp *= sc.optArg / ((aP + a0) * sc.ratioSqr +
+                         (dE + d0) - e * sc.delxSqr);
+    return sC + temp;
+}
+
+// the same with B == 0 and C == 0 everywhere (5-point coupling)
+__device__ __forceinline__ double xinv_upd_std2dt_5(
+    double sC, double sP, double sM, double sW, double sE,
+    double aP, double a0, double dE, double d0, double e, double f, bool inrange,
+    const XinvScal &sc)
+{
+    const double u = sc.undef;
+    bool cond = inrange && (f != u) && (aP != u) && (a0 != u) && (dE != u) && (d0 != u) && (e != u);
+    double temp = (
+        (
+            aP * (sP - sC) -
+            a0 * (sC - sM)
+        ) * sc.ratioSqr + (
+            dE * (sE - sC) -
+            d0 * (sC - sW)
+        )
+    ) + (e * sC - f) * sc.delxSqr;
+    temp *= sc.optArg / ((aP + a0) * sc.ratioSqr +
+                         (dE + d0) - e * sc.delxSqr);
+    return cond ? sC + temp : sC;
+}

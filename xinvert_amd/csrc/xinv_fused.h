@@ -140,6 +140,53 @@ struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
     }
 };
 
+struct FusedStd2DT {                // numbas.invert_standard_2D_test, B == 0 and C == 0
+    static constexpr int NC = 4;    // A, D, E, F
+    template <unsigned UM> static constexpr bool hoist() { return (UM & 7u) == 7u; }   // A, D, E uniform
+
+    template <unsigned UM, int D>
+    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int s1, const XinvScal &sc)
+    {
+        if (hoist<UM>()) {          // row r-1
+            const double aP = w.s[0][sr], a0 = w.s[0][s1], d = w.s[1][s1], e = w.s[2][s1];
+            w.rq[s1] = sc.optArg / ((aP + a0) * sc.ratioSqr +
+                                    (d + d) - e * sc.delxSqr);
+            w.rok[s1] = (aP != sc.undef) && (a0 != sc.undef) && (d != sc.undef) && (e != sc.undef);
+        }
+    }
+
+    template <int X, unsigned UM, int D>
+    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 bool inr, const XinvScal &sc)
+    {
+        const double aP = cget<X, UM, 0>(w, sjp);
+        const double a0 = cget<X, UM, 0>(w, sj);
+        const double d0 = cget<X, UM, 1>(w, sj);
+        double dE;
+        if ((UM >> 1) & 1u) dE = w.s[1][sj];
+        else if (X == 0)    dE = w.v[1][sj].y;
+        else                dE = xinv_lane_down(w.v[1][sj].x);
+        const double e = cget<X, UM, 2>(w, sj);
+        const double f = cget<X, UM, 3>(w, sj);
+        if (hoist<UM>()) {
+            const bool cond = inr && w.rok[sj] && (f != sc.undef);
+            double temp = (
+                (
+                    aP * (sP - sC) -
+                    a0 * (sC - sM)
+                ) * sc.ratioSqr + (
+                    dE * (sE - sC) -
+                    d0 * (sC - sW)
+                )
+            ) + (e * sC - f) * sc.delxSqr;
+            temp *= w.rq[sj];
+            return cond ? sC + temp : sC;
+        }
+        return xinv_upd_std2dt_5(sC, sP, sM, sW, sE, aP, a0, dE, d0, e, f, inr, sc);
+    }
+};
+
 struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     static constexpr int NC = 6;    // A, C, D, E, F, G
     template <unsigned UM> static constexpr bool hoist() { return (UM & 0x13u) == 0x13u; }  // A, C, F uniform

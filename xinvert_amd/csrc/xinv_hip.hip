@@ -86,13 +86,13 @@ static int ensure_dev(T **p, size_t *cap, size_t need_bytes)
 }
 
 // ------------------------------------------------------------------ problem description
-enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3 };
+enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3, KIND_STD2DT = 4 };
 
 struct Problem {
     int kind;
     int64_t nbatch, zc, yc, xc;
     double *S;
-    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J
+    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J ; std2dt: A..F
     int64_t sS, sc[10];
     int ncoef;
     int BCz, BCy, BCx;
@@ -145,6 +145,7 @@ struct Plan {
 static unsigned pick_um(int kind, unsigned umask)
 {
     if (kind == KIND_STD2D) return ((umask & 3u) == 3u) ? 3u : 0u;            // A, C
+    if (kind == KIND_STD2DT) return ((umask & 7u) == 7u) ? 7u : 0u;           // A, D, E
     if ((umask & 0x1fu) == 0x1fu) return 0x1fu;                                // A, C, D, E, F
     if ((umask & 0x1cu) == 0x1cu) return 0x1cu;                                // D, E, F
     return 0u;
@@ -166,6 +167,8 @@ static int launch_fused_um(unsigned um, int K, dim3 grid, dim3 block, hipStream_
 {
     if constexpr (std::is_same<M, FusedStd2D>::value) {
         if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a);
+    } else if constexpr (std::is_same<M, FusedStd2DT>::value) {
+        if (um == 7u) return launch_fused_k<M, AL, 7u, EXT>(K, grid, block, st, a);
     } else {
         if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a);
         if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a);
@@ -197,6 +200,9 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
         a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
         a.c[1] = p.c[2]; a.sc[1] = p.sc[2];      // C
         a.c[2] = p.c[3]; a.sc[2] = p.sc[3];      // F
+    } else if (p.kind == KIND_STD2DT) {
+        a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
+        for (int q = 3; q < 6; q++) { a.c[q - 2] = p.c[q]; a.sc[q - 2] = p.sc[q]; }   // D, E, F
     } else {
         a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
         for (int q = 2; q < 7; q++) { a.c[q - 1] = p.c[q]; a.sc[q - 1] = p.sc[q]; }   // C..G
@@ -223,6 +229,8 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
         a.member0 = member0 + m0;
         dim3 grid((unsigned)(a.nsg * a.nrb), (unsigned)nm, 1), block(256, 1, 1);
         const int bad = gen ? launch_fused_m<FusedGen2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a)
+                        : (p.kind == KIND_STD2DT)
+                            ? launch_fused_m<FusedStd2DT>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a)
                             : launch_fused_m<FusedStd2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a);
         if (bad) return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     }
@@ -343,6 +351,9 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
             if (p.kind == KIND_STD2D) {
                 if (nine) hipLaunchKernelGGL(k_colour_std2d<true>, g, b, 0, st, a);
                 else      hipLaunchKernelGGL(k_colour_std2d<false>, g, b, 0, st, a);
+            } else if (p.kind == KIND_STD2DT) {
+                if (nine) hipLaunchKernelGGL(k_colour_std2dt<true>, g, b, 0, st, a);
+                else      hipLaunchKernelGGL(k_colour_std2dt<false>, g, b, 0, st, a);
             } else {
                 if (nine) hipLaunchKernelGGL(k_colour_gen2d<true>, g, b, 0, st, a);
                 else      hipLaunchKernelGGL(k_colour_gen2d<false>, g, b, 0, st, a);
@@ -403,7 +414,16 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         pl.base = 9;                                   // radius-2 stencil: (j%3, i%3)
     } else {
         bool bzero = (p.c[1] == nullptr);
-        if (!bzero && p.sc_.undef != 0.0) {
+        if (p.kind == KIND_STD2DT && p.sc_.undef != 0.0) {          // cross coefficients B and C
+            HIPCHK(hipMemsetAsync(ws->dflag, 0, sizeof(int), st));
+            for (int q = 1; q <= 2; q++) {
+                const int64_t nb = (p.sc[q] == 0) ? n : (p.nbatch - 1) * p.sc[q] + n;
+                hipLaunchKernelGGL(k_any_nonzero, dim3(1024), dim3(256), 0, st, p.c[q], nb, ws->dflag);
+            }
+            HIPCHK(hipMemcpyAsync(ws->hflag, ws->dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            bzero = (*ws->hflag == 0);
+        } else if (!bzero && p.sc_.undef != 0.0) {
             HIPCHK(hipMemsetAsync(ws->dflag, 0, sizeof(int), st));
             const int64_t nb = (p.sc[1] == 0) ? n : (p.nbatch - 1) * p.sc[1] + n;
             hipLaunchKernelGGL(k_any_nonzero, dim3(1024), dim3(256), 0, st, p.c[1], nb, ws->dflag);
@@ -467,10 +487,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         {
             XUniArgs xa;
             memset(&xa, 0, sizeof xa);
-            const int cmapS[3] = {0, 2, 3}, cmapG[6] = {0, 2, 3, 4, 5, 6};
-            xa.nstream = (p.kind == KIND_STD2D) ? 3 : 6;
+            const int cmapS[3] = {0, 2, 3}, cmapG[6] = {0, 2, 3, 4, 5, 6}, cmapT[4] = {0, 3, 4, 5};
+            xa.nstream = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
             for (int q = 0; q < xa.nstream; q++) {
-                const int sidx = (p.kind == KIND_STD2D) ? cmapS[q] : cmapG[q];
+                const int sidx = (p.kind == KIND_STD2D) ? cmapS[q] : (p.kind == KIND_STD2DT ? cmapT[q] : cmapG[q]);
                 xa.c[q] = p.c[sidx]; xa.stride[q] = p.sc[sidx];
             }
             xa.nbatch = p.nbatch; xa.yc = p.yc; xa.xc = p.xc;
@@ -510,10 +530,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         pl.nsg = (int)cdiv(cdiv(p.xc, 128 - 4 * XINV_KMAX), 4);   // most strips any K needs: sizes the partials
         pl.nrb = (int)cdiv(p.yc, pl.RY);
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
-        const int cmap3[3] = {0, 2, 3}, cmap6[6] = {0, 2, 3, 4, 5, 6};
-        const int nc = (p.kind == KIND_STD2D) ? 3 : 6;
+        const int cmap3[3] = {0, 2, 3}, cmap6[6] = {0, 2, 3, 4, 5, 6}, cmap4[4] = {0, 3, 4, 5};
+        const int nc = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
         for (int q = 0; q < nc; q++) {
-            const int s = (p.kind == KIND_STD2D) ? cmap3[q] : cmap6[q];
+            const int s = (p.kind == KIND_STD2D) ? cmap3[q] : (p.kind == KIND_STD2DT ? cmap4[q] : cmap6[q]);
             pl.aligned = pl.aligned && ptr_al16(p.c[s]) && !(p.sc[s] & 1);
         }
     }
@@ -829,6 +849,24 @@ static Problem mk_gen2d(double *S, const double *A, const double *B, const doubl
     return p;
 }
 
+static Problem mk_std2dt(double *S, const double *const *co, int64_t nbatch, const int64_t *st,
+                         int64_t yc, int64_t xc, double delx, int BCy, int BCx, double delxSqr,
+                         double ratioQtr, double ratioSqr, double optArg, double undef,
+                         int64_t mxLoop, double tol)
+{
+    Problem p;
+    memset(&p, 0, sizeof p);
+    p.kind = KIND_STD2DT; p.nbatch = nbatch; p.zc = 1; p.yc = yc; p.xc = xc;
+    p.S = S; p.ncoef = 6;
+    const int64_t n = yc * xc;
+    p.sS = st ? st[0] : n;
+    for (int q = 0; q < 6; q++) { p.c[q] = co[q]; p.sc[q] = st ? st[1 + q] : n; }
+    p.BCz = 0; p.BCy = BCy; p.BCx = BCx;
+    set_scal2d(p, delx, delxSqr, 0.0, ratioQtr, ratioSqr, optArg, undef);
+    p.stop.mxLoop = mxLoop; p.stop.tolerance = tol; p.stop.stop_on_zero_norm = 1;
+    return p;
+}
+
 static Problem mk_bih2d(double *S, const double *const *co, int64_t nbatch, const int64_t *st,
                         int64_t yc, int64_t xc, int BCy, int BCx, double delxSSr, double delxTr,
                         double delxSqr, double ratio, double ratioSSr, double ratioQtr,
@@ -1075,6 +1113,51 @@ int xinv_general_bih_2d_f64_dev(double *S, const double *A, const double *B, con
     const double *co[10] = { A, B, C, D, E, F, G, H, I, J };
     Problem p = mk_bih2d(S, co, nbatch, strides, yc, xc, BCy, BCx, delxSSr, delxTr, delxSqr,
                          ratio, ratioSSr, ratioQtr, ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
+}
+
+int xinv_standard_2d_test_f64(double *S, const double *A, const double *B, const double *C,
+                              const double *D, const double *E, const double *F, int64_t yc,
+                              int64_t xc, double dely, double delx, int BCy, int BCx,
+                              double delxSqr, double ratioQtr, double ratioSqr, double optArg,
+                              double undef, double *flags, int64_t mxLoop, double tolerance)
+{
+    (void)dely;
+    const double *co[6] = { A, B, C, D, E, F };
+    Problem p = mk_std2dt(S, co, 1, nullptr, yc, xc, delx, BCy, BCx, delxSqr, ratioQtr, ratioSqr,
+                          optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, nullptr))
+}
+
+int xinv_standard_2d_test_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                      const double *D, const double *E, const double *F,
+                                      int64_t nbatch, const int64_t *strides, int64_t yc,
+                                      int64_t xc, double dely, double delx, int BCy, int BCx,
+                                      double delxSqr, double ratioQtr, double ratioSqr,
+                                      double optArg, double undef, double *flags, int64_t mxLoop,
+                                      double tolerance, const xinv_options *opt)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    const double *co[6] = { A, B, C, D, E, F };
+    Problem p = mk_std2dt(S, co, nbatch, strides, yc, xc, delx, BCy, BCx, delxSqr, ratioQtr,
+                          ratioSqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, opt))
+}
+
+int xinv_standard_2d_test_f64_dev(double *S, const double *A, const double *B, const double *C,
+                                  const double *D, const double *E, const double *F,
+                                  int64_t nbatch, const int64_t *strides, int64_t yc, int64_t xc,
+                                  double dely, double delx, int BCy, int BCx, double delxSqr,
+                                  double ratioQtr, double ratioSqr, double optArg, double undef,
+                                  double *flags, int64_t mxLoop, double tolerance,
+                                  const xinv_options *opt, void *stream)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    const double *co[6] = { A, B, C, D, E, F };
+    Problem p = mk_std2dt(S, co, nbatch, strides, yc, xc, delx, BCy, BCx, delxSqr, ratioQtr,
+                          ratioSqr, optArg, undef, mxLoop, tolerance);
     GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
 }
 
