@@ -172,6 +172,9 @@ def main():
                        'parallelism': 'batch-axis shard x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         # measured bytes / launch time: the part of HBM peak really drawn
+                         'traffic_GBps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                         'traffic_frac': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          'kernel': 'k_fused2d<FusedStd2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask']),
                          'avg_launch_ms': avg_ms, 'alg_bytes_per_launch': alg_bytes},
         }

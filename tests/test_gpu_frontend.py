@@ -185,6 +185,26 @@ def test_invert_poisson_real_data_both_times():
         assert util.rel_l2(sf.values[t], Sl) < 1e-6
 
 
+def test_animate_iteration_poisson_real_data():
+    """reference tests/test_AnimateConverge.py:13-31: 40 frames of (1+1) sweeps on the bundled
+    vorticity; frames must equal single solves of the same total sweep count (restartability)."""
+    import xinvert_amd as xa
+    d = golden('poisson_atmos.npz')
+    lat, lon = d['lat'].astype(np.float64), d['lon'].astype(np.float64)
+    vor = xa.Field(d['vor_f32'][0], ('lat', 'lon'), {'lat': lat, 'lon': lon})
+    iParams = {'BCs': ['fixed', 'periodic'], 'tolerance': 1e-30}
+    sf = xa.animate_iteration('Poisson', vor, dims=['lat', 'lon'], iParams=iParams,
+                              loop_per_frame=1, max_frames=40)
+    assert sf.dims == ('iter', 'lat', 'lon') and sf.shape == (40, 73, 144)
+    assert list(sf['iter'][:3]) == [1, 2, 3]
+    one = xa.invert_Poisson(vor, dims=['lat', 'lon'],
+                            iParams={'BCs': ['fixed', 'periodic'], 'tolerance': 1e-30, 'mxLoop': 79,
+                                     'printInfo': False})
+    assert np.array_equal(sf.values[-1], one.values)           # 40 frames x 2 sweeps == 80 sweeps
+    with pytest.raises(Exception, match='unsupported problem'):
+        xa.animate_iteration('nonsense', vor, dims=['lat', 'lon'])
+
+
 def test_invert_omega_3d_small():
     import xinvert_amd as xa
     from xinvert_amd import synthetic

@@ -175,3 +175,23 @@ def test_cal_flow_gill_matsuno_matches_reference_formula():
     assert np.array_equal(v.values, -c1 * Sy / d + c2 * Sx / d / cosL)
     with pytest.raises(Exception, match='unsupported vtype'):
         apps.cal_flow(S, ['lat', 'lon'], vtype='streamfunction')
+
+
+def test_xarray_like_objects_are_accepted_and_returned():
+    """The boundary accepts anything with .dims/.coords/.values (xarray.DataArray) -- exercised
+    with a stand-in because xarray is not installed in this image."""
+    from xinvert_amd.field import from_any, to_like
+
+    class Coord:
+        def __init__(self, v): self.values = np.asarray(v)
+
+    class FakeDA:
+        def __init__(self, v, dims, coords):
+            self.values, self.dims, self.name = np.asarray(v), tuple(dims), 'x'
+            self.coords = {k: Coord(c) for k, c in coords.items()}
+
+    da = FakeDA(np.zeros((3, 4)), ('lat', 'lon'), {'lat': [0., 1., 2.], 'lon': [0., 10., 20., 30.]})
+    f = from_any(da)
+    assert isinstance(f, Field) and f.dims == ('lat', 'lon') and list(f['lon']) == [0., 10., 20., 30.]
+    assert to_like(f, f) is f
+    assert to_like(f, da) is f            # no xarray here: the Field comes back unchanged

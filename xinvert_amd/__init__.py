@@ -14,6 +14,6 @@ from .core import (inv_standard2D, inv_standard2D_test, inv_general2D, inv_gener
                    inv_standard3D)
 from .apps import (invert_Poisson, invert_Stommel, invert_StommelMunk, invert_GillMatsuno,  # noqa: F401
                    invert_Fofonoff, invert_BrethertonHaidvogel, invert_omega,
-                   cal_flow, default_iParams, default_mParams)
+                   animate_iteration, cal_flow, default_iParams, default_mParams)
 
 __version__ = '0.1.0'

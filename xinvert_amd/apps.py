@@ -122,6 +122,68 @@ def invert_omega(F, dims, coords='lat-lon', icbc=None,
                      icbc, ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth'], mParams, iParams)
 
 
+_ANIMATE = {
+    # app name -> (coefficient function name, core function name, valid mParams)   (apps.py:949-1006)
+    'poisson': ('_coeffs_Poisson', 'inv_standard2D', ['g', 'Omega', 'Rearth']),
+    'gillmatsuno': ('_coeffs_GillMatsuno', 'inv_general2D',
+                    ['f0', 'beta', 'epsilon', 'Phi', 'g', 'Omega', 'Rearth']),
+    'stommel': ('_coeffs_Stommel', 'inv_general2D', ['beta', 'R', 'D', 'rho0', 'g', 'Omega', 'Rearth']),
+    'stommelmunk': ('_coeffs_StommelMunk', 'inv_general2D_bih',
+                    ['A4', 'beta', 'R', 'D', 'rho0', 'g', 'Omega', 'Rearth']),
+    'brethertonhaidvogel': ('_coeffs_Bretherton', 'inv_standard2D_test',
+                            ['f0', 'beta', 'D', 'lambda', 'g', 'Omega', 'Rearth']),
+    'fofonoff': ('_coeffs_Fofonoff', 'inv_standard2D_test',
+                 ['c0', 'c1', 'f0', 'beta', 'g', 'Omega', 'Rearth']),
+    'omega': ('_coeffs_omega', 'inv_standard3D', ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth']),
+}
+
+
+def animate_iteration(app_name, F, dims, coords='lat-lon', icbc=None,
+                      mParams=default_mParams, iParams=default_iParams,
+                      loop_per_frame=5, max_frames=30):
+    """Result after every `loop_per_frame` (+1) sweeps, stacked along a new leading `iter` axis
+    (reference apps.py:895-1058).  Relies on the kernels being in place and restartable: every
+    frame continues from the previous frame's S.  ('stommel' is routed to the general 2-D form;
+    the reference's table pairs it with the biharmonic wrapper, which cannot take its 7 arrays.)"""
+    tmpl = F
+    F = from_any(F)
+    if len(F.dims) != len(dims):
+        raise Exception('For 2D case, only 2D slice  F is allowed;\n' +
+                        'For 3D case, only 3D volume F is allowed.')
+    name = app_name.lower()
+    if name not in _ANIMATE:
+        raise Exception('unsupported problem: ' + name + ', should be one of:\n' +
+                        '\n'.join(repr(k) for k in _ANIMATE))
+    coef_name, inv_name, validMPs = _ANIMATE[name]
+    coef_func, invt_func = globals()[coef_name], getattr(core, inv_name)
+    iParams = _update(default_iParams, iParams)
+    mParams = _update(default_mParams, mParams, validMPs)
+    if icbc is not None:
+        icbc = from_any(icbc)
+    maskF, initS, coeffs = coef_func(F, dims, coords, mParams, iParams, icbc)
+    if len(dims) == 2:
+        ps = _cal_params2D(maskF[dims[0]], maskF[dims[1]], coords, Rearth=mParams['Rearth'])
+    elif len(dims) == 3:
+        ps = _cal_params3D(maskF[dims[0]], maskF[dims[1]], maskF[dims[2]], coords,
+                           Rearth=mParams['Rearth'])
+    else:
+        raise Exception('dimension length should be one of [2, 3]')
+    iParams = _update(ps, iParams)
+    iParams['mxLoop'] = loop_per_frame
+    iParams['printInfo'] = False
+    frames = []
+    for _ in range(max_frames):
+        S = invt_func(*coeffs, maskF, initS, dims, iParams)
+        frames.append(np.array(S.values, copy=True))
+    out = np.stack(frames)
+    if icbc is None:
+        out = np.where(maskF.values[None] != _undeftmp, out, iParams['undef'])
+    coords_out = dict(maskF.coords)
+    coords_out['iter'] = np.arange(loop_per_frame, loop_per_frame * (max_frames + 1), loop_per_frame)
+    res = Field(out, ('iter',) + maskF.dims, coords_out, name='inverted')
+    return to_like(res, tmpl) if not isinstance(tmpl, Field) else res
+
+
 def cal_flow(S, dims, coords='lat-lon', BCs=('fixed', 'fixed'), vtype='GillMatsuno',
              mParams=default_mParams):
     """(u, v) from the Gill-Matsuno mass field (reference apps.py:1277-1317).
