@@ -11,6 +11,12 @@
 #include <math.h>
 
 #define XINV_WAVE 64
+#ifndef XINV_DPP_ZERO_EDGE
+#define XINV_DPP_ZERO_EDGE 1
+#endif
+#ifndef XINV_INCR_OFF
+#define XINV_INCR_OFF 1
+#endif
 
 // One control block per batch member, resident in HBM for the whole solve.  Written only by
 // the last-arriving workgroup of a sweep launch (fused path) or by k_norm_final (colour path);
@@ -81,16 +87,28 @@ __device__ __forceinline__ long long xinv_wave_sum_ll(long long v)
 __device__ __forceinline__ double xinv_lane_up(double v)       // lane i <- lane i-1
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
+#if XINV_DPP_ZERO_EDGE
+    // bound_ctrl: the edge lane reads 0 instead of keeping its own value, so the destination
+    // needs no prior copy of the source (one v_mov_b32 less per half).  Edge lanes are halo.
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);     // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+#else
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+#endif
     return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double xinv_lane_down(double v)     // lane i <- lane i+1
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
+#if XINV_DPP_ZERO_EDGE
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);     // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+#else
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+#endif
     return __hiloint2double(hi, lo);
 }
 

@@ -358,10 +358,21 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
     for (int s = 0; s < K; s++) { acc[s] = 0.0; cnt[s] = 0; }
 
     if (active) {
+#if XINV_INCR_OFF
+        // rows are requested in increasing order: keep the clamped row offset incrementally
+        int64_t lrow = yu0 - H, loff = (lrow < 0 ? 0 : (lrow > yc - 1 ? yc - 1 : lrow)) * xc;
+#endif
         auto load = [&](int64_t r) {
             RowPack<NC> p;
+#if XINV_INCR_OFF
+            const int64_t off = loff;
+            loff += (lrow >= 0 && lrow < yc - 1) ? xc : 0;
+            lrow += 1;
+            (void)r;
+#else
             const int64_t rr = r < 0 ? 0 : (r > yc - 1 ? yc - 1 : r);
             const int64_t off = rr * xc;
+#endif
             p.s = ld2<AL>(srcS, off, lc);
 #pragma unroll
             for (int q = 0; q < NC; q++) {
