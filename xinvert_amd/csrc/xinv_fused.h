@@ -338,8 +338,16 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t xc = a.xc, yc = a.yc;
     const int64_t xu0 = (int64_t)(sg * 4 + wave) * UW;
-    const int64_t yu0 = (int64_t)rb * a.RY;
-    const int64_t yu1 = (yu0 + a.RY < yc) ? yu0 + a.RY : yc;
+    // rows owned by this tile: fixed height RY, or (RY == 0) the yc rows split evenly over the
+    // nrb row blocks, boundaries rounded to even rows
+    int64_t yu0, yu1;
+    if (a.RY > 0) {
+        yu0 = (int64_t)rb * a.RY;
+        yu1 = (yu0 + a.RY < yc) ? yu0 + a.RY : yc;
+    } else {
+        yu0 = (((int64_t)rb * yc) / a.nrb) & ~(int64_t)1;
+        yu1 = (rb + 1 == a.nrb) ? yc : ((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
+    }
     const bool active = xu0 < xc;
     const double u = a.sc_.undef;
 

@@ -139,6 +139,7 @@ struct Plan {
     bool aligned;
     unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
     unsigned um;             // the kernel variant's mask (subset of umask)
+    bool even_split;         // rows split evenly over nrb row blocks (RY = average height)
 };
 
 // kernel variants instantiated per model: mask of streams read as one scalar per row
@@ -211,10 +212,10 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.per = (p.BCx == XINV_BC_PERIODIC);
     a.ext = (p.BCy == XINV_BC_EXTEND);
     a.tall = (p.yc > p.xc);
-    a.RY = pl.RY;
+    a.RY = pl.even_split ? 0 : pl.RY;
     const int UW = 128 - 4 * K;
     a.nsg = (int)cdiv(cdiv(p.xc, UW), 4);
-    a.nrb = (int)cdiv(p.yc, pl.RY);
+    a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
     a.force = force; a.no_ctl = no_ctl;
     a.member0 = member0;
     a.sc_ = p.sc_;
@@ -516,19 +517,38 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         // Tall tiles amortise the 4K recomputed halo rows, but a launch needs ~1500 wavefronts
         // to occupy 1024 SIMDs, so small problems get short tiles (measured: 180x360 is best at
         // RY = 4, 1800x3600 at 34, large batches are flat from 34 to 94).
+        pl.even_split = false;
         if (opt.rows_per_tile > 0) {
             pl.RY = (opt.rows_per_tile + 1) & ~1;
+            pl.nrb = (int)cdiv(p.yc, pl.RY);
+        } else if (opt.rows_per_tile < 0) {              // -n: exactly n row blocks, even split
+            pl.nrb = (int)std::max<int64_t>(1, std::min<int64_t>(-opt.rows_per_tile, p.yc / 2));
+            pl.even_split = true;
+            pl.RY = (int)cdiv(p.yc, pl.nrb);
         } else {
-            const int ry_max = (pl.K == 1) ? 32 : 34, period = 2 * pl.K + 2;
-            const double slots = (double)cdiv(cdiv(p.xc, 128 - 4 * pl.K), 4) * 4.0 * (double)p.nbatch;
-            int want = (int)((double)p.yc * slots / 1536.0);
-            want = std::max(4, std::min(ry_max, want));
-            int ry = ry_max;
-            while (ry - period >= 4 && ry - period >= want) ry -= period;     // smallest valid >= want
-            pl.RY = ry;
+            // Tall tiles amortise the 4K recomputed halo rows, but the launch should put the same
+            // number of workgroups on every CU: with the K = 2 kernels two workgroups fit per CU
+            // (register-limited), so the target is a multiple of 512 workgroups.  Pick the row-block
+            // count that minimises (workgroups per CU) x (steps per tile); rows are then split
+            // evenly (measured at 3600x1800: 64 blocks of ~28 rows beat 53 blocks of 34).
+            const int64_t slots = (int64_t)cdiv(cdiv(p.xc, 128 - 4 * pl.K), 4) * p.nbatch;
+            const int64_t cap = (pl.K == 1) ? 768 : 512, period = 2 * pl.K + 2;
+            int64_t best = 1; double best_cost = 1e300;
+            const int64_t nmin = std::max<int64_t>(1, cdiv(p.yc, 128)), nmax = std::max<int64_t>(nmin, p.yc / 4);
+            for (int64_t nr = nmin; nr <= nmax; nr++) {
+                const int64_t rows = cdiv(p.yc, nr) + 1;                     // +1: even rounding
+                const int64_t steps = cdiv(rows + 4 * pl.K, period) * period;
+                const int64_t wgs = slots * nr;
+                const double per_cu = (double)cdiv(wgs, 256);
+                // a lone workgroup on a CU leaves issue slots idle: charge it like 1.6 workgroups
+                const double cost = (wgs <= 256 ? 1.6 : per_cu) * (double)steps * (wgs > cap ? (double)cdiv(wgs, cap) * cap / (double)wgs : 1.0);
+                if (cost <= best_cost * 1.0001) { best_cost = std::min(cost, best_cost); best = nr; }   // ties: more, shorter tiles
+            }
+            pl.nrb = (int)best;
+            pl.even_split = true;
+            pl.RY = (int)cdiv(p.yc, pl.nrb);
         }
         pl.nsg = (int)cdiv(cdiv(p.xc, 128 - 4 * XINV_KMAX), 4);   // most strips any K needs: sizes the partials
-        pl.nrb = (int)cdiv(p.yc, pl.RY);
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
         const int cmap3[3] = {0, 2, 3}, cmap6[6] = {0, 2, 3, 4, 5, 6}, cmap4[4] = {0, 3, 4, 5};
         const int nc = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
