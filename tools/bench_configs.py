@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--path', type=int, default=0)
     ap.add_argument('--members', type=int, default=0)
     ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--no-xuniform', action='store_true', help='stream every coefficient array in full')
     a = ap.parse_args()
     import torch
     from xinvert_amd import _lib, synthetic
@@ -58,7 +59,8 @@ def main():
         cs = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.float64)).to(dev) for c in p['coefs']]
         strides = [n] + [0 if k in p['shared'] else n for k in range(len(cs))]
         fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
-        opt = _lib.options(sweeps_per_launch=a.spl, rows_per_tile=a.rows, path=a.path, timing=1)
+        opt = _lib.options(sweeps_per_launch=a.spl, rows_per_tile=a.rows, path=a.path, timing=1,
+                           no_xuniform=1 if a.no_xuniform else 0)
         fn = getattr(L, util._FN[p['kind']] + '_dev')
         args = [ctypes.c_void_p(S.data_ptr())] + [ctypes.c_void_p(c.data_ptr()) for c in cs] + \
                [nb, _lib.strides_arg(strides)] + util._scal(p, fl, sw - 1, 0.0) + [ctypes.byref(opt), None]
@@ -76,7 +78,7 @@ def main():
         avg_ms = st['sweep_ms'] / max(st['sweep_launches'], 1)
         print(json.dumps({'config': name, 'kind': p['kind'], 'shape': list(p['S0'].shape), 'sweeps': sw,
                           'point_sweeps_per_s': nb * n * sw / dt, 'solve_ms': dt * 1e3,
-                          'path': st['path'], 'colours': st['colours'], 'sweeps_per_launch': k,
+                          'path': st['path'], 'colours': st['colours'], 'xuniform_mask': st['xuniform_mask'], 'sweeps_per_launch': k,
                           'avg_launch_ms': avg_ms,
                           'alg_GBps': ALG[p['kind']] * nb * n * k / (avg_ms * 1e-3) / 1e9 if st['path'] == 2
                           else ALG[p['kind']] * nb * n * sw / (st['sweep_ms'] * 1e-3) / 1e9,

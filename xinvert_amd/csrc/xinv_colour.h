@@ -263,8 +263,12 @@ struct ColourArgsBih {
     int64_t member0;
     XinvScal sc_;
     const XinvCtl *ctl;
+    unsigned umask;            // bit q: coefficient array q is constant along x (scalar per row)
 };
 
+// One wavefront per row (block = 64 x 4): with UNI the row index is made wave-uniform so the
+// x-uniform coefficient arrays (bit set in umask) are fetched with one scalar load per row.
+template <bool UNI>
 __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
 {
     const int64_t m = a.member0 + blockIdx.z;
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
         if (a.trail && i >= xc - a.trail) return;
     }
     j = 2 + ((cj - 2) % 3 + 3) % 3 + 3 * tj;           // first row >= 2 with j % 3 == cj
+    if (UNI) j = __builtin_amdgcn_readfirstlane((int)j);   // blockDim.x == 64: one row per wave
     if (j > yc - 3) return;
 
     int64_t im2 = i - 2, im1 = i - 1, ip1 = i + 1, ip2 = i + 2;
@@ -309,7 +314,10 @@ __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
     const int64_t p = j * xc + i;
     double cv[10];
 #pragma unroll
-    for (int q = 0; q < 10; q++) cv[q] = a.c[q][m * a.sc[q] + p];
+    for (int q = 0; q < 10; q++) {
+        if (UNI && ((a.umask >> q) & 1u)) cv[q] = a.c[q][m * a.sc[q] + j * xc];   // wave-uniform address
+        else cv[q] = a.c[q][m * a.sc[q] + p];
+    }
     const double *r0 = S + j * xc;
     S[p] = xinv_upd_bih2d(r0, r0 + xc, r0 + 2 * xc, r0 - xc, r0 - 2 * xc, i, im2, im1, ip1, ip2,
                           bm2, edge, cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7],

@@ -545,11 +545,11 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
 // ---- detection of x-uniform coefficient rows (once per solve) -----------------------------
 // flag[q] |= 1 when array q has a row whose elements are not all bitwise equal to its first.
 struct XUniArgs {
-    const double *c[6];
-    int64_t stride[6];         // batch stride; 0 = shared (checked once)
+    const double *c[10];
+    int64_t stride[10];        // batch stride; 0 = shared (checked once)
     int64_t nbatch, yc, xc;
     int nstream;
-    int *flag;                 // [8]
+    int *flag;                 // [16]
 };
 
 __global__ __launch_bounds__(256) void k_xuniform(XUniArgs a)

@@ -303,12 +303,13 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
         a.S = p.S; a.sS = p.sS;
         for (int q = 0; q < 10; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
         a.yc = p.yc; a.xc = p.xc; a.per = per; a.trail = pl.seam; a.force = 0; a.member0 = m0;
-        a.sc_ = p.sc_; a.ctl = ws->ctl;
+        a.sc_ = p.sc_; a.ctl = ws->ctl; a.umask = pl.umask;
         dim3 b(64, 4, 1);
         dim3 g(cdiv(cdiv(p.xc, 3) + 1, 64), cdiv(cdiv(p.yc, 3) + 1, 4), (unsigned)nm);
         for (int cc = 0; cc < pl.ncol; cc++) {
             a.colour = cc;
-            hipLaunchKernelGGL(k_colour_bih2d, g, b, 0, st, a);
+            if (pl.umask) hipLaunchKernelGGL(k_colour_bih2d<true>, g, b, 0, st, a);
+            else          hipLaunchKernelGGL(k_colour_bih2d<false>, g, b, 0, st, a);
         }
     } else if (p.BCy == XINV_BC_EXTEND) {
         ExtendArgs e;
@@ -468,13 +469,13 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             for (int q = 0; q < 3; q++) { xa.c[q] = p.c[q]; xa.stride[q] = p.sc[q]; }
             xa.nbatch = p.nbatch; xa.yc = p.zc * p.yc; xa.xc = p.xc;
             if (!ws->dflags8) {
-                HIPCHK(hipMalloc((void **)&ws->dflags8, 8 * sizeof(int)));
-                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 8 * sizeof(int), hipHostMallocDefault));
+                HIPCHK(hipMalloc((void **)&ws->dflags8, 16 * sizeof(int)));
+                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 16 * sizeof(int), hipHostMallocDefault));
             }
             xa.flag = ws->dflags8;
-            HIPCHK(hipMemsetAsync(ws->dflags8, 0, 8 * sizeof(int), st));
+            HIPCHK(hipMemsetAsync(ws->dflags8, 0, 16 * sizeof(int), st));
             hipLaunchKernelGGL(k_xuniform, dim3(512, 3, 1), dim3(256), 0, st, xa);
-            HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             for (int q = 0; q < 3; q++) if (!ws->hflags8[q]) pl.umask |= (1u << q);
         }
@@ -496,15 +497,15 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             }
             xa.nbatch = p.nbatch; xa.yc = p.yc; xa.xc = p.xc;
             if (!ws->dflags8) {
-                HIPCHK(hipMalloc((void **)&ws->dflags8, 8 * sizeof(int)));
-                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 8 * sizeof(int), hipHostMallocDefault));
+                HIPCHK(hipMalloc((void **)&ws->dflags8, 16 * sizeof(int)));
+                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 16 * sizeof(int), hipHostMallocDefault));
             }
             xa.flag = ws->dflags8;
             pl.umask = 0;
             if (!(opt.reserved[0] & 1)) {               // reserved[0] bit 0: disable the detection
-                HIPCHK(hipMemsetAsync(ws->dflags8, 0, 8 * sizeof(int), st));
+                HIPCHK(hipMemsetAsync(ws->dflags8, 0, 16 * sizeof(int), st));
                 hipLaunchKernelGGL(k_xuniform, dim3(512, (unsigned)xa.nstream, 1), dim3(256), 0, st, xa);
-                HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 for (int q = 0; q < xa.nstream; q++) if (!ws->hflags8[q]) pl.umask |= (1u << q);
             }
@@ -556,6 +557,28 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             const int s = (p.kind == KIND_STD2D) ? cmap3[q] : (p.kind == KIND_STD2DT ? cmap4[q] : cmap6[q]);
             pl.aligned = pl.aligned && ptr_al16(p.c[s]) && !(p.sc[s] & 1);
         }
+    }
+
+    if (p.kind == KIND_BIH2D) {                       // x-uniform coefficient rows -> scalar loads
+        pl.umask = 0;
+        if (!(opt.reserved[0] & 1)) {
+            XUniArgs xa;
+            memset(&xa, 0, sizeof xa);
+            xa.nstream = 10;
+            for (int q = 0; q < 10; q++) { xa.c[q] = p.c[q]; xa.stride[q] = p.sc[q]; }
+            xa.nbatch = p.nbatch; xa.yc = p.yc; xa.xc = p.xc;
+            if (!ws->dflags8) {
+                HIPCHK(hipMalloc((void **)&ws->dflags8, 16 * sizeof(int)));
+                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 16 * sizeof(int), hipHostMallocDefault));
+            }
+            xa.flag = ws->dflags8;
+            HIPCHK(hipMemsetAsync(ws->dflags8, 0, 16 * sizeof(int), st));
+            hipLaunchKernelGGL(k_xuniform, dim3(512, 10, 1), dim3(256), 0, st, xa);
+            HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int q = 0; q < 10; q++) if (!ws->hflags8[q]) pl.umask |= (1u << q);
+        }
+        pl.um = pl.umask;
     }
 
     // ---- workspace ---------------------------------------------------------------------------
@@ -672,7 +695,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     t_stats.colours = pl.ncol;
     t_stats.sweeps_per_launch = Kf;
     t_stats.rows_per_tile = pl.RY;
-    t_stats.xuniform_mask = (pl.path == XINV_PATH_FUSED) ? (int32_t)pl.um : 0;
+    t_stats.xuniform_mask = (pl.path == XINV_PATH_FUSED || p.kind == KIND_BIH2D) ? (int32_t)pl.um : 0;
     t_stats.sweep_launches = nlaunch;
     t_stats.sweeps_max = sweeps_max;
     t_stats.sweep_ms = ms_total;
