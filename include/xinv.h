@@ -48,14 +48,19 @@ extern "C" {
 #define XINV_PATH_COLOUR 1   /* one launch per colour, in place (general fallback)              */
 #define XINV_PATH_FUSED  2   /* streaming fused red+black sweep(s), ping-pong buffers (2-D)     */
 
+#define XINV_FLAG_NO_XUNIFORM 1  /* stream every coefficient array in full: do not look for rows
+                                    that are constant along x                                    */
+
 typedef struct xinv_options {
     int32_t device;             /* HIP device ordinal; -1 = current device                      */
     int32_t path;               /* XINV_PATH_*                                                   */
     int32_t sweeps_per_launch;  /* fused path: sweeps fused in one launch (1 or 2); 0 = auto    */
     int32_t check_every;        /* launches between host polls of the device stop flags; 0=auto */
-    int32_t rows_per_tile;      /* fused path: rows marched by one wavefront; 0 = auto          */
+    int32_t rows_per_tile;      /* fused 2-D: rows per tile (n > 0) or exactly -n evenly split row
+                                   blocks (n < 0); fused 3-D: rows per workgroup (8, 12, 16); 0=auto */
     int32_t timing;             /* 1: bracket launch chunks with HIP events (xinv_last_stats)   */
-    int32_t reserved[2];        /* reserved[0] bit 0: do not look for x-uniform coefficient rows */
+    int32_t flags;              /* XINV_FLAG_* bits                                              */
+    int32_t reserved;
 } xinv_options;
 
 typedef struct xinv_stats {

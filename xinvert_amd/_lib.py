@@ -23,7 +23,7 @@ class XinvOptions(ctypes.Structure):
     _fields_ = [('device', ctypes.c_int32), ('path', ctypes.c_int32),
                 ('sweeps_per_launch', ctypes.c_int32), ('check_every', ctypes.c_int32),
                 ('rows_per_tile', ctypes.c_int32), ('timing', ctypes.c_int32),
-                ('reserved', ctypes.c_int32 * 2)]
+                ('flags', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class XinvStats(ctypes.Structure):
@@ -128,7 +128,7 @@ def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
     o.check_every, o.rows_per_tile, o.timing = check_every, rows_per_tile, timing
-    o.reserved[0] = 1 if no_xuniform else 0
+    o.flags = 1 if no_xuniform else 0             # XINV_FLAG_NO_XUNIFORM
     return o
 
 

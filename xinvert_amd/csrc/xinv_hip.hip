@@ -9,6 +9,10 @@
 //   control blocks -> repeat until every member has stopped.  The stopping rule runs on the
 //   device after every sweep (last-arriving workgroup / k_norm_final); once a member is done
 //   every later launch is a no-op for it, so S holds exactly the sweep the reference stops at.
+//
+// Threading: one solve at a time per device (the per-device workspace is not locked during a
+// solve); different devices may be driven from different host threads.  Statistics and the
+// last error text are thread-local.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -462,7 +466,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
         for (int q = 0; q < 4; q++) pl.aligned = pl.aligned && ptr_al16(p.c[q]) && !(p.sc[q] & 1);
         pl.umask = 0;
-        if (!(opt.reserved[0] & 1)) {
+        if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
             XUniArgs xa;
             memset(&xa, 0, sizeof xa);
             xa.nstream = 3;
@@ -502,7 +506,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             }
             xa.flag = ws->dflags8;
             pl.umask = 0;
-            if (!(opt.reserved[0] & 1)) {               // reserved[0] bit 0: disable the detection
+            if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
                 HIPCHK(hipMemsetAsync(ws->dflags8, 0, 16 * sizeof(int), st));
                 hipLaunchKernelGGL(k_xuniform, dim3(512, (unsigned)xa.nstream, 1), dim3(256), 0, st, xa);
                 HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -561,7 +565,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
 
     if (p.kind == KIND_BIH2D) {                       // x-uniform coefficient rows -> scalar loads
         pl.umask = 0;
-        if (!(opt.reserved[0] & 1)) {
+        if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
             XUniArgs xa;
             memset(&xa, 0, sizeof xa);
             xa.nstream = 10;
@@ -806,9 +810,12 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt)
     double *hS = p.S;
     const int64_t hsS = p.nbatch > 1 ? p.sS : n;
     hipStream_t st = 0;
-    hipEvent_t e0, e1, e2, e3;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
+    struct Events {                                   // destroyed on every return path
+        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+        ~Events() { for (auto x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (auto &x : ev.e) HIPCHK(hipEventCreate(&x));
+    hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2], e3 = ev.e[3];
     HIPCHK(hipEventRecord(e0, st));
     int64_t ds;
     rc = upload(pool, pin, st, p.S, p.nbatch, hsS, n, &d.S, &ds);
@@ -837,8 +844,6 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt)
     HIPCHK(hipEventElapsedTime(&a, e0, e1));
     HIPCHK(hipEventElapsedTime(&b, e2, e3));
     t_stats.h2d_ms = a; t_stats.d2h_ms = b;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     return XINV_OK;
 }
 
