@@ -39,6 +39,9 @@
 #include <utility>
 
 #define XINV_KMAX 2
+#ifndef XINV_LOAD_EARLY
+#define XINV_LOAD_EARLY 0
+#endif
 
 struct FusedArgs {
     const double *src;
@@ -409,14 +412,20 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
             for (int q = 0; q < NC; q++) { cw.v[q][t] = make_double2(0.0, 0.0); cw.s[q][t] = 0.0; }
         }
 
-        // one pipeline step: row r (= rbase + U) enters slot U
-        auto step = [&](int64_t r, const RowPack<NC> &p, auto utag) {
+        // row r (= rbase + U) enters slot U: the prefetched pack is consumed here, so that its
+        // registers can be re-loaded BEFORE this step's arithmetic (prefetch distance = PF steps)
+        auto enter = [&](const RowPack<NC> &p, auto utag) {
             constexpr int U = decltype(utag)::value;
-            constexpr int X = (U & 1) ? 0 : 1;       // r even -> .y ; all stages of a step share it
-#define SLOT(w) ((U - (w) + 4 * D) % D)              /* slot of row r - w */
             sw[U] = p.s;
 #pragma unroll
             for (int q = 0; q < NC; q++) { cw.v[q][U] = p.c[q]; cw.s[q][U] = p.cs[q]; }
+        };
+
+        // one pipeline step on the window whose newest row r sits in slot U
+        auto step = [&](int64_t r, auto utag) {
+            constexpr int U = decltype(utag)::value;
+            constexpr int X = (U & 1) ? 0 : 1;       // r even -> .y ; all stages of a step share it
+#define SLOT(w) ((U - (w) + 4 * D) % D)              /* slot of row r - w */
             M::template derive<UM, D>(cw, U, SLOT(1), a.sc_);
             const bool okc = X ? lc.ok_y : lc.ok_x;
 #pragma unroll
@@ -480,8 +489,14 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
         for (int64_t rb_ = r0; rb_ <= rlast; rb_ += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
-                step(rb_ + U, pf[U % PF], utag);
+                enter(pf[U % PF], utag);
+#if XINV_LOAD_EARLY
                 pf[U % PF] = load(rb_ + U + PF);
+                step(rb_ + U, utag);
+#else
+                step(rb_ + U, utag);
+                pf[U % PF] = load(rb_ + U + PF);
+#endif
             }, std::make_integer_sequence<int, D>{});
         }
     }
