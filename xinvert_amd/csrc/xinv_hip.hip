@@ -60,7 +60,7 @@ struct Workspace {
     XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
     void *partials = nullptr; size_t partials_cap = 0;  // psum + pcnt
     int *dflag = nullptr;
-    int *dflags8 = nullptr, *hflags8 = nullptr;
+    int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
     int *hflag = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -390,6 +390,31 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
     return XINV_OK;
 }
 
+// Which of `nstream` arrays have rows (of xc elements, `rows` per member) that are bitwise constant
+// along x?  One pass over each array on the device; *mask gets bit q set for uniform array q.
+static int detect_xuniform(Workspace *ws, hipStream_t st, const double *const *arr,
+                           const int64_t *stride, int nstream, int64_t nbatch, int64_t rows,
+                           int64_t xc, unsigned *mask)
+{
+    XUniArgs xa;
+    memset(&xa, 0, sizeof xa);
+    xa.nstream = nstream;
+    for (int q = 0; q < nstream; q++) { xa.c[q] = arr[q]; xa.stride[q] = stride[q]; }
+    xa.nbatch = nbatch; xa.yc = rows; xa.xc = xc;
+    if (!ws->dflags16) {
+        HIPCHK(hipMalloc((void **)&ws->dflags16, 16 * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&ws->hflags16, 16 * sizeof(int), hipHostMallocDefault));
+    }
+    xa.flag = ws->dflags16;
+    HIPCHK(hipMemsetAsync(ws->dflags16, 0, 16 * sizeof(int), st));
+    hipLaunchKernelGGL(k_xuniform, dim3(512, (unsigned)nstream, 1), dim3(256), 0, st, xa);
+    HIPCHK(hipMemcpyAsync(ws->hflags16, ws->dflags16, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *mask = 0;
+    for (int q = 0; q < nstream; q++) if (!ws->hflags16[q]) *mask |= (1u << q);
+    return XINV_OK;
+}
+
 // ------------------------------------------------------------------ the solve (device ptrs)
 static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st)
 {
@@ -467,21 +492,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         for (int q = 0; q < 4; q++) pl.aligned = pl.aligned && ptr_al16(p.c[q]) && !(p.sc[q] & 1);
         pl.umask = 0;
         if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-            XUniArgs xa;
-            memset(&xa, 0, sizeof xa);
-            xa.nstream = 3;
-            for (int q = 0; q < 3; q++) { xa.c[q] = p.c[q]; xa.stride[q] = p.sc[q]; }
-            xa.nbatch = p.nbatch; xa.yc = p.zc * p.yc; xa.xc = p.xc;
-            if (!ws->dflags8) {
-                HIPCHK(hipMalloc((void **)&ws->dflags8, 16 * sizeof(int)));
-                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 16 * sizeof(int), hipHostMallocDefault));
-            }
-            xa.flag = ws->dflags8;
-            HIPCHK(hipMemsetAsync(ws->dflags8, 0, 16 * sizeof(int), st));
-            hipLaunchKernelGGL(k_xuniform, dim3(512, 3, 1), dim3(256), 0, st, xa);
-            HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            for (int q = 0; q < 3; q++) if (!ws->hflags8[q]) pl.umask |= (1u << q);
+            rc = detect_xuniform(ws, st, p.c, p.sc, 3, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
+            if (rc) return rc;
         }
         pl.um = (pl.umask == 7u) ? 7u : 0u;
         // 16 waves x 64 lanes leaves 128 VGPRs per lane: enough only for the x-uniform variant
@@ -491,27 +503,17 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (pl.path == XINV_PATH_FUSED) {
         // which coefficient streams are constant along x (lat-lon grids: functions of latitude)
         {
-            XUniArgs xa;
-            memset(&xa, 0, sizeof xa);
             const int cmapS[3] = {0, 2, 3}, cmapG[6] = {0, 2, 3, 4, 5, 6}, cmapT[4] = {0, 3, 4, 5};
-            xa.nstream = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
-            for (int q = 0; q < xa.nstream; q++) {
+            const int ns = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
+            const double *arr[6]; int64_t strd[6];
+            for (int q = 0; q < ns; q++) {
                 const int sidx = (p.kind == KIND_STD2D) ? cmapS[q] : (p.kind == KIND_STD2DT ? cmapT[q] : cmapG[q]);
-                xa.c[q] = p.c[sidx]; xa.stride[q] = p.sc[sidx];
+                arr[q] = p.c[sidx]; strd[q] = p.sc[sidx];
             }
-            xa.nbatch = p.nbatch; xa.yc = p.yc; xa.xc = p.xc;
-            if (!ws->dflags8) {
-                HIPCHK(hipMalloc((void **)&ws->dflags8, 16 * sizeof(int)));
-                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 16 * sizeof(int), hipHostMallocDefault));
-            }
-            xa.flag = ws->dflags8;
             pl.umask = 0;
             if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-                HIPCHK(hipMemsetAsync(ws->dflags8, 0, 16 * sizeof(int), st));
-                hipLaunchKernelGGL(k_xuniform, dim3(512, (unsigned)xa.nstream, 1), dim3(256), 0, st, xa);
-                HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                for (int q = 0; q < xa.nstream; q++) if (!ws->hflags8[q]) pl.umask |= (1u << q);
+                rc = detect_xuniform(ws, st, arr, strd, ns, p.nbatch, p.yc, p.xc, &pl.umask);
+                if (rc) return rc;
             }
             pl.um = pick_um(p.kind, pl.umask);
         }
@@ -566,21 +568,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (p.kind == KIND_BIH2D) {                       // x-uniform coefficient rows -> scalar loads
         pl.umask = 0;
         if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-            XUniArgs xa;
-            memset(&xa, 0, sizeof xa);
-            xa.nstream = 10;
-            for (int q = 0; q < 10; q++) { xa.c[q] = p.c[q]; xa.stride[q] = p.sc[q]; }
-            xa.nbatch = p.nbatch; xa.yc = p.yc; xa.xc = p.xc;
-            if (!ws->dflags8) {
-                HIPCHK(hipMalloc((void **)&ws->dflags8, 16 * sizeof(int)));
-                HIPCHK(hipHostMalloc((void **)&ws->hflags8, 16 * sizeof(int), hipHostMallocDefault));
-            }
-            xa.flag = ws->dflags8;
-            HIPCHK(hipMemsetAsync(ws->dflags8, 0, 16 * sizeof(int), st));
-            hipLaunchKernelGGL(k_xuniform, dim3(512, 10, 1), dim3(256), 0, st, xa);
-            HIPCHK(hipMemcpyAsync(ws->hflags8, ws->dflags8, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            for (int q = 0; q < 10; q++) if (!ws->hflags8[q]) pl.umask |= (1u << q);
+            rc = detect_xuniform(ws, st, p.c, p.sc, 10, p.nbatch, p.yc, p.xc, &pl.umask);
+            if (rc) return rc;
         }
         pl.um = pl.umask;
     }
