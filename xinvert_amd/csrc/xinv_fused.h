@@ -4,7 +4,7 @@
 //
 // Decomposition.  One wavefront owns a tile: a strip of 128 columns (two adjacent columns per
 // lane, one of each colour, so every lane works in every half-sweep) marched top to bottom over
-// RY rows.  A 256-thread workgroup is four independent wavefronts on four adjacent strips; the
+// RY rows.  A 256-thread workgroup is four independent wavefronts on four consecutive tiles; the
 // only workgroup-level step is the final reduction of the norm partials.  Neighbouring tiles
 // overlap by a halo of 2K columns / 2K rows that is recomputed (never exchanged), so a launch
 // needs no inter-workgroup synchronisation and S ping-pongs between two buffers.
@@ -50,7 +50,8 @@ struct FusedArgs {
     int64_t sS, sc[6];         // batch strides (elements)
     int64_t yc, xc;
     int per, ext, tall;
-    int nsg, nrb, RY;          // strip groups (4 strips each), row blocks, rows per tile
+    int nstrip, nrb, RY;       // x strips, row blocks, rows per tile (0: even split)
+    int nwg;                   // workgroups per member = ceil(nstrip * nrb / 4)
     int force, no_ctl;
     int64_t member0;
     XinvScal sc_;
@@ -331,16 +332,19 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
     if (!a.force && ctl->done) return;
 
     // ---- tile of this wavefront; workgroup -> tile map keeps each XCD on a band of rows ----
-    const int NB = a.nsg * a.nrb;
+    // A member's wave-tiles are numbered strip-fastest, then row block; workgroup T takes four
+    // consecutive ones (so narrow grids do not leave wavefronts idle).
+    const int NB = a.nwg;
     int T;
     {
         const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
         T = xcd * q + (xcd < rem ? xcd : rem) + idx;
     }
-    const int rb = T / a.nsg, sg = T - rb * a.nsg;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wt = T * 4 + wave;
+    const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
     const int64_t xc = a.xc, yc = a.yc;
-    const int64_t xu0 = (int64_t)(sg * 4 + wave) * UW;
+    const int64_t xu0 = (int64_t)strip * UW;
     // rows owned by this tile: fixed height RY, or (RY == 0) the yc rows split evenly over the
     // nrb row blocks, boundaries rounded to even rows
     int64_t yu0, yu1;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
         yu0 = (((int64_t)rb * yc) / a.nrb) & ~(int64_t)1;
         yu1 = (rb + 1 == a.nrb) ? yc : ((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
     }
-    const bool active = xu0 < xc;
+    const bool active = wt < a.nstrip * a.nrb;
     const double u = a.sc_.undef;
 
     const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);

@@ -139,7 +139,7 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 
 struct Plan {
     int path, base, seam, ncol;
-    int K, RY, nsg, nrb;
+    int K, RY, nsg, nrb;     // nsg: 2-D = workgroups per member (partials sizing); 3-D = x strips
     bool aligned;
     unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
     unsigned um;             // the kernel variant's mask (subset of umask)
@@ -156,39 +156,64 @@ static unsigned pick_um(int kind, unsigned umask)
     return 0u;
 }
 
+// Launch one instantiation -- or, when `occ` is given, only report how many of its workgroups
+// fit on a CU (register-limited: 1 to 3), which the tiling heuristic needs.
+template <class M, int K, bool AL, unsigned UM, bool EXT>
+static int fused_one(dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a, int *occ)
+{
+    if (occ) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused2d<M, K, AL, UM, EXT>, 256, 0) != hipSuccess)
+            n = 1;
+        *occ = n < 1 ? 1 : n;
+        return 0;
+    }
+    hipLaunchKernelGGL((k_fused2d<M, K, AL, UM, EXT>), grid, block, 0, st, a);
+    return 0;
+}
+
 template <class M, bool AL, unsigned UM, bool EXT>
-static int launch_fused_k(int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a)
+static int launch_fused_k(int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a, int *occ)
 {
     switch (K) {
-    case 1: hipLaunchKernelGGL((k_fused2d<M, 1, AL, UM, EXT>), grid, block, 0, st, a); return 0;
-    case 2: hipLaunchKernelGGL((k_fused2d<M, 2, AL, UM, EXT>), grid, block, 0, st, a); return 0;
+    case 1: return fused_one<M, 1, AL, UM, EXT>(grid, block, st, a, occ);
+    case 2: return fused_one<M, 2, AL, UM, EXT>(grid, block, st, a, occ);
     default: break;
     }
     return 1;
 }
 
 template <class M, bool AL, bool EXT>
-static int launch_fused_um(unsigned um, int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a)
+static int launch_fused_um(unsigned um, int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a,
+                           int *occ)
 {
     if constexpr (std::is_same<M, FusedStd2D>::value) {
-        if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a);
+        if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a, occ);
     } else if constexpr (std::is_same<M, FusedStd2DT>::value) {
-        if (um == 7u) return launch_fused_k<M, AL, 7u, EXT>(K, grid, block, st, a);
+        if (um == 7u) return launch_fused_k<M, AL, 7u, EXT>(K, grid, block, st, a, occ);
     } else {
-        if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a);
-        if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a);
+        if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a, occ);
+        if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a, occ);
     }
-    return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a);
+    return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a, occ);
 }
 
 template <class M>
 static int launch_fused_m(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
-                          const FusedArgs &a)
+                          const FusedArgs &a, int *occ)
 {
-    if (al) return ext ? launch_fused_um<M, true, true>(um, K, grid, block, st, a)
-                       : launch_fused_um<M, true, false>(um, K, grid, block, st, a);
-    return ext ? launch_fused_um<M, false, true>(um, K, grid, block, st, a)
-               : launch_fused_um<M, false, false>(um, K, grid, block, st, a);
+    if (al) return ext ? launch_fused_um<M, true, true>(um, K, grid, block, st, a, occ)
+                       : launch_fused_um<M, true, false>(um, K, grid, block, st, a, occ);
+    return ext ? launch_fused_um<M, false, true>(um, K, grid, block, st, a, occ)
+               : launch_fused_um<M, false, false>(um, K, grid, block, st, a, occ);
+}
+
+static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                          hipStream_t st, const FusedArgs &a, int *occ)
+{
+    if (kind == KIND_GEN2D) return launch_fused_m<FusedGen2D>(al, ext, um, K, grid, block, st, a, occ);
+    if (kind == KIND_STD2DT) return launch_fused_m<FusedStd2DT>(al, ext, um, K, grid, block, st, a, occ);
+    return launch_fused_m<FusedStd2D>(al, ext, um, K, grid, block, st, a, occ);
 }
 
 static bool ptr_al16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
@@ -218,26 +243,23 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.tall = (p.yc > p.xc);
     a.RY = pl.even_split ? 0 : pl.RY;
     const int UW = 128 - 4 * K;
-    a.nsg = (int)cdiv(cdiv(p.xc, UW), 4);
+    a.nstrip = (int)cdiv(p.xc, UW);
     a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
+    a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
     a.force = force; a.no_ctl = no_ctl;
     a.member0 = member0;
     a.sc_ = p.sc_;
     a.ctl = ws->ctl;
     a.stop = p.stop;
-    const size_t NBmax = (size_t)pl.nsg * pl.nrb;   // partials are sized for the narrowest strips (K = XINV_KMAX)
+    const size_t NBmax = (size_t)pl.nsg;             // workgroups per member, narrowest strips (K = XINV_KMAX)
     a.psum = (unsigned long long *)ws->partials;
     a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
-    const bool gen = (p.kind == KIND_GEN2D);
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {      // grid.y is limited to 65535
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
-        dim3 grid((unsigned)(a.nsg * a.nrb), (unsigned)nm, 1), block(256, 1, 1);
-        const int bad = gen ? launch_fused_m<FusedGen2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a)
-                        : (p.kind == KIND_STD2DT)
-                            ? launch_fused_m<FusedStd2DT>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a)
-                            : launch_fused_m<FusedStd2D>(pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a);
-        if (bad) return fail_arg("unsupported sweeps_per_launch for this kernel variant");
+        dim3 grid((unsigned)a.nwg, (unsigned)nm, 1), block(256, 1, 1);
+        if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
+            return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;
@@ -520,10 +542,14 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         const int kmax = XINV_KMAX;
         pl.K = opt.sweeps_per_launch > 0 ? opt.sweeps_per_launch : 2;   // 2 sweeps per pass over HBM
         if (pl.K > kmax) return fail_arg("sweeps_per_launch must be 1 or 2");
-        // Rows per tile.  RY + 4K is kept a multiple of the window depth 2K+2 (no idle steps).
-        // Tall tiles amortise the 4K recomputed halo rows, but a launch needs ~1500 wavefronts
-        // to occupy 1024 SIMDs, so small problems get short tiles (measured: 180x360 is best at
-        // RY = 4, 1800x3600 at 34, large batches are flat from 34 to 94).
+        // Rows per tile (see the cost model below).
+        pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
+        const int cmap3[3] = {0, 2, 3}, cmap6[6] = {0, 2, 3, 4, 5, 6}, cmap4[4] = {0, 3, 4, 5};
+        const int nc = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
+        for (int q = 0; q < nc; q++) {
+            const int s = (p.kind == KIND_STD2D) ? cmap3[q] : (p.kind == KIND_STD2DT ? cmap4[q] : cmap6[q]);
+            pl.aligned = pl.aligned && ptr_al16(p.c[s]) && !(p.sc[s] & 1);
+        }
         pl.even_split = false;
         if (opt.rows_per_tile > 0) {
             pl.RY = (opt.rows_per_tile + 1) & ~1;
@@ -538,31 +564,36 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             // (register-limited), so the target is a multiple of 512 workgroups.  Pick the row-block
             // count that minimises (workgroups per CU) x (steps per tile); rows are then split
             // evenly (measured at 3600x1800: 64 blocks of ~28 rows beat 53 blocks of 34).
-            const int64_t slots = (int64_t)cdiv(cdiv(p.xc, 128 - 4 * pl.K), 4) * p.nbatch;
-            const int64_t cap = (pl.K == 1) ? 768 : 512, period = 2 * pl.K + 2;
+            const int64_t nstrip = cdiv(p.xc, 128 - 4 * pl.K);
+            int occ = 2;                                   // workgroups of the chosen variant per CU
+            {
+                FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
+                fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
+                               st, dummy, &occ);
+                occ = std::min(occ, 3);
+            }
+            const int64_t cap = 256 * (int64_t)occ, period = 2 * pl.K + 2;
             int64_t best = 1; double best_cost = 1e300;
             const int64_t nmin = std::max<int64_t>(1, cdiv(p.yc, 128)), nmax = std::max<int64_t>(nmin, p.yc / 4);
             for (int64_t nr = nmin; nr <= nmax; nr++) {
                 const int64_t rows = cdiv(p.yc, nr) + 1;                     // +1: even rounding
                 const int64_t steps = cdiv(rows + 4 * pl.K, period) * period;
-                const int64_t wgs = slots * nr;
-                const double per_cu = (double)cdiv(wgs, 256);
-                // a lone workgroup on a CU leaves issue slots idle: charge it like 1.6 workgroups
-                const double cost = (wgs <= 256 ? 1.6 : per_cu) * (double)steps * (wgs > cap ? (double)cdiv(wgs, cap) * cap / (double)wgs : 1.0);
+                const int64_t wgs = (int64_t)cdiv(nstrip * nr, 4) * p.nbatch;
+                // rounds of `cap` resident workgroups; inside a round a CU holds ceil(w/256) of them,
+                // and a lone workgroup on a CU leaves issue slots idle (charged like 1.6)
+                const int64_t rounds = cdiv(wgs, cap);
+                const int64_t w_last = wgs - (rounds - 1) * cap;
+                const double full = (occ == 1) ? 1.6 : (double)occ;
+                const double last = (w_last <= 256) ? 1.6 : (double)cdiv(w_last, 256);
+                const double cost = ((double)(rounds - 1) * full + last) * (double)steps;
                 if (cost <= best_cost * 1.0001) { best_cost = std::min(cost, best_cost); best = nr; }   // ties: more, shorter tiles
             }
             pl.nrb = (int)best;
             pl.even_split = true;
             pl.RY = (int)cdiv(p.yc, pl.nrb);
         }
-        pl.nsg = (int)cdiv(cdiv(p.xc, 128 - 4 * XINV_KMAX), 4);   // most strips any K needs: sizes the partials
-        pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
-        const int cmap3[3] = {0, 2, 3}, cmap6[6] = {0, 2, 3, 4, 5, 6}, cmap4[4] = {0, 3, 4, 5};
-        const int nc = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
-        for (int q = 0; q < nc; q++) {
-            const int s = (p.kind == KIND_STD2D) ? cmap3[q] : (p.kind == KIND_STD2DT ? cmap4[q] : cmap6[q]);
-            pl.aligned = pl.aligned && ptr_al16(p.c[s]) && !(p.sc[s] & 1);
-        }
+        // workgroups per member with the narrowest strips any K uses: sizes the partials
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
     }
 
     if (p.kind == KIND_BIH2D) {                       // x-uniform coefficient rows -> scalar loads
@@ -584,7 +615,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     }
     size_t pbytes;
     if (pl.path == XINV_PATH_FUSED)
-        pbytes = (size_t)p.nbatch * XINV_KMAX * pl.nsg * pl.nrb * (sizeof(double) + sizeof(long long));   // (3-D uses a 1/KMAX prefix)
+        pbytes = (size_t)p.nbatch * XINV_KMAX * (p.kind == KIND_STD3D ? (size_t)pl.nsg * pl.nrb : (size_t)pl.nsg) *
+                 (sizeof(double) + sizeof(long long));
     else
         pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
     rc = ensure_dev(&ws->partials, &ws->partials_cap, pbytes);
