@@ -222,6 +222,16 @@ int xinv_standard_2d_test_f64_dev(double *S, const double *A, const double *B, c
                                   double *flags, int64_t mxLoop, double tolerance,
                                   const xinv_options *opt, void *stream);
 
+/* ---- Gill-Matsuno winds from the inverted mass field, SURVEY 8(f) rank 3 -----------------------
+ * replaces apps.cal_flow(vtype='GillMatsuno') (apps.py:1277-1317) for device-resident fields, so
+ * config 4 delivers (phi, u, v) without a host round trip.  All array arguments are DEVICE
+ * pointers.  ytab[3*yc+3] / xtab[3*xc+3]: numpy.gradient's non-uniform interior weights a, b, c
+ * per index followed by {dx, dx_first, dx_last}; y/xuniform select numpy's uniform-spacing form.
+ * rowtab[3*yc]: coef1 = eps/(eps^2+f^2), coef2 = f/(eps^2+f^2), cos(lat) per row. */
+int xinv_gm_flow_f64_dev(const double *S, double *u, double *v, int64_t nbatch, int64_t yc,
+                         int64_t xc, const double *ytab, const double *xtab, int yuniform,
+                         int xuniform, const double *rowtab, double deg2m, int latlon, void *stream);
+
 /* mean |S| over S != undef of one device-resident slab of n elements (reference
  * numbas.absNorm2D/3D, numbas.py:1710-1728 / 1689-1708); *out is a host double. */
 int xinv_abs_norm_f64_dev(const double *S, int64_t n, double undef, double *out, void *stream);

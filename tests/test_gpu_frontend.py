@@ -205,6 +205,27 @@ def test_animate_iteration_poisson_real_data():
         xa.animate_iteration('nonsense', vor, dims=['lat', 'lon'])
 
 
+@pytest.mark.parametrize('coords', ['lat-lon', 'cartesian'])
+def test_gill_matsuno_flow_on_device(coords):
+    """xinv_gm_flow_f64_dev == apps.cal_flow(vtype='GillMatsuno') bit for bit (uniform lat axis,
+    non-uniform-in-the-last-bit lon axis = both numpy.gradient forms), batched."""
+    import torch
+    import xinvert_amd as xa
+    from xinvert_amd import apps
+    rng = np.random.default_rng(4)
+    lat = np.linspace(-90, 90, 73) if coords == 'lat-lon' else np.linspace(-2e6, 2e6, 73)
+    lon = np.linspace(0, 360, 144) if coords == 'lat-lon' else np.linspace(0, 1e7, 144)
+    if coords == 'lat-lon':
+        lat = lat[1:-1]                       # keep cos(lat) away from zero for a clean comparison
+    phi = rng.standard_normal((3, lat.size, lon.size)) * 100.0
+    mP = {'epsilon': 1e-5, 'Phi': 5000}
+    u0, v0 = apps.cal_flow(xa.Field(phi, ('m', 'lat', 'lon'), {'lat': lat, 'lon': lon}), ['lat', 'lon'],
+                           coords=coords, mParams=mP)
+    S = torch.from_numpy(phi).cuda(); u = torch.empty_like(S); v = torch.empty_like(S)
+    apps.cal_flow_gm_device(S.data_ptr(), u.data_ptr(), v.data_ptr(), 3, lat, lon, coords=coords, mParams=mP)
+    assert np.array_equal(u.cpu().numpy(), u0.values) and np.array_equal(v.cpu().numpy(), v0.values)
+
+
 def test_invert_omega_3d_small():
     import xinvert_amd as xa
     from xinvert_amd import synthetic

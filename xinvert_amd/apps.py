@@ -226,6 +226,61 @@ def cal_flow(S, dims, coords='lat-lon', BCs=('fixed', 'fixed'), vtype='GillMatsu
     return to_like(S.like(c1, 'u'), tmpl), to_like(S.like(c2, 'v'), tmpl)
 
 
+def gradient_tables(coord):
+    """What numpy.gradient(f, coord, edge_order=1) (= xarray .differentiate) needs per index:
+    (table[3n+3], uniform) with the non-uniform interior weights a, b, c and {dx, dx_first, dx_last}."""
+    x = np.asarray(coord, dtype=np.float64)
+    n = x.size
+    d = np.diff(x)
+    uniform = bool((d == d[0]).all())
+    a = np.zeros(n); b = np.zeros(n); c = np.zeros(n)
+    if n > 2:
+        dx1, dx2 = d[:-1], d[1:]
+        a[1:-1] = -(dx2) / (dx1 * (dx1 + dx2))
+        b[1:-1] = (dx2 - dx1) / (dx1 * dx2)
+        c[1:-1] = dx1 / (dx2 * (dx1 + dx2))
+    tail = np.array([d[0], d[0], d[-1]])
+    return np.concatenate([a, b, c, tail]), uniform
+
+
+def cal_flow_gm_device(S_dev_ptr, u_dev_ptr, v_dev_ptr, nbatch, lat_or_y, lon_or_x, coords='lat-lon',
+                       mParams=default_mParams, stream=None):
+    """cal_flow(vtype='GillMatsuno') on fields that are already in HBM (device addresses of
+    [nbatch, ny, nx] float64 arrays): the third field pair of config 4 without a host round trip.
+    Bitwise equal to `cal_flow` on the same data.  Needs torch for the small coefficient tables."""
+    import ctypes
+    import torch
+    from . import _lib
+    L = _lib.require_gpu()
+    mParams = _update(default_mParams, mParams, ['f0', 'beta', 'epsilon', 'Phi', 'Omega', 'Rearth'])
+    eps, f0, beta = mParams['epsilon'], mParams['f0'], mParams['beta']
+    Omega, Rearth = mParams['Omega'], mParams['Rearth']
+    yv = np.asarray(lat_or_y, dtype=np.float64); xv = np.asarray(lon_or_x, dtype=np.float64)
+    ytab, yuni = gradient_tables(yv)
+    xtab, xuni = gradient_tables(xv)
+    latlon = coords.lower() == 'lat-lon'
+    if latlon:
+        lats = np.deg2rad(yv)
+        f = 2.0 * Omega * np.sin(lats)
+        cosl = np.cos(lats)
+        deg2m = np.deg2rad(1.0) * Rearth
+    elif coords.lower() == 'cartesian':
+        f = f0 + beta * yv
+        cosl = np.ones_like(yv)
+        deg2m = 1.0
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be [lat-lon, cartesian]')
+    rowtab = np.concatenate([eps / (eps**2.0 + f**2.0), f / (eps**2.0 + f**2.0), cosl])
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ty, tx, tr = (torch.from_numpy(t).to(dev) for t in (ytab, xtab, rowtab))
+    vp = ctypes.c_void_p
+    sp = vp(stream) if stream else None
+    rc = L.xinv_gm_flow_f64_dev(vp(S_dev_ptr), vp(u_dev_ptr), vp(v_dev_ptr), int(nbatch), yv.size, xv.size,
+                                vp(ty.data_ptr()), vp(tx.data_ptr()), int(yuni), int(xuni),
+                                vp(tr.data_ptr()), float(deg2m), int(latlon), sp)
+    _lib.check(rc)
+
+
 # ------------------------------------------------------------------------- helpers
 def _template(coef_func, inv_func, dimLen, F, dims, coords='lat-lon', icbc=None,
               validParams=(), mParams=default_mParams, iParams=default_iParams):

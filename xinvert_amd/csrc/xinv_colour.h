@@ -452,3 +452,62 @@ __global__ void k_ctl_init(XinvCtl *ctl, int64_t nbatch)
     c.done = 0; c.overflow = 0; c.wrote = 0; c.ticket = 0;
     ctl[m] = c;
 }
+
+// ------------------------------------------------------------------ Gill-Matsuno flow (u, v)
+// reference apps.cal_flow(vtype='GillMatsuno') (apps.py:1277-1317): pointwise combination of
+// the two first derivatives of the inverted mass field, computed exactly as xarray's
+// .differentiate / numpy.gradient(edge_order=1) does -- uniform-spacing form when the coordinate
+// differences are all equal, 3-point non-uniform form otherwise -- so that the device result is
+// bitwise the host restatement's.
+struct GradAxis {
+    const double *a, *b, *c;   // non-uniform interior weights (numpy: a*f[i-1] + b*f[i] + c*f[i+1])
+    double dx, dx0, dxn;       // uniform spacing; first / last spacing for the one-sided edges
+    int uniform;
+};
+
+struct FlowArgs {
+    const double *S;
+    double *u, *v;
+    int64_t nbatch, yc, xc;
+    GradAxis gy, gx;
+    const double *coef1, *coef2, *cosl;   // per row
+    double deg2m;
+    int latlon;
+};
+
+__device__ __forceinline__ double xinv_grad1(const GradAxis &g, double fm, double f0, double fp,
+                                              int64_t i, int64_t n)
+{
+    if (i == 0) return (fp - f0) / g.dx0;
+    if (i == n - 1) return (f0 - fm) / g.dxn;
+    if (g.uniform) return (fp - fm) / (2. * g.dx);
+    return g.a[i] * fm + g.b[i] * f0 + g.c[i] * fp;
+}
+
+__global__ __launch_bounds__(256) void k_gm_flow(FlowArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = blockIdx.y;
+    const int64_t m = blockIdx.z;
+    if (i >= a.xc) return;
+    const int64_t xc = a.xc, yc = a.yc;
+    const double *S = a.S + m * yc * xc;
+    const int64_t p = j * xc + i;
+    const double f0 = S[p];
+    const double fxm = S[j * xc + (i > 0 ? i - 1 : i)], fxp = S[j * xc + (i < xc - 1 ? i + 1 : i)];
+    const double fym = S[(j > 0 ? j - 1 : j) * xc + i], fyp = S[(j < yc - 1 ? j + 1 : j) * xc + i];
+    const double Sx = xinv_grad1(a.gx, fxm, f0, fxp, i, xc);
+    const double Sy = xinv_grad1(a.gy, fym, f0, fyp, j, yc);
+    const double c1 = a.coef1[j], c2 = a.coef2[j];
+    double u, v;
+    if (a.latlon) {
+        const double cl = a.cosl[j];
+        u = - c1 * Sx / a.deg2m / cl - c2 * Sy / a.deg2m;
+        v = - c1 * Sy / a.deg2m + c2 * Sx / a.deg2m / cl;
+    } else {
+        u = - c1 * Sx - c2 * Sy;
+        v = - c1 * Sy + c2 * Sx;
+    }
+    a.u[m * yc * xc + p] = u;
+    a.v[m * yc * xc + p] = v;
+}

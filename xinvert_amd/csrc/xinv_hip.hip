@@ -1230,6 +1230,47 @@ int xinv_standard_2d_test_f64_dev(double *S, const double *A, const double *B, c
     GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
 }
 
+// Gill-Matsuno (u, v) from the mass field; every array argument is a DEVICE pointer.
+static int gm_flow_dev(const double *S, double *u, double *v, int64_t nbatch, int64_t yc, int64_t xc,
+                       const double *ytab, const double *xtab, int yuniform, int xuniform,
+                       const double *rowtab, double deg2m, int latlon, hipStream_t st)
+{
+    if (!S || !u || !v || !ytab || !xtab || !rowtab || nbatch < 1 || yc < 2 || xc < 2)
+        return fail_arg("bad arguments to xinv_gm_flow_f64_dev");
+    FlowArgs a;
+    memset(&a, 0, sizeof a);
+    a.S = S; a.u = u; a.v = v; a.nbatch = nbatch; a.yc = yc; a.xc = xc;
+    // ytab / xtab: [3][n] interior weights a, b, c followed by {dx, dx0, dxn}
+    a.gy.a = ytab; a.gy.b = ytab + yc; a.gy.c = ytab + 2 * yc; a.gy.uniform = yuniform;
+    a.gx.a = xtab; a.gx.b = xtab + xc; a.gx.c = xtab + 2 * xc; a.gx.uniform = xuniform;
+    double hy[3], hx[3];
+    HIPCHK(hipMemcpyAsync(hy, ytab + 3 * yc, sizeof hy, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hx, xtab + 3 * xc, sizeof hx, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    a.gy.dx = hy[0]; a.gy.dx0 = hy[1]; a.gy.dxn = hy[2];
+    a.gx.dx = hx[0]; a.gx.dx0 = hx[1]; a.gx.dxn = hx[2];
+    a.coef1 = rowtab; a.coef2 = rowtab + yc; a.cosl = rowtab + 2 * yc;
+    a.deg2m = deg2m; a.latlon = latlon;
+    for (int64_t m0 = 0; m0 < nbatch; m0 += XINV_MEMBER_CHUNK) {
+        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nbatch - m0);
+        FlowArgs b = a;
+        b.S = S + m0 * yc * xc; b.u = u + m0 * yc * xc; b.v = v + m0 * yc * xc;
+        if (yc > 65535) return fail_arg("xinv_gm_flow_f64_dev: yc > 65535 not supported");
+        hipLaunchKernelGGL(k_gm_flow, dim3(cdiv(xc, 256), (unsigned)yc, (unsigned)nm), dim3(256), 0, st, b);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return XINV_OK;
+}
+
+int xinv_gm_flow_f64_dev(const double *S, double *u, double *v, int64_t nbatch, int64_t yc,
+                         int64_t xc, const double *ytab, const double *xtab, int yuniform,
+                         int xuniform, const double *rowtab, double deg2m, int latlon, void *stream)
+{
+    GUARD(gm_flow_dev(S, u, v, nbatch, yc, xc, ytab, xtab, yuniform, xuniform, rowtab, deg2m, latlon,
+                      (hipStream_t)stream))
+}
+
 static int abs_norm_dev(const double *S, int64_t n, double undef, double *out, hipStream_t st)
 {
     if (!S || !out || n < 1) return fail_arg("bad arguments to xinv_abs_norm_f64_dev");
