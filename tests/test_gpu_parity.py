@@ -315,3 +315,20 @@ def test_standard_2d_test_form(BCy, BCx, bnz, msk, shape):
             S, fl, st = run_hip_batched([q], 20, 1e-9)
             assert st['xuniform_mask'] == 7
             assert_same(S[0], fl[0], So, flo, 'std2dt fused x-uniform')
+
+
+def test_concurrent_host_threads_are_serialised_safely():
+    """Two host threads solving on the same device share the cached workspace: the per-device
+    lock must keep both results exact."""
+    import threading
+    ps = [rand2d('gen2d', 60, 300, 'fixed', 'periodic', 0, 1, seed=s) for s in (31, 32)]
+    want = [run_oracle(p, 60, 0.0, COLOUR_2)[0] for p in ps]
+    got = [None, None]
+
+    def work(k):
+        for _ in range(5):
+            got[k] = run_hip_batched([ps[k]], 60, 0.0)[0][0]
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

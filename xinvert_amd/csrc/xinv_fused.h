@@ -311,8 +311,11 @@ __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &i
     }
 }
 
+#ifndef XINV_MINWAVES
+#define XINV_MINWAVES 1
+#endif
 template <class M, int K, bool AL, unsigned UM, bool EXT, int PFD = 0>
-__global__ __launch_bounds__(256) void k_fused2d(FusedArgs a)
+__global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 {
     constexpr int NC = M::NC;
     constexpr int H = 2 * K;            // halo (rows and columns) consumed by K sweeps

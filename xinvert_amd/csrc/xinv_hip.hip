@@ -10,9 +10,9 @@
 //   device after every sweep (last-arriving workgroup / k_norm_final); once a member is done
 //   every later launch is a no-op for it, so S holds exactly the sweep the reference stops at.
 //
-// Threading: one solve at a time per device (the per-device workspace is not locked during a
-// solve); different devices may be driven from different host threads.  Statistics and the
-// last error text are thread-local.
+// Threading: solves on one device are serialised by a per-device lock (they share the cached
+// workspace); different devices may be driven concurrently from different host threads.
+// Statistics and the last error text are thread-local.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -56,6 +56,7 @@ static int fail_arg(const char *msg) { t_err = msg; return XINV_ERR_ARG; }
 // Grown on demand, reused across solves (no hipMalloc in steady state).
 struct Workspace {
     int device = -1;
+    std::recursive_mutex busy;                          // one solve at a time per device
     double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
     XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
     void *partials = nullptr; size_t partials_cap = 0;  // psum + pcnt
@@ -449,6 +450,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (device < 0) HIPCHK(hipGetDevice(&device));
     else HIPCHK(hipSetDevice(device));
     Workspace *ws = get_ws(device);
+    std::lock_guard<std::recursive_mutex> solve_lock(ws->busy);
     if (!ws->ev0) { HIPCHK(hipEventCreate(&ws->ev0)); HIPCHK(hipEventCreate(&ws->ev1)); }
     if (!ws->dflag) {
         HIPCHK(hipMalloc((void **)&ws->dflag, sizeof(int)));
@@ -824,6 +826,9 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt)
     int device = 0;
     HIPCHK(hipGetDevice(&device));
     const int64_t n = p.zc * p.yc * p.xc;
+    // the staging pool and the solver workspace are per device: hold the device for the whole
+    // upload -> solve -> download sequence
+    std::lock_guard<std::recursive_mutex> host_lock(get_ws(device)->busy);
     DevPool *pool = get_pool(device);
     pool->reset();
     Pinned pin;
