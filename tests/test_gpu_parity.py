@@ -332,3 +332,34 @@ def test_concurrent_host_threads_are_serialised_safely():
     th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
     [t.start() for t in th]; [t.join() for t in th]
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+NINE_SHAPES = [(17, 24), (12, 20), (40, 300), (33, 257), (9, 8), (3, 3), (50, 512), (21, 130)]
+
+
+@pytest.mark.parametrize('kind,K', [('std2d', 1), ('std2d', 2), ('gen2d', 1)])
+@pytest.mark.parametrize('BCy,BCx', BCS)
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', NINE_SHAPES)
+def test_fused_nine_point(kind, K, BCy, BCx, msk, shape):
+    """B != 0: the fused 4-colour kernel against the oracle's 4-colour ordering (incl. the
+    reference's west-periodic operands of invert_standard_2D)."""
+    yc, xc = shape
+    if BCx == 'periodic' and xc % 2:
+        pytest.skip('odd-xc periodic seam goes through the colour path')
+    p = rand2d(kind, yc, xc, BCy, BCx, 1, msk, seed=_seed((kind, BCy, BCx, msk, shape, 9)), omega=1.1)
+    So, flo = run_oracle(p, 17, 1e-9, COLOUR_AUTO)
+    S, fl, st = run_hip_batched([p], 17, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=10)
+    assert st['path'] == PATH_FUSED and st['colours'] == 4 and st['sweeps_per_launch'] == K
+    assert_same(S[0], fl[0], So, flo, 'fused 9-point K=%d %s %r' % (K, kind, shape))
+
+
+def test_fused_nine_point_default_tiling_and_batch():
+    ps = [rand2d('gen2d', 70, 380, 'extend', 'periodic', 1, 1, seed=s, omega=1.1) for s in (41, 42, 43)]
+    S, fl, st = run_hip_batched(ps, 200, 3e-4)
+    assert st['path'] == PATH_FUSED and st['colours'] == 4
+    S2, fl2, st2 = run_hip_batched(ps, 200, 3e-4, path=PATH_COLOUR)
+    assert np.array_equal(S, S2) and np.allclose(fl, fl2, rtol=1e-9, atol=1e-12)
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 200, 3e-4, COLOUR_AUTO)
+        assert_same(S[m], fl[m], So, flo, '9-point member %d' % m)

@@ -46,8 +46,9 @@
 struct FusedArgs {
     const double *src;
     double *dst;
-    const double *c[6];        // std: A, C, F ; gen: A, C, D, E, F, G   (B is identically 0)
-    int64_t sS, sc[6];         // batch strides (elements)
+    const double *c[7];        // 5-point: std A, C, F ; gen A, C, D, E, F, G (B == 0)
+                               // 9-point: std A, B, C, F ; gen A, B, C, D, E, F, G
+    int64_t sS, sc[7];         // batch strides (elements)
     int64_t yc, xc;
     int per, ext, tall;
     int nstrip, nrb, RY;       // x strips, row blocks, rows per tile (0: even split)
@@ -311,6 +312,66 @@ __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &i
     }
 }
 
+// ---- norm partials: wave -> workgroup -> global, then the last-arriving workgroup finalises ---
+// acc/cnt: this lane's sum |S| and count over S != undef for each of the K fused sweeps.  Partials
+// are written write-through (agent-scope atomic stores), the arrival ticket is an agent-scope
+// atomic, and the last workgroup reads the partials with agent-scope loads and adds them in
+// index order: deterministic, no floating-point atomics.  NWV = wavefronts per workgroup.
+template <int K, int NWV>
+__device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const int (&cnt)[K],
+                                                   int wave, int lane, int NB, int T,
+                                                   unsigned long long *psum, long long *pcnt,
+                                                   XinvCtl *ctl, const XinvStop &stop)
+{
+    __shared__ double ls[NWV][K];
+    __shared__ long long lcn[NWV][K];
+    __shared__ unsigned s_last;
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        double ws = xinv_wave_sum(acc[s]);
+        long long wc = xinv_wave_sum_ll((long long)cnt[s]);
+        if (lane == 0) { ls[wave][s] = ws; lcn[wave][s] = wc; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            double ts = 0.0; long long tc = 0;
+            for (int q = 0; q < NWV; q++) { ts += ls[q][s]; tc += lcn[q][s]; }
+            __hip_atomic_store(&psum[s * NB + T], (unsigned long long)__double_as_longlong(ts),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pcnt[s * NB + T], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
+        unsigned old = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == (unsigned)(NB - 1)) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || wave != 0) return;
+
+    double tot[K];
+    long long tcn[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        double ps = 0.0; long long pc = 0;
+        for (int t = lane; t < NB; t += XINV_WAVE) {
+            unsigned long long bits = __hip_atomic_load(&psum[s * NB + t], __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+            ps += __longlong_as_double((long long)bits);
+            pc += __hip_atomic_load(&pcnt[s * NB + t], __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+        }
+        tot[s] = xinv_wave_sum(ps);
+        tcn[s] = xinv_wave_sum_ll(pc);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < K; s++) xinv_ctl_update(ctl, tot[s], tcn[s], stop);
+        __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 #ifndef XINV_MINWAVES
 #define XINV_MINWAVES 1
 #endif
@@ -510,58 +571,8 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 
     if (a.no_ctl) return;
 
-    // ---- norm partials: wave -> workgroup -> global, then last-arriver finalises ----------
-    __shared__ double ls[4][K];
-    __shared__ long long lcn[4][K];
-    __shared__ unsigned s_last;
-#pragma unroll
-    for (int s = 0; s < K; s++) {
-        double ws = xinv_wave_sum(acc[s]);
-        long long wc = xinv_wave_sum_ll((long long)cnt[s]);
-        if (lane == 0) { ls[wave][s] = ws; lcn[wave][s] = wc; }
-    }
-    __syncthreads();
-    unsigned long long *psum = a.psum + (size_t)m * XINV_KMAX * NB;
-    long long *pcnt = a.pcnt + (size_t)m * XINV_KMAX * NB;
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int s = 0; s < K; s++) {
-            double ts = 0.0; long long tc = 0;
-            for (int q = 0; q < 4; q++) { ts += ls[q][s]; tc += lcn[q][s]; }
-            __hip_atomic_store(&psum[s * NB + T], (unsigned long long)__double_as_longlong(ts),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&pcnt[s * NB + T], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
-        unsigned old = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old == (unsigned)(NB - 1)) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last || wave != 0) return;
-
-    // last workgroup of this member's launch: every partial is in memory (write-through);
-    // read them with agent-scope loads (bypass this CU's L1), sum in index order.
-    double tot[K];
-    long long tcn[K];
-#pragma unroll
-    for (int s = 0; s < K; s++) {
-        double ps = 0.0; long long pc = 0;
-        for (int t = lane; t < NB; t += XINV_WAVE) {
-            unsigned long long bits = __hip_atomic_load(&psum[s * NB + t], __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-            ps += __longlong_as_double((long long)bits);
-            pc += __hip_atomic_load(&pcnt[s * NB + t], __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT);
-        }
-        tot[s] = xinv_wave_sum(ps);
-        tcn[s] = xinv_wave_sum_ll(pc);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int s = 0; s < K; s++) xinv_ctl_update(ctl, tot[s], tcn[s], a.stop);
-        __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, a.psum + (size_t)m * XINV_KMAX * NB,
+                             a.pcnt + (size_t)m * XINV_KMAX * NB, ctl, a.stop);
 }
 
 // ---- detection of x-uniform coefficient rows (once per solve) -----------------------------

@@ -30,6 +30,7 @@
 #include "xinv_colour.h"
 #include "xinv_fused.h"
 #include "xinv_fused3d.h"
+#include "xinv_fused9.h"
 
 #define XINV_VERSION 100
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
@@ -145,6 +146,7 @@ struct Plan {
     unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
     unsigned um;             // the kernel variant's mask (subset of umask)
     bool even_split;         // rows split evenly over nrb row blocks (RY = average height)
+    bool nine;               // 9-point form on the fused 4-colour kernel
 };
 
 // kernel variants instantiated per model: mask of streams read as one scalar per row
@@ -261,6 +263,70 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
         dim3 grid((unsigned)a.nwg, (unsigned)nm, 1), block(256, 1, 1);
         if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
             return fail_arg("unsupported sweeps_per_launch for this kernel variant");
+    }
+    HIPCHK(hipGetLastError());
+    return XINV_OK;
+}
+
+// ---- 9-point fused launch ---------------------------------------------------------------------
+template <class M, int K>
+static void launch_fused9_k(bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ)
+{
+    dim3 block(256, 1, 1);
+#define L9(AL, EXT)                                                                              \
+    do {                                                                                         \
+        if (occ) {                                                                               \
+            int n = 0;                                                                           \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused9<M, K, AL, EXT>, 256, 0) != hipSuccess) n = 1; \
+            *occ = n < 1 ? 1 : n;                                                                \
+        } else hipLaunchKernelGGL((k_fused9<M, K, AL, EXT>), grid, block, 0, st, a);             \
+    } while (0)
+    if (al) { if (ext) L9(true, true); else L9(true, false); }
+    else    { if (ext) L9(false, true); else L9(false, false); }
+#undef L9
+}
+
+static int fused9_dispatch(int kind, int K, bool al, bool ext, dim3 grid, hipStream_t st,
+                           const FusedArgs &a, int *occ)
+{
+    if (kind == KIND_GEN2D) {
+        if (K == 1) launch_fused9_k<Fused9Gen, 1>(al, ext, grid, st, a, occ); else return 1;
+    } else {
+        if (K == 1) launch_fused9_k<Fused9Std, 1>(al, ext, grid, st, a, occ);
+        else if (K == 2) launch_fused9_k<Fused9Std, 2>(al, ext, grid, st, a, occ);
+        else return 1;
+    }
+    return 0;
+}
+
+static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
+                         Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
+                         int no_ctl)
+{
+    FusedArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = src; a.dst = dst; a.sS = p.sS;
+    const int nc = (p.kind == KIND_GEN2D) ? 7 : 4;
+    for (int q = 0; q < nc; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
+    a.yc = p.yc; a.xc = p.xc;
+    a.per = (p.BCx == XINV_BC_PERIODIC);
+    a.ext = (p.BCy == XINV_BC_EXTEND);
+    a.tall = (p.yc > p.xc);
+    a.RY = pl.even_split ? 0 : pl.RY;
+    a.nstrip = (int)cdiv(p.xc, 128 - 8 * K);
+    a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
+    a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
+    a.force = force; a.no_ctl = no_ctl;
+    a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
+    const size_t NBmax = (size_t)pl.nsg;
+    a.psum = (unsigned long long *)ws->partials;
+    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
+    for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
+        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
+        a.member0 = member0 + m0;
+        dim3 grid((unsigned)a.nwg, (unsigned)nm, 1);
+        if (fused9_dispatch(p.kind, K, pl.aligned, a.ext != 0, grid, st, a, nullptr))
+            return fail_arg("unsupported sweeps_per_launch for the 9-point kernel");
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;
@@ -413,6 +479,32 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
     return XINV_OK;
 }
 
+// Number of row blocks for the fused 2-D kernels.  Tall tiles amortise the 4K recomputed halo
+// rows, but every CU should hold the same number of workgroups: `occ` of the chosen variant fit
+// per CU (register-limited, queried from the runtime).  Minimise (workgroups per CU, in rounds of
+// 256*occ resident ones) x (steps per tile); rows are then split evenly over the blocks.
+static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int K, int occ)
+{
+    occ = std::max(1, std::min(occ, 3));
+    const int64_t cap = 256 * (int64_t)occ, period = 2 * K + 2;
+    int64_t best = 1; double best_cost = 1e300;
+    const int64_t nmin = std::max<int64_t>(1, cdiv(yc, 128)), nmax = std::max<int64_t>(nmin, yc / 4);
+    for (int64_t nr = nmin; nr <= nmax; nr++) {
+        const int64_t rows = cdiv(yc, nr) + 1;                     // +1: even rounding
+        const int64_t steps = cdiv(rows + 4 * K, period) * period;
+        const int64_t wgs = (int64_t)cdiv(nstrip * nr, 4) * nbatch;
+        // rounds of `cap` resident workgroups; inside a round a CU holds ceil(w/256) of them,
+        // and a lone workgroup on a CU leaves issue slots idle (charged like 1.6)
+        const int64_t rounds = cdiv(wgs, cap);
+        const int64_t w_last = wgs - (rounds - 1) * cap;
+        const double full = (occ == 1) ? 1.6 : (double)occ;
+        const double last = (w_last <= 256) ? 1.6 : (double)cdiv(w_last, 256);
+        const double cost = ((double)(rounds - 1) * full + last) * (double)steps;
+        if (cost <= best_cost * 1.0001) { best_cost = std::min(cost, best_cost); best = nr; }   // ties: more, shorter tiles
+    }
+    return best;
+}
+
 // Which of `nstream` arrays have rows (of xc elements, `rows` per member) that are bitwise constant
 // along x?  One pass over each array on the device; *mask gets bit q set for uniform array q.
 static int detect_xuniform(Workspace *ws, hipStream_t st, const double *const *arr,
@@ -497,15 +589,42 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     }
 
     // ---- path ------------------------------------------------------------------------------
-    const bool fused_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D;
+    const bool fused5_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D;
+    const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
+                           (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
+    const bool fused_ok = fused5_ok || fused9_ok;
     pl.path = XINV_PATH_COLOUR;
-    if (fused_ok && opt.path != XINV_PATH_COLOUR) pl.path = XINV_PATH_FUSED;
+    pl.nine = false;
+    if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("fused path needs B == 0 (2-D) and no odd-xc periodic seam");
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam, biharmonic, or 9-point test form)");
     if (pl.path == XINV_PATH_COLOUR && p.kind != KIND_STD3D && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 
-    if (pl.path == XINV_PATH_FUSED && p.kind == KIND_STD3D) {
+    if (pl.path == XINV_PATH_FUSED && pl.nine) {
+        // 9-point forms: 4-colour fused kernel, all coefficient arrays streamed
+        pl.um = pl.umask = 0;
+        pl.K = (p.kind == KIND_STD2D && opt.sweeps_per_launch != 1) ? 2 : 1;    // general form: registers allow K = 1 only
+        pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
+        for (int q = 0; q < p.ncoef; q++) pl.aligned = pl.aligned && ptr_al16(p.c[q]) && !(p.sc[q] & 1);
+        pl.even_split = false;
+        if (opt.rows_per_tile > 0) {
+            pl.RY = (opt.rows_per_tile + 1) & ~1;
+            pl.nrb = (int)cdiv(p.yc, pl.RY);
+        } else {
+            if (opt.rows_per_tile < 0) {
+                pl.nrb = (int)std::max<int64_t>(1, std::min<int64_t>(-opt.rows_per_tile, p.yc / 2));
+            } else {
+                int occ = 1;
+                FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
+                fused9_dispatch(p.kind, pl.K, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
+                pl.nrb = (int)choose_row_blocks(p.yc, cdiv(p.xc, 128 - 8 * pl.K), p.nbatch, pl.K, occ);
+            }
+            pl.even_split = true;
+            pl.RY = (int)cdiv(p.yc, pl.nrb);
+        }
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 8 * XINV_KMAX) * pl.nrb, 4) + 1;
+    } else if (pl.path == XINV_PATH_FUSED && p.kind == KIND_STD3D) {
         // 3-D: one sweep per launch; cross-section of NW rows per workgroup (rows_per_tile = NW)
         pl.K = 1;
         pl.RY = (opt.rows_per_tile == 8 || opt.rows_per_tile == 12 || opt.rows_per_tile == 16)
@@ -566,30 +685,13 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             // (register-limited), so the target is a multiple of 512 workgroups.  Pick the row-block
             // count that minimises (workgroups per CU) x (steps per tile); rows are then split
             // evenly (measured at 3600x1800: 64 blocks of ~28 rows beat 53 blocks of 34).
-            const int64_t nstrip = cdiv(p.xc, 128 - 4 * pl.K);
             int occ = 2;                                   // workgroups of the chosen variant per CU
             {
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
                 fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
                                st, dummy, &occ);
-                occ = std::min(occ, 3);
             }
-            const int64_t cap = 256 * (int64_t)occ, period = 2 * pl.K + 2;
-            int64_t best = 1; double best_cost = 1e300;
-            const int64_t nmin = std::max<int64_t>(1, cdiv(p.yc, 128)), nmax = std::max<int64_t>(nmin, p.yc / 4);
-            for (int64_t nr = nmin; nr <= nmax; nr++) {
-                const int64_t rows = cdiv(p.yc, nr) + 1;                     // +1: even rounding
-                const int64_t steps = cdiv(rows + 4 * pl.K, period) * period;
-                const int64_t wgs = (int64_t)cdiv(nstrip * nr, 4) * p.nbatch;
-                // rounds of `cap` resident workgroups; inside a round a CU holds ceil(w/256) of them,
-                // and a lone workgroup on a CU leaves issue slots idle (charged like 1.6)
-                const int64_t rounds = cdiv(wgs, cap);
-                const int64_t w_last = wgs - (rounds - 1) * cap;
-                const double full = (occ == 1) ? 1.6 : (double)occ;
-                const double last = (w_last <= 256) ? 1.6 : (double)cdiv(w_last, 256);
-                const double cost = ((double)(rounds - 1) * full + last) * (double)steps;
-                if (cost <= best_cost * 1.0001) { best_cost = std::min(cost, best_cost); best = nr; }   // ties: more, shorter tiles
-            }
+            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, 128 - 4 * pl.K), p.nbatch, pl.K, occ);
             pl.nrb = (int)best;
             pl.even_split = true;
             pl.RY = (int)cdiv(p.yc, pl.nrb);
@@ -659,6 +761,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
                 const int cur = (int)(bound.size() & 1);
                 rc = (p.kind == KIND_STD3D)
                          ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
+                     : pl.nine
+                         ? launch_fused9(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
                          : launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0);
                 if (rc) return rc;
                 bound.push_back(launched);
@@ -700,6 +804,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
                 for (int64_t s = bound[i]; s < sw; s++) {
                     rc = (p.kind == KIND_STD3D)
                              ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
+                         : pl.nine
+                             ? launch_fused9(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
                              : launch_fused(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1);
                     if (rc) return rc;
                     cur ^= 1;
