@@ -241,6 +241,26 @@ def test_biharmonic_colour_path(BCy, BCx, bnz, msk, shape):
     assert np.array_equal(S1, S[0])
 
 
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('xc', [7, 8, 179, 180, 181, 185, 186, 187, 360, 366, 545])
+@pytest.mark.parametrize('xuni', [0, 1])
+def test_biharmonic_rowclass_strips(BCy, xc, xuni):
+    """Non-periodic x runs the row-class kernel (three column colours per launch, 180-column
+    strips with two halo lanes a side): strip seams, a last strip of 1..7 columns, x-uniform
+    coefficient rows as per-row scalars -- all bitwise equal to the oracle's 9-colour order."""
+    p = randbih(13, xc, BCy, 'fixed', 1, 1, seed=_seed((BCy, xc, xuni)))
+    if xuni:
+        p['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k in (0, 2, 3, 5, 8) else c
+                      for k, c in enumerate(p['coefs'])]
+    So, flo = run_oracle(p, 9, 1e-9, COLOUR_AUTO)
+    S, fl, st = run_hip_batched([p, p], 9, 1e-9)
+    assert st['path'] == PATH_COLOUR and st['colours'] == 9
+    if xuni:
+        assert st['xuniform_mask'] & 0x12d == 0x12d
+    assert_same(S[0], fl[0], So, flo, 'bih rowclass')
+    assert np.array_equal(S[0], S[1])
+
+
 def test_biharmonic_batched_dev():
     ps = [randbih(16, 33, 'extend', 'periodic', 1, 1, seed=s) for s in (3, 4)]
     S1, f1, _ = run_hip_batched(ps, 20, 1e-7)

@@ -324,6 +324,85 @@ __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
                           cv[8], cv[9], a.sc_);
 }
 
+
+// ---- biharmonic: the three i-colours of one row class in ONE launch (non-periodic x) ---------
+// A wavefront owns one row j of the class (j % 3 == a.colour) and a strip of 192 columns, three
+// adjacent columns per lane = the three colours i % 3.  Rows j+-1, j+-2 belong to other row
+// classes and are constant during the launch; the lane's columns of row j are updated colour
+// after colour in registers, the columns of the neighbouring lanes coming in by DPP shifts after
+// every stage.  Two lanes on each side are halo (each later colour needs the earlier colours two
+// columns away), so a strip owns 180 columns.  Same ordering as nine separate colour launches
+// (bitwise equal), one third of the launches and of the passes over S.
+struct Tri { double v[3]; };
+
+__device__ __forceinline__ void bih_ext(const Tri &t, double (&e)[7])   // e[k+2] = column c+k, k=-2..4
+{
+    e[2] = t.v[0]; e[3] = t.v[1]; e[4] = t.v[2];
+    e[1] = xinv_lane_up(t.v[2]); e[0] = xinv_lane_up(t.v[1]);
+    e[5] = xinv_lane_down(t.v[0]); e[6] = xinv_lane_down(t.v[1]);
+}
+
+template <bool UNI>
+__global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
+{
+    const int64_t m = a.member0 + blockIdx.z;
+    if (!a.force && a.ctl[m].done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t strip = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t xc = a.xc, yc = a.yc;
+    const int cj = a.colour;
+    int64_t j = 2 + ((cj - 2) % 3 + 3) % 3 + 3 * (int64_t)blockIdx.y;
+    if (j > yc - 3) return;
+    const int64_t c = strip * 180 - 6 + 3 * lane;              // unwrapped first column (c % 3 == 0)
+    if (strip * 180 >= xc) return;
+    double *S = a.S + m * a.sS;
+    int64_t lcol[3];
+    bool upd[3], own[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int64_t cc = c + k;
+        lcol[k] = cc < 0 ? 0 : (cc > xc - 1 ? xc - 1 : cc);
+        upd[k] = (cc >= 2) && (cc <= xc - 3);
+        own[k] = upd[k] && (lane >= 2) && (lane < 62);
+    }
+    Tri R[5];                                                   // rows j-2 .. j+2
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const double *row = S + (j - 2 + q) * xc;
+#pragma unroll
+        for (int k = 0; k < 3; k++) R[q].v[k] = row[lcol[k]];
+    }
+    double cv[10][3];
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+        const double *cr = a.c[q] + m * a.sc[q] + j * xc;
+        if (UNI && ((a.umask >> q) & 1u)) {
+            const double t = cr[0];
+            cv[q][0] = t; cv[q][1] = t; cv[q][2] = t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) cv[q][k] = cr[lcol[k]];
+        }
+    }
+    double em2[7], em1[7], ep1[7], ep2[7];
+    bih_ext(R[0], em2); bih_ext(R[1], em1); bih_ext(R[3], ep1); bih_ext(R[4], ep2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                               // colour i % 3 == k
+        double e0[7];
+        bih_ext(R[2], e0);
+        const int o = k + 2;                                    // index of column c+k in e[]
+        R[2].v[k] = xinv_upd_bih2d_v(
+            ep2[o], ep2[o + 2], ep2[o - 2], ep1[o], ep1[o + 1], ep1[o - 1],
+            e0[o], e0[o + 1], e0[o - 1], e0[o + 2], e0[o - 2],
+            em1[o], em1[o + 1], em1[o - 1], em2[o], em2[o + 2], em2[o - 2],
+            cv[0][k], cv[1][k], cv[2][k], cv[3][k], cv[4][k], cv[5][k], cv[6][k], cv[7][k],
+            cv[8][k], cv[9][k], upd[k], a.sc_);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (own[k]) S[j * xc + c + k] = R[2].v[k];
+}
+
 // 'extend' pre-pass of the biharmonic kernel (numbas.py:1299-1343): one thread per column.
 __global__ __launch_bounds__(256) void k_extend_bih(ExtendArgs a)
 {

@@ -367,3 +367,51 @@ __device__ __forceinline__ double xinv_upd_std2dt_5(
                          (dE + d0) - e * sc.delxSqr);
     return cond ? sC + temp : sC;
 }
+
+// the inner-loop form of the biharmonic update on register operands (numbas.py:1437-1479);
+// XY naming: first letter = row (p2, p1, r0, m1, m2), suffix = column offset (m2, m1, 0, p1, p2)
+__device__ __forceinline__ double xinv_upd_bih2d_v(
+    double p2_0, double p2_p2, double p2_m2, double p1_0, double p1_p1, double p1_m1,
+    double r0_0, double r0_p1, double r0_m1, double r0_p2, double r0_m2,
+    double m1_0, double m1_p1, double m1_m1, double m2_0, double m2_p2, double m2_m2,
+    double A, double B, double C, double D, double E, double F, double G, double H, double I,
+    double J, bool inr, const XinvScal &sc)
+{
+    const double u = sc.undef;
+    const bool cond = inr && (A != u) && (B != u) && (C != u) && (D != u) && (E != u) &&
+                      (F != u) && (G != u) && (H != u) && (I != u) && (J != u);
+    double temp = (
+        A * (
+            (p2_0 - 4.0*p1_0 + 6.0*r0_0 - 4.0*m1_0 + m2_0)
+        ) * sc.ratioSSr +
+        B * (
+            (    p2_p2 - 2.0*p2_0 +     p2_m2 +
+            -2.0*r0_p2 + 4.0*r0_0 - 2.0*r0_m2 +
+                 m2_p2 - 2.0*m2_0 +     m2_m2)
+        ) * sc.ratioSqr / 16.0 +
+        C * (
+            (r0_p2 - 4.0*r0_p1 + 6.0*r0_0 - 4.0*r0_m1 + r0_m2)
+        ) +
+        D * (
+            (p1_0 - r0_0)-(r0_0 - m1_0)
+        ) * sc.ratioSqr * sc.delxSqr +
+        E * (
+            (p1_p1 - m1_p1)-(p1_m1 - m1_m1)
+        ) * sc.ratioQtr * sc.delxSqr +
+        F * (
+            (r0_p1 - r0_0)-(r0_0 - r0_m1)
+        ) * sc.delxSqr +
+        G * (
+            (p1_0 - m1_0)
+        ) * sc.delxTr * sc.ratio / 2.0 +
+        H * (
+            (r0_p1 - r0_m1)
+        ) * sc.delxTr / 2.0 + (
+        I * r0_0 - J) * sc.delxSSr
+    );
+    temp *= -sc.optArg / ((A*sc.ratioSSr + C) * 6.0 +
+                           B*sc.ratioSqr / 4.0 +
+                         -(D*sc.ratioSqr + F) * 2.0 * sc.delxSqr +
+                           I*sc.delxSSr);
+    return cond ? r0_0 + temp : r0_0;
+}
