@@ -162,6 +162,37 @@ int xinv_standard_3d_f64_dev(double *S, const double *A, const double *B, const 
                              double *flags, int64_t mxLoop, double tolerance,
                              const xinv_options *opt, void *stream);
 
+/* ---- general 3-D form (3DOcean), SURVEY 8(f) rank 4 -----------------------------------------
+ * xinv_general_3d_f64 replaces numbas.invert_general_3D called at core.py:345-356.
+ * strides[]: S,A,B,C,D,E,F,G,H.  7-point stencil, red-black on (k+j+i)&1; colour-pass kernels.
+ * The reference's west-periodic branch never tests the forcing H against undef
+ * (numbas.py:849-852) -- kept.  BCz is accepted and never read. */
+int xinv_general_3d_f64(double *S, const double *A, const double *B, const double *C,
+                        const double *D, const double *E, const double *F, const double *G,
+                        const double *H, int64_t zc, int64_t yc, int64_t xc, double delz,
+                        double dely, double delx, int BCz, int BCy, int BCx, double delxSqr,
+                        double ratio2, double ratio1, double ratio2Sqr, double ratio1Sqr,
+                        double optArg, double undef, double *flags, int64_t mxLoop,
+                        double tolerance);
+
+int xinv_general_3d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                const double *D, const double *E, const double *F,
+                                const double *G, const double *H, int64_t nbatch,
+                                const int64_t *strides, int64_t zc, int64_t yc, int64_t xc,
+                                double delz, double dely, double delx, int BCz, int BCy, int BCx,
+                                double delxSqr, double ratio2, double ratio1, double ratio2Sqr,
+                                double ratio1Sqr, double optArg, double undef, double *flags,
+                                int64_t mxLoop, double tolerance, const xinv_options *opt);
+
+int xinv_general_3d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                            const double *D, const double *E, const double *F, const double *G,
+                            const double *H, int64_t nbatch, const int64_t *strides, int64_t zc,
+                            int64_t yc, int64_t xc, double delz, double dely, double delx, int BCz,
+                            int BCy, int BCx, double delxSqr, double ratio2, double ratio1,
+                            double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                            double *flags, int64_t mxLoop, double tolerance,
+                            const xinv_options *opt, void *stream);
+
 /* ---- biharmonic 2-D form (Munk / Stommel-Munk), SURVEY 8(f) rank 1 ----------------------------
  * xinv_general_bih_2d_f64 replaces numbas.invert_general_bih_2D called at core.py:503-516.
  * strides[]: S,A,B,C,D,E,F,G,H,I,J.  Radius-2 stencil, 9 colours (j%3, i%3) (+3 per trailing

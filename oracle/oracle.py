@@ -48,6 +48,9 @@ def lib():
                                                  _int, _int, _int, _f64, _f64, _f64, _f64,
                                                  _f64, _dp, _i64, _f64, _int]
         L.xo_general_bih_2d.restype = _int
+        L.xo_general_3d.restype = _int
+        L.xo_general_3d.argtypes = [_dp] * 9 + [_i64, _i64, _i64, _f64, _f64, _f64, _int, _int, _int] + \
+            [_f64] * 7 + [_dp, _i64, _f64, _int]
         L.xo_general_bih_2d.argtypes = [_dp] * 11 + [_i64, _i64, _f64, _f64, _int, _int] + \
             [_f64] * 9 + [_dp, _i64, _f64, _int]
         L.xo_standard_2d_test.restype = _int
@@ -109,6 +112,20 @@ def standard_3d(S, A, B, C, F, zc, yc, xc, delz, dely, delx, BCz, BCy, BCx, delx
     rc = lib().xo_standard_3d(_p(S), _p(A), _p(B), _p(C), _p(F), zc, yc, xc, delz, dely,
                               delx, _bc(BCz), _bc(BCy), _bc(BCx), delxSqr, ratio2Sqr,
                               ratio1Sqr, optArg, undef, _p(flags), mxLoop, tolerance, order)
+    if rc:
+        raise ValueError('oracle: bad arguments (rc=%d)' % rc)
+    return S
+
+
+def general_3d(S, A, B, C, D, E, F, G, H, zc, yc, xc, delz, dely, delx, BCz, BCy, BCx, delxSqr,
+               ratio2, ratio1, ratio2Sqr, ratio1Sqr, optArg, undef, flags, mxLoop, tolerance,
+               order=LEX):
+    sh = (zc, yc, xc)
+    _chk(S, sh, True); [_chk(a, sh) for a in (A, B, C, D, E, F, G, H)]
+    rc = lib().xo_general_3d(_p(S), *[_p(a) for a in (A, B, C, D, E, F, G, H)], zc, yc, xc, delz,
+                             dely, delx, _bc(BCz), _bc(BCy), _bc(BCx), delxSqr, ratio2, ratio1,
+                             ratio2Sqr, ratio1Sqr, optArg, undef, _p(flags), mxLoop, tolerance,
+                             order)
     if rc:
         raise ValueError('oracle: bad arguments (rc=%d)' % rc)
     return S

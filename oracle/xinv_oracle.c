@@ -10,6 +10,7 @@
  *   xo_general_2d   <- xinvert/numbas.py:987-1201  invert_general_2D
  *   xo_standard_3d  <- xinvert/numbas.py:15-212    invert_standard_3D
  *   xo_general_bih_2d <- xinvert/numbas.py:1204-1586 invert_general_bih_2D (radius-2, Munk)
+ *   xo_general_3d     <- xinvert/numbas.py:745-984 invert_general_3D (7-point, 3DOcean)
  *   xo_standard_2d_test <- xinvert/numbas.py:420-629 invert_standard_2D_test (Fofonoff, Bretherton)
  *   norm2d / norm3d <- xinvert/numbas.py:1710-1728 / 1689-1708  absNorm2D / absNorm3D
  *
@@ -112,7 +113,9 @@ static void extend2d(double *S, int64_t yc, int64_t xc, int BCx, double undef)
 
 /* numbas.py:87-115: planes k = 1 .. zc-2 only; the non-periodic branch repeats the same
  * i-loop twice (idempotent) and fixes the four corners of each plane. */
-static void extend3d(double *S, int64_t zc, int64_t yc, int64_t xc, int BCx, double undef)
+/* `tall`: the general 3-D kernel's second loop runs over range(1, yc-1) (numbas.py:872-876); inside
+ * the array bounds it re-copies the same rows, plus column xc-1 when yc > xc (as extend2d). */
+static void extend3d(double *S, int64_t zc, int64_t yc, int64_t xc, int BCx, double undef, int tall)
 {
     for (int64_t k = 1; k < zc - 1; k++) {
         double *P = S + k * yc * xc;
@@ -126,6 +129,10 @@ static void extend3d(double *S, int64_t zc, int64_t yc, int64_t xc, int BCx, dou
             for (int64_t i = 1; i < xc - 1; i++) {
                 if (r1[i] != undef) r0[i] = r1[i];
                 if (rm2[i] != undef) rm1[i] = rm2[i];
+            }
+            if (tall && yc > xc) {
+                if (r1[xc - 1] != undef) r0[xc - 1] = r1[xc - 1];
+                if (rm2[xc - 1] != undef) rm1[xc - 1] = rm2[xc - 1];
             }
             if (r1[1] != undef) r0[0] = r1[1];
             if (r1[xc - 2] != undef) r0[xc - 1] = r1[xc - 2];
@@ -237,6 +244,46 @@ static inline void upd_std3d(double *S, const double *A, const double *B, const 
                       (B[c + xc] + B[c]) * ratio1Sqr +
                       (C[r + ip] + C[c]));
     S[c] += temp;
+}
+
+/* numbas.py:899-930 (inner), 848-893 (west: tests G twice and never H, numbas.py:849-852),
+ * 933-966 (east).  7-point, no cross terms. */
+static inline void upd_gen3d(double *S, const double *const *c, int64_t P, int64_t xc, int64_t k,
+                             int64_t j, int64_t i, int64_t im, int64_t ip, int west,
+                             double delx, double delxSqr, double ratio2, double ratio1,
+                             double ratio2Sqr, double ratio1Sqr, double optArg, double undef)
+{
+    const int64_t r = k * P + j * xc, q = r + i;
+    const double A = c[0][q], B = c[1][q], C = c[2][q], D = c[3][q], E = c[4][q];
+    const double F = c[5][q], G = c[6][q], H = c[7][q];
+    int cond = ((west || H != undef) && G != undef && A != undef && B != undef && C != undef &&
+                D != undef && E != undef && F != undef);
+    if (!cond) return;
+    double temp = (
+        A * (
+            (S[q + P] - S[q])-(S[q] - S[q - P])
+        ) * ratio2Sqr +
+        B * (
+            (S[q + xc] - S[q])-(S[q] - S[q - xc])
+        ) * ratio1Sqr +
+        C * (
+            (S[r + ip] - S[q])-(S[q] - S[r + im])
+        ) + (
+        D * (
+            (S[q + P] - S[q - P])
+        ) * ratio2 +
+        E * (
+            (S[q + xc] - S[q - xc])
+        ) * ratio1 +
+        F * (
+            (S[r + ip] - S[r + im])
+        )) * delx / 2.0 + (
+        G * S[q] - H) * delxSqr
+    );
+    temp *= optArg / ((
+        A*ratio2Sqr + B*ratio1Sqr + C
+    ) * 2.0 - G*delxSqr);
+    S[q] += temp;
 }
 
 /* ------------------------------------------------------------------ colours */
@@ -379,7 +426,7 @@ int xo_standard_3d(double *S, const double *A, const double *B, const double *C,
     const int64_t P = yc * xc;
 
     for (;;) {
-        if (BCy == BC_EXTEND) extend3d(S, zc, yc, xc, BCx, undef);
+        if (BCy == BC_EXTEND) extend3d(S, zc, yc, xc, BCx, undef, 0);
 
         if (order == XO_LEX) {
             for (int64_t k = 1; k < zc - 1; k++)
@@ -406,6 +453,63 @@ int xo_standard_3d(double *S, const double *A, const double *B, const double *C,
                             int64_t ip = i == xc - 1 ? 0 : i + 1;
                             upd_std3d(S, A, B, C, F, P, xc, k, j, i, im, ip,
                                       delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                        }
+        }
+
+        double norm = norm3d(S, zc, yc, xc, undef);
+        if (ctl_step(&ctl, norm, flags, mxLoop, tolerance, 0)) break;
+    }
+    return 0;
+}
+
+
+/* numbas.py:745-984 invert_general_3D (optional; apps.invert_3DOcean).
+ * BCz is accepted and never read.  Same loop control and norm as the standard 3-D kernel. */
+int xo_general_3d(double *S, const double *A, const double *B, const double *C, const double *D,
+                  const double *E, const double *F, const double *G, const double *H,
+                  int64_t zc, int64_t yc, int64_t xc, double delz, double dely, double delx,
+                  int BCz, int BCy, int BCx, double delxSqr, double ratio2, double ratio1,
+                  double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                  double *flags, int64_t mxLoop, double tolerance, int order)
+{
+    (void)delz; (void)dely; (void)BCz;
+    if (zc < 3 || yc < 3 || xc < 3) return -1;
+    const double *c[8] = { A, B, C, D, E, F, G, H };
+    xo_ctl ctl = { 0, DBL_MAX };
+    const int per = (BCx == BC_PERIODIC);
+    const int seam = (order != XO_LEX) && per && (xc & 1);
+    const int ncol = 2 + (seam ? 2 : 0);
+    const int64_t i0 = per ? 0 : 1, i1 = per ? xc : xc - 1;
+    const int64_t P = yc * xc;
+
+    for (;;) {
+        if (BCy == BC_EXTEND) extend3d(S, zc, yc, xc, BCx, undef, 1);
+
+        if (order == XO_LEX) {
+            for (int64_t k = 1; k < zc - 1; k++)
+                for (int64_t j = 1; j < yc - 1; j++) {
+                    if (per)
+                        upd_gen3d(S, c, P, xc, k, j, 0, xc - 1, 1, 1, delx, delxSqr, ratio2,
+                                  ratio1, ratio2Sqr, ratio1Sqr, optArg, undef);
+                    for (int64_t i = 1; i < xc - 1; i++)
+                        upd_gen3d(S, c, P, xc, k, j, i, i - 1, i + 1, 0, delx, delxSqr, ratio2,
+                                  ratio1, ratio2Sqr, ratio1Sqr, optArg, undef);
+                    if (per)
+                        upd_gen3d(S, c, P, xc, k, j, xc - 1, xc - 2, 0, 0, delx, delxSqr, ratio2,
+                                  ratio1, ratio2Sqr, ratio1Sqr, optArg, undef);
+                }
+        } else {
+            for (int cc = 0; cc < ncol; cc++)
+                for (int64_t k = 1; k < zc - 1; k++)
+                    for (int64_t j = 1; j < yc - 1; j++)
+                        for (int64_t i = i0; i < i1; i++) {
+                            int col = (seam && i == xc - 1) ? 2 + (int)((k + j) & 1)
+                                                             : (int)((k + j + i) & 1);
+                            if (col != cc) continue;
+                            int64_t im = i == 0 ? xc - 1 : i - 1;
+                            int64_t ip = i == xc - 1 ? 0 : i + 1;
+                            upd_gen3d(S, c, P, xc, k, j, i, im, ip, per && i == 0, delx, delxSqr,
+                                      ratio2, ratio1, ratio2Sqr, ratio1Sqr, optArg, undef);
                         }
         }
 

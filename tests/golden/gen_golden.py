@@ -11,6 +11,7 @@ Fixtures written
                     inputs, S after the lexicographic sweeps, flags
   bih_cases.npz     the same for the biharmonic kernel (numbas.invert_general_bih_2D)
   std2dt_cases.npz  the same for numbas.invert_standard_2D_test
+  gen3d_cases.npz   the same for numbas.invert_general_3D
   gill_matsuno.npz  the reference's Gill-Matsuno known-answer case (tests/test_GillMatsuno.py:
                     14-57 inputs; notebook 07 parameters mxLoop=600, tol=1e-5): fields + flags
   stommel.npz       tests/test_StommelWBC.py:14-55 case S2 (beta = 1.8e-11): field + flags
@@ -271,12 +272,50 @@ def real_data():
         print('poisson_atmos', tag, fls[0], fls[1])
     np.savez_compressed(os.path.join(HERE, 'poisson_atmos.npz'), **out)
     np.savez_compressed(os.path.join(HERE, 'mjo_ol.npz'), ol_f32=d['ol'], lat=d['mlat'], lon=d['mlon'])
+def gen3d_cases():
+    """numbas.invert_general_3D (3DOcean) on tiny random volumes: BCy x BCx x mask, including
+    yc > xc with periodic x and a masked H at i == 0 (the west branch never tests H)."""
+    rng = np.random.default_rng(20250512)
+    out, meta, cid = {}, [], 0
+    for (zc, yc, xc) in [(6, 9, 12), (5, 7, 9), (4, 10, 8)]:
+        for BCy in ('fixed', 'extend'):
+            for BCx in ('fixed', 'periodic', 'extend'):
+                if yc > xc and BCy == 'extend' and BCx != 'periodic':
+                    continue                       # the reference indexes out of bounds there
+                for msk in (0, 1):
+                    sh = (zc, yc, xc)
+                    mk = lambda s=1.0: rng.uniform(0.5, 1.5, sh) * s
+                    A, B, C = mk(), mk(), mk()
+                    D, E, F = mk(0.1), -mk(0.1), mk(0.1)
+                    G = -mk(0.01); H = rng.standard_normal(sh)
+                    if msk:
+                        H[rng.random(sh) < 0.15] = U
+                        H[:, :, 0][rng.random((zc, yc)) < 0.3] = U
+                        B[rng.random(sh) < 0.03] = U
+                        G[rng.random(sh) < 0.03] = U
+                    S0 = rng.standard_normal(sh) * 0.1
+                    if msk:
+                        S0[rng.random(sh) < 0.05] = U
+                    delz, dely, delx = 2.0, 1.3, 1.1
+                    omega, nsw = 1.2, 12
+                    S = S0.copy(); fl = np.array([0., 1., 0.])
+                    ref.invert_general_3D(S, A, B, C, D, E, F, G, H, zc, yc, xc, delz, dely, delx,
+                                          'fixed', BCy, BCx, delx**2, delx / delz, delx / dely,
+                                          (delx / delz)**2, (delx / dely)**2, omega, U, fl, nsw, 1e-9)
+                    k = 'g%03d' % cid; cid += 1
+                    out[k + '_in'] = np.stack([S0, A, B, C, D, E, F, G, H])
+                    out[k + '_S'] = S; out[k + '_flags'] = fl
+                    meta.append((k, zc, yc, xc, BCy, BCx, delz, dely, delx, omega, nsw, 1e-9))
+    out['meta'] = np.array([repr(m) for m in meta])
+    np.savez_compressed(os.path.join(HERE, 'gen3d_cases.npz'), **out)
+    print('gen3d_cases: %d cases' % cid)
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['small', 'bih', 'std2dt', 'real', 'gm', 'stommel']
+    which = sys.argv[1:] or ['small', 'bih', 'std2dt', 'gen3d', 'real', 'gm', 'stommel']
     if 'bih' in which: bih_cases()
     if 'std2dt' in which: std2dt_cases()
+    if 'gen3d' in which: gen3d_cases()
     if 'small' in which: small_cases()
     if 'real' in which: real_data()
     if 'gm' in which: gill_matsuno()

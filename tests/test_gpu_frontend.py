@@ -236,6 +236,43 @@ def test_invert_omega_3d_small():
         assert util.rel_l2(S[m], Sl) < 1e-6
 
 
+@pytest.mark.parametrize('coords', ['lat-lon', 'cartesian'])
+def test_invert_3DOcean_matches_lexicographic_oracle(coords):
+    """apps.invert_3DOcean (reference apps.py:830-888, 2055-2109) on a small masked volume with a
+    stratification profile: converged red-black result within 1e-6 rel-L2 of the reference's
+    lexicographic order run on the same coefficients."""
+    import xinvert_amd as xa
+    from xinvert_amd import apps
+    rng = np.random.default_rng(7)
+    zc, yc, xc = 9, 20, 36
+    lev = np.linspace(0., 400., zc)
+    lat = np.linspace(-40, 40, yc) if coords == 'lat-lon' else np.linspace(-2e6, 2e6, yc)
+    lon = np.linspace(0, 350, xc) if coords == 'lat-lon' else np.linspace(0, 6e6, xc)
+    Fv = rng.standard_normal((2, zc, yc, xc)) * 1e-9
+    Fv[:, :, 8:12, 10:14] = np.nan
+    N2 = xa.Field(np.linspace(2e-4, 1e-4, zc), ('lev',), {'lev': lev})
+    F = xa.Field(Fv, ('t', 'lev', 'lat', 'lon'), {'lev': lev, 'lat': lat, 'lon': lon})
+    BCs = ['fixed', 'fixed', 'periodic' if coords == 'lat-lon' else 'fixed']
+    iP = {'BCs': BCs, 'mxLoop': 4000, 'tolerance': 1e-13, 'printInfo': False}
+    mP = {'epsilon': 1e-5, 'N2': N2, 'k': 1e-7, 'f0': 3e-5, 'beta': 2e-11}
+    S = apps.invert_3DOcean(F, ['lev', 'lat', 'lon'], coords=coords, mParams=mP, iParams=iP)
+    assert S.shape == Fv.shape and np.isnan(S.values[:, :, 8:12, 10:14]).all()
+    # the same coefficients through the oracle's lexicographic order
+    mPf = apps._update(apps.default_mParams, mP, ['f0', 'beta', 'epsilon', 'N2', 'k', 'g', 'Omega', 'Rearth'])
+    iPf = apps._update(apps.default_iParams, iP)
+    H, initS, cs = apps._coeffs_3DOcean(F, ['lev', 'lat', 'lon'], coords, mPf, iPf, None)
+    ps = apps._cal_params3D(lev, lat, lon, coords)
+    for m in range(2):
+        p = dict(kind='gen3d', zc=zc, yc=yc, xc=xc, BCz='fixed', BCy=BCs[1], BCx=BCs[2], delz=ps['del3'],
+                 dely=ps['del2'], delx=ps['del1'], delxSqr=ps['del1Sqr'], ratio2=ps['ratio2'],
+                 ratio1=ps['ratio1'], ratio2Sqr=ps['ratio2Sqr'], ratio1Sqr=ps['ratio1Sqr'],
+                 optArg=ps['optArg'], undef=U, S0=np.zeros((zc, yc, xc)),
+                 coefs=[np.ascontiguousarray(c) for c in cs] + [np.ascontiguousarray(H.values[m])])
+        Sl, fll = util.run_oracle(p, 4000, 1e-13, LEX)
+        ok = H.values[m] != U
+        assert fll[2] < 4000 and util.rel_l2(S.values[m][ok], Sl[ok]) < 1e-6
+
+
 def test_non_trailing_core_dims_and_inplace():
     """Core dims anywhere in F (the reference's .loc[sel].values views): result lands in place."""
     import xinvert_amd as xa

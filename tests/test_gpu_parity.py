@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import util
-from util import rand2d, rand2dt, rand3d, randbih, run_oracle, run_hip_single, run_hip_batched, run_hip_dev
+from util import rand2d, rand2dt, rand3d, rand3dg, randbih, run_oracle, run_hip_single, run_hip_batched, run_hip_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +60,38 @@ def test_colour_path_3d(BCy, BCx, msk, shape):
     So, flo = run_oracle(p, 15, 1e-9, COLOUR_AUTO)
     S, fl, st = run_hip_batched([p], 15, 1e-9)
     assert_same(S[0], fl[0], So, flo, '3d')
+
+
+@pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'),
+                                     ('extend', 'fixed'), ('fixed', 'extend')])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', [(6, 9, 12), (5, 7, 9), (7, 10, 66), (4, 12, 8), (3, 3, 3)])
+def test_general_3d_colour_path(BCy, BCx, msk, shape):
+    """numbas.invert_general_3D: red-black on (k+j+i)&1 (+2 seam colours for odd-xc periodic),
+    the west-periodic branch that never tests H, the pre-pass with its range(1, yc-1) second
+    loop (yc > xc), single-slice and batched entries."""
+    p = rand3dg(shape[0], shape[1], shape[2], BCy, BCx, msk, seed=_seed(('g3', BCy, BCx, msk, shape)))
+    So, flo = run_oracle(p, 15, 1e-9, COLOUR_AUTO)
+    S, fl, st = run_hip_batched([p, p], 15, 1e-9)
+    assert st['path'] == PATH_COLOUR
+    assert st['colours'] == 2 + (2 if BCx == 'periodic' and shape[2] % 2 else 0)
+    assert_same(S[0], fl[0], So, flo, 'gen3d')
+    assert np.array_equal(S[0], S[1])
+    S1, f1 = run_hip_single(p, 15, 1e-9)
+    assert np.array_equal(S1, S[0]) and np.array_equal(f1, fl[0])
+
+
+def test_general_3d_dev_and_early_stop():
+    ps = [rand3dg(6, 14, 40, 'fixed', 'periodic', 1, seed=s) for s in (1, 2, 3)]
+    S1, f1, _ = run_hip_batched(ps, 400, 1e-5)
+    S2, f2, _ = run_hip_dev(ps, 400, 1e-5)
+    assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
+    loops = set()
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 400, 1e-5, COLOUR_2)
+        assert_same(S1[m], f1[m], So, flo, 'gen3d member %d' % m)
+        loops.add(flo[2])
+    assert len(loops) > 1
 
 
 def _uniform3d(p, rng):

@@ -91,6 +91,18 @@ def test_converged_3d(oracle):
     assert util.rel_l2(Sc, Sl) < 1e-6
 
 
+@pytest.mark.parametrize('BCx', ['fixed', 'periodic'])
+def test_converged_general_3d(oracle, BCx):
+    """numbas.invert_general_3D: red-black and lexicographic orders converge to the same field
+    (odd xc with periodic x exercises the seam colours)."""
+    p = util.rand3dg(6, 11, 15, 'fixed', BCx, msk=True, seed=31)
+    p['S0'] = np.zeros_like(p['S0'])
+    Sl, fl = util.run_oracle(p, 4000, 1e-15, LEX)
+    Sc, fc = util.run_oracle(p, 4000, 1e-15, AUTO)
+    assert fl[2] < 4000 and fc[2] < 4000
+    assert util.rel_l2(Sc, Sl) < 1e-6
+
+
 def test_auto_picks_two_colours_when_B_is_zero(oracle):
     p = util.rand2d('gen2d', 14, 20, 'fixed', 'periodic', bnz=False, msk=True, seed=8)
     Sa, fa = util.run_oracle(p, 10, 0.0, AUTO)

@@ -224,6 +224,24 @@ def test_munk_known_answers(oracle, A4, pin):
     assert (fl[2] == 4000) == (A4 == 5e3)
 
 
+# ------------------------------------------------------------------ general 3-D (3DOcean), SURVEY 8(f)
+def test_gen3d_small_cases_bitwise(oracle):
+    d = golden('gen3d_cases.npz')
+    metas = [ast.literal_eval(str(m)) for m in d['meta']]
+    assert len(metas) == 32
+    for m in metas:
+        k, zc, yc, xc, BCy, BCx, delz, dely, delx, om, nsw, tol = m
+        arr = d[k + '_in']
+        S = np.ascontiguousarray(arr[0]).copy()
+        fl = np.array([0., 1., 0.])
+        c = [np.ascontiguousarray(a) for a in arr[1:]]
+        oracle.general_3d(S, *c, zc, yc, xc, delz, dely, delx, 'fixed', BCy, BCx, delx**2,
+                          delx / delz, delx / dely, (delx / delz)**2, (delx / dely)**2, om, U, fl,
+                          nsw, tol, LEX)
+        assert np.array_equal(S, d[k + '_S']), m
+        assert np.array_equal(fl, d[k + '_flags']), m
+
+
 # ------------------------------------------------------------------ standard_2D_test, SURVEY 8(f)
 def test_std2dt_small_cases_bitwise(oracle):
     d = golden('std2dt_cases.npz')

@@ -102,6 +102,29 @@ def rand3d(zc, yc, xc, BCy, BCx, msk=False, seed=0, delz=2.0, dely=1.3, delx=1.1
                 ratio1Sqr=(delx / dely)**2, optArg=omega, undef=U, S0=S0, coefs=[A, B, C, F])
 
 
+def rand3dg(zc, yc, xc, BCy, BCx, msk=False, seed=0, delz=2.0, dely=1.3, delx=1.1, omega=1.2):
+    """Random problem for the general 3-D form (A..G, forcing H)."""
+    rng = np.random.default_rng(seed)
+    sh = (zc, yc, xc)
+    mk = lambda s=1.0: rng.uniform(0.5, 1.5, sh) * s
+    A, B, C = mk(), mk(), mk()
+    D, E, F = mk(0.1), -mk(0.1), mk(0.1)
+    G = -mk(0.01)
+    H = rng.standard_normal(sh)
+    if msk:
+        H[rng.random(sh) < 0.15] = U
+        H[:, :, 0][rng.random((zc, yc)) < 0.3] = U
+        B[rng.random(sh) < 0.03] = U
+        G[rng.random(sh) < 0.03] = U
+    S0 = rng.standard_normal(sh) * 0.1
+    if msk:
+        S0[rng.random(sh) < 0.05] = U
+    return dict(kind='gen3d', zc=zc, yc=yc, xc=xc, BCz='fixed', BCy=BCy, BCx=BCx, delz=delz,
+                dely=dely, delx=delx, delxSqr=delx**2, ratio2=delx / delz, ratio1=delx / dely,
+                ratio2Sqr=(delx / delz)**2, ratio1Sqr=(delx / dely)**2, optArg=omega, undef=U,
+                S0=S0, coefs=[A, B, C, D, E, F, G, H])
+
+
 # ------------------------------------------------------------------ oracle runner
 def run_oracle(p, mxLoop, tol, order):
     import oracle as orc
@@ -125,6 +148,10 @@ def run_oracle(p, mxLoop, tol, order):
                            p['delxSSr'], p['delxTr'], p['delxSqr'], p['ratio'], p['ratioSSr'],
                            p['ratioQtr'], p['ratioSqr'], p['optArg'], p['undef'], fl, mxLoop, tol,
                            order)
+    elif p['kind'] == 'gen3d':
+        orc.general_3d(S, *c, p['zc'], p['yc'], p['xc'], p['delz'], p['dely'], p['delx'],
+                       p['BCz'], p['BCy'], p['BCx'], p['delxSqr'], p['ratio2'], p['ratio1'],
+                       p['ratio2Sqr'], p['ratio1Sqr'], p['optArg'], p['undef'], fl, mxLoop, tol, order)
     else:
         orc.standard_3d(S, *c, p['zc'], p['yc'], p['xc'], p['delz'], p['dely'], p['delx'],
                         p['BCz'], p['BCy'], p['BCx'], p['delxSqr'], p['ratio2Sqr'], p['ratio1Sqr'],
@@ -147,13 +174,18 @@ def _scal(p, flags, mxLoop, tol):
         return [p['yc'], p['xc'], p['dely'], p['delx'], b(p['BCy']), b(p['BCx']), p['delxSSr'],
                 p['delxTr'], p['delxSqr'], p['ratio'], p['ratioSSr'], p['ratioQtr'], p['ratioSqr'],
                 p['optArg'], p['undef'], fp, mxLoop, tol]
+    if p['kind'] == 'gen3d':
+        return [p['zc'], p['yc'], p['xc'], p['delz'], p['dely'], p['delx'], b(p['BCz']), b(p['BCy']),
+                b(p['BCx']), p['delxSqr'], p['ratio2'], p['ratio1'], p['ratio2Sqr'], p['ratio1Sqr'],
+                p['optArg'], p['undef'], fp, mxLoop, tol]
     return [p['zc'], p['yc'], p['xc'], p['delz'], p['dely'], p['delx'], b(p['BCz']), b(p['BCy']),
             b(p['BCx']), p['delxSqr'], p['ratio2Sqr'], p['ratio1Sqr'], p['optArg'], p['undef'],
             fp, mxLoop, tol]
 
 
 _FN = {'std2d': 'xinv_standard_2d_f64', 'gen2d': 'xinv_general_2d_f64', 'std3d': 'xinv_standard_3d_f64',
-       'bih2d': 'xinv_general_bih_2d_f64', 'std2dt': 'xinv_standard_2d_test_f64'}
+       'bih2d': 'xinv_general_bih_2d_f64', 'std2dt': 'xinv_standard_2d_test_f64',
+       'gen3d': 'xinv_general_3d_f64'}
 
 
 def run_hip_single(p, mxLoop, tol):

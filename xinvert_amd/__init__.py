@@ -3,7 +3,7 @@
 Layout (only what the hot path needs):
   csrc/          hand-written HIP kernels for gfx950 + the C-ABI (include/xinv.h)
   _lib.py        ctypes binding of libxinv_hip.so (no CPU fallback)
-  core.py        inv_standard2D / inv_general2D / inv_standard3D   (reference xinvert/core.py)
+  core.py        inv_standard2D / inv_general2D / inv_standard3D / inv_general3D ...   (reference xinvert/core.py)
   apps.py        invert_Poisson / invert_Stommel / invert_GillMatsuno / invert_omega, cal_flow
                  (reference xinvert/apps.py)
   dist.py        batch-axis sharding across ranks (one process per GPU) + flags gather
@@ -11,9 +11,9 @@ Layout (only what the hot path needs):
 """
 from .field import Field                                           # noqa: F401
 from .core import (inv_standard2D, inv_standard2D_test, inv_general2D, inv_general2D_bih,    # noqa: F401
-                   inv_standard3D)
+                   inv_standard3D, inv_general3D)
 from .apps import (invert_Poisson, invert_Stommel, invert_StommelMunk, invert_GillMatsuno,  # noqa: F401
-                   invert_Fofonoff, invert_BrethertonHaidvogel, invert_omega,
+                   invert_Fofonoff, invert_BrethertonHaidvogel, invert_omega, invert_3DOcean,
                    animate_iteration, cal_flow, default_iParams, default_mParams)
 
 __version__ = '0.1.0'

@@ -49,6 +49,7 @@ EXPORTS = [
     'xinv_standard_2d_f64_dev', 'xinv_general_2d_f64_dev', 'xinv_standard_3d_f64_dev',
     'xinv_general_bih_2d_f64', 'xinv_general_bih_2d_f64_batched', 'xinv_general_bih_2d_f64_dev',
     'xinv_standard_2d_test_f64', 'xinv_standard_2d_test_f64_batched', 'xinv_standard_2d_test_f64_dev',
+    'xinv_general_3d_f64', 'xinv_general_3d_f64_batched', 'xinv_general_3d_f64_dev',
     'xinv_gm_flow_f64_dev',
     'xinv_abs_norm_f64_dev',
 ]
@@ -99,6 +100,10 @@ def load():
     L.xinv_standard_2d_test_f64.argtypes = [_dp] * 7 + std2d_scal
     L.xinv_standard_2d_test_f64_batched.argtypes = [_dp] * 7 + [_i64, _ip] + std2d_scal + [_opt]
     L.xinv_standard_2d_test_f64_dev.argtypes = [_vp] * 7 + [_i64, _ip] + std2d_scal + [_opt, _vp]
+    gen3d_scal = [_i64, _i64, _i64, _f64, _f64, _f64, _int, _int, _int] + [_f64] * 7 + [_dp, _i64, _f64]
+    L.xinv_general_3d_f64.argtypes = [_dp] * 9 + gen3d_scal
+    L.xinv_general_3d_f64_batched.argtypes = [_dp] * 9 + [_i64, _ip] + gen3d_scal + [_opt]
+    L.xinv_general_3d_f64_dev.argtypes = [_vp] * 9 + [_i64, _ip] + gen3d_scal + [_opt, _vp]
     L.xinv_gm_flow_f64_dev.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _vp, _f64, _int, _vp]
     L.xinv_abs_norm_f64_dev.argtypes = [_vp, _i64, _f64, _dp, _vp]
     for name in EXPORTS:

@@ -104,9 +104,9 @@ def invert_GillMatsuno(Q, dims, coords='lat-lon', icbc=None,
                      mParams, iParams)
 
 
-def invert_omega(F, dims, coords='lat-lon', icbc=None,
-                 mParams=default_mParams, iParams=default_iParams):
-    """QG omega equation, standard 3-D form (reference apps.py:766-827)."""
+def _check_N2(mParams):
+    """Stratification profile sanity checks shared by the 3-D apps (reference apps.py:817-823,
+    877-883): only array-valued N2 is checked, from its second level on."""
     N2 = mParams['N2'] if 'N2' in mParams else None
     if N2 is not None and not np.isscalar(N2):
         n2 = np.asarray(N2.values if hasattr(N2, 'values') else N2)
@@ -118,8 +118,23 @@ def invert_omega(F, dims, coords='lat-lon', icbc=None,
                 raise Exception('nan in coefficient A')
             if (tail <= 0).any():
                 raise Exception('unstable stratification in coefficient A')
+
+
+def invert_omega(F, dims, coords='lat-lon', icbc=None,
+                 mParams=default_mParams, iParams=default_iParams):
+    """QG omega equation, standard 3-D form (reference apps.py:766-827)."""
+    _check_N2(mParams)
     return _template(_coeffs_omega, core.inv_standard3D, 3, F, dims, coords,
                      icbc, ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_3DOcean(F, dims, coords='lat-lon', icbc=None,
+                   mParams=default_mParams, iParams=default_iParams):
+    """3-D wind-driven ocean flow with linear damping, general 3-D form
+    (reference apps.py:830-888).  mParams needs 'k' (buoyancy damping) besides the defaults."""
+    _check_N2(mParams)
+    return _template(_coeffs_3DOcean, core.inv_general3D, 3, F, dims, coords, icbc,
+                     ['f0', 'beta', 'epsilon', 'N2', 'k', 'g', 'Omega', 'Rearth'], mParams, iParams)
 
 
 _ANIMATE = {
@@ -135,6 +150,8 @@ _ANIMATE = {
     'fofonoff': ('_coeffs_Fofonoff', 'inv_standard2D_test',
                  ['c0', 'c1', 'f0', 'beta', 'g', 'Omega', 'Rearth']),
     'omega': ('_coeffs_omega', 'inv_standard3D', ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth']),
+    '3docean': ('_coeffs_3DOcean', 'inv_general3D',
+                ['f0', 'beta', 'N2', 'epsilon', 'k', 'g', 'Omega', 'Rearth']),
 }
 
 
@@ -586,6 +603,56 @@ def _coeffs_omega(force, dims, coords, mParams, iParams, icbc):
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
     return maskF.like(Fv), initS, (A, B, C)
+
+
+def _coeffs_3DOcean(force, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:2055-2109.  c3 = k / N2 (scalar or a profile over dims[0]); the
+    derivative coefficients use numpy.gradient (== xarray's differentiate, edge_order 1) over the
+    level and latitude coordinates; G is identically zero.  Every coefficient depends on
+    (level, latitude) only, so they are built once on the core shape (batch stride 0)."""
+    f0, beta, epsilon = mParams['f0'], mParams['beta'], mParams['epsilon']
+    N2, k = mParams['N2'], mParams['k']
+    Omega, Rearth = mParams['Omega'], mParams['Rearth']
+    maskF, initS, zero = _mask_FS(force, dims, iParams, icbc)
+    zc, yc, xc = (maskF.shape[maskF.axis(d)] for d in dims)
+    z3 = np.zeros((zc, yc, xc))
+    zv = np.asarray(force[dims[0]], dtype=np.float64)
+    yv = np.asarray(force[dims[1]], dtype=np.float64)
+    if np.isscalar(N2):
+        c3 = (zv - zv) + k / N2
+    else:
+        c3 = (zv - zv) + k / np.asarray(N2.values if hasattr(N2, 'values') else N2, dtype=np.float64)
+    lev = lambda v: v[:, None, None]
+    lat = lambda v: v[None, :, None]
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosL = np.cos(lats)
+        f = 2. * Omega * np.sin(lats)
+        c1 = epsilon / (epsilon**2. + f**2.)
+        c2 = f / (epsilon**2. + f**2.)
+        deg2m = Rearth / 180. * np.pi
+        A = z3 + lev(c3)
+        B = z3 + lat(c1)
+        C = z3 + lat(c1 / cosL**2.)
+        D = z3 + lev(np.gradient(c3, zv))
+        E = z3 + lat(np.gradient(c1, yv) / deg2m - c1 * np.tan(lats) / Rearth)
+        Fc = z3 - lat(np.gradient(c2, yv) / deg2m / cosL)
+        G = z3
+    elif c == 'cartesian':
+        f = f0 + beta * yv
+        c1 = epsilon / (epsilon**2. + f**2.)
+        c2 = f / (epsilon**2. + f**2.)
+        A = z3 + lev(c3)
+        B = z3 + lat(c1)
+        C = z3 + lat(c1)
+        D = z3 + lev(np.gradient(c3, zv))
+        E = z3 + lat(np.gradient(c1, yv))
+        Fc = z3 - lat(np.gradient(c2, yv))
+        G = z3
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    return maskF.like(maskF.values), initS, (A, B, C, D, E, Fc, G)
 
 
 def _core_zero(maskF, dims):

@@ -58,6 +58,14 @@ def inv_standard3D(A, B, C, F, S, dims, iParams):
     return _solve('std3d', (A, B, C), F, S, dims, iParams)
 
 
+def inv_general3D(A, B, C, D, E, F, G, H, S, dims, iParams):
+    """A d2S/dz2 + B d2S/dy2 + C d2S/dx2 + D dS/dz + E dS/dy + F dS/dx + G S = H
+    (reference core.py:294-371)."""
+    if len(dims) != 3:
+        raise Exception('3 dimensions are needed for inversion')
+    return _solve('gen3d', (A, B, C, D, E, F, G), H, S, dims, iParams)
+
+
 # ------------------------------------------------------------------------------ internals
 def _vals(a):
     return a.values if isinstance(a, Field) or hasattr(a, 'values') else np.asarray(a)
@@ -160,6 +168,13 @@ def _solve(kind, coefs, F, S, dims, iParams):
             float(iParams['ratio']), float(iParams['ratioSSr']), float(iParams['ratioQtr']),
             float(iParams['ratioSqr']), float(iParams['optArg']), _undeftmp,
             _lib.hptr(flags), mx, tol, opt)
+    elif kind == 'gen3d':
+        rc = L.xinv_general_3d_f64_batched(
+            *ptrs, nbatch, st, iParams['gc3'], iParams['gc2'], iParams['gc1'],
+            float(iParams['del3']), float(iParams['del2']), float(iParams['del1']),
+            BCs[0], BCs[1], BCs[2], float(iParams['del1Sqr']), float(iParams['ratio2']),
+            float(iParams['ratio1']), float(iParams['ratio2Sqr']), float(iParams['ratio1Sqr']),
+            float(iParams['optArg']), _undeftmp, _lib.hptr(flags), mx, tol, opt)
     else:
         rc = L.xinv_standard_3d_f64_batched(
             *ptrs, nbatch, st, iParams['gc3'], iParams['gc2'], iParams['gc1'],

@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void k_colour_std2dt(ColourArgs2D a)
 // ------------------------------------------------------------------------------- 3-D
 struct ColourArgs3D {
     double *S;
-    const double *c[4];        // A,B,C,F
-    int64_t sS, sc[4];
+    const double *c[8];        // standard: A,B,C,F ; general: A..H
+    int64_t sS, sc[8];
     int64_t zc, yc, xc;
     int per, seam, colour, force;
     XinvScal sc_;
@@ -203,6 +203,41 @@ __global__ __launch_bounds__(256) void k_colour_std3d(ColourArgs3D a)
     const int64_t p = r + i;
     S[p] = xinv_upd_std3d(S[p], S[p + P], S[p - P], S[p + xc], S[p - xc], S[r + ip], S[r + im],
                           A[p + P], A[p], B[p + xc], B[p], C[r + ip], C[p], F[p], a.sc_);
+}
+
+// general 3-D form (numbas.invert_general_3D, numbas.py:745-984): same colouring and grid.
+__global__ __launch_bounds__(256) void k_colour_gen3d(ColourArgs3D a)
+{
+    const int64_t nk = a.zc - 2;
+    const int64_t m = a.member0 + blockIdx.z / nk;
+    const int64_t k = 1 + blockIdx.z % nk;
+    if (!a.force && a.ctl[m].done) return;
+    const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = 1 + (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    if (j > a.yc - 2) return;
+    const int64_t xc = a.xc;
+    int64_t i;
+    if (a.colour >= 2) {
+        if (ti != 0 || ((k + j) & 1) != a.colour - 2) return;
+        i = xc - 1;
+    } else {
+        i = 2 * ti + ((k + j + a.colour) & 1);
+        const int64_t ilo = a.per ? 0 : 1;
+        const int64_t ihi = a.per ? xc - 1 : xc - 2;
+        if (i < ilo || i > ihi) return;
+        if (a.seam && i == xc - 1) return;
+    }
+    const int64_t P = a.yc * xc;
+    double *S = a.S + m * a.sS;
+    const int64_t im = (i == 0) ? xc - 1 : i - 1;
+    const int64_t ip = (i == xc - 1) ? 0 : i + 1;
+    const int64_t r = k * P + j * xc;
+    const int64_t p = r + i;
+    double cv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) cv[q] = a.c[q][m * a.sc[q] + p];
+    S[p] = xinv_upd_gen3d(S[p], S[p + P], S[p - P], S[p + xc], S[p - xc], S[r + ip], S[r + im],
+                          cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7], i != 0, a.sc_);
 }
 
 // ---------------------------------------------------------------- 'extend' pre-pass

@@ -116,6 +116,7 @@ __device__ __forceinline__ double xinv_lane_down(double v)     // lane i <- lane
 struct XinvScal {
     double delx, delxSqr, ratio, ratioQtr, ratioSqr;   // 2-D
     double ratio2Sqr, ratio1Sqr;                       // 3-D
+    double ratio2, ratio1;                             // general 3-D
     double delxSSr, delxTr, ratioSSr;                  // biharmonic 2-D
     double optArg, undef;
 };
@@ -258,6 +259,44 @@ __device__ __forceinline__ double xinv_upd_std3d(
     temp *= sc.optArg / ((aP + a0) * sc.ratio2Sqr +
                          (bP + b0) * sc.ratio1Sqr +
                          (cE + c0));
+    return sC + temp;
+}
+
+// general 3-D, 7-point (numbas.py:899-930).  `testH` is false in the reference's west-periodic
+// branch, which tests G twice and never H (numbas.py:849-852).
+__device__ __forceinline__ double xinv_upd_gen3d(
+    double sC, double sKP, double sKM, double sJP, double sJM, double sE, double sW,
+    double A, double B, double C, double D, double E, double F, double G, double H, bool testH,
+    const XinvScal &sc)
+{
+    const double u = sc.undef;
+    bool cond = (!testH || H != u) && (G != u) && (A != u) && (B != u) && (C != u) && (D != u) &&
+                (E != u) && (F != u);
+    if (!cond) return sC;
+    double temp = (
+        A * (
+            (sKP - sC)-(sC - sKM)
+        ) * sc.ratio2Sqr +
+        B * (
+            (sJP - sC)-(sC - sJM)
+        ) * sc.ratio1Sqr +
+        C * (
+            (sE - sC)-(sC - sW)
+        ) + (
+        D * (
+            (sKP - sKM)
+        ) * sc.ratio2 +
+        E * (
+            (sJP - sJM)
+        ) * sc.ratio1 +
+        F * (
+            (sE - sW)
+        )) * sc.delx / 2.0 + (
+        G * sC - H) * sc.delxSqr
+    );
+    temp *= sc.optArg / ((
+        A*sc.ratio2Sqr + B*sc.ratio1Sqr + C
+    ) * 2.0 - G*sc.delxSqr);
     return sC + temp;
 }
 

@@ -92,13 +92,14 @@ static int ensure_dev(T **p, size_t *cap, size_t need_bytes)
 }
 
 // ------------------------------------------------------------------ problem description
-enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3, KIND_STD2DT = 4 };
+enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3, KIND_STD2DT = 4, KIND_GEN3D = 5 };
+static inline bool is3d(int kind) { return kind == KIND_STD3D || kind == KIND_GEN3D; }
 
 struct Problem {
     int kind;
     int64_t nbatch, zc, yc, xc;
     double *S;
-    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J ; std2dt: A..F
+    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J ; std2dt: A..F ; gen3d: A..H
     int64_t sS, sc[10];
     int ncoef;
     int BCz, BCy, BCx;
@@ -115,9 +116,9 @@ static int validate(const Problem &p, const double *flags)
         if (!p.c[q] && !(q == 1 && (p.kind == KIND_STD2D || p.kind == KIND_GEN2D)))   // B may be NULL: identically 0
             return fail_arg("null coefficient array");
     if (p.nbatch < 1) return fail_arg("nbatch < 1");
-    if (p.yc < 3 || p.xc < 3 || (p.kind == KIND_STD3D && p.zc < 3))
+    if (p.yc < 3 || p.xc < 3 || (is3d(p.kind) && p.zc < 3))
         return fail_arg("every core dimension needs at least 3 points");
-    if (!bc_ok(p.BCy) || !bc_ok(p.BCx) || (p.kind == KIND_STD3D && !bc_ok(p.BCz)))
+    if (!bc_ok(p.BCy) || !bc_ok(p.BCx) || (is3d(p.kind) && !bc_ok(p.BCz)))
         return fail_arg("unknown boundary-condition code");
     if (p.kind == KIND_BIH2D && (p.yc < 5 || p.xc < 7))
         return fail_arg("the biharmonic form needs yc >= 5 and xc >= 7");
@@ -416,8 +417,9 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
     } else if (p.BCy == XINV_BC_EXTEND) {
         ExtendArgs e;
         e.S = p.S; e.sS = p.sS; e.yc = p.yc; e.xc = p.xc;
-        e.kfirst = (p.kind == KIND_STD3D) ? 1 : 0;
-        e.nk = (p.kind == KIND_STD3D) ? p.zc - 2 : 1;
+        e.kfirst = is3d(p.kind) ? 1 : 0;
+        e.nk = is3d(p.kind) ? p.zc - 2 : 1;
+        // the standard 3-D kernel's second loop stays inside the row (numbas.py:104-108)
         e.per = per; e.tall = (p.kind != KIND_STD3D) && (p.yc > p.xc); e.force = 0;
         e.undef = p.sc_.undef; e.ctl = ws->ctl; e.member0 = m0;
         dim3 g(cdiv(p.xc, 256), (unsigned)e.nk, (unsigned)nm), b(256, 1, 1);
@@ -425,11 +427,11 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
     }
     if (p.kind == KIND_BIH2D) {
         // sweeps launched above
-    } else if (p.kind == KIND_STD3D) {
+    } else if (is3d(p.kind)) {
         ColourArgs3D a;
         memset(&a, 0, sizeof a);
         a.S = p.S; a.sS = p.sS;
-        for (int q = 0; q < 4; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
+        for (int q = 0; q < p.ncoef; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
         a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
         a.per = per; a.seam = pl.seam; a.force = 0; a.sc_ = p.sc_; a.ctl = ws->ctl;
         a.nbatch = p.nbatch; a.member0 = m0;
@@ -437,7 +439,8 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
         dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)(nm * (p.zc - 2)));
         for (int cc = 0; cc < pl.ncol; cc++) {
             a.colour = cc;
-            hipLaunchKernelGGL(k_colour_std3d, g, b, 0, st, a);
+            if (p.kind == KIND_GEN3D) hipLaunchKernelGGL(k_colour_gen3d, g, b, 0, st, a);
+            else                      hipLaunchKernelGGL(k_colour_std3d, g, b, 0, st, a);
         }
     } else {
         ColourArgs2D a;
@@ -480,7 +483,7 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
 {
     // grid.z carries members (x planes in 3-D) and is limited to 65535
     int64_t chunk = XINV_MEMBER_CHUNK;
-    if (p.kind == KIND_STD3D) chunk = std::max<int64_t>(1, 65535 / std::max<int64_t>(1, p.zc - 2));
+    if (is3d(p.kind)) chunk = std::max<int64_t>(1, 65535 / std::max<int64_t>(1, p.zc - 2));
     for (int64_t m0 = 0; m0 < p.nbatch; m0 += chunk) {
         int rc = launch_colour_chunk(p, pl, ws, st, m0, std::min<int64_t>(chunk, p.nbatch - m0));
         if (rc) return rc;
@@ -564,7 +567,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     // ---- colouring: red-black when the cross coefficient vanishes, else 4 colours ----------
     Plan pl;
     memset(&pl, 0, sizeof pl);
-    if (p.kind == KIND_STD3D) {
+    if (is3d(p.kind)) {
         pl.base = 2;
     } else if (p.kind == KIND_BIH2D) {
         pl.base = 9;                                   // radius-2 stencil: (j%3, i%3)
@@ -598,7 +601,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     }
 
     // ---- path ------------------------------------------------------------------------------
-    const bool fused5_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D;
+    const bool fused5_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
     const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
                            (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
     const bool fused_ok = fused5_ok || fused9_ok;
@@ -607,7 +610,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
         return fail_arg("no fused kernel for this form (odd-xc periodic seam, biharmonic, or 9-point test form)");
-    if (pl.path == XINV_PATH_COLOUR && p.kind != KIND_STD3D && !p.c[1] && pl.base == 4)
+    if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 
     if (pl.path == XINV_PATH_FUSED && pl.nine) {
@@ -1098,6 +1101,27 @@ static Problem mk_std3d(double *S, const double *A, const double *B, const doubl
     return p;
 }
 
+static Problem mk_gen3d(double *S, const double *const *c, int64_t nbatch, const int64_t *st,
+                        int64_t zc, int64_t yc, int64_t xc, double delx, int BCz, int BCy, int BCx,
+                        double delxSqr, double ratio2, double ratio1, double ratio2Sqr,
+                        double ratio1Sqr, double optArg, double undef, int64_t mxLoop, double tol)
+{
+    Problem p;
+    memset(&p, 0, sizeof p);
+    p.kind = KIND_GEN3D; p.nbatch = nbatch; p.zc = zc; p.yc = yc; p.xc = xc;
+    p.S = S; p.ncoef = 8;
+    const int64_t n = zc * yc * xc;
+    p.sS = st ? st[0] : n;
+    for (int q = 0; q < 8; q++) { p.c[q] = c[q]; p.sc[q] = st ? st[1 + q] : n; }
+    p.BCz = BCz; p.BCy = BCy; p.BCx = BCx;
+    memset(&p.sc_, 0, sizeof p.sc_);
+    p.sc_.delx = delx; p.sc_.delxSqr = delxSqr; p.sc_.ratio2 = ratio2; p.sc_.ratio1 = ratio1;
+    p.sc_.ratio2Sqr = ratio2Sqr; p.sc_.ratio1Sqr = ratio1Sqr;
+    p.sc_.optArg = optArg; p.sc_.undef = undef;
+    p.stop.mxLoop = mxLoop; p.stop.tolerance = tol; p.stop.stop_on_zero_norm = 0;
+    return p;
+}
+
 // ------------------------------------------------------------------ C-ABI
 extern "C" {
 
@@ -1251,6 +1275,55 @@ int xinv_standard_3d_f64_dev(double *S, const double *A, const double *B, const 
     if (!strides) return fail_arg("null strides");
     Problem p = mk_std3d(S, A, B, C, F, nbatch, strides, zc, yc, xc, BCz, BCy, BCx, delxSqr,
                          ratio2Sqr, ratio1Sqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
+}
+
+int xinv_general_3d_f64(double *S, const double *A, const double *B, const double *C,
+                        const double *D, const double *E, const double *F, const double *G,
+                        const double *H, int64_t zc, int64_t yc, int64_t xc, double delz,
+                        double dely, double delx, int BCz, int BCy, int BCx, double delxSqr,
+                        double ratio2, double ratio1, double ratio2Sqr, double ratio1Sqr,
+                        double optArg, double undef, double *flags, int64_t mxLoop,
+                        double tolerance)
+{
+    (void)delz; (void)dely;
+    const double *c[8] = { A, B, C, D, E, F, G, H };
+    Problem p = mk_gen3d(S, c, 1, nullptr, zc, yc, xc, delx, BCz, BCy, BCx, delxSqr, ratio2, ratio1,
+                         ratio2Sqr, ratio1Sqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, nullptr))
+}
+
+int xinv_general_3d_f64_batched(double *S, const double *A, const double *B, const double *C,
+                                const double *D, const double *E, const double *F,
+                                const double *G, const double *H, int64_t nbatch,
+                                const int64_t *strides, int64_t zc, int64_t yc, int64_t xc,
+                                double delz, double dely, double delx, int BCz, int BCy, int BCx,
+                                double delxSqr, double ratio2, double ratio1, double ratio2Sqr,
+                                double ratio1Sqr, double optArg, double undef, double *flags,
+                                int64_t mxLoop, double tolerance, const xinv_options *opt)
+{
+    (void)delz; (void)dely;
+    if (!strides) return fail_arg("null strides");
+    const double *c[8] = { A, B, C, D, E, F, G, H };
+    Problem p = mk_gen3d(S, c, nbatch, strides, zc, yc, xc, delx, BCz, BCy, BCx, delxSqr, ratio2,
+                         ratio1, ratio2Sqr, ratio1Sqr, optArg, undef, mxLoop, tolerance);
+    GUARD(solve_host(p, flags, opt))
+}
+
+int xinv_general_3d_f64_dev(double *S, const double *A, const double *B, const double *C,
+                            const double *D, const double *E, const double *F, const double *G,
+                            const double *H, int64_t nbatch, const int64_t *strides, int64_t zc,
+                            int64_t yc, int64_t xc, double delz, double dely, double delx, int BCz,
+                            int BCy, int BCx, double delxSqr, double ratio2, double ratio1,
+                            double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                            double *flags, int64_t mxLoop, double tolerance,
+                            const xinv_options *opt, void *stream)
+{
+    (void)delz; (void)dely;
+    if (!strides) return fail_arg("null strides");
+    const double *c[8] = { A, B, C, D, E, F, G, H };
+    Problem p = mk_gen3d(S, c, nbatch, strides, zc, yc, xc, delx, BCz, BCy, BCx, delxSqr, ratio2,
+                         ratio1, ratio2Sqr, ratio1Sqr, optArg, undef, mxLoop, tolerance);
     GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
 }
 
