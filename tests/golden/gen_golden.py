@@ -17,6 +17,8 @@ Fixtures written
   stommel.npz       tests/test_StommelWBC.py:14-55 case S2 (beta = 1.8e-11): field + flags
   poisson_atmos.npz real data: Data/Helmholtz_atmos.nc `vor` (2x73x144 f32, promoted to f64),
                     lat, lon, and S after 60 reference sweeps for two BC sets
+  eliassen.npz      real data for the 9-point form: Data/ZonalMean.nc (Hadley) and Data/TC2D.nc (TC)
+                    coefficients + forcing, S and flags from the reference kernel
   mjo_ol.npz        real data: Data/MJO.nc `ol` (73x144 f32) for the Gill-Matsuno real case
 """
 import os
@@ -272,6 +274,59 @@ def real_data():
         print('poisson_atmos', tag, fls[0], fls[1])
     np.savez_compressed(os.path.join(HERE, 'poisson_atmos.npz'), **out)
     np.savez_compressed(os.path.join(HERE, 'mjo_ol.npz'), ol_f32=d['ol'], lat=d['mlat'], lon=d['mlon'])
+def eliassen():
+    """Real data for the 9-point standard form (B != 0): the reference's Eliassen tests.
+    Hadley: tests/test_Eliassen.py:16-147 inverts F_EHF + F_AHF with Acoef/Bcoef/Ccoef -- exactly
+    the fields bundled in Data/ZonalMean.nc (37 x 72, f64), BCs fixed/fixed, mxLoop 600, tol 1e-10.
+    TC: tests/test_Eliassen.py:207-232 (Data/TC2D.nc Aa/Bb/Cc/faf, 37 x 50 f32 promoted to f64,
+    undef 9.99e20 -> NaN, optArg 1.4, tol 1e-12)."""
+    tmp = os.path.join(HERE, '_tmp_extract.npz')
+    code = (
+        "import h5py, numpy as np\n"
+        "z=h5py.File('/root/reference/Data/ZonalMean.nc','r')\n"
+        "t=h5py.File('/root/reference/Data/TC2D.nc','r')\n"
+        "np.savez(%r, zA=z['Acoef'][...], zB=z['Bcoef'][...], zC=z['Ccoef'][...], zEHF=z['EHF'][...],"
+        " zEAF=z['EAF'][...], zlev=z['LEV'][...], zlat=z['lat'][...], tA=t['Aa'][...], tB=t['Bb'][...],"
+        " tC=t['Cc'][...], tF=t['faf'][...], tlev=t['lev'][...], tlat=t['lat'][...])\n" % tmp)
+    subprocess.check_call(['/opt/conda/bin/python3.9', '-c', code])
+    d = np.load(tmp)
+    os.remove(tmp)
+    out = {}
+    und = np.float32(9.99e20)
+    cases = {
+        'hadley': dict(A=d['zA'], B=d['zB'], C=d['zC'], F=d['zEHF'] + d['zEAF'], lev=d['zlev'],
+                       lat=d['zlat'].astype(np.float64), iP={'mxLoop': 600, 'tolerance': 1e-10}),
+        'tc': dict(A=np.where(d['tA'] != und, d['tA'], np.nan).astype(np.float64),
+                   B=np.where(d['tB'] != und, d['tB'], np.nan).astype(np.float64),
+                   C=np.where(d['tC'] != und, d['tC'], np.nan).astype(np.float64),
+                   F=np.where(d['tF'] != und, d['tF'], np.nan).astype(np.float64),
+                   lev=d['tlev'], lat=d['tlat'], iP={'mxLoop': 600, 'tolerance': 1e-12, 'optArg': 1.4}),
+    }
+    for tag, c in cases.items():
+        lev, lat = c['lev'], c['lat']
+        F = Field(c['F'], ('lev', 'lat'), {'lev': lev, 'lat': lat})
+        iP = apps._update(apps.default_iParams, dict(c['iP'], BCs=['fixed', 'fixed']))
+        mP = apps._update(apps.default_mParams, {'A': c['A'], 'B': c['B'], 'C': c['C']},
+                          ['A', 'B', 'C', 'g', 'Omega', 'Rearth'])
+        Fm, initS, (A, B, C) = apps._coeffs_Eliassen(F, ['lev', 'lat'], 'z-lat', mP, iP, None)
+        ps = apps._cal_params2D(lev, lat, 'z-lat')
+        om = iP['optArg'] if iP['optArg'] is not None else ps['optArg']
+        yc, xc = F.shape
+        S = np.zeros((yc, xc)); fl = np.array([0., 1., 0.])
+        t = time.time()
+        ref.invert_standard_2D(S, np.ascontiguousarray(A), np.ascontiguousarray(B), np.ascontiguousarray(C),
+                               np.ascontiguousarray(Fm.values), yc, xc, ps['del2'], ps['del1'], 'fixed',
+                               'fixed', ps['del1Sqr'], ps['ratioQtr'], ps['ratioSqr'], om, U, fl,
+                               iP['mxLoop'], iP['tolerance'])
+        print('Eliassen %s: loops %4.0f and tolerance is %e, max|S| %.6e, nan %d (%.1fs)'
+              % (tag, fl[2], fl[1], np.nanmax(np.abs(S)), np.isnan(S).sum(), time.time() - t))
+        for k in ('A', 'B', 'C', 'F', 'lev', 'lat'):
+            out[tag + '_' + k] = c[k]
+        out[tag + '_S'] = S; out[tag + '_flags'] = fl
+        out[tag + '_optArg'] = np.float64(om)
+    np.savez_compressed(os.path.join(HERE, 'eliassen.npz'), **out)
+
+
 def gen3d_cases():
     """numbas.invert_general_3D (3DOcean) on tiny random volumes: BCy x BCx x mask, including
     yc > xc with periodic x and a masked H at i == 0 (the west branch never tests H)."""
@@ -312,11 +367,12 @@ def gen3d_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['small', 'bih', 'std2dt', 'gen3d', 'real', 'gm', 'stommel']
+    which = sys.argv[1:] or ['small', 'bih', 'std2dt', 'gen3d', 'real', 'eliassen', 'gm', 'stommel']
     if 'bih' in which: bih_cases()
     if 'std2dt' in which: std2dt_cases()
     if 'gen3d' in which: gen3d_cases()
     if 'small' in which: small_cases()
     if 'real' in which: real_data()
+    if 'eliassen' in which: eliassen()
     if 'gm' in which: gill_matsuno()
     if 'stommel' in which: stommel()

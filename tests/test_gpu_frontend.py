@@ -185,6 +185,123 @@ def test_invert_poisson_real_data_both_times():
         assert util.rel_l2(sf.values[t], Sl) < 1e-6
 
 
+def test_invert_eliassen_real_data_nine_point():
+    """invert_Eliassen on the reference's bundled data (Data/ZonalMean.nc Hadley case,
+    tests/test_Eliassen.py:131-147; Data/TC2D.nc, :207-232): the fused 4-colour kernel against (i)
+    the REFERENCE's converged field (Hadley: 142 loops) within 1e-6 rel-L2 and (ii) the oracle's
+    4-colour ordering bit for bit on the un-converged 600-sweep TC run."""
+    import xinvert_amd as xa
+    from xinvert_amd import apps
+    d = golden('eliassen.npz')
+    F = xa.Field(d['hadley_F'], ('LEV', 'lat'), {'LEV': d['hadley_lev'], 'lat': d['hadley_lat']})
+    mk = lambda k: xa.Field(d['hadley_' + k], ('LEV', 'lat'), {'LEV': d['hadley_lev'], 'lat': d['hadley_lat']})
+    sf = apps.invert_Eliassen(F, dims=['LEV', 'lat'], coords='z-lat',
+                              iParams={'BCs': ['fixed', 'fixed'], 'mxLoop': 3000, 'tolerance': 1e-13,
+                                       'printInfo': False},
+                              mParams={'A': mk('A'), 'B': mk('B'), 'C': mk('C')})
+    assert sf.dims == F.dims and sf.shape == F.shape
+    ok = ~np.isnan(d['hadley_F'])
+    assert util.rel_l2(sf.values[ok], d['hadley_S'][ok]) < 1e-6
+    # coefficients handed in with swapped dim order are aligned by name
+    sw = lambda k: xa.Field(d['hadley_' + k].T, ('lat', 'LEV'), {'LEV': d['hadley_lev'], 'lat': d['hadley_lat']})
+    sf2 = apps.invert_Eliassen(F, dims=['LEV', 'lat'], coords='z-lat',
+                               iParams={'BCs': ['fixed', 'fixed'], 'mxLoop': 3000, 'tolerance': 1e-13,
+                                        'printInfo': False},
+                               mParams={'A': sw('A'), 'B': sw('B'), 'C': sw('C')})
+    assert np.array_equal(sf2.values, sf.values, equal_nan=True)
+    p, _, _ = util.eliassen_problem('tc')
+    So, flo = util.run_oracle(p, 600, 1e-12, AUTO)
+    S, fl, st = util.run_hip_batched([p], 600, 1e-12)
+    assert st['colours'] == 4 and st['path'] == 2
+    assert np.array_equal(S[0], So) and fl[0][2] == flo[2] == 600
+
+
+_APPS = {
+    # name: (entry, coefficient builder, kernel kind, coords, mParams, valid)
+    'GillMatsuno_test': ('invert_GillMatsuno_test', '_coeffs_GillMatsuno_test', 'std2dt', 'lat-lon',
+                         {'epsilon': 1e-4, 'Phi': 5000.}, ['f0', 'beta', 'epsilon', 'Phi', 'g', 'Omega', 'Rearth']),
+    'Stommel_test': ('invert_Stommel_test', '_coeffs_Stommel_test', 'std2dt', 'cartesian',
+                     {'beta': 1.8e-11, 'R': 8e-4, 'D': 200.}, ['beta', 'R', 'D', 'rho0', 'g', 'Omega', 'Rearth']),
+    'StommelArons': ('invert_StommelArons', '_coeffs_StommelArons', 'gen2d', 'lat-lon',
+                     {'epsilon': 1e-4}, ['f0', 'beta', 'epsilon', 'g', 'Omega', 'Rearth']),
+    'geostrophic': ('invert_geostrophic', '_coeffs_geostrophic', 'std2d', 'lat-lon', {},
+                    ['f0', 'beta', 'Omega', 'g', 'Omega', 'Rearth']),
+    'PV2D': ('invert_PV2D', '_coeffs_PV2D', 'std2d', 'z-lat', {'f0': 1e-4, 'N2': 2e-4},
+             ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth']),
+}
+
+
+@pytest.mark.parametrize('app', sorted(_APPS))
+def test_remaining_apps_converge_to_the_lexicographic_result(app):
+    """the other invert_* entry points that sit on the same kernels.  Each
+    runs through the front end on a small masked problem and must land within 1e-6 rel-L2 of
+    the reference's lexicographic order run on the same coefficients."""
+    import xinvert_amd as xa
+    from xinvert_amd import apps
+    entry, builder, kind, coords, mP, valid = _APPS[app]
+    rng = np.random.default_rng(11)
+    yc, xc = 30, 48
+    if coords == 'lat-lon':
+        y = np.linspace(10, 60, yc); x = np.linspace(0, 352.5, xc); BCs = ['fixed', 'periodic']
+    elif coords == 'z-lat':
+        y = np.linspace(1e5, 2e4, yc); x = np.linspace(10, 60, xc); BCs = ['fixed', 'fixed']
+    else:
+        y = np.linspace(0, 3e6, yc); x = np.linspace(0, 5e6, xc); BCs = ['fixed', 'fixed']
+    Fv = rng.standard_normal((2, yc, xc)) * 1e-10
+    # invert_geostrophic rebuilds its forcing from the RAW input compared against -9.99e8
+    # (apps.py:1913), so only that sentinel masks it -- as in the reference
+    und = U if app == 'geostrophic' else -9999.0
+    Fv[:, 12:16, 20:25] = und
+    F = xa.Field(Fv, ('t', 'y', 'x'), {'y': y, 'x': x})
+    iP = {'BCs': BCs, 'mxLoop': 6000, 'tolerance': 1e-14, 'printInfo': False, 'undef': und}
+    if kind == 'std2dt':
+        iP['optArg'] = 1.0      # the flux forms carry large antisymmetric cross terms: plain SOR needs omega <= 1
+    S = getattr(apps, entry)(F, ['y', 'x'], coords=coords, mParams=mP, iParams=iP)
+    assert S.shape == Fv.shape and (S.values[:, 12:16, 20:25] == und).all()
+    iPf = apps._update(apps.default_iParams, iP)
+    mPf = apps._update(apps.default_mParams, mP, valid)
+    H, initS, cs = getattr(apps, builder)(F, ['y', 'x'], coords, mPf, iPf, None)
+    ps = apps._cal_params2D(y, x, coords)
+    for m in range(2):
+        p = dict(kind=kind, yc=yc, xc=xc, BCy=BCs[0], BCx=BCs[1], dely=ps['del2'], delx=ps['del1'],
+                 delxSqr=ps['del1Sqr'], ratio=ps['ratio'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'],
+                 optArg=iP.get('optArg', ps['optArg']), undef=U, S0=np.zeros((yc, xc)),
+                 coefs=[np.ascontiguousarray(c[m]) for c in cs] + [np.ascontiguousarray(H.values[m])])
+        Sl, fll = util.run_oracle(p, 6000, 1e-14, LEX)
+        ok = H.values[m] != U
+        assert fll[0] == 0 and fll[2] < 6000, fll
+        assert util.rel_l2(S.values[m][ok], Sl[ok]) < 1e-6
+
+
+def test_invert_refstate_vertical_plane():
+    """invert_RefState (apps.py:104-145): PV-dependent C coefficient (varies per batch member),
+    Gamma profile aligned by dim name; 'Gamma' has no default."""
+    import xinvert_amd as xa
+    from xinvert_amd import apps
+    rng = np.random.default_rng(5)
+    th = np.linspace(300, 400, 21); r = np.linspace(1e5, 2.1e6, 41)
+    PV = xa.Field(2e-6 * (1 + 0.3 * rng.random((3, 21, 41))), ('t', 'th', 'r'), {'th': th, 'r': r})
+    gam = xa.Field(np.linspace(1e-3, 2e-3, 21), ('th',), {'th': th})
+    ic = xa.Field(np.broadcast_to((r**2 * 5e-5)[None, None, :], PV.shape).copy(), PV.dims, PV.coords)
+    iP = {'BCs': ['fixed', 'fixed'], 'mxLoop': 4000, 'tolerance': 1e-13, 'printInfo': False}
+    with pytest.raises(KeyError):
+        apps.invert_RefState(PV, ['th', 'r'], coords='cartesian', iParams=iP, icbc=ic)
+    S = apps.invert_RefState(PV, ['th', 'r'], coords='cartesian', mParams={'Gamma': gam}, iParams=iP, icbc=ic)
+    assert S.iParams['stats']['path'] == 2
+    mPf = apps._update(apps.default_mParams, {'Gamma': gam}, ['Ang0', 'Gamma', 'g', 'Omega', 'Rearth'])
+    iPf = apps._update(apps.default_iParams, iP)
+    H, initS, cs = apps._coeffs_RefState(PV, ['th', 'r'], 'cartesian', mPf, iPf, ic)
+    assert cs[2].strides[0] != 0 and cs[0].strides[0] == 0          # C per member, A shared
+    ps = apps._cal_params2D(th, r, 'cartesian')
+    for m in range(3):
+        p = dict(kind='std2d', yc=21, xc=41, BCy='fixed', BCx='fixed', dely=ps['del2'], delx=ps['del1'],
+                 delxSqr=ps['del1Sqr'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'], optArg=ps['optArg'],
+                 undef=U, S0=initS.values[m].copy(),
+                 coefs=[np.ascontiguousarray(c[m]) for c in cs] + [np.ascontiguousarray(H.values[m])])
+        Sl, fll = util.run_oracle(p, 4000, 1e-13, LEX)
+        assert fll[2] < 4000 and util.rel_l2(S.values[m], Sl) < 1e-6
+
+
 def test_animate_iteration_poisson_real_data():
     """reference tests/test_AnimateConverge.py:13-31: 40 frames of (1+1) sweeps on the bundled
     vorticity; frames must equal single solves of the same total sweep count (restartability)."""

@@ -114,6 +114,71 @@ def test_poisson_coefficients_latlon():
     assert Fm.values[1, 4, 3] == -9.99e8 and Fm.values[0, 4, 3] == np.cos(np.deg2rad(lat[4]))
 
 
+def test_remaining_app_coefficients_follow_the_reference_formulas():
+    """Spot values of the coefficient builders added for SURVEY 8(f) rank 4, written out from
+    the reference's formulas (apps.py:1440-1467, 1556-1606, 1660-1709, 1751-1790, 1839-1931,
+    2055-2109) independently of the builders."""
+    Om, Re = 7.292e-5, 6371200.0
+    lat = np.linspace(-30, 40, 8); lon = np.linspace(0, 315, 8)
+    z = np.ones((2, 8, 8)); z[1, 4, 3] = np.nan
+    F = Field(z, ('time', 'lat', 'lon'), {'lat': lat, 'lon': lon})
+    iP = apps._update(apps.default_iParams, {})
+    mP = apps._update(apps.default_mParams, {'epsilon': 1e-5, 'Phi': 5000., 'D': 200., 'R': 1e-4})
+    la = np.deg2rad(lat); f = 2 * Om * np.sin(la)
+    j = 5
+    half = (la[j] + la[j - 1]) / 2
+    # Gill-Matsuno, flux form
+    Fm, S, (A, B, C, D, E) = apps._coeffs_GillMatsuno_test(F, ['lat', 'lon'], 'lat-lon', mP, iP, None)
+    fH = 2 * Om * np.sin(half)
+    assert np.isnan(A[0, 0, 0]) and A[1, j, 2] == 1e-5 / (1e-10 + fH**2) * 5000. * np.cos(half)
+    assert B[0, j, 0] == -(f[j] / (1e-10 + f[j]**2)) * 5000. and C[0, j, 0] == -B[0, j, 0]
+    assert D[0, j, 1] == 1e-5 / (1e-10 + f[j]**2) * 5000. / np.cos(la[j]) and E[0, j, 1] == -1e-5 * np.cos(la[j])
+    assert Fm.values[1, 4, 3] == -9.99e8 and Fm.values[0, j, 3] == np.cos(la[j])
+    # Stommel, flux form
+    Fm, S, (A, B, C, D, E) = apps._coeffs_Stommel_test(F, ['lat', 'lon'], 'lat-lon', mP, iP, None)
+    assert A[0, j, 0] == -1e-4 / 200. * np.cos(half) and B[0, j, 0] == -f[j] and C[0, j, 0] == f[j]
+    assert D[0, j, 0] == -1e-4 / 200. / np.cos(la[j]) and (E == 0).all()
+    assert Fm.values[0, j, 0] == -1.0 / 200. / 1027 * np.cos(la[j])
+    # Stommel-Arons: the Gill-Matsuno operator with Phi = 1, F == 0
+    G, S, (A, B, C, D, E, Fc) = apps._coeffs_StommelArons(F, ['lat', 'lon'], 'lat-lon', mP, iP, None)
+    c1 = 1e-5 / (1e-10 + f**2); c2 = f / (1e-10 + f**2); d2m = Re / 180. * np.pi
+    assert A[0, j, 0] == c1[j] and C[0, j, 0] == c1[j] / np.cos(la[j])**2 and (B == 0).all() and (Fc == 0).all()
+    assert D[0, j, 0] == np.gradient(c1, lat)[j] / d2m + c1[j] * np.tan(la[j]) / Re
+    assert E[0, j, 0] == -np.gradient(c2, lat)[j] / d2m / np.cos(la[j])
+    # geostrophic: |f| < 2e-5 inflated by 1.5; forcing rebuilt from the RAW input (NaN stays NaN)
+    Fm, S, (A, B, C) = apps._coeffs_geostrophic(F, ['lat', 'lon'], 'lat-lon', mP, iP, None)
+    jj = int(np.argmin(np.abs(lat)))
+    assert abs(f[jj]) < 2e-5 and C[0, jj, 0] == f[jj] * 1.5 / np.cos(la[jj])
+    assert C[0, j, 0] == f[j] / np.cos(la[j]) and A[0, j, 0] == fH * np.cos(half)
+    assert np.isnan(Fm.values[1, 4, 3])
+    # PV2D / RefState / Eliassen in a vertical plane
+    lev = np.linspace(1e5, 2e4, 5)
+    P = Field(np.full((5, 8), 2e-6), ('lev', 'lat'), {'lev': lev, 'lat': lat + 45.})
+    n2 = Field(np.linspace(1e-4, 3e-4, 5), ('lev',), {'lev': lev})
+    Fm, S, (A, B, C) = apps._coeffs_PV2D(P, ['lev', 'lat'], 'z-lat', dict(mP, N2=n2), iP, None)
+    assert A.shape == (5, 8) and A[3, 2] == mP['f0']**2 / n2.values[3] and (C == 1).all() and (B == 0).all()
+    gam = Field(np.linspace(1e-3, 2e-3, 5), ('lev',), {'lev': lev})
+    Fm, S, (A, B, C) = apps._coeffs_RefState(P, ['lev', 'lat'], 'z-lat', dict(mP, Gamma=gam), iP, None)
+    assert A[2, 3] == np.sin(np.deg2rad(lat[3] + 45.)) and C[2, 3] == gam.values[2] * mP['g'] / 2e-6 / (lat[3] + 45.)
+    Fm, S, (A, B, C) = apps._coeffs_RefState(P, ['lev', 'lat'], 'cartesian', dict(mP, Gamma=gam), iP, None)
+    assert A[2, 3] == 2.0 * mP['ang0'] / (lat[3] + 45.)**3.0
+    with pytest.raises(Exception, match='is not used'):
+        apps.invert_RefState(P, ['lev', 'lat'], mParams={'ang0': 1.0, 'Gamma': gam})     # the valid key is 'Ang0'
+    a = Field(np.arange(40.).reshape(8, 5), ('lat', 'lev'), {'lev': lev, 'lat': lat + 45.})
+    Fm, S, (A, B, C) = apps._coeffs_Eliassen(P, ['lev', 'lat'], 'z-lat', dict(mP, A=a, B=0.5, C=np.ones((5, 8))), iP, None)
+    assert A.shape == (5, 8) and A[1, 2] == a.values[2, 1] and (B == 0.5).all() and (C == 1).all()
+    # 3-D ocean
+    F3 = Field(np.ones((5, 8, 8)), ('lev', 'lat', 'lon'), {'lev': np.linspace(0, 400, 5), 'lat': lat, 'lon': lon})
+    n2 = Field(np.linspace(2e-4, 1e-4, 5), ('lev',), {'lev': F3['lev']})
+    H, S, (A, B, C, D, E, Fc, G) = apps._coeffs_3DOcean(F3, ['lev', 'lat', 'lon'], 'lat-lon',
+                                                         dict(mP, N2=n2, k=1e-7), iP, None)
+    c3 = 1e-7 / n2.values
+    assert A[3, j, 0] == c3[3] and B[3, j, 0] == c1[j] and C[3, j, 0] == c1[j] / np.cos(la[j])**2
+    assert D[3, j, 0] == np.gradient(c3, F3['lev'])[3] and (G == 0).all()
+    assert E[0, j, 0] == np.gradient(c1, lat)[j] / d2m - c1[j] * np.tan(la[j]) / Re
+    assert Fc[0, j, 0] == -np.gradient(c2, lat)[j] / d2m / np.cos(la[j])
+
+
 def test_dims_length_errors():
     F = Field(np.zeros((4, 5)), ('y', 'x'))
     with pytest.raises(Exception, match='2 dimensions are needed for inversion'):

@@ -157,6 +157,16 @@ def test_poisson_real_data(oracle, tag, BCs):
         assert np.array_equal(fl, d['flags_' + tag][t])
 
 
+@pytest.mark.parametrize('tag,mx,tol,loops', [('hadley', 600, 1e-10, 142), ('tc', 600, 1e-12, 600)])
+def test_eliassen_real_data_bitwise(oracle, tag, mx, tol, loops):
+    p, d, ps = util.eliassen_problem(tag)
+    if tag == 'hadley':
+        assert p['optArg'] == ps['optArg']             # default over-relaxation factor
+    S, fl = util.run_oracle(p, mx, tol, LEX)
+    assert fl[2] == loops
+    assert np.array_equal(S, d[tag + '_S']) and np.array_equal(fl, d[tag + '_flags'])
+
+
 def test_norm_semantics(oracle):
     """absNorm2D (numbas.py:1710-1728): mean |S| over S != undef, NaN when nothing is defined."""
     S = np.array([[1.0, -3.0, U], [U, 2.0, -2.0]])

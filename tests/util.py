@@ -125,6 +125,27 @@ def rand3dg(zc, yc, xc, BCy, BCx, msk=False, seed=0, delz=2.0, dely=1.3, delx=1.
                 S0=S0, coefs=[A, B, C, D, E, F, G, H])
 
 
+def eliassen_problem(tag):
+    """The reference's Eliassen tests (tests/test_Eliassen.py:16-147 Hadley, :207-232 TC) through
+    the front end's coefficient code: real data, true 9-point form (B != 0)."""
+    from xinvert_amd import apps
+    from xinvert_amd.field import Field
+    d = golden('eliassen.npz')
+    lev, lat = d[tag + '_lev'], d[tag + '_lat']
+    F = Field(d[tag + '_F'], ('lev', 'lat'), {'lev': lev, 'lat': lat})
+    iP = apps._update(apps.default_iParams, {'BCs': ['fixed', 'fixed']})
+    mP = apps._update(apps.default_mParams, {k: d[tag + '_' + k] for k in 'ABC'},
+                      ['A', 'B', 'C', 'g', 'Omega', 'Rearth'])
+    Fm, initS, cs = apps._coeffs_Eliassen(F, ['lev', 'lat'], 'z-lat', mP, iP, None)
+    ps = apps._cal_params2D(lev, lat, 'z-lat')
+    yc, xc = F.shape
+    p = dict(kind='std2d', yc=yc, xc=xc, BCy='fixed', BCx='fixed', dely=ps['del2'], delx=ps['del1'],
+             delxSqr=ps['del1Sqr'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'],
+             optArg=float(d[tag + '_optArg']), undef=U, S0=np.zeros((yc, xc)),
+             coefs=[np.ascontiguousarray(c) for c in cs] + [np.ascontiguousarray(Fm.values)])
+    return p, d, ps
+
+
 # ------------------------------------------------------------------ oracle runner
 def run_oracle(p, mxLoop, tol, order):
     import oracle as orc

@@ -14,6 +14,8 @@ from .core import (inv_standard2D, inv_standard2D_test, inv_general2D, inv_gener
                    inv_standard3D, inv_general3D)
 from .apps import (invert_Poisson, invert_Stommel, invert_StommelMunk, invert_GillMatsuno,  # noqa: F401
                    invert_Fofonoff, invert_BrethertonHaidvogel, invert_omega, invert_3DOcean,
+                   invert_RefState, invert_PV2D, invert_Eliassen, invert_GillMatsuno_test,
+                   invert_Stommel_test, invert_StommelArons, invert_geostrophic,
                    animate_iteration, cal_flow, default_iParams, default_mParams)
 
 __version__ = '0.1.0'

@@ -23,7 +23,7 @@ import copy
 import numpy as np
 
 from . import core
-from .field import Field, along, from_any, to_like
+from .field import Field, aligned, along, from_any, full, to_like
 
 # default undefined value (reference apps.py:18, core.py:15)
 _undeftmp = -9.99e8
@@ -104,6 +104,58 @@ def invert_GillMatsuno(Q, dims, coords='lat-lon', icbc=None,
                      mParams, iParams)
 
 
+def invert_RefState(PV, dims, coords='z-lat', icbc=None,
+                    mParams=default_mParams, iParams=default_iParams):
+    """Balanced symmetric vortex: angular momentum from PV (reference apps.py:104-145).  As in the
+    reference the accepted mParams key is 'Ang0' while the coefficients read the default 'ang0';
+    'Gamma' has no default and must be supplied."""
+    return _template(_coeffs_RefState, core.inv_standard2D, 2, PV, dims, coords, icbc,
+                     ['Ang0', 'Gamma', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_PV2D(PV, dims, coords='z-lat', icbc=None,
+                mParams=default_mParams, iParams=default_iParams):
+    """QG PV inversion in a vertical plane (reference apps.py:246-297)."""
+    return _template(_coeffs_PV2D, core.inv_standard2D, 2, PV, dims, coords, icbc,
+                     ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_Eliassen(F, dims, coords='z-lat', icbc=None,
+                    mParams=default_mParams, iParams=default_iParams):
+    """Eliassen balanced-vortex model, 9-point standard form with user-supplied A, B, C
+    (reference apps.py:300-346)."""
+    return _template(_coeffs_Eliassen, core.inv_standard2D, 2, F, dims, coords, icbc,
+                     ['A', 'B', 'C', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_GillMatsuno_test(Q, dims, coords='lat-lon', icbc=None,
+                            mParams=default_mParams, iParams=default_iParams):
+    """Gill-Matsuno model in flux form (reference apps.py:397-442)."""
+    return _template(_coeffs_GillMatsuno_test, core.inv_standard2D_test, 2, Q, dims, coords, icbc,
+                     ['f0', 'beta', 'epsilon', 'Phi', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_Stommel_test(curl, dims, coords='lat-lon', icbc=None,
+                        mParams=default_mParams, iParams=default_iParams):
+    """Stommel model in flux form (reference apps.py:491-534)."""
+    return _template(_coeffs_Stommel_test, core.inv_standard2D_test, 2, curl, dims, coords, icbc,
+                     ['beta', 'R', 'D', 'rho0', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_StommelArons(Q, dims, coords='lat-lon', icbc=None,
+                        mParams=default_mParams, iParams=default_iParams):
+    """Stommel-Arons abyssal circulation (reference apps.py:585-629)."""
+    return _template(_coeffs_StommelArons, core.inv_general2D, 2, Q, dims, coords, icbc,
+                     ['f0', 'beta', 'epsilon', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
+def invert_geostrophic(lapPhi, dims, coords='lat-lon', icbc=None,
+                       mParams=default_mParams, iParams=default_iParams):
+    """Geostrophic streamfunction from the Laplacian of geopotential (reference apps.py:632-673)."""
+    return _template(_coeffs_geostrophic, core.inv_standard2D, 2, lapPhi, dims, coords, icbc,
+                     ['f0', 'beta', 'Omega', 'g', 'Omega', 'Rearth'], mParams, iParams)
+
+
 def _check_N2(mParams):
     """Stratification profile sanity checks shared by the 3-D apps (reference apps.py:817-823,
     877-883): only array-valued N2 is checked, from its second level on."""
@@ -150,6 +202,10 @@ _ANIMATE = {
     'fofonoff': ('_coeffs_Fofonoff', 'inv_standard2D_test',
                  ['c0', 'c1', 'f0', 'beta', 'g', 'Omega', 'Rearth']),
     'omega': ('_coeffs_omega', 'inv_standard3D', ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth']),
+    'pv2d': ('_coeffs_PV2D', 'inv_standard2D', ['f0', 'beta', 'N2', 'g', 'Omega', 'Rearth']),
+    'geostrophic': ('_coeffs_geostrophic', 'inv_standard2D', ['f0', 'beta', 'g', 'Omega', 'Rearth']),
+    'eliassen': ('_coeffs_Eliassen', 'inv_standard2D', ['A', 'B', 'C', 'g', 'Omega', 'Rearth']),
+    'refstate': ('_coeffs_RefState', 'inv_standard2D', ['Ang0', 'Gamma', 'g', 'Omega', 'Rearth']),
     '3docean': ('_coeffs_3DOcean', 'inv_general3D',
                 ['f0', 'beta', 'N2', 'epsilon', 'k', 'g', 'Omega', 'Rearth']),
 }
@@ -602,6 +658,188 @@ def _coeffs_omega(force, dims, coords, mParams, iParams, icbc):
         Fv = maskF.values
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    return maskF.like(Fv), initS, (A, B, C)
+
+
+def _half_shift(v):
+    """(v + v.shift(1)) / 2 of the reference: half-point values, NaN in the first entry."""
+    return (v + np.concatenate(([np.nan], v[:-1]))) / 2.
+
+
+def _coeffs_RefState(Q, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1440-1467.  C divides by the RAW input Q (not the masked copy) and, in
+    'z-lat', by the latitude coordinate in degrees -- as written there."""
+    ang0, Gamma, g = mParams['ang0'], mParams['Gamma'], mParams['g']
+    maskF, initS, zero = _mask_FS(Q, dims, iParams, icbc)
+    x1 = along(np.asarray(maskF[dims[1]], dtype=np.float64), maskF, dims[1])
+    Qv = np.asarray(Q.values, dtype=np.float64)
+    c = coords.lower()
+    if c == 'z-lat':
+        A = full(np.sin(np.deg2rad(x1)), maskF)
+    elif c == 'cartesian':
+        A = full(2.0 * ang0 / x1**3.0, maskF)
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [z-lat, cartesian]')
+    B = full(0.0, maskF)
+    C = full(aligned(Gamma, maskF) * g / Qv / x1, maskF)
+    return maskF.like(maskF.values), initS, (A, B, C)
+
+
+def _coeffs_PV2D(PV, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1556-1579 (both coordinate branches are the same expression)."""
+    f0, N2 = mParams['f0'], mParams['N2']
+    maskF, initS, zero = _mask_FS(PV, dims, iParams, icbc)
+    if coords.lower() not in ('z-lat', 'cartesian'):
+        raise Exception('unsupported coords ' + coords + ', should be in [z-lat, cartesian]')
+    A = full(f0**2 / aligned(N2, maskF), maskF)
+    B = full(0.0, maskF)
+    C = full(1.0, maskF)
+    return maskF.like(maskF.values), initS, (A, B, C)
+
+
+def _coeffs_Eliassen(force, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1582-1606: A, B, C are handed in by the caller (labelled arrays are
+    aligned by dim name; NaNs in them are kept, as `zero + Am` keeps them)."""
+    maskF, initS, zero = _mask_FS(force, dims, iParams, icbc)
+    if coords.lower() not in ('z-lat', 'cartesian'):
+        raise Exception('unsupported coords ' + coords + ', should be in [z-lat, cartesian]')
+    A, B, C = (full(aligned(mParams[k], maskF), maskF) for k in ('A', 'B', 'C'))
+    return maskF.like(maskF.values), initS, (A, B, C)
+
+
+def _coeffs_GillMatsuno_test(Q, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1660-1709: flux form, A on half points (NaN in row 0, never read)."""
+    Phi, epsilon = mParams['Phi'], mParams['epsilon']
+    f0, beta, Omega = mParams['f0'], mParams['beta'], mParams['Omega']
+    maskF, initS, zero = _mask_FS(Q, dims, iParams, icbc)
+    yv = np.asarray(Q[dims[0]], dtype=np.float64)
+    col = lambda v: full(along(v, maskF, dims[0]), maskF)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosG, cosH = np.cos(lats), np.cos(_half_shift(lats))
+        fG = 2. * Omega * np.sin(lats)
+        fH = 2. * Omega * np.sin(_half_shift(lats))
+        c1G = epsilon / (epsilon**2. + fG**2.)
+        c1H = epsilon / (epsilon**2. + fH**2.)
+        c2G = fG / (epsilon**2. + fG**2.)
+        A = col(c1H * Phi * cosH)
+        B = col(0. - c2G * Phi)
+        C = col(c2G * Phi)
+        D = col(c1G * Phi / cosG)
+        E = col(0. - epsilon * cosG)
+        Fv = _remask(maskF.values * along(cosG, maskF, dims[0]), maskF)
+    elif c == 'cartesian':
+        fG = f0 + beta * yv
+        fH = f0 + beta * _half_shift(yv)
+        c1G = epsilon / (epsilon**2. + fG**2.)
+        c1H = epsilon / (epsilon**2. + fH**2.)
+        c2G = fG / (epsilon**2. + fG**2.)
+        A = col(c1H * Phi)
+        B = col(0. - c2G * Phi)
+        C = col(c2G * Phi)
+        D = col(c1G * Phi)
+        E = full(0. - epsilon, maskF)
+        Fv = maskF.values
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    return maskF.like(Fv), initS, (A, B, C, D, E)
+
+
+def _coeffs_Stommel_test(curl, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1751-1790."""
+    f0, beta, R, depth = mParams['f0'], mParams['beta'], mParams['R'], mParams['D']
+    rho0, Omega = mParams['rho0'], mParams['Omega']
+    maskF, initS, zero = _mask_FS(curl, dims, iParams, icbc)
+    yv = np.asarray(curl[dims[0]], dtype=np.float64)
+    col = lambda v: full(along(v, maskF, dims[0]), maskF)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosG, cosH = np.cos(lats), np.cos(_half_shift(lats))
+        f = 2. * Omega * np.sin(lats)
+        A = col(0. - R / depth * cosH)
+        B = col(0. - f)
+        C = col(f)
+        D = col(0. - R / depth / cosG)
+        E = full(0.0, maskF)
+        Fv = _remask(-maskF.values / depth / rho0 * along(cosG, maskF, dims[0]), maskF)
+    elif c == 'cartesian':
+        f = f0 + beta * yv
+        A = full(0. - R / depth, maskF)
+        B = col(0. - f)
+        C = col(f)
+        D = full(0. - R / depth, maskF)
+        E = full(0.0, maskF)
+        Fv = _remask(-maskF.values / depth / rho0, maskF)
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, z-lat, z-lon, cartesian]')
+    return maskF.like(Fv), initS, (A, B, C, D, E)
+
+
+def _coeffs_StommelArons(Q, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1839-1886 (the Gill-Matsuno operator with Phi = 1 and no damping term)."""
+    epsilon, f0, beta = mParams['epsilon'], mParams['f0'], mParams['beta']
+    Omega, Rearth = mParams['Omega'], mParams['Rearth']
+    maskF, initS, zero = _mask_FS(Q, dims, iParams, icbc)
+    yv = np.asarray(Q[dims[0]], dtype=np.float64)
+    col = lambda v: full(along(v, maskF, dims[0]), maskF)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosL = np.cos(lats)
+        f = 2.0 * Omega * np.sin(lats)
+        c1 = epsilon / (epsilon**2. + f**2.)
+        c2 = f / (epsilon**2. + f**2.)
+        deg2m = Rearth / 180. * np.pi
+        A = col(c1)
+        C = col(c1 / cosL**2.)
+        D = col(np.gradient(c1, yv) / deg2m + c1 * np.tan(lats) / Rearth)
+        E = col(0. - np.gradient(c2, yv) / deg2m / cosL)
+    elif c == 'cartesian':
+        f = f0 + beta * yv
+        c1 = epsilon / (epsilon**2. + f**2.)
+        c2 = f / (epsilon**2. + f**2.)
+        A = col(c1)
+        C = col(c1)
+        D = col(np.gradient(c1, yv))
+        E = col(0. - np.gradient(c2, yv))
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    B = full(0.0, maskF)
+    Fc = full(0.0, maskF)
+    return maskF.like(maskF.values), initS, (A, B, C, D, E, Fc)
+
+
+def _coeffs_geostrophic(lapPhi, dims, coords, mParams, iParams, icbc):
+    """reference apps.py:1889-1931.  The forcing is rebuilt from the RAW input (`lapPhi.where(
+    lapPhi != undef)`), so NaN-masked input keeps its NaNs here exactly as in the reference;
+    |f| < 2e-5 is inflated by 1.5 near the equator."""
+    f0, beta, Omega = mParams['f0'], mParams['beta'], mParams['Omega']
+    maskF, initS, zero = _mask_FS(lapPhi, dims, iParams, icbc)
+    yv = np.asarray(maskF[dims[0]], dtype=np.float64)
+    raw = np.asarray(lapPhi.values, dtype=np.float64)
+    col = lambda v: full(along(v, maskF, dims[0]), maskF)
+    c = coords.lower()
+    if c == 'lat-lon':
+        lats = np.deg2rad(yv)
+        cosG, cosH = np.cos(lats), np.cos(_half_shift(lats))
+        fH = 2. * Omega * np.sin(_half_shift(lats))
+        fG = 2. * Omega * np.sin(lats)
+        fH = np.where(np.abs(fH) < 2e-05, fH * 1.5, fH)
+        fG = np.where(np.abs(fG) < 2e-05, fG * 1.5, fG)
+        A = col(fH * cosH)
+        C = col(fG / cosG)
+        Fv = np.where(raw != _undeftmp, raw * along(cosG, maskF, dims[0]), _undeftmp)
+    elif c == 'cartesian':
+        fG = f0 + beta * yv
+        fH = f0 + beta * _half_shift(yv)
+        A = col(fH)
+        C = col(fG)
+        Fv = np.where(raw != _undeftmp, raw, _undeftmp)
+    else:
+        raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
+    B = full(0.0, maskF)
     return maskF.like(Fv), initS, (A, B, C)
 
 

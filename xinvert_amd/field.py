@@ -52,6 +52,36 @@ def along(vec, field, dim):
     return np.asarray(vec).reshape(shape)
 
 
+def aligned(param, field):
+    """A model parameter lined up against `field` the way xarray arithmetic would: scalars pass
+    through; labelled arrays (Field / DataArray) are transposed and reshaped by dim NAME, absent
+    dims becoming length-1 axes; bare ndarrays follow numpy's trailing-axis broadcasting."""
+    if np.isscalar(param):
+        return param
+    if hasattr(param, 'dims') and hasattr(param, 'values'):
+        pd = tuple(param.dims)
+        for d in pd:
+            if d not in field.dims:
+                raise Exception('parameter dimension %r is not a dimension of the forcing %r' % (d, field.dims))
+        v = np.asarray(param.values, dtype=np.float64)
+        order = sorted(range(len(pd)), key=lambda a: field.axis(pd[a]))
+        v = np.transpose(v, order)
+        shape = [1] * len(field.dims)
+        for a in order:
+            shape[field.axis(pd[a])] = param.values.shape[a]
+        return v.reshape(shape)
+    v = np.asarray(param, dtype=np.float64)
+    np.broadcast_shapes(v.shape, field.shape)
+    return v
+
+
+def full(value, field):
+    """`zero + value` of the reference: the value broadcast to the forcing's full shape.  Axes the
+    value does not depend on get stride 0, which the solver front end (core._prep_coef) turns
+    into one shared slice on the device."""
+    return np.broadcast_to(np.asarray(value, dtype=np.float64), field.shape)
+
+
 def from_any(obj, dims=None):
     """Field from a Field, an xarray.DataArray (if xarray is importable) or (ndarray, dims)."""
     if isinstance(obj, Field):
