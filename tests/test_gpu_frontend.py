@@ -185,6 +185,42 @@ def test_invert_poisson_real_data_both_times():
         assert util.rel_l2(sf.values[t], Sl) < 1e-6
 
 
+def test_reference_poisson_test_assertion_on_real_data():
+    """The reference's own check (tests/test_Poisson.py:14-41): invert the bundled vorticity with
+    BCs ['extend', 'periodic'], tol 1e-11, take the rotational wind with cal_flow and verify that
+    its divergence vanishes away from the poles (FiniteDiff.divg restated: finitediffs.py:208-272).
+    Added here: the inverted streamfunction satisfies the discrete Poisson equation it was built
+    from (residual of the 5-point operator relative to the forcing)."""
+    import xinvert_amd as xa
+    from xinvert_amd import apps
+    d = golden('poisson_atmos.npz')
+    lat, lon = d['lat'].astype(np.float64), d['lon'].astype(np.float64)
+    vor = xa.Field(d['vor_f32'], ('time', 'lat', 'lon'), {'time': np.arange(2), 'lat': lat, 'lon': lon})
+    iParams = {'BCs': ['extend', 'periodic'], 'undef': np.nan, 'mxLoop': 5000, 'tolerance': 1e-11,
+               'printInfo': False}
+    sf = xa.invert_Poisson(vor, dims=['lat', 'lon'], iParams=iParams)
+    us, vs = xa.cal_flow(sf, dims=['lat', 'lon'], BCs=iParams['BCs'], vtype='streamfunction')
+    deg2m = np.pi * 6371200.0 / 180.0
+    cos = np.cos(np.deg2rad(lat))[None, :, None]
+    div0 = apps._deriv_center(us.values, 2, lon, 'periodic', deg2m * cos) + \
+        apps._deriv_center(vs.values * cos, 1, lat, 'extend', deg2m * cos)
+    assert np.isclose(div0[:, 1:-1], 0).all()
+    assert np.abs(us.values[:, 2:-2]).max() > 5.0               # a real wind field, not zeros
+    # discrete residual of the converged field (interior rows): L(psi) == vor * cos(lat) * delx^2 ...
+    ps = apps._cal_params2D(lat, lon, 'lat-lon')
+    Fv = xa.Field(d['vor_f32'].astype(np.float64), ('time', 'lat', 'lon'), {'lat': lat, 'lon': lon})
+    F, _, (A, B, C) = apps._coeffs_Poisson(Fv, ['lat', 'lon'], 'lat-lon', apps.default_mParams,
+                                           apps._update(apps.default_iParams, iParams), None)
+    for t in range(2):
+        S = sf.values[t]
+        Se, Sw = np.roll(S, -1, 1), np.roll(S, 1, 1)
+        Ce = np.roll(C, -1, 1)
+        L = ((A[2:, :] * (S[2:] - S[1:-1]) - A[1:-1] * (S[1:-1] - S[:-2])) * ps['ratioSqr'] +
+             (Ce[1:-1] * (Se[1:-1] - S[1:-1]) - C[1:-1] * (S[1:-1] - Sw[1:-1])))
+        rhs = F.values[t][1:-1] * ps['del1Sqr']
+        assert np.linalg.norm(L - rhs) / np.linalg.norm(rhs) < 1e-5
+
+
 def test_invert_eliassen_real_data_nine_point():
     """invert_Eliassen on the reference's bundled data (Data/ZonalMean.nc Hadley case,
     tests/test_Eliassen.py:131-147; Data/TC2D.nc, :207-232): the fused 4-colour kernel against (i)

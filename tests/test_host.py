@@ -230,7 +230,7 @@ def test_cal_flow_gill_matsuno_matches_reference_formula():
     lat = np.linspace(-90, 90, 19); lon = np.linspace(0, 360, 24)
     rng = np.random.default_rng(0)
     S = Field(rng.standard_normal((19, 24)), ('lat', 'lon'), {'lat': lat, 'lon': lon})
-    u, v = apps.cal_flow(S, ['lat', 'lon'], mParams={'epsilon': 1e-5, 'Phi': 5000})
+    u, v = apps.cal_flow(S, ['lat', 'lon'], vtype='GillMatsuno', mParams={'epsilon': 1e-5, 'Phi': 5000})
     f = 2 * 7.292e-5 * np.sin(np.deg2rad(lat)); eps = 1e-5
     c1 = (eps / (eps**2 + f**2))[:, None]; c2 = (f / (eps**2 + f**2))[:, None]
     d = np.deg2rad(1.0) * 6371200.0
@@ -239,7 +239,38 @@ def test_cal_flow_gill_matsuno_matches_reference_formula():
     assert np.array_equal(u.values, -c1 * Sx / d / cosL - c2 * Sy / d)
     assert np.array_equal(v.values, -c1 * Sy / d + c2 * Sx / d / cosL)
     with pytest.raises(Exception, match='unsupported vtype'):
-        apps.cal_flow(S, ['lat', 'lon'], vtype='streamfunction')
+        apps.cal_flow(S, ['lat', 'lon'], vtype='vorticity')
+
+
+def test_cal_flow_streamfunction_and_potential():
+    """reference apps.py:1207-1273 + finitediffs.py:548-659: centred differences on the BC-padded
+    field.  Solid-body rotation psi = -a*U*sin(lat) gives u = U*cos(lat), v = 0; periodic padding
+    makes d/dlon exact across the date line; 'fixed' pads with 0, 'extend' with the edge value."""
+    Re = 6371200.0
+    lat = np.linspace(-80, 80, 33); lon = np.arange(0, 360, 7.5)
+    la = np.deg2rad(lat)[:, None]; lo = np.deg2rad(lon)[None, :]
+    psi = Field(-Re * 10.0 * np.sin(la) + 0 * lo, ('lat', 'lon'), {'lat': lat, 'lon': lon})
+    u, v = apps.cal_flow(psi, ['lat', 'lon'], BCs=['extend', 'periodic'])
+    assert np.allclose(u.values[1:-1], 10.0 * np.cos(la)[1:-1], rtol=2e-3) and np.abs(v.values).max() == 0
+    wave = Field(Re * np.cos(la) * np.sin(2 * lo), ('lat', 'lon'), {'lat': lat, 'lon': lon})
+    u, v = apps.cal_flow(wave, ['lat', 'lon'], BCs=['extend', 'periodic'])
+    assert np.allclose(v.values, 2 * np.cos(2 * lo) * np.ones_like(la), atol=0.03)     # across the date line too
+    up, vp = apps.cal_flow(wave, ['lat', 'lon'], BCs=['extend', 'periodic'], vtype='velocitypotential')
+    assert np.array_equal(up.values, v.values) and np.array_equal(vp.values, -u.values)
+    # boundary padding: first row uses (S[1] - pad) / (2 dy)
+    y = np.linspace(0, 4e5, 5); x = np.linspace(0, 6e5, 7)
+    Sv = np.random.default_rng(3).standard_normal((5, 7))
+    S = Field(Sv, ('y', 'x'), {'y': y, 'x': x})
+    u, v = apps.cal_flow(S, ['y', 'x'], coords='cartesian', BCs=['fixed', 'extend'])
+    assert np.allclose(-u.values[0], (Sv[1] - 0.0) / 2e5) and np.allclose(-u.values[2], (Sv[3] - Sv[1]) / 2e5)
+    assert np.allclose(v.values[:, 0], (Sv[:, 1] - Sv[:, 0]) / 2e5) and np.allclose(v.values[:, -1], (Sv[:, -1] - Sv[:, -2]) / 2e5)
+    # vertical planes
+    lev = np.linspace(1e5, 2e4, 9)
+    Z = Field(np.random.default_rng(4).standard_normal((9, 33)), ('lev', 'lat'), {'lev': lev, 'lat': lat})
+    a, b = apps.cal_flow(Z, ['lev', 'lat'], coords='z-lat', BCs=['extend', 'extend'])
+    cs = np.cos(np.deg2rad(lat))[None, :]
+    assert np.allclose(-a.values[3], (Z.values[4] - Z.values[2]) / (lev[4] - lev[2]) / cs[0])
+    assert np.allclose(b.values[:, 5], (Z.values[:, 6] - Z.values[:, 4]) / (np.deg2rad(lat[6] - lat[4]) * Re) / cs[0, 5])
 
 
 def test_xarray_like_objects_are_accepted_and_returned():

@@ -257,16 +257,73 @@ def animate_iteration(app_name, F, dims, coords='lat-lon', icbc=None,
     return to_like(res, tmpl) if not isinstance(tmpl, Field) else res
 
 
-def cal_flow(S, dims, coords='lat-lon', BCs=('fixed', 'fixed'), vtype='GillMatsuno',
-             mParams=default_mParams):
-    """(u, v) from the Gill-Matsuno mass field (reference apps.py:1277-1317).
+def _deriv_center(vals, axis, coord, BC, scale=1.0, fill=0.0):
+    """Centred first derivative with one padded point per side (reference finitediffs.py:548-659,
+    `padBCs` + `deriv(scheme='center')`): pad by the boundary condition, extrapolate the
+    coordinate linearly, numpy.gradient (== xarray's differentiate), drop the padded points."""
+    coord = np.asarray(coord, dtype=np.float64)
+    pw = [(0, 0)] * vals.ndim
+    pw[axis] = (1, 1)
+    if BC == 'periodic':
+        p = np.pad(vals, pw, mode='wrap')
+    elif BC == 'fixed':
+        p = np.pad(vals, pw, mode='constant', constant_values=fill)
+    elif BC == 'extend':
+        p = np.pad(vals, pw, mode='edge')
+    elif BC == 'reflect':
+        p = np.pad(vals, pw, mode='reflect')
+    else:
+        raise Exception('unsupported BC: ' + str((BC, BC)))
+    c = np.concatenate(([coord[0] * 2 - coord[1]], coord, [coord[-1] * 2 - coord[-2]]))
+    g = np.gradient(p, c, axis=axis)
+    sl = [slice(None)] * vals.ndim
+    sl[axis] = slice(1, -1)
+    return g[tuple(sl)] / scale
 
-    Only vtype='GillMatsuno' is restated (it completes config 4's "3-field" output);
-    the streamfunction / velocity-potential branches need the reference's FiniteDiff class,
-    which is outside the hot path.
-    """
-    if vtype.lower() != 'gillmatsuno':
-        raise Exception('unsupported vtype: ' + vtype + ' (only GillMatsuno is provided)')
+
+def cal_flow(S, dims, coords='lat-lon', BCs=('fixed', 'fixed'), vtype='streamfunction',
+             mParams=default_mParams):
+    """Flow components from an inverted field (reference apps.py:1181-1317).
+
+    vtype 'streamfunction' -> (u, v) = (-dS/dy, dS/dx); 'velocitypotential' -> (dS/dx, dS/dy),
+    centred differences on the BC-padded field with the lat-lon metric (finitediffs.py:151-207);
+    'GillMatsuno' -> winds of the Gill-Matsuno mass field (apps.py:1277-1317), which also runs on
+    the device (`cal_flow_gm_device`)."""
+    if vtype.lower() not in ['streamfunction', 'velocitypotential', 'gillmatsuno']:
+        raise Exception('unsupported vtype: ' + vtype + ', should be one of:\n' +
+                        "['streamfunction', 'velocitypotential', 'gillmatsuno']")
+    if vtype != 'GillMatsuno':
+        tmpl = S
+        S = from_any(S)
+        sf = vtype == 'streamfunction'
+        vals = np.asarray(S.values, dtype=np.float64)
+        a0, a1 = S.axis(dims[0]), S.axis(dims[1])
+        c0 = np.asarray(S[dims[0]], dtype=np.float64)
+        c1 = np.asarray(S[dims[1]], dtype=np.float64)
+        Rearth = default_mParams['Rearth']            # FiniteDiff's default R
+        deg2m = np.pi * Rearth / 180.0
+        out = lambda a, b: (to_like(S.like(a, 'u'), tmpl), to_like(S.like(b, 'v'), tmpl))
+        c = coords.lower()
+        if c == 'lat-lon':
+            cos = along(np.cos(np.deg2rad(c0)), S, dims[0])
+            grdy = _deriv_center(vals, a0, c0, BCs[0], deg2m)
+            grdx = _deriv_center(vals, a1, c1, BCs[1], deg2m * cos)
+            return out(-grdy, grdx) if sf else out(grdx, grdy)
+        if c == 'z-lat':
+            cos = along(np.cos(np.deg2rad(c1)), S, dims[1])
+            grdz = _deriv_center(vals, a0, c0, BCs[0]) / cos
+            grdy = _deriv_center(vals, a1, c1, BCs[1], deg2m) / cos
+            grdy = np.where(along(np.abs(c1) != 90, S, dims[1]), grdy, 0.0)
+            return out(-grdz, grdy) if sf else out(grdy, grdz)
+        if c == 'z-lon':
+            grdz = _deriv_center(vals, a0, c0, BCs[0])
+            grdx = _deriv_center(vals, a1, c1, BCs[1], deg2m)      # no latitude dim: cos == 1
+            return out(grdz, -grdx) if sf else out(grdx, grdz)
+        if c == 'cartesian':
+            grdy = _deriv_center(vals, a0, c0, BCs[0])
+            grdx = _deriv_center(vals, a1, c1, BCs[1])
+            return out(-grdy, grdx) if sf else out(grdx, grdy)
+        raise Exception('unsupported coords ' + coords + ', should be [lat-lon, z-lat, z-lon, cartesian]')
     tmpl = S
     S = from_any(S)
     mParams = _update(default_mParams, mParams,
