@@ -373,7 +373,7 @@ def test_gill_matsuno_flow_on_device(coords):
     phi = rng.standard_normal((3, lat.size, lon.size)) * 100.0
     mP = {'epsilon': 1e-5, 'Phi': 5000}
     u0, v0 = apps.cal_flow(xa.Field(phi, ('m', 'lat', 'lon'), {'lat': lat, 'lon': lon}), ['lat', 'lon'],
-                           coords=coords, mParams=mP)
+                           coords=coords, vtype='GillMatsuno', mParams=mP)
     S = torch.from_numpy(phi).cuda(); u = torch.empty_like(S); v = torch.empty_like(S)
     apps.cal_flow_gm_device(S.data_ptr(), u.data_ptr(), v.data_ptr(), 3, lat, lon, coords=coords, mParams=mP)
     assert np.array_equal(u.cpu().numpy(), u0.values) and np.array_equal(v.cpu().numpy(), v0.values)
