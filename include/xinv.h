@@ -50,6 +50,9 @@ extern "C" {
 
 #define XINV_FLAG_NO_XUNIFORM 1  /* stream every coefficient array in full: do not look for rows
                                     that are constant along x                                    */
+#define XINV_FLAG_NO_TILE_SKIP 2 /* run every tile even where the forcing is masked throughout    */
+#define XINV_FLAG_FORCE_TILE_SKIP 4 /* testing aid: skip masked tiles whatever the grid size, keep
+                                    the row split                                                */
 
 typedef struct xinv_options {
     int32_t device;             /* HIP device ordinal; -1 = current device                      */
@@ -69,7 +72,7 @@ typedef struct xinv_stats {
     int32_t sweeps_per_launch;
     int32_t rows_per_tile;
     int32_t xuniform_mask;      /* fused path: coefficient streams read as one scalar per row    */
-    int32_t pad_;
+    int32_t masked_tile_pct;    /* fused 2-D path: share of tiles skipped because fully masked   */
     int64_t sweep_launches;     /* sweep-kernel launches issued (incl. no-op tail launches)     */
     int64_t sweeps_max;         /* max over members of sweeps executed                          */
     double  sweep_ms;           /* HIP-event time over all launch chunks (timing=1), ms         */

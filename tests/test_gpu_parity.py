@@ -195,6 +195,47 @@ def test_batched_shared_coefficients_and_per_member_stop(kind):
     assert len(loops) > 1, 'test should exercise different stopping sweeps'
 
 
+def _blocky(p, rng, boxes):
+    """Mask whole rectangles of the forcing (land / topography): tiles inside them never change."""
+    q = dict(p); q['coefs'] = [c.copy() for c in p['coefs']]; q['S0'] = p['S0'].copy()
+    F = q['coefs'][-1]
+    for (j0, j1, i0, i1) in boxes:
+        F[j0:j1, i0:i1] = util.U
+        q['S0'][j0:j1, i0:i1] = np.where(rng.random((j1 - j0, i1 - i0)) < 0.2, util.U, 0.25)
+    return q
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d', 'std2dt'])
+@pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'), ('extend', 'fixed')])
+@pytest.mark.parametrize('spl', [1, 2])
+@pytest.mark.parametrize('rows', [-6, -15])
+def test_masked_tiles_are_skipped_without_changing_a_bit(kind, BCy, BCx, spl, rows):
+    """Masked-tile skipping (fully masked wave-tiles are left out of the launches, their constant
+    share of the norm is added by the last workgroup): S bit for bit, flags, loop counts equal to
+    the oracle -- with defined and undefined S inside the skipped tiles, members with different
+    masks, 'extend' rows inside a masked block, an early stop inside a 2-sweep launch."""
+    rng = np.random.default_rng(_seed(('skip', kind, BCy, BCx, spl, rows)))
+    mk = (lambda s: rand2dt(60, 372, BCy, BCx, 0, 1, seed=s)) if kind == 'std2dt' else \
+         (lambda s: rand2d(kind, 60, 372, BCy, BCx, 0, 1, seed=s))
+    ps = [_blocky(mk(1), rng, [(0, 30, 0, 250), (44, 60, 120, 372)]),
+          _blocky(mk(2), rng, [(10, 60, 100, 372)]),
+          mk(3)]
+    S, fl, st = run_hip_batched(ps, 60, 3e-5, path=PATH_FUSED, sweeps_per_launch=spl, rows_per_tile=rows,
+                                force_tile_skip=1)
+    assert st['path'] == PATH_FUSED and st['masked_tile_pct'] > 10
+    S0, fl0, st0 = run_hip_batched(ps, 60, 3e-5, path=PATH_FUSED, sweeps_per_launch=spl, rows_per_tile=rows,
+                                   no_tile_skip=1)
+    assert st0['masked_tile_pct'] == 0
+    loops = set()
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 60, 3e-5, COLOUR_2)
+        assert_same(S[m], fl[m], So, flo, 'skip member %d' % m)
+        assert np.array_equal(S[m], S0[m], equal_nan=True) and fl[m][2] == fl0[m][2]
+        assert abs(fl[m][1] - fl0[m][1]) <= 1e-12
+        loops.add(flo[2])
+    assert max(loops) < 60                      # every member stopped on the tolerance
+
+
 def test_dev_api_matches_host_api():
     ps = [rand2d('std2d', 48, 280, 'fixed', 'periodic', 0, 1, seed=s) for s in (1, 2, 3)]
     S1, f1, _ = run_hip_batched(ps, 40, 1e-7)

@@ -78,7 +78,7 @@ def main():
         avg_ms = st['sweep_ms'] / max(st['sweep_launches'], 1)
         print(json.dumps({'config': name, 'kind': p['kind'], 'shape': list(p['S0'].shape), 'sweeps': sw,
                           'point_sweeps_per_s': nb * n * sw / dt, 'solve_ms': dt * 1e3,
-                          'path': st['path'], 'colours': st['colours'], 'xuniform_mask': st['xuniform_mask'], 'sweeps_per_launch': k,
+                          'path': st['path'], 'colours': st['colours'], 'xuniform_mask': st['xuniform_mask'], 'sweeps_per_launch': k, 'rows_per_tile': st['rows_per_tile'], 'masked_tile_pct': st['masked_tile_pct'],
                           'avg_launch_ms': avg_ms,
                           'alg_GBps': ALG[p['kind']] * nb * n * k / (avg_ms * 1e-3) / 1e9 if st['path'] == 2
                           else ALG[p['kind']] * nb * n * sw / (st['sweep_ms'] * 1e-3) / 1e9,

@@ -29,7 +29,7 @@ class XinvOptions(ctypes.Structure):
 class XinvStats(ctypes.Structure):
     _fields_ = [('path', ctypes.c_int32), ('colours', ctypes.c_int32),
                 ('sweeps_per_launch', ctypes.c_int32), ('rows_per_tile', ctypes.c_int32),
-                ('xuniform_mask', ctypes.c_int32), ('pad_', ctypes.c_int32),
+                ('xuniform_mask', ctypes.c_int32), ('masked_tile_pct', ctypes.c_int32),
                 ('sweep_launches', ctypes.c_int64), ('sweeps_max', ctypes.c_int64),
                 ('sweep_ms', ctypes.c_double), ('h2d_ms', ctypes.c_double),
                 ('d2h_ms', ctypes.c_double)]
@@ -130,12 +130,13 @@ def check(rc):
 
 
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
-            timing=0, no_xuniform=0):
+            timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
     o.check_every, o.rows_per_tile, o.timing = check_every, rows_per_tile, timing
-    o.flags = 1 if no_xuniform else 0             # XINV_FLAG_NO_XUNIFORM
+    # XINV_FLAG_NO_XUNIFORM | XINV_FLAG_NO_TILE_SKIP | XINV_FLAG_FORCE_TILE_SKIP
+    o.flags = (1 if no_xuniform else 0) | (2 if no_tile_skip else 0) | (4 if force_tile_skip else 0)
     return o
 
 

@@ -66,6 +66,12 @@ struct Workspace {
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
     int *hflag = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // masked-tile skipping
+    unsigned char *d_act = nullptr; size_t d_act_cap = 0;
+    unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
+    int *d_list = nullptr; size_t d_list_cap = 0;               // [nbatch][ntl] then [nbatch][nskip]
+    int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
+    double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
 };
 
 static std::mutex g_ws_mutex;
@@ -148,6 +154,9 @@ struct Plan {
     unsigned um;             // the kernel variant's mask (subset of umask)
     bool even_split;         // rows split evenly over nrb row blocks (RY = average height)
     bool nine;               // 9-point form on the fused 4-colour kernel
+    bool skip;               // masked-tile skipping: launches of K == Plan::K run the listed tiles only
+    int ntl, nskip;          // list entries per member (active, multiple of 4 / skipped)
+    int skip_pct;            // share of wave-tiles skipped, percent
 };
 
 // kernel variants instantiated per model: mask of streams read as one scalar per row
@@ -258,6 +267,15 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     const size_t NBmax = (size_t)pl.nsg;             // workgroups per member, narrowest strips (K = XINV_KMAX)
     a.psum = (unsigned long long *)ws->partials;
     a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
+    if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
+        a.tile_list = ws->d_list;
+        a.ntl = pl.ntl;
+        a.nwg = pl.ntl / 4;
+        char *base = (char *)ws->d_tsum;
+        const size_t nt = (size_t)p.nbatch * pl.nskip;
+        a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
+        a.xcnt = (const long long *)(base + nt * (sizeof(double) + sizeof(long long)) + p.nbatch * sizeof(double));
+    }
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {      // grid.y is limited to 65535
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
@@ -517,6 +535,171 @@ static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int
     return best;
 }
 
+// Cost of a fused 2-D launch in (workgroups per CU) x (steps per tile) units -- the model behind
+// choose_row_blocks, shared with the masked-tile planner.
+static double tile_cost(int64_t wgs, int64_t rows, int K, int occ)
+{
+    occ = std::max(1, std::min(occ, 3));
+    const int64_t cap = 256 * (int64_t)occ, period = 2 * K + 2;
+    const int64_t steps = cdiv(rows + 1 + 4 * K, period) * period;
+    const int64_t rounds = std::max<int64_t>(1, cdiv(wgs, cap));
+    const int64_t w_last = wgs - (rounds - 1) * cap;
+    const double full = (occ == 1) ? 1.6 : (double)occ;
+    const double last = (w_last <= 256) ? 1.6 : (double)cdiv(w_last, 256);
+    return ((double)(rounds - 1) * full + last) * (double)steps;
+}
+
+static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                          hipStream_t st, const FusedArgs &a, int *occ);
+
+// Masked-tile skipping for the 5-point fused kernels.  Wave-tiles whose forcing is undefined at
+// every owned point (land, topography, polar caps) can never change (every mask predicate of the
+// reference tests the forcing), so launches run the other tiles only; the row split is re-chosen
+// so that the ACTIVE tiles fill the CUs evenly, and the skipped tiles' constant share of the norm
+// is computed once.  Decided per solve from one pass over the forcing.
+static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t st,
+                          const xinv_options &opt)
+{
+    pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0;
+    const bool forced = (opt.flags & XINV_FLAG_FORCE_TILE_SKIP) != 0;
+    const int K = pl.K, UW = 128 - 4 * K;
+    const int nstrip = (int)cdiv(p.xc, UW);
+    if (!forced && ((int64_t)nstrip * pl.nrb * p.nbatch < 1024 || (int64_t)nstrip * pl.nrb < 64 || p.nbatch > 64))
+        return XINV_OK;                                   // small problems: nothing to balance
+    const int64_t yc = p.yc, nb = p.nbatch;
+    const int64_t cells = yc * nstrip;
+    const int fi = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_GEN2D ? 6 : 5);     // the forcing
+
+    int rc = ensure_dev(&ws->d_act, &ws->d_act_cap, (size_t)(nb * cells));
+    if (rc) return rc;
+    if (ws->h_act_cap < (size_t)(nb * cells)) {
+        if (ws->h_act) HIPCHK(hipHostFree(ws->h_act));
+        HIPCHK(hipHostMalloc((void **)&ws->h_act, (size_t)(nb * cells), hipHostMallocDefault));
+        ws->h_act_cap = (size_t)(nb * cells);
+    }
+    StripActArgs sa;
+    sa.f = p.c[fi]; sa.sf = p.sc[fi]; sa.yc = yc; sa.xc = p.xc; sa.nstrip = nstrip; sa.UW = UW;
+    sa.undef = p.sc_.undef; sa.act = ws->d_act;
+    hipLaunchKernelGGL(k_strip_active, dim3(cdiv(cells, 4), (unsigned)nb, 1), dim3(256), 0, st, sa);
+    HIPCHK(hipMemcpyAsync(ws->h_act, ws->d_act, (size_t)(nb * cells), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+
+    // prefix counts of active rows per (member, strip)
+    std::vector<int> pre((size_t)(nb * nstrip * (yc + 1)));
+    int64_t nact = 0;
+    for (int64_t m = 0; m < nb; m++)
+        for (int s = 0; s < nstrip; s++) {
+            int *q = &pre[(size_t)((m * nstrip + s) * (yc + 1))];
+            q[0] = 0;
+            for (int64_t r = 0; r < yc; r++) q[r + 1] = q[r] + ws->h_act[(m * yc + r) * nstrip + s];
+            nact += q[yc];
+        }
+    if (!forced && (double)nact > 0.92 * (double)(nb * cells)) return XINV_OK;     // little to skip
+
+    const bool ext = (p.BCy == XINV_BC_EXTEND);
+    auto bounds = [&](int nrb, int rb, int64_t &y0, int64_t &y1) {
+        y0 = (((int64_t)rb * yc) / nrb) & ~(int64_t)1;
+        y1 = (rb + 1 == nrb) ? yc : ((((int64_t)(rb + 1) * yc) / nrb) & ~(int64_t)1);
+    };
+    auto tile_active = [&](int64_t m, int nrb, int rb, int s) {
+        if (ext && (rb == 0 || rb == nrb - 1)) return true;    // the boundary rows get their copy
+        int64_t y0, y1; bounds(nrb, rb, y0, y1);
+        const int *q = &pre[(size_t)((m * nstrip + s) * (yc + 1))];
+        return q[y1] - q[y0] > 0;
+    };
+    auto active_wgs = [&](int nrb, int64_t *maxact) {
+        int64_t wgs = 0, mx = 0;
+        for (int64_t m = 0; m < nb; m++) {
+            int64_t c = 0;
+            for (int rb = 0; rb < nrb; rb++) {
+                if (ext && (rb == 0 || rb == nrb - 1)) { c += nstrip; continue; }
+                int64_t y0, y1; bounds(nrb, rb, y0, y1);
+                const int *q = &pre[(size_t)(m * nstrip * (yc + 1))];
+                for (int s = 0; s < nstrip; s++, q += yc + 1) c += (q[y1] - q[y0] > 0) ? 1 : 0;
+            }
+            wgs += cdiv(c, 4); mx = std::max(mx, c);
+        }
+        if (maxact) *maxact = mx;
+        return wgs;
+    };
+    int occ = 2;
+    {
+        FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
+        fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
+    }
+    const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb, cdiv(yc, pl.nrb), K, occ);
+    // candidates: the row split that brings the ACTIVE workgroups back to the default count sits
+    // near nrb / (active share); search a window around it
+    int best = pl.nrb; double best_cost = 1e300;
+    int lo = pl.nrb, hi = pl.nrb;
+    if (!forced && opt.rows_per_tile == 0) {
+        const int64_t w0 = active_wgs(pl.nrb, nullptr);
+        const double share = std::max(0.05, (double)w0 / (double)((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb));
+        const double centre = (double)pl.nrb / share;
+        const int64_t cap_rows = std::max<int64_t>(pl.nrb, yc / 4);
+        lo = (int)std::min<int64_t>(cap_rows, std::max<int64_t>(pl.nrb, (int64_t)(centre * 0.85)));
+        hi = (int)std::min<int64_t>(cap_rows, std::max<int64_t>(lo, (int64_t)(centre * 1.10) + 1));
+    }
+    best_cost = tile_cost(active_wgs(pl.nrb, nullptr), cdiv(yc, pl.nrb), K, occ);   // keep the split, skip only
+    for (int nrb = lo; nrb <= hi; nrb++) {
+        const double c = tile_cost(active_wgs(nrb, nullptr), cdiv(yc, nrb), K, occ);
+        if (c < best_cost) { best_cost = c; best = nrb; }
+    }
+    if (!forced && best_cost > 0.95 * cost0) return XINV_OK;
+
+    // lists for the chosen split
+    int64_t maxact = 0;
+    active_wgs(best, &maxact);
+    const int64_t ntiles = (int64_t)nstrip * best;
+    const int ntl = (int)(4 * std::max<int64_t>(1, cdiv(maxact, 4)));
+    int64_t maxskip = 0, nskipped = 0;
+    std::vector<std::vector<int>> act((size_t)nb), skp((size_t)nb);
+    for (int64_t m = 0; m < nb; m++) {
+        for (int rb = 0; rb < best; rb++)
+            for (int s = 0; s < nstrip; s++)
+                (tile_active(m, best, rb, s) ? act[(size_t)m] : skp[(size_t)m]).push_back(rb * nstrip + s);
+        maxskip = std::max<int64_t>(maxskip, (int64_t)skp[(size_t)m].size());
+        nskipped += (int64_t)skp[(size_t)m].size();
+    }
+    if (nskipped == 0) return XINV_OK;
+    const int nskip = (int)maxskip;
+    const size_t nints = (size_t)nb * ((size_t)ntl + nskip);
+    rc = ensure_dev(&ws->d_list, &ws->d_list_cap, nints * sizeof(int));
+    if (rc) return rc;
+    if (ws->h_list_cap < nints * sizeof(int)) {
+        if (ws->h_list) HIPCHK(hipHostFree(ws->h_list));
+        HIPCHK(hipHostMalloc((void **)&ws->h_list, nints * sizeof(int), hipHostMallocDefault));
+        ws->h_list_cap = nints * sizeof(int);
+    }
+    int *hl = ws->h_list, *hs = ws->h_list + (size_t)nb * ntl;
+    for (int64_t m = 0; m < nb; m++) {
+        for (int t = 0; t < ntl; t++) hl[m * ntl + t] = t < (int)act[(size_t)m].size() ? act[(size_t)m][t] : -1;
+        for (int t = 0; t < nskip; t++) hs[m * nskip + t] = t < (int)skp[(size_t)m].size() ? skp[(size_t)m][t] : -1;
+    }
+    HIPCHK(hipMemcpyAsync(ws->d_list, ws->h_list, nints * sizeof(int), hipMemcpyHostToDevice, st));
+    const size_t nt = (size_t)nb * nskip;
+    rc = ensure_dev(&ws->d_tsum, &ws->d_tsum_cap,
+                    (nt + (size_t)nb) * (sizeof(double) + sizeof(long long)));
+    if (rc) return rc;
+    SkipNormArgs na;
+    na.S = p.S; na.sS = p.sS; na.yc = yc; na.xc = p.xc; na.nstrip = nstrip; na.nrb = best; na.UW = UW;
+    na.undef = p.sc_.undef; na.skip_list = ws->d_list + (size_t)nb * ntl; na.nskip_max = nskip;
+    char *base = (char *)ws->d_tsum;
+    na.tsum = (double *)base;
+    na.tcnt = (long long *)(base + nt * sizeof(double));
+    na.xsum = (double *)(base + nt * (sizeof(double) + sizeof(long long)));
+    na.xcnt = (long long *)(base + nt * (sizeof(double) + sizeof(long long)) + (size_t)nb * sizeof(double));
+    hipLaunchKernelGGL(k_skip_norm_tile, dim3((unsigned)nskip, (unsigned)nb, 1), dim3(64), 0, st, na);
+    hipLaunchKernelGGL(k_skip_norm_sum, dim3((unsigned)nb, 1, 1), dim3(64), 0, st, na);
+    HIPCHK(hipGetLastError());
+
+    pl.skip = true; pl.ntl = ntl; pl.nskip = nskip;
+    pl.skip_pct = (int)((100 * nskipped) / (ntiles * nb));
+    pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
+    pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
+    return XINV_OK;
+}
+
 // Which of `nstream` arrays have rows (of xc elements, `rows` per member) that are bitwise constant
 // along x?  One pass over each array on the device; *mask gets bit q set for uniform array q.
 static int detect_xuniform(Workspace *ws, hipStream_t st, const double *const *arr,
@@ -710,6 +893,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         }
         // workgroups per member with the narrowest strips any K uses: sizes the partials
         pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
+        if (pl.even_split && !(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
+            rc = plan_tile_skip(p, pl, ws, st, opt);
+            if (rc) return rc;
+        }
     }
 
     if (p.kind == KIND_BIH2D) {                       // x-uniform coefficient rows -> scalar loads
@@ -743,6 +930,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         rc = ensure_dev(&ws->S2, &ws->S2_cap, need);
         if (rc) return rc;
         S2 = ws->S2;
+        if (pl.skip)            // skipped tiles are never written: both buffers start from the caller's S
+            HIPCHK(hipMemcpyAsync(S2, p.S, need, hipMemcpyDeviceToDevice, st));
     }
 
     hipLaunchKernelGGL(k_ctl_init, dim3(cdiv(p.nbatch, 256)), dim3(256), 0, st, ws->ctl, p.nbatch);
@@ -841,6 +1030,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     t_stats.sweeps_per_launch = Kf;
     t_stats.rows_per_tile = pl.RY;
     t_stats.xuniform_mask = (pl.path == XINV_PATH_FUSED || p.kind == KIND_BIH2D) ? (int32_t)pl.um : 0;
+    t_stats.masked_tile_pct = (pl.path == XINV_PATH_FUSED && pl.skip) ? pl.skip_pct : 0;
     t_stats.sweep_launches = nlaunch;
     t_stats.sweeps_max = sweeps_max;
     t_stats.sweep_ms = ms_total;
