@@ -167,7 +167,7 @@ def main():
                                    '(BASELINE configs[1])' % (a.nx, a.ny),
                        'sweeps_per_step': a.sweeps, 'members_per_gpu': nb,
                        'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'],
-                       'xuniform_mask': s['xuniform_mask'],
+                       'xuniform_mask': s['xuniform_mask'], 'masked_tile_pct': s['masked_tile_pct'],
                        'path': {1: 'colour', 2: 'fused'}.get(s['path'], '?'),
                        'parallelism': 'batch-axis shard x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
