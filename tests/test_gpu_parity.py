@@ -236,6 +236,29 @@ def test_masked_tiles_are_skipped_without_changing_a_bit(kind, BCy, BCx, spl, ro
     assert max(loops) < 60                      # every member stopped on the tolerance
 
 
+def test_masked_tile_skipping_degenerate_members():
+    """A member whose forcing is masked everywhere (no active tile at all: the whole norm comes from
+    the constant share), next to an ordinary one and to one with a NaN in a masked block's
+    neighbourhood (NaN != undef: that tile must stay active and poison S as in the reference)."""
+    rng = np.random.default_rng(77)
+    a = rand2d('std2d', 48, 300, 'fixed', 'periodic', 0, 1, seed=5)
+    dead = dict(a); dead['coefs'] = [c.copy() for c in a['coefs']]; dead['coefs'][-1][:] = util.U
+    dead['S0'] = rng.standard_normal((48, 300)); dead['S0'][rng.random((48, 300)) < 0.1] = util.U
+    nanm = _blocky(a, rng, [(0, 48, 0, 130)]); nanm['coefs'][-1][20, 60] = np.nan
+    ps = [dead, a, nanm]
+    S, fl, st = run_hip_batched(ps, 30, 1e-9, path=PATH_FUSED, rows_per_tile=-8, force_tile_skip=1)
+    assert st['masked_tile_pct'] > 30
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 30, 1e-9, COLOUR_2)
+        if m == 2:                      # S holds the NaN: compare NaN-aware
+            assert np.array_equal(S[m], So, equal_nan=True) and np.isnan(S[m]).sum() >= 1
+            assert fl[m][0] == flo[0] == 1.0
+        else:
+            assert_same(S[m], fl[m], So, flo, 'degenerate member %d' % m)
+    assert np.array_equal(S[0], dead['S0']) and fl[0][2] == 1 and fl[0][1] == 0.0   # norm constant: stops at loop 1
+    assert fl[2][0] == 1.0                                                          # NaN -> overflow exit
+
+
 def test_dev_api_matches_host_api():
     ps = [rand2d('std2d', 48, 280, 'fixed', 'periodic', 0, 1, seed=s) for s in (1, 2, 3)]
     S1, f1, _ = run_hip_batched(ps, 40, 1e-7)

@@ -65,7 +65,7 @@ struct Workspace {
     int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
     int *hflag = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
     // masked-tile skipping
     unsigned char *d_act = nullptr; size_t d_act_cap = 0;
     unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
@@ -738,7 +738,11 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     else HIPCHK(hipSetDevice(device));
     Workspace *ws = get_ws(device);
     std::lock_guard<std::recursive_mutex> solve_lock(ws->busy);
-    if (!ws->ev0) { HIPCHK(hipEventCreate(&ws->ev0)); HIPCHK(hipEventCreate(&ws->ev1)); }
+    if (!ws->ev0[0])
+        for (int q = 0; q < 2; q++) {
+            HIPCHK(hipEventCreate(&ws->ev0[q])); HIPCHK(hipEventCreate(&ws->ev1[q]));
+            HIPCHK(hipEventCreateWithFlags(&ws->evc[q], hipEventDisableTiming));
+        }
     if (!ws->dflag) {
         HIPCHK(hipMalloc((void **)&ws->dflag, sizeof(int)));
         HIPCHK(hipHostMalloc((void **)&ws->hflag, sizeof(int), hipHostMallocDefault));
@@ -911,9 +915,9 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     // ---- workspace ---------------------------------------------------------------------------
     rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)p.nbatch * sizeof(XinvCtl));
     if (rc) return rc;
-    if (ws->hctl_cap < (size_t)p.nbatch) {
+    if (ws->hctl_cap < (size_t)p.nbatch) {             // two slots: polling is pipelined
         if (ws->hctl) HIPCHK(hipHostFree(ws->hctl));
-        HIPCHK(hipHostMalloc((void **)&ws->hctl, (size_t)p.nbatch * sizeof(XinvCtl), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&ws->hctl, 2 * (size_t)p.nbatch * sizeof(XinvCtl), hipHostMallocDefault));
         ws->hctl_cap = (size_t)p.nbatch;
     }
     size_t pbytes;
@@ -954,39 +958,58 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     bool all_done = false;
     double ms_total = 0.0;
     int64_t nlaunch = 0;
-    while (launched < max_sweeps && !all_done) {
-        if (opt.timing) HIPCHK(hipEventRecord(ws->ev0, st));
+    // A chunk = `check_every` launches followed by an asynchronous copy of the control blocks.
+    // Polling is pipelined: chunk c+1 is queued BEFORE the host waits for chunk c's copy, so the
+    // GPU never idles on the host's reaction time; once every member has stopped, the launches
+    // already queued are no-ops (each kernel returns on ctl.done).
+    auto issue_chunk = [&](int slot) -> int {
+        if (opt.timing) HIPCHK(hipEventRecord(ws->ev0[slot], st));
         for (int i = 0; i < check_every && launched < max_sweeps; i++) {
+            int r;
             if (pl.path == XINV_PATH_FUSED) {
                 const int k = (max_sweeps - launched >= Kf) ? Kf : 1;
                 const int cur = (int)(bound.size() & 1);
-                rc = (p.kind == KIND_STD3D)
-                         ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
-                     : pl.nine
-                         ? launch_fused9(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
-                         : launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0);
-                if (rc) return rc;
+                r = (p.kind == KIND_STD3D)
+                        ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
+                    : pl.nine
+                        ? launch_fused9(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
+                        : launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0);
+                if (r) return r;
                 bound.push_back(launched);
                 launched += k;
             } else {
-                rc = launch_colour_sweep(p, pl, ws, st);
-                if (rc) return rc;
+                r = launch_colour_sweep(p, pl, ws, st);
+                if (r) return r;
                 launched += 1;
             }
             nlaunch++;
         }
-        if (opt.timing) HIPCHK(hipEventRecord(ws->ev1, st));
-        HIPCHK(hipMemcpyAsync(ws->hctl, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl),
+        if (opt.timing) HIPCHK(hipEventRecord(ws->ev1[slot], st));
+        HIPCHK(hipMemcpyAsync(ws->hctl + (size_t)slot * p.nbatch, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl),
                               hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipEventRecord(ws->evc[slot], st));
+        return XINV_OK;
+    };
+    const XinvCtl *hc = ws->hctl;                        // the slot holding the final control blocks
+    rc = issue_chunk(0);
+    if (rc) return rc;
+    for (int c = 0;; c++) {
+        const int slot = c & 1;
+        const bool more = launched < max_sweeps;
+        if (more) { rc = issue_chunk(slot ^ 1); if (rc) return rc; }
+        HIPCHK(hipEventSynchronize(ws->evc[slot]));
         if (opt.timing) {
             float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
+            HIPCHK(hipEventElapsedTime(&ms, ws->ev0[slot], ws->ev1[slot]));
             ms_total += ms;
         }
+        hc = ws->hctl + (size_t)slot * p.nbatch;
         all_done = true;
-        for (int64_t m = 0; m < p.nbatch; m++) all_done = all_done && ws->hctl[m].done;
+        for (int64_t m = 0; m < p.nbatch; m++) all_done = all_done && hc[m].done;
+        if (all_done || !more) break;
     }
+    if (pl.path != XINV_PATH_FUSED)                      // drain the queued no-op tail (the fused path syncs below)
+        HIPCHK(hipStreamSynchronize(st));
     if (!all_done) { t_err = "internal: sweep budget exhausted before the stop rule fired"; return XINV_ERR_HIP; }
 
     // ---- fused path: put each member's final state into S ------------------------------------
@@ -994,7 +1017,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (pl.path == XINV_PATH_FUSED) {
         bound.push_back(launched);
         for (int64_t m = 0; m < p.nbatch; m++) {
-            const int64_t sw = ws->hctl[m].sweeps;
+            const int64_t sw = hc[m].sweeps;
             // launch i covers sweeps (bound[i], bound[i+1]]; find the one holding sweep `sw`
             size_t i = std::upper_bound(bound.begin(), bound.end(), sw - 1) - bound.begin() - 1;
             int where;                                   // buffer index holding the final state
@@ -1020,7 +1043,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         HIPCHK(hipStreamSynchronize(st));
     }
     for (int64_t m = 0; m < p.nbatch; m++) {
-        const XinvCtl &c = ws->hctl[m];
+        const XinvCtl &c = hc[m];
         if (c.overflow) flags[3 * m + 0] = 1.0;
         if (c.wrote) { flags[3 * m + 1] = c.flag1; flags[3 * m + 2] = c.flag2; }
         sweeps_max = std::max<int64_t>(sweeps_max, c.sweeps);
