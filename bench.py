@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--sweeps', type=int, default=200, help='SOR sweeps per step')
+    ap.add_argument('--sweeps', type=int, default=500, help='SOR sweeps per step (SURVEY.md 8(d): 500 for C1-C4)')
     ap.add_argument('--spl', type=int, default=0, help='sweeps fused per launch (0 = engine default)')
     ap.add_argument('--rows', type=int, default=0, help='rows per tile (0 = engine default)')
     ap.add_argument('--members', type=int, default=1, help='batch members per GPU')
