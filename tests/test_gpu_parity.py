@@ -479,3 +479,51 @@ def test_fused_nine_point_default_tiling_and_batch():
     for m, q in enumerate(ps):
         So, flo = run_oracle(q, 200, 3e-4, COLOUR_AUTO)
         assert_same(S[m], fl[m], So, flo, '9-point member %d' % m)
+
+
+@pytest.mark.parametrize('chunk', range(32))
+def test_seeded_fuzz_against_the_oracle(chunk):
+    """Seeded random configurations (kind x shape x BCs x mask density x B != 0 x engine options) --
+    whatever path the engine picks must reproduce the oracle's coloured ordering bit for bit."""
+    rng = np.random.default_rng(9000 + chunk)
+    for case in range(24):
+        kind = ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'][int(rng.integers(6))]
+        BCy = ['fixed', 'extend'][int(rng.integers(2))]
+        BCx = ['fixed', 'periodic', 'extend'][int(rng.integers(3))]
+        msk = int(rng.integers(2)); bnz = int(rng.integers(2))
+        seed = int(rng.integers(1 << 30))
+        if kind in ('std3d', 'gen3d'):
+            zc, yc, xc = int(rng.integers(3, 9)), int(rng.integers(3, 40)), int(rng.integers(3, 300))
+            p = (rand3d if kind == 'std3d' else rand3dg)(zc, yc, xc, BCy, BCx, msk, seed=seed)
+        elif kind == 'bih2d':
+            yc, xc = int(rng.integers(5, 60)), int(rng.integers(7, 400))
+            p = randbih(yc, xc, BCy, BCx, bnz, msk, seed=seed)
+        else:
+            yc, xc = int(rng.integers(3, 90)), int(rng.integers(3, 520))
+            p = rand2dt(yc, xc, BCy, BCx, bnz, msk, seed=seed) if kind == 'std2dt' else \
+                rand2d(kind, yc, xc, BCy, BCx, bnz, msk, seed=seed)
+        if msk and kind in ('std2d', 'gen2d', 'std2dt') and int(rng.integers(2)):
+            j0 = int(rng.integers(0, max(1, yc // 2))); i0 = int(rng.integers(0, max(1, xc // 2)))
+            p = _blocky(p, rng, [(j0, yc, i0, xc)])
+        opt = {}
+        if kind in ('std2d', 'gen2d', 'std2dt'):
+            opt['sweeps_per_launch'] = int(rng.integers(0, 3))
+            if yc >= 8 and int(rng.integers(2)):
+                opt['rows_per_tile'] = -int(rng.integers(1, max(2, yc // 4) + 1))
+            opt['force_tile_skip'] = int(rng.integers(2))
+            opt['no_xuniform'] = int(rng.integers(2))
+        nsw = int(rng.integers(1, 14)); tol = [0.0, 1e-3][int(rng.integers(2))]
+        So, flo = run_oracle(p, nsw, tol, COLOUR_AUTO)
+        try:
+            S, fl, st = run_hip_batched([p], nsw, tol, **opt)
+        except Exception as e:                       # general 9-point form has no K = 2 kernel
+            if 'sweeps_per_launch' in str(e) or 'unsupported' in str(e):
+                opt.pop('sweeps_per_launch', None)
+                S, fl, st = run_hip_batched([p], nsw, tol, **opt)
+            else:
+                raise
+        what = 'fuzz %d/%d %s %r %s %s msk=%d bnz=%d %r' % (chunk, case, kind, p['S0'].shape, BCy, BCx, msk, bnz, opt)
+        if np.isnan(So).any():
+            assert np.array_equal(S[0], So, equal_nan=True), what
+        else:
+            assert_same(S[0], fl[0], So, flo, what)
