@@ -497,18 +497,18 @@ def _coeffs_Poisson(force, dims, coords, mParams, iParams, icbc):
         shifted = np.concatenate(([np.nan], lats[:-1]))
         cosH = np.cos((lats + shifted) / 2.0)
         A = z2 + cosH[:, None]
-        B = z2
+        B = _zero_like(z2)
         C = z2 + (1.0 / cosG)[:, None]
         Fv = _remask(maskF.values * along(cosG, maskF, dims[0]), maskF)
     elif c == 'z-lat':
         cosG = np.cos(np.deg2rad(np.asarray(maskF[dims[1]], dtype=np.float64)))
         A = z2 + 1.0
-        B = z2
+        B = _zero_like(z2)
         C = z2 + 1.0
         Fv = _remask(maskF.values * along(cosG, maskF, dims[1]), maskF)
     elif c in ('z-lon', 'cartesian'):
         A = z2 + 1.0
-        B = z2
+        B = _zero_like(z2)
         C = z2 + 1.0
         Fv = maskF.values
     else:
@@ -529,14 +529,14 @@ def _coeffs_Stommel(curl, dims, coords, mParams, iParams, icbc):
         lats = np.deg2rad(np.asarray(curl[dims[0]], dtype=np.float64))
         cosL = np.cos(lats)
         A = z2 - R2 / depth
-        B = z2
+        B = _zero_like(z2)
         C = z2 - R2 / depth / (cosL**2.)[:, None]
         D = z2
         E = z2 - 2. * Omega / Rearth
         Fc = z2
     elif c == 'cartesian':
         A = z2 - R2 / depth
-        B = z2
+        B = _zero_like(z2)
         C = z2 - R2 / depth
         D = z2
         E = z2 - beta
@@ -562,7 +562,7 @@ def _coeffs_Fofonoff(f, dims, coords, mParams, iParams, icbc):
         cosH = np.cos((lats + np.concatenate(([np.nan], lats[:-1]))) / 2.0)
         fc = 2. * Omega * np.sin(lats)
         A = z2 + cosH[:, None]
-        B = z2
+        B = _zero_like(z2)
         C = z2
         D = z2 + (1.0 / cosG)[:, None]
         E = z2 - (c0 * cosG)[:, None]
@@ -570,7 +570,7 @@ def _coeffs_Fofonoff(f, dims, coords, mParams, iParams, icbc):
     elif c == 'cartesian':
         fc = f0 + beta * yv
         A = z2 + 1.0
-        B = z2
+        B = _zero_like(z2)
         C = z2
         D = z2 + 1.0
         E = z2 - c0
@@ -593,7 +593,7 @@ def _coeffs_Bretherton(h, dims, coords, mParams, iParams, icbc):
         cosH = np.cos((lats + np.concatenate(([np.nan], lats[:-1]))) / 2.0)
         fc = 2. * Omega * np.sin(lats)
         A = z2 + cosH[:, None]
-        B = z2
+        B = _zero_like(z2)
         C = z2
         D = z2 + (1.0 / cosG)[:, None]
         E = z2 - (lamb * depth * cosG)[:, None]
@@ -601,7 +601,7 @@ def _coeffs_Bretherton(h, dims, coords, mParams, iParams, icbc):
     elif c == 'cartesian':
         fc = f0 + beta * yv
         A = z2 + 1.0
-        B = z2
+        B = _zero_like(z2)
         C = z2
         D = z2 + 1.0
         E = z2 - lamb * depth
@@ -622,7 +622,7 @@ def _coeffs_StommelMunk(curl, dims, coords, mParams, iParams, icbc):
         lats = np.deg2rad(np.asarray(curl[dims[0]], dtype=np.float64))
         cosL = np.cos(lats)
         A = z2 + A4
-        B = z2
+        B = _zero_like(z2)
         C = z2 + (A4 / cosL**2.)[:, None]
         D = z2 - R / depth
         E = z2
@@ -632,7 +632,7 @@ def _coeffs_StommelMunk(curl, dims, coords, mParams, iParams, icbc):
         I = z2
     elif c == 'cartesian':
         A = z2 + A4
-        B = z2
+        B = _zero_like(z2)
         C = z2 + A4
         D = z2 - R / depth
         E = z2
@@ -663,7 +663,7 @@ def _coeffs_GillMatsuno(Q, dims, coords, mParams, iParams, icbc):
         c2 = f / (epsilon**2. + f**2.)
         deg2m = Rearth / 180. * np.pi
         A = z2 + (c1 * Phi)[:, None]
-        B = z2
+        B = _zero_like(z2)
         C = z2 + (c1 * Phi / cosL**2.)[:, None]
         D = z2 + (Phi * (np.gradient(c1, yv) / deg2m + c1 * np.tan(lats) / Rearth))[:, None]
         E = z2 - (Phi * np.gradient(c2, yv) / deg2m / cosL)[:, None]
@@ -673,7 +673,7 @@ def _coeffs_GillMatsuno(Q, dims, coords, mParams, iParams, icbc):
         c1 = epsilon / (epsilon**2. + f**2.)
         c2 = f / (epsilon**2. + f**2.)
         A = z2 + (c1 * Phi)[:, None]
-        B = z2
+        B = _zero_like(z2)
         C = z2 + (c1 * Phi)[:, None]
         D = z2 + (Phi * np.gradient(c1, yv))[:, None]
         E = z2 - (Phi * np.gradient(c2, yv))[:, None]
@@ -948,6 +948,12 @@ def _coeffs_3DOcean(force, dims, coords, mParams, iParams, icbc):
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
     return maskF.like(maskF.values), initS, (A, B, C, D, E, Fc, G)
+
+
+def _zero_like(z):
+    """An identically-zero coefficient as a stride-0 view: core._solve recognises it and passes
+    NULL for the cross coefficient B (nothing to pin, upload or scan on the device)."""
+    return np.broadcast_to(np.float64(0.0), z.shape)
 
 
 def _core_zero(maskF, dims):

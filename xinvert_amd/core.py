@@ -82,10 +82,13 @@ def _batch_layout(F, dims):
     return perm, bdims, bshape
 
 
-def _prep_coef(c, F, perm, core_shape, nbatch):
-    """-> (contiguous float64 array, batch stride in elements)."""
+def _prep_coef(c, F, perm, core_shape, nbatch, allow_null=False):
+    """-> (contiguous float64 array, batch stride in elements); (None, 0) for an identically-zero
+    stride-0 view where the C-ABI accepts NULL (the cross coefficient B)."""
     v = np.asarray(_vals(c), dtype=np.float64)
     n = int(np.prod(core_shape))
+    if allow_null and v.size > 1 and all(st == 0 for st in v.strides) and v.flat[0] == 0.0:
+        return None, 0
     if v.shape == tuple(core_shape):
         return np.ascontiguousarray(v), 0
     if v.shape == F.shape:
@@ -101,7 +104,7 @@ def _prep_coef(c, F, perm, core_shape, nbatch):
     except ValueError:
         raise Exception('coefficient shape %r matches neither the core shape %r nor F %r'
                         % (v.shape, tuple(core_shape), F.shape))
-    return _prep_coef(t, F, perm, core_shape, nbatch)
+    return _prep_coef(t, F, perm, core_shape, nbatch, allow_null)
 
 
 def _info(sel):
@@ -125,8 +128,9 @@ def _solve(kind, coefs, F, S, dims, iParams):
     Fv = np.ascontiguousarray(np.transpose(np.asarray(F.values, dtype=np.float64), perm)
                               ).reshape((nbatch,) + core_shape)
     arrs, strides = [Sv], [n]
-    for c in coefs:
-        a, st = _prep_coef(c, F, perm, core_shape, nbatch)
+    for k, c in enumerate(coefs):
+        a, st = _prep_coef(c, F, perm, core_shape, nbatch,
+                           allow_null=(k == 1 and kind in ('std2d', 'gen2d')))
         arrs.append(a)
         strides.append(st)
     arrs.append(Fv)
