@@ -63,7 +63,11 @@ typedef struct xinv_options {
                                    blocks (n < 0); fused 3-D: rows per workgroup (8, 12, 16); 0=auto */
     int32_t timing;             /* 1: bracket launch chunks with HIP events (xinv_last_stats)   */
     int32_t flags;              /* XINV_FLAG_* bits                                              */
-    int32_t reserved;
+    int32_t rowconst_mask;      /* host-pointer entries: bit q set = coefficient array q (argument order
+                                   without S: A = bit 0) holds ONE value per row, [rows] per member with
+                                   rows = yc (zc*yc in 3-D); its batch stride is 0 or >= rows.  The rows
+                                   are uploaded and expanded on the device: lat-lon coefficients are
+                                   functions of latitude only (apps.py:1406-1408, 1630-1635)             */
 } xinv_options;
 
 typedef struct xinv_stats {

@@ -8,6 +8,8 @@ perturbs each norm by a few ulp (~1e-16 relative) and therefore their relative D
 """
 import zlib
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -257,6 +259,49 @@ def test_masked_tile_skipping_degenerate_members():
             assert_same(S[m], fl[m], So, flo, 'degenerate member %d' % m)
     assert np.array_equal(S[0], dead['S0']) and fl[0][2] == 1 and fl[0][1] == 0.0   # norm constant: stops at loop 1
     assert fl[2][0] == 1.0                                                          # NaN -> overflow exit
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d', 'std3d', 'bih2d'])
+def test_row_constant_coefficients_travel_as_rows(kind):
+    """xinv_options.rowconst_mask: coefficient arrays given as one value per row ([rows] per member,
+    batch stride 0 or rows) are expanded on the device -- same bits as passing the full arrays."""
+    from xinvert_amd import _lib
+    L = _lib.require_gpu()
+    if kind == 'std3d':
+        ps = [rand3d(5, 12, 40, 'fixed', 'periodic', 1, seed=s) for s in (1, 2)]
+    elif kind == 'bih2d':
+        ps = [randbih(14, 40, 'fixed', 'fixed', 1, 1, seed=s) for s in (1, 2)]
+    else:
+        ps = [rand2d(kind, 14, 40, 'fixed', 'periodic', 0, 1, seed=s) for s in (1, 2)]
+    nco = len(ps[0]['coefs'])
+    rowq = [0, 2] if kind != 'bih2d' else [0, 2, 3, 5, 8]          # made constant along x
+    ps[1]['coefs'][0] = ps[0]['coefs'][0]                           # array 0 is shared by the members
+    for q in ps:
+        q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[..., :1], c.shape)) if k in rowq else c
+                      for k, c in enumerate(q['coefs'])]
+    S_full, fl_full, _ = run_hip_batched(ps, 12, 1e-9, shared=(0,))
+    # the same call with rows: array 0 shared (stride 0), the others per member (stride = rows)
+    p = ps[0]; nb = len(ps); n = int(np.prod(p['S0'].shape)); rows = n // p['S0'].shape[-1]
+    S = np.ascontiguousarray(np.stack([q['S0'] for q in ps]))
+    arrs, strides, mask = [S], [n], 0
+    for k in range(nco):
+        if k in rowq:
+            mask |= 1 << k
+            if k == 0:
+                arrs.append(np.ascontiguousarray(p['coefs'][k][..., 0])); strides.append(0)
+            else:
+                arrs.append(np.ascontiguousarray(np.stack([q['coefs'][k][..., 0] for q in ps]))); strides.append(rows)
+        else:
+            arrs.append(np.ascontiguousarray(np.stack([q['coefs'][k] for q in ps]))); strides.append(n)
+    fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
+    o = _lib.options(rowconst_mask=mask)
+    rc = getattr(L, util._FN[kind] + '_batched')(*[_lib.hptr(a) for a in arrs], nb, _lib.strides_arg(strides),
+                                                 *util._scal(p, fl, 12, 1e-9), ctypes.byref(o))
+    _lib.check(rc)
+    assert np.array_equal(S, S_full) and np.array_equal(fl, fl_full)
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 12, 1e-9, COLOUR_AUTO)
+        assert_same(S[m], fl[m], So, flo, 'rowconst member %d' % m)
 
 
 def test_dev_api_matches_host_api():

@@ -207,16 +207,35 @@ def test_batch_layout_and_shared_coefficients():
     perm, bdims, bshape = core._batch_layout(F, ['lat', 'lon'])
     assert perm == [0, 2, 1, 3] and bdims == ['time', 'mem'] and bshape == [3, 2]
     core2 = np.arange(20.0).reshape(4, 5)
-    a, st = core._prep_coef(core2, F, perm, (4, 5), 6)
-    assert st == 0 and a.shape == (4, 5)
+    a, st, rc = core._prep_coef(core2, F, perm, (4, 5), 6)
+    assert st == 0 and a.shape == (4, 5) and not rc
     full = np.broadcast_to(core2[None, :, None, :], F.shape)      # zero batch strides -> shared
-    a, st = core._prep_coef(full, F, perm, (4, 5), 6)
-    assert st == 0 and np.array_equal(a, core2)
+    a, st, rc = core._prep_coef(full, F, perm, (4, 5), 6)
+    assert st == 0 and np.array_equal(a, core2) and not rc
     per = np.arange(120.0).reshape(3, 4, 2, 5)
-    a, st = core._prep_coef(per, F, perm, (4, 5), 6)
-    assert st == 20 and a.shape == (6, 4, 5) and np.array_equal(a[1], per[0, :, 1, :])
+    a, st, rc = core._prep_coef(per, F, perm, (4, 5), 6)
+    assert st == 20 and a.shape == (6, 4, 5) and np.array_equal(a[1], per[0, :, 1, :]) and not rc
     with pytest.raises(Exception, match='matches neither'):
         core._prep_coef(np.zeros((7, 7)), F, perm, (4, 5), 6)
+    # one value per row (stride-0 view along x): only the rows travel (xinv_options.rowconst_mask)
+    lat = np.arange(4.0) + 1
+    a, st, rc = core._prep_coef(np.broadcast_to(lat[:, None], (4, 5)), F, perm, (4, 5), 6)
+    assert rc and st == 0 and a.shape == (4,) and np.array_equal(a, lat)
+    rows_b = np.broadcast_to(np.arange(24.0).reshape(3, 4, 2, 1), F.shape)              # per member, row-constant
+    a, st, rc = core._prep_coef(rows_b, F, perm, (4, 5), 6)
+    assert rc and st == 4 and a.shape == (6, 4) and np.array_equal(a[1], rows_b[0, :, 1, 0])
+    # identically-zero stride-0 view: NULL for the cross coefficient only
+    z = np.broadcast_to(np.float64(0.0), (4, 5))
+    assert core._prep_coef(z, F, perm, (4, 5), 6, allow_null=True)[0] is None
+    a, st, rc = core._prep_coef(z, F, perm, (4, 5), 6)
+    assert rc and a.shape == (4,) and not a.any()
+    # the lat-lon builders produce such views
+    lt = np.linspace(-60, 60, 7); ln = np.linspace(0, 300, 6)
+    Fp = Field(np.ones((7, 6)), ('lat', 'lon'), {'lat': lt, 'lon': ln})
+    Fm, S0, (A, B, C) = apps._coeffs_Poisson(Fp, ['lat', 'lon'], 'lat-lon', apps.default_mParams,
+                                             apps.default_iParams, None)
+    assert A.shape == B.shape == C.shape == (7, 6) and A.strides[-1] == 0 and C.strides[-1] == 0
+    assert all(st == 0 for st in B.strides)
 
 
 def test_info_line_format():

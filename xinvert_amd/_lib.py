@@ -23,7 +23,7 @@ class XinvOptions(ctypes.Structure):
     _fields_ = [('device', ctypes.c_int32), ('path', ctypes.c_int32),
                 ('sweeps_per_launch', ctypes.c_int32), ('check_every', ctypes.c_int32),
                 ('rows_per_tile', ctypes.c_int32), ('timing', ctypes.c_int32),
-                ('flags', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('flags', ctypes.c_int32), ('rowconst_mask', ctypes.c_int32)]
 
 
 class XinvStats(ctypes.Structure):
@@ -130,13 +130,14 @@ def check(rc):
 
 
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
-            timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0):
+            timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
     o.check_every, o.rows_per_tile, o.timing = check_every, rows_per_tile, timing
     # XINV_FLAG_NO_XUNIFORM | XINV_FLAG_NO_TILE_SKIP | XINV_FLAG_FORCE_TILE_SKIP
     o.flags = (1 if no_xuniform else 0) | (2 if no_tile_skip else 0) | (4 if force_tile_skip else 0)
+    o.rowconst_mask = int(rowconst_mask)
     return o
 
 

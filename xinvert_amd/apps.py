@@ -514,7 +514,7 @@ def _coeffs_Poisson(force, dims, coords, mParams, iParams, icbc):
     else:
         raise Exception('unsupported coords ' + coords +
                         ', should be in [lat-lon, z-lat, z-lon, cartesian]')
-    return maskF.like(Fv), initS, (A, B, C)
+    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C)
 
 
 def _coeffs_Stommel(curl, dims, coords, mParams, iParams, icbc):
@@ -545,7 +545,7 @@ def _coeffs_Stommel(curl, dims, coords, mParams, iParams, icbc):
         raise Exception('unsupported coords ' + coords +
                         ', should be in [lat-lon, z-lat, z-lon, cartesian]')
     G = _remask(-maskF.values / depth / rho0, maskF)
-    return maskF.like(G), initS, (A, B, C, D, E, Fc)
+    return maskF.like(G), initS, _cs(maskF, dims, A, B, C, D, E, Fc)
 
 
 def _coeffs_Fofonoff(f, dims, coords, mParams, iParams, icbc):
@@ -577,7 +577,7 @@ def _coeffs_Fofonoff(f, dims, coords, mParams, iParams, icbc):
         Fv = _remask(zero + c1 - along(fc, maskF, dims[0]), maskF)
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
-    return maskF.like(Fv), initS, (A, B, C, D, E)
+    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C, D, E)
 
 
 def _coeffs_Bretherton(h, dims, coords, mParams, iParams, icbc):
@@ -608,7 +608,7 @@ def _coeffs_Bretherton(h, dims, coords, mParams, iParams, icbc):
         Fv = _remask(-maskF.values * along(fc, maskF, dims[0]) / depth, maskF)
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
-    return maskF.like(Fv), initS, (A, B, C, D, E)
+    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C, D, E)
 
 
 def _coeffs_StommelMunk(curl, dims, coords, mParams, iParams, icbc):
@@ -643,7 +643,7 @@ def _coeffs_StommelMunk(curl, dims, coords, mParams, iParams, icbc):
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
     J = _remask(-maskF.values / depth / rho0, maskF)
-    return maskF.like(J), initS, (A, B, C, D, E, F, G, H, I)
+    return maskF.like(J), initS, _cs(maskF, dims, A, B, C, D, E, F, G, H, I)
 
 
 def _coeffs_GillMatsuno(Q, dims, coords, mParams, iParams, icbc):
@@ -680,7 +680,7 @@ def _coeffs_GillMatsuno(Q, dims, coords, mParams, iParams, icbc):
         Fc = z2 - epsilon
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
-    return maskF.like(maskF.values), initS, (A, B, C, D, E, Fc)
+    return maskF.like(maskF.values), initS, _cs(maskF, dims, A, B, C, D, E, Fc)
 
 
 def _coeffs_omega(force, dims, coords, mParams, iParams, icbc):
@@ -688,7 +688,7 @@ def _coeffs_omega(force, dims, coords, mParams, iParams, icbc):
     f0, beta, N2, Omega = mParams['f0'], mParams['beta'], mParams['N2'], mParams['Omega']
     maskF, initS, zero = _mask_FS(force, dims, iParams, icbc)
     zc, yc, xc = (maskF.shape[maskF.axis(d)] for d in dims)
-    z3 = np.zeros((zc, yc, xc))
+    z3 = np.zeros((zc, yc, 1))
     if np.isscalar(N2):
         n2 = N2
     else:
@@ -715,7 +715,7 @@ def _coeffs_omega(force, dims, coords, mParams, iParams, icbc):
         Fv = maskF.values
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
-    return maskF.like(Fv), initS, (A, B, C)
+    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C)
 
 
 def _half_shift(v):
@@ -739,7 +739,7 @@ def _coeffs_RefState(Q, dims, coords, mParams, iParams, icbc):
         raise Exception('unsupported coords ' + coords + ', should be in [z-lat, cartesian]')
     B = full(0.0, maskF)
     C = full(aligned(Gamma, maskF) * g / Qv / x1, maskF)
-    return maskF.like(maskF.values), initS, (A, B, C)
+    return maskF.like(maskF.values), initS, _cs(maskF, dims, A, B, C)
 
 
 def _coeffs_PV2D(PV, dims, coords, mParams, iParams, icbc):
@@ -751,7 +751,7 @@ def _coeffs_PV2D(PV, dims, coords, mParams, iParams, icbc):
     A = full(f0**2 / aligned(N2, maskF), maskF)
     B = full(0.0, maskF)
     C = full(1.0, maskF)
-    return maskF.like(maskF.values), initS, (A, B, C)
+    return maskF.like(maskF.values), initS, _cs(maskF, dims, A, B, C)
 
 
 def _coeffs_Eliassen(force, dims, coords, mParams, iParams, icbc):
@@ -761,7 +761,7 @@ def _coeffs_Eliassen(force, dims, coords, mParams, iParams, icbc):
     if coords.lower() not in ('z-lat', 'cartesian'):
         raise Exception('unsupported coords ' + coords + ', should be in [z-lat, cartesian]')
     A, B, C = (full(aligned(mParams[k], maskF), maskF) for k in ('A', 'B', 'C'))
-    return maskF.like(maskF.values), initS, (A, B, C)
+    return maskF.like(maskF.values), initS, _cs(maskF, dims, A, B, C)
 
 
 def _coeffs_GillMatsuno_test(Q, dims, coords, mParams, iParams, icbc):
@@ -800,7 +800,7 @@ def _coeffs_GillMatsuno_test(Q, dims, coords, mParams, iParams, icbc):
         Fv = maskF.values
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
-    return maskF.like(Fv), initS, (A, B, C, D, E)
+    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C, D, E)
 
 
 def _coeffs_Stommel_test(curl, dims, coords, mParams, iParams, icbc):
@@ -831,7 +831,7 @@ def _coeffs_Stommel_test(curl, dims, coords, mParams, iParams, icbc):
         Fv = _remask(-maskF.values / depth / rho0, maskF)
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, z-lat, z-lon, cartesian]')
-    return maskF.like(Fv), initS, (A, B, C, D, E)
+    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C, D, E)
 
 
 def _coeffs_StommelArons(Q, dims, coords, mParams, iParams, icbc):
@@ -865,7 +865,7 @@ def _coeffs_StommelArons(Q, dims, coords, mParams, iParams, icbc):
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
     B = full(0.0, maskF)
     Fc = full(0.0, maskF)
-    return maskF.like(maskF.values), initS, (A, B, C, D, E, Fc)
+    return maskF.like(maskF.values), initS, _cs(maskF, dims, A, B, C, D, E, Fc)
 
 
 def _coeffs_geostrophic(lapPhi, dims, coords, mParams, iParams, icbc):
@@ -897,7 +897,7 @@ def _coeffs_geostrophic(lapPhi, dims, coords, mParams, iParams, icbc):
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
     B = full(0.0, maskF)
-    return maskF.like(Fv), initS, (A, B, C)
+    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C)
 
 
 def _coeffs_3DOcean(force, dims, coords, mParams, iParams, icbc):
@@ -910,7 +910,7 @@ def _coeffs_3DOcean(force, dims, coords, mParams, iParams, icbc):
     Omega, Rearth = mParams['Omega'], mParams['Rearth']
     maskF, initS, zero = _mask_FS(force, dims, iParams, icbc)
     zc, yc, xc = (maskF.shape[maskF.axis(d)] for d in dims)
-    z3 = np.zeros((zc, yc, xc))
+    z3 = np.zeros((zc, yc, 1))
     zv = np.asarray(force[dims[0]], dtype=np.float64)
     yv = np.asarray(force[dims[1]], dtype=np.float64)
     if np.isscalar(N2):
@@ -947,7 +947,17 @@ def _coeffs_3DOcean(force, dims, coords, mParams, iParams, icbc):
         G = z3
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
-    return maskF.like(maskF.values), initS, (A, B, C, D, E, Fc, G)
+    return maskF.like(maskF.values), initS, _cs(maskF, dims, A, B, C, D, E, Fc, G)
+
+
+def _cs(maskF, dims, *coefs):
+    """Coefficients at the core shape; the ones built on `_core_zero` become stride-0 views along x."""
+    shape = tuple(maskF.shape[maskF.axis(d)] for d in dims)
+    out = []
+    for c in coefs:
+        c = np.asarray(c)
+        out.append(c if c.shape[-len(shape):] == shape else np.broadcast_to(c, shape))
+    return tuple(out)
 
 
 def _zero_like(z):
@@ -957,10 +967,14 @@ def _zero_like(z):
 
 
 def _core_zero(maskF, dims):
-    """`zero` restricted to the core dims: coefficients that do not depend on the batch axis
-    are built once and shared by every slice (batch stride 0 at the C-ABI), instead of the
-    reference's broadcast to F's full shape (apps.py:2141)."""
-    return np.zeros(tuple(maskF.shape[maskF.axis(d)] for d in dims))
+    """`zero` restricted to the core dims, with the x axis left at length 1: coefficients that do
+    not depend on the batch axis are built once and shared by every slice (batch stride 0 at the
+    C-ABI), and those that depend on latitude / level only stay one value per row -- `_cs`
+    broadcasts them to the core shape as stride-0 views, which core._solve ships as rows
+    (xinv_options.rowconst_mask) -- instead of the reference's materialised broadcast to F's
+    full shape (apps.py:2141)."""
+    shape = tuple(maskF.shape[maskF.axis(d)] for d in dims)
+    return np.zeros(shape[:-1] + (1,))
 
 
 def _core_param(p, maskF, dims):

@@ -83,22 +83,34 @@ def _batch_layout(F, dims):
 
 
 def _prep_coef(c, F, perm, core_shape, nbatch, allow_null=False):
-    """-> (contiguous float64 array, batch stride in elements); (None, 0) for an identically-zero
-    stride-0 view where the C-ABI accepts NULL (the cross coefficient B)."""
+    """-> (contiguous float64 array, batch stride in elements, rowconst).
+
+    (None, 0, False) for an identically-zero stride-0 view where the C-ABI accepts NULL (the
+    cross coefficient B).  rowconst: the coefficient does not vary along x (a stride-0 view along
+    the last core axis, as the lat-lon builders of apps.py produce): only its first column
+    travels, [rows] per member, and the library expands it on the device."""
     v = np.asarray(_vals(c), dtype=np.float64)
     n = int(np.prod(core_shape))
+    rows = n // core_shape[-1]
     if allow_null and v.size > 1 and all(st == 0 for st in v.strides) and v.flat[0] == 0.0:
-        return None, 0
+        return None, 0, False
     if v.shape == tuple(core_shape):
-        return np.ascontiguousarray(v), 0
+        if v.strides[-1] == 0 and core_shape[-1] > 1:
+            return np.ascontiguousarray(v[..., 0]), 0, True
+        return np.ascontiguousarray(v), 0, False
     if v.shape == F.shape:
         # a broadcast view over the batch axes (zero strides) is one shared slice
         t = np.transpose(v, perm)
         nb_axes = len(perm) - len(core_shape)
+        rc = t.strides[-1] == 0 and core_shape[-1] > 1
         if all(t.strides[ax] == 0 or t.shape[ax] == 1 for ax in range(nb_axes)):
             idx = (0,) * nb_axes
-            return np.ascontiguousarray(t[idx]), 0
-        return np.ascontiguousarray(t).reshape((nbatch,) + tuple(core_shape)), n
+            if rc:
+                return np.ascontiguousarray(t[idx][..., 0]), 0, True
+            return np.ascontiguousarray(t[idx]), 0, False
+        if rc:
+            return np.ascontiguousarray(t[..., 0]).reshape((nbatch, rows)), rows, True
+        return np.ascontiguousarray(t).reshape((nbatch,) + tuple(core_shape)), n, False
     try:
         t = np.broadcast_to(v, F.shape)
     except ValueError:
@@ -128,11 +140,13 @@ def _solve(kind, coefs, F, S, dims, iParams):
     Fv = np.ascontiguousarray(np.transpose(np.asarray(F.values, dtype=np.float64), perm)
                               ).reshape((nbatch,) + core_shape)
     arrs, strides = [Sv], [n]
+    rowconst = 0
     for k, c in enumerate(coefs):
-        a, st = _prep_coef(c, F, perm, core_shape, nbatch,
-                           allow_null=(k == 1 and kind in ('std2d', 'gen2d')))
+        a, st, rc = _prep_coef(c, F, perm, core_shape, nbatch,
+                               allow_null=(k == 1 and kind in ('std2d', 'gen2d')))
         arrs.append(a)
         strides.append(st)
+        rowconst |= (1 << k) if rc else 0
     arrs.append(Fv)
     strides.append(n)
 
@@ -141,7 +155,7 @@ def _solve(kind, coefs, F, S, dims, iParams):
     opt = _lib.options(device=int(iParams.get('device', -1)),
                        path=int(iParams.get('engine_path', 0)),
                        sweeps_per_launch=int(iParams.get('sweeps_per_launch', 0)),
-                       check_every=int(iParams.get('check_every', 0)))
+                       check_every=int(iParams.get('check_every', 0)), rowconst_mask=rowconst)
     st = _lib.strides_arg(strides)
     ptrs = [_lib.hptr(a) for a in arrs]
     mx, tol = int(iParams['mxLoop']), float(iParams['tolerance'])

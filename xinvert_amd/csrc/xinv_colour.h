@@ -555,6 +555,17 @@ __global__ __launch_bounds__(256) void k_any_nonzero(const double *B, int64_t n,
     if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// row-constant coefficient arrays (xinv_options.rowconst_mask): out[m][row][0..xc) = in[m][row]
+__global__ __launch_bounds__(256) void k_expand_rows(const double *in, double *out, int64_t rows,
+                                                     int64_t xc, int64_t nmem)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows * nmem) return;
+    const double v = in[row];
+    double *o = out + row * xc;
+    for (int64_t i = threadIdx.x & 63; i < xc; i += 64) o[i] = v;
+}
+
 __global__ void k_ctl_init(XinvCtl *ctl, int64_t nbatch)
 {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

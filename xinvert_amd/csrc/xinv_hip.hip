@@ -108,6 +108,7 @@ struct Problem {
     const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J ; std2dt: A..F ; gen3d: A..H
     int64_t sS, sc[10];
     int ncoef;
+    unsigned rowconst;           // host entries: arrays given as one value per row (see xinv.h)
     int BCz, BCy, BCx;
     XinvScal sc_;
     XinvStop stop;
@@ -131,9 +132,11 @@ static int validate(const Problem &p, const double *flags)
     if (p.stop.mxLoop < 0) return fail_arg("mxLoop < 0");
     const int64_t n = p.zc * p.yc * p.xc;
     if (p.nbatch > 1 && p.sS < n) return fail_arg("S batch stride smaller than one slice");
-    for (int q = 0; q < p.ncoef; q++)
-        if (p.c[q] && p.sc[q] != 0 && p.sc[q] < n)
+    for (int q = 0; q < p.ncoef; q++) {
+        const int64_t need = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
+        if (p.c[q] && p.sc[q] != 0 && p.sc[q] < need)
             return fail_arg("coefficient batch stride must be 0 (shared) or >= slice size");
+    }
     return XINV_OK;
 }
 
@@ -1146,6 +1149,7 @@ static int upload(DevPool *pool, Pinned &pin, hipStream_t st, const double *h, i
 
 static int solve_host(Problem &p, double *flags, const xinv_options *opt)
 {
+    p.rowconst = opt ? ((unsigned)opt->rowconst_mask & ((1u << p.ncoef) - 1u)) : 0u;
     int rc = validate(p, flags);
     if (rc) return rc;
     int ndev = 0;
@@ -1180,10 +1184,24 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt)
     d.sS = n;
     for (int q = 0; q < p.ncoef; q++) {
         double *dc;
-        rc = upload(pool, pin, st, p.c[q], p.nbatch, p.nbatch > 1 ? p.sc[q] : 0, n, &dc, &d.sc[q]);
-        if (rc) return rc;
+        if (((p.rowconst >> q) & 1u) && p.c[q]) {        // one value per row: upload rows, expand on the device
+            const int64_t rows = p.zc * p.yc;
+            double *drow; int64_t rstride;
+            rc = upload(pool, pin, st, p.c[q], p.nbatch, p.nbatch > 1 ? p.sc[q] : 0, rows, &drow, &rstride);
+            if (rc) return rc;
+            const int64_t members = (rstride == 0) ? 1 : p.nbatch;
+            rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &dc);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_expand_rows, dim3(cdiv(rows * members, 4)), dim3(256), 0, st,
+                               (const double *)drow, dc, rows, p.xc, members);
+            d.sc[q] = (rstride == 0) ? 0 : n;
+        } else {
+            rc = upload(pool, pin, st, p.c[q], p.nbatch, p.nbatch > 1 ? p.sc[q] : 0, n, &dc, &d.sc[q]);
+            if (rc) return rc;
+        }
         d.c[q] = dc;
     }
+    d.rowconst = 0;
     HIPCHK(hipEventRecord(e1, st));
     rc = solve_dev(d, flags, opt, st);
     if (rc) return rc;
