@@ -86,6 +86,7 @@ def main():
     from xinvert_amd import dist as xdist
 
     rank, local, world = xdist.init_process_group()
+    joined = torch.distributed.is_available() and torch.distributed.is_initialized()
     if world != a.gpus and world > 1:
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, a.gpus))
     L = _lib.require_gpu()
@@ -117,11 +118,11 @@ def main():
             a.sweeps - 1, 0.0, ctypes.byref(opt), sp)
         _lib.check(rc)
         s = _lib.last_stats()
-        allf = xdist.gather_flags(flags, nb * world) if world > 1 else flags
+        allf = xdist.gather_flags(flags, nb * world) if joined else flags
         return s, allf
 
     def barrier():
-        if world > 1:
+        if joined:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +138,7 @@ def main():
         ms_sweeps += s['sweep_ms']; launches += s['sweep_launches']
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if joined:
         tdev = dev if torch.distributed.get_backend() == 'nccl' else torch.device('cpu')
         tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -181,7 +182,7 @@ def main():
         if world == 1 and not a.no_cpu:
             out['cpu_baseline'] = cpu_baseline(p, a.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if joined:
         torch.distributed.destroy_process_group()
 
 

@@ -28,7 +28,9 @@ def init_process_group(backend=None):
     import torch
     import torch.distributed as dist
     rank, local, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    # XINV_DIST_FORCE_INIT=1: join even as a single rank (exercises the RCCL path on a 1-GPU box)
+    force = os.environ.get('XINV_DIST_FORCE_INIT') == '1'
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -47,7 +49,7 @@ def gather_flags(local_flags, nbatch, device=None):
     import torch
     import torch.distributed as dist
     local_flags = np.asarray(local_flags, dtype=np.float64).reshape(-1, 3)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_flags.copy()
     world, rank = dist.get_world_size(), dist.get_rank()
     longest = -(-int(nbatch) // world)
