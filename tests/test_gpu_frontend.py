@@ -470,6 +470,9 @@ def test_full_size_c2_properties():
     S2, f2, s2 = util.run_hip_dev([q], 19, 0.0, sweeps_per_launch=2)
     S3, f3, s3 = util.run_hip_dev([q], 19, 0.0, path=1)
     assert s1['path'] == 2 and s2['sweeps_per_launch'] == 2 and s3['path'] == 1
+    assert s2['masked_tile_pct'] >= 15                   # land blobs + polar caps: skipped tiles
+    S4, f4, s4 = util.run_hip_dev([q], 19, 0.0, sweeps_per_launch=2, no_tile_skip=1)
+    assert s4['masked_tile_pct'] == 0 and np.array_equal(S2, S4) and np.allclose(f2, f4, rtol=1e-9, atol=1e-12)
     assert np.array_equal(S1, S2) and np.array_equal(S1, S3)
     assert np.allclose(f1, f2, rtol=1e-9, atol=1e-12) and np.allclose(f1, f3, rtol=1e-9, atol=1e-12)
     land = q['coefs'][3] == U
@@ -505,6 +508,38 @@ def test_full_size_c3_stommel_bitwise_paths():
     S2, f2, _ = util.run_hip_dev([q], 9, 0.0, path=1)
     assert np.array_equal(S1, S2)
     assert (S1[0][0] == 0).all() and (S1[0][:, 0] == 0).all() and (S1[0][-1] == 0).all()
+
+
+def test_full_size_c4_gill_matsuno_members():
+    """BASELINE configs[3] at full grid size (720 x 1440), 8 of the 64 members: fused K=2 with every
+    latitude-only coefficient read as a per-row scalar == the same kernel streaming every array ==
+    the colour path, bit for bit; members are independent (member 3 alone == member 3 in the batch)."""
+    from xinvert_amd import synthetic
+    p = synthetic.gill_matsuno(720, 1440, 8)
+    qs = [synthetic.member(p, m) for m in range(8)]
+    S1, f1, s1 = util.run_hip_dev(qs, 11, 0.0, shared=p['shared'])
+    S2, f2, s2 = util.run_hip_dev(qs, 11, 0.0, shared=p['shared'], no_xuniform=1)
+    S3, f3, s3 = util.run_hip_dev(qs, 11, 0.0, shared=p['shared'], path=1)
+    assert s1['path'] == 2 and s1['xuniform_mask'] == 31 and s2['xuniform_mask'] == 0 and s3['path'] == 1
+    assert np.array_equal(S1, S2) and np.array_equal(S1, S3)
+    Sm, fm, _ = util.run_hip_dev([qs[3]], 11, 0.0)
+    assert np.array_equal(Sm[0], S1[3]) and fm[0][2] == f1[3][2]
+    assert np.abs(S1).max() > 0 and np.isfinite(S1).all()
+
+
+def test_full_size_c5_omega_volume():
+    """BASELINE configs[4] volume size (50 x 360 x 720, topography mask): the fused 3-D kernel
+    (x-uniform coefficients) == the same kernel with every array streamed == the colour path."""
+    from xinvert_amd import synthetic
+    p = synthetic.omega_latlon(50, 360, 720, 1)
+    q = synthetic.member(p, 0)
+    S1, f1, s1 = util.run_hip_dev([q], 5, 0.0)
+    S2, f2, s2 = util.run_hip_dev([q], 5, 0.0, no_xuniform=1)
+    S3, f3, s3 = util.run_hip_dev([q], 5, 0.0, path=1)
+    assert s1['path'] == 2 and s1['xuniform_mask'] == 7 and s2['xuniform_mask'] == 0 and s3['path'] == 1
+    assert np.array_equal(S1, S2) and np.array_equal(S1, S3)
+    below = q['coefs'][3] == U
+    assert below.mean() > 0.01 and (S1[0][below] == q['S0'][below]).all()
 
 
 def test_abs_norm_dev():
