@@ -74,9 +74,28 @@ def cpu_baseline(p, budget_s):
     t2 = run(2)
     n = int(max(4, min(400, budget_s / max(t2 / 2, 1e-6))))
     t = run(n)
-    return {'value': npts * n / t, 'unit': 'point-sweeps/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d lexicographic sweeps of the full %dx%d slice (%.1f s), oracle/xinv_oracle.c '
-                      'gcc -O3 -ffp-contract=off' % (n, q['yc'], q['xc'], t)}
+    out = {'value': npts * n / t, 'unit': 'point-sweeps/s', 'cores': 1, 'kind': 'port',
+           'sample': '%d lexicographic sweeps of the full %dx%d slice (%.1f s), oracle/xinv_oracle.c '
+                     'gcc -O3 -ffp-contract=off' % (n, q['yc'], q['xc'], t)}
+    # the most generous reading of the reference: every host core sweeping its
+    # own slice of a batch at once (coefficients shared, one S per thread; ctypes drops the GIL)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        nthr = max(1, min(os.cpu_count() or 1, 256))
+        if nthr > 1:
+            with ThreadPoolExecutor(nthr) as ex:
+                t0 = time.perf_counter()
+                list(ex.map(lambda _: run(2), range(nthr)))          # probe: memory-bound, far from linear
+                tp = time.perf_counter() - t0
+                nsw = int(max(2, min(n, 2 * 10.0 / max(tp, 1e-6))))  # ~10 s of wall time
+                t0 = time.perf_counter()
+                list(ex.map(lambda _: run(nsw), range(nthr)))
+                ta = time.perf_counter() - t0
+            out['all_cores'] = {'value': npts * nsw * nthr / ta, 'unit': 'point-sweeps/s', 'cores': nthr,
+                                'sample': '%d threads x %d sweeps, one slice each (%.1f s)' % (nthr, nsw, ta)}
+    except Exception as e:                                   # the 1-core figure stands on its own
+        out['all_cores'] = {'error': str(e)}
+    return out
 
 
 def main():
