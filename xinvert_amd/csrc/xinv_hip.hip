@@ -35,698 +35,8 @@
 #define XINV_VERSION 100
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
 
-// ------------------------------------------------------------------ errors / thread state
-static thread_local std::string t_err;
-static thread_local xinv_stats t_stats;
-
-#define HIPCHK(call)                                                                   \
-    do {                                                                               \
-        hipError_t e_ = (call);                                                        \
-        if (e_ != hipSuccess) {                                                        \
-            char b_[512];                                                              \
-            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
-                     __FILE__, __LINE__);                                              \
-            t_err = b_;                                                                \
-            return (e_ == hipErrorOutOfMemory) ? XINV_ERR_NOMEM : XINV_ERR_HIP;        \
-        }                                                                              \
-    } while (0)
-
-static int fail_arg(const char *msg) { t_err = msg; return XINV_ERR_ARG; }
-
-// ------------------------------------------------------------------ per-device workspace
-// Grown on demand, reused across solves (no hipMalloc in steady state).
-struct Workspace {
-    int device = -1;
-    std::recursive_mutex busy;                          // one solve at a time per device
-    double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
-    XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
-    void *partials = nullptr; size_t partials_cap = 0;  // psum + pcnt
-    int *dflag = nullptr;
-    int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
-    XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
-    int *hflag = nullptr;
-    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
-    // masked-tile skipping
-    unsigned char *d_act = nullptr; size_t d_act_cap = 0;
-    unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
-    int *d_list = nullptr; size_t d_list_cap = 0;               // [nbatch][ntl] then [nbatch][nskip]
-    int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
-    double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
-};
-
-static std::mutex g_ws_mutex;
-static std::vector<Workspace *> g_ws;
-
-static Workspace *get_ws(int device)
-{
-    std::lock_guard<std::mutex> lk(g_ws_mutex);
-    for (auto *w : g_ws) if (w->device == device) return w;
-    Workspace *w = new Workspace();
-    w->device = device;
-    g_ws.push_back(w);
-    return w;
-}
-
-template <class T>
-static int ensure_dev(T **p, size_t *cap, size_t need_bytes)
-{
-    if (*cap >= need_bytes && *p) return XINV_OK;
-    if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
-    HIPCHK(hipMalloc((void **)p, need_bytes));
-    *cap = need_bytes;
-    return XINV_OK;
-}
-
-// ------------------------------------------------------------------ problem description
-enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3, KIND_STD2DT = 4, KIND_GEN3D = 5 };
-static inline bool is3d(int kind) { return kind == KIND_STD3D || kind == KIND_GEN3D; }
-
-struct Problem {
-    int kind;
-    int64_t nbatch, zc, yc, xc;
-    double *S;
-    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J ; std2dt: A..F ; gen3d: A..H
-    int64_t sS, sc[10];
-    int ncoef;
-    unsigned rowconst;           // host entries: arrays given as one value per row (see xinv.h)
-    int BCz, BCy, BCx;
-    XinvScal sc_;
-    XinvStop stop;
-};
-
-static int bc_ok(int b) { return b == XINV_BC_FIXED || b == XINV_BC_EXTEND || b == XINV_BC_PERIODIC; }
-
-static int validate(const Problem &p, const double *flags)
-{
-    if (!p.S || !flags) return fail_arg("null S or flags");
-    for (int q = 0; q < p.ncoef; q++)
-        if (!p.c[q] && !(q == 1 && (p.kind == KIND_STD2D || p.kind == KIND_GEN2D)))   // B may be NULL: identically 0
-            return fail_arg("null coefficient array");
-    if (p.nbatch < 1) return fail_arg("nbatch < 1");
-    if (p.yc < 3 || p.xc < 3 || (is3d(p.kind) && p.zc < 3))
-        return fail_arg("every core dimension needs at least 3 points");
-    if (!bc_ok(p.BCy) || !bc_ok(p.BCx) || (is3d(p.kind) && !bc_ok(p.BCz)))
-        return fail_arg("unknown boundary-condition code");
-    if (p.kind == KIND_BIH2D && (p.yc < 5 || p.xc < 7))
-        return fail_arg("the biharmonic form needs yc >= 5 and xc >= 7");
-    if (p.stop.mxLoop < 0) return fail_arg("mxLoop < 0");
-    const int64_t n = p.zc * p.yc * p.xc;
-    if (p.nbatch > 1 && p.sS < n) return fail_arg("S batch stride smaller than one slice");
-    for (int q = 0; q < p.ncoef; q++) {
-        const int64_t need = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
-        if (p.c[q] && p.sc[q] != 0 && p.sc[q] < need)
-            return fail_arg("coefficient batch stride must be 0 (shared) or >= slice size");
-    }
-    return XINV_OK;
-}
-
-static void fill_options(xinv_options &o, const xinv_options *in)
-{
-    xinv_default_options(&o);
-    if (in) o = *in;
-}
-
-// ------------------------------------------------------------------ launch helpers
-static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
-
-struct Plan {
-    int path, base, seam, ncol;
-    int K, RY, nsg, nrb;     // nsg: 2-D = workgroups per member (partials sizing); 3-D = x strips
-    bool aligned;
-    unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
-    unsigned um;             // the kernel variant's mask (subset of umask)
-    bool even_split;         // rows split evenly over nrb row blocks (RY = average height)
-    bool nine;               // 9-point form on the fused 4-colour kernel
-    bool skip;               // masked-tile skipping: launches of K == Plan::K run the listed tiles only
-    int ntl, nskip;          // list entries per member (active, multiple of 4 / skipped)
-    int skip_pct;            // share of wave-tiles skipped, percent
-};
-
-// kernel variants instantiated per model: mask of streams read as one scalar per row
-static unsigned pick_um(int kind, unsigned umask)
-{
-    if (kind == KIND_STD2D) return ((umask & 3u) == 3u) ? 3u : 0u;            // A, C
-    if (kind == KIND_STD2DT) return ((umask & 7u) == 7u) ? 7u : 0u;           // A, D, E
-    if ((umask & 0x1fu) == 0x1fu) return 0x1fu;                                // A, C, D, E, F
-    if ((umask & 0x1cu) == 0x1cu) return 0x1cu;                                // D, E, F
-    return 0u;
-}
-
-// Launch one instantiation -- or, when `occ` is given, only report how many of its workgroups
-// fit on a CU (register-limited: 1 to 3), which the tiling heuristic needs.
-template <class M, int K, bool AL, unsigned UM, bool EXT>
-static int fused_one(dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a, int *occ)
-{
-    if (occ) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused2d<M, K, AL, UM, EXT>, 256, 0) != hipSuccess)
-            n = 1;
-        *occ = n < 1 ? 1 : n;
-        return 0;
-    }
-    hipLaunchKernelGGL((k_fused2d<M, K, AL, UM, EXT>), grid, block, 0, st, a);
-    return 0;
-}
-
-template <class M, bool AL, unsigned UM, bool EXT>
-static int launch_fused_k(int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a, int *occ)
-{
-    switch (K) {
-    case 1: return fused_one<M, 1, AL, UM, EXT>(grid, block, st, a, occ);
-    case 2: return fused_one<M, 2, AL, UM, EXT>(grid, block, st, a, occ);
-    default: break;
-    }
-    return 1;
-}
-
-template <class M, bool AL, bool EXT>
-static int launch_fused_um(unsigned um, int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a,
-                           int *occ)
-{
-    if constexpr (std::is_same<M, FusedStd2D>::value) {
-        if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a, occ);
-    } else if constexpr (std::is_same<M, FusedStd2DT>::value) {
-        if (um == 7u) return launch_fused_k<M, AL, 7u, EXT>(K, grid, block, st, a, occ);
-    } else {
-        if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a, occ);
-        if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a, occ);
-    }
-    return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a, occ);
-}
-
-template <class M>
-static int launch_fused_m(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
-                          const FusedArgs &a, int *occ)
-{
-    if (al) return ext ? launch_fused_um<M, true, true>(um, K, grid, block, st, a, occ)
-                       : launch_fused_um<M, true, false>(um, K, grid, block, st, a, occ);
-    return ext ? launch_fused_um<M, false, true>(um, K, grid, block, st, a, occ)
-               : launch_fused_um<M, false, false>(um, K, grid, block, st, a, occ);
-}
-
-static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
-                          hipStream_t st, const FusedArgs &a, int *occ)
-{
-    if (kind == KIND_GEN2D) return launch_fused_m<FusedGen2D>(al, ext, um, K, grid, block, st, a, occ);
-    if (kind == KIND_STD2DT) return launch_fused_m<FusedStd2DT>(al, ext, um, K, grid, block, st, a, occ);
-    return launch_fused_m<FusedStd2D>(al, ext, um, K, grid, block, st, a, occ);
-}
-
-static bool ptr_al16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
-
-static int launch_fused(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
-                        Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
-                        int no_ctl)
-{
-    FusedArgs a;
-    memset(&a, 0, sizeof a);
-    a.src = src; a.dst = dst;
-    a.sS = p.sS;
-    if (p.kind == KIND_STD2D) {
-        a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
-        a.c[1] = p.c[2]; a.sc[1] = p.sc[2];      // C
-        a.c[2] = p.c[3]; a.sc[2] = p.sc[3];      // F
-    } else if (p.kind == KIND_STD2DT) {
-        a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
-        for (int q = 3; q < 6; q++) { a.c[q - 2] = p.c[q]; a.sc[q - 2] = p.sc[q]; }   // D, E, F
-    } else {
-        a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
-        for (int q = 2; q < 7; q++) { a.c[q - 1] = p.c[q]; a.sc[q - 1] = p.sc[q]; }   // C..G
-    }
-    a.yc = p.yc; a.xc = p.xc;
-    a.per = (p.BCx == XINV_BC_PERIODIC);
-    a.ext = (p.BCy == XINV_BC_EXTEND);
-    a.tall = (p.yc > p.xc);
-    a.RY = pl.even_split ? 0 : pl.RY;
-    const int UW = 128 - 4 * K;
-    a.nstrip = (int)cdiv(p.xc, UW);
-    a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
-    a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
-    a.force = force; a.no_ctl = no_ctl;
-    a.member0 = member0;
-    a.sc_ = p.sc_;
-    a.ctl = ws->ctl;
-    a.stop = p.stop;
-    const size_t NBmax = (size_t)pl.nsg;             // workgroups per member, narrowest strips (K = XINV_KMAX)
-    a.psum = (unsigned long long *)ws->partials;
-    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
-    if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
-        a.tile_list = ws->d_list;
-        a.ntl = pl.ntl;
-        a.nwg = pl.ntl / 4;
-        char *base = (char *)ws->d_tsum;
-        const size_t nt = (size_t)p.nbatch * pl.nskip;
-        a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
-        a.xcnt = (const long long *)(base + nt * (sizeof(double) + sizeof(long long)) + p.nbatch * sizeof(double));
-    }
-    for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {      // grid.y is limited to 65535
-        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
-        a.member0 = member0 + m0;
-        dim3 grid((unsigned)a.nwg, (unsigned)nm, 1), block(256, 1, 1);
-        if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
-            return fail_arg("unsupported sweeps_per_launch for this kernel variant");
-    }
-    HIPCHK(hipGetLastError());
-    return XINV_OK;
-}
-
-// ---- 9-point fused launch ---------------------------------------------------------------------
-template <class M, int K>
-static void launch_fused9_k(bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ)
-{
-    dim3 block(256, 1, 1);
-#define L9(AL, EXT)                                                                              \
-    do {                                                                                         \
-        if (occ) {                                                                               \
-            int n = 0;                                                                           \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused9<M, K, AL, EXT>, 256, 0) != hipSuccess) n = 1; \
-            *occ = n < 1 ? 1 : n;                                                                \
-        } else hipLaunchKernelGGL((k_fused9<M, K, AL, EXT>), grid, block, 0, st, a);             \
-    } while (0)
-    if (al) { if (ext) L9(true, true); else L9(true, false); }
-    else    { if (ext) L9(false, true); else L9(false, false); }
-#undef L9
-}
-
-static int fused9_dispatch(int kind, int K, bool al, bool ext, dim3 grid, hipStream_t st,
-                           const FusedArgs &a, int *occ)
-{
-    if (kind == KIND_GEN2D) {
-        if (K == 1) launch_fused9_k<Fused9Gen, 1>(al, ext, grid, st, a, occ); else return 1;
-    } else {
-        if (K == 1) launch_fused9_k<Fused9Std, 1>(al, ext, grid, st, a, occ);
-        else if (K == 2) launch_fused9_k<Fused9Std, 2>(al, ext, grid, st, a, occ);
-        else return 1;
-    }
-    return 0;
-}
-
-static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
-                         Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
-                         int no_ctl)
-{
-    FusedArgs a;
-    memset(&a, 0, sizeof a);
-    a.src = src; a.dst = dst; a.sS = p.sS;
-    const int nc = (p.kind == KIND_GEN2D) ? 7 : 4;
-    for (int q = 0; q < nc; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
-    a.yc = p.yc; a.xc = p.xc;
-    a.per = (p.BCx == XINV_BC_PERIODIC);
-    a.ext = (p.BCy == XINV_BC_EXTEND);
-    a.tall = (p.yc > p.xc);
-    a.RY = pl.even_split ? 0 : pl.RY;
-    a.nstrip = (int)cdiv(p.xc, 128 - 8 * K);
-    a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
-    a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
-    a.force = force; a.no_ctl = no_ctl;
-    a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
-    const size_t NBmax = (size_t)pl.nsg;
-    a.psum = (unsigned long long *)ws->partials;
-    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
-    for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
-        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
-        a.member0 = member0 + m0;
-        dim3 grid((unsigned)a.nwg, (unsigned)nm, 1);
-        if (fused9_dispatch(p.kind, K, pl.aligned, a.ext != 0, grid, st, a, nullptr))
-            return fail_arg("unsupported sweeps_per_launch for the 9-point kernel");
-    }
-    HIPCHK(hipGetLastError());
-    return XINV_OK;
-}
-
-// ---- 3-D fused launch ------------------------------------------------------------------------
-template <int NW>
-static int launch_fused3d_nw(bool al, bool uni, bool ext, dim3 grid, hipStream_t st, const Fused3Args &a)
-{
-    dim3 block(NW * 64, 1, 1);
-#define L3(AL, UNI, EXT) hipLaunchKernelGGL((k_fused3d<NW, AL, UNI, EXT>), grid, block, 0, st, a)
-    if (al) {
-        if (uni) { if (ext) L3(true, true, true); else L3(true, true, false); }
-        else     { if (ext) L3(true, false, true); else L3(true, false, false); }
-    } else {
-        if (uni) { if (ext) L3(false, true, true); else L3(false, true, false); }
-        else     { if (ext) L3(false, false, true); else L3(false, false, false); }
-    }
-#undef L3
-    return 0;
-}
-
-static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, double *dst,
-                          Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
-                          int no_ctl)
-{
-    Fused3Args a;
-    memset(&a, 0, sizeof a);
-    a.src = src; a.dst = dst; a.sS = p.sS;
-    for (int q = 0; q < 4; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
-    a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
-    a.per = (p.BCx == XINV_BC_PERIODIC);
-    a.nstrip = pl.nsg; a.njb = pl.nrb;
-    a.force = force; a.no_ctl = no_ctl; a.member0 = member0;
-    a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
-    const size_t NB = (size_t)pl.nsg * pl.nrb;
-    a.psum = (unsigned long long *)ws->partials;
-    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * NB * sizeof(double));
-    const bool ext = (p.BCy == XINV_BC_EXTEND), uni = (pl.um == 7u);
-    for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
-        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
-        a.member0 = member0 + m0;
-        dim3 grid((unsigned)NB, (unsigned)nm, 1);
-        if (pl.RY == 8) launch_fused3d_nw<8>(pl.aligned, uni, ext, grid, st, a);
-        else if (pl.RY == 12) launch_fused3d_nw<12>(pl.aligned, uni, ext, grid, st, a);
-        else launch_fused3d_nw<16>(pl.aligned, uni, ext, grid, st, a);
-    }
-    HIPCHK(hipGetLastError());
-    return XINV_OK;
-}
-
-// one full coloured sweep (+ norm + stop rule) in place on p.S
-static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st,
-                               int64_t m0, int64_t nm)
-{
-    const int per = (p.BCx == XINV_BC_PERIODIC);
-    if (p.kind == KIND_BIH2D) {
-        if (p.BCy == XINV_BC_EXTEND) {
-            ExtendArgs e;
-            e.S = p.S; e.sS = p.sS; e.yc = p.yc; e.xc = p.xc; e.kfirst = 0; e.nk = 1;
-            e.per = per; e.tall = (p.yc > p.xc); e.force = 0;
-            e.undef = p.sc_.undef; e.ctl = ws->ctl; e.member0 = m0;
-            hipLaunchKernelGGL(k_extend_bih, dim3(cdiv(p.xc, 256), 1, (unsigned)nm), dim3(256, 1, 1), 0, st, e);
-        }
-        ColourArgsBih a;
-        memset(&a, 0, sizeof a);
-        a.S = p.S; a.sS = p.sS;
-        for (int q = 0; q < 10; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
-        a.yc = p.yc; a.xc = p.xc; a.per = per; a.trail = pl.seam; a.force = 0; a.member0 = m0;
-        a.sc_ = p.sc_; a.ctl = ws->ctl; a.umask = pl.umask;
-        dim3 b(64, 4, 1);
-        dim3 g(cdiv(cdiv(p.xc, 3) + 1, 64), cdiv(cdiv(p.yc, 3) + 1, 4), (unsigned)nm);
-        if (!per) {
-            // non-periodic x: one launch per row class does its three column colours in registers
-            dim3 gb(cdiv(cdiv(p.xc, 180), 4), cdiv(p.yc, 3) + 1, (unsigned)nm), bb(256, 1, 1);
-            for (int cj = 0; cj < 3; cj++) {
-                a.colour = cj;
-                if (pl.umask) hipLaunchKernelGGL(k_bih_rowclass<true>, gb, bb, 0, st, a);
-                else          hipLaunchKernelGGL(k_bih_rowclass<false>, gb, bb, 0, st, a);
-            }
-        } else
-        for (int cc = 0; cc < pl.ncol; cc++) {
-            a.colour = cc;
-            if (pl.umask) hipLaunchKernelGGL(k_colour_bih2d<true>, g, b, 0, st, a);
-            else          hipLaunchKernelGGL(k_colour_bih2d<false>, g, b, 0, st, a);
-        }
-    } else if (p.BCy == XINV_BC_EXTEND) {
-        ExtendArgs e;
-        e.S = p.S; e.sS = p.sS; e.yc = p.yc; e.xc = p.xc;
-        e.kfirst = is3d(p.kind) ? 1 : 0;
-        e.nk = is3d(p.kind) ? p.zc - 2 : 1;
-        // the standard 3-D kernel's second loop stays inside the row (numbas.py:104-108)
-        e.per = per; e.tall = (p.kind != KIND_STD3D) && (p.yc > p.xc); e.force = 0;
-        e.undef = p.sc_.undef; e.ctl = ws->ctl; e.member0 = m0;
-        dim3 g(cdiv(p.xc, 256), (unsigned)e.nk, (unsigned)nm), b(256, 1, 1);
-        hipLaunchKernelGGL(k_extend, g, b, 0, st, e);
-    }
-    if (p.kind == KIND_BIH2D) {
-        // sweeps launched above
-    } else if (is3d(p.kind)) {
-        ColourArgs3D a;
-        memset(&a, 0, sizeof a);
-        a.S = p.S; a.sS = p.sS;
-        for (int q = 0; q < p.ncoef; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
-        a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
-        a.per = per; a.seam = pl.seam; a.force = 0; a.sc_ = p.sc_; a.ctl = ws->ctl;
-        a.nbatch = p.nbatch; a.member0 = m0;
-        dim3 b(64, 4, 1);
-        dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)(nm * (p.zc - 2)));
-        for (int cc = 0; cc < pl.ncol; cc++) {
-            a.colour = cc;
-            if (p.kind == KIND_GEN3D) hipLaunchKernelGGL(k_colour_gen3d, g, b, 0, st, a);
-            else                      hipLaunchKernelGGL(k_colour_std3d, g, b, 0, st, a);
-        }
-    } else {
-        ColourArgs2D a;
-        memset(&a, 0, sizeof a);
-        a.S = p.S; a.sS = p.sS;
-        for (int q = 0; q < p.ncoef; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
-        a.yc = p.yc; a.xc = p.xc;
-        a.per = per; a.base = pl.base; a.seam = pl.seam; a.force = 0;
-        a.sc_ = p.sc_; a.ctl = ws->ctl; a.member0 = m0;
-        dim3 b(64, 4, 1);
-        dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)nm);
-        const bool nine = (pl.base == 4);
-        for (int cc = 0; cc < pl.ncol; cc++) {
-            a.colour = cc;
-            if (p.kind == KIND_STD2D) {
-                if (nine) hipLaunchKernelGGL(k_colour_std2d<true>, g, b, 0, st, a);
-                else      hipLaunchKernelGGL(k_colour_std2d<false>, g, b, 0, st, a);
-            } else if (p.kind == KIND_STD2DT) {
-                if (nine) hipLaunchKernelGGL(k_colour_std2dt<true>, g, b, 0, st, a);
-                else      hipLaunchKernelGGL(k_colour_std2dt<false>, g, b, 0, st, a);
-            } else {
-                if (nine) hipLaunchKernelGGL(k_colour_gen2d<true>, g, b, 0, st, a);
-                else      hipLaunchKernelGGL(k_colour_gen2d<false>, g, b, 0, st, a);
-            }
-        }
-    }
-    NormArgs n;
-    n.S = p.S; n.sS = p.sS; n.n = p.zc * p.yc * p.xc; n.undef = p.sc_.undef;
-    n.psum = (double *)ws->partials;
-    n.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_NORM_BLOCKS * sizeof(double));
-    n.ctl = ws->ctl; n.stop = p.stop; n.force = 0; n.member0 = m0;
-    int nblk = (int)std::min<int64_t>(XINV_NORM_BLOCKS, std::max<int64_t>(1, n.n / 2048));
-    hipLaunchKernelGGL(k_norm_partial, dim3(nblk, (unsigned)nm, 1), dim3(256, 1, 1), 0, st, n);
-    hipLaunchKernelGGL(k_norm_final, dim3((unsigned)nm, 1, 1), dim3(64, 1, 1), 0, st, n, nblk);
-    HIPCHK(hipGetLastError());
-    return XINV_OK;
-}
-
-static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st)
-{
-    // grid.z carries members (x planes in 3-D) and is limited to 65535
-    int64_t chunk = XINV_MEMBER_CHUNK;
-    if (is3d(p.kind)) chunk = std::max<int64_t>(1, 65535 / std::max<int64_t>(1, p.zc - 2));
-    for (int64_t m0 = 0; m0 < p.nbatch; m0 += chunk) {
-        int rc = launch_colour_chunk(p, pl, ws, st, m0, std::min<int64_t>(chunk, p.nbatch - m0));
-        if (rc) return rc;
-    }
-    return XINV_OK;
-}
-
-// Number of row blocks for the fused 2-D kernels.  Tall tiles amortise the 4K recomputed halo
-// rows, but every CU should hold the same number of workgroups: `occ` of the chosen variant fit
-// per CU (register-limited, queried from the runtime).  Minimise (workgroups per CU, in rounds of
-// 256*occ resident ones) x (steps per tile); rows are then split evenly over the blocks.
-static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int K, int occ)
-{
-    occ = std::max(1, std::min(occ, 3));
-    const int64_t cap = 256 * (int64_t)occ, period = 2 * K + 2;
-    int64_t best = 1; double best_cost = 1e300;
-    const int64_t nmin = std::max<int64_t>(1, cdiv(yc, 128)), nmax = std::max<int64_t>(nmin, yc / 4);
-    for (int64_t nr = nmin; nr <= nmax; nr++) {
-        const int64_t rows = cdiv(yc, nr) + 1;                     // +1: even rounding
-        const int64_t steps = cdiv(rows + 4 * K, period) * period;
-        const int64_t wgs = (int64_t)cdiv(nstrip * nr, 4) * nbatch;
-        // rounds of `cap` resident workgroups; inside a round a CU holds ceil(w/256) of them,
-        // and a lone workgroup on a CU leaves issue slots idle (charged like 1.6)
-        const int64_t rounds = cdiv(wgs, cap);
-        const int64_t w_last = wgs - (rounds - 1) * cap;
-        const double full = (occ == 1) ? 1.6 : (double)occ;
-        const double last = (w_last <= 256) ? 1.6 : (double)cdiv(w_last, 256);
-        const double cost = ((double)(rounds - 1) * full + last) * (double)steps;
-        if (cost <= best_cost * 1.0001) { best_cost = std::min(cost, best_cost); best = nr; }   // ties: more, shorter tiles
-    }
-    return best;
-}
-
-// Cost of a fused 2-D launch in (workgroups per CU) x (steps per tile) units -- the model behind
-// choose_row_blocks, shared with the masked-tile planner.
-static double tile_cost(int64_t wgs, int64_t rows, int K, int occ)
-{
-    occ = std::max(1, std::min(occ, 3));
-    const int64_t cap = 256 * (int64_t)occ, period = 2 * K + 2;
-    const int64_t steps = cdiv(rows + 1 + 4 * K, period) * period;
-    const int64_t rounds = std::max<int64_t>(1, cdiv(wgs, cap));
-    const int64_t w_last = wgs - (rounds - 1) * cap;
-    const double full = (occ == 1) ? 1.6 : (double)occ;
-    const double last = (w_last <= 256) ? 1.6 : (double)cdiv(w_last, 256);
-    return ((double)(rounds - 1) * full + last) * (double)steps;
-}
-
-static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
-                          hipStream_t st, const FusedArgs &a, int *occ);
-
-// Masked-tile skipping for the 5-point fused kernels.  Wave-tiles whose forcing is undefined at
-// every owned point (land, topography, polar caps) can never change (every mask predicate of the
-// reference tests the forcing), so launches run the other tiles only; the row split is re-chosen
-// so that the ACTIVE tiles fill the CUs evenly, and the skipped tiles' constant share of the norm
-// is computed once.  Decided per solve from one pass over the forcing.
-static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t st,
-                          const xinv_options &opt)
-{
-    pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0;
-    const bool forced = (opt.flags & XINV_FLAG_FORCE_TILE_SKIP) != 0;
-    const int K = pl.K, UW = 128 - 4 * K;
-    const int nstrip = (int)cdiv(p.xc, UW);
-    if (!forced && ((int64_t)nstrip * pl.nrb * p.nbatch < 1024 || (int64_t)nstrip * pl.nrb < 64 || p.nbatch > 64))
-        return XINV_OK;                                   // small problems: nothing to balance
-    const int64_t yc = p.yc, nb = p.nbatch;
-    const int64_t cells = yc * nstrip;
-    const int fi = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_GEN2D ? 6 : 5);     // the forcing
-
-    int rc = ensure_dev(&ws->d_act, &ws->d_act_cap, (size_t)(nb * cells));
-    if (rc) return rc;
-    if (ws->h_act_cap < (size_t)(nb * cells)) {
-        if (ws->h_act) HIPCHK(hipHostFree(ws->h_act));
-        HIPCHK(hipHostMalloc((void **)&ws->h_act, (size_t)(nb * cells), hipHostMallocDefault));
-        ws->h_act_cap = (size_t)(nb * cells);
-    }
-    StripActArgs sa;
-    sa.f = p.c[fi]; sa.sf = p.sc[fi]; sa.yc = yc; sa.xc = p.xc; sa.nstrip = nstrip; sa.UW = UW;
-    sa.undef = p.sc_.undef; sa.act = ws->d_act;
-    hipLaunchKernelGGL(k_strip_active, dim3(cdiv(cells, 4), (unsigned)nb, 1), dim3(256), 0, st, sa);
-    HIPCHK(hipMemcpyAsync(ws->h_act, ws->d_act, (size_t)(nb * cells), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-
-    // prefix counts of active rows per (member, strip)
-    std::vector<int> pre((size_t)(nb * nstrip * (yc + 1)));
-    int64_t nact = 0;
-    for (int64_t m = 0; m < nb; m++)
-        for (int s = 0; s < nstrip; s++) {
-            int *q = &pre[(size_t)((m * nstrip + s) * (yc + 1))];
-            q[0] = 0;
-            for (int64_t r = 0; r < yc; r++) q[r + 1] = q[r] + ws->h_act[(m * yc + r) * nstrip + s];
-            nact += q[yc];
-        }
-    if (!forced && (double)nact > 0.92 * (double)(nb * cells)) return XINV_OK;     // little to skip
-
-    const bool ext = (p.BCy == XINV_BC_EXTEND);
-    auto bounds = [&](int nrb, int rb, int64_t &y0, int64_t &y1) {
-        y0 = (((int64_t)rb * yc) / nrb) & ~(int64_t)1;
-        y1 = (rb + 1 == nrb) ? yc : ((((int64_t)(rb + 1) * yc) / nrb) & ~(int64_t)1);
-    };
-    auto tile_active = [&](int64_t m, int nrb, int rb, int s) {
-        if (ext && (rb == 0 || rb == nrb - 1)) return true;    // the boundary rows get their copy
-        int64_t y0, y1; bounds(nrb, rb, y0, y1);
-        const int *q = &pre[(size_t)((m * nstrip + s) * (yc + 1))];
-        return q[y1] - q[y0] > 0;
-    };
-    auto active_wgs = [&](int nrb, int64_t *maxact) {
-        int64_t wgs = 0, mx = 0;
-        for (int64_t m = 0; m < nb; m++) {
-            int64_t c = 0;
-            for (int rb = 0; rb < nrb; rb++) {
-                if (ext && (rb == 0 || rb == nrb - 1)) { c += nstrip; continue; }
-                int64_t y0, y1; bounds(nrb, rb, y0, y1);
-                const int *q = &pre[(size_t)(m * nstrip * (yc + 1))];
-                for (int s = 0; s < nstrip; s++, q += yc + 1) c += (q[y1] - q[y0] > 0) ? 1 : 0;
-            }
-            wgs += cdiv(c, 4); mx = std::max(mx, c);
-        }
-        if (maxact) *maxact = mx;
-        return wgs;
-    };
-    int occ = 2;
-    {
-        FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-        fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
-    }
-    const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb, cdiv(yc, pl.nrb), K, occ);
-    // candidates: the row split that brings the ACTIVE workgroups back to the default count sits
-    // near nrb / (active share); search a window around it
-    int best = pl.nrb; double best_cost = 1e300;
-    int lo = pl.nrb, hi = pl.nrb;
-    if (!forced && opt.rows_per_tile == 0) {
-        const int64_t w0 = active_wgs(pl.nrb, nullptr);
-        const double share = std::max(0.05, (double)w0 / (double)((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb));
-        const double centre = (double)pl.nrb / share;
-        const int64_t cap_rows = std::max<int64_t>(pl.nrb, yc / 4);
-        lo = (int)std::min<int64_t>(cap_rows, std::max<int64_t>(pl.nrb, (int64_t)(centre * 0.85)));
-        hi = (int)std::min<int64_t>(cap_rows, std::max<int64_t>(lo, (int64_t)(centre * 1.10) + 1));
-    }
-    best_cost = tile_cost(active_wgs(pl.nrb, nullptr), cdiv(yc, pl.nrb), K, occ);   // keep the split, skip only
-    for (int nrb = lo; nrb <= hi; nrb++) {
-        const double c = tile_cost(active_wgs(nrb, nullptr), cdiv(yc, nrb), K, occ);
-        if (c < best_cost) { best_cost = c; best = nrb; }
-    }
-    if (!forced && best_cost > 0.95 * cost0) return XINV_OK;
-
-    // lists for the chosen split
-    int64_t maxact = 0;
-    active_wgs(best, &maxact);
-    const int64_t ntiles = (int64_t)nstrip * best;
-    const int ntl = (int)(4 * std::max<int64_t>(1, cdiv(maxact, 4)));
-    int64_t maxskip = 0, nskipped = 0;
-    std::vector<std::vector<int>> act((size_t)nb), skp((size_t)nb);
-    for (int64_t m = 0; m < nb; m++) {
-        for (int rb = 0; rb < best; rb++)
-            for (int s = 0; s < nstrip; s++)
-                (tile_active(m, best, rb, s) ? act[(size_t)m] : skp[(size_t)m]).push_back(rb * nstrip + s);
-        maxskip = std::max<int64_t>(maxskip, (int64_t)skp[(size_t)m].size());
-        nskipped += (int64_t)skp[(size_t)m].size();
-    }
-    if (nskipped == 0) return XINV_OK;
-    const int nskip = (int)maxskip;
-    const size_t nints = (size_t)nb * ((size_t)ntl + nskip);
-    rc = ensure_dev(&ws->d_list, &ws->d_list_cap, nints * sizeof(int));
-    if (rc) return rc;
-    if (ws->h_list_cap < nints * sizeof(int)) {
-        if (ws->h_list) HIPCHK(hipHostFree(ws->h_list));
-        HIPCHK(hipHostMalloc((void **)&ws->h_list, nints * sizeof(int), hipHostMallocDefault));
-        ws->h_list_cap = nints * sizeof(int);
-    }
-    int *hl = ws->h_list, *hs = ws->h_list + (size_t)nb * ntl;
-    for (int64_t m = 0; m < nb; m++) {
-        for (int t = 0; t < ntl; t++) hl[m * ntl + t] = t < (int)act[(size_t)m].size() ? act[(size_t)m][t] : -1;
-        for (int t = 0; t < nskip; t++) hs[m * nskip + t] = t < (int)skp[(size_t)m].size() ? skp[(size_t)m][t] : -1;
-    }
-    HIPCHK(hipMemcpyAsync(ws->d_list, ws->h_list, nints * sizeof(int), hipMemcpyHostToDevice, st));
-    const size_t nt = (size_t)nb * nskip;
-    rc = ensure_dev(&ws->d_tsum, &ws->d_tsum_cap,
-                    (nt + (size_t)nb) * (sizeof(double) + sizeof(long long)));
-    if (rc) return rc;
-    SkipNormArgs na;
-    na.S = p.S; na.sS = p.sS; na.yc = yc; na.xc = p.xc; na.nstrip = nstrip; na.nrb = best; na.UW = UW;
-    na.undef = p.sc_.undef; na.skip_list = ws->d_list + (size_t)nb * ntl; na.nskip_max = nskip;
-    char *base = (char *)ws->d_tsum;
-    na.tsum = (double *)base;
-    na.tcnt = (long long *)(base + nt * sizeof(double));
-    na.xsum = (double *)(base + nt * (sizeof(double) + sizeof(long long)));
-    na.xcnt = (long long *)(base + nt * (sizeof(double) + sizeof(long long)) + (size_t)nb * sizeof(double));
-    hipLaunchKernelGGL(k_skip_norm_tile, dim3((unsigned)nskip, (unsigned)nb, 1), dim3(64), 0, st, na);
-    hipLaunchKernelGGL(k_skip_norm_sum, dim3((unsigned)nb, 1, 1), dim3(64), 0, st, na);
-    HIPCHK(hipGetLastError());
-
-    pl.skip = true; pl.ntl = ntl; pl.nskip = nskip;
-    pl.skip_pct = (int)((100 * nskipped) / (ntiles * nb));
-    pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
-    pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
-    return XINV_OK;
-}
-
-// Which of `nstream` arrays have rows (of xc elements, `rows` per member) that are bitwise constant
-// along x?  One pass over each array on the device; *mask gets bit q set for uniform array q.
-static int detect_xuniform(Workspace *ws, hipStream_t st, const double *const *arr,
-                           const int64_t *stride, int nstream, int64_t nbatch, int64_t rows,
-                           int64_t xc, unsigned *mask)
-{
-    XUniArgs xa;
-    memset(&xa, 0, sizeof xa);
-    xa.nstream = nstream;
-    for (int q = 0; q < nstream; q++) { xa.c[q] = arr[q]; xa.stride[q] = stride[q]; }
-    xa.nbatch = nbatch; xa.yc = rows; xa.xc = xc;
-    if (!ws->dflags16) {
-        HIPCHK(hipMalloc((void **)&ws->dflags16, 16 * sizeof(int)));
-        HIPCHK(hipHostMalloc((void **)&ws->hflags16, 16 * sizeof(int), hipHostMallocDefault));
-    }
-    xa.flag = ws->dflags16;
-    HIPCHK(hipMemsetAsync(ws->dflags16, 0, 16 * sizeof(int), st));
-    hipLaunchKernelGGL(k_xuniform, dim3(512, (unsigned)nstream, 1), dim3(256), 0, st, xa);
-    HIPCHK(hipMemcpyAsync(ws->hflags16, ws->dflags16, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    *mask = 0;
-    for (int q = 0; q < nstream; q++) if (!ws->hflags16[q]) *mask |= (1u << q);
-    return XINV_OK;
-}
+#include "xinv_host.h"
+#include "xinv_launch.h"
 
 // ------------------------------------------------------------------ the solve (device ptrs)
 static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st)
@@ -1060,90 +370,6 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     t_stats.sweep_launches = nlaunch;
     t_stats.sweeps_max = sweeps_max;
     t_stats.sweep_ms = ms_total;
-    return XINV_OK;
-}
-
-// ------------------------------------------------------------------ host-pointer staging
-// Host <-> HBM path of the *_f64 / *_batched entry points.  Device buffers come from a
-// per-device pool that is kept across calls (the coefficient stack of a repeated solve is
-// re-uploaded but never re-allocated).  Large host arrays are pinned IN PLACE for the duration
-// of the call (hipHostRegister) so the DMA engines read them directly at PCIe rate and all
-// uploads are queued asynchronously on one stream; small arrays, or hosts where registration
-// fails, take the runtime's staged copy.
-struct DevPool {
-    std::vector<std::pair<void *, size_t>> bufs;   // (ptr, capacity)
-    size_t next = 0;
-    void reset() { next = 0; }
-};
-static std::mutex g_pool_mutex;
-static std::vector<std::pair<int, DevPool *>> g_pools;
-
-static DevPool *get_pool(int device)
-{
-    std::lock_guard<std::mutex> lk(g_pool_mutex);
-    for (auto &e : g_pools) if (e.first == device) return e.second;
-    DevPool *p = new DevPool();
-    g_pools.push_back({device, p});
-    return p;
-}
-
-static int pool_alloc(DevPool *pool, size_t bytes, double **out)
-{
-    if (pool->next < pool->bufs.size()) {
-        auto &b = pool->bufs[pool->next];
-        if (b.second < bytes) {
-            HIPCHK(hipFree(b.first));
-            b.first = nullptr; b.second = 0;
-            HIPCHK(hipMalloc(&b.first, bytes));
-            b.second = bytes;
-        }
-        *out = (double *)b.first;
-        pool->next++;
-        return XINV_OK;
-    }
-    void *d = nullptr;
-    HIPCHK(hipMalloc(&d, bytes));
-    pool->bufs.push_back({d, bytes});
-    pool->next++;
-    *out = (double *)d;
-    return XINV_OK;
-}
-
-struct Pinned {                                     // host ranges registered for this call
-    std::vector<void *> regs;
-    bool try_pin(const void *h, size_t bytes)
-    {
-        if (bytes < (1u << 20)) return false;
-        if (hipHostRegister((void *)h, bytes, hipHostRegisterDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        regs.push_back((void *)h);
-        return true;
-    }
-    ~Pinned() { for (void *h : regs) (void)hipHostUnregister(h); }
-};
-
-static int upload(DevPool *pool, Pinned &pin, hipStream_t st, const double *h, int64_t nbatch,
-                  int64_t stride, int64_t n, double **out, int64_t *dstride)
-{
-    if (!h) { *out = nullptr; *dstride = 0; return XINV_OK; }
-    const int64_t members = (stride == 0) ? 1 : nbatch;
-    double *d = nullptr;
-    int rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &d);
-    if (rc) return rc;
-    if (members == 1 || stride == n) {
-        const size_t bytes = (size_t)members * n * sizeof(double);
-        pin.try_pin(h, bytes);
-        HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
-    } else {
-        pin.try_pin(h, (size_t)((members - 1) * stride + n) * sizeof(double));
-        for (int64_t m = 0; m < members; m++)
-            HIPCHK(hipMemcpyAsync(d + m * n, h + m * stride, (size_t)n * sizeof(double),
-                                  hipMemcpyHostToDevice, st));
-    }
-    *out = d;
-    *dstride = (stride == 0) ? 0 : n;
     return XINV_OK;
 }
 

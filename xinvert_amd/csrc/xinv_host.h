@@ -1,0 +1,201 @@
+// xinv_host.h -- host-side state of libxinv_hip.so: error/stat slots of the calling thread, the
+// per-device workspace, the problem description handed from the C-ABI to the solver, and the
+// staging of host arrays (pinning in place, pooled device buffers).  Included by xinv_hip.hip only.
+#pragma once
+
+// ------------------------------------------------------------------ errors / thread state
+static thread_local std::string t_err;
+static thread_local xinv_stats t_stats;
+
+#define HIPCHK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            char b_[512];                                                              \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                              \
+            t_err = b_;                                                                \
+            return (e_ == hipErrorOutOfMemory) ? XINV_ERR_NOMEM : XINV_ERR_HIP;        \
+        }                                                                              \
+    } while (0)
+
+static int fail_arg(const char *msg) { t_err = msg; return XINV_ERR_ARG; }
+
+// ------------------------------------------------------------------ per-device workspace
+// Grown on demand, reused across solves (no hipMalloc in steady state).
+struct Workspace {
+    int device = -1;
+    std::recursive_mutex busy;                          // one solve at a time per device
+    double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
+    XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
+    void *partials = nullptr; size_t partials_cap = 0;  // psum + pcnt
+    int *dflag = nullptr;
+    int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
+    XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
+    int *hflag = nullptr;
+    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
+    // masked-tile skipping
+    unsigned char *d_act = nullptr; size_t d_act_cap = 0;
+    unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
+    int *d_list = nullptr; size_t d_list_cap = 0;               // [nbatch][ntl] then [nbatch][nskip]
+    int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
+    double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
+};
+
+static std::mutex g_ws_mutex;
+static std::vector<Workspace *> g_ws;
+
+static Workspace *get_ws(int device)
+{
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    for (auto *w : g_ws) if (w->device == device) return w;
+    Workspace *w = new Workspace();
+    w->device = device;
+    g_ws.push_back(w);
+    return w;
+}
+
+template <class T>
+static int ensure_dev(T **p, size_t *cap, size_t need_bytes)
+{
+    if (*cap >= need_bytes && *p) return XINV_OK;
+    if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIPCHK(hipMalloc((void **)p, need_bytes));
+    *cap = need_bytes;
+    return XINV_OK;
+}
+
+// ------------------------------------------------------------------ problem description
+enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3, KIND_STD2DT = 4, KIND_GEN3D = 5 };
+static inline bool is3d(int kind) { return kind == KIND_STD3D || kind == KIND_GEN3D; }
+
+struct Problem {
+    int kind;
+    int64_t nbatch, zc, yc, xc;
+    double *S;
+    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J ; std2dt: A..F ; gen3d: A..H
+    int64_t sS, sc[10];
+    int ncoef;
+    unsigned rowconst;           // host entries: arrays given as one value per row (see xinv.h)
+    int BCz, BCy, BCx;
+    XinvScal sc_;
+    XinvStop stop;
+};
+
+static int bc_ok(int b) { return b == XINV_BC_FIXED || b == XINV_BC_EXTEND || b == XINV_BC_PERIODIC; }
+
+static int validate(const Problem &p, const double *flags)
+{
+    if (!p.S || !flags) return fail_arg("null S or flags");
+    for (int q = 0; q < p.ncoef; q++)
+        if (!p.c[q] && !(q == 1 && (p.kind == KIND_STD2D || p.kind == KIND_GEN2D)))   // B may be NULL: identically 0
+            return fail_arg("null coefficient array");
+    if (p.nbatch < 1) return fail_arg("nbatch < 1");
+    if (p.yc < 3 || p.xc < 3 || (is3d(p.kind) && p.zc < 3))
+        return fail_arg("every core dimension needs at least 3 points");
+    if (!bc_ok(p.BCy) || !bc_ok(p.BCx) || (is3d(p.kind) && !bc_ok(p.BCz)))
+        return fail_arg("unknown boundary-condition code");
+    if (p.kind == KIND_BIH2D && (p.yc < 5 || p.xc < 7))
+        return fail_arg("the biharmonic form needs yc >= 5 and xc >= 7");
+    if (p.stop.mxLoop < 0) return fail_arg("mxLoop < 0");
+    const int64_t n = p.zc * p.yc * p.xc;
+    if (p.nbatch > 1 && p.sS < n) return fail_arg("S batch stride smaller than one slice");
+    for (int q = 0; q < p.ncoef; q++) {
+        const int64_t need = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
+        if (p.c[q] && p.sc[q] != 0 && p.sc[q] < need)
+            return fail_arg("coefficient batch stride must be 0 (shared) or >= slice size");
+    }
+    return XINV_OK;
+}
+
+static void fill_options(xinv_options &o, const xinv_options *in)
+{
+    xinv_default_options(&o);
+    if (in) o = *in;
+}
+
+
+// ------------------------------------------------------------------ host-pointer staging
+// Host <-> HBM path of the *_f64 / *_batched entry points.  Device buffers come from a
+// per-device pool that is kept across calls (the coefficient stack of a repeated solve is
+// re-uploaded but never re-allocated).  Large host arrays are pinned IN PLACE for the duration
+// of the call (hipHostRegister) so the DMA engines read them directly at PCIe rate and all
+// uploads are queued asynchronously on one stream; small arrays, or hosts where registration
+// fails, take the runtime's staged copy.
+struct DevPool {
+    std::vector<std::pair<void *, size_t>> bufs;   // (ptr, capacity)
+    size_t next = 0;
+    void reset() { next = 0; }
+};
+static std::mutex g_pool_mutex;
+static std::vector<std::pair<int, DevPool *>> g_pools;
+
+static DevPool *get_pool(int device)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    for (auto &e : g_pools) if (e.first == device) return e.second;
+    DevPool *p = new DevPool();
+    g_pools.push_back({device, p});
+    return p;
+}
+
+static int pool_alloc(DevPool *pool, size_t bytes, double **out)
+{
+    if (pool->next < pool->bufs.size()) {
+        auto &b = pool->bufs[pool->next];
+        if (b.second < bytes) {
+            HIPCHK(hipFree(b.first));
+            b.first = nullptr; b.second = 0;
+            HIPCHK(hipMalloc(&b.first, bytes));
+            b.second = bytes;
+        }
+        *out = (double *)b.first;
+        pool->next++;
+        return XINV_OK;
+    }
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, bytes));
+    pool->bufs.push_back({d, bytes});
+    pool->next++;
+    *out = (double *)d;
+    return XINV_OK;
+}
+
+struct Pinned {                                     // host ranges registered for this call
+    std::vector<void *> regs;
+    bool try_pin(const void *h, size_t bytes)
+    {
+        if (bytes < (1u << 20)) return false;
+        if (hipHostRegister((void *)h, bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        regs.push_back((void *)h);
+        return true;
+    }
+    ~Pinned() { for (void *h : regs) (void)hipHostUnregister(h); }
+};
+
+static int upload(DevPool *pool, Pinned &pin, hipStream_t st, const double *h, int64_t nbatch,
+                  int64_t stride, int64_t n, double **out, int64_t *dstride)
+{
+    if (!h) { *out = nullptr; *dstride = 0; return XINV_OK; }
+    const int64_t members = (stride == 0) ? 1 : nbatch;
+    double *d = nullptr;
+    int rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &d);
+    if (rc) return rc;
+    if (members == 1 || stride == n) {
+        const size_t bytes = (size_t)members * n * sizeof(double);
+        pin.try_pin(h, bytes);
+        HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
+    } else {
+        pin.try_pin(h, (size_t)((members - 1) * stride + n) * sizeof(double));
+        for (int64_t m = 0; m < members; m++)
+            HIPCHK(hipMemcpyAsync(d + m * n, h + m * stride, (size_t)n * sizeof(double),
+                                  hipMemcpyHostToDevice, st));
+    }
+    *out = d;
+    *dstride = (stride == 0) ? 0 : n;
+    return XINV_OK;
+}
+
