@@ -122,6 +122,23 @@ def test_fused_path_3d(BCy, BCx, msk, uni, nw, shape):
     assert_same(S[0], fl[0], So, flo, 'fused 3d %r' % (shape,))
 
 
+@pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic')])
+@pytest.mark.parametrize('uni', [0, 1])
+@pytest.mark.parametrize('shape', [(70, 9, 12), (45, 30, 130), (33, 14, 260), (129, 5, 8), (64, 12, 20)])
+def test_fused_path_3d_k_chunks(BCy, BCx, uni, shape):
+    """Tall volumes are split into k chunks (two halo planes a side, recomputed): every chunk
+    boundary must be invisible -- bit for bit the oracle, masks and early stop included."""
+    ps = [rand3d(shape[0], shape[1], shape[2], BCy, BCx, 1, seed=_seed(('kc', BCy, BCx, uni, shape, m)))
+          for m in range(2)]
+    if uni:
+        ps = [_uniform3d(q, None) for q in ps]
+    S, fl, st = run_hip_batched(ps, 40, 1e-4, path=PATH_FUSED)
+    assert st['path'] == PATH_FUSED
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 40, 1e-4, COLOUR_2)
+        assert_same(S[m], fl[m], So, flo, 'k-chunks %r member %d' % (shape, m))
+
+
 def test_fused_3d_batched_early_stop():
     ps = [rand3d(7, 20, 140, 'fixed', 'periodic', 1, seed=s) for s in (1, 2, 3)]
     S, fl, st = run_hip_batched(ps, 300, 2e-4)

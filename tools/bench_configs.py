@@ -50,6 +50,11 @@ def main():
             p = synthetic.gill_matsuno(720, 1440, a.members or 8); sw = a.sweeps or 200
         elif name == 'c5':
             p = synthetic.omega_latlon(50, 360, 720, a.members or 2); sw = a.sweeps or 50
+        elif name == 'ofes':
+            # the shape of the reference's only published wall-clock figure: invert_omega on a
+            # 601 x 300 x 300 ocean grid, 501 sweeps, 730 s per solve on one CPU core
+            # (docs/source/notebooks/11_Omega_equation.ipynb:525-529, tests/test_OmegaEq.py:188-222)
+            p = synthetic.omega_latlon(601, 300, 300, a.members or 1); sw = a.sweeps or 501
         else:
             raise SystemExit('unknown config ' + name)
         nb = p['S0'].shape[0]

@@ -33,6 +33,7 @@ struct Fused3Args {
     int64_t zc, yc, xc;
     int per;
     int nstrip, njb;           // x strips, j blocks
+    int nkc, KC;               // k chunks of KC planes (KC % 4 == 0); nkc == 1: the whole column
     int force, no_ctl;
     int64_t member0;
     XinvScal sc_;
@@ -82,13 +83,19 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && ctl->done) return;
 
-    const int NB = a.nstrip * a.njb;
+    const int NB = a.nstrip * a.njb * a.nkc;
     int T;
     {
         const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
         T = xcd * q + (xcd < rem ? xcd : rem) + idx;
     }
-    const int jb = T / a.nstrip, st = T - jb * a.nstrip;
+    // tile = (k chunk, j block, x strip).  A chunk owns planes [k0, k1); two planes on each side
+    // are halo (loaded, recomputed, not stored), exactly like the rows of the 2-D kernel: tall
+    // volumes and small batches then give every CU a workgroup.
+    const int kc = T / (a.nstrip * a.njb), Tj = T - kc * (a.nstrip * a.njb);
+    const int jb = Tj / a.nstrip, st = Tj - jb * a.nstrip;
+    const int64_t k0 = (int64_t)kc * a.KC;
+    const int64_t k1 = (kc + 1 == a.nkc) ? a.zc : k0 + a.KC;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t xc = a.xc, yc = a.yc, zc = a.zc;
     const int64_t xu0 = (int64_t)st * UW;
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
     struct Pack { double2 s, f, sfix; Coef3Pack<UNI> c; };
     auto load = [&](int64_t r) {
         Pack p;
-        const int64_t pr = r > zc - 1 ? zc - 1 : r;
+        const int64_t pr = r > zc - 1 ? zc - 1 : (r < 0 ? 0 : r);
         const int64_t off = (pr * yc + jr) * xc, off1 = (pr * yc + jr1) * xc;
         p.s = ld2<AL>(srcS, off, lc);
         p.f = ld2<AL>(pF, off, lc);
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
             const int64_t kk = r - 2;
             const double jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
             update(S2, S1, S3, kk, jP, jM, XT{});
-            const bool pin = row_use && (kk >= 0) && (kk <= zc - 1);
+            const bool pin = row_use && (kk >= k0) && (kk < k1);
             const double2 t = sw[S2];
             const bool cx = pin && lc.use_x && (t.x != u);
             const bool cy = pin && lc.use_y && (t.y != u);
@@ -242,9 +249,12 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
     };
 
     auto march = [&](auto jtag) {
-        Pack p0 = load(0), p1 = load(1);
-        const int64_t rlast = zc - 1 + 2;
-        for (int64_t rb_ = 0; rb_ <= rlast; rb_ += D) {
+        // start a multiple of D planes below k0 - 2 (slot indices are compile-time), run until the
+        // black half-sweep of plane k1 - 1 (step k1 + 1)
+        const int64_t rstart = (k0 >= D) ? k0 - D : 0;
+        Pack p0 = load(rstart), p1 = load(rstart + 1);
+        const int64_t rlast = k1 - 1 + 2;
+        for (int64_t rb_ = rstart; rb_ <= rlast; rb_ += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
                 if (U & 1) { step(rb_ + U, p1, utag, jtag); p1 = load(rb_ + U + 2); }

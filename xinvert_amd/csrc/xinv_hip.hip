@@ -154,6 +154,21 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         // 16 waves x 64 lanes leaves 128 VGPRs per lane: enough only for the x-uniform variant
         if (pl.RY == 0) pl.RY = (pl.um == 7u && p.BCy != XINV_BC_EXTEND) ? 16 : 12;
         pl.nrb = (int)cdiv(p.yc, pl.RY - 4);
+        // k chunks: one workgroup per CU is resident (16 / 12 waves); pick the chunk count that
+        // minimises (rounds of 256 workgroups) x (planes marched per workgroup, incl. 4 halo + 4 warm-up)
+        {
+            const int64_t wg1 = (int64_t)pl.nsg * pl.nrb * p.nbatch;
+            int best = 1; double best_cost = 1e300;
+            for (int nk = 1; nk <= 16; nk++) {
+                const int64_t KC = (int64_t)cdiv(cdiv(p.zc, nk), 4) * 4;
+                if (nk > 1 && (KC < 16 || (int64_t)(nk - 1) * KC >= p.zc)) break;
+                const int64_t rounds = cdiv(wg1 * nk, 256);
+                const double cost = (double)rounds * (double)(KC + (nk > 1 ? 10 : 2));
+                if (cost < best_cost * 0.97) { best_cost = cost; best = nk; }
+            }
+            pl.nkc = best;
+            pl.KC = (int)(cdiv(cdiv(p.zc, best), 4) * 4);
+        }
     } else
     if (pl.path == XINV_PATH_FUSED) {
         // which coefficient streams are constant along x (lat-lon grids: functions of latitude)
@@ -235,7 +250,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     }
     size_t pbytes;
     if (pl.path == XINV_PATH_FUSED)
-        pbytes = (size_t)p.nbatch * XINV_KMAX * (p.kind == KIND_STD3D ? (size_t)pl.nsg * pl.nrb : (size_t)pl.nsg) *
+        pbytes = (size_t)p.nbatch * XINV_KMAX * (p.kind == KIND_STD3D ? (size_t)pl.nsg * pl.nrb * std::max(1, pl.nkc) : (size_t)pl.nsg) *
                  (sizeof(double) + sizeof(long long));
     else
         pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));

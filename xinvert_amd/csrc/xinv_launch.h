@@ -9,6 +9,7 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 struct Plan {
     int path, base, seam, ncol;
     int K, RY, nsg, nrb;     // nsg: 2-D = workgroups per member (partials sizing); 3-D = x strips
+    int nkc, KC;             // 3-D: k chunks and planes per chunk
     bool aligned;
     unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
     unsigned um;             // the kernel variant's mask (subset of umask)
@@ -239,9 +240,10 @@ static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, d
     a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
     a.per = (p.BCx == XINV_BC_PERIODIC);
     a.nstrip = pl.nsg; a.njb = pl.nrb;
+    a.nkc = std::max(1, pl.nkc); a.KC = pl.KC;
     a.force = force; a.no_ctl = no_ctl; a.member0 = member0;
     a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
-    const size_t NB = (size_t)pl.nsg * pl.nrb;
+    const size_t NB = (size_t)pl.nsg * pl.nrb * a.nkc;
     a.psum = (unsigned long long *)ws->partials;
     a.pcnt = (long long *)((char *)ws->partials + p.nbatch * NB * sizeof(double));
     const bool ext = (p.BCy == XINV_BC_EXTEND), uni = (pl.um == 7u);
