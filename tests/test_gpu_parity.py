@@ -419,6 +419,25 @@ def test_biharmonic_rowclass_strips(BCy, xc, xuni):
     assert np.array_equal(S[0], S[1])
 
 
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('xc', [9, 12, 177, 180, 183, 186, 360, 363, 543])
+@pytest.mark.parametrize('xuni', [0, 1])
+def test_biharmonic_rowclass_periodic(BCy, xc, xuni):
+    """Periodic x with xc % 3 == 0 also runs the row-class kernel: wrapped lane->column map, the
+    periodic branches' G-term association in the first/last two columns and the reference's
+    stale-index B operand (five columns to the west) in the two east columns -- bit for bit the
+    oracle's 9-colour order, across strip seams and with per-row scalar coefficients."""
+    p = randbih(13, xc, BCy, 'periodic', 1, 1, seed=_seed(('bp', BCy, xc, xuni)))
+    if xuni:
+        p['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k in (0, 2, 3, 5, 8) else c
+                      for k, c in enumerate(p['coefs'])]
+    So, flo = run_oracle(p, 9, 1e-9, COLOUR_AUTO)
+    S, fl, st = run_hip_batched([p, p], 9, 1e-9)
+    assert st['path'] == PATH_COLOUR and st['colours'] == 9
+    assert_same(S[0], fl[0], So, flo, 'bih rowclass periodic')
+    assert np.array_equal(S[0], S[1])
+
+
 def test_biharmonic_batched_dev():
     ps = [randbih(16, 33, 'extend', 'periodic', 1, 1, seed=s) for s in (3, 4)]
     S1, f1, _ = run_hip_batched(ps, 20, 1e-7)

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
 }
 
 
-// ---- biharmonic: the three i-colours of one row class in ONE launch (non-periodic x) ---------
+// ---- biharmonic: the three i-colours of one row class in ONE launch ---------------------------
 // A wavefront owns one row j of the class (j % 3 == a.colour) and a strip of 192 columns, three
 // adjacent columns per lane = the three colours i % 3.  Rows j+-1, j+-2 belong to other row
 // classes and are constant during the launch; the lane's columns of row j are updated colour
@@ -368,6 +368,11 @@ __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
 // every stage.  Two lanes on each side are halo (each later colour needs the earlier colours two
 // columns away), so a strip owns 180 columns.  Same ordering as nine separate colour launches
 // (bitwise equal), one third of the launches and of the passes over S.
+// Periodic x (xc % 3 == 0, so that the wrap keeps colour == column % 3): the lane->column map
+// wraps, the first/last two columns take the periodic branches' G-term association, and the two
+// east columns read the B term's west operand FIVE columns away (the reference's stale loop index,
+// numbas.py:1495-1497, 1540-1542) -- one and two lanes to the left, in the state the 9-colour
+// order gives them (column xc-7 has colour 2: not yet updated; column xc-6 colour 0: updated).
 struct Tri { double v[3]; };
 
 __device__ __forceinline__ void bih_ext(const Tri &t, double (&e)[7])   // e[k+2] = column c+k, k=-2..4
@@ -376,8 +381,14 @@ __device__ __forceinline__ void bih_ext(const Tri &t, double (&e)[7])   // e[k+2
     e[1] = xinv_lane_up(t.v[2]); e[0] = xinv_lane_up(t.v[1]);
     e[5] = xinv_lane_down(t.v[0]); e[6] = xinv_lane_down(t.v[1]);
 }
+// columns c-4 and c-3: the stale-index operands of components 1 and 2
+__device__ __forceinline__ void bih_far(const Tri &t, double &cm4, double &cm3)
+{
+    cm4 = xinv_lane_up(xinv_lane_up(t.v[2]));
+    cm3 = xinv_lane_up(t.v[0]);
+}
 
-template <bool UNI>
+template <bool UNI, bool PER>
 __global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
 {
     const int64_t m = a.member0 + blockIdx.z;
@@ -392,13 +403,23 @@ __global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
     if (strip * 180 >= xc) return;
     double *S = a.S + m * a.sS;
     int64_t lcol[3];
-    bool upd[3], own[3];
+    bool upd[3], own[3], edge[3], east[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int64_t cc = c + k;
-        lcol[k] = cc < 0 ? 0 : (cc > xc - 1 ? xc - 1 : cc);
-        upd[k] = (cc >= 2) && (cc <= xc - 3);
-        own[k] = upd[k] && (lane >= 2) && (lane < 62);
+        if (PER) {
+            int64_t w = cc % xc; if (w < 0) w += xc;
+            lcol[k] = w;
+            upd[k] = true;
+            edge[k] = (w < 2) || (w >= xc - 2);
+            east[k] = (w >= xc - 2);
+            own[k] = (cc >= 0) && (cc < xc) && (lane >= 2) && (lane < 62);
+        } else {
+            lcol[k] = cc < 0 ? 0 : (cc > xc - 1 ? xc - 1 : cc);
+            upd[k] = (cc >= 2) && (cc <= xc - 3);
+            edge[k] = false; east[k] = false;
+            own[k] = upd[k] && (lane >= 2) && (lane < 62);
+        }
     }
     Tri R[5];                                                   // rows j-2 .. j+2
 #pragma unroll
@@ -421,21 +442,29 @@ __global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
     }
     double em2[7], em1[7], ep1[7], ep2[7];
     bih_ext(R[0], em2); bih_ext(R[1], em1); bih_ext(R[3], ep1); bih_ext(R[4], ep2);
+    double fm2[2] = {0.0, 0.0}, fp2[2] = {0.0, 0.0};            // columns c-4, c-3 of rows j-2, j+2
+    if (PER) { bih_far(R[0], fm2[0], fm2[1]); bih_far(R[4], fp2[0], fp2[1]); }
 #pragma unroll
     for (int k = 0; k < 3; k++) {                               // colour i % 3 == k
         double e0[7];
         bih_ext(R[2], e0);
         const int o = k + 2;                                    // index of column c+k in e[]
+        double p2_b = ep2[o - 2], r0_b = e0[o - 2], m2_b = em2[o - 2];
+        if (PER && k > 0) {
+            double f0[2];
+            bih_far(R[2], f0[0], f0[1]);
+            if (east[k]) { p2_b = fp2[k - 1]; r0_b = f0[k - 1]; m2_b = fm2[k - 1]; }
+        }
         R[2].v[k] = xinv_upd_bih2d_v(
-            ep2[o], ep2[o + 2], ep2[o - 2], ep1[o], ep1[o + 1], ep1[o - 1],
-            e0[o], e0[o + 1], e0[o - 1], e0[o + 2], e0[o - 2],
-            em1[o], em1[o + 1], em1[o - 1], em2[o], em2[o + 2], em2[o - 2],
+            ep2[o], ep2[o + 2], p2_b, ep1[o], ep1[o + 1], ep1[o - 1],
+            e0[o], e0[o + 1], e0[o - 1], e0[o + 2], e0[o - 2], r0_b,
+            em1[o], em1[o + 1], em1[o - 1], em2[o], em2[o + 2], m2_b,
             cv[0][k], cv[1][k], cv[2][k], cv[3][k], cv[4][k], cv[5][k], cv[6][k], cv[7][k],
-            cv[8][k], cv[9][k], upd[k], a.sc_);
+            cv[8][k], cv[9][k], upd[k], edge[k], a.sc_);
     }
 #pragma unroll
     for (int k = 0; k < 3; k++)
-        if (own[k]) S[j * xc + c + k] = R[2].v[k];
+        if (own[k]) S[j * xc + lcol[k]] = R[2].v[k];
 }
 
 // 'extend' pre-pass of the biharmonic kernel (numbas.py:1299-1343): one thread per column.

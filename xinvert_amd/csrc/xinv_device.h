@@ -407,26 +407,33 @@ __device__ __forceinline__ double xinv_upd_std2dt_5(
     return cond ? sC + temp : sC;
 }
 
-// the inner-loop form of the biharmonic update on register operands (numbas.py:1437-1479);
-// XY naming: first letter = row (p2, p1, r0, m1, m2), suffix = column offset (m2, m1, 0, p1, p2)
+// the biharmonic update on register operands (numbas.py:1437-1479 inner loop; 1347-1434,
+// 1482-1570 periodic branches); XY naming: first letter = row (p2, p1, r0, m1, m2), suffix =
+// column offset (m2, m1, 0, p1, p2).  p2_b / r0_b / m2_b are the west operands of the B term: column
+// i-2, except in the reference's two east-periodic branches where the stale loop index makes it
+// column i-5; `edge` selects the G-term association of the periodic branches.
 __device__ __forceinline__ double xinv_upd_bih2d_v(
-    double p2_0, double p2_p2, double p2_m2, double p1_0, double p1_p1, double p1_m1,
-    double r0_0, double r0_p1, double r0_m1, double r0_p2, double r0_m2,
-    double m1_0, double m1_p1, double m1_m1, double m2_0, double m2_p2, double m2_m2,
+    double p2_0, double p2_p2, double p2_b, double p1_0, double p1_p1, double p1_m1,
+    double r0_0, double r0_p1, double r0_m1, double r0_p2, double r0_m2, double r0_b,
+    double m1_0, double m1_p1, double m1_m1, double m2_0, double m2_p2, double m2_b,
     double A, double B, double C, double D, double E, double F, double G, double H, double I,
-    double J, bool inr, const XinvScal &sc)
+    double J, bool inr, bool edge, const XinvScal &sc)
 {
     const double u = sc.undef;
     const bool cond = inr && (A != u) && (B != u) && (C != u) && (D != u) && (E != u) &&
                       (F != u) && (G != u) && (H != u) && (I != u) && (J != u);
+    double gterm = G * (
+                       (p1_0 - m1_0)
+                   );
+    gterm = edge ? gterm * sc.delxTr / 2.0 * sc.ratio : gterm * sc.delxTr * sc.ratio / 2.0;
     double temp = (
         A * (
             (p2_0 - 4.0*p1_0 + 6.0*r0_0 - 4.0*m1_0 + m2_0)
         ) * sc.ratioSSr +
         B * (
-            (    p2_p2 - 2.0*p2_0 +     p2_m2 +
-            -2.0*r0_p2 + 4.0*r0_0 - 2.0*r0_m2 +
-                 m2_p2 - 2.0*m2_0 +     m2_m2)
+            (    p2_p2 - 2.0*p2_0 +     p2_b +
+            -2.0*r0_p2 + 4.0*r0_0 - 2.0*r0_b +
+                 m2_p2 - 2.0*m2_0 +     m2_b)
         ) * sc.ratioSqr / 16.0 +
         C * (
             (r0_p2 - 4.0*r0_p1 + 6.0*r0_0 - 4.0*r0_m1 + r0_m2)
@@ -440,9 +447,7 @@ __device__ __forceinline__ double xinv_upd_bih2d_v(
         F * (
             (r0_p1 - r0_0)-(r0_0 - r0_m1)
         ) * sc.delxSqr +
-        G * (
-            (p1_0 - m1_0)
-        ) * sc.delxTr * sc.ratio / 2.0 +
+        gterm +
         H * (
             (r0_p1 - r0_m1)
         ) * sc.delxTr / 2.0 + (

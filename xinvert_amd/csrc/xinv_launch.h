@@ -280,13 +280,19 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
         a.sc_ = p.sc_; a.ctl = ws->ctl; a.umask = pl.umask;
         dim3 b(64, 4, 1);
         dim3 g(cdiv(cdiv(p.xc, 3) + 1, 64), cdiv(cdiv(p.yc, 3) + 1, 4), (unsigned)nm);
-        if (!per) {
-            // non-periodic x: one launch per row class does its three column colours in registers
+        if (!per || p.xc % 3 == 0) {
+            // one launch per row class does its three column colours in registers (periodic x needs
+            // xc % 3 == 0 so that the wrap keeps colour == column % 3; otherwise nine + trailing colours)
             dim3 gb(cdiv(cdiv(p.xc, 180), 4), cdiv(p.yc, 3) + 1, (unsigned)nm), bb(256, 1, 1);
             for (int cj = 0; cj < 3; cj++) {
                 a.colour = cj;
-                if (pl.umask) hipLaunchKernelGGL(k_bih_rowclass<true>, gb, bb, 0, st, a);
-                else          hipLaunchKernelGGL(k_bih_rowclass<false>, gb, bb, 0, st, a);
+                if (per) {
+                    if (pl.umask) hipLaunchKernelGGL((k_bih_rowclass<true, true>), gb, bb, 0, st, a);
+                    else          hipLaunchKernelGGL((k_bih_rowclass<false, true>), gb, bb, 0, st, a);
+                } else {
+                    if (pl.umask) hipLaunchKernelGGL((k_bih_rowclass<true, false>), gb, bb, 0, st, a);
+                    else          hipLaunchKernelGGL((k_bih_rowclass<false, false>), gb, bb, 0, st, a);
+                }
             }
         } else
         for (int cc = 0; cc < pl.ncol; cc++) {
