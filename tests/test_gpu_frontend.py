@@ -410,6 +410,7 @@ def test_invert_3DOcean_matches_lexicographic_oracle(coords):
     mP = {'epsilon': 1e-5, 'N2': N2, 'k': 1e-7, 'f0': 3e-5, 'beta': 2e-11}
     S = apps.invert_3DOcean(F, ['lev', 'lat', 'lon'], coords=coords, mParams=mP, iParams=iP)
     assert S.shape == Fv.shape and np.isnan(S.values[:, :, 8:12, 10:14]).all()
+    assert S.iParams['stats']['path'] == 2 and S.iParams['stats']['xuniform_mask'] == 0x7f   # streaming kernel
     # the same coefficients through the oracle's lexicographic order
     mPf = apps._update(apps.default_mParams, mP, ['f0', 'beta', 'epsilon', 'N2', 'k', 'g', 'Omega', 'Rearth'])
     iPf = apps._update(apps.default_iParams, iP)

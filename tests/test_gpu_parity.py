@@ -96,6 +96,37 @@ def test_general_3d_dev_and_early_stop():
     assert len(loops) > 1
 
 
+def _uniform3dg(p):
+    """A..G constant along x (every 3DOcean coefficient is a function of level and latitude)."""
+    q = dict(p)
+    q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[..., :1], c.shape)) if k < 7 else c
+                  for k, c in enumerate(p['coefs'])]
+    return q
+
+
+@pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'),
+                                     ('extend', 'fixed'), ('fixed', 'extend')])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('nw', [0, 8, 16])
+@pytest.mark.parametrize('shape', [(6, 9, 12), (5, 30, 130), (9, 21, 260), (4, 14, 10), (3, 3, 4), (70, 9, 12),
+                                   (45, 30, 130)])
+def test_general_3d_fused_path(BCy, BCx, msk, nw, shape):
+    """k_fused3dg: the general 3-D form on the streaming path when A..G are constant along x --
+    red-black order of the oracle bit for bit, including the west-periodic branch that never tests H,
+    the pre-pass with its range(1, yc-1) second loop, k chunks on tall volumes, batches."""
+    ps = [_uniform3dg(rand3dg(shape[0], shape[1], shape[2], BCy, BCx, msk, seed=_seed(('g3f', BCy, BCx, msk, shape, m))))
+          for m in range(2)]
+    S, fl, st = run_hip_batched(ps, 14, 1e-9, path=PATH_FUSED, rows_per_tile=nw)
+    assert st['path'] == PATH_FUSED and st['xuniform_mask'] == 0x7f
+    assert st['rows_per_tile'] == (nw or 12)
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 14, 1e-9, COLOUR_2)
+        assert_same(S[m], fl[m], So, flo, 'gen3d fused %r member %d' % (shape, m))
+    # coefficients that vary along x have no fused kernel
+    with pytest.raises(Exception, match='no fused kernel'):
+        run_hip_batched([rand3dg(shape[0], shape[1], max(shape[2], 4), BCy, BCx, msk, seed=3)], 3, 0.0, path=PATH_FUSED)
+
+
 def _uniform3d(p, rng):
     """Make A, B, C constant along x (what every lat-lon omega coefficient looks like)."""
     q = dict(p)

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-ALG = {'std2d': 48, 'gen2d': 72, 'std3d': 48, 'bih2d': 96}
+ALG = {'std2d': 48, 'gen2d': 72, 'std3d': 48, 'bih2d': 96, 'gen3d': 80}
 
 
 def main():
@@ -50,6 +50,8 @@ def main():
             p = synthetic.gill_matsuno(720, 1440, a.members or 8); sw = a.sweeps or 200
         elif name == 'c5':
             p = synthetic.omega_latlon(50, 360, 720, a.members or 2); sw = a.sweeps or 50
+        elif name == 'c5g':
+            p = synthetic.ocean3d_latlon(50, 360, 720, a.members or 2); sw = a.sweeps or 50
         elif name == 'ofes':
             # the shape of the reference's only published wall-clock figure: invert_omega on a
             # 601 x 300 x 300 ocean grid, 501 sweeps, 730 s per solve on one CPU core

@@ -30,6 +30,7 @@
 #include "xinv_colour.h"
 #include "xinv_fused.h"
 #include "xinv_fused3d.h"
+#include "xinv_fused3dg.h"
 #include "xinv_fused9.h"
 
 #define XINV_VERSION 100
@@ -104,12 +105,19 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     const bool fused5_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
     const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
                            (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
-    const bool fused_ok = fused5_ok || fused9_ok;
+    // general 3-D: the fused kernel exists for x-uniform coefficients only (every 3DOcean array)
+    bool fused3g_ok = false;
+    if (p.kind == KIND_GEN3D && !pl.seam && opt.path != XINV_PATH_COLOUR && !(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
+        rc = detect_xuniform(ws, st, p.c, p.sc, 7, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
+        if (rc) return rc;
+        fused3g_ok = (pl.umask == 0x7fu);
+    }
+    const bool fused_ok = fused5_ok || fused9_ok || fused3g_ok;
     pl.path = XINV_PATH_COLOUR;
     pl.nine = false;
-    if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = !fused5_ok; }
+    if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("no fused kernel for this form (odd-xc periodic seam, biharmonic, or 9-point test form)");
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam, biharmonic, 9-point test form, or general 3-D with coefficients that vary along x)");
     if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 
@@ -136,23 +144,29 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             pl.RY = (int)cdiv(p.yc, pl.nrb);
         }
         pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 8 * XINV_KMAX) * pl.nrb, 4) + 1;
-    } else if (pl.path == XINV_PATH_FUSED && p.kind == KIND_STD3D) {
+    } else if (pl.path == XINV_PATH_FUSED && is3d(p.kind)) {
         // 3-D: one sweep per launch; cross-section of NW rows per workgroup (rows_per_tile = NW)
         pl.K = 1;
         pl.RY = (opt.rows_per_tile == 8 || opt.rows_per_tile == 12 || opt.rows_per_tile == 16)
                     ? opt.rows_per_tile : 0;     // 0: decided below, once the variant is known
         pl.nsg = (int)cdiv(p.xc, 124);                      // x strips
-        pl.nrb = (int)cdiv(p.yc, pl.RY - 4);                // j blocks
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
-        for (int q = 0; q < 4; q++) pl.aligned = pl.aligned && ptr_al16(p.c[q]) && !(p.sc[q] & 1);
-        pl.umask = 0;
-        if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-            rc = detect_xuniform(ws, st, p.c, p.sc, 3, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
-            if (rc) return rc;
+        // only S and the forcing are read as vectors when the coefficients are per-row scalars
+        pl.aligned = pl.aligned && ptr_al16(p.c[p.ncoef - 1]) && !(p.sc[p.ncoef - 1] & 1);
+        if (p.kind == KIND_STD3D) {
+            for (int q = 0; q < 3; q++) pl.aligned = pl.aligned && ptr_al16(p.c[q]) && !(p.sc[q] & 1);
+            pl.umask = 0;
+            if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
+                rc = detect_xuniform(ws, st, p.c, p.sc, 3, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
+                if (rc) return rc;
+            }
+            pl.um = (pl.umask == 7u) ? 7u : 0u;
+            // 16 waves x 64 lanes leaves 128 VGPRs per lane: enough only for the x-uniform variant
+            if (pl.RY == 0) pl.RY = (pl.um == 7u && p.BCy != XINV_BC_EXTEND) ? 16 : 12;
+        } else {
+            pl.um = pl.umask;                               // 0x7f: A..G are per-row scalars
+            if (pl.RY == 0) pl.RY = 12;                     // seven coefficient windows: 12 waves x 170 VGPRs
         }
-        pl.um = (pl.umask == 7u) ? 7u : 0u;
-        // 16 waves x 64 lanes leaves 128 VGPRs per lane: enough only for the x-uniform variant
-        if (pl.RY == 0) pl.RY = (pl.um == 7u && p.BCy != XINV_BC_EXTEND) ? 16 : 12;
         pl.nrb = (int)cdiv(p.yc, pl.RY - 4);
         // k chunks: one workgroup per CU is resident (16 / 12 waves); pick the chunk count that
         // minimises (rounds of 256 workgroups) x (planes marched per workgroup, incl. 4 halo + 4 warm-up)
@@ -250,7 +264,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     }
     size_t pbytes;
     if (pl.path == XINV_PATH_FUSED)
-        pbytes = (size_t)p.nbatch * XINV_KMAX * (p.kind == KIND_STD3D ? (size_t)pl.nsg * pl.nrb * std::max(1, pl.nkc) : (size_t)pl.nsg) *
+        pbytes = (size_t)p.nbatch * XINV_KMAX * (is3d(p.kind) ? (size_t)pl.nsg * pl.nrb * std::max(1, pl.nkc) : (size_t)pl.nsg) *
                  (sizeof(double) + sizeof(long long));
     else
         pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
@@ -297,7 +311,9 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             if (pl.path == XINV_PATH_FUSED) {
                 const int k = (max_sweeps - launched >= Kf) ? Kf : 1;
                 const int cur = (int)(bound.size() & 1);
-                r = (p.kind == KIND_STD3D)
+                r = (p.kind == KIND_GEN3D)
+                        ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
+                    : (p.kind == KIND_STD3D)
                         ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
                     : pl.nine
                         ? launch_fused9(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
@@ -354,7 +370,9 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             } else {                                     // stopped inside a K-sweep launch: redo
                 int cur = (int)(i & 1);
                 for (int64_t s = bound[i]; s < sw; s++) {
-                    rc = (p.kind == KIND_STD3D)
+                    rc = (p.kind == KIND_GEN3D)
+                             ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
+                         : (p.kind == KIND_STD3D)
                              ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
                          : pl.nine
                              ? launch_fused9(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)

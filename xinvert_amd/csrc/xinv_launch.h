@@ -259,6 +259,47 @@ static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, d
     return XINV_OK;
 }
 
+// ---- general 3-D fused launch (every coefficient array x-uniform) --------------------------------
+template <int NW>
+static void launch_fused3dg_nw(bool al, bool ext, dim3 grid, hipStream_t st, const Fused3GArgs &a)
+{
+    dim3 block(NW * 64, 1, 1);
+    if (al) { if (ext) hipLaunchKernelGGL((k_fused3dg<NW, true, true>), grid, block, 0, st, a);
+              else     hipLaunchKernelGGL((k_fused3dg<NW, true, false>), grid, block, 0, st, a); }
+    else    { if (ext) hipLaunchKernelGGL((k_fused3dg<NW, false, true>), grid, block, 0, st, a);
+              else     hipLaunchKernelGGL((k_fused3dg<NW, false, false>), grid, block, 0, st, a); }
+}
+
+static int launch_fused3dg(const Problem &p, const Plan &pl, const double *src, double *dst,
+                           Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
+                           int no_ctl)
+{
+    Fused3GArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = src; a.dst = dst; a.sS = p.sS;
+    for (int q = 0; q < 8; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
+    a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
+    a.per = (p.BCx == XINV_BC_PERIODIC);
+    a.nstrip = pl.nsg; a.njb = pl.nrb;
+    a.nkc = std::max(1, pl.nkc); a.KC = pl.KC;
+    a.force = force; a.no_ctl = no_ctl; a.member0 = member0;
+    a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
+    const size_t NB = (size_t)pl.nsg * pl.nrb * a.nkc;
+    a.psum = (unsigned long long *)ws->partials;
+    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * NB * sizeof(double));
+    const bool ext = (p.BCy == XINV_BC_EXTEND);
+    for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
+        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
+        a.member0 = member0 + m0;
+        dim3 grid((unsigned)NB, (unsigned)nm, 1);
+        if (pl.RY == 8) launch_fused3dg_nw<8>(pl.aligned, ext, grid, st, a);
+        else if (pl.RY == 16) launch_fused3dg_nw<16>(pl.aligned, ext, grid, st, a);
+        else launch_fused3dg_nw<12>(pl.aligned, ext, grid, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return XINV_OK;
+}
+
 // one full coloured sweep (+ norm + stop rule) in place on p.S
 static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st,
                                int64_t m0, int64_t nm)

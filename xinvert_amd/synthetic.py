@@ -144,6 +144,32 @@ def omega_latlon(nz, ny, nx, steps=1, seed=SEED):
                 undef=apps._undeftmp, S0=initS.values, coefs=[A, B, C, Fm.values], shared=(0, 1, 2))
 
 
+def ocean3d_latlon(nz, ny, nx, steps=1, seed=SEED):
+    """3-D wind-driven ocean (general 3-D form, apps.invert_3DOcean) with a bathymetry mask."""
+    rng = np.random.default_rng(seed)
+    lev = np.linspace(0.0, 500.0, nz)
+    dlat = 120.0 / ny
+    lat = -60 + dlat / 2 + dlat * np.arange(ny); lon = (360.0 / nx) * np.arange(nx)
+    frc = []
+    for _ in range(steps):
+        base = _modes(rng, lat, lon, 8, 6, 5)
+        prof = np.exp(-np.linspace(0, 4, nz))[:, None, None]
+        frc.append(1e-9 * prof * base[None])
+    frc = np.stack(frc)
+    depth = 500.0 - 350.0 * np.clip(_modes(rng, lat, lon, 8, 4, 4), 0, None)
+    frc[:, lev[:, None, None] > depth[None]] = np.nan
+    F = Field(frc, ('time', 'lev', 'lat', 'lon'), {'lev': lev, 'lat': lat, 'lon': lon})
+    iP = apps._update(apps.default_iParams, {'BCs': ['fixed', 'fixed', 'periodic']})
+    mP = dict(apps.default_mParams); mP.update({'epsilon': 1e-5, 'k': 1e-7, 'N2': 1e-4 * (1.0 + np.linspace(0, 1, nz))})
+    Fm, initS, cs = apps._coeffs_3DOcean(F, ['lev', 'lat', 'lon'], 'lat-lon', mP, iP, None)
+    p3 = apps._cal_params3D(lev, lat, lon, 'lat-lon')
+    return dict(kind='gen3d', zc=nz, yc=ny, xc=nx, BCz='fixed', BCy='fixed', BCx='periodic',
+                delz=p3['del3'], dely=p3['del2'], delx=p3['del1'], delxSqr=p3['del1Sqr'],
+                ratio2=p3['ratio2'], ratio1=p3['ratio1'], ratio2Sqr=p3['ratio2Sqr'],
+                ratio1Sqr=p3['ratio1Sqr'], optArg=p3['optArg'], undef=apps._undeftmp, S0=initS.values,
+                coefs=[np.ascontiguousarray(c) for c in cs] + [Fm.values], shared=(0, 1, 2, 3, 4, 5, 6))
+
+
 def member(p, m):
     """Problem dict of one member (views) in the layout tests/util.py's runners take."""
     q = dict(p)
