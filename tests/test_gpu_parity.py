@@ -469,6 +469,35 @@ def test_biharmonic_rowclass_periodic(BCy, xc, xuni):
     assert np.array_equal(S[0], S[1])
 
 
+def _uniform_bih(p):
+    """A..I constant along x (Munk / Stommel-Munk coefficients are functions of latitude at most)."""
+    q = dict(p)
+    q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k < 9 else c
+                  for k, c in enumerate(p['coefs'])]
+    return q
+
+
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('BCx', ['fixed', 'periodic', 'extend'])
+@pytest.mark.parametrize('rows', [0, 3, 9])
+@pytest.mark.parametrize('shape', [(5, 9), (7, 12), (13, 183), (31, 366), (64, 543), (20, 72), (9, 180)])
+def test_biharmonic_one_pass_kernel(BCy, BCx, rows, shape):
+    """k_fusedbih: all nine colours of a sweep in one streaming pass (nine-row register window,
+    ping-pong buffers): bit for bit the oracle's 9-colour order -- tile seams in both directions,
+    first/last rows, masks, periodic wrap with the stale-index east columns, batch with early stop."""
+    if BCx == 'periodic' and shape[1] % 3:
+        pytest.skip('periodic x with xc % 3 != 0 runs the colour launches')
+    ps = [_uniform_bih(randbih(shape[0], shape[1], BCy, BCx, 1, 1, seed=_seed(('b1p', BCy, BCx, shape, m))))
+          for m in range(2)]
+    S, fl, st = run_hip_batched(ps, 25, 1e-4, rows_per_tile=rows)
+    assert st['path'] == PATH_FUSED and st['colours'] == 9 and st['xuniform_mask'] & 0x1ff == 0x1ff
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 25, 1e-4, COLOUR_AUTO)
+        assert_same(S[m], fl[m], So, flo, 'bih one-pass %r member %d' % (shape, m))
+    Sc, flc, stc = run_hip_batched(ps, 25, 1e-4, path=PATH_COLOUR)
+    assert stc['path'] == PATH_COLOUR and np.array_equal(S, Sc) and np.array_equal(fl[:, 2], flc[:, 2])
+
+
 def test_biharmonic_batched_dev():
     ps = [randbih(16, 33, 'extend', 'periodic', 1, 1, seed=s) for s in (3, 4)]
     S1, f1, _ = run_hip_batched(ps, 20, 1e-7)

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libxinv_hip.so')
 SOURCES = ['xinv_hip.hip']
-HEADERS = ['xinv_device.h', 'xinv_colour.h', 'xinv_fused.h', 'xinv_fused3d.h', 'xinv_fused3dg.h', 'xinv_fused9.h',
+HEADERS = ['xinv_device.h', 'xinv_colour.h', 'xinv_fused.h', 'xinv_fused3d.h', 'xinv_fused3dg.h', 'xinv_fused9.h', 'xinv_fusedbih.h',
            'xinv_host.h', 'xinv_launch.h']
 # -ffp-contract=off: no FMA contraction, so device results are bitwise those of the
 # CPU restatement of the same sweep ordering (see DESIGN.md "Arithmetic").

@@ -412,7 +412,14 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
         const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
         T = xcd * q + (xcd < rem ? xcd : rem) + idx;
     }
+#ifndef XINV_WAVE_UNIFORM
+#define XINV_WAVE_UNIFORM 0
+#endif
+#if XINV_WAVE_UNIFORM
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+#else
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#endif
     int wt = T * 4 + wave;
     bool active = wt < a.nstrip * a.nrb;
     if (a.tile_list) {

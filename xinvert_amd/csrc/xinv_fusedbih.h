@@ -1,0 +1,209 @@
+// xinv_fusedbih.h -- one pass per sweep for the biharmonic form (gfx950).
+//
+// numbas.invert_general_bih_2D (reference numbas.py:1204-1586): radius-2 stencil, 9 colours
+// (j % 3 major, i % 3 minor).  The colour order decouples into a streaming schedule: with rows
+// entering a register window top to bottom, row j of class 0 can take its three column colours as
+// soon as row j+2 is in (it reads only old values), class 1 once row j+4 is in (it needs the new
+// class-0 rows j-1 and j+2), class 2 once row j+6 is in (new rows j-2, j-1, j+1, j+2).  All three
+// conditions fall on the steps r = 2 (mod 3): such a step updates rows r-2, r-4, r-6 in that order
+// and retires rows r-8, r-7, r-6 -- a nine-row window, one read and one write of S per sweep instead
+// of the row-class kernel's three passes that re-read five rows per updated row.
+//
+// A wavefront owns a strip of 192 columns -- three adjacent columns per lane = the three column
+// colours, neighbours by DPP -- and RB rows.  Updated rows stay in the window, so what the edge lanes
+// get wrong feeds the next class.  Colours run west to east, so the error zone is asymmetric: on
+// the left a class-0 / 1 / 2 update is wrong in one / two / three lanes; on the right in columns
+// E, E-1, E-3 (class 0), up to E-9 (class 1), up to E-15 (class 2), E = the wave's last column.
+// THREE halo lanes on the left and SIX on the right (165 owned columns) cover the chain; class-0
+// rows read only source values, so nothing accumulates from sweep to sweep.  With periodic x the
+// two east columns read five columns to the west (the stale index), and their wrapped copies sit in
+// the left halo next to the owned west columns: two more halo lanes on the left (159 owned).  RB is a multiple
+// of 3, so every tile starts on a class-0 row and needs no recomputation above it: two source rows
+// suffice); below the tile rows y1, y1+1, y1+3 are recomputed from source rows up to y1+5.  Tiles
+// do not communicate: S ping-pongs between two buffers; the 'extend' pre-pass (k_extend_bih) runs
+// on the source buffer before the sweep.  Requires the coefficient arrays A..I to be constant
+// along x (per-row scalars: Munk / Stommel-Munk on Cartesian and lat-lon grids); otherwise the
+// row-class kernel runs.  Periodic x needs xc % 3 == 0 (see k_bih_rowclass).  Same ordering as
+// nine colour launches: bitwise equal results.
+#pragma once
+#include "xinv_fused.h"
+
+#define XINV_BIH_OWN(per) ((per) ? 159 : 165)   /* owned columns: lanes 3..57 (5..57 when periodic) x 3 */
+
+struct FusedBihArgs {
+    const double *src;
+    double *dst;
+    const double *c[10];       // A..I (x-uniform), J
+    int64_t sS, sc[10];
+    int64_t yc, xc;
+    int per;
+    int nstrip, nrb, RB;       // x strips, row blocks, rows per block (RB % 3 == 0)
+    int nwg;
+    int force, no_ctl;
+    int64_t member0;
+    XinvScal sc_;
+    XinvCtl *ctl;
+    XinvStop stop;
+    unsigned long long *psum;  // [nbatch][XINV_KMAX][NB]
+    long long *pcnt;
+};
+
+#ifndef XINV_BIH_MINWAVES
+#define XINV_BIH_MINWAVES 2
+#endif
+template <bool PER>
+__global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArgs a)
+{
+    constexpr int D = 9;
+    const int64_t m = a.member0 + blockIdx.y;
+    XinvCtl *ctl = a.ctl + m;
+    if (!a.force && ctl->done) return;
+
+    const int NB = a.nwg;
+    int T;
+    {
+        const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
+        T = xcd * q + (xcd < rem ? xcd : rem) + idx;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wt = T * 4 + wave;
+    const bool active = wt < a.nstrip * a.nrb;
+    const int rb = active ? wt / a.nstrip : 0, strip = active ? wt - rb * a.nstrip : 0;
+    const int64_t xc = a.xc, yc = a.yc;
+    const int64_t y0 = (int64_t)rb * a.RB;
+    const int64_t y1 = (rb + 1 == a.nrb) ? yc : y0 + a.RB;
+    const double u = a.sc_.undef;
+    const double *srcS = a.src + m * a.sS;
+    double *dstS = a.dst + m * a.sS;
+
+    double acc[1] = {0.0};
+    int cnt[1] = {0};
+
+    if (active) {
+        constexpr int LH = PER ? 5 : 3;                              // halo lanes on the left (6 on the right)
+        const int64_t c = (int64_t)strip * XINV_BIH_OWN(PER) - 3 * LH + 3 * lane;   // unwrapped first column (c % 3 == 0)
+        int64_t lcol[3];
+        bool upd[3], own[3], edge[3], east[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int64_t cc = c + k;
+            if (PER) {
+                int64_t w = cc % xc; if (w < 0) w += xc;
+                lcol[k] = w;
+                upd[k] = true;
+                edge[k] = (w < 2) || (w >= xc - 2);
+                east[k] = (w >= xc - 2);
+                own[k] = (cc >= 0) && (cc < xc) && (lane >= LH) && (lane < 58);
+            } else {
+                lcol[k] = cc < 0 ? 0 : (cc > xc - 1 ? xc - 1 : cc);
+                upd[k] = (cc >= 2) && (cc <= xc - 3);
+                edge[k] = false; east[k] = false;
+                own[k] = (cc >= 0) && (cc < xc) && (lane >= LH) && (lane < 58);
+            }
+        }
+        const double *cp[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) cp[q] = a.c[q] + m * a.sc[q];
+        const double *pJ = a.c[9] + m * a.sc[9];
+
+        auto load_row = [&](const double *base, int64_t r) {
+            const int64_t rr = r < 0 ? 0 : (r > yc - 1 ? yc - 1 : r);
+            const double *row = base + rr * xc;
+            Tri t;
+#pragma unroll
+            for (int k = 0; k < 3; k++) t.v[k] = row[lcol[k]];
+            return t;
+        };
+
+        Tri W[D];
+#pragma unroll
+        for (int t = 0; t < D; t++) { W[t].v[0] = 0.0; W[t].v[1] = 0.0; W[t].v[2] = 0.0; }
+        Tri Jst[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) Jst[t] = W[0];
+
+        // the three column colours of row j (window slot SJ), forcing row Jt
+        auto upd_row = [&](auto sjtag, int64_t j, const Tri &Jt) {
+            constexpr int SJ = decltype(sjtag)::value;
+            constexpr int SM2 = (SJ + 7) % D, SM1 = (SJ + 8) % D, SP1 = (SJ + 1) % D, SP2 = (SJ + 2) % D;
+            if (j < 2 || j > yc - 3) return;                       // rows 0, 1, yc-2, yc-1 are never updated
+            double cs[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) cs[q] = cp[q][j * xc];     // one value per row
+            double em2[7], em1[7], ep1[7], ep2[7];
+            bih_ext(W[SM2], em2); bih_ext(W[SM1], em1); bih_ext(W[SP1], ep1); bih_ext(W[SP2], ep2);
+            double fm2[2] = {0.0, 0.0}, fp2[2] = {0.0, 0.0};
+            if (PER) { bih_far(W[SM2], fm2[0], fm2[1]); bih_far(W[SP2], fp2[0], fp2[1]); }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                double e0[7];
+                bih_ext(W[SJ], e0);
+                const int o = k + 2;
+                double p2_b = ep2[o - 2], r0_b = e0[o - 2], m2_b = em2[o - 2];
+                if (PER && k > 0) {
+                    double f0[2];
+                    bih_far(W[SJ], f0[0], f0[1]);
+                    if (east[k]) { p2_b = fp2[k - 1]; r0_b = f0[k - 1]; m2_b = fm2[k - 1]; }
+                }
+                W[SJ].v[k] = xinv_upd_bih2d_v(
+                    ep2[o], ep2[o + 2], p2_b, ep1[o], ep1[o + 1], ep1[o - 1],
+                    e0[o], e0[o + 1], e0[o - 1], e0[o + 2], e0[o - 2], r0_b,
+                    em1[o], em1[o + 1], em1[o - 1], em2[o], em2[o + 2], m2_b,
+                    cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[7], cs[8],
+                    Jt.v[k], upd[k], edge[k], a.sc_);
+            }
+        };
+        auto retire = [&](auto stag, int64_t j) {
+            constexpr int SL = decltype(stag)::value;
+            if (j < y0 || j >= y1) return;
+            double *row = dstS + j * xc;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double v = W[SL].v[k];
+                if (own[k]) {
+                    row[lcol[k]] = v;
+                    if (v != u) { acc[0] += fabs(v); cnt[0] += 1; }
+                }
+            }
+        };
+
+        // Rows y0-3 .. y1+7 stream through the window three at a time.  The window is shifted by
+        // three rows per group (18 register moves against ~900 instructions of updates), so the
+        // newest row always sits in slot 8 and every slot index below is a constant: with
+        // r = base + 2 = 2 (mod 3), rows r-2 / r-4 / r-6 are slots 6 / 4 / 2 and rows r-8..r-6
+        // (slots 0..2) retire.  The next group's three rows and forcing rows are requested before
+        // the updates of this one.
+        const int64_t rstart = y0 - 3, rlast = y1 + 7;           // row j retires by step j + 8
+#ifndef XINV_BIH_PREFETCH
+#define XINV_BIH_PREFETCH 0
+#endif
+#if XINV_BIH_PREFETCH
+        Tri N0 = load_row(srcS, rstart), N1 = load_row(srcS, rstart + 1), N2 = load_row(srcS, rstart + 2);
+#endif
+        Jst[0] = load_row(pJ, rstart + 2 - 2); Jst[1] = load_row(pJ, rstart + 2 - 4); Jst[2] = load_row(pJ, rstart + 2 - 6);
+        for (int64_t base = rstart; base <= rlast; base += 3) {
+            const int64_t r = base + 2;
+#pragma unroll
+            for (int t = 0; t < 6; t++) W[t] = W[t + 3];
+#if XINV_BIH_PREFETCH
+            W[6] = N0; W[7] = N1; W[8] = N2;
+            const Tri J0 = Jst[0], J1 = Jst[1], J2 = Jst[2];
+            N0 = load_row(srcS, base + 3); N1 = load_row(srcS, base + 4); N2 = load_row(srcS, base + 5);
+#else
+            W[6] = load_row(srcS, base); W[7] = load_row(srcS, base + 1); W[8] = load_row(srcS, base + 2);
+            const Tri J0 = Jst[0], J1 = Jst[1], J2 = Jst[2];
+#endif
+            Jst[0] = load_row(pJ, r + 3 - 2); Jst[1] = load_row(pJ, r + 3 - 4); Jst[2] = load_row(pJ, r + 3 - 6);
+            upd_row(std::integral_constant<int, 6>{}, r - 2, J0);   // class 0
+            upd_row(std::integral_constant<int, 4>{}, r - 4, J1);   // class 1
+            upd_row(std::integral_constant<int, 2>{}, r - 6, J2);   // class 2
+            retire(std::integral_constant<int, 0>{}, r - 8);
+            retire(std::integral_constant<int, 1>{}, r - 7);
+            retire(std::integral_constant<int, 2>{}, r - 6);
+        }
+    }
+
+    if (a.no_ctl) return;
+    xinv_norm_finalize<1, 4>(acc, cnt, wave, lane, NB, T, a.psum + (size_t)m * XINV_KMAX * NB,
+                             a.pcnt + (size_t)m * XINV_KMAX * NB, ctl, a.stop);
+}

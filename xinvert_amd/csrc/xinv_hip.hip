@@ -32,6 +32,7 @@
 #include "xinv_fused3d.h"
 #include "xinv_fused3dg.h"
 #include "xinv_fused9.h"
+#include "xinv_fusedbih.h"
 
 #define XINV_VERSION 100
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
@@ -105,6 +106,17 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     const bool fused5_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
     const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
                            (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
+    // biharmonic: the one-pass kernel needs A..I as per-row scalars (and xc % 3 == 0 when periodic)
+    bool fusedbih_ok = false;
+    if (p.kind == KIND_BIH2D) {
+        pl.umask = 0;
+        if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
+            rc = detect_xuniform(ws, st, p.c, p.sc, 10, p.nbatch, p.yc, p.xc, &pl.umask);
+            if (rc) return rc;
+        }
+        pl.um = pl.umask;
+        fusedbih_ok = ((pl.umask & 0x1ffu) == 0x1ffu) && (p.BCx != XINV_BC_PERIODIC || p.xc % 3 == 0);
+    }
     // general 3-D: the fused kernel exists for x-uniform coefficients only (every 3DOcean array)
     bool fused3g_ok = false;
     if (p.kind == KIND_GEN3D && !pl.seam && opt.path != XINV_PATH_COLOUR && !(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
@@ -112,15 +124,39 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         if (rc) return rc;
         fused3g_ok = (pl.umask == 0x7fu);
     }
-    const bool fused_ok = fused5_ok || fused9_ok || fused3g_ok;
+    const bool fused_ok = fused5_ok || fused9_ok || fused3g_ok || fusedbih_ok;
     pl.path = XINV_PATH_COLOUR;
     pl.nine = false;
     if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("no fused kernel for this form (odd-xc periodic seam, biharmonic, 9-point test form, or general 3-D with coefficients that vary along x)");
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam, 9-point test form, biharmonic or general 3-D with coefficients that vary along x)");
     if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 
+    if (pl.path == XINV_PATH_FUSED && p.kind == KIND_BIH2D) {
+        // biharmonic: one pass per sweep; row blocks of RB rows (multiple of 3) x 180-column strips,
+        // four consecutive wave-tiles per workgroup; RB from the (workgroups per CU) x (steps) model
+        pl.K = 1;
+        pl.aligned = false;
+        const int nstrip = (int)cdiv(p.xc, XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC));
+        int occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fusedbih<false>, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        int bestRB = 3; double best = 1e300;
+        for (int RB = 3; RB <= 192; RB += 3) {
+            if (opt.rows_per_tile > 0 && RB != std::max(3, (opt.rows_per_tile / 3) * 3)) continue;
+            const int64_t nrb = cdiv(p.yc, RB);
+            const int64_t wgs = (int64_t)cdiv((int64_t)nstrip * nrb, 4) * p.nbatch;
+            const int64_t cap = 256 * (int64_t)std::min(occ, 3);
+            const int64_t rounds = cdiv(wgs, cap);
+            const int64_t w_last = wgs - (rounds - 1) * cap;
+            const double last = (w_last <= 256) ? 1.3 : (double)cdiv(w_last, 256);
+            const double cost = ((double)(rounds - 1) * std::min(occ, 3) + last) * (double)(RB + 11 + 8);
+            if (cost < best) { best = cost; bestRB = RB; }
+        }
+        pl.RY = bestRB;
+        pl.nrb = (int)cdiv(p.yc, bestRB);
+        pl.nsg = (int)cdiv((int64_t)nstrip * pl.nrb, 4) + 1;
+    } else
     if (pl.path == XINV_PATH_FUSED && pl.nine) {
         // 9-point forms: 4-colour fused kernel, all coefficient arrays streamed
         pl.um = pl.umask = 0;
@@ -245,15 +281,6 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         }
     }
 
-    if (p.kind == KIND_BIH2D) {                       // x-uniform coefficient rows -> scalar loads
-        pl.umask = 0;
-        if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-            rc = detect_xuniform(ws, st, p.c, p.sc, 10, p.nbatch, p.yc, p.xc, &pl.umask);
-            if (rc) return rc;
-        }
-        pl.um = pl.umask;
-    }
-
     // ---- workspace ---------------------------------------------------------------------------
     rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)p.nbatch * sizeof(XinvCtl));
     if (rc) return rc;
@@ -311,7 +338,9 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             if (pl.path == XINV_PATH_FUSED) {
                 const int k = (max_sweeps - launched >= Kf) ? Kf : 1;
                 const int cur = (int)(bound.size() & 1);
-                r = (p.kind == KIND_GEN3D)
+                r = (p.kind == KIND_BIH2D)
+                        ? launch_fusedbih(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
+                    : (p.kind == KIND_GEN3D)
                         ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
                     : (p.kind == KIND_STD3D)
                         ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
@@ -370,7 +399,9 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             } else {                                     // stopped inside a K-sweep launch: redo
                 int cur = (int)(i & 1);
                 for (int64_t s = bound[i]; s < sw; s++) {
-                    rc = (p.kind == KIND_GEN3D)
+                    rc = (p.kind == KIND_BIH2D)
+                             ? launch_fusedbih(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
+                         : (p.kind == KIND_GEN3D)
                              ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
                          : (p.kind == KIND_STD3D)
                              ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)

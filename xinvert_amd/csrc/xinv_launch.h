@@ -259,6 +259,46 @@ static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, d
     return XINV_OK;
 }
 
+// ---- biharmonic one-pass launch (A..I x-uniform) ----------------------------------------------
+static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, double *dst,
+                           Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
+                           int no_ctl)
+{
+    const bool per = (p.BCx == XINV_BC_PERIODIC);
+    if (p.BCy == XINV_BC_EXTEND) {                   // the kernel's own pre-pass, on the source buffer
+        ExtendArgs e;
+        e.S = const_cast<double *>(src); e.sS = p.sS; e.yc = p.yc; e.xc = p.xc; e.kfirst = 0; e.nk = 1;
+        e.per = per; e.tall = (p.yc > p.xc); e.force = force;
+        e.undef = p.sc_.undef; e.ctl = ws->ctl;
+        for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
+            const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
+            e.member0 = member0 + m0;
+            hipLaunchKernelGGL(k_extend_bih, dim3(cdiv(p.xc, 256), 1, (unsigned)nm), dim3(256, 1, 1), 0, st, e);
+        }
+    }
+    FusedBihArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = src; a.dst = dst; a.sS = p.sS;
+    for (int q = 0; q < 10; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
+    a.yc = p.yc; a.xc = p.xc; a.per = per;
+    a.nstrip = (int)cdiv(p.xc, XINV_BIH_OWN(per)); a.nrb = pl.nrb; a.RB = pl.RY;
+    a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
+    a.force = force; a.no_ctl = no_ctl;
+    a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
+    const size_t NBmax = (size_t)pl.nsg;
+    a.psum = (unsigned long long *)ws->partials;
+    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
+    for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
+        const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
+        a.member0 = member0 + m0;
+        dim3 grid((unsigned)a.nwg, (unsigned)nm, 1), block(256, 1, 1);
+        if (per) hipLaunchKernelGGL(k_fusedbih<true>, grid, block, 0, st, a);
+        else     hipLaunchKernelGGL(k_fusedbih<false>, grid, block, 0, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return XINV_OK;
+}
+
 // ---- general 3-D fused launch (every coefficient array x-uniform) --------------------------------
 template <int NW>
 static void launch_fused3dg_nw(bool al, bool ext, dim3 grid, hipStream_t st, const Fused3GArgs &a)
