@@ -121,6 +121,9 @@ def main():
     S0 = torch.from_numpy(np.ascontiguousarray(p['S0'])).to(dev)
     S = S0.clone()
     coefs = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.float64)).to(dev) for c in p['coefs']]
+    # the cross coefficient B of invert_Poisson is identically zero: it travels as NULL, exactly as
+    # the front end (xinvert_amd/core.py:_prep_coef) hands it to the library
+    b_null = not np.asarray(p['coefs'][1]).any()
     strides = [n] + [0 if k in p['shared'] else n for k in range(len(coefs))]
     st = _lib.strides_arg(strides)
     flags = np.tile(np.array([0., 1., 0.]), (nb, 1))
@@ -131,7 +134,8 @@ def main():
 
     def step():
         rc = L.xinv_standard_2d_f64_dev(
-            ctypes.c_void_p(S.data_ptr()), *[ctypes.c_void_p(c.data_ptr()) for c in coefs],
+            ctypes.c_void_p(S.data_ptr()),
+            *[None if (k == 1 and b_null) else ctypes.c_void_p(c.data_ptr()) for k, c in enumerate(coefs)],
             nb, st, a.ny, a.nx, p['dely'], p['delx'], b(p['BCy']), b(p['BCx']), p['delxSqr'],
             p['ratioQtr'], p['ratioSqr'], p['optArg'], p['undef'], _lib.hptr(flags),
             a.sweeps - 1, 0.0, ctypes.byref(opt), sp)

@@ -646,7 +646,16 @@ def test_seeded_fuzz_against_the_oracle(chunk):
         if msk and kind in ('std2d', 'gen2d', 'std2dt') and int(rng.integers(2)):
             j0 = int(rng.integers(0, max(1, yc // 2))); i0 = int(rng.integers(0, max(1, xc // 2)))
             p = _blocky(p, rng, [(j0, yc, i0, xc)])
+        if int(rng.integers(2)):                   # coefficients constant along x: the streaming variants
+            if kind == 'bih2d':
+                p = _uniform_bih(p)
+            elif kind == 'gen3d':
+                p = _uniform3dg(p)
+            elif kind == 'std3d':
+                p = _uniform3d(p, None)
         opt = {}
+        if kind in ('bih2d', 'std3d', 'gen3d') and int(rng.integers(2)):
+            opt['rows_per_tile'] = [3, 9, 27][int(rng.integers(3))] if kind == 'bih2d' else [8, 12, 16][int(rng.integers(3))]
         if kind in ('std2d', 'gen2d', 'std2dt'):
             opt['sweeps_per_launch'] = int(rng.integers(0, 3))
             if yc >= 8 and int(rng.integers(2)):
