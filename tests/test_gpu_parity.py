@@ -481,13 +481,15 @@ def _uniform_bih(p):
 @pytest.mark.parametrize('BCx', ['fixed', 'periodic', 'extend'])
 @pytest.mark.parametrize('rows', [0, 3, 9])
 @pytest.mark.parametrize('shape', [(5, 9), (7, 12), (13, 183), (31, 366), (64, 543), (20, 72), (9, 180)])
-def test_biharmonic_one_pass_kernel(BCy, BCx, rows, shape):
+@pytest.mark.parametrize('bnz', [0, 1])
+def test_biharmonic_one_pass_kernel(BCy, BCx, rows, shape, bnz):
     """k_fusedbih: all nine colours of a sweep in one streaming pass (nine-row register window,
     ping-pong buffers): bit for bit the oracle's 9-colour order -- tile seams in both directions,
     first/last rows, masks, periodic wrap with the stale-index east columns, batch with early stop."""
     if BCx == 'periodic' and shape[1] % 3:
         pytest.skip('periodic x with xc % 3 != 0 runs the colour launches')
-    ps = [_uniform_bih(randbih(shape[0], shape[1], BCy, BCx, 1, 1, seed=_seed(('b1p', BCy, BCx, shape, m))))
+    # bnz = 0: B == E == 0 (no mixed derivatives, as in Munk): the variant that leaves those terms out
+    ps = [_uniform_bih(randbih(shape[0], shape[1], BCy, BCx, bnz, 1, seed=_seed(('b1p', BCy, BCx, shape, m, bnz))))
           for m in range(2)]
     S, fl, st = run_hip_batched(ps, 25, 1e-4, rows_per_tile=rows)
     assert st['path'] == PATH_FUSED and st['colours'] == 9 and st['xuniform_mask'] & 0x1ff == 0x1ff

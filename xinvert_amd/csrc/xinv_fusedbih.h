@@ -30,6 +30,55 @@
 
 #define XINV_BIH_OWN(per) ((per) ? 159 : 165)   /* owned columns: lanes 3..57 (5..57 when periodic) x 3 */
 
+// Point update of the one-pass kernel: every coefficient is a per-row scalar here, so the divide
+// -optArg / denominator (numbas.py:1474-1477) is the same for the whole row and comes in as `rq`.
+// ZBE: B and E are identically zero (Munk / Stommel-Munk on a Cartesian or lat-lon grid: no mixed
+// derivatives) -- their terms are exact zeros and are left out, with the diagonal operands they
+// would have needed (only the sign of a zero sum could differ; DESIGN.md section 2, "Arithmetic").
+template <bool ZBE>
+__device__ __forceinline__ double xinv_upd_bih2d_rq(
+    double p2_0, double p2_p2, double p2_b, double p1_0, double p1_p1, double p1_m1,
+    double r0_0, double r0_p1, double r0_m1, double r0_p2, double r0_m2, double r0_b,
+    double m1_0, double m1_p1, double m1_m1, double m2_0, double m2_p2, double m2_b,
+    double A, double B, double C, double D, double E, double F, double G, double H, double I,
+    double J, double rq, bool cond, bool edge, const XinvScal &sc)
+{
+    double gterm = G * (
+                       (p1_0 - m1_0)
+                   );
+    gterm = edge ? gterm * sc.delxTr / 2.0 * sc.ratio : gterm * sc.delxTr * sc.ratio / 2.0;
+    double temp = A * (
+            (p2_0 - 4.0*p1_0 + 6.0*r0_0 - 4.0*m1_0 + m2_0)
+        ) * sc.ratioSSr;
+    if (!ZBE)
+        temp = temp + B * (
+            (    p2_p2 - 2.0*p2_0 +     p2_b +
+            -2.0*r0_p2 + 4.0*r0_0 - 2.0*r0_b +
+                 m2_p2 - 2.0*m2_0 +     m2_b)
+        ) * sc.ratioSqr / 16.0;
+    temp = temp + C * (
+            (r0_p2 - 4.0*r0_p1 + 6.0*r0_0 - 4.0*r0_m1 + r0_m2)
+        );
+    temp = temp + D * (
+            (p1_0 - r0_0)-(r0_0 - m1_0)
+        ) * sc.ratioSqr * sc.delxSqr;
+    if (!ZBE)
+        temp = temp + E * (
+            (p1_p1 - m1_p1)-(p1_m1 - m1_m1)
+        ) * sc.ratioQtr * sc.delxSqr;
+    temp = temp + F * (
+            (r0_p1 - r0_0)-(r0_0 - r0_m1)
+        ) * sc.delxSqr;
+    temp = temp + gterm;
+    temp = temp + H * (
+            (r0_p1 - r0_m1)
+        ) * sc.delxTr / 2.0;
+    temp = temp + (
+        I * r0_0 - J) * sc.delxSSr;
+    temp *= rq;
+    return cond ? r0_0 + temp : r0_0;
+}
+
 struct FusedBihArgs {
     const double *src;
     double *dst;
@@ -51,7 +100,7 @@ struct FusedBihArgs {
 #ifndef XINV_BIH_MINWAVES
 #define XINV_BIH_MINWAVES 2
 #endif
-template <bool PER>
+template <bool PER, bool ZBE>
 __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArgs a)
 {
     constexpr int D = 9;
@@ -130,27 +179,34 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
             double cs[9];
 #pragma unroll
             for (int q = 0; q < 9; q++) cs[q] = cp[q][j * xc];     // one value per row
+            bool rowok = true;
+#pragma unroll
+            for (int q = 0; q < 9; q++) rowok = rowok && (cs[q] != u);
+            const double rq = -a.sc_.optArg / ((cs[0]*a.sc_.ratioSSr + cs[2]) * 6.0 +
+                                                 cs[1]*a.sc_.ratioSqr / 4.0 +
+                                               -(cs[3]*a.sc_.ratioSqr + cs[5]) * 2.0 * a.sc_.delxSqr +
+                                                 cs[8]*a.sc_.delxSSr);
             double em2[7], em1[7], ep1[7], ep2[7];
             bih_ext(W[SM2], em2); bih_ext(W[SM1], em1); bih_ext(W[SP1], ep1); bih_ext(W[SP2], ep2);
             double fm2[2] = {0.0, 0.0}, fp2[2] = {0.0, 0.0};
-            if (PER) { bih_far(W[SM2], fm2[0], fm2[1]); bih_far(W[SP2], fp2[0], fp2[1]); }
+            if (PER && !ZBE) { bih_far(W[SM2], fm2[0], fm2[1]); bih_far(W[SP2], fp2[0], fp2[1]); }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 double e0[7];
                 bih_ext(W[SJ], e0);
                 const int o = k + 2;
                 double p2_b = ep2[o - 2], r0_b = e0[o - 2], m2_b = em2[o - 2];
-                if (PER && k > 0) {
+                if (PER && !ZBE && k > 0) {
                     double f0[2];
                     bih_far(W[SJ], f0[0], f0[1]);
                     if (east[k]) { p2_b = fp2[k - 1]; r0_b = f0[k - 1]; m2_b = fm2[k - 1]; }
                 }
-                W[SJ].v[k] = xinv_upd_bih2d_v(
+                W[SJ].v[k] = xinv_upd_bih2d_rq<ZBE>(
                     ep2[o], ep2[o + 2], p2_b, ep1[o], ep1[o + 1], ep1[o - 1],
                     e0[o], e0[o + 1], e0[o - 1], e0[o + 2], e0[o - 2], r0_b,
                     em1[o], em1[o + 1], em1[o - 1], em2[o], em2[o + 2], m2_b,
                     cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[7], cs[8],
-                    Jt.v[k], upd[k], edge[k], a.sc_);
+                    Jt.v[k], rq, upd[k] && rowok && (Jt.v[k] != u), edge[k], a.sc_);
             }
         };
         auto retire = [&](auto stag, int64_t j) {

@@ -140,7 +140,17 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         pl.aligned = false;
         const int nstrip = (int)cdiv(p.xc, XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC));
         int occ = 1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fusedbih<false>, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        {   // no mixed derivatives (B == E == 0 everywhere)?  One flag pass over the two arrays.
+            HIPCHK(hipMemsetAsync(ws->dflag, 0, sizeof(int), st));
+            for (int q = 1; q <= 4; q += 3) {
+                const int64_t nb = (p.sc[q] == 0) ? n : (p.nbatch - 1) * p.sc[q] + n;
+                hipLaunchKernelGGL(k_any_nonzero, dim3(1024), dim3(256), 0, st, p.c[q], nb, ws->dflag);
+            }
+            HIPCHK(hipMemcpyAsync(ws->hflag, ws->dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            pl.bih_zbe = (*ws->hflag == 0) && (p.sc_.undef != 0.0);
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fusedbih<false, false>, 256, 0) != hipSuccess || occ < 1) occ = 1;
         int bestRB = 3; double best = 1e300;
         for (int RB = 3; RB <= 192; RB += 3) {
             if (opt.rows_per_tile > 0 && RB != std::max(3, (opt.rows_per_tile / 3) * 3)) continue;

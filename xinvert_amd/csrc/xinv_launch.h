@@ -10,6 +10,7 @@ struct Plan {
     int path, base, seam, ncol;
     int K, RY, nsg, nrb;     // nsg: 2-D = workgroups per member (partials sizing); 3-D = x strips
     int nkc, KC;             // 3-D: k chunks and planes per chunk
+    bool bih_zbe;            // biharmonic one-pass kernel: B and E identically zero (terms left out)
     bool aligned;
     unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
     unsigned um;             // the kernel variant's mask (subset of umask)
@@ -292,8 +293,13 @@ static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, 
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)a.nwg, (unsigned)nm, 1), block(256, 1, 1);
-        if (per) hipLaunchKernelGGL(k_fusedbih<true>, grid, block, 0, st, a);
-        else     hipLaunchKernelGGL(k_fusedbih<false>, grid, block, 0, st, a);
+        if (pl.bih_zbe) {
+            if (per) hipLaunchKernelGGL((k_fusedbih<true, true>), grid, block, 0, st, a);
+            else     hipLaunchKernelGGL((k_fusedbih<false, true>), grid, block, 0, st, a);
+        } else {
+            if (per) hipLaunchKernelGGL((k_fusedbih<true, false>), grid, block, 0, st, a);
+            else     hipLaunchKernelGGL((k_fusedbih<false, false>), grid, block, 0, st, a);
+        }
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;
