@@ -679,3 +679,53 @@ def test_seeded_fuzz_against_the_oracle(chunk):
             assert np.array_equal(S[0], So, equal_nan=True), what
         else:
             assert_same(S[0], fl[0], So, flo, what)
+
+
+@pytest.mark.parametrize('chunk', range(16))
+def test_seeded_fuzz_medium_grids(chunk):
+    """Larger seeded cases (hundreds of rows, several strips and row blocks, batches of two with a
+    shared coefficient stack): automatic tiling, masked-tile skipping, k chunks and the x-uniform
+    variants all engage on their own here."""
+    rng = np.random.default_rng(7000 + chunk)
+    for case in range(4):
+        kind = ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'][int(rng.integers(6))]
+        BCy = ['fixed', 'extend'][int(rng.integers(2))]
+        BCx = ['fixed', 'periodic'][int(rng.integers(2))]
+        seed = int(rng.integers(1 << 30))
+        uni = int(rng.integers(2))
+        if kind in ('std3d', 'gen3d'):
+            zc, yc, xc = int(rng.integers(20, 60)), int(rng.integers(30, 80)), 2 * int(rng.integers(60, 200))
+            mk = (lambda s: rand3d(zc, yc, xc, BCy, BCx, 1, seed=s)) if kind == 'std3d' else \
+                 (lambda s: rand3dg(zc, yc, xc, BCy, BCx, 1, seed=s))
+            un = (lambda q: _uniform3d(q, None)) if kind == 'std3d' else _uniform3dg
+        elif kind == 'bih2d':
+            yc, xc = int(rng.integers(60, 300)), 3 * int(rng.integers(60, 400))
+            mk = lambda s: randbih(yc, xc, BCy, BCx, int(rng.integers(2)), 1, seed=s)
+            un = _uniform_bih
+        else:
+            yc, xc = int(rng.integers(100, 400)), 2 * int(rng.integers(100, 700))
+            mk = (lambda s: rand2dt(yc, xc, BCy, BCx, 0, 1, seed=s)) if kind == 'std2dt' else \
+                 (lambda s: rand2d(kind, yc, xc, BCy, BCx, 0, 1, seed=s))
+            un = None
+        ps = [mk(seed), mk(seed + 1)]
+        if kind in ('std2d', 'gen2d', 'std2dt'):
+            ps = [_blocky(q, rng, [(0, yc // 2, 0, xc // 3), (yc // 2, yc, xc // 2, xc)]) for q in ps]
+            if uni:                                   # latitude-only coefficients
+                ps = [dict(q, coefs=[np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape))
+                                     if k < len(q['coefs']) - 1 else c for k, c in enumerate(q['coefs'])])
+                      for q in ps]
+        elif uni:
+            ps = [un(q) for q in ps]
+        for k in range(len(ps[0]['coefs']) - 1):      # one coefficient stack for both members
+            ps[1]['coefs'][k] = ps[0]['coefs'][k]
+        shared = tuple(range(len(ps[0]['coefs']) - 1))
+        nsw = int(rng.integers(2, 8))
+        opt = {'force_tile_skip': 1} if kind in ('std2d', 'gen2d', 'std2dt') and int(rng.integers(2)) else {}
+        S, fl, st = run_hip_batched(ps, nsw, 0.0, shared=shared, **opt)
+        for m, q in enumerate(ps):
+            So, flo = run_oracle(q, nsw, 0.0, COLOUR_AUTO)
+            what = 'medium fuzz %d/%d %s %r %s %s uni=%d member %d %r' % (chunk, case, kind, q['S0'].shape, BCy, BCx, uni, m, st)
+            if np.isnan(So).any():
+                assert np.array_equal(S[m], So, equal_nan=True), what
+            else:
+                assert_same(S[m], fl[m], So, flo, what)

@@ -299,6 +299,8 @@ struct ColourArgsBih {
     XinvScal sc_;
     const XinvCtl *ctl;
     unsigned umask;            // bit q: coefficient array q is constant along x (scalar per row)
+    double *Y;                 // row-class kernel: where the rows of this class are written (see there)
+    int64_t sY;
 };
 
 // One wavefront per row (block = 64 x 4): with UNI the row index is made wave-uniform so the
@@ -368,6 +370,11 @@ __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
 // every stage.  Two lanes on each side are halo (each later colour needs the earlier colours two
 // columns away), so a strip owns 180 columns.  Same ordering as nine separate colour launches
 // (bitwise equal), one third of the launches and of the passes over S.
+// NOT in place: the halo lanes of a strip read columns of row j that the neighbouring strip's
+// wavefront updates in the same launch, so the updated rows go to a side buffer Y (every owned
+// column, updatable or not) and later launches of the sweep read a neighbour row from Y when its
+// class has already run (rows 2..yc-3 of a lower class), from S otherwise; k_rows_copy_back moves
+// rows 2..yc-3 of Y into S after the third launch.
 // Periodic x (xc % 3 == 0, so that the wrap keeps colour == column % 3): the lane->column map
 // wraps, the first/last two columns take the periodic branches' G-term association, and the two
 // east columns read the B term's west operand FIVE columns away (the reference's stale loop index,
@@ -401,7 +408,8 @@ __global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
     if (j > yc - 3) return;
     const int64_t c = strip * 180 - 6 + 3 * lane;              // unwrapped first column (c % 3 == 0)
     if (strip * 180 >= xc) return;
-    double *S = a.S + m * a.sS;
+    const double *S = a.S + m * a.sS;
+    double *Y = a.Y + m * a.sY;
     int64_t lcol[3];
     bool upd[3], own[3], edge[3], east[3];
 #pragma unroll
@@ -413,18 +421,20 @@ __global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
             upd[k] = true;
             edge[k] = (w < 2) || (w >= xc - 2);
             east[k] = (w >= xc - 2);
-            own[k] = (cc >= 0) && (cc < xc) && (lane >= 2) && (lane < 62);
         } else {
             lcol[k] = cc < 0 ? 0 : (cc > xc - 1 ? xc - 1 : cc);
             upd[k] = (cc >= 2) && (cc <= xc - 3);
             edge[k] = false; east[k] = false;
-            own[k] = upd[k] && (lane >= 2) && (lane < 62);
         }
+        own[k] = (cc >= 0) && (cc < xc) && (lane >= 2) && (lane < 62);
     }
     Tri R[5];                                                   // rows j-2 .. j+2
 #pragma unroll
     for (int q = 0; q < 5; q++) {
-        const double *row = S + (j - 2 + q) * xc;
+        const int64_t jr = j - 2 + q;
+        // a row of a lower class has been rewritten in this sweep: its current values are in Y
+        const bool newer = (jr >= 2) && (jr <= yc - 3) && ((int)(jr % 3) < cj);
+        const double *row = (newer ? (const double *)Y : S) + jr * xc;
 #pragma unroll
         for (int k = 0; k < 3; k++) R[q].v[k] = row[lcol[k]];
     }
@@ -464,7 +474,21 @@ __global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
     }
 #pragma unroll
     for (int k = 0; k < 3; k++)
-        if (own[k]) S[j * xc + lcol[k]] = R[2].v[k];
+        if (own[k]) Y[j * xc + lcol[k]] = R[2].v[k];
+}
+
+// rows 2..yc-3 of the side buffer back into S (after the three row-class launches of a sweep)
+__global__ __launch_bounds__(256) void k_rows_copy_back(const double *Y, int64_t sY, double *S, int64_t sS,
+                                                        int64_t yc, int64_t xc, const XinvCtl *ctl,
+                                                        int64_t member0, int force)
+{
+    const int64_t m = member0 + blockIdx.y;
+    if (!force && ctl[m].done) return;
+    const int64_t n = (yc - 4) * xc;
+    const double *y = Y + m * sY + 2 * xc;
+    double *s = S + m * sS + 2 * xc;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        s[t] = y[t];
 }
 
 // 'extend' pre-pass of the biharmonic kernel (numbas.py:1299-1343): one thread per column.

@@ -308,6 +308,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     rc = ensure_dev(&ws->partials, &ws->partials_cap, pbytes);
     if (rc) return rc;
     double *S2 = nullptr;
+    if (pl.path == XINV_PATH_COLOUR && p.kind == KIND_BIH2D) {       // side buffer of the row-class kernel
+        rc = ensure_dev(&ws->S2, &ws->S2_cap, (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double));
+        if (rc) return rc;
+    }
     if (pl.path == XINV_PATH_FUSED) {
         const size_t need = (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double);
         rc = ensure_dev(&ws->S2, &ws->S2_cap, need);

@@ -371,6 +371,7 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
             // one launch per row class does its three column colours in registers (periodic x needs
             // xc % 3 == 0 so that the wrap keeps colour == column % 3; otherwise nine + trailing colours)
             dim3 gb(cdiv(cdiv(p.xc, 180), 4), cdiv(p.yc, 3) + 1, (unsigned)nm), bb(256, 1, 1);
+            a.Y = ws->S2; a.sY = p.sS;                     // side buffer (allocated by solve_dev for this path)
             for (int cj = 0; cj < 3; cj++) {
                 a.colour = cj;
                 if (per) {
@@ -381,6 +382,9 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
                     else          hipLaunchKernelGGL((k_bih_rowclass<false, false>), gb, bb, 0, st, a);
                 }
             }
+            hipLaunchKernelGGL(k_rows_copy_back, dim3(256, (unsigned)nm, 1), dim3(256), 0, st,
+                               (const double *)ws->S2, p.sS, p.S, p.sS, p.yc, p.xc,
+                               (const XinvCtl *)ws->ctl, m0, 0);
         } else
         for (int cc = 0; cc < pl.ncol; cc++) {
             a.colour = cc;
