@@ -543,6 +543,43 @@ def test_full_size_c5_omega_volume():
     assert below.mean() > 0.01 and (S1[0][below] == q['S0'][below]).all()
 
 
+def test_full_size_c3_munk_three_launch_schemes():
+    """BASELINE configs[2], Munk branch, 2000 x 2000: the one-pass kernel, the row-class kernel
+    (x-uniform detection off) and nothing-fused must agree bit for bit -- twelve strips, seventy-odd
+    row blocks: the size at which a cross-strip race would show."""
+    from xinvert_amd import synthetic
+    p = synthetic.munk_cartesian(2000, 2000)
+    q = synthetic.member(p, 0)
+    S1, f1, s1 = util.run_hip_dev([q], 5, 0.0)
+    S2, f2, s2 = util.run_hip_dev([q], 5, 0.0, no_xuniform=1)
+    S3, f3, s3 = util.run_hip_dev([q], 5, 0.0, path=1)
+    assert s1['path'] == 2 and s2['path'] == 1 and s2['xuniform_mask'] == 0 and s3['path'] == 1
+    assert np.array_equal(S1, S2) and np.array_equal(S1, S3)
+    assert np.allclose(f1, f2, rtol=1e-9, atol=1e-12)
+    # a periodic variant (xc % 3 == 0 keeps the fast kernels; the east columns use the stale index)
+    r = dict(q); r['BCx'] = 'periodic'; r['xc'] = 1998
+    r['S0'] = np.ascontiguousarray(q['S0'][:, :1998]); r['coefs'] = [np.ascontiguousarray(c[:, :1998]) for c in q['coefs']]
+    P1, _, t1 = util.run_hip_dev([r], 5, 0.0)
+    P2, _, t2 = util.run_hip_dev([r], 5, 0.0, no_xuniform=1)
+    assert t1['path'] == 2 and t2['path'] == 1 and np.array_equal(P1, P2)
+
+
+def test_full_size_nine_point_and_general_3d_paths():
+    """2000 x 2000 9-point forms (fused 4-colour kernel vs colour launches) and a 50 x 360 x 720
+    general 3-D volume (k_fused3dg vs colour launches): bit for bit."""
+    from xinvert_amd import synthetic
+    for kind in ('std2d', 'gen2d'):
+        q = util.rand2d(kind, 2000, 2000, 'fixed', 'fixed', 1, 1, seed=77)
+        S1, f1, s1 = util.run_hip_dev([q], 5, 0.0)
+        S2, f2, s2 = util.run_hip_dev([q], 5, 0.0, path=1)
+        assert s1['path'] == 2 and s1['colours'] == 4 and s2['path'] == 1 and np.array_equal(S1, S2)
+    p = synthetic.ocean3d_latlon(50, 360, 720, 1)
+    q = synthetic.member(p, 0)
+    S1, f1, s1 = util.run_hip_dev([q], 5, 0.0)
+    S2, f2, s2 = util.run_hip_dev([q], 5, 0.0, path=1)
+    assert s1['path'] == 2 and s1['xuniform_mask'] == 0x7f and s2['path'] == 1 and np.array_equal(S1, S2)
+
+
 def test_abs_norm_dev():
     import ctypes
     import torch
