@@ -704,8 +704,9 @@ def test_seeded_fuzz_medium_grids(chunk):
             un = _uniform_bih
         else:
             yc, xc = int(rng.integers(100, 400)), 2 * int(rng.integers(100, 700))
-            mk = (lambda s: rand2dt(yc, xc, BCy, BCx, 0, 1, seed=s)) if kind == 'std2dt' else \
-                 (lambda s: rand2d(kind, yc, xc, BCy, BCx, 0, 1, seed=s))
+            bnz = int(rng.integers(2))                 # 1: cross terms -> 4-colour kernels
+            mk = (lambda s: rand2dt(yc, xc, BCy, BCx, bnz, 1, seed=s)) if kind == 'std2dt' else \
+                 (lambda s: rand2d(kind, yc, xc, BCy, BCx, bnz, 1, seed=s))
             un = None
         ps = [mk(seed), mk(seed + 1)]
         if kind in ('std2d', 'gen2d', 'std2dt'):
