@@ -465,10 +465,18 @@ def _mask_FS(F, dims, iParams, icbc):
     else:
         mvals = np.where(vals != undef, vals, _undeftmp)
     maskF = F.like(mvals)
-    zero = mvals - mvals
+    # `zero = maskF - maskF` of the reference: all zeros unless the forcing holds an infinity or (with
+    # a value-undef) a NaN, which then turn into NaN.  Finite input is the rule: one cheap check
+    # replaces two passes over the array and a copy.
+    if np.isfinite(mvals).all():
+        zero = np.zeros_like(mvals)
+        zinit = np.zeros_like(mvals)
+    else:
+        zero = mvals - mvals
+        zinit = zero.copy()
 
     if icbc is None:
-        initS = F.like(zero.copy())
+        initS = F.like(zinit)
     else:
         mask = mvals == _undeftmp
         for dim, BC in zip(dims, iParams['BCs']):
