@@ -524,6 +524,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         return XINV_OK;                                   // small problems: nothing to balance
     const int64_t yc = p.yc, nb = p.nbatch;
     const int64_t cells = yc * nstrip;
+    if (nb * nstrip * (yc + 1) > (int64_t)50000000) return XINV_OK;   // host-side prefix table would exceed 200 MB
     const int fi = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_GEN2D ? 6 : 5);     // the forcing
 
     int rc = ensure_dev(&ws->d_act, &ws->d_act_cap, (size_t)(nb * cells));
