@@ -580,6 +580,18 @@ def test_full_size_nine_point_and_general_3d_paths():
     assert s1['path'] == 2 and s1['xuniform_mask'] == 0x7f and s2['path'] == 1 and np.array_equal(S1, S2)
 
 
+def test_larger_than_baseline_grid():
+    """Four times the BASELINE grid (7200 x 3600, 26 M points, land mask): tall tiles, many strips,
+    masked-tile skipping re-planned -- K = 2 with skipping == K = 1 without, bit for bit."""
+    from xinvert_amd import synthetic
+    p = synthetic.poisson_latlon(3600, 7200, mask=True)
+    q = synthetic.member(p, 0)
+    S2, f2, s2 = util.run_hip_dev([q], 9, 0.0, sweeps_per_launch=2)
+    S1, f1, s1 = util.run_hip_dev([q], 9, 0.0, sweeps_per_launch=1, no_tile_skip=1)
+    assert s2['masked_tile_pct'] >= 15 and s1['masked_tile_pct'] == 0
+    assert np.array_equal(S1, S2) and np.allclose(f1, f2, rtol=1e-9, atol=1e-12)
+
+
 def test_abs_norm_dev():
     import ctypes
     import torch
