@@ -592,6 +592,37 @@ def test_larger_than_baseline_grid():
     assert np.array_equal(S1, S2) and np.allclose(f1, f2, rtol=1e-9, atol=1e-12)
 
 
+def test_integration_md_ctypes_stub_runs():
+    """The ctypes stub INTEGRATION.md tells a maintainer of the reference to add (xinvert/hipbind.py)
+    is executed as written -- only the library path is filled in -- and must reproduce the oracle."""
+    import os
+    import re
+    from xinvert_amd import _lib
+    _lib.require_gpu()                                   # torch first, then the library (single HIP runtime)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, 'INTEGRATION.md')).read()
+    code = re.search(r"```python\n(# xinvert/hipbind.py.*?)```", md, re.S).group(1)
+    code = code.replace("ctypes.CDLL('libxinv_hip.so')", "ctypes.CDLL(%r)" % _lib.SO)
+    ns = {}
+    exec(compile(code, 'hipbind.py', 'exec'), ns)
+    for kind, fn in (('std2d', 'invert_standard_2D'), ('gen2d', 'invert_general_2D'), ('std3d', 'invert_standard_3D')):
+        q = util.rand3d(6, 12, 20, 'fixed', 'periodic', 1, seed=9) if kind == 'std3d' else \
+            util.rand2d(kind, 24, 40, 'extend', 'periodic', 0, 1, seed=9)
+        So, flo = util.run_oracle(q, 15, 1e-9, AUTO)
+        S = q['S0'].copy(); fl = np.array([0., 1., 0.])
+        c = [a.copy() for a in q['coefs']]
+        if kind == 'std2d':
+            ns[fn](S, *c, q['yc'], q['xc'], q['dely'], q['delx'], q['BCy'], q['BCx'], q['delxSqr'],
+                   q['ratioQtr'], q['ratioSqr'], q['optArg'], q['undef'], fl, 15, 1e-9)
+        elif kind == 'gen2d':
+            ns[fn](S, *c, q['yc'], q['xc'], q['dely'], q['delx'], q['BCy'], q['BCx'], q['delxSqr'], q['ratio'],
+                   q['ratioQtr'], q['ratioSqr'], q['optArg'], q['undef'], fl, 15, 1e-9)
+        else:
+            ns[fn](S, *c, q['zc'], q['yc'], q['xc'], q['delz'], q['dely'], q['delx'], q['BCz'], q['BCy'], q['BCx'],
+                   q['delxSqr'], q['ratio2Sqr'], q['ratio1Sqr'], q['optArg'], q['undef'], fl, 15, 1e-9)
+        assert np.array_equal(S, So) and fl[2] == flo[2], kind
+
+
 def test_abs_norm_dev():
     import ctypes
     import torch
