@@ -623,6 +623,21 @@ def test_integration_md_ctypes_stub_runs():
         assert np.array_equal(S, So) and fl[2] == flo[2], kind
 
 
+def test_converged_half_degree_poisson_vs_reference_ordering():
+    """north_star's acceptance criterion at a mid size: invert_Poisson on a 0.5-degree masked lat-lon
+    grid (360 x 720, fixed / periodic) run to convergence on the GPU (red-black, masked tiles skipped)
+    against the reference's lexicographic ordering (oracle) run to convergence: rel-L2 <= 1e-6."""
+    from xinvert_amd import synthetic
+    p = synthetic.poisson_latlon(360, 720, mask=True)
+    q = synthetic.member(p, 0)
+    S, fl, st = util.run_hip_dev([q], 20000, 1e-13)
+    Sl, fll = util.run_oracle(q, 20000, 1e-13, LEX)
+    assert fl[0][2] < 20000 and fll[2] < 20000 and st['path'] == 2
+    ok = q['coefs'][3] != U
+    assert util.rel_l2(S[0][ok], Sl[ok]) < 1e-6
+    assert (S[0][~ok] == 0).all()
+
+
 def test_abs_norm_dev():
     import ctypes
     import torch
