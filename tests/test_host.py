@@ -238,6 +238,14 @@ def test_batch_layout_and_shared_coefficients():
     assert all(st == 0 for st in B.strides)
 
 
+def test_empty_batch_axis_is_a_no_op():
+    """An empty non-core axis: the reference's `for selDict in loop_noncore(...)` body never runs and S
+    comes back untouched -- no library call (and so no GPU needed) here either."""
+    F = Field(np.zeros((0, 6, 8)), ('time', 'lat', 'lon'), {'lat': np.linspace(-50, 50, 6), 'lon': np.arange(8) * 45.})
+    S = apps.invert_Poisson(F, ['lat', 'lon'], iParams={'BCs': ['fixed', 'periodic'], 'printInfo': False})
+    assert S.shape == (0, 6, 8)
+
+
 def test_info_line_format():
     assert core._info({'time': np.float64(3.0)}) == '{time: 3.0}'
     assert core._info({}) == '{}'

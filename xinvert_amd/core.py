@@ -127,13 +127,15 @@ def _info(sel):
 
 
 def _solve(kind, coefs, F, S, dims, iParams):
-    L = _lib.require_gpu()
     if not isinstance(F, Field) or not isinstance(S, Field):
         raise Exception('forcing and solution must be Field objects (see xinvert_amd.field)')
     perm, bdims, bshape = _batch_layout(F, dims)
     core_shape = tuple(F.shape[F.axis(d)] for d in dims)
     nbatch = int(np.prod(bshape)) if bshape else 1
     n = int(np.prod(core_shape))
+    if nbatch == 0:                # an empty non-core axis: the reference's loop_noncore yields nothing
+        return S
+    L = _lib.require_gpu()
 
     Sv = np.ascontiguousarray(np.transpose(np.asarray(S.values, dtype=np.float64), perm)
                               ).reshape((nbatch,) + core_shape)
