@@ -352,6 +352,25 @@ def test_row_constant_coefficients_travel_as_rows(kind):
         assert_same(S[m], fl[m], So, flo, 'rowconst member %d' % m)
 
 
+@pytest.mark.parametrize('kind,per,bnz', [('gen2d', 'periodic', 0), ('std2d', 'fixed', 1), ('std2d', 'periodic', 0), ('bih2d', 'fixed', 1)])
+def test_graph_replay_equals_plain_launches(kind, per, bnz, monkeypatch):
+    """Small problems replay a captured chunk of sweep launches (hipGraph): same bits, same loop
+    counts as plain launches -- colour path with the odd-width seam, fused 4-colour, fused
+    red-black, biharmonic; members stopping at different sweeps inside replayed chunks."""
+    xc = 251 if (kind == 'gen2d') else 144
+    mk = (lambda s: randbih(40, xc, 'fixed', per, bnz, 1, seed=s)) if kind == 'bih2d' else \
+         (lambda s: rand2d(kind, 73, xc, 'fixed', per, bnz, 1, seed=s))
+    ps = [mk(s) for s in (1, 2, 3)]
+    out = {}
+    for g in ('0', '1'):
+        monkeypatch.setenv('XINV_GRAPH', g)
+        out[g] = run_hip_batched(ps, 3000, 1e-7, check_every=16)
+    S0, f0, _ = out['0']; S1, f1, _ = out['1']
+    assert np.array_equal(S0, S1, equal_nan=True) and np.array_equal(f0, f1, equal_nan=True)
+    So, flo = run_oracle(ps[1], 3000, 1e-7, COLOUR_AUTO)
+    assert np.array_equal(S1[1], So, equal_nan=True) and f1[1][2] == flo[2]
+
+
 def test_dev_api_matches_host_api():
     ps = [rand2d('std2d', 48, 280, 'fixed', 'periodic', 0, 1, seed=s) for s in (1, 2, 3)]
     S1, f1, _ = run_hip_batched(ps, 40, 1e-7)

@@ -345,27 +345,71 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     // Polling is pipelined: chunk c+1 is queued BEFORE the host waits for chunk c's copy, so the
     // GPU never idles on the host's reaction time; once every member has stopped, the launches
     // already queued are no-ops (each kernel returns on ctl.done).
+    // one sweep launch (fused: K sweeps from buf[cur] into buf[cur^1]; colour path: one sweep in place)
+    auto launch_one = [&](hipStream_t s, int cur, int k) -> int {
+        if (pl.path != XINV_PATH_FUSED) return launch_colour_sweep(p, pl, ws, s);
+        return (p.kind == KIND_BIH2D)
+                   ? launch_fusedbih(p, pl, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
+               : (p.kind == KIND_GEN3D)
+                   ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
+               : (p.kind == KIND_STD3D)
+                   ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
+               : pl.nine
+                   ? launch_fused9(p, pl, k, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
+                   : launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0);
+    };
+    // Small problems are bound by the host's launch rate (a 151x251 coloured sweep is six launches
+    // of 2-3 us each): a full chunk is captured once into a hipGraph on an engine-owned stream and
+    // replayed into the caller's stream.  The chunk has an even number of launches, so the
+    // ping-pong parity at its start is always 0.
+    struct GraphHolder {
+        hipGraphExec_t exec = nullptr;
+        ~GraphHolder() { if (exec) (void)hipGraphExecDestroy(exec); }
+    } gh;
+    bool use_graph = false;
+    {
+        const char *e = getenv("XINV_GRAPH");
+        const double est_launch_us = (double)p.nbatch * (double)n * Kf /
+                                     ((pl.path == XINV_PATH_FUSED) ? 2.0e5 : 4.0e4);
+        const bool want = e ? (atoi(e) != 0) : (est_launch_us < 12.0);
+        if (want && max_sweeps >= 2 * (int64_t)check_every * Kf) {
+            check_every = (check_every + 1) & ~1;
+            if (!ws->gstream) HIPCHK(hipStreamCreateWithFlags(&ws->gstream, hipStreamNonBlocking));
+            hipGraph_t g = nullptr;
+            if (hipStreamBeginCapture(ws->gstream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                int r = XINV_OK;
+                for (int i = 0; i < check_every && r == XINV_OK; i++) r = launch_one(ws->gstream, i & 1, Kf);
+                const hipError_t ce = hipStreamEndCapture(ws->gstream, &g);
+                if (r == XINV_OK && ce == hipSuccess && g &&
+                    hipGraphInstantiate(&gh.exec, g, nullptr, nullptr, 0) == hipSuccess)
+                    use_graph = true;
+                if (g) (void)hipGraphDestroy(g);
+            }
+            (void)hipGetLastError();                       // a failed capture falls back to plain launches
+        }
+    }
     auto issue_chunk = [&](int slot) -> int {
         if (opt.timing) HIPCHK(hipEventRecord(ws->ev0[slot], st));
+        if (use_graph && max_sweeps - launched >= (int64_t)check_every * Kf &&
+            (pl.path != XINV_PATH_FUSED || (bound.size() & 1) == 0)) {
+            HIPCHK(hipGraphLaunch(gh.exec, st));
+            for (int i = 0; i < check_every; i++) {
+                if (pl.path == XINV_PATH_FUSED) bound.push_back(launched);
+                launched += Kf;
+                nlaunch++;
+            }
+        } else
         for (int i = 0; i < check_every && launched < max_sweeps; i++) {
             int r;
             if (pl.path == XINV_PATH_FUSED) {
                 const int k = (max_sweeps - launched >= Kf) ? Kf : 1;
                 const int cur = (int)(bound.size() & 1);
-                r = (p.kind == KIND_BIH2D)
-                        ? launch_fusedbih(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
-                    : (p.kind == KIND_GEN3D)
-                        ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
-                    : (p.kind == KIND_STD3D)
-                        ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
-                    : pl.nine
-                        ? launch_fused9(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0)
-                        : launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, st, 0, p.nbatch, 0, 0);
+                r = launch_one(st, cur, k);
                 if (r) return r;
                 bound.push_back(launched);
                 launched += k;
             } else {
-                r = launch_colour_sweep(p, pl, ws, st);
+                r = launch_one(st, 0, 1);
                 if (r) return r;
                 launched += 1;
             }

@@ -34,6 +34,7 @@ struct Workspace {
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
     int *hflag = nullptr;
     hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
+    hipStream_t gstream = nullptr;                      // capture stream for the small-problem hipGraph
     // masked-tile skipping
     unsigned char *d_act = nullptr; size_t d_act_cap = 0;
     unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
