@@ -519,6 +519,35 @@ def test_biharmonic_one_pass_kernel(BCy, BCx, rows, shape, bnz):
     assert stc['path'] == PATH_COLOUR and np.array_equal(S, Sc) and np.array_equal(fl[:, 2], flc[:, 2])
 
 
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('BCx', ['fixed', 'periodic'])
+@pytest.mark.parametrize('rows', [3, 9, 12])
+def test_biharmonic_one_pass_skips_masked_tiles(BCy, BCx, rows):
+    """Masked-tile skipping in k_fusedbih (land in an ocean Munk problem): tiles whose forcing is
+    undefined throughout are left out, their norm share is constant -- bit for bit the oracle and the
+    run that visits every tile; a last row block of a single row with 'extend' (rows yc-2, yc-1 sit
+    in two different blocks)."""
+    rng = np.random.default_rng(_seed(('bskip', BCy, BCx, rows)))
+    yc, xc = 3 * 13 + 1, 3 * 170
+    ps = []
+    for m in range(2):
+        q = _uniform_bih(randbih(yc, xc, BCy, BCx, 0, 1, seed=_seed(('bskip', m))))
+        J = q['coefs'][9]
+        J[: yc // 2, : xc // 2] = util.U
+        if m == 1:
+            J[yc // 2:, 200:] = util.U
+        q['S0'][: yc // 2, : xc // 2] = np.where(rng.random((yc // 2, xc // 2)) < 0.2, util.U, 0.5)
+        ps.append(q)
+    S, fl, st = run_hip_batched(ps, 30, 1e-5, rows_per_tile=rows, force_tile_skip=1)
+    # ('extend' keeps the first and the last two row blocks active: with 12-row blocks nothing is left to skip)
+    assert st['path'] == PATH_FUSED and (st['masked_tile_pct'] > 0 or (BCy == 'extend' and rows == 12))
+    S0, fl0, st0 = run_hip_batched(ps, 30, 1e-5, rows_per_tile=rows, no_tile_skip=1)
+    assert st0['masked_tile_pct'] == 0 and np.array_equal(S, S0) and np.array_equal(fl[:, 2], fl0[:, 2])
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 30, 1e-5, COLOUR_AUTO)
+        assert_same(S[m], fl[m], So, flo, 'bih skip member %d' % m)
+
+
 def test_biharmonic_batched_dev():
     ps = [randbih(16, 33, 'extend', 'periodic', 1, 1, seed=s) for s in (3, 4)]
     S1, f1, _ = run_hip_batched(ps, 20, 1e-7)

@@ -630,6 +630,7 @@ struct SkipNormArgs {
     const double *S;
     int64_t sS, yc, xc;
     int nstrip, nrb, UW;
+    int RB;                    // > 0: row blocks of exactly RB rows (biharmonic kernel); 0: even split
     double undef;
     const int *skip_list;      // [nbatch][nskip_max] wave-tile ids, -1 = none
     int nskip_max;
@@ -647,8 +648,14 @@ __global__ __launch_bounds__(64) void k_skip_norm_tile(SkipNormArgs a)
     double acc = 0.0; long long cnt = 0;
     if (wt >= 0) {
         const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
-        const int64_t yu0 = (((int64_t)rb * a.yc) / a.nrb) & ~(int64_t)1;
-        const int64_t yu1 = (rb + 1 == a.nrb) ? a.yc : ((((int64_t)(rb + 1) * a.yc) / a.nrb) & ~(int64_t)1);
+        int64_t yu0, yu1;
+        if (a.RB > 0) {
+            yu0 = (int64_t)rb * a.RB;
+            yu1 = (yu0 + a.RB < a.yc) ? yu0 + a.RB : a.yc;
+        } else {
+            yu0 = (((int64_t)rb * a.yc) / a.nrb) & ~(int64_t)1;
+            yu1 = (rb + 1 == a.nrb) ? a.yc : ((((int64_t)(rb + 1) * a.yc) / a.nrb) & ~(int64_t)1);
+        }
         const int64_t c0 = (int64_t)strip * a.UW;
         const int64_t c1 = (c0 + a.UW < a.xc) ? c0 + a.UW : a.xc;
         const double *S = a.S + m * a.sS;

@@ -95,6 +95,10 @@ struct FusedBihArgs {
     XinvStop stop;
     unsigned long long *psum;  // [nbatch][XINV_KMAX][NB]
     long long *pcnt;
+    const int *tile_list;      // masked-tile skipping, as FusedArgs
+    int ntl;
+    const double *xsum;
+    const long long *xcnt;
 };
 
 #ifndef XINV_BIH_MINWAVES
@@ -115,8 +119,12 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
         T = xcd * q + (xcd < rem ? xcd : rem) + idx;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wt = T * 4 + wave;
-    const bool active = wt < a.nstrip * a.nrb;
+    int wt = T * 4 + wave;
+    bool active = wt < a.nstrip * a.nrb;
+    if (a.tile_list) {
+        wt = a.tile_list[m * a.ntl + wt];
+        active = wt >= 0;
+    }
     const int rb = active ? wt / a.nstrip : 0, strip = active ? wt - rb * a.nstrip : 0;
     const int64_t xc = a.xc, yc = a.yc;
     const int64_t y0 = (int64_t)rb * a.RB;
@@ -261,5 +269,6 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
 
     if (a.no_ctl) return;
     xinv_norm_finalize<1, 4>(acc, cnt, wave, lane, NB, T, a.psum + (size_t)m * XINV_KMAX * NB,
-                             a.pcnt + (size_t)m * XINV_KMAX * NB, ctl, a.stop);
+                             a.pcnt + (size_t)m * XINV_KMAX * NB, ctl, a.stop,
+                             a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
 }

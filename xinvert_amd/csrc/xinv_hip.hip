@@ -166,6 +166,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         pl.RY = bestRB;
         pl.nrb = (int)cdiv(p.yc, bestRB);
         pl.nsg = (int)cdiv((int64_t)nstrip * pl.nrb, 4) + 1;
+        if (!(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
+            rc = plan_tile_skip(p, pl, ws, st, opt, bestRB, XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC));
+            if (rc) return rc;
+        }
     } else
     if (pl.path == XINV_PATH_FUSED && pl.nine) {
         // 9-point forms: 4-colour fused kernel, all coefficient arrays streamed

@@ -289,6 +289,15 @@ static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, 
     const size_t NBmax = (size_t)pl.nsg;
     a.psum = (unsigned long long *)ws->partials;
     a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
+    if (pl.skip) {                                   // fully masked tiles are left out (plan_tile_skip)
+        a.tile_list = ws->d_list;
+        a.ntl = pl.ntl;
+        a.nwg = pl.ntl / 4;
+        char *base = (char *)ws->d_tsum;
+        const size_t nt = (size_t)p.nbatch * pl.nskip;
+        a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
+        a.xcnt = (const long long *)(base + nt * (sizeof(double) + sizeof(long long)) + p.nbatch * sizeof(double));
+    }
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
@@ -513,19 +522,21 @@ static double tile_cost(int64_t wgs, int64_t rows, int K, int occ)
 // reference tests the forcing), so launches run the other tiles only; the row split is re-chosen
 // so that the ACTIVE tiles fill the CUs evenly, and the skipped tiles' constant share of the norm
 // is computed once.  Decided per solve from one pass over the forcing.
+// `fixedRB` > 0 (biharmonic one-pass kernel): tiles are row blocks of exactly fixedRB rows x `UW_` owned
+// columns and the split is kept; 0: the 5-point kernels' even split, re-planned for the active tiles.
 static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t st,
-                          const xinv_options &opt)
+                          const xinv_options &opt, int fixedRB = 0, int UW_ = 0)
 {
     pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0;
     const bool forced = (opt.flags & XINV_FLAG_FORCE_TILE_SKIP) != 0;
-    const int K = pl.K, UW = 128 - 4 * K;
+    const int K = pl.K, UW = fixedRB ? UW_ : 128 - 4 * K;
     const int nstrip = (int)cdiv(p.xc, UW);
     if (!forced && ((int64_t)nstrip * pl.nrb * p.nbatch < 1024 || (int64_t)nstrip * pl.nrb < 64 || p.nbatch > 64))
         return XINV_OK;                                   // small problems: nothing to balance
     const int64_t yc = p.yc, nb = p.nbatch;
     const int64_t cells = yc * nstrip;
     if (nb * nstrip * (yc + 1) > (int64_t)50000000) return XINV_OK;   // host-side prefix table would exceed 200 MB
-    const int fi = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_GEN2D ? 6 : 5);     // the forcing
+    const int fi = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_GEN2D ? 6 : (p.kind == KIND_BIH2D ? 9 : 5));   // the forcing
 
     int rc = ensure_dev(&ws->d_act, &ws->d_act_cap, (size_t)(nb * cells));
     if (rc) return rc;
@@ -555,11 +566,13 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
 
     const bool ext = (p.BCy == XINV_BC_EXTEND);
     auto bounds = [&](int nrb, int rb, int64_t &y0, int64_t &y1) {
+        if (fixedRB) { y0 = (int64_t)rb * fixedRB; y1 = std::min<int64_t>(yc, y0 + fixedRB); return; }
         y0 = (((int64_t)rb * yc) / nrb) & ~(int64_t)1;
         y1 = (rb + 1 == nrb) ? yc : ((((int64_t)(rb + 1) * yc) / nrb) & ~(int64_t)1);
     };
     auto tile_active = [&](int64_t m, int nrb, int rb, int s) {
-        if (ext && (rb == 0 || rb == nrb - 1)) return true;    // the boundary rows get their copy
+        if (ext && (rb == 0 || rb >= nrb - (fixedRB ? 2 : 1))) return true;    // the boundary rows get their copy
+                                                               // (a last block of one row: yc-2 sits in the one before)
         int64_t y0, y1; bounds(nrb, rb, y0, y1);
         const int *q = &pre[(size_t)((m * nstrip + s) * (yc + 1))];
         return q[y1] - q[y0] > 0;
@@ -569,7 +582,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         for (int64_t m = 0; m < nb; m++) {
             int64_t c = 0;
             for (int rb = 0; rb < nrb; rb++) {
-                if (ext && (rb == 0 || rb == nrb - 1)) { c += nstrip; continue; }
+                if (ext && (rb == 0 || rb >= nrb - (fixedRB ? 2 : 1))) { c += nstrip; continue; }
                 int64_t y0, y1; bounds(nrb, rb, y0, y1);
                 const int *q = &pre[(size_t)(m * nstrip * (yc + 1))];
                 for (int s = 0; s < nstrip; s++, q += yc + 1) c += (q[y1] - q[y0] > 0) ? 1 : 0;
@@ -580,7 +593,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         return wgs;
     };
     int occ = 2;
-    {
+    if (!fixedRB) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
         fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
     }
@@ -589,7 +602,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     // near nrb / (active share); search a window around it
     int best = pl.nrb; double best_cost = 1e300;
     int lo = pl.nrb, hi = pl.nrb;
-    if (!forced && opt.rows_per_tile == 0) {
+    if (!forced && opt.rows_per_tile == 0 && !fixedRB) {
         const int64_t w0 = active_wgs(pl.nrb, nullptr);
         const double share = std::max(0.05, (double)w0 / (double)((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb));
         const double centre = (double)pl.nrb / share;
@@ -602,7 +615,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         const double c = tile_cost(active_wgs(nrb, nullptr), cdiv(yc, nrb), K, occ);
         if (c < best_cost) { best_cost = c; best = nrb; }
     }
-    if (!forced && best_cost > 0.95 * cost0) return XINV_OK;
+    if (!forced && best_cost > 0.95 * cost0) return XINV_OK;            // (fixed split: skipping must save 5 % of the workgroups)
 
     // lists for the chosen split
     int64_t maxact = 0;
@@ -639,7 +652,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
                     (nt + (size_t)nb) * (sizeof(double) + sizeof(long long)));
     if (rc) return rc;
     SkipNormArgs na;
-    na.S = p.S; na.sS = p.sS; na.yc = yc; na.xc = p.xc; na.nstrip = nstrip; na.nrb = best; na.UW = UW;
+    na.S = p.S; na.sS = p.sS; na.yc = yc; na.xc = p.xc; na.nstrip = nstrip; na.nrb = best; na.UW = UW; na.RB = fixedRB;
     na.undef = p.sc_.undef; na.skip_list = ws->d_list + (size_t)nb * ntl; na.nskip_max = nskip;
     char *base = (char *)ws->d_tsum;
     na.tsum = (double *)base;
@@ -652,8 +665,10 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
 
     pl.skip = true; pl.ntl = ntl; pl.nskip = nskip;
     pl.skip_pct = (int)((100 * nskipped) / (ntiles * nb));
-    pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
-    pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
+    if (!fixedRB) {
+        pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
+    }
     return XINV_OK;
 }
 
