@@ -765,11 +765,13 @@ def test_seeded_fuzz_medium_grids(chunk):
                       for q in ps]
         elif uni:
             ps = [un(q) for q in ps]
+            if kind == 'bih2d':                       # land blocks in the forcing: skippable tiles
+                ps = [_blocky(q, rng, [(0, yc // 2, 0, xc // 3), (yc // 2, yc, xc // 2, xc)]) for q in ps]
         for k in range(len(ps[0]['coefs']) - 1):      # one coefficient stack for both members
             ps[1]['coefs'][k] = ps[0]['coefs'][k]
         shared = tuple(range(len(ps[0]['coefs']) - 1))
         nsw = int(rng.integers(2, 8))
-        opt = {'force_tile_skip': 1} if kind in ('std2d', 'gen2d', 'std2dt') and int(rng.integers(2)) else {}
+        opt = {'force_tile_skip': 1} if kind in ('std2d', 'gen2d', 'std2dt', 'bih2d') and int(rng.integers(2)) else {}
         S, fl, st = run_hip_batched(ps, nsw, 0.0, shared=shared, **opt)
         for m, q in enumerate(ps):
             So, flo = run_oracle(q, nsw, 0.0, COLOUR_AUTO)
