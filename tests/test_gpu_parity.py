@@ -286,6 +286,24 @@ def test_masked_tiles_are_skipped_without_changing_a_bit(kind, BCy, BCx, spl, ro
     assert max(loops) < 60                      # every member stopped on the tolerance
 
 
+@pytest.mark.parametrize('kind,spl', [('std2d', 1), ('std2d', 2), ('gen2d', 1)])
+@pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic')])
+@pytest.mark.parametrize('rows', [-6, -12])
+def test_masked_tiles_skipped_nine_point(kind, spl, BCy, BCx, rows):
+    """The 4-colour fused kernel (B != 0) with masked-tile skipping: bit for bit the oracle and the
+    run that visits every tile."""
+    rng = np.random.default_rng(_seed(('skip9', kind, spl, BCy, BCx, rows)))
+    ps = [_blocky(rand2d(kind, 60, 360, BCy, BCx, 1, 1, seed=11), rng, [(0, 30, 0, 250), (44, 60, 120, 360)]),
+          _blocky(rand2d(kind, 60, 360, BCy, BCx, 1, 1, seed=12), rng, [(10, 60, 100, 360)])]
+    S, fl, st = run_hip_batched(ps, 40, 1e-4, path=PATH_FUSED, sweeps_per_launch=spl, rows_per_tile=rows, force_tile_skip=1)
+    assert st['path'] == PATH_FUSED and st['colours'] == 4 and st['masked_tile_pct'] > 0
+    S0, fl0, st0 = run_hip_batched(ps, 40, 1e-4, path=PATH_FUSED, sweeps_per_launch=spl, rows_per_tile=rows, no_tile_skip=1)
+    assert st0['masked_tile_pct'] == 0 and np.array_equal(S, S0) and np.array_equal(fl[:, 2], fl0[:, 2])
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 40, 1e-4, COLOUR_AUTO)
+        assert_same(S[m], fl[m], So, flo, 'skip9 member %d' % m)
+
+
 def test_masked_tile_skipping_degenerate_members():
     """A member whose forcing is masked everywhere (no active tile at all: the whole norm comes from
     the constant share), next to an ordinary one and to one with a NaN in a masked block's

@@ -156,7 +156,13 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
         T = xcd * q + (xcd < rem ? xcd : rem) + idx;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wt = T * 4 + wave;
+    int wt = T * 4 + wave;
+    bool active = wt < a.nstrip * a.nrb;
+    if (a.tile_list) {                                       // masked-tile skipping, as k_fused2d
+        wt = a.tile_list[m * a.ntl + wt];
+        active = wt >= 0;
+        wt = active ? wt : 0;
+    }
     const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
     const int64_t xc = a.xc, yc = a.yc;
     const int64_t xu0 = (int64_t)strip * UW;
@@ -168,7 +174,6 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
         yu0 = (((int64_t)rb * yc) / a.nrb) & ~(int64_t)1;
         yu1 = (rb + 1 == a.nrb) ? yc : ((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
     }
-    const bool active = wt < a.nstrip * a.nrb;
     const double u = a.sc_.undef;
     const LaneCols lc = make_lanecols<AL>(xu0, HX, UW, lane, xc, a.per != 0);
     const int64_t st0 = xu0 - HX + 2 * lane;
@@ -277,5 +282,6 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
 
     if (a.no_ctl) return;
     xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, a.psum + (size_t)m * XINV_KMAX * NB,
-                             a.pcnt + (size_t)m * XINV_KMAX * NB, ctl, a.stop);
+                             a.pcnt + (size_t)m * XINV_KMAX * NB, ctl, a.stop,
+                             a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
 }

@@ -194,6 +194,13 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             pl.RY = (int)cdiv(p.yc, pl.nrb);
         }
         pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 8 * XINV_KMAX) * pl.nrb, 4) + 1;
+        if (pl.even_split && !(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
+            int occ9 = 1;
+            FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
+            fused9_dispatch(p.kind, pl.K, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ9);
+            rc = plan_tile_skip(p, pl, ws, st, opt, 0, 128 - 8 * pl.K, occ9);
+            if (rc) return rc;
+        }
     } else if (pl.path == XINV_PATH_FUSED && is3d(p.kind)) {
         // 3-D: one sweep per launch; cross-section of NW rows per workgroup (rows_per_tile = NW)
         pl.K = 1;

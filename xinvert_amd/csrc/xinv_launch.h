@@ -202,6 +202,15 @@ static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *
     const size_t NBmax = (size_t)pl.nsg;
     a.psum = (unsigned long long *)ws->partials;
     a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
+    if (pl.skip && K == pl.K) {                      // fully masked tiles are left out (plan_tile_skip)
+        a.tile_list = ws->d_list;
+        a.ntl = pl.ntl;
+        a.nwg = pl.ntl / 4;
+        char *base = (char *)ws->d_tsum;
+        const size_t nt = (size_t)p.nbatch * pl.nskip;
+        a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
+        a.xcnt = (const long long *)(base + nt * (sizeof(double) + sizeof(long long)) + p.nbatch * sizeof(double));
+    }
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
@@ -525,11 +534,11 @@ static double tile_cost(int64_t wgs, int64_t rows, int K, int occ)
 // `fixedRB` > 0 (biharmonic one-pass kernel): tiles are row blocks of exactly fixedRB rows x `UW_` owned
 // columns and the split is kept; 0: the 5-point kernels' even split, re-planned for the active tiles.
 static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t st,
-                          const xinv_options &opt, int fixedRB = 0, int UW_ = 0)
+                          const xinv_options &opt, int fixedRB = 0, int UW_ = 0, int occ_ = 0)
 {
     pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0;
     const bool forced = (opt.flags & XINV_FLAG_FORCE_TILE_SKIP) != 0;
-    const int K = pl.K, UW = fixedRB ? UW_ : 128 - 4 * K;
+    const int K = pl.K, UW = UW_ ? UW_ : 128 - 4 * K;            // 9-point kernel: 128 - 8K owned columns
     const int nstrip = (int)cdiv(p.xc, UW);
     if (!forced && ((int64_t)nstrip * pl.nrb * p.nbatch < 1024 || (int64_t)nstrip * pl.nrb < 64 || p.nbatch > 64))
         return XINV_OK;                                   // small problems: nothing to balance
@@ -592,8 +601,8 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         if (maxact) *maxact = mx;
         return wgs;
     };
-    int occ = 2;
-    if (!fixedRB) {
+    int occ = occ_ > 0 ? occ_ : 2;
+    if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
         fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
     }
@@ -667,7 +676,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     pl.skip_pct = (int)((100 * nskipped) / (ntiles * nb));
     if (!fixedRB) {
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX) * pl.nrb, 4) + 1;
     }
     return XINV_OK;
 }
