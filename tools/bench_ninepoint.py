@@ -9,6 +9,7 @@ from xinvert_amd import _lib
 import util
 L = _lib.require_gpu()
 dev = torch.device('cuda', 0)
+ROWS = int(os.environ.get('NINE_ROWS', '0'))
 for kind, spl, path in (('std2d', 1, 0), ('std2d', 2, 0), ('std2d', 0, 1), ('gen2d', 1, 0), ('gen2d', 0, 1)):
     ny = nx = 2000
     p = util.rand2d(kind, ny, nx, 'fixed', 'periodic', bnz=True, msk=False, seed=1, omega=0.9)
@@ -18,7 +19,7 @@ for kind, spl, path in (('std2d', 1, 0), ('std2d', 2, 0), ('std2d', 0, 1), ('gen
     cs = [torch.from_numpy(np.ascontiguousarray(c)).to(dev) for c in p['coefs']]
     strides = [n] * (1 + len(cs))
     fl = np.tile(np.array([0., 1., 0.]), (1, 1)); sw = 100
-    opt = _lib.options(timing=1, sweeps_per_launch=spl, path=path)
+    opt = _lib.options(timing=1, sweeps_per_launch=spl, path=path, rows_per_tile=ROWS)
     args = [ctypes.c_void_p(S.data_ptr())] + [ctypes.c_void_p(c.data_ptr()) for c in cs] + \
            [1, _lib.strides_arg(strides)] + util._scal(p, fl, sw - 1, 0.0) + [ctypes.byref(opt), None]
     fn = getattr(L, util._FN[kind] + '_dev')
@@ -28,4 +29,4 @@ for kind, spl, path in (('std2d', 1, 0), ('std2d', 2, 0), ('std2d', 0, 1), ('gen
         t = time.perf_counter(); _lib.check(fn(*args)); best = min(best, time.perf_counter() - t)
     st = _lib.last_stats()
     print(json.dumps({'kind': kind, 'spl': st['sweeps_per_launch'], 'flags': fl[0].tolist(), 'shape': [ny, nx], 'point_sweeps_per_s': n * sw / best, 'path': st['path'],
-                      'colours': st['colours'], 'sweep_ms': st['sweep_ms'] / sw}))
+                      'colours': st['colours'], 'rows': st['rows_per_tile'], 'sweep_ms': st['sweep_ms'] / sw}))
