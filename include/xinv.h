@@ -20,8 +20,8 @@
  *
  * Sweep ordering.  The reference sweeps lexicographically (serial Gauss-Seidel).  The engine
  * sweeps red-black on (j+i)&1 when the cross coefficient B is identically zero and 4-colour on
- * (j&1, i&1) otherwise (3-D: (k+j+i)&1); with periodic x and odd xc the last column is its own
- * pair of colours.  Point arithmetic, masking predicate, 'extend' pre-pass, norm (mean |S| over
+* (j&1, i&1) otherwise (3-D: (k+j+i)&1; biharmonic: 9 colours (j%3, i%3)); with periodic x and odd xc
+ * the last column is its own pair of colours.  Point arithmetic, masking predicate, 'extend' pre-pass, norm (mean |S| over
  * S != undef) and the stopping rule are the reference's.
  */
 #ifndef XINV_H
@@ -46,7 +46,7 @@ extern "C" {
 /* kernel paths (xinv_options.path / xinv_stats.path) */
 #define XINV_PATH_AUTO   0
 #define XINV_PATH_COLOUR 1   /* one launch per colour, in place (general fallback)              */
-#define XINV_PATH_FUSED  2   /* streaming fused red+black sweep(s), ping-pong buffers (2-D)     */
+#define XINV_PATH_FUSED  2   /* streaming kernels: a whole sweep (or two) per pass, ping-pong buffers */
 
 #define XINV_FLAG_NO_XUNIFORM 1  /* stream every coefficient array in full: do not look for rows
                                     that are constant along x                                    */
@@ -60,7 +60,8 @@ typedef struct xinv_options {
     int32_t sweeps_per_launch;  /* fused path: sweeps fused in one launch (1 or 2); 0 = auto    */
     int32_t check_every;        /* launches between host polls of the device stop flags; 0=auto */
     int32_t rows_per_tile;      /* fused 2-D: rows per tile (n > 0) or exactly -n evenly split row
-                                   blocks (n < 0); fused 3-D: rows per workgroup (8, 12, 16); 0=auto */
+                                   blocks (n < 0); biharmonic one-pass kernel: rows per block (multiple
+                                   of 3); fused 3-D: rows per workgroup (8, 12, 16); 0 = auto            */
     int32_t timing;             /* 1: bracket launch chunks with HIP events (xinv_last_stats)   */
     int32_t flags;              /* XINV_FLAG_* bits                                              */
     int32_t rowconst_mask;      /* host-pointer entries: bit q set = coefficient array q (argument order
@@ -72,7 +73,7 @@ typedef struct xinv_options {
 
 typedef struct xinv_stats {
     int32_t path;               /* path actually used                                           */
-    int32_t colours;            /* colours per sweep (2, 4, or +2 with the odd-periodic seam)   */
+    int32_t colours;            /* colours per sweep (2, 4, +2 with the odd-periodic seam; biharmonic 9+) */
     int32_t sweeps_per_launch;
     int32_t rows_per_tile;
     int32_t xuniform_mask;      /* fused path: coefficient streams read as one scalar per row    */
