@@ -20,7 +20,7 @@
  *
  * Sweep ordering.  The reference sweeps lexicographically (serial Gauss-Seidel).  The engine
  * sweeps red-black on (j+i)&1 when the cross coefficient B is identically zero and 4-colour on
-* (j&1, i&1) otherwise (3-D: (k+j+i)&1; biharmonic: 9 colours (j%3, i%3)); with periodic x and odd xc
+ * (j&1, i&1) otherwise (3-D: (k+j+i)&1; biharmonic: 9 colours (j%3, i%3)); with periodic x and odd xc
  * the last column is its own pair of colours.  Point arithmetic, masking predicate, 'extend' pre-pass, norm (mean |S| over
  * S != undef) and the stopping rule are the reference's.
  */
