@@ -789,10 +789,13 @@ def test_seeded_fuzz_medium_grids(chunk):
             ps[1]['coefs'][k] = ps[0]['coefs'][k]
         shared = tuple(range(len(ps[0]['coefs']) - 1))
         nsw = int(rng.integers(2, 8))
+        tol = 0.0
+        if case == 3:                                 # one case per chunk stops on the tolerance (odd sweep
+            nsw, tol = 60, 3e-3                       # counts inside 2-sweep launches: the redo path)
         opt = {'force_tile_skip': 1} if kind in ('std2d', 'gen2d', 'std2dt', 'bih2d') and int(rng.integers(2)) else {}
-        S, fl, st = run_hip_batched(ps, nsw, 0.0, shared=shared, **opt)
+        S, fl, st = run_hip_batched(ps, nsw, tol, shared=shared, **opt)
         for m, q in enumerate(ps):
-            So, flo = run_oracle(q, nsw, 0.0, COLOUR_AUTO)
+            So, flo = run_oracle(q, nsw, tol, COLOUR_AUTO)
             what = 'medium fuzz %d/%d %s %r %s %s uni=%d member %d %r' % (chunk, case, kind, q['S0'].shape, BCy, BCx, uni, m, st)
             if np.isnan(So).any():
                 assert np.array_equal(S[m], So, equal_nan=True), what
