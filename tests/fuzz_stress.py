@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Extended seeded fuzz on a GPU box: the two fuzz tests of tests/test_gpu_parity.py with fresh seeds.
 
-  python tools/fuzz_stress.py [first_chunk] [count]      (default 100, 60: 240 medium + 2400 small cases)
+  python tests/fuzz_stress.py [first_chunk] [count]      (default 100, 60: 240 medium + 2400 small cases)
 """
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))   # (this file lives there: it runs the oracle, which only tests/ may)
 
 
 def main():

@@ -2,7 +2,7 @@
 """Converged parity for the other BASELINE configurations at full grid size: the GPU result (whatever
 path the engine picks) against the reference's lexicographic ordering (oracle, one CPU core).
 
-  python tools/validate_converged.py [c3 c3m c4 c5] [--tol 1e-12]
+  python tests/validate_converged.py [c3 c3m c4 c5] [--tol 1e-12]
 """
 import argparse
 import os
@@ -13,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))   # (this file lives there: it runs the oracle, which only tests/ may)
 
 
 def main():
