@@ -1,0 +1,129 @@
+"""Batches of more than 2^31 elements per array: 64-bit offsets on every path.
+
+The oracle cannot run these sizes, so the check is a size-independent property: slices of a batch
+are independent (reference core.py:129), hence a member that lies entirely beyond element 2^31
+of the batch must come out bit for bit like the same data solved alone.  Data are a small random
+problem tiled over the big grid on the device (nothing this size crosses PCIe).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+NB = 10            # 10 x 2^28 elements: members 8 and 9 start at / beyond element 2^31
+
+
+def _need_hbm(gib):
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < gib * 2**30:
+        pytest.skip('needs %d GiB of free HBM' % gib)
+
+
+def _tile(a, reps):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda().repeat(*reps).contiguous()
+
+
+def _solve_dev(p, ts, strides, nb, sweeps, **opt):
+    from xinvert_amd import _lib
+    L = _lib.require_gpu()
+    fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
+    o = _lib.options(**opt)
+    rc = getattr(L, util._FN[p['kind']] + '_dev')(
+        *[ctypes.c_void_p(t.data_ptr()) if t is not None else None for t in ts], nb,
+        _lib.strides_arg(strides), *util._scal(p, fl, sweeps - 1, 0.0), ctypes.byref(o), None)
+    _lib.check(rc)
+    return fl, _lib.last_stats()
+
+
+def _big_problem(kind, BCy, BCx):
+    """Two small problems (even / odd members) and how often to repeat them per axis."""
+    if kind in ('std3d', 'gen3d'):
+        mk = util.rand3d if kind == 'std3d' else util.rand3dg
+        ps = [mk(8, 128, 128, BCy, BCx, msk=True, seed=s) for s in (11, 12)]
+        reps = (8, 16, 16)                                  # 64 x 2048 x 2048 = 2^28
+    elif kind == 'bih2d':
+        ps = [util.randbih(256, 256, BCy, BCx, msk=True, seed=s) for s in (11, 12)]
+        reps = (64, 64)                                     # 16384 x 16384 = 2^28
+    elif kind == 'std2dt':
+        ps = [util.rand2dt(256, 256, BCy, BCx, msk=True, seed=s) for s in (11, 12)]
+        reps = (64, 64)
+    else:
+        ps = [util.rand2d(kind, 256, 256, BCy, BCx, bnz=(kind == 'gen2d'), msk=True, seed=s)
+              for s in (11, 12)]
+        reps = (64, 64)
+    return ps, reps
+
+
+CASES = [('std2d', 'fixed', 'periodic', {}),
+         ('std2d', 'extend', 'fixed', dict(no_tile_skip=1)),
+         ('gen2d', 'fixed', 'fixed', {}),
+         ('std2dt', 'fixed', 'periodic', {}),
+         ('bih2d', 'fixed', 'fixed', {}),
+         ('std3d', 'fixed', 'periodic', {}),
+         ('gen3d', 'extend', 'fixed', {}),
+         ('std2d', 'fixed', 'fixed', dict(path=1)),
+         ('std3d', 'fixed', 'fixed', dict(path=1))]
+
+
+@pytest.mark.parametrize('kind,BCy,BCx,opt', CASES)
+def test_members_beyond_2G_elements(kind, BCy, BCx, opt):
+    import torch
+    _need_hbm(120)
+    ps, reps = _big_problem(kind, BCy, BCx)
+    p = dict(ps[0])
+    shape = tuple(int(s * r) for s, r in zip(ps[0]['S0'].shape, reps))
+    n = int(np.prod(shape))
+    assert NB * n > 2**31 and 8 * n >= 2**31
+    if len(shape) == 3:
+        p['zc'], p['yc'], p['xc'] = shape
+    else:
+        p['yc'], p['xc'] = shape
+    nco = len(p['coefs'])
+    per_member = {0, nco - 1}               # first coefficient and the forcing vary per member
+    # a band of fully undefined forcing rows so that masked-tile skipping has something to skip
+    band = slice(shape[-2] // 4, shape[-2] // 4 + shape[-2] // 8)
+
+    def big(q, k):
+        t = _tile(q['coefs'][k], reps)
+        if k == nco - 1:
+            t[..., band, :] = util.U
+        return t
+
+    S = torch.empty((NB,) + shape, dtype=torch.float64, device='cuda')
+    for m in range(NB):
+        S[m] = _tile(ps[m % 2]['S0'], reps)
+    ts, strides = [S], [n]
+    for k in range(nco):
+        if k in per_member:
+            t = torch.empty((NB,) + shape, dtype=torch.float64, device='cuda')
+            e, o = big(ps[0], k), big(ps[1], k)
+            for m in range(NB):
+                t[m] = o if m % 2 else e
+            del e, o
+            ts.append(t); strides.append(n)
+        else:
+            ts.append(big(ps[0], k)); strides.append(0)
+    torch.cuda.synchronize()
+    # members 8 (even data) and 9 (odd data), each alone, from untouched copies
+    alone = []
+    for m in (NB - 2, NB - 1):
+        one = [S[m].clone()] + [t[m] if st else t for t, st in zip(ts[1:], strides[1:])]
+        fl1, _ = _solve_dev(p, one, strides, 1, 6, **opt)
+        alone.append((one[0], fl1[0].copy()))
+    fl, st = _solve_dev(p, ts, strides, NB, 6, **opt)
+    torch.cuda.synchronize()
+    for (S1, f1), m in zip(alone, (NB - 2, NB - 1)):
+        assert torch.equal(S[m], S1), '%s: member %d differs from the same data solved alone' % (kind, m)
+        assert fl[m][2] == f1[2] == 5 and fl[m][0] == f1[0]
+        assert abs(fl[m][1] - f1[1]) <= 1e-12
+    # identical data => identical result wherever the member sits in the batch
+    assert torch.equal(S[0], S[NB - 2]) and torch.equal(S[1], S[NB - 1])
+    assert np.array_equal(fl[0::2, [0, 2]], np.tile(fl[0, [0, 2]], (NB // 2, 1)))
+    assert np.allclose(fl[0::2, 1], fl[0, 1], rtol=0, atol=1e-12)
+    assert bool(torch.isfinite(S[NB - 1][S[NB - 1] != util.U]).all())
