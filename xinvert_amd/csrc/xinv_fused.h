@@ -39,6 +39,12 @@
 #include <utility>
 
 #define XINV_KMAX 2
+#ifndef XINV_VGPR_MASK
+#define XINV_VGPR_MASK 0
+#endif
+#ifndef XINV_NORM_BRANCH
+#define XINV_NORM_BRANCH 1
+#endif
 #ifndef XINV_LOAD_EARLY
 #define XINV_LOAD_EARLY 0
 #endif
@@ -90,12 +96,37 @@ template <int X> __device__ __forceinline__ void row_neighbours(const double2 &r
 // (v[q][slot], two columns per lane) or, when bit q of UM is set, one scalar per row (s[q][slot]).
 // rq / rok: per-row relaxation factor optArg/denom and uniform part of the mask predicate, used
 // when the model's denominator is x-uniform (M::hoist<UM>()).
+// mx / my: the complete update predicate of the row's two columns (row and column in range and
+// every operand the reference's `cond` lists defined), evaluated ONCE when the row below it has
+// entered and kept as all-ones / zero words, so that each of the 2K half-sweeps that touch the
+// row selects with two v_bfi instead of re-deriving the predicate (compares + lane-mask logic).
 template <int NC, int D> struct CoefWin {
     double2 v[NC][D];
     double s[NC][D];
     double rq[D];
-    bool rok[D];
+    unsigned mx[D], my[D];
 };
+
+// all-ones / zero word per lane, opaque to the optimiser: it would otherwise fold the word back
+// into a lane mask in SGPRs and re-create the scalar logic this representation is there to avoid
+__device__ __forceinline__ unsigned xinv_lane_word(bool b)
+{
+    unsigned m = b ? ~0u : 0u;
+#if XINV_VGPR_MASK
+    asm("" : "+v"(m));
+#endif
+    return m;
+}
+
+// bitwise select: m == ~0u -> a, m == 0 -> b   (v_bfi_b32 on each half; exact, no arithmetic)
+__device__ __forceinline__ double xinv_bitsel(unsigned m, double a, double b)
+{
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a);
+    const unsigned long long ub = (unsigned long long)__double_as_longlong(b);
+    const unsigned lo = ((unsigned)ua & m) | ((unsigned)ub & ~m);
+    const unsigned hi = ((unsigned)(ua >> 32) & m) | ((unsigned)(ub >> 32) & ~m);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 template <int X, unsigned UM, int Q, int NC, int D>
 __device__ __forceinline__ double cget(const CoefWin<NC, D> &w, int slot)
@@ -109,22 +140,40 @@ struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
     static constexpr int NC = 3;    // A, C, F
     template <unsigned UM> static constexpr bool hoist() { return (UM & 3u) == 3u; }   // A and C uniform
 
-    // called once per step after row r entered slot `sr`; `s1` = slot of row r-1.
+    // called once per step after row r entered slot `sr`; `s1` = slot of row r-1, whose operands
+    // (A[r], A[r-1], C[r-1], F[r-1]) are all in the window now: relaxation factor when it is
+    // x-uniform, the update predicate (numbas.py:344-348), and F*delxSqr in place of F.
     template <unsigned UM, int D>
-    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int s1, const XinvScal &sc)
+    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int s1, bool okx, bool oky,
+                                                  const XinvScal &sc)
     {
-        if (hoist<UM>()) {          // row r-1: A[r], A[r-1], C[r-1] are all known now
+        const double u = sc.undef;
+        const double fx = cget<0, UM, 2>(w, s1), fy = cget<1, UM, 2>(w, s1);
+        bool bx = okx && (fx != u), by = oky && (fy != u);
+        if (hoist<UM>()) {
             const double aP = w.s[0][sr], a0 = w.s[0][s1], c = w.s[1][s1];
             w.rq[s1] = sc.optArg / ((aP + a0) * sc.ratioSqr + (c + c));
-            w.rok[s1] = (aP != sc.undef) && (a0 != sc.undef) && (c != sc.undef);
+            const bool rok = (aP != u) && (a0 != u) && (c != u);
+            bx = bx && rok; by = by && rok;
+        } else {
+            const double aPx = cget<0, UM, 0>(w, sr), aPy = cget<1, UM, 0>(w, sr);
+            const double a0x = cget<0, UM, 0>(w, s1), a0y = cget<1, UM, 0>(w, s1);
+            const double c0x = cget<0, UM, 1>(w, s1), c0y = cget<1, UM, 1>(w, s1);
+            const double cEy = ((UM >> 1) & 1u) ? w.s[1][s1] : xinv_lane_down(w.v[1][s1].x);
+            bx = bx && (aPx != u) && (a0x != u) && (c0y != u) && (c0x != u);      // east of .x is .y
+            by = by && (aPy != u) && (a0y != u) && (cEy != u) && (c0y != u);
         }
+        w.mx[s1] = xinv_lane_word(bx);
+        w.my[s1] = xinv_lane_word(by);
+        if (!((UM >> 2) & 1u)) { w.v[2][s1].x = fx * sc.delxSqr; w.v[2][s1].y = fy * sc.delxSqr; }
+        else                   w.s[2][s1] = fx * sc.delxSqr;
     }
 
     // sj = slot of row j, sjp = slot of row j+1.
     template <int X, unsigned UM, int D>
     static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
                                                  double sP, double sM, double sW, double sE,
-                                                 bool inr, const XinvScal &sc)
+                                                 const XinvScal &sc)
     {
         const double aP = cget<X, UM, 0>(w, sjp);
         const double a0 = cget<X, UM, 0>(w, sj);
@@ -133,22 +182,19 @@ struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
         if ((UM >> 1) & 1u) cE = w.s[1][sj];
         else if (X == 0)    cE = w.v[1][sj].y;
         else                cE = xinv_lane_down(w.v[1][sj].x);
-        const double f = cget<X, UM, 2>(w, sj);
-        if (hoist<UM>()) {
-            const bool cond = inr && w.rok[sj] && (f != sc.undef);
-            double temp = (
-                (
-                    aP * (sP - sC) -
-                    a0 * (sC - sM)
-                ) * sc.ratioSqr + (
-                    cE * (sE - sC) -
-                    c0 * (sC - sW)
-                )
-            ) - f * sc.delxSqr;
-            temp *= w.rq[sj];
-            return cond ? sC + temp : sC;
-        }
-        return xinv_upd_std2d_5(sC, sP, sM, sW, sE, aP, a0, cE, c0, f, inr, sc);
+        const double fd = cget<X, UM, 2>(w, sj);             // F * delxSqr (see derive)
+        double temp = (
+            (
+                aP * (sP - sC) -
+                a0 * (sC - sM)
+            ) * sc.ratioSqr + (
+                cE * (sE - sC) -
+                c0 * (sC - sW)
+            )
+        ) - fd;
+        if (hoist<UM>()) temp *= w.rq[sj];
+        else             temp *= sc.optArg / ((aP + a0) * sc.ratioSqr + (cE + c0));
+        return xinv_bitsel(X ? w.my[sj] : w.mx[sj], sC + temp, sC);
     }
 };
 
@@ -157,20 +203,33 @@ struct FusedStd2DT {                // numbas.invert_standard_2D_test, B == 0 an
     template <unsigned UM> static constexpr bool hoist() { return (UM & 7u) == 7u; }   // A, D, E uniform
 
     template <unsigned UM, int D>
-    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int s1, const XinvScal &sc)
+    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int s1, bool okx, bool oky,
+                                                  const XinvScal &sc)
     {
+        const double u = sc.undef;
+        bool bx = okx && (cget<0, UM, 3>(w, s1) != u), by = oky && (cget<1, UM, 3>(w, s1) != u);
         if (hoist<UM>()) {          // row r-1
             const double aP = w.s[0][sr], a0 = w.s[0][s1], d = w.s[1][s1], e = w.s[2][s1];
             w.rq[s1] = sc.optArg / ((aP + a0) * sc.ratioSqr +
                                     (d + d) - e * sc.delxSqr);
-            w.rok[s1] = (aP != sc.undef) && (a0 != sc.undef) && (d != sc.undef) && (e != sc.undef);
+            const bool rok = (aP != u) && (a0 != u) && (d != u) && (e != u);
+            bx = bx && rok; by = by && rok;
+        } else {
+            const double d0x = cget<0, UM, 1>(w, s1), d0y = cget<1, UM, 1>(w, s1);
+            const double dEy = ((UM >> 1) & 1u) ? w.s[1][s1] : xinv_lane_down(w.v[1][s1].x);
+            bx = bx && (cget<0, UM, 0>(w, sr) != u) && (cget<0, UM, 0>(w, s1) != u) && (d0y != u) &&
+                 (d0x != u) && (cget<0, UM, 2>(w, s1) != u);
+            by = by && (cget<1, UM, 0>(w, sr) != u) && (cget<1, UM, 0>(w, s1) != u) && (dEy != u) &&
+                 (d0y != u) && (cget<1, UM, 2>(w, s1) != u);
         }
+        w.mx[s1] = xinv_lane_word(bx);
+        w.my[s1] = xinv_lane_word(by);
     }
 
     template <int X, unsigned UM, int D>
     static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
                                                  double sP, double sM, double sW, double sE,
-                                                 bool inr, const XinvScal &sc)
+                                                 const XinvScal &sc)
     {
         const double aP = cget<X, UM, 0>(w, sjp);
         const double a0 = cget<X, UM, 0>(w, sj);
@@ -181,21 +240,19 @@ struct FusedStd2DT {                // numbas.invert_standard_2D_test, B == 0 an
         else                dE = xinv_lane_down(w.v[1][sj].x);
         const double e = cget<X, UM, 2>(w, sj);
         const double f = cget<X, UM, 3>(w, sj);
-        if (hoist<UM>()) {
-            const bool cond = inr && w.rok[sj] && (f != sc.undef);
-            double temp = (
-                (
-                    aP * (sP - sC) -
-                    a0 * (sC - sM)
-                ) * sc.ratioSqr + (
-                    dE * (sE - sC) -
-                    d0 * (sC - sW)
-                )
-            ) + (e * sC - f) * sc.delxSqr;
-            temp *= w.rq[sj];
-            return cond ? sC + temp : sC;
-        }
-        return xinv_upd_std2dt_5(sC, sP, sM, sW, sE, aP, a0, dE, d0, e, f, inr, sc);
+        double temp = (
+            (
+                aP * (sP - sC) -
+                a0 * (sC - sM)
+            ) * sc.ratioSqr + (
+                dE * (sE - sC) -
+                d0 * (sC - sW)
+            )
+        ) + (e * sC - f) * sc.delxSqr;
+        if (hoist<UM>()) temp *= w.rq[sj];
+        else             temp *= sc.optArg / ((aP + a0) * sc.ratioSqr +
+                                              (dE + d0) - e * sc.delxSqr);
+        return xinv_bitsel(X ? w.my[sj] : w.mx[sj], sC + temp, sC);
     }
 };
 
@@ -203,51 +260,59 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     static constexpr int NC = 6;    // A, C, D, E, F, G
     template <unsigned UM> static constexpr bool hoist() { return (UM & 0x13u) == 0x13u; }  // A, C, F uniform
 
+    // every operand of the predicate (numbas.py:1126-1129) sits on the point itself: row r-1 is
+    // handled here like in the other models (its first half-sweep runs in this very step)
     template <unsigned UM, int D>
-    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int, const XinvScal &sc)
+    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int, int s1, bool okx, bool oky,
+                                                  const XinvScal &sc)
     {
+        const double u = sc.undef;
+        bool bx = okx && (cget<0, UM, 5>(w, s1) != u), by = oky && (cget<1, UM, 5>(w, s1) != u);
         if (hoist<UM>()) {
-            const double A = w.s[0][sr], C = w.s[1][sr], F = w.s[4][sr];
-            w.rq[sr] = sc.optArg / ((A * sc.ratioSqr + C) * 2.0
+            const double A = w.s[0][s1], C = w.s[1][s1], F = w.s[4][s1];
+            w.rq[s1] = sc.optArg / ((A * sc.ratioSqr + C) * 2.0
                                     - F * sc.delxSqr);
-            bool ok = (A != sc.undef) && (C != sc.undef) && (F != sc.undef);
-            if ((UM >> 2) & 1u) ok = ok && (w.s[2][sr] != sc.undef);
-            if ((UM >> 3) & 1u) ok = ok && (w.s[3][sr] != sc.undef);
-            w.rok[sr] = ok;
+            const bool rok = (A != u) && (C != u) && (F != u);
+            bx = bx && rok; by = by && rok;
+            bx = bx && (cget<0, UM, 2>(w, s1) != u) && (cget<0, UM, 3>(w, s1) != u);
+            by = by && (cget<1, UM, 2>(w, s1) != u) && (cget<1, UM, 3>(w, s1) != u);
+        } else {
+            bx = bx && (cget<0, UM, 0>(w, s1) != u) && (cget<0, UM, 1>(w, s1) != u) &&
+                 (cget<0, UM, 2>(w, s1) != u) && (cget<0, UM, 3>(w, s1) != u) && (cget<0, UM, 4>(w, s1) != u);
+            by = by && (cget<1, UM, 0>(w, s1) != u) && (cget<1, UM, 1>(w, s1) != u) &&
+                 (cget<1, UM, 2>(w, s1) != u) && (cget<1, UM, 3>(w, s1) != u) && (cget<1, UM, 4>(w, s1) != u);
         }
+        w.mx[s1] = xinv_lane_word(bx);
+        w.my[s1] = xinv_lane_word(by);
     }
 
     template <int X, unsigned UM, int D>
     static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int, double sC,
                                                  double sP, double sM, double sW, double sE,
-                                                 bool inr, const XinvScal &sc)
+                                                 const XinvScal &sc)
     {
         const double A = cget<X, UM, 0>(w, sj), C = cget<X, UM, 1>(w, sj);
         const double Dd = cget<X, UM, 2>(w, sj), E = cget<X, UM, 3>(w, sj);
         const double F = cget<X, UM, 4>(w, sj), G = cget<X, UM, 5>(w, sj);
-        if (hoist<UM>()) {
-            bool cond = inr && w.rok[sj] && (G != sc.undef);
-            if (!((UM >> 2) & 1u)) cond = cond && (Dd != sc.undef);
-            if (!((UM >> 3) & 1u)) cond = cond && (E != sc.undef);
-            double temp = (
-                A * (
-                    (sP - sC) - (sC - sM)
-                ) * sc.ratioSqr +
-                C * (
-                    (sE - sC) - (sC - sW)
-                ) + (
-                Dd * (
-                    (sP - sM)
-                ) * sc.ratio +
-                E * (
-                    (sE - sW)
-                )) * sc.delx / 2.0 + (
-                F * sC - G) * sc.delxSqr
-            );
-            temp *= w.rq[sj];
-            return cond ? sC + temp : sC;
-        }
-        return xinv_upd_gen2d_5(sC, sP, sM, sW, sE, A, C, Dd, E, F, G, inr, sc);
+        double temp = (
+            A * (
+                (sP - sC) - (sC - sM)
+            ) * sc.ratioSqr +
+            C * (
+                (sE - sC) - (sC - sW)
+            ) + (
+            Dd * (
+                (sP - sM)
+            ) * sc.ratio +
+            E * (
+                (sE - sW)
+            )) * sc.delx / 2.0 + (
+            F * sC - G) * sc.delxSqr
+        );
+        if (hoist<UM>()) temp *= w.rq[sj];
+        else             temp *= sc.optArg / ((A * sc.ratioSqr + C) * 2.0
+                                              - F * sc.delxSqr);
+        return xinv_bitsel(X ? w.my[sj] : w.mx[sj], sC + temp, sC);
     }
 };
 
@@ -396,7 +461,11 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #ifndef XINV_FORCE_VGPR
 #define XINV_FORCE_VGPR 0
 #endif
+#ifdef XINV_PF_FIXED
+    constexpr int PF = (D % XINV_PF_FIXED == 0) ? XINV_PF_FIXED : 2;
+#else
     constexpr int PF = PFD > 0 ? PFD : (XINV_PF_MODE == 0 ? 2 : ((UM != 0u) ? D : (K == 1 ? 4 : 3)));
+#endif
     static_assert(D % PF == 0, "prefetch depth must divide the window depth");
 
     const int64_t m = a.member0 + blockIdx.y;
@@ -495,7 +564,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #pragma unroll
         for (int t = 0; t < D; t++) {
             sw[t] = make_double2(0.0, 0.0);
-            cw.rq[t] = 0.0; cw.rok[t] = false;
+            cw.rq[t] = 0.0; cw.mx[t] = 0u; cw.my[t] = 0u;
 #pragma unroll
             for (int q = 0; q < NC; q++) { cw.v[q][t] = make_double2(0.0, 0.0); cw.s[q][t] = 0.0; }
         }
@@ -514,8 +583,10 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
             constexpr int U = decltype(utag)::value;
             constexpr int X = (U & 1) ? 0 : 1;       // r even -> .y ; all stages of a step share it
 #define SLOT(w) ((U - (w) + 4 * D) % D)              /* slot of row r - w */
-            M::template derive<UM, D>(cw, U, SLOT(1), a.sc_);
-            const bool okc = X ? lc.ok_y : lc.ok_x;
+            {   // row r-1 is complete in the window: its predicate, once for all 2K half-sweeps
+                const bool rv = (r - 1 >= 1) && (r - 1 <= yc - 2);
+                M::template derive<UM, D>(cw, U, SLOT(1), rv && lc.ok_x, rv && lc.ok_y, a.sc_);
+            }
 #pragma unroll
             for (int s = 1; s <= K; s++) {
                 {   // red half-sweep of sweep s on row ja = r-2s+1
@@ -527,10 +598,9 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                     }
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
-                    const bool inr = okc && (ja >= 1) && (ja <= yc - 2);
                     const double v = M::template upd<X, UM, D>(cw, sj, sjp, comp<X>(sw[sj]),
                                                                comp<X>(sw[sjp]), comp<X>(sw[sjm]),
-                                                               w, e, inr, a.sc_);
+                                                               w, e, a.sc_);
                     setc<X>(sw[sj], v);
                 }
                 {   // black half-sweep of sweep s on row jb = r-2s
@@ -538,12 +608,21 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                     const int sj = SLOT(2 * s), sjp = SLOT(2 * s - 1), sjm = SLOT(2 * s + 1);
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
-                    const bool inr = okc && (jb >= 1) && (jb <= yc - 2);
                     const double v = M::template upd<X, UM, D>(cw, sj, sjp, comp<X>(sw[sj]),
                                                                comp<X>(sw[sjp]), comp<X>(sw[sjm]),
-                                                               w, e, inr, a.sc_);
+                                                               w, e, a.sc_);
                     setc<X>(sw[sj], v);
                     // row jb now holds sweep s: its share of mean|S| (branch-free)
+#if XINV_NORM_BRANCH
+                    if ((jb >= yu0) && (jb < yu1)) {           // wave-uniform: an owned row
+                        const double2 t = sw[sj];
+                        const bool cx = lc.use_x & (t.x != u);
+                        const bool cy = lc.use_y & (t.y != u);
+                        acc[s - 1] += (cx ? fabs(t.x) : 0.0);
+                        acc[s - 1] += (cy ? fabs(t.y) : 0.0);
+                        cnt[s - 1] += (cx ? 1 : 0) + (cy ? 1 : 0);
+                    }
+#else
                     const bool rowin = (jb >= yu0) && (jb < yu1);
                     const double2 t = sw[sj];
                     const bool cx = rowin && lc.use_x && (t.x != u);
@@ -551,6 +630,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                     acc[s - 1] += (cx ? fabs(t.x) : 0.0);
                     acc[s - 1] += (cy ? fabs(t.y) : 0.0);
                     cnt[s - 1] += (cx ? 1 : 0) + (cy ? 1 : 0);
+#endif
                 }
             }
             const int64_t jo = r - 2 * K;                  // row leaving the pipeline

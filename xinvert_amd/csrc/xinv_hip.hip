@@ -293,7 +293,16 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
                 fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
                                st, dummy, &occ);
             }
-            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, 128 - 4 * pl.K), p.nbatch, pl.K, occ);
+            {   // vector streams per row step: S plus every coefficient array that is not x-uniform.
+                // With one or two (lat-lon Poisson, Gill-Matsuno) the kernel is issue-bound and a second
+                // workgroup per CU fills idle slots; with four or more it sits at the fabric's
+                // bandwidth, a pair runs no faster than one, and tall tiles (less halo) win
+                // (2000x2000 general form, A C G streamed: 40-row tiles 38.3 us, 17-row tiles 44.0 us)
+                const int nc = (p.kind == KIND_GEN2D) ? 6 : (p.kind == KIND_STD2DT ? 4 : 3);
+                const int nvec = 1 + nc - __builtin_popcount(pl.um & ((1u << nc) - 1u));
+                pl.lone = nvec <= 2 ? 1.6 : (nvec == 3 ? 1.3 : 1.0);
+            }
+            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, 128 - 4 * pl.K), p.nbatch, pl.K, occ, pl.lone);
             pl.nrb = (int)best;
             pl.even_split = true;
             pl.RY = (int)cdiv(p.yc, pl.nrb);

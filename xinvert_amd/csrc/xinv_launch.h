@@ -19,6 +19,7 @@ struct Plan {
     bool skip;               // masked-tile skipping: launches of K == Plan::K run the listed tiles only
     int ntl, nskip;          // list entries per member (active, multiple of 4 / skipped)
     int skip_pct;            // share of wave-tiles skipped, percent
+    double lone = 1.6;       // planner: cost of a workgroup alone on its CU relative to one of a pair
 };
 
 // kernel variants instantiated per model: mask of streams read as one scalar per row
@@ -490,7 +491,7 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
 // rows, but every CU should hold the same number of workgroups: `occ` of the chosen variant fit
 // per CU (register-limited, queried from the runtime).  Minimise (workgroups per CU, in rounds of
 // 256*occ resident ones) x (steps per tile); rows are then split evenly over the blocks.
-static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int K, int occ)
+static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int K, int occ, double lone = 1.6)
 {
     occ = std::max(1, std::min(occ, 3));
     const int64_t cap = 256 * (int64_t)occ, period = 2 * K + 2;
@@ -501,11 +502,12 @@ static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int
         const int64_t steps = cdiv(rows + 4 * K, period) * period;
         const int64_t wgs = (int64_t)cdiv(nstrip * nr, 4) * nbatch;
         // rounds of `cap` resident workgroups; inside a round a CU holds ceil(w/256) of them,
-        // and a lone workgroup on a CU leaves issue slots idle (charged like 1.6)
+        // and a lone workgroup on a CU leaves issue slots idle (charged like `lone`: 1.6 for the
+        // issue-bound variants with one or two vector streams, ~1 for the bandwidth-bound ones)
         const int64_t rounds = cdiv(wgs, cap);
         const int64_t w_last = wgs - (rounds - 1) * cap;
-        const double full = (occ == 1) ? 1.6 : (double)occ;
-        const double last = (w_last <= 256) ? 1.6 : (double)cdiv(w_last, 256);
+        const double full = (occ == 1) ? lone : (double)occ;
+        const double last = (w_last <= 256) ? lone : (double)cdiv(w_last, 256);
         const double cost = ((double)(rounds - 1) * full + last) * (double)steps;
         if (cost <= best_cost * 1.0001) { best_cost = std::min(cost, best_cost); best = nr; }   // ties: more, shorter tiles
     }
@@ -514,15 +516,15 @@ static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int
 
 // Cost of a fused 2-D launch in (workgroups per CU) x (steps per tile) units -- the model behind
 // choose_row_blocks, shared with the masked-tile planner.
-static double tile_cost(int64_t wgs, int64_t rows, int K, int occ)
+static double tile_cost(int64_t wgs, int64_t rows, int K, int occ, double lone = 1.6)
 {
     occ = std::max(1, std::min(occ, 3));
     const int64_t cap = 256 * (int64_t)occ, period = 2 * K + 2;
     const int64_t steps = cdiv(rows + 1 + 4 * K, period) * period;
     const int64_t rounds = std::max<int64_t>(1, cdiv(wgs, cap));
     const int64_t w_last = wgs - (rounds - 1) * cap;
-    const double full = (occ == 1) ? 1.6 : (double)occ;
-    const double last = (w_last <= 256) ? 1.6 : (double)cdiv(w_last, 256);
+    const double full = (occ == 1) ? lone : (double)occ;
+    const double last = (w_last <= 256) ? lone : (double)cdiv(w_last, 256);
     return ((double)(rounds - 1) * full + last) * (double)steps;
 }
 
@@ -606,7 +608,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
         fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
     }
-    const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb, cdiv(yc, pl.nrb), K, occ);
+    const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb, cdiv(yc, pl.nrb), K, occ, pl.lone);
     // candidates: the row split that brings the ACTIVE workgroups back to the default count sits
     // near nrb / (active share); search a window around it
     int best = pl.nrb; double best_cost = 1e300;
@@ -619,9 +621,9 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         lo = (int)std::min<int64_t>(cap_rows, std::max<int64_t>(pl.nrb, (int64_t)(centre * 0.85)));
         hi = (int)std::min<int64_t>(cap_rows, std::max<int64_t>(lo, (int64_t)(centre * 1.10) + 1));
     }
-    best_cost = tile_cost(active_wgs(pl.nrb, nullptr), cdiv(yc, pl.nrb), K, occ);   // keep the split, skip only
+    best_cost = tile_cost(active_wgs(pl.nrb, nullptr), cdiv(yc, pl.nrb), K, occ, pl.lone);   // keep the split, skip only
     for (int nrb = lo; nrb <= hi; nrb++) {
-        const double c = tile_cost(active_wgs(nrb, nullptr), cdiv(yc, nrb), K, occ);
+        const double c = tile_cost(active_wgs(nrb, nullptr), cdiv(yc, nrb), K, occ, pl.lone);
         if (c < best_cost) { best_cost = c; best = nrb; }
     }
     if (!forced && best_cost > 0.95 * cost0) return XINV_OK;            // (fixed split: skipping must save 5 % of the workgroups)
