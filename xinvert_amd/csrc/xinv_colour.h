@@ -627,7 +627,7 @@ __global__ void k_ctl_init(XinvCtl *ctl, int64_t nbatch)
     c.normPrev = DBL_MAX;
     c.flag1 = 0.0; c.flag2 = 0.0;
     c.loop = 0; c.sweeps = 0;
-    c.done = 0; c.overflow = 0; c.wrote = 0; c.ticket = 0;
+    c.done = 0; c.overflow = 0; c.wrote = 0; c.ticket = 0; c.seq = 1; c.pad_ = 0;
     ctl[m] = c;
 }
 

@@ -45,6 +45,14 @@
 #ifndef XINV_NORM_BRANCH
 #define XINV_NORM_BRANCH 1
 #endif
+#ifndef XINV_ROW32
+#define XINV_ROW32 0
+#endif
+#if XINV_ROW32
+typedef int row_t;                 // row counters (the grid has fewer than 2^31 rows; offsets stay 64-bit)
+#else
+typedef int64_t row_t;
+#endif
 #ifndef XINV_LOAD_EARLY
 #define XINV_LOAD_EARLY 0
 #endif
@@ -384,21 +392,29 @@ __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &i
     }
 }
 
-// ---- norm partials: wave -> workgroup -> global, then the last-arriving workgroup finalises ---
-// acc/cnt: this lane's sum |S| and count over S != undef for each of the K fused sweeps.  Partials
-// are written write-through (agent-scope atomic stores), the arrival ticket is an agent-scope
-// atomic, and the last workgroup reads the partials with agent-scope loads and adds them in
-// index order: deterministic, no floating-point atomics.  NWV = wavefronts per workgroup.
+// ---- norm partials: wave -> workgroup -> global, then one workgroup finalises ----------------
+// acc/cnt: this lane's sum |S| and count over S != undef for each of the K fused sweeps.
+// No workgroup waits on memory here except the reducer: a workgroup publishes its partial of
+// sweep s as three 64-bit words -- low half of the sum, high half, count -- each carrying the
+// launch's sequence number (ctl->seq, read at kernel start) in its upper 32 bits, with relaxed
+// agent-scope stores (write-through, each word single-copy atomic, any arrival order).  The
+// workgroup dispatched last (blockIdx.x == gridDim.x - 1: every other one of the member is
+// resident or finished by then, so waiting on them cannot deadlock) polls the words until all
+// carry the current number, adds the partials in a fixed order (deterministic; no floating-point
+// atomics), applies the reference's stop rule once per fused sweep and advances ctl->seq.
+// The buffer is cleared per solve (sequence numbers restart at 1).  Against an arrival ticket
+// (store, wait, atomic, wait, last one reads) this takes two memory round trips off the tail of
+// EVERY workgroup: 3600x1800 launch 32.8 -> see DESIGN.md.  NWV = wavefronts per workgroup.
+#define XINV_PW 3          /* words per partial */
 template <int K, int NWV>
 __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const int (&cnt)[K],
-                                                   int wave, int lane, int NB, int T,
-                                                   unsigned long long *psum, long long *pcnt,
-                                                   XinvCtl *ctl, const XinvStop &stop,
+                                                   int wave, int lane, int NB, int T, unsigned tag,
+                                                   unsigned long long *pw, XinvCtl *ctl,
+                                                   const XinvStop &stop,
                                                    double xsum = 0.0, long long xcnt = 0)
 {
     __shared__ double ls[NWV][K];
     __shared__ long long lcn[NWV][K];
-    __shared__ unsigned s_last;
 #pragma unroll
     for (int s = 0; s < K; s++) {
         double ws = xinv_wave_sum(acc[s]);
@@ -406,42 +422,79 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
         if (lane == 0) { ls[wave][s] = ws; lcn[wave][s] = wc; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    const unsigned long long hi = (unsigned long long)tag << 32;
+    if (threadIdx.x < K) {
+        const int s = threadIdx.x;
+        double ts = 0.0; long long tc = 0;
+        for (int q = 0; q < NWV; q++) { ts += ls[q][s]; tc += lcn[q][s]; }
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(ts);
+        unsigned long long *q = pw + ((size_t)s * NB + T) * XINV_PW;
+        __hip_atomic_store(q + 0, hi | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, hi | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 2, hi | (unsigned long long)(unsigned)tc, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (blockIdx.x != gridDim.x - 1) return;
+
+    // reducer: item i = s * NB + t ; thread tid takes i = tid, tid + NT, ... four at a time so
+    // that the twelve loads of a pass are in flight together
+    constexpr int NT = NWV * XINV_WAVE, C = 4;
+    const int tid = threadIdx.x, nitem = K * NB;
+    double ps[K]; long long pc[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) { ps[s] = 0.0; pc[s] = 0; }
+    for (int base = 0; base < nitem; base += NT * C) {
+        unsigned long long w[C][XINV_PW];
+        bool ready;
+        do {
+            ready = true;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int i = base + c * NT + tid;
+                if (i < nitem) {
+#pragma unroll
+                    for (int k = 0; k < XINV_PW; k++)
+                        w[c][k] = __hip_atomic_load(pw + (size_t)i * XINV_PW + k, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < XINV_PW; k++) w[c][k] = hi;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++)
+#pragma unroll
+                for (int k = 0; k < XINV_PW; k++) ready = ready && ((unsigned)(w[c][k] >> 32) == tag);
+        } while (!ready);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int i = base + c * NT + tid;
+            const double v = __longlong_as_double((long long)((w[c][1] << 32) | (w[c][0] & 0xffffffffull)));
+            const long long n = (long long)(unsigned)w[c][2];
+#pragma unroll
+            for (int s = 0; s < K; s++) {
+                const bool mine = (i < nitem) && (i >= s * NB) && (i < (s + 1) * NB);
+                ps[s] += mine ? v : 0.0;
+                pc[s] += mine ? n : 0;
+            }
+        }
+    }
+    __syncthreads();                                   // ls / lcn are reused
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        double ws = xinv_wave_sum(ps[s]);
+        long long wc = xinv_wave_sum_ll(pc[s]);
+        if (lane == 0) { ls[wave][s] = ws; lcn[wave][s] = wc; }
+    }
+    __syncthreads();
+    if (tid == 0) {
 #pragma unroll
         for (int s = 0; s < K; s++) {
             double ts = 0.0; long long tc = 0;
             for (int q = 0; q < NWV; q++) { ts += ls[q][s]; tc += lcn[q][s]; }
-            __hip_atomic_store(&psum[s * NB + T], (unsigned long long)__double_as_longlong(ts),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&pcnt[s * NB + T], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xinv_ctl_update(ctl, ts + xsum, tc + xcnt, stop);     // + the skipped tiles' constant share
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
-        unsigned old = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old == (unsigned)(NB - 1)) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last || wave != 0) return;
-
-    double tot[K];
-    long long tcn[K];
-#pragma unroll
-    for (int s = 0; s < K; s++) {
-        double ps = 0.0; long long pc = 0;
-        for (int t = lane; t < NB; t += XINV_WAVE) {
-            unsigned long long bits = __hip_atomic_load(&psum[s * NB + t], __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-            ps += __longlong_as_double((long long)bits);
-            pc += __hip_atomic_load(&pcnt[s * NB + t], __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT);
-        }
-        tot[s] = xinv_wave_sum(ps) + xsum;                 // + the skipped tiles' constant share
-        tcn[s] = xinv_wave_sum_ll(pc) + xcnt;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int s = 0; s < K; s++) xinv_ctl_update(ctl, tot[s], tcn[s], stop);
-        __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl->seq = tag + 1u;
     }
 }
 
@@ -471,6 +524,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && ctl->done) return;
+    const unsigned tag = ctl->seq;
 
     // ---- tile of this wavefront; workgroup -> tile map keeps each XCD on a band of rows ----
     // A member's wave-tiles are numbered strip-fastest, then row block; workgroup T takes four
@@ -496,18 +550,22 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
         active = wt >= 0;
         wt = active ? wt : 0;
     }
+#if XINV_WAVE_UNIFORM
+    wt = __builtin_amdgcn_readfirstlane(wt);       // row bookkeeping on the scalar unit
+#endif
     const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
     const int64_t xc = a.xc, yc = a.yc;
+    const row_t ycr = (row_t)yc;
     const int64_t xu0 = (int64_t)strip * UW;
     // rows owned by this tile: fixed height RY, or (RY == 0) the yc rows split evenly over the
     // nrb row blocks, boundaries rounded to even rows
-    int64_t yu0, yu1;
+    row_t yu0, yu1;
     if (a.RY > 0) {
-        yu0 = (int64_t)rb * a.RY;
-        yu1 = (yu0 + a.RY < yc) ? yu0 + a.RY : yc;
+        yu0 = (row_t)rb * a.RY;
+        yu1 = (yu0 + a.RY < ycr) ? yu0 + a.RY : ycr;
     } else {
-        yu0 = (((int64_t)rb * yc) / a.nrb) & ~(int64_t)1;
-        yu1 = (rb + 1 == a.nrb) ? yc : ((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
+        yu0 = (row_t)((((int64_t)rb * yc) / a.nrb) & ~(int64_t)1);
+        yu1 = (rb + 1 == a.nrb) ? ycr : (row_t)((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
     }
     const double u = a.sc_.undef;
 
@@ -528,24 +586,31 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     if (active) {
 #if XINV_INCR_OFF
         // rows are requested in increasing order: keep the clamped row offset incrementally
-        int64_t lrow = yu0 - H, loff = (lrow < 0 ? 0 : (lrow > yc - 1 ? yc - 1 : lrow)) * xc;
+        row_t lrow = yu0 - H;
+        int64_t loff = (int64_t)(lrow < 0 ? 0 : (lrow > ycr - 1 ? ycr - 1 : lrow)) * xc;
 #endif
-        auto load = [&](int64_t r) {
+        auto load = [&](row_t r) {
             RowPack<NC> p;
 #if XINV_INCR_OFF
             const int64_t off = loff;
-            loff += (lrow >= 0 && lrow < yc - 1) ? xc : 0;
+            loff += (lrow >= 0 && lrow < ycr - 1) ? xc : 0;
             lrow += 1;
             (void)r;
 #else
-            const int64_t rr = r < 0 ? 0 : (r > yc - 1 ? yc - 1 : r);
-            const int64_t off = rr * xc;
+            const row_t rr = r < 0 ? 0 : (r > ycr - 1 ? ycr - 1 : r);
+            const int64_t off = (int64_t)rr * xc;
 #endif
             p.s = ld2<AL>(srcS, off, lc);
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 if ((UM >> q) & 1u) {
+#if XINV_WAVE_UNIFORM == 2
+                    const double *rp = cp[q] + off;      // keep the row value a (broadcast) vector load:
+                    asm("" : "+v"(rp));                  // in order with the others on vmcnt
+                    double t = *rp;
+#else
                     double t = cp[q][off];               // scalar load: one value per row
+#endif
 #if XINV_FORCE_VGPR
                     asm volatile("" : "+v"(t));          // held in a VGPR pair: SGPRs are scarcer here
 #endif
@@ -579,22 +644,22 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
         };
 
         // one pipeline step on the window whose newest row r sits in slot U
-        auto step = [&](int64_t r, auto utag) {
+        auto step = [&](row_t r, auto utag) {
             constexpr int U = decltype(utag)::value;
             constexpr int X = (U & 1) ? 0 : 1;       // r even -> .y ; all stages of a step share it
 #define SLOT(w) ((U - (w) + 4 * D) % D)              /* slot of row r - w */
             {   // row r-1 is complete in the window: its predicate, once for all 2K half-sweeps
-                const bool rv = (r - 1 >= 1) && (r - 1 <= yc - 2);
+                const bool rv = (r - 1 >= 1) && (r - 1 <= ycr - 2);
                 M::template derive<UM, D>(cw, U, SLOT(1), rv && lc.ok_x, rv && lc.ok_y, a.sc_);
             }
 #pragma unroll
             for (int s = 1; s <= K; s++) {
                 {   // red half-sweep of sweep s on row ja = r-2s+1
-                    const int64_t ja = r - 2 * s + 1;
+                    const row_t ja = r - 2 * s + 1;
                     const int sj = SLOT(2 * s - 1), sjp = SLOT(2 * s - 2), sjm = SLOT(2 * s);
                     if (EXT) {           // BCy == 'extend': compiled out otherwise
                         if (ja == 1) fused_extend_fix(sw[sjm], sw[sj], lc, a.tall, u);
-                        if (ja == yc - 2) fused_extend_fix(sw[sjp], sw[sj], lc, a.tall, u);
+                        if (ja == ycr - 2) fused_extend_fix(sw[sjp], sw[sj], lc, a.tall, u);
                     }
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
@@ -604,7 +669,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                     setc<X>(sw[sj], v);
                 }
                 {   // black half-sweep of sweep s on row jb = r-2s
-                    const int64_t jb = r - 2 * s;
+                    const row_t jb = r - 2 * s;
                     const int sj = SLOT(2 * s), sjp = SLOT(2 * s - 1), sjm = SLOT(2 * s + 1);
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
@@ -633,14 +698,14 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #endif
                 }
             }
-            const int64_t jo = r - 2 * K;                  // row leaving the pipeline
+            const row_t jo = r - 2 * K;                  // row leaving the pipeline
             if (jo >= yu0 && jo < yu1) {
                 const double2 t = sw[SLOT(2 * K)];
                 if (AL) {
-                    if (lc.use_x) *reinterpret_cast<double2 *>(dstS + jo * xc + st0) = t;
+                    if (lc.use_x) *reinterpret_cast<double2 *>(dstS + (int64_t)jo * xc + st0) = t;
                 } else {
-                    if (lc.use_x) dstS[jo * xc + st0] = t.x;
-                    if (lc.use_y) dstS[jo * xc + st0 + 1] = t.y;
+                    if (lc.use_x) dstS[(int64_t)jo * xc + st0] = t.x;
+                    if (lc.use_y) dstS[(int64_t)jo * xc + st0 + 1] = t.y;
                 }
             }
 #undef SLOT
@@ -649,12 +714,12 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
         // Prefetch ring: PF rows in flight per wavefront (PF divides D so ring indices are
         // compile-time constants).  Bytes in flight, not issue rate, bound this kernel: a wave
         // keeps PF x (1 + vector streams) KiB outstanding.
-        const int64_t r0 = yu0 - H;                        // even: RY and H are even
-        const int64_t rlast = yu1 - 1 + H;
+        const row_t r0 = yu0 - H;                        // even: RY and H are even
+        const row_t rlast = yu1 - 1 + H;
         RowPack<NC> pf[PF];
 #pragma unroll
         for (int t = 0; t < PF; t++) pf[t] = load(r0 + t);
-        for (int64_t rb_ = r0; rb_ <= rlast; rb_ += D) {
+        for (row_t rb_ = r0; rb_ <= rlast; rb_ += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
                 enter(pf[U % PF], utag);
@@ -671,8 +736,8 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 
     if (a.no_ctl) return;
 
-    xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, a.psum + (size_t)m * XINV_KMAX * NB,
-                             a.pcnt + (size_t)m * XINV_KMAX * NB, ctl, a.stop,
+    xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, tag,
+                             a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop,
                              a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
 }
 

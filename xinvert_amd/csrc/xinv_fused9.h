@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && ctl->done) return;
+    const unsigned tag = ctl->seq;
 
     const int NB = a.nwg;
     int T;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     }
 
     if (a.no_ctl) return;
-    xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, a.psum + (size_t)m * XINV_KMAX * NB,
-                             a.pcnt + (size_t)m * XINV_KMAX * NB, ctl, a.stop,
+    xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, tag,
+                             a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop,
                              a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
 }
