@@ -32,8 +32,8 @@ struct XinvCtl {
     int done;
     int overflow;
     int wrote;             // flag1/flag2 have been written at least once
-    unsigned ticket;       // 3-D fused kernels: workgroup arrival counter of the current launch
-    unsigned seq;          // 2-D fused kernels: sequence number of the next launch (tags its norm partials)
+    unsigned ticket;       // (unused)
+    unsigned seq;          // fused kernels: sequence number of the next launch (tags its norm partials)
     unsigned pad_;
 };
 

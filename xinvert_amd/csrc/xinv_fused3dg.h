@@ -40,6 +40,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && ctl->done) return;
+    const unsigned tag = ctl->seq;
 
     const int NB = a.nstrip * a.njb * a.nkc;
     int T;
@@ -214,40 +215,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
 
     if (a.no_ctl) return;
 
-    __shared__ double ls[NW];
-    __shared__ long long lcn[NW];
-    __shared__ unsigned s_last;
-    {
-        double ws = xinv_wave_sum(acc);
-        long long wc = xinv_wave_sum_ll((long long)cnt);
-        if (lane == 0) { ls[wave] = ws; lcn[wave] = wc; }
-    }
-    __syncthreads();
-    unsigned long long *psum = a.psum + (size_t)m * NB;
-    long long *pcnt = a.pcnt + (size_t)m * NB;
-    if (threadIdx.x == 0) {
-        double ts = 0.0; long long tc = 0;
-        for (int q = 0; q < NW; q++) { ts += ls[q]; tc += lcn[q]; }
-        __hip_atomic_store(&psum[T], (unsigned long long)__double_as_longlong(ts),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&pcnt[T], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned old = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old == (unsigned)(NB - 1)) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last || wave != 0) return;
-    double ps = 0.0; long long pcs = 0;
-    for (int t = lane; t < NB; t += XINV_WAVE) {
-        unsigned long long bits = __hip_atomic_load(&psum[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ps += __longlong_as_double((long long)bits);
-        pcs += __hip_atomic_load(&pcnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ps = xinv_wave_sum(ps);
-    pcs = xinv_wave_sum_ll(pcs);
-    if (lane == 0) {
-        xinv_ctl_update(ctl, ps, pcs, a.stop);
-        __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // norm partials: sequence-tagged words, the last-dispatched workgroup finalises
+    // (xinv_norm_finalize, xinv_fused.h)
+    const double acc1[1] = {acc};
+    const int cnt1[1] = {cnt};
+    xinv_norm_finalize<1, NW>(acc1, cnt1, wave, lane, NB, T, tag, a.psum + (size_t)m * NB * XINV_PW,
+                              ctl, a.stop);
 }

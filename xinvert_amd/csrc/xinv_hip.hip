@@ -326,12 +326,12 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     size_t pbytes;
     if (pl.path == XINV_PATH_FUSED)
         pbytes = (size_t)p.nbatch * XINV_KMAX * (is3d(p.kind) ? (size_t)pl.nsg * pl.nrb * std::max(1, pl.nkc) : (size_t)pl.nsg) *
-                 (3 * sizeof(unsigned long long));      // 2-D: three tagged words per partial; 3-D: sum + count
+                 (3 * sizeof(unsigned long long));      // three tagged words per partial
     else
         pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
     rc = ensure_dev(&ws->partials, &ws->partials_cap, pbytes);
     if (rc) return rc;
-    if (pl.path == XINV_PATH_FUSED && !is3d(p.kind))            // tagged partials: no stale sequence numbers
+    if (pl.path == XINV_PATH_FUSED)                              // tagged partials: no stale sequence numbers
         HIPCHK(hipMemsetAsync(ws->partials, 0, pbytes, st));
     double *S2 = nullptr;
     if (pl.path == XINV_PATH_COLOUR && p.kind == KIND_BIH2D) {       // side buffer of the row-class kernel
