@@ -184,12 +184,12 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
             update(S2, S1, S3, kk, jP, jM, XT{});
             const bool pin = row_use && (kk >= k0) && (kk < k1);
             const double2 t = sw[S2];
-            const bool cx = pin && lc.use_x && (t.x != u);
-            const bool cy = pin && lc.use_y && (t.y != u);
-            acc += (cx ? fabs(t.x) : 0.0);
-            acc += (cy ? fabs(t.y) : 0.0);
-            cnt += (cx ? 1 : 0) + (cy ? 1 : 0);
-            if (pin) {
+            if (pin) {                                         // wave-uniform: an owned row of an owned plane
+                const bool cx = lc.use_x & (t.x != u);
+                const bool cy = lc.use_y & (t.y != u);
+                acc += (cx ? fabs(t.x) : 0.0);
+                acc += (cy ? fabs(t.y) : 0.0);
+                cnt += (cx ? 1 : 0) + (cy ? 1 : 0);
                 double *d = dstS + (kk * yc + j) * xc + st0;
                 if (AL) { if (lc.use_x) *reinterpret_cast<double2 *>(d) = t; }
                 else { if (lc.use_x) d[0] = t.x; if (lc.use_y) d[1] = t.y; }

@@ -213,12 +213,13 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
         }
 
         auto tally = [&](int s, int64_t j, const double2 &t) {      // row j now holds sweep s+1
-            const bool rowin = (j >= yu0) && (j < yu1);
-            const bool cx = rowin && lc.use_x && (t.x != u);
-            const bool cy = rowin && lc.use_y && (t.y != u);
-            acc[s] += (cx ? fabs(t.x) : 0.0);
-            acc[s] += (cy ? fabs(t.y) : 0.0);
-            cnt[s] += (cx ? 1 : 0) + (cy ? 1 : 0);
+            if ((j >= yu0) && (j < yu1)) {                          // wave-uniform: an owned row
+                const bool cx = lc.use_x & (t.x != u);
+                const bool cy = lc.use_y & (t.y != u);
+                acc[s] += (cx ? fabs(t.x) : 0.0);
+                acc[s] += (cy ? fabs(t.y) : 0.0);
+                cnt[s] += (cx ? 1 : 0) + (cy ? 1 : 0);
+            }
         };
         auto store = [&](int64_t j, const double2 &t) {
             if (j >= yu0 && j < yu1) {
