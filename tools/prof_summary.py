@@ -7,7 +7,7 @@
         HBM-side bytes per launch of one kernel = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes).
         The factor 2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM section):
         this rocprofv3 tallies 128-B read requests at 64 B.  It is re-checked in every profile by
-        k_any_nonzero, which streams exactly one coefficient array (known byte count).
+        k_strip_active / k_any_nonzero, which stream exactly one array (known byte count).
 """
 import json
 import os
@@ -56,18 +56,24 @@ def main():
         fdb, wdb, ksub, key = sys.argv[2:6]
         f, nf = mean_counter(fdb, 'FETCH_SIZE', ksub)
         w, nw = mean_counter(wdb, 'WRITE_SIZE', ksub)
-        cal, _ = mean_counter(fdb, 'FETCH_SIZE', 'k_any_nonzero')
+        # calibration: a kernel that streams exactly one yc*xc array once -- k_strip_active reads
+        # the forcing (every solve with masked-tile skipping), k_any_nonzero a coefficient array
+        cal, _ = mean_counter(fdb, 'FETCH_SIZE', 'k_strip_active')
+        calname = 'k_strip_active'
+        if not cal:
+            cal, _ = mean_counter(fdb, 'FETCH_SIZE', 'k_any_nonzero')
+            calname = 'k_any_nonzero'
         traffic = (2.0 * f + w) * 1024.0
         print('%s: FETCH_SIZE %.1f KiB (n=%d) x2, WRITE_SIZE %.1f KiB (n=%d) -> %.4e B per launch'
               % (ksub, f, nf, w, nw, traffic))
         if cal:
-            print('calibration: k_any_nonzero FETCH_SIZE %.1f KiB (streams one coefficient array)' % cal)
+            print('calibration: %s FETCH_SIZE %.1f KiB (streams one yc*xc array)' % (calname, cal))
         if len(sys.argv) > 6:
             path = sys.argv[6]
             d = json.load(open(path)) if os.path.exists(path) else {}
             d[key] = traffic
             d[key + '_detail'] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'fetch_correction': 2.0,
-                                  'calibration_any_nonzero_FETCH_KiB': cal}
+                                  'calibration_kernel': calname, 'calibration_FETCH_KiB': cal}
             json.dump(d, open(path, 'w'), indent=1, sort_keys=True)
     else:
         raise SystemExit(__doc__)
