@@ -19,7 +19,7 @@
 #endif
 
 // One control block per batch member, resident in HBM for the whole solve.  Written only by
-// the last-arriving workgroup of a sweep launch (fused path) or by k_norm_final (colour path);
+// the reducing workgroup of a sweep launch (fused path) or by k_norm_final (colour path);
 // read by every later launch (`done` => the launch is a no-op for that member) and by the host
 // every `check_every` launches.  Mirrors the reference's loop variables (numbas.py:278-283,
 // 401-414): loop, normPrev, flags[1], flags[2], overflow.
@@ -32,7 +32,7 @@ struct XinvCtl {
     int done;
     int overflow;
     int wrote;             // flag1/flag2 have been written at least once
-    unsigned ticket;       // (unused)
+    unsigned ticket;       // (spare)
     unsigned seq;          // fused kernels: sequence number of the next launch (tags its norm partials)
     unsigned pad_;
 };

@@ -21,7 +21,7 @@
 //
 // 'extend' (BCy): rows 0 / yc-1 of planes 1..zc-2 take rows 1 / yc-2 of the same plane at the
 // start of the sweep (numbas.py:87-115); folded into the load of those rows.
-// Norm and stopping rule: as the 2-D kernel (deterministic partials, last-arriver finalises).
+// Norm and stopping rule: as the 2-D kernel (xinv_norm_finalize: tagged partials, one reducer).
 #pragma once
 #include "xinv_fused.h"
 
@@ -40,7 +40,6 @@ struct Fused3Args {
     XinvCtl *ctl;
     XinvStop stop;
     unsigned long long *psum;  // [nbatch][NB]
-    long long *pcnt;
 };
 
 // 7-point update with the mask folded into a select (numbas.py:146-169).

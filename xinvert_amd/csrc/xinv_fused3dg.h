@@ -29,7 +29,6 @@ struct Fused3GArgs {
     XinvCtl *ctl;
     XinvStop stop;
     unsigned long long *psum;  // [nbatch][NB]
-    long long *pcnt;
 };
 
 template <int NW, bool AL, bool EXT>

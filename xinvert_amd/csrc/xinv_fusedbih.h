@@ -93,8 +93,7 @@ struct FusedBihArgs {
     XinvScal sc_;
     XinvCtl *ctl;
     XinvStop stop;
-    unsigned long long *psum;  // [nbatch][XINV_KMAX][NB]
-    long long *pcnt;
+    unsigned long long *psum;  // [nbatch][XINV_KMAX][NB][3] sequence-tagged norm partials
     const int *tile_list;      // masked-tile skipping, as FusedArgs
     int ntl;
     const double *xsum;

@@ -7,7 +7,7 @@
 // Control flow of one solve (all batch members together, one stream):
 //   k_ctl_init -> [ sweep launches ... ] x check_every -> async read-back of the per-member
 //   control blocks -> repeat until every member has stopped.  The stopping rule runs on the
-//   device after every sweep (last-arriving workgroup / k_norm_final); once a member is done
+//   device after every sweep (reducing workgroup / k_norm_final); once a member is done
 //   every later launch is a no-op for it, so S holds exactly the sweep the reference stops at.
 //
 // Threading: solves on one device are serialised by a per-device lock (they share the cached

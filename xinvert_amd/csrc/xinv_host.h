@@ -28,7 +28,7 @@ struct Workspace {
     std::recursive_mutex busy;                          // one solve at a time per device
     double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
     XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
-    void *partials = nullptr; size_t partials_cap = 0;  // psum + pcnt
+    void *partials = nullptr; size_t partials_cap = 0;  // norm partials
     int *dflag = nullptr;
     int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl

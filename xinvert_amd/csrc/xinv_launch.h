@@ -129,7 +129,6 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.stop = p.stop;
     const size_t NBmax = (size_t)pl.nsg;             // workgroups per member, narrowest strips (K = XINV_KMAX)
     a.psum = (unsigned long long *)ws->partials;
-    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
     if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
         a.tile_list = ws->d_list;
         a.ntl = pl.ntl;
@@ -202,7 +201,6 @@ static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *
     a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
     const size_t NBmax = (size_t)pl.nsg;
     a.psum = (unsigned long long *)ws->partials;
-    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
     if (pl.skip && K == pl.K) {                      // fully masked tiles are left out (plan_tile_skip)
         a.tile_list = ws->d_list;
         a.ntl = pl.ntl;
@@ -256,7 +254,6 @@ static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, d
     a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
     const size_t NB = (size_t)pl.nsg * pl.nrb * a.nkc;
     a.psum = (unsigned long long *)ws->partials;
-    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * NB * sizeof(double));
     const bool ext = (p.BCy == XINV_BC_EXTEND), uni = (pl.um == 7u);
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
@@ -298,7 +295,6 @@ static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, 
     a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
     const size_t NBmax = (size_t)pl.nsg;
     a.psum = (unsigned long long *)ws->partials;
-    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * XINV_KMAX * NBmax * sizeof(double));
     if (pl.skip) {                                   // fully masked tiles are left out (plan_tile_skip)
         a.tile_list = ws->d_list;
         a.ntl = pl.ntl;
@@ -351,7 +347,6 @@ static int launch_fused3dg(const Problem &p, const Plan &pl, const double *src, 
     a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
     const size_t NB = (size_t)pl.nsg * pl.nrb * a.nkc;
     a.psum = (unsigned long long *)ws->partials;
-    a.pcnt = (long long *)((char *)ws->partials + p.nbatch * NB * sizeof(double));
     const bool ext = (p.BCy == XINV_BC_EXTEND);
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
