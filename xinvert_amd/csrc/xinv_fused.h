@@ -414,6 +414,8 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
 {
     __shared__ double ls[NWV][K];
     __shared__ long long lcn[NWV][K];
+    __shared__ unsigned s_timeout;
+    if (threadIdx.x == 0) s_timeout = 0u;
 #pragma unroll
     for (int s = 0; s < K; s++) {
         double ws = xinv_wave_sum(acc[s]);
@@ -442,7 +444,12 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
     double ps[K]; long long pc[K];
 #pragma unroll
     for (int s = 0; s < K; s++) { ps[s] = 0.0; pc[s] = 0; }
-    for (int base = 0; base < nitem; base += NT * C) {
+    // Watchdog: a partial that never arrives would otherwise spin until the driver's reset.  After
+    // ~2 s (s_memrealtime ticks at 100 MHz) the member is stopped with overflow = 2, which the
+    // host reports as an internal error.
+    unsigned long long t0 = 0;                         // taken lazily: only a pass that found nothing costs a clock read
+    bool timed_out = false;
+    for (int base = 0; base < nitem && !timed_out; base += NT * C) {
         unsigned long long w[C][XINV_PW];
         bool ready;
         do {
@@ -464,7 +471,12 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
             for (int c = 0; c < C; c++)
 #pragma unroll
                 for (int k = 0; k < XINV_PW; k++) ready = ready && ((unsigned)(w[c][k] >> 32) == tag);
-        } while (!ready);
+            if (!ready) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > 200000000ull) { timed_out = true; s_timeout = 1u; }
+            }
+        } while (!ready && !timed_out);
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int i = base + c * NT + tid;
@@ -478,7 +490,14 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
             }
         }
     }
-    __syncthreads();                                   // ls / lcn are reused
+    __syncthreads();                                   // ls / lcn are reused below
+    if (s_timeout) {
+        if (tid == 0) {
+            ctl->overflow = 2; ctl->done = 1; ctl->sweeps = ctl->loop + 1;
+            ctl->seq = tag + 1u;
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < K; s++) {
         double ws = xinv_wave_sum(ps[s]);

@@ -468,6 +468,11 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (pl.path != XINV_PATH_FUSED)                      // drain the queued no-op tail (the fused path syncs below)
         HIPCHK(hipStreamSynchronize(st));
     if (!all_done) { t_err = "internal: sweep budget exhausted before the stop rule fired"; return XINV_ERR_HIP; }
+    for (int64_t m = 0; m < p.nbatch; m++)
+        if (hc[m].overflow == 2) {
+            t_err = "internal: norm partials of a sweep launch never arrived (watchdog)";
+            return XINV_ERR_HIP;
+        }
 
     // ---- fused path: put each member's final state into S ------------------------------------
     int64_t sweeps_max = 0;
