@@ -57,7 +57,8 @@ extern "C" {
 typedef struct xinv_options {
     int32_t device;             /* HIP device ordinal; -1 = current device                      */
     int32_t path;               /* XINV_PATH_*                                                   */
-    int32_t sweeps_per_launch;  /* fused path: sweeps fused in one launch (1 or 2); 0 = auto    */
+    int32_t sweeps_per_launch;  /* fused path: sweeps fused in one launch (1..4, capped at what
+                                   the kernel variant supports); 0 = auto                      */
     int32_t check_every;        /* launches between host polls of the device stop flags; 0=auto */
     int32_t rows_per_tile;      /* fused 2-D: rows per tile (n > 0) or exactly -n evenly split row
                                    blocks (n < 0); biharmonic one-pass kernel: rows per block (multiple

@@ -215,6 +215,53 @@ def test_fused_early_stop_exact_sweep(kind, K, tol):
     assert st['sweeps_max'] == flo[2] + 1
 
 
+def _uniform2d(p):
+    """A and C constant along x (a lat-lon grid's cos(lat) factors): the per-row-scalar variants."""
+    q = dict(p); cs = [np.array(c, copy=True) for c in p['coefs']]
+    ic = 2                                            # std2d: A B C F ; gen2d: A B C D E F G
+    cs[0] = np.repeat(cs[0][:, :1], cs[0].shape[1], axis=1)
+    cs[ic] = np.repeat(cs[ic][:, :1], cs[ic].shape[1], axis=1)
+    q['coefs'] = cs
+    return q
+
+
+@pytest.mark.parametrize('BCy,BCx', BCS)
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', FUSED_SHAPES + [(90, 250)])
+@pytest.mark.parametrize('K', [3, 4])
+@pytest.mark.parametrize('nsw', [24, 22])
+def test_fused_standard_three_and_four_sweeps_per_pass(BCy, BCx, msk, shape, K, nsw):
+    """K = 3, 4 (standard form with per-row A, C): same ordering, so bit for bit the oracle;
+    nsw + 1 sweeps leave a tail of 1 (25 = 6x4 + 1 = 8x3 + 1) or 3 / 2 (23) for a shorter last pass."""
+    yc, xc = shape
+    if BCx == 'periodic' and xc % 2:
+        pytest.skip('odd-xc periodic seam goes through the colour path (covered there)')
+    p = _uniform2d(rand2d('std2d', yc, xc, BCy, BCx, 0, msk, seed=_seed(('k34', BCy, BCx, msk, shape))))
+    So, flo = run_oracle(p, nsw, 1e-9, COLOUR_2)
+    for rows in (16, 0):
+        S, fl, st = run_hip_batched([p], nsw, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=rows)
+        assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == K, st
+        assert_same(S[0], fl[0], So, flo, 'fused K=%d %r rows=%d' % (K, shape, rows))
+    S, fl, st = run_hip_batched([p], nsw, 1e-9, path=PATH_FUSED)            # auto: the deepest variant
+    assert st['sweeps_per_launch'] in (3, 4)
+    assert_same(S[0], fl[0], So, flo, 'fused K=auto %r' % (shape,))
+
+
+@pytest.mark.parametrize('K', [3, 4])
+@pytest.mark.parametrize('tol', [3e-3, 1e-3, 2e-4, 5e-5])
+def test_fused_early_stop_exact_sweep_deep_passes(K, tol):
+    """Stopping inside a 3- or 4-sweep launch returns exactly the stopping sweep."""
+    p = _uniform2d(rand2d('std2d', 40, 300, 'fixed', 'periodic', 0, 1, seed=7))
+    So, flo = run_oracle(p, 500, tol, COLOUR_2)
+    assert 2 < flo[2] < 499
+    for skip in (0, 1):
+        S, fl, st = run_hip_batched([p], 500, tol, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=8,
+                                    check_every=5, force_tile_skip=skip)
+        assert st['sweeps_per_launch'] == K
+        assert_same(S[0], fl[0], So, flo, 'early stop K=%d' % K)
+        assert st['sweeps_max'] == flo[2] + 1
+
+
 def test_fused_equals_colour_path():
     p = rand2d('gen2d', 50, 260, 'extend', 'periodic', 0, 1, seed=11)
     S1, f1, _ = run_hip_batched([p], 30, 0.0, path=PATH_FUSED)
@@ -721,11 +768,13 @@ def test_seeded_fuzz_against_the_oracle(chunk):
                 p = _uniform3dg(p)
             elif kind == 'std3d':
                 p = _uniform3d(p, None)
+            elif kind == 'std2d' and not bnz:
+                p = _uniform2d(p)
         opt = {}
         if kind in ('bih2d', 'std3d', 'gen3d') and int(rng.integers(2)):
             opt['rows_per_tile'] = [3, 9, 27][int(rng.integers(3))] if kind == 'bih2d' else [8, 12, 16][int(rng.integers(3))]
         if kind in ('std2d', 'gen2d', 'std2dt'):
-            opt['sweeps_per_launch'] = int(rng.integers(0, 3))
+            opt['sweeps_per_launch'] = int(rng.integers(0, 5))     # capped at what the variant supports
             if yc >= 8 and int(rng.integers(2)):
                 opt['rows_per_tile'] = -int(rng.integers(1, max(2, yc // 4) + 1))
             opt['force_tile_skip'] = int(rng.integers(2))

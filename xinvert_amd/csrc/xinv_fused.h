@@ -38,7 +38,7 @@
 #include <type_traits>
 #include <utility>
 
-#define XINV_KMAX 2
+#define XINV_KMAX 4             /* most sweeps fused into one pass (standard form with per-row A, C); 2 elsewhere */
 #ifndef XINV_VGPR_MASK
 #define XINV_VGPR_MASK 0
 #endif

@@ -262,10 +262,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             }
             pl.um = pick_um(p.kind, pl.umask);
         }
-        const int kmax = XINV_KMAX;
-        pl.K = opt.sweeps_per_launch > 0 ? opt.sweeps_per_launch : 2;   // 2 sweeps per pass over HBM
-        if (pl.K > kmax) return fail_arg("sweeps_per_launch must be 1 or 2");
-        // Rows per tile (see the cost model below).
+        if (opt.sweeps_per_launch > XINV_KMAX) return fail_arg("sweeps_per_launch must be 1 to 4");
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
         const int cmap3[3] = {0, 2, 3}, cmap6[6] = {0, 2, 3, 4, 5, 6}, cmap4[4] = {0, 3, 4, 5};
         const int nc = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
@@ -273,6 +270,24 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             const int s = (p.kind == KIND_STD2D) ? cmap3[q] : (p.kind == KIND_STD2DT ? cmap4[q] : cmap6[q]);
             pl.aligned = pl.aligned && ptr_al16(p.c[s]) && !(p.sc[s] & 1);
         }
+        // Sweeps per pass over HBM.  Each one costs two more window rows of registers and 2 more
+        // halo rows/columns per side, and saves a pass and a launch: the standard form with per-row
+        // A and C (lat-lon Poisson) still runs two wavefronts per SIMD at K = 4 (3600x1800:
+        // 14.2 / 12.8 / 11.7 us per sweep for K = 2 / 3 / 4); the other variants stay at 2.
+        {
+            const int ksup = (p.kind == KIND_STD2D && pl.um == 3u) ? XINV_KMAX : 2;
+            if (opt.sweeps_per_launch > 0) pl.K = std::min(opt.sweeps_per_launch, ksup);
+            else {
+                pl.K = 2;
+                for (int k = ksup; k > 2; k--) {
+                    int o = 0;
+                    FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
+                    if (fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, k, dim3(1), dim3(256),
+                                       st, dummy, &o) == 0 && o >= 2) { pl.K = k; break; }
+                }
+            }
+        }
+        // Rows per tile (see the cost model below).
         pl.even_split = false;
         if (opt.rows_per_tile > 0) {
             pl.RY = (opt.rows_per_tile + 1) & ~1;
@@ -428,7 +443,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         for (int i = 0; i < check_every && launched < max_sweeps; i++) {
             int r;
             if (pl.path == XINV_PATH_FUSED) {
-                const int k = (max_sweeps - launched >= Kf) ? Kf : 1;
+                const int k = (int)std::min<int64_t>(Kf, max_sweeps - launched);   // the tail: one shorter pass
                 const int cur = (int)(bound.size() & 1);
                 r = launch_one(st, cur, k);
                 if (r) return r;

@@ -54,6 +54,16 @@ static int launch_fused_k(int K, dim3 grid, dim3 block, hipStream_t st, const Fu
     switch (K) {
     case 1: return fused_one<M, 1, AL, UM, EXT>(grid, block, st, a, occ);
     case 2: return fused_one<M, 2, AL, UM, EXT>(grid, block, st, a, occ);
+    // three and four sweeps per pass: only the standard form with per-row A and C keeps two
+    // wavefronts per SIMD at that window depth (194 / 249 VGPRs; the general form does not gain)
+    case 3:
+        if constexpr (std::is_same<M, FusedStd2D>::value && UM == 3u)
+            return fused_one<M, 3, AL, UM, EXT>(grid, block, st, a, occ);
+        break;
+    case 4:
+        if constexpr (std::is_same<M, FusedStd2D>::value && UM == 3u)
+            return fused_one<M, 4, AL, UM, EXT>(grid, block, st, a, occ);
+        break;
     default: break;
     }
     return 1;
