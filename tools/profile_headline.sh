@@ -18,7 +18,7 @@ python $R/tools/prof_summary.py counters $(db /tmp/p_w) $out/${tag}_pmc_write_c2
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d /tmp/p_s -o r -- $cmd > /dev/null 2>&1
 python $R/tools/prof_summary.py counters $(db /tmp/p_s) $out/${tag}_pmc_sq_issue_c2.txt
 cp $R/profiles/traffic.json $out/traffic.json 2>/dev/null
-python $R/tools/prof_summary.py traffic $(db /tmp/p_f) $(db /tmp/p_w) k_fused2d std2d_spl2_um3 $out/traffic.json
+python $R/tools/prof_summary.py traffic $(db /tmp/p_f) $(db /tmp/p_w) k_fused2d std2d_spl4_um3 $out/traffic.json
 head -4 $out/${tag}_kernel_trace_c2.txt | cut -c1-160
 grep k_fused2d $out/${tag}_pmc_sq_issue_c2.txt | cut -c1-30,60-140
 cat $out/traffic.json
