@@ -461,7 +461,7 @@ def _full_c2():
 
 def test_full_size_c2_properties():
     """BASELINE configs[1] (3600 x 1800, land mask).  The oracle cannot finish this size in test
-    time, so check size-independent properties: (i) K=2 fused launches == K=1 launches == colour
+    time, so check size-independent properties: (i) K = 1, 2, 3, 4 fused launches == colour
     path, bit for bit; (ii) land points never change; (iii) the device norm equals a host
     recomputation; (iv) restart: 10 + 10 sweeps == 20 sweeps."""
     from xinvert_amd import synthetic
@@ -476,6 +476,10 @@ def test_full_size_c2_properties():
     assert s4['masked_tile_pct'] == 0 and np.array_equal(S2, S4) and np.allclose(f2, f4, rtol=1e-9, atol=1e-12)
     assert np.array_equal(S1, S2) and np.array_equal(S1, S3)
     assert np.allclose(f1, f2, rtol=1e-9, atol=1e-12) and np.allclose(f1, f3, rtol=1e-9, atol=1e-12)
+    for spl in (3, 4, 0):                                # deeper passes (20 sweeps = 5x4 = 6x3 + 2) and the default
+        S5, f5, s5 = util.run_hip_dev([q], 19, 0.0, sweeps_per_launch=spl)
+        assert s5['sweeps_per_launch'] == (spl or 4) and s5['masked_tile_pct'] >= 15
+        assert np.array_equal(S1, S5) and np.allclose(f1, f5, rtol=1e-9, atol=1e-12)
     land = q['coefs'][3] == U
     assert land.mean() > 0.2 and (S1[0][land] == 0).all()
     assert np.abs(S1[0][~land]).max() > 0
