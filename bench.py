@@ -7,7 +7,7 @@ hot-path pass: `xinv_standard_2d_f64_dev` over one batch of synthetic input alre
 HBM, running a fixed number of sweeps (tolerance = 0, mxLoop = sweeps - 1), norm + stopping
 rule evaluated on the device after every sweep exactly as in production.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--sweeps S] [--spl 1|2] [--members M]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--sweeps S] [--spl 1..4] [--members M]
 
 N > 1: launched by torch.distributed.run, one rank per GPU; every rank solves its own
 member(s) of the batch axis (weak scaling, no data-path collective) and the per-slice flags
@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.m
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--sweeps', type=int, default=500, help='SOR sweeps per step (SURVEY.md 8(d): 500 for C1-C4)')
     ap.add_argument('--spl', type=int, default=0, help='sweeps fused per launch (0 = engine default)')
     ap.add_argument('--rows', type=int, default=0, help='rows per tile (0 = engine default)')
