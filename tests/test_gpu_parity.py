@@ -189,7 +189,7 @@ FUSED_SHAPES = [(17, 24), (12, 20), (40, 300), (70, 130), (33, 257), (8, 4), (3,
 @pytest.mark.parametrize('BCy,BCx', BCS)
 @pytest.mark.parametrize('msk', [0, 1])
 @pytest.mark.parametrize('shape', FUSED_SHAPES)
-@pytest.mark.parametrize('K', [1, 2])
+@pytest.mark.parametrize('K', [1, 2, 3, 4])
 def test_fused_path(kind, BCy, BCx, msk, shape, K):
     yc, xc = shape
     if BCx == 'periodic' and xc % 2:
@@ -197,12 +197,13 @@ def test_fused_path(kind, BCy, BCx, msk, shape, K):
     p = rand2d(kind, yc, xc, BCy, BCx, 0, msk, seed=_seed((kind, BCy, BCx, msk, shape)))
     So, flo = run_oracle(p, 24, 1e-9, COLOUR_2)
     S, fl, st = run_hip_batched([p], 24, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=16)
-    assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == K
+    # the general form has K = 1, 2; the standard form with full coefficient arrays also 3 and 4
+    assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == (K if kind == 'std2d' else min(K, 2))
     assert_same(S[0], fl[0], So, flo, 'fused K=%d %s %r' % (K, kind, shape))
 
 
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
-@pytest.mark.parametrize('K', [1, 2])
+@pytest.mark.parametrize('K', [1, 2, 3])
 @pytest.mark.parametrize('tol', [3e-3, 1e-3, 2e-4])
 def test_fused_early_stop_exact_sweep(kind, K, tol):
     """Stopping inside a K-sweep launch must return the state of exactly the stopping sweep."""
@@ -304,7 +305,7 @@ def _blocky(p, rng, boxes):
 
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d', 'std2dt'])
 @pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'), ('extend', 'fixed')])
-@pytest.mark.parametrize('spl', [1, 2])
+@pytest.mark.parametrize('spl', [1, 2, 3])
 @pytest.mark.parametrize('rows', [-6, -15])
 def test_masked_tiles_are_skipped_without_changing_a_bit(kind, BCy, BCx, spl, rows):
     """Masked-tile skipping (fully masked wave-tiles are left out of the launches, their constant
@@ -669,24 +670,25 @@ def test_mxloop_zero_does_one_sweep():
 @pytest.mark.parametrize('shape', [(9, 12), (12, 19), (30, 260)])
 def test_standard_2d_test_form(BCy, BCx, bnz, msk, shape):
     """numbas.invert_standard_2D_test: colour path (5/9-point, seam) and, when B == C == 0,
-    the fused kernels (K = 1, 2; full-array and x-uniform variants)."""
+    the fused kernels (K = 1, 2, 3; full-array and x-uniform variants)."""
     p = rand2dt(shape[0], shape[1], BCy, BCx, bnz, msk, seed=_seed((BCy, BCx, bnz, msk, shape)))
     So, flo = run_oracle(p, 20, 1e-9, COLOUR_AUTO)
     S, fl, st = run_hip_batched([p], 20, 1e-9, path=PATH_COLOUR)
     assert_same(S[0], fl[0], So, flo, 'std2dt colour')
     if bnz == 0 and not (BCx == 'periodic' and shape[1] % 2):
-        for K in (1, 2):
+        for K in (1, 2, 3):
             S, fl, st = run_hip_batched([p], 20, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=10)
-            assert st['path'] == PATH_FUSED
+            assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == K
             assert_same(S[0], fl[0], So, flo, 'std2dt fused K=%d' % K)
         if not msk:
             q = dict(p)
             q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k in (0, 3, 4) else c
                           for k, c in enumerate(p['coefs'])]
             So, flo = run_oracle(q, 20, 1e-9, COLOUR_AUTO)
-            S, fl, st = run_hip_batched([q], 20, 1e-9)
-            assert st['xuniform_mask'] == 7
-            assert_same(S[0], fl[0], So, flo, 'std2dt fused x-uniform')
+            for K in (0, 1, 2, 3):
+                S, fl, st = run_hip_batched([q], 20, 1e-9, sweeps_per_launch=K)
+                assert st['xuniform_mask'] == 7 and (K == 0 or st['sweeps_per_launch'] == K)
+                assert_same(S[0], fl[0], So, flo, 'std2dt fused x-uniform K=%d' % K)
 
 
 def test_concurrent_host_threads_are_serialised_safely():

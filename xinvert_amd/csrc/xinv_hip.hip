@@ -275,7 +275,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         // A and C (lat-lon Poisson) still runs two wavefronts per SIMD at K = 4 (3600x1800:
         // 14.2 / 12.8 / 11.7 us per sweep for K = 2 / 3 / 4); the other variants stay at 2.
         {
-            const int ksup = (p.kind == KIND_STD2D && pl.um == 3u) ? XINV_KMAX : 2;
+            const int ksup = (p.kind == KIND_STD2D) ? XINV_KMAX : (p.kind == KIND_STD2DT ? 3 : 2);
             if (opt.sweeps_per_launch > 0) pl.K = std::min(opt.sweeps_per_launch, ksup);
             else {
                 pl.K = 2;
