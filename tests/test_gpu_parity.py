@@ -197,8 +197,8 @@ def test_fused_path(kind, BCy, BCx, msk, shape, K):
     p = rand2d(kind, yc, xc, BCy, BCx, 0, msk, seed=_seed((kind, BCy, BCx, msk, shape)))
     So, flo = run_oracle(p, 24, 1e-9, COLOUR_2)
     S, fl, st = run_hip_batched([p], 24, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=16)
-    # the general form has K = 1, 2; the standard form with full coefficient arrays also 3 and 4
-    assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == (K if kind == 'std2d' else min(K, 2))
+    # the general form has K = 1, 2, 3; the standard form also 4
+    assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == (K if kind == 'std2d' else min(K, 3))
     assert_same(S[0], fl[0], So, flo, 'fused K=%d %s %r' % (K, kind, shape))
 
 

@@ -271,19 +271,30 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             pl.aligned = pl.aligned && ptr_al16(p.c[s]) && !(p.sc[s] & 1);
         }
         // Sweeps per pass over HBM.  Each one costs two more window rows of registers and 2 more
-        // halo rows/columns per side, and saves a pass and a launch: the standard form with per-row
-        // A and C (lat-lon Poisson) still runs two wavefronts per SIMD at K = 4 (3600x1800:
-        // 14.2 / 12.8 / 11.7 us per sweep for K = 2 / 3 / 4); the other variants stay at 2.
+        // halo rows/columns per side, and saves a pass and a launch.  Vector streams per row step
+        // (S plus every coefficient array that is not x-uniform) tell the two regimes apart:
+        //  - one or two (lat-lon Poisson, Gill-Matsuno): issue-bound, needs two wavefronts per
+        //    SIMD.  The standard form still has them at K = 4 (3600x1800: 14.2 / 12.8 / 11.7 us
+        //    per sweep for K = 2 / 3 / 4); the general form gains nothing from K = 3 (C4);
+        //  - four or more (full coefficient arrays): bandwidth-bound, one workgroup per CU is as
+        //    fast as two, so K = 3 pays even at one wavefront per SIMD (2000x2000 general form:
+        //    2.20 -> 2.38e11 with A, C, G streamed, 1.53 -> 2.21e11 with all seven; standard form
+        //    3600x1800: 2.65 -> 3.9e11), K = 4 does not (one wavefront per SIMD: 3.4e11).
+        const int nvec = 1 + nc - __builtin_popcount(pl.um & ((1u << nc) - 1u));
+        pl.lone = nvec <= 2 ? 1.6 : (nvec == 3 ? 1.3 : 1.0);
         {
-            const int ksup = (p.kind == KIND_STD2D) ? XINV_KMAX : (p.kind == KIND_STD2DT ? 3 : 2);
-            if (opt.sweeps_per_launch > 0) pl.K = std::min(opt.sweeps_per_launch, ksup);
+            const bool hoisted_gen = (p.kind == KIND_GEN2D && nvec <= 2);
+            const int ksup = (p.kind == KIND_STD2D && nvec <= 2) ? XINV_KMAX : (hoisted_gen ? 2 : 3);
+            const int occ_needed = nvec >= 4 ? 1 : 2;
+            if (opt.sweeps_per_launch > 0)
+                pl.K = std::min(opt.sweeps_per_launch, (p.kind == KIND_STD2D) ? XINV_KMAX : 3);
             else {
                 pl.K = 2;
                 for (int k = ksup; k > 2; k--) {
                     int o = 0;
                     FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
                     if (fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, k, dim3(1), dim3(256),
-                                       st, dummy, &o) == 0 && o >= 2) { pl.K = k; break; }
+                                       st, dummy, &o) == 0 && o >= occ_needed) { pl.K = k; break; }
                 }
             }
         }
@@ -308,15 +319,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
                 fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
                                st, dummy, &occ);
             }
-            {   // vector streams per row step: S plus every coefficient array that is not x-uniform.
-                // With one or two (lat-lon Poisson, Gill-Matsuno) the kernel is issue-bound and a second
-                // workgroup per CU fills idle slots; with four or more it sits at the fabric's
-                // bandwidth, a pair runs no faster than one, and tall tiles (less halo) win
-                // (2000x2000 general form, A C G streamed: 40-row tiles 38.3 us, 17-row tiles 44.0 us)
-                const int nc = (p.kind == KIND_GEN2D) ? 6 : (p.kind == KIND_STD2DT ? 4 : 3);
-                const int nvec = 1 + nc - __builtin_popcount(pl.um & ((1u << nc) - 1u));
-                pl.lone = nvec <= 2 ? 1.6 : (nvec == 3 ? 1.3 : 1.0);
-            }
+            // (pl.lone, set with K above: with one or two vector streams a second workgroup per CU
+            // fills idle issue slots; with four or more a pair runs no faster than one, and tall
+            // tiles (less halo) win -- 2000x2000 general form, A C G streamed: 40-row tiles 38.3 us,
+            // 17-row tiles 44.0 us)
             const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, 128 - 4 * pl.K), p.nbatch, pl.K, occ, pl.lone);
             pl.nrb = (int)best;
             pl.even_split = true;

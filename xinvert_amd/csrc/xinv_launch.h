@@ -57,8 +57,7 @@ static int launch_fused_k(int K, dim3 grid, dim3 block, hipStream_t st, const Fu
     // three and four sweeps per pass: only the standard form with per-row A and C keeps two
     // wavefronts per SIMD at that window depth (194 / 249 VGPRs; the general form does not gain)
     case 3:
-        if constexpr (std::is_same<M, FusedStd2D>::value || std::is_same<M, FusedStd2DT>::value)
-            return fused_one<M, 3, AL, UM, EXT>(grid, block, st, a, occ);
+        return fused_one<M, 3, AL, UM, EXT>(grid, block, st, a, occ);
         break;
     case 4:
         if constexpr (std::is_same<M, FusedStd2D>::value)
