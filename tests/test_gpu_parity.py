@@ -334,7 +334,7 @@ def test_masked_tiles_are_skipped_without_changing_a_bit(kind, BCy, BCx, spl, ro
     assert max(loops) < 60                      # every member stopped on the tolerance
 
 
-@pytest.mark.parametrize('kind,spl', [('std2d', 1), ('std2d', 2), ('gen2d', 1)])
+@pytest.mark.parametrize('kind,spl', [('std2d', 1), ('std2d', 2), ('std2d', 3), ('gen2d', 1), ('gen2d', 2)])
 @pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic')])
 @pytest.mark.parametrize('rows', [-6, -12])
 def test_masked_tiles_skipped_nine_point(kind, spl, BCy, BCx, rows):
@@ -711,7 +711,7 @@ def test_concurrent_host_threads_are_serialised_safely():
 NINE_SHAPES = [(17, 24), (12, 20), (40, 300), (33, 257), (9, 8), (3, 3), (50, 512), (21, 130)]
 
 
-@pytest.mark.parametrize('kind,K', [('std2d', 1), ('std2d', 2), ('gen2d', 1)])
+@pytest.mark.parametrize('kind,K', [('std2d', 1), ('std2d', 2), ('std2d', 3), ('gen2d', 1), ('gen2d', 2)])
 @pytest.mark.parametrize('BCy,BCx', BCS)
 @pytest.mark.parametrize('msk', [0, 1])
 @pytest.mark.parametrize('shape', NINE_SHAPES)

@@ -10,7 +10,7 @@ import util
 L = _lib.require_gpu()
 dev = torch.device('cuda', 0)
 ROWS = int(os.environ.get('NINE_ROWS', '0'))
-for kind, spl, path in (('std2d', 1, 0), ('std2d', 2, 0), ('std2d', 0, 1), ('gen2d', 1, 0), ('gen2d', 0, 1)):
+for kind, spl, path in (('std2d', 1, 0), ('std2d', 2, 0), ('std2d', 3, 0), ('std2d', 0, 0), ('std2d', 0, 1), ('gen2d', 1, 0), ('gen2d', 2, 0), ('gen2d', 0, 0), ('gen2d', 0, 1)):
     ny = nx = 2000
     p = util.rand2d(kind, ny, nx, 'fixed', 'periodic', bnz=True, msk=False, seed=1, omega=0.9)
     p['coefs'][1] = p['coefs'][1] * 0.2            # weak cross term: keeps the iteration stable

@@ -174,7 +174,11 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (pl.path == XINV_PATH_FUSED && pl.nine) {
         // 9-point forms: 4-colour fused kernel, all coefficient arrays streamed
         pl.um = pl.umask = 0;
-        pl.K = (p.kind == KIND_STD2D && opt.sweeps_per_launch != 1) ? 2 : 1;    // general form: registers allow K = 1 only
+        {
+            const int k9max = (p.kind == KIND_STD2D) ? 3 : 2;
+            const int k9def = 2;      // bandwidth-bound: 2000x2000 general 0.74 -> 1.24e11, standard 1.07 -> 1.42e11 against K = 1
+            pl.K = opt.sweeps_per_launch > 0 ? std::min(opt.sweeps_per_launch, k9max) : k9def;
+        }
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
         for (int q = 0; q < p.ncoef; q++) pl.aligned = pl.aligned && ptr_al16(p.c[q]) && !(p.sc[q] & 1);
         pl.even_split = false;
@@ -191,8 +195,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
                 // the 9-point kernels stream every coefficient array and sit at the fabric's bandwidth
                 // (6+ TB/s): halo re-reads cost more than occupancy gives, so one workgroup per CU
                 // (tall tiles) is the target -- measured +25 % (standard, K=1) / +21 % (general) at 2000x2000
-                (void)occ;
-                pl.nrb = (int)choose_row_blocks(p.yc, cdiv(p.xc, 128 - 8 * pl.K), p.nbatch, pl.K, pl.K == 1 ? 1 : occ);
+                pl.lone = 1.0;
+                pl.nrb = (int)choose_row_blocks(p.yc, cdiv(p.xc, 128 - 8 * pl.K), p.nbatch, pl.K, occ, pl.lone);
             }
             pl.even_split = true;
             pl.RY = (int)cdiv(p.yc, pl.nrb);

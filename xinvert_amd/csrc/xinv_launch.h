@@ -180,10 +180,13 @@ static int fused9_dispatch(int kind, int K, bool al, bool ext, dim3 grid, hipStr
                            const FusedArgs &a, int *occ)
 {
     if (kind == KIND_GEN2D) {
-        if (K == 1) launch_fused9_k<Fused9Gen, 1>(al, ext, grid, st, a, occ); else return 1;
+        if (K == 1) launch_fused9_k<Fused9Gen, 1>(al, ext, grid, st, a, occ);
+        else if (K == 2) launch_fused9_k<Fused9Gen, 2>(al, ext, grid, st, a, occ);
+        else return 1;
     } else {
         if (K == 1) launch_fused9_k<Fused9Std, 1>(al, ext, grid, st, a, occ);
         else if (K == 2) launch_fused9_k<Fused9Std, 2>(al, ext, grid, st, a, occ);
+        else if (K == 3) launch_fused9_k<Fused9Std, 3>(al, ext, grid, st, a, occ);
         else return 1;
     }
     return 0;
