@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """north_star's acceptance criterion at the headline size: invert_Poisson 3600 x 1800 (land mask) run to
-convergence on the GPU (red-black, K = 2, masked tiles skipped) against the reference's lexicographic
+convergence on the GPU (red-black, K sweeps per pass, masked tiles skipped) against the reference's lexicographic
 ordering (oracle, one CPU core, ~2.5 minutes).  Prints loops, wall times and the rel-L2 difference."""
 import os
 import sys
