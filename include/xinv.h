@@ -54,6 +54,8 @@ extern "C" {
 #define XINV_FLAG_FORCE_TILE_SKIP 4 /* testing aid: skip masked tiles whatever the grid size, keep
                                     the row split                                                */
 
+#define XINV_MAX_DEVICES 16
+
 typedef struct xinv_options {
     int32_t device;             /* HIP device ordinal; -1 = current device                      */
     int32_t path;               /* XINV_PATH_*                                                   */
@@ -70,6 +72,13 @@ typedef struct xinv_options {
                                    rows = yc (zc*yc in 3-D); its batch stride is 0 or >= rows.  The rows
                                    are uploaded and expanded on the device: lat-lon coefficients are
                                    functions of latitude only (apps.py:1406-1408, 1630-1635)             */
+    int32_t host_chunk;         /* host-pointer entries: members per upload/solve/download chunk (the
+                                   three overlap, chunk c+1 travelling while chunk c sweeps); 0 = auto  */
+    int32_t ndev;               /* host-pointer batched entries: 0 = one device (`device`); n > 0 = split
+                                   the batch axis in contiguous blocks over device_ids[0..n-1] (one host
+                                   thread per GPU, no collective: slices are independent, reference
+                                   core.py:129-139); -1 = every visible GPU.  Ignored by *_dev entries.  */
+    int32_t device_ids[XINV_MAX_DEVICES];
 } xinv_options;
 
 typedef struct xinv_stats {
@@ -82,7 +91,11 @@ typedef struct xinv_stats {
     int64_t sweep_launches;     /* sweep-kernel launches issued (incl. no-op tail launches)     */
     int64_t sweeps_max;         /* max over members of sweeps executed                          */
     double  sweep_ms;           /* HIP-event time over all launch chunks (timing=1), ms         */
-    double  h2d_ms, d2h_ms;     /* host-pointer entry points only                               */
+    double  h2d_ms, d2h_ms;     /* host-pointer entry points only: span of the upload / download
+                                   streams (they overlap the sweeps when the batch has chunks)  */
+    double  wall_ms;            /* host-pointer entry points: wall clock of the whole call      */
+    int32_t host_chunks;        /* member chunks the call was pipelined over (all devices)      */
+    int32_t devices;            /* GPUs the batch was split over                                */
 } xinv_stats;
 
 void        xinv_default_options(xinv_options *opt);

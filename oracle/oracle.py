@@ -29,12 +29,51 @@ def build(force=False):
     return _SO
 
 
+_SO_NATIVE = os.path.join(_HERE, 'libxinv_oracle_native.so')
+_portable = None
+
+
+def use_native():
+    """Switch to a -march=native build of the same source, compiled NOW on this machine (SURVEY.md
+    8(d): the CPU baseline is the generous reading -- what numba/LLVM emits for the host CPU).
+    Used by bench.py's cpu_baseline leg only; the travelling portable build stays the parity
+    checker.  Returns False (and keeps the portable build) when gcc is not available."""
+    global _lib, _portable
+    src = os.path.join(_HERE, 'xinv_oracle.c')
+    try:
+        subprocess.check_call(['gcc', '-O3', '-march=native', '-std=c11', '-fPIC', '-ffp-contract=off',
+                               '-fno-fast-math', '-shared', '-o', _SO_NATIVE, src, '-lm'])
+    except Exception:
+        return False
+    if _portable is None and _lib is not None:
+        _portable = _lib
+    _lib = None
+    _load(_SO_NATIVE)
+    return True
+
+
+def use_portable():
+    global _lib, _portable
+    if _portable is not None:
+        _lib = _portable
+    elif _lib is not None and getattr(_lib, '_xo_path', _SO) != _SO:
+        _lib = None
+    return lib()
+
+
 def lib():
-    global _lib
     if _lib is None:
         if not os.path.exists(_SO):
             build()
-        L = ctypes.CDLL(_SO)
+        _load(_SO)
+    return _lib
+
+
+def _load(path):
+    global _lib, _portable
+    if True:
+        L = ctypes.CDLL(path)
+        L._xo_path = path
         L.xo_standard_2d.restype = _int
         L.xo_standard_2d.argtypes = [_dp] * 5 + [_i64, _i64, _f64, _f64, _int, _int,
                                                  _f64, _f64, _f64, _f64, _f64, _dp, _i64,
@@ -62,6 +101,8 @@ def lib():
         L.xo_abs_norm_3d.restype = _f64
         L.xo_abs_norm_3d.argtypes = [_dp, _i64, _i64, _i64, _f64]
         _lib = L
+        if path == _SO:
+            _portable = L
     return _lib
 
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Fixtures for the converged-field acceptance tests (tests/test_gpu_fullsize.py).
+
+For each full-size BASELINE configuration, run the CPU oracle in the REFERENCE's lexicographic
+ordering (oracle/xinv_oracle.c, XO_LEX -- pinned bit for bit to the reference's own numbas.py by
+tests/test_oracle_golden.py and tests/test_oracle_live_reference.py) to the stated tolerance and
+keep a seeded random sample of the converged field: 200 000 points, their forcing values (so a test
+can tell that it regenerated the same synthetic input), the loop count and the final flags.
+
+  python tests/golden/gen_converged.py c2 c3 c5        (minutes of one CPU core each)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+# tolerance on the relative change of mean|S| per sweep (the reference's stop rule watches THAT, not
+# the error): chosen so that both orderings stop well inside 1e-6 of the fixed point
+CASES = {
+    'c2': dict(tol=1e-13, mx=200000),
+    'c3': dict(tol=1e-14, mx=200000),
+    'c5': dict(tol=1e-13, mx=200000),
+}
+
+
+def problem(name):
+    from xinvert_amd import synthetic
+    if name == 'c2':
+        return synthetic.member(synthetic.poisson_latlon(1800, 3600, mask=True), 0)
+    if name == 'c3':
+        return synthetic.member(synthetic.stommel_cartesian(2000, 2000), 0)
+    if name == 'c5':
+        return synthetic.member(synthetic.omega_latlon(50, 360, 720, 1), 0)
+    raise SystemExit('unknown case ' + name)
+
+
+def main():
+    import util
+    for name in sys.argv[1:] or list(CASES):
+        c = CASES[name]
+        q = problem(name)
+        t = time.time()
+        S, fl = util.run_oracle(q, c['mx'], c['tol'], 0)
+        dt = time.time() - t
+        rng = np.random.default_rng(7)
+        index = np.sort(rng.choice(S.size, size=min(200000, S.size), replace=False)).astype(np.int64)
+        out = os.path.join(HERE, 'converged_%s.npz' % name)
+        np.savez_compressed(out, index=index, S_lex=S.ravel()[index],
+                            forcing=np.asarray(q['coefs'][-1], dtype=np.float64).ravel()[index],
+                            loops=np.int64(fl[2]), flags=fl, tolerance=np.float64(c['tol']),
+                            mxLoop=np.int64(c['mx']), optArg=np.float64(q['optArg']),
+                            shape=np.array(S.shape, dtype=np.int64))
+        print('%s: %r lexicographic loops %d, last change %.3e, %.0f s -> %s (%.1f MB)'
+              % (name, S.shape, fl[2], fl[1], dt, out, os.path.getsize(out) / 1e6), flush=True)
+
+
+if __name__ == '__main__':
+    main()

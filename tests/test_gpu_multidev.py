@@ -1,0 +1,100 @@
+"""In-process multi-device batched entry and the chunked upload / solve / download pipeline of the
+host-pointer entry points (include/xinv.h: xinv_options.ndev / device_ids / host_chunk).
+
+The GPU box has one GPU, so the device list names device 0 twice: two host threads, two contiguous
+blocks of the batch axis, the same code path as two distinct GPUs (the threads then serialise on
+the per-device lock).  What is checked is the part that can go wrong: block boundaries, pointer
+offsets with shared (stride-0) and per-member arrays, S and flags landing in the caller's arrays.
+"""
+import numpy as np
+import pytest
+
+import util
+from util import rand2d, rand3d, run_oracle
+
+pytestmark = pytest.mark.gpu
+C2 = 2
+
+
+def _members(nb, kind='gen2d', yc=40, xc=130):
+    if kind == 'std3d':
+        return [rand3d(9, 20, 66, 'fixed', 'periodic', 1, seed=s) for s in range(nb)]
+    return [rand2d(kind, yc, xc, 'fixed', 'periodic', 0, 1, seed=s) for s in range(nb)]
+
+
+@pytest.mark.parametrize('nb,devs', [(5, [0, 0]), (7, [0, 0, 0]), (2, [0, 0, 0, 0]), (1, [0, 0])])
+def test_device_list_splits_batch_in_contiguous_blocks(nb, devs):
+    ps = _members(nb)
+    for q in ps:                                  # A shared by every member, the rest per member
+        q['coefs'][0] = ps[0]['coefs'][0]
+    S1, f1, s1 = util.run_hip_batched(ps, 60, 1e-6, shared=(0,))
+    S2, f2, s2 = util.run_hip_batched(ps, 60, 1e-6, shared=(0,), devices=devs)
+    assert s1['devices'] == 1 and s2['devices'] == min(len(devs), nb)
+    assert np.array_equal(S1, S2) and np.array_equal(f1, f2)
+    for m in (0, nb - 1):
+        So, flo = run_oracle(ps[m], 60, 1e-6, C2)
+        assert np.array_equal(S2[m], So) and f2[m][2] == flo[2]
+    assert len(set(f2[:, 2])) > 1 or nb == 1      # members stop at different sweeps: flags are per slice
+
+
+def test_device_list_3d_and_all_devices():
+    ps = _members(4, 'std3d')
+    S1, f1, _ = util.run_hip_batched(ps, 20, 0.0)
+    S2, f2, s2 = util.run_hip_batched(ps, 20, 0.0, devices=[0, 0])
+    S3, f3, s3 = util.run_hip_batched(ps, 20, 0.0, devices='all')
+    assert np.array_equal(S1, S2) and np.array_equal(S1, S3) and np.array_equal(f1, f2) and np.array_equal(f1, f3)
+    assert s2['devices'] == 2 and s3['devices'] >= 1
+
+
+def test_bad_device_id_is_an_argument_error():
+    from xinvert_amd import _lib
+    ps = _members(2)
+    with pytest.raises(_lib.XinvError, match='no such device'):
+        util.run_hip_batched(ps, 5, 0.0, devices=[0, 99])
+
+
+@pytest.mark.parametrize('chunk', [1, 2, 3, 0])
+def test_host_chunk_pipeline_is_result_neutral(chunk):
+    """Upload / sweeps / download overlap over member chunks: any chunking gives the same bits."""
+    ps = _members(7)
+    Sref, fref, sref = util.run_hip_batched(ps, 40, 1e-5, host_chunk=7)
+    S, fl, st = util.run_hip_batched(ps, 40, 1e-5, host_chunk=chunk)
+    assert sref['host_chunks'] == 1
+    if chunk:
+        assert st['host_chunks'] == -(-7 // chunk)
+    assert np.array_equal(S, Sref) and np.array_equal(fl, fref)
+    assert st['wall_ms'] > 0
+
+
+def test_host_chunks_large_batch_strided_members():
+    """Members that are not contiguous on the host (batch stride > slice size) through the chunked
+    path, row-constant coefficients expanded once for all chunks."""
+    import ctypes
+    from xinvert_amd import _lib
+    L = _lib.require_gpu()
+    nb, yc, xc = 6, 30, 64
+    ps = [rand2d('std2d', yc, xc, 'extend', 'periodic', 0, 1, seed=10 + s) for s in range(nb)]
+    n = yc * xc
+    pad = n + 24
+    Sbuf = np.zeros(nb * pad); Fbuf = np.zeros(nb * pad)
+    for m, q in enumerate(ps):
+        Sbuf[m * pad:m * pad + n] = q['S0'].ravel()
+        Fbuf[m * pad:m * pad + n] = q['coefs'][3].ravel()
+    Arow = np.ascontiguousarray(np.linspace(0.8, 1.2, yc))          # one value per row
+    C = np.ascontiguousarray(ps[0]['coefs'][2])
+    fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
+    o = _lib.options(rowconst_mask=1, host_chunk=2)
+    p = ps[0]
+    rc = L.xinv_standard_2d_f64_batched(
+        _lib.hptr(Sbuf), _lib.hptr(Arow), None, _lib.hptr(C), _lib.hptr(Fbuf), nb,
+        _lib.strides_arg([pad, 0, 0, 0, pad]), yc, xc, p['dely'], p['delx'], _lib.bc('extend'),
+        _lib.bc('periodic'), p['delxSqr'], p['ratioQtr'], p['ratioSqr'], p['optArg'], p['undef'],
+        _lib.hptr(fl), 25, 0.0, ctypes.byref(o))
+    _lib.check(rc)
+    assert _lib.last_stats()['host_chunks'] == 3
+    A = np.repeat(Arow[:, None], xc, axis=1)
+    for m, q in enumerate(ps):
+        r = dict(q); r['coefs'] = [A, np.zeros((yc, xc)), C, q['coefs'][3]]
+        So, flo = run_oracle(r, 25, 0.0, C2)
+        assert np.array_equal(Sbuf[m * pad:m * pad + n].reshape(yc, xc), So)
+        assert (Sbuf[m * pad + n:(m + 1) * pad] == 0).all()          # the gaps are never touched

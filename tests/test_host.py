@@ -318,3 +318,29 @@ def test_xarray_like_objects_are_accepted_and_returned():
     assert isinstance(f, Field) and f.dims == ('lat', 'lon') and list(f['lon']) == [0., 10., 20., 30.]
     assert to_like(f, f) is f
     assert to_like(f, da) is f            # no xarray here: the Field comes back unchanged
+
+
+def test_labelled_coefficients_align_by_dim_name():
+    """A labelled coefficient or icbc whose dims are ordered differently from the forcing is lined
+    up by NAME (xarray semantics, reference apps.py `.loc` arithmetic), never by shape coincidence:
+    a square core is the case where a shape test cannot tell."""
+    from xinvert_amd import core, apps
+    n = 6
+    y = np.arange(n, dtype=float); x = np.arange(n, dtype=float) * 2
+    F = Field(np.zeros((3, n, n)), ('t', 'y', 'x'), {'y': y, 'x': x})
+    perm, _, _ = core._batch_layout(F, ['y', 'x'])
+    base = np.arange(n * n, dtype=float).reshape(n, n)             # [y, x]
+    a, st, rc = core._prep_coef(Field(base.T.copy(), ('x', 'y')), F, perm, (n, n), 3)
+    assert st == 0 and not rc and np.array_equal(a, base)         # transposed back to [y, x]
+    a, st, rc = core._prep_coef(Field(base, ('y', 'x')), F, perm, (n, n), 3)
+    assert st == 0 and np.array_equal(a, base)
+    a, st, rc = core._prep_coef(base, F, perm, (n, n), 3)          # bare ndarray: core layout
+    assert st == 0 and np.array_equal(a, base)
+    with pytest.raises(Exception):
+        core._prep_coef(Field(base, ('y', 'z')), F, perm, (n, n), 3)
+    # icbc with swapped dims
+    iP = apps._update(apps.default_iParams, {'BCs': ['fixed', 'fixed']})
+    ic = Field(base.T.copy(), ('x', 'y'), {'y': y, 'x': x})
+    _, initS, _ = apps._mask_FS(F, ['y', 'x'], iP, ic)
+    assert np.array_equal(initS.values[1][0], base[0]) and np.array_equal(initS.values[2][:, -1], base[:, -1])
+    assert (initS.values[:, 1:-1, 1:-1] == 0).all()

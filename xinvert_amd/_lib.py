@@ -13,6 +13,7 @@ SO = os.environ.get('XINV_SO') or os.path.join(HERE, 'libxinv_hip.so')
 
 BC_CODES = {'fixed': 0, 'extend': 1, 'periodic': 2}
 PATH_AUTO, PATH_COLOUR, PATH_FUSED = 0, 1, 2
+MAX_DEVICES = 16                      # XINV_MAX_DEVICES
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int64)
@@ -23,7 +24,9 @@ class XinvOptions(ctypes.Structure):
     _fields_ = [('device', ctypes.c_int32), ('path', ctypes.c_int32),
                 ('sweeps_per_launch', ctypes.c_int32), ('check_every', ctypes.c_int32),
                 ('rows_per_tile', ctypes.c_int32), ('timing', ctypes.c_int32),
-                ('flags', ctypes.c_int32), ('rowconst_mask', ctypes.c_int32)]
+                ('flags', ctypes.c_int32), ('rowconst_mask', ctypes.c_int32),
+                ('host_chunk', ctypes.c_int32), ('ndev', ctypes.c_int32),
+                ('device_ids', ctypes.c_int32 * MAX_DEVICES)]
 
 
 class XinvStats(ctypes.Structure):
@@ -32,7 +35,8 @@ class XinvStats(ctypes.Structure):
                 ('xuniform_mask', ctypes.c_int32), ('masked_tile_pct', ctypes.c_int32),
                 ('sweep_launches', ctypes.c_int64), ('sweeps_max', ctypes.c_int64),
                 ('sweep_ms', ctypes.c_double), ('h2d_ms', ctypes.c_double),
-                ('d2h_ms', ctypes.c_double)]
+                ('d2h_ms', ctypes.c_double), ('wall_ms', ctypes.c_double),
+                ('host_chunks', ctypes.c_int32), ('devices', ctypes.c_int32)]
 
 
 class XinvError(RuntimeError):
@@ -130,7 +134,8 @@ def check(rc):
 
 
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
-            timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0):
+            timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0,
+            host_chunk=0, devices=None):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
@@ -138,6 +143,21 @@ def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_
     # XINV_FLAG_NO_XUNIFORM | XINV_FLAG_NO_TILE_SKIP | XINV_FLAG_FORCE_TILE_SKIP
     o.flags = (1 if no_xuniform else 0) | (2 if no_tile_skip else 0) | (4 if force_tile_skip else 0)
     o.rowconst_mask = int(rowconst_mask)
+    o.host_chunk = int(host_chunk)
+    # devices: None = the single device `device`; 'all' = every visible GPU; a list = those GPUs
+    if devices is None:
+        o.ndev = 0
+    elif isinstance(devices, str):
+        if devices != 'all':
+            raise XinvError("devices must be None, 'all' or a list of device ordinals")
+        o.ndev = -1
+    else:
+        devices = [int(d) for d in devices]
+        if len(devices) > MAX_DEVICES:
+            raise XinvError('at most %d devices' % MAX_DEVICES)
+        o.ndev = len(devices)
+        for i, d in enumerate(devices):
+            o.device_ids[i] = d
     return o
 
 

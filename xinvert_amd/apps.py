@@ -484,7 +484,9 @@ def _mask_FS(F, dims, iParams, icbc):
                 dv = np.asarray(F[dim])
                 cond = along(np.isin(dv, [dv[0], dv[-1]]), F, dim)
                 mask = np.logical_or(mask, cond)
-        ic = np.broadcast_to(np.asarray(icbc.values, dtype=np.float64), vals.shape)
+        # aligned by dim NAME as xarray's `where` would (a labelled icbc whose dims are ordered
+        # differently from F is transposed; an unknown dim raises)
+        ic = np.broadcast_to(aligned(icbc, F), vals.shape)
         initS = F.like(np.where(mask, ic, 0.0))
     return maskF, initS, zero
 

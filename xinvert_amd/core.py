@@ -11,11 +11,12 @@ Arrays may be `Field`s or ndarrays.  Coefficients are either core-shaped ([yc, x
 [zc, yc, xc]: shared by all slices) or shaped like F (one per slice).
 """
 import itertools
+import os
 
 import numpy as np
 
 from . import _lib
-from .field import Field
+from .field import Field, aligned
 
 # default undefined value (reference core.py:15)
 _undeftmp = -9.99e8
@@ -89,12 +90,18 @@ def _prep_coef(c, F, perm, core_shape, nbatch, allow_null=False):
     cross coefficient B).  rowconst: the coefficient does not vary along x (a stride-0 view along
     the last core axis, as the lat-lon builders of apps.py produce): only its first column
     travels, [rows] per member, and the library expands it on the device."""
-    v = np.asarray(_vals(c), dtype=np.float64)
+    labelled = hasattr(c, 'dims') and hasattr(c, 'values')
+    if labelled:
+        # labelled coefficient (Field / DataArray): line it up with F by dim NAME, as the
+        # reference's xarray arithmetic does -- never by shape coincidence (square cores)
+        v = np.broadcast_to(aligned(c, F), F.shape)
+    else:
+        v = np.asarray(_vals(c), dtype=np.float64)
     n = int(np.prod(core_shape))
     rows = n // core_shape[-1]
     if allow_null and v.size > 1 and all(st == 0 for st in v.strides) and v.flat[0] == 0.0:
         return None, 0, False
-    if v.shape == tuple(core_shape):
+    if not labelled and v.shape == tuple(core_shape):     # bare ndarray in core layout [dims[0], dims[1], ...]
         if v.strides[-1] == 0 and core_shape[-1] > 1:
             return np.ascontiguousarray(v[..., 0]), 0, True
         return np.ascontiguousarray(v), 0, False
@@ -117,6 +124,20 @@ def _prep_coef(c, F, perm, core_shape, nbatch, allow_null=False):
         raise Exception('coefficient shape %r matches neither the core shape %r nor F %r'
                         % (v.shape, tuple(core_shape), F.shape))
     return _prep_coef(t, F, perm, core_shape, nbatch, allow_null)
+
+
+def _device_list(iParams, nbatch):
+    """GPUs the batch axis is split over inside this one call (contiguous blocks, the order of the
+    reference's slice loop core.py:129).  iParams['devices']: a list of ordinals or 'all'; unset =
+    every visible GPU, except when one device was asked for (iParams['device']), when the process
+    is one rank of a one-process-per-GPU job (WORLD_SIZE > 1: xinvert_amd.dist shards instead), or
+    when there is a single slice."""
+    d = iParams.get('devices')
+    if d is not None:
+        return d
+    if nbatch <= 1 or iParams.get('device') is not None or int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        return None
+    return 'all'
 
 
 def _info(sel):
@@ -157,7 +178,9 @@ def _solve(kind, coefs, F, S, dims, iParams):
     opt = _lib.options(device=int(iParams.get('device', -1)),
                        path=int(iParams.get('engine_path', 0)),
                        sweeps_per_launch=int(iParams.get('sweeps_per_launch', 0)),
-                       check_every=int(iParams.get('check_every', 0)), rowconst_mask=rowconst)
+                       check_every=int(iParams.get('check_every', 0)), rowconst_mask=rowconst,
+                       host_chunk=int(iParams.get('host_chunk', 0)),
+                       devices=_device_list(iParams, nbatch))
     st = _lib.strides_arg(strides)
     ptrs = [_lib.hptr(a) for a in arrs]
     mx, tol = int(iParams['mxLoop']), float(iParams['tolerance'])

@@ -20,7 +20,9 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <exception>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -48,9 +50,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     xinv_options opt;
     fill_options(opt, opt_in);
 
-    int device = opt.device;
-    if (device < 0) HIPCHK(hipGetDevice(&device));
-    else HIPCHK(hipSetDevice(device));
+    DeviceGuard dg;
+    HIPCHK(dg.select(opt.device));
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
     Workspace *ws = get_ws(device);
     std::lock_guard<std::recursive_mutex> solve_lock(ws->busy);
     if (!ws->ev0[0])
@@ -551,78 +554,256 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     return XINV_OK;
 }
 
-static int solve_host(Problem &p, double *flags, const xinv_options *opt)
-{
-    p.rowconst = opt ? ((unsigned)opt->rowconst_mask & ((1u << p.ncoef) - 1u)) : 0u;
-    int rc = validate(p, flags);
-    if (rc) return rc;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
-        t_err = "no HIP device available";
-        return XINV_ERR_NODEV;
+// ------------------------------------------------------------------ the solve (host ptrs)
+// One device: upload -> solve -> download, pipelined over chunks of members on three streams.
+// Every upload is queued at once on the `up` stream (shared coefficient arrays first, then S and
+// the per-member arrays chunk by chunk, an event after each chunk); the solve of chunk c waits only
+// for ITS event, so chunk c+1 travels while chunk c sweeps, and the download of chunk c (queued on
+// the `down` stream when its solve returns) overlaps the sweeps of chunk c+1.  Both DMA directions
+// and the CUs are busy at once; what stays exposed is the first chunk's upload and the last
+// chunk's download.  Members are independent (reference core.py:129: no cross-slice state), so the
+// chunking cannot change any result.
+struct HostEvents {                                   // destroyed on every return path
+    std::vector<hipEvent_t> e;
+    ~HostEvents() { for (auto x : e) if (x) (void)hipEventDestroy(x); }
+    int make(hipEvent_t *out, bool timing)
+    {
+        hipEvent_t x = nullptr;
+        HIPCHK(timing ? hipEventCreate(&x) : hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        e.push_back(x);
+        *out = x;
+        return XINV_OK;
     }
-    if (opt && opt->device >= 0) HIPCHK(hipSetDevice(opt->device));
+};
+
+static int64_t host_chunk_members(const Problem &p, const xinv_options &opt)
+{
+    if (p.nbatch <= 1) return 1;
+    if (opt.host_chunk > 0) return std::min<int64_t>(opt.host_chunk, p.nbatch);
+    const int64_t n = p.zc * p.yc * p.xc;
+    // at most 8 chunks; a chunk holds at least ~2 M points (one round of workgroups on 256 CUs)
+    // and at least 16 MiB of S, so that neither the sweeps nor the DMA run half-empty
+    int64_t mc = (p.nbatch + 7) / 8;
+    mc = std::max<int64_t>(mc, ((int64_t)1 << 21) / std::max<int64_t>(1, n) + 1);
+    return std::min<int64_t>(mc, p.nbatch);
+}
+
+static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bool pin_enabled)
+{
+    const auto wall0 = std::chrono::steady_clock::now();
+    DeviceGuard dg;
+    HIPCHK(dg.select(opt.device));
     int device = 0;
     HIPCHK(hipGetDevice(&device));
     const int64_t n = p.zc * p.yc * p.xc;
     // the staging pool and the solver workspace are per device: hold the device for the whole
     // upload -> solve -> download sequence
-    std::lock_guard<std::recursive_mutex> host_lock(get_ws(device)->busy);
+    Workspace *ws = get_ws(device);
+    std::lock_guard<std::recursive_mutex> host_lock(ws->busy);
+    for (hipStream_t *sp : { &ws->s_up, &ws->s_down, &ws->s_compute })
+        if (!*sp) HIPCHK(hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+    hipStream_t sup = ws->s_up, sdn = ws->s_down, scp = ws->s_compute;
     DevPool *pool = get_pool(device);
     pool->reset();
-    Pinned pin;
-    Problem d = p;
-    double *hS = p.S;
+    Pinned pin;                                       // (declared after the lock: drained + unpinned before it is released)
+    pin.enabled = pin_enabled;
+    pin.streams = { sup, sdn, scp };
+    HostEvents ev;
+    hipEvent_t e_up0, e_up1, e_dn0 = nullptr, e_dn1;
+    int rc;
+    if ((rc = ev.make(&e_up0, true)) || (rc = ev.make(&e_up1, true)) || (rc = ev.make(&e_dn1, true))) return rc;
+
     const int64_t hsS = p.nbatch > 1 ? p.sS : n;
-    hipStream_t st = 0;
-    struct Events {                                   // destroyed on every return path
-        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
-        ~Events() { for (auto x : e) if (x) (void)hipEventDestroy(x); }
-    } ev;
-    for (auto &x : ev.e) HIPCHK(hipEventCreate(&x));
-    hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2], e3 = ev.e[3];
-    HIPCHK(hipEventRecord(e0, st));
-    int64_t ds;
-    rc = upload(pool, pin, st, p.S, p.nbatch, hsS, n, &d.S, &ds);
-    if (rc) return rc;
+    const int64_t mc = host_chunk_members(p, opt);
+    const int64_t nchunk = (p.nbatch + mc - 1) / mc;
+
+    // ---- device buffers, shared (stride-0) arrays and per-row arrays first ------------------
+    Problem d = p;
+    d.rowconst = 0;
     d.sS = n;
+    rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &d.S);
+    if (rc) return rc;
+    pin.try_pin(p.S, (size_t)((p.nbatch - 1) * hsS + n) * sizeof(double));
+    HIPCHK(hipEventRecord(e_up0, sup));
+    bool per_member[10];
     for (int q = 0; q < p.ncoef; q++) {
+        per_member[q] = false;
+        if (!p.c[q]) { d.c[q] = nullptr; d.sc[q] = 0; continue; }
+        const int64_t hst = p.nbatch > 1 ? p.sc[q] : 0;
         double *dc;
-        if (((p.rowconst >> q) & 1u) && p.c[q]) {        // one value per row: upload rows, expand on the device
+        if ((p.rowconst >> q) & 1u) {                 // one value per row: upload rows, expand on the device
             const int64_t rows = p.zc * p.yc;
             double *drow; int64_t rstride;
-            rc = upload(pool, pin, st, p.c[q], p.nbatch, p.nbatch > 1 ? p.sc[q] : 0, rows, &drow, &rstride);
+            rc = upload(pool, pin, sup, p.c[q], p.nbatch, hst, rows, &drow, &rstride);
             if (rc) return rc;
             const int64_t members = (rstride == 0) ? 1 : p.nbatch;
             rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &dc);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_expand_rows, dim3(cdiv(rows * members, 4)), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_expand_rows, dim3(cdiv(rows * members, 4)), dim3(256), 0, sup,
                                (const double *)drow, dc, rows, p.xc, members);
             d.sc[q] = (rstride == 0) ? 0 : n;
-        } else {
-            rc = upload(pool, pin, st, p.c[q], p.nbatch, p.nbatch > 1 ? p.sc[q] : 0, n, &dc, &d.sc[q]);
+        } else if (hst == 0) {
+            rc = upload(pool, pin, sup, p.c[q], 1, 0, n, &dc, &d.sc[q]);
             if (rc) return rc;
+        } else {                                      // per member: travels with its chunk
+            rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &dc);
+            if (rc) return rc;
+            pin.try_pin(p.c[q], (size_t)((p.nbatch - 1) * hst + n) * sizeof(double));
+            d.sc[q] = n;
+            per_member[q] = true;
         }
         d.c[q] = dc;
     }
-    d.rowconst = 0;
-    HIPCHK(hipEventRecord(e1, st));
-    rc = solve_dev(d, flags, opt, st);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(e2, st));
-    if (p.nbatch == 1 || hsS == n) {
-        HIPCHK(hipMemcpyAsync(hS, d.S, (size_t)p.nbatch * n * sizeof(double), hipMemcpyDeviceToHost, st));
-    } else {
-        for (int64_t m = 0; m < p.nbatch; m++)
-            HIPCHK(hipMemcpyAsync(hS + m * hsS, d.S + m * n, (size_t)n * sizeof(double),
-                                  hipMemcpyDeviceToHost, st));
+    auto copy_members = [&](double *dev, const double *host, int64_t hstride, int64_t m0, int64_t nm,
+                            bool up, hipStream_t s) -> int {
+        const hipMemcpyKind kind = up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+        if (hstride == n || nm == 1) {
+            double *dp = dev + m0 * n; const double *hp = host + m0 * hstride;
+            HIPCHK(up ? hipMemcpyAsync(dp, hp, (size_t)nm * n * sizeof(double), kind, s)
+                      : hipMemcpyAsync((void *)hp, dp, (size_t)nm * n * sizeof(double), kind, s));
+        } else
+            for (int64_t m = m0; m < m0 + nm; m++)
+                HIPCHK(up ? hipMemcpyAsync(dev + m * n, host + m * hstride, (size_t)n * sizeof(double), kind, s)
+                          : hipMemcpyAsync((void *)(host + m * hstride), dev + m * n, (size_t)n * sizeof(double), kind, s));
+        return XINV_OK;
+    };
+    // ---- every chunk's upload, queued now ---------------------------------------------------
+    std::vector<hipEvent_t> e_chunk((size_t)nchunk);
+    for (int64_t c = 0; c < nchunk; c++) {
+        const int64_t m0 = c * mc, nm = std::min(mc, p.nbatch - m0);
+        rc = copy_members(d.S, p.S, hsS, m0, nm, true, sup);
+        if (rc) return rc;
+        for (int q = 0; q < p.ncoef; q++)
+            if (per_member[q]) {
+                rc = copy_members(const_cast<double *>(d.c[q]), p.c[q], p.sc[q], m0, nm, true, sup);
+                if (rc) return rc;
+            }
+        if ((rc = ev.make(&e_chunk[(size_t)c], false))) return rc;
+        HIPCHK(hipEventRecord(e_chunk[(size_t)c], sup));
     }
-    HIPCHK(hipEventRecord(e3, st));
-    HIPCHK(hipEventSynchronize(e3));
+    HIPCHK(hipEventRecord(e_up1, sup));
+
+    // ---- solve chunk by chunk; downloads trail on their own stream -------------------------
+    xinv_stats acc;
+    memset(&acc, 0, sizeof acc);
+    xinv_options o1 = opt;
+    o1.device = device; o1.ndev = 0;
+    for (int64_t c = 0; c < nchunk; c++) {
+        const int64_t m0 = c * mc, nm = std::min(mc, p.nbatch - m0);
+        HIPCHK(hipStreamWaitEvent(scp, e_chunk[(size_t)c], 0));
+        Problem dc = d;
+        dc.nbatch = nm;
+        dc.S = d.S + m0 * n;
+        for (int q = 0; q < p.ncoef; q++)
+            if (d.c[q] && d.sc[q] != 0) dc.c[q] = d.c[q] + m0 * d.sc[q];
+        rc = solve_dev(dc, flags + 3 * m0, &o1, scp);
+        if (rc) return rc;
+        if (c == 0) acc = t_stats;
+        else {
+            acc.sweep_launches += t_stats.sweep_launches;
+            acc.sweeps_max = std::max(acc.sweeps_max, t_stats.sweeps_max);
+            acc.sweep_ms += t_stats.sweep_ms;
+        }
+        // solve_dev has returned: the chunk's S is final on the device
+        if (c == 0) { if ((rc = ev.make(&e_dn0, true))) return rc; HIPCHK(hipEventRecord(e_dn0, sdn)); }
+        rc = copy_members(d.S, p.S, hsS, m0, nm, false, sdn);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(e_dn1, sdn));
+    HIPCHK(hipEventSynchronize(e_dn1));
+    HIPCHK(hipStreamSynchronize(sup));
     float a = 0.f, b = 0.f;
-    HIPCHK(hipEventElapsedTime(&a, e0, e1));
-    HIPCHK(hipEventElapsedTime(&b, e2, e3));
+    HIPCHK(hipEventElapsedTime(&a, e_up0, e_up1));
+    HIPCHK(hipEventElapsedTime(&b, e_dn0, e_dn1));
+    t_stats = acc;
     t_stats.h2d_ms = a; t_stats.d2h_ms = b;
+    t_stats.host_chunks = (int32_t)nchunk;
+    t_stats.devices = 1;
+    t_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return XINV_OK;
+}
+
+// Host-pointer entry: one device, or the batch axis split in contiguous blocks over a device list
+// (the reference loops slices in ONE process, core.py:129-139; so does this --
+// one host thread per GPU, no collective, S and flags land in the caller's arrays).
+static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
+{
+    xinv_options opt;
+    fill_options(opt, opt_in);
+    p.rowconst = (unsigned)opt.rowconst_mask & ((1u << p.ncoef) - 1u);
+    int rc = validate(p, flags);
+    if (rc) return rc;
+    int nvis = 0;
+    if (hipGetDeviceCount(&nvis) != hipSuccess || nvis < 1) {
+        (void)hipGetLastError();
+        t_err = "no HIP device available";
+        return XINV_ERR_NODEV;
+    }
+    std::vector<int> devs;
+    if (opt.ndev < 0) {                                // every visible GPU
+        for (int i = 0; i < nvis; i++) devs.push_back(i);
+    } else if (opt.ndev > 0) {
+        if (opt.ndev > XINV_MAX_DEVICES) return fail_arg("ndev exceeds XINV_MAX_DEVICES");
+        for (int i = 0; i < opt.ndev; i++) {
+            if (opt.device_ids[i] < 0 || opt.device_ids[i] >= nvis) return fail_arg("device_ids: no such device");
+            devs.push_back(opt.device_ids[i]);
+        }
+    }
+    if ((int64_t)devs.size() > p.nbatch) devs.resize((size_t)p.nbatch);
+    if (devs.size() <= 1) {
+        if (devs.size() == 1) opt.device = devs[0];
+        return solve_host_one(p, flags, opt, true);
+    }
+
+    const auto wall0 = std::chrono::steady_clock::now();
+    const int nd = (int)devs.size();
+    const int64_t n = p.zc * p.yc * p.xc;
+    // host ranges pinned ONCE for every device (portable registration); the per-device threads
+    // then copy straight out of / into the caller's arrays
+    Pinned pin;
+    pin.flags = hipHostRegisterPortable;
+    pin.try_pin(p.S, (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double));
+    for (int q = 0; q < p.ncoef; q++) {
+        if (!p.c[q]) continue;
+        const int64_t len = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
+        pin.try_pin(p.c[q], (size_t)((p.sc[q] == 0 ? 0 : (p.nbatch - 1) * p.sc[q]) + len) * sizeof(double));
+    }
+    struct Result { int rc = 0; std::string err; xinv_stats st; };
+    std::vector<Result> res((size_t)nd);
+    std::vector<std::thread> th;
+    const int64_t q0 = p.nbatch / nd, r0 = p.nbatch % nd;
+    for (int i = 0; i < nd; i++) {
+        const int64_t lo = i * q0 + std::min<int64_t>(i, r0), hi = lo + q0 + (i < r0 ? 1 : 0);
+        th.emplace_back([&, i, lo, hi]() {
+            Problem sub = p;
+            sub.nbatch = hi - lo;
+            sub.S = p.S + lo * p.sS;
+            for (int q = 0; q < p.ncoef; q++)
+                if (p.c[q]) sub.c[q] = p.c[q] + lo * p.sc[q];
+            xinv_options o1 = opt;
+            o1.device = devs[(size_t)i]; o1.ndev = 0;
+            int r;
+            try { r = solve_host_one(sub, flags + 3 * lo, o1, false); }
+            catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
+            catch (...) { t_err = "unknown C++ exception"; r = XINV_ERR_HIP; }
+            res[(size_t)i].rc = r; res[(size_t)i].err = t_err; res[(size_t)i].st = t_stats;
+        });
+    }
+    for (auto &t : th) t.join();
+    t_stats = res[0].st;
+    for (int i = 0; i < nd; i++) {
+        if (res[(size_t)i].rc) { t_err = res[(size_t)i].err; return res[(size_t)i].rc; }
+        if (i == 0) continue;
+        const xinv_stats &s = res[(size_t)i].st;
+        t_stats.sweep_launches += s.sweep_launches;
+        t_stats.sweeps_max = std::max(t_stats.sweeps_max, s.sweeps_max);
+        t_stats.sweep_ms = std::max(t_stats.sweep_ms, s.sweep_ms);
+        t_stats.h2d_ms = std::max(t_stats.h2d_ms, s.h2d_ms);
+        t_stats.d2h_ms = std::max(t_stats.d2h_ms, s.d2h_ms);
+        t_stats.host_chunks += s.host_chunks;
+    }
+    t_stats.devices = nd;
+    t_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return XINV_OK;
 }
 
@@ -1105,6 +1286,8 @@ static int abs_norm_dev(const double *S, int64_t n, double undef, double *out, h
     int device;
     HIPCHK(hipGetDevice(&device));
     Workspace *ws = get_ws(device);
+    // shares the solver's partials / ctl buffers: one user of a device's workspace at a time
+    std::lock_guard<std::recursive_mutex> ws_lock(ws->busy);
     int rc = ensure_dev(&ws->partials, &ws->partials_cap,
                         (size_t)XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long)) + 64);
     if (rc) return rc;

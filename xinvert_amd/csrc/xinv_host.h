@@ -21,6 +21,25 @@ static thread_local xinv_stats t_stats;
 
 static int fail_arg(const char *msg) { t_err = msg; return XINV_ERR_ARG; }
 
+// The entry points select `opt.device` for the duration of the call and put the caller's current
+// device back on every return path (the caller's torch tensors / streams live on ITS device).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t select(int dev)                         // dev < 0: keep the current device
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) { prev = -1; return e; }
+        if (dev >= 0 && dev != prev) {
+            e = hipSetDevice(dev);
+            if (e != hipSuccess) return e;
+            changed = true;
+        }
+        return hipSuccess;
+    }
+    ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // ------------------------------------------------------------------ per-device workspace
 // Grown on demand, reused across solves (no hipMalloc in steady state).
 struct Workspace {
@@ -35,6 +54,7 @@ struct Workspace {
     int *hflag = nullptr;
     hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
     hipStream_t gstream = nullptr;                      // capture stream for the small-problem hipGraph
+    hipStream_t s_up = nullptr, s_down = nullptr, s_compute = nullptr;   // host-pointer entries: copy / sweep overlap
     // masked-tile skipping
     unsigned char *d_act = nullptr; size_t d_act_cap = 0;
     unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
@@ -164,17 +184,26 @@ static int pool_alloc(DevPool *pool, size_t bytes, double **out)
 
 struct Pinned {                                     // host ranges registered for this call
     std::vector<void *> regs;
+    std::vector<hipStream_t> streams;               // streams that may still hold copies of these ranges
+    bool enabled = true;                            // false: the caller (multi-device parent) pinned already
+    unsigned flags = hipHostRegisterDefault;
     bool try_pin(const void *h, size_t bytes)
     {
-        if (bytes < (1u << 20)) return false;
-        if (hipHostRegister((void *)h, bytes, hipHostRegisterDefault) != hipSuccess) {
+        if (!enabled || bytes < (1u << 20)) return false;
+        if (hipHostRegister((void *)h, bytes, flags) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
         regs.push_back((void *)h);
         return true;
     }
-    ~Pinned() { for (void *h : regs) (void)hipHostUnregister(h); }
+    // Every return path -- error paths included -- drains the copy streams before the ranges are
+    // unregistered: an async copy still in flight must not lose its pinning.
+    ~Pinned()
+    {
+        if (!regs.empty()) for (hipStream_t s : streams) (void)hipStreamSynchronize(s);
+        for (void *h : regs) (void)hipHostUnregister(h);
+    }
 };
 
 static int upload(DevPool *pool, Pinned &pin, hipStream_t st, const double *h, int64_t nbatch,

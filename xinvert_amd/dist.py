@@ -68,6 +68,40 @@ def gather_flags(local_flags, nbatch, device=None):
     return res
 
 
+def gather_blocks(local, nbatch, dst=None):
+    """Reassemble the batch axis: rank r holds `local` = its contiguous block [hi-lo, ...core]
+    (numpy or a torch tensor on its GPU); returns the full [nbatch, ...core] array on every rank
+    (dst=None, all_gather) or on rank `dst` only (gather; None elsewhere).  Blocks may differ in
+    length by one slice: each rank pads to the longest.  This is the only bulk exchange the path
+    has, and only a caller that wants the whole field in one place needs it -- the solves never do."""
+    import torch
+    import torch.distributed as dist
+    is_np = isinstance(local, np.ndarray)
+    if not (dist.is_available() and dist.is_initialized()):
+        return local.copy() if is_np else local.clone()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local.contiguous()
+    if dist.get_backend() == 'nccl' and not t.is_cuda:
+        t = t.to(torch.device('cuda', torch.cuda.current_device()))
+    longest = -(-int(nbatch) // world)
+    core = tuple(t.shape[1:])
+    pad = torch.zeros((longest,) + core, dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    if dst is None:
+        out = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(out, pad)
+    else:
+        out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, out, dst=dst)
+        if rank != dst:
+            return None
+    full = torch.empty((int(nbatch),) + core, dtype=t.dtype, device=t.device)
+    for r in range(world):
+        lo, hi = shard_range(nbatch, r, world)
+        full[lo:hi] = out[r][:hi - lo]
+    return full.cpu().numpy() if is_np else full
+
+
 def sharded_solve(solve_local, nbatch):
     """Run `solve_local(lo, hi) -> flags[hi-lo, 3]` on this rank's block, gather all flags."""
     import torch.distributed as dist
@@ -78,3 +112,18 @@ def sharded_solve(solve_local, nbatch):
     lo, hi = shard_range(nbatch, rank, world)
     fl = solve_local(lo, hi) if hi > lo else np.zeros((0, 3))
     return gather_flags(fl, nbatch)
+
+
+def sharded_solve_field(solve_local, S, nbatch, dst=None):
+    """Like `sharded_solve`, for callers that want the whole solution in one place:
+    `solve_local(lo, hi, S_block) -> flags` updates its block S[lo:hi] in place (a view); returns
+    (flags [nbatch, 3], S reassembled along the batch axis on every rank, or on `dst` only)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_range(nbatch, rank, world)
+    block = S[lo:hi]
+    fl = solve_local(lo, hi, block) if hi > lo else np.zeros((0, 3))
+    return gather_flags(fl, nbatch), gather_blocks(block, nbatch, dst=dst)
