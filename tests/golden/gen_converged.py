@@ -4,7 +4,7 @@
 For each full-size BASELINE configuration, run the CPU oracle in the REFERENCE's lexicographic
 ordering (oracle/xinv_oracle.c, XO_LEX -- pinned bit for bit to the reference's own numbas.py by
 tests/test_oracle_golden.py and tests/test_oracle_live_reference.py) to the stated tolerance and
-keep a seeded random sample of the converged field: 200 000 points, their forcing values (so a test
+keep a seeded random sample of the converged field: 40 000 points, their forcing values (so a test
 can tell that it regenerated the same synthetic input), the loop count and the final flags.
 
   python tests/golden/gen_converged.py c2 c3 c5        (minutes of one CPU core each)
@@ -26,6 +26,10 @@ CASES = {
     'c2': dict(tol=1e-13, mx=200000),
     'c3': dict(tol=1e-14, mx=200000),
     'c5': dict(tol=1e-13, mx=200000),
+    # Gill-Matsuno at 0.25 degrees: with the notebooks' omega = 1.4 neither ordering converges within
+    # 1e5 sweeps, and the automatic omega (1.9931, apps.py:2283) diverges for this operator (so do 1.98
+    # and 1.99); omega = 1.95 converges in ~15 000 lexicographic sweeps
+    'c4': dict(tol=1e-13, mx=200000, optArg=1.95),
 }
 
 
@@ -37,6 +41,10 @@ def problem(name):
         return synthetic.member(synthetic.stommel_cartesian(2000, 2000), 0)
     if name == 'c5':
         return synthetic.member(synthetic.omega_latlon(50, 360, 720, 1), 0)
+    if name == 'c4':
+        q = synthetic.member(synthetic.gill_matsuno(720, 1440, 3), 2)
+        q['optArg'] = CASES['c4']['optArg']
+        return q
     raise SystemExit('unknown case ' + name)
 
 
@@ -49,7 +57,7 @@ def main():
         S, fl = util.run_oracle(q, c['mx'], c['tol'], 0)
         dt = time.time() - t
         rng = np.random.default_rng(7)
-        index = np.sort(rng.choice(S.size, size=min(200000, S.size), replace=False)).astype(np.int64)
+        index = np.sort(rng.choice(S.size, size=min(200000, S.size), replace=False)).astype(np.int64)[::5]   # 40 000 points
         out = os.path.join(HERE, 'converged_%s.npz' % name)
         np.savez_compressed(out, index=index, S_lex=S.ravel()[index],
                             forcing=np.asarray(q['coefs'][-1], dtype=np.float64).ravel()[index],

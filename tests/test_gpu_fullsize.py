@@ -93,7 +93,6 @@ def _converged(name, q, valid):
     assert float(g['optArg']) == q['optArg']
     S, fl, st = util.run_hip_dev([q], mx, tol)
     assert fl[0][0] == 0 and fl[0][1] < tol, fl
-    idx = tuple(g['index'])                                  # flat sample positions
     samp = S[0].ravel()[g['index']]
     ok = valid.ravel()[g['index']]
     # the sample was drawn from the same seeded input: its forcing values must match what the
@@ -114,6 +113,16 @@ def test_c3_stommel_converged_within_1e6_of_reference_ordering():
     from xinvert_amd import synthetic
     q = synthetic.member(synthetic.stommel_cartesian(2000, 2000), 0)
     _converged('c3', q, q['coefs'][-1] != util.U)
+
+
+def test_c4_gill_matsuno_converged_within_1e6_of_reference_ordering():
+    """One C4 member at full size.  omega = 1.95: with the notebooks' 1.4 neither ordering converges
+    within 1e5 sweeps at 0.25 degrees (fields 8e-6 apart at equal counts, profiles/r01_converged_parity_c3_c4_c5.txt),
+    and the automatic omega 1.9931 diverges for this operator in both orderings."""
+    from xinvert_amd import synthetic
+    q = synthetic.member(synthetic.gill_matsuno(720, 1440, 3), 2)
+    q['optArg'] = 1.95
+    _converged('c4', q, np.ones(q['S0'].shape, dtype=bool))
 
 
 def test_c5_omega_converged_within_1e6_of_reference_ordering():

@@ -1,22 +1,42 @@
-"""Build the HIP extension in-tree:  python -m xinvert_amd.build
+"""Build the HIP extension in-tree:  python -m xinvert_amd.build [--force] [-jN]
 
 hipcc cross-compiles gfx950 code objects without a GPU; the resulting
 xinvert_amd/libxinv_hip.so travels to the GPU box with the repo snapshot.
+
+The library is several translation units -- the host driver + C-ABI, and one unit per family of
+templated sweep kernels -- compiled in parallel into build/obj/ and linked into one shared object.
+Only units whose sources (or any header) changed are recompiled.
 """
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SO = os.path.join(HERE, 'libxinv_hip.so')
-SOURCES = ['xinv_hip.hip']
-HEADERS = ['xinv_device.h', 'xinv_colour.h', 'xinv_fused.h', 'xinv_fused3d.h', 'xinv_fused3dg.h', 'xinv_fused9.h', 'xinv_fusedbih.h',
-           'xinv_host.h', 'xinv_launch.h']
+# A/B variants (tuning switches of the kernels): XINV_EXTRA_FLAGS="-DXINV_STAGE_SKIP=0"
+# XINV_BUILD_TAG=noskip  ->  build/libxinv_noskip.so (objects in build/obj_noskip); run it with XINV_SO=...
+TAG = os.environ.get('XINV_BUILD_TAG', '')
+EXTRA = os.environ.get('XINV_EXTRA_FLAGS', '').split()
+SO = os.path.join(HERE, 'libxinv_hip.so') if not TAG else os.path.join(HERE, '..', 'build', 'libxinv_%s.so' % TAG)
+OBJ = os.path.join(HERE, '..', 'build', 'obj' + ('_' + TAG if TAG else ''))
+# (object name, source, extra flags)
+UNITS = [
+    ('xinv_hip', 'xinv_hip.hip', []),
+    ('xinv_tu_fused2d_std', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=0']),
+    ('xinv_tu_fused2d_gen', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=1']),
+    ('xinv_tu_fused2d_std2dt', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=2']),
+    ('xinv_tu_fused9', 'xinv_tu_fused9.hip', []),
+    ('xinv_tu_fused3d', 'xinv_tu_fused3d.hip', []),
+    ('xinv_tu_bih', 'xinv_tu_bih.hip', []),
+    ('xinv_tu_small2d', 'xinv_tu_small2d.hip', []),
+]
+SOURCES = sorted({u[1] for u in UNITS})
 # -ffp-contract=off: no FMA contraction, so device results are bitwise those of the
 # CPU restatement of the same sweep ordering (see DESIGN.md "Arithmetic").
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC'] + EXTRA
 
 
 def hipcc():
@@ -26,24 +46,70 @@ def hipcc():
     raise RuntimeError('hipcc not found')
 
 
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')]
+    hs.append(os.path.join(HERE, '..', 'include', 'xinv.h'))
+    return hs
+
+
+def _stamp(src, extra):
+    """Content hash of everything a unit depends on (its source, every header, its flags)."""
+    h = hashlib.sha256()
+    for f in [src] + _headers():
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(FLAGS + extra).encode())
+    return h.hexdigest()
+
+
+def _units():
+    return [u for u in UNITS if os.path.exists(os.path.join(CSRC, u[1]))]
+
+
 def stale():
     if not os.path.exists(SO):
         return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps.append(os.path.join(HERE, '..', 'include', 'xinv.h'))
-    return any(os.path.getmtime(d) > t for d in deps)
+    for name, src, extra in _units():
+        st = os.path.join(OBJ, name + '.stamp')
+        if not os.path.exists(os.path.join(OBJ, name + '.o')) or not os.path.exists(st):
+            return True
+        if open(st).read() != _stamp(os.path.join(CSRC, src), extra):
+            return True
+    return False
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     if not force and not stale():
         return SO
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', SO]
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    todo = []
+    for name, src, extra in _units():
+        srcp = os.path.join(CSRC, src)
+        obj, st = os.path.join(OBJ, name + '.o'), os.path.join(OBJ, name + '.stamp')
+        stamp = _stamp(srcp, extra)
+        if force or not os.path.exists(obj) or not os.path.exists(st) or open(st).read() != stamp:
+            todo.append((name, [cc] + FLAGS + extra + ['-c', srcp, '-o', obj], st, stamp))
+
+    def run(job):
+        name, cmd, st, stamp = job
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(st, 'w') as fh:
+            fh.write(stamp)
+
+    jobs = jobs or min(len(todo) or 1, max(1, (os.cpu_count() or 2) - 1))
+    with ThreadPoolExecutor(jobs) as ex:
+        list(ex.map(run, todo))
+    link = [cc, '--offload-arch=gfx950', '-shared', '-fPIC'] + \
+           [os.path.join(OBJ, u[0] + '.o') for u in _units()] + ['-o', SO]
     if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+        print(' '.join(link), flush=True)
+    subprocess.check_call(link)
     return SO
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    j = [int(a[2:]) for a in sys.argv if a.startswith('-j') and a[2:].isdigit()]
+    print(build(force='--force' in sys.argv, verbose=True, jobs=j[0] if j else None))

@@ -380,21 +380,6 @@ __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
 // east columns read the B term's west operand FIVE columns away (the reference's stale loop index,
 // numbas.py:1495-1497, 1540-1542) -- one and two lanes to the left, in the state the 9-colour
 // order gives them (column xc-7 has colour 2: not yet updated; column xc-6 colour 0: updated).
-struct Tri { double v[3]; };
-
-__device__ __forceinline__ void bih_ext(const Tri &t, double (&e)[7])   // e[k+2] = column c+k, k=-2..4
-{
-    e[2] = t.v[0]; e[3] = t.v[1]; e[4] = t.v[2];
-    e[1] = xinv_lane_up(t.v[2]); e[0] = xinv_lane_up(t.v[1]);
-    e[5] = xinv_lane_down(t.v[0]); e[6] = xinv_lane_down(t.v[1]);
-}
-// columns c-4 and c-3: the stale-index operands of components 1 and 2
-__device__ __forceinline__ void bih_far(const Tri &t, double &cm4, double &cm3)
-{
-    cm4 = xinv_lane_up(xinv_lane_up(t.v[2]));
-    cm3 = xinv_lane_up(t.v[0]);
-}
-
 template <bool UNI, bool PER>
 __global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
 {

@@ -461,3 +461,20 @@ __device__ __forceinline__ double xinv_upd_bih2d_v(
                            I*sc.delxSSr);
     return cond ? r0_0 + temp : r0_0;
 }
+
+// three adjacent columns of one row held by a lane (biharmonic kernels: the three column colours)
+struct Tri { double v[3]; };
+
+__device__ __forceinline__ void bih_ext(const Tri &t, double (&e)[7])   // e[k+2] = column c+k, k=-2..4
+{
+    e[2] = t.v[0]; e[3] = t.v[1]; e[4] = t.v[2];
+    e[1] = xinv_lane_up(t.v[2]); e[0] = xinv_lane_up(t.v[1]);
+    e[5] = xinv_lane_down(t.v[0]); e[6] = xinv_lane_down(t.v[1]);
+}
+// columns c-4 and c-3: the stale-index operands of components 1 and 2
+__device__ __forceinline__ void bih_far(const Tri &t, double &cm4, double &cm3)
+{
+    cm4 = xinv_lane_up(xinv_lane_up(t.v[2]));
+    cm3 = xinv_lane_up(t.v[0]);
+}
+

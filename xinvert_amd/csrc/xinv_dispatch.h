@@ -1,0 +1,28 @@
+// xinv_dispatch.h -- host-side launchers of the templated sweep kernels.  Each kernel family is
+// instantiated in its own translation unit (xinv_tu_*.hip) so that the library builds in parallel
+// and a change to one family recompiles one file; the host driver (xinv_hip.hip) sees only these
+// plain functions.  With `occ` non-null a launcher reports how many workgroups of the variant fit
+// on a CU (register-limited) instead of launching it.  Return 0, or 1 for an uninstantiated variant.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "xinv_fused.h"
+#include "xinv_fused3d.h"
+#include "xinv_fused3dg.h"
+#include "xinv_fusedbih.h"
+
+#define XINV_HIDDEN __attribute__((visibility("hidden")))
+
+XINV_HIDDEN int xinv_launch_fused2d_std(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                        hipStream_t st, const FusedArgs &a, int *occ);
+XINV_HIDDEN int xinv_launch_fused2d_gen(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                        hipStream_t st, const FusedArgs &a, int *occ);
+XINV_HIDDEN int xinv_launch_fused2d_std2dt(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                           hipStream_t st, const FusedArgs &a, int *occ);
+XINV_HIDDEN int xinv_launch_fused9(bool gen, int K, bool al, bool ext, dim3 grid, hipStream_t st,
+                                   const FusedArgs &a, int *occ);
+XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 grid, hipStream_t st,
+                                    const Fused3Args &a);
+XINV_HIDDEN int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st,
+                                     const Fused3GArgs &a);
+XINV_HIDDEN int xinv_launch_fusedbih(bool per, bool zbe, dim3 grid, hipStream_t st,
+                                     const FusedBihArgs &a, int *occ);

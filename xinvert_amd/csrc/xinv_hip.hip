@@ -30,11 +30,8 @@
 #include "../../include/xinv.h"
 #include "xinv_device.h"
 #include "xinv_colour.h"
-#include "xinv_fused.h"
-#include "xinv_fused3d.h"
-#include "xinv_fused3dg.h"
-#include "xinv_fused9.h"
-#include "xinv_fusedbih.h"
+#define XINV_AUX_KERNELS            /* the detection / skip-norm helper kernels live in this unit */
+#include "xinv_dispatch.h"          /* argument structs + launchers of the sweep kernels (xinv_tu_*.hip) */
 
 #define XINV_VERSION 100
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
@@ -153,7 +150,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             HIPCHK(hipStreamSynchronize(st));
             pl.bih_zbe = (*ws->hflag == 0) && (p.sc_.undef != 0.0);
         }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fusedbih<false, false>, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        {
+            FusedBihArgs dummy; memset(&dummy, 0, sizeof dummy);
+            xinv_launch_fusedbih(false, false, dim3(1), st, dummy, &occ);
+        }
         int bestRB = 3; double best = 1e300;
         for (int RB = 3; RB <= 192; RB += 3) {
             if (opt.rows_per_tile > 0 && RB != std::max(3, (opt.rows_per_tile / 3) * 3)) continue;

@@ -32,73 +32,12 @@ static unsigned pick_um(int kind, unsigned umask)
     return 0u;
 }
 
-// Launch one instantiation -- or, when `occ` is given, only report how many of its workgroups
-// fit on a CU (register-limited: 1 to 3), which the tiling heuristic needs.
-template <class M, int K, bool AL, unsigned UM, bool EXT>
-static int fused_one(dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a, int *occ)
-{
-    if (occ) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused2d<M, K, AL, UM, EXT>, 256, 0) != hipSuccess)
-            n = 1;
-        *occ = n < 1 ? 1 : n;
-        return 0;
-    }
-    hipLaunchKernelGGL((k_fused2d<M, K, AL, UM, EXT>), grid, block, 0, st, a);
-    return 0;
-}
-
-template <class M, bool AL, unsigned UM, bool EXT>
-static int launch_fused_k(int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a, int *occ)
-{
-    switch (K) {
-    case 1: return fused_one<M, 1, AL, UM, EXT>(grid, block, st, a, occ);
-    case 2: return fused_one<M, 2, AL, UM, EXT>(grid, block, st, a, occ);
-    // three and four sweeps per pass: only the standard form with per-row A and C keeps two
-    // wavefronts per SIMD at that window depth (194 / 249 VGPRs; the general form does not gain)
-    case 3:
-        return fused_one<M, 3, AL, UM, EXT>(grid, block, st, a, occ);
-        break;
-    case 4:
-        if constexpr (std::is_same<M, FusedStd2D>::value)
-            return fused_one<M, 4, AL, UM, EXT>(grid, block, st, a, occ);
-        break;
-    default: break;
-    }
-    return 1;
-}
-
-template <class M, bool AL, bool EXT>
-static int launch_fused_um(unsigned um, int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a,
-                           int *occ)
-{
-    if constexpr (std::is_same<M, FusedStd2D>::value) {
-        if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a, occ);
-    } else if constexpr (std::is_same<M, FusedStd2DT>::value) {
-        if (um == 7u) return launch_fused_k<M, AL, 7u, EXT>(K, grid, block, st, a, occ);
-    } else {
-        if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a, occ);
-        if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a, occ);
-    }
-    return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a, occ);
-}
-
-template <class M>
-static int launch_fused_m(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
-                          const FusedArgs &a, int *occ)
-{
-    if (al) return ext ? launch_fused_um<M, true, true>(um, K, grid, block, st, a, occ)
-                       : launch_fused_um<M, true, false>(um, K, grid, block, st, a, occ);
-    return ext ? launch_fused_um<M, false, true>(um, K, grid, block, st, a, occ)
-               : launch_fused_um<M, false, false>(um, K, grid, block, st, a, occ);
-}
-
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                           hipStream_t st, const FusedArgs &a, int *occ)
 {
-    if (kind == KIND_GEN2D) return launch_fused_m<FusedGen2D>(al, ext, um, K, grid, block, st, a, occ);
-    if (kind == KIND_STD2DT) return launch_fused_m<FusedStd2DT>(al, ext, um, K, grid, block, st, a, occ);
-    return launch_fused_m<FusedStd2D>(al, ext, um, K, grid, block, st, a, occ);
+    if (kind == KIND_GEN2D) return xinv_launch_fused2d_gen(al, ext, um, K, grid, block, st, a, occ);
+    if (kind == KIND_STD2DT) return xinv_launch_fused2d_std2dt(al, ext, um, K, grid, block, st, a, occ);
+    return xinv_launch_fused2d_std(al, ext, um, K, grid, block, st, a, occ);
 }
 
 static bool ptr_al16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
@@ -158,38 +97,10 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     return XINV_OK;
 }
 
-// ---- 9-point fused launch ---------------------------------------------------------------------
-template <class M, int K>
-static void launch_fused9_k(bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ)
-{
-    dim3 block(256, 1, 1);
-#define L9(AL, EXT)                                                                              \
-    do {                                                                                         \
-        if (occ) {                                                                               \
-            int n = 0;                                                                           \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused9<M, K, AL, EXT>, 256, 0) != hipSuccess) n = 1; \
-            *occ = n < 1 ? 1 : n;                                                                \
-        } else hipLaunchKernelGGL((k_fused9<M, K, AL, EXT>), grid, block, 0, st, a);             \
-    } while (0)
-    if (al) { if (ext) L9(true, true); else L9(true, false); }
-    else    { if (ext) L9(false, true); else L9(false, false); }
-#undef L9
-}
-
 static int fused9_dispatch(int kind, int K, bool al, bool ext, dim3 grid, hipStream_t st,
                            const FusedArgs &a, int *occ)
 {
-    if (kind == KIND_GEN2D) {
-        if (K == 1) launch_fused9_k<Fused9Gen, 1>(al, ext, grid, st, a, occ);
-        else if (K == 2) launch_fused9_k<Fused9Gen, 2>(al, ext, grid, st, a, occ);
-        else return 1;
-    } else {
-        if (K == 1) launch_fused9_k<Fused9Std, 1>(al, ext, grid, st, a, occ);
-        else if (K == 2) launch_fused9_k<Fused9Std, 2>(al, ext, grid, st, a, occ);
-        else if (K == 3) launch_fused9_k<Fused9Std, 3>(al, ext, grid, st, a, occ);
-        else return 1;
-    }
-    return 0;
+    return xinv_launch_fused9(kind == KIND_GEN2D, K, al, ext, grid, st, a, occ);
 }
 
 static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
@@ -233,23 +144,6 @@ static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *
     return XINV_OK;
 }
 
-// ---- 3-D fused launch ------------------------------------------------------------------------
-template <int NW>
-static int launch_fused3d_nw(bool al, bool uni, bool ext, dim3 grid, hipStream_t st, const Fused3Args &a)
-{
-    dim3 block(NW * 64, 1, 1);
-#define L3(AL, UNI, EXT) hipLaunchKernelGGL((k_fused3d<NW, AL, UNI, EXT>), grid, block, 0, st, a)
-    if (al) {
-        if (uni) { if (ext) L3(true, true, true); else L3(true, true, false); }
-        else     { if (ext) L3(true, false, true); else L3(true, false, false); }
-    } else {
-        if (uni) { if (ext) L3(false, true, true); else L3(false, true, false); }
-        else     { if (ext) L3(false, false, true); else L3(false, false, false); }
-    }
-#undef L3
-    return 0;
-}
-
 static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, double *dst,
                           Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
                           int no_ctl)
@@ -271,9 +165,7 @@ static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, d
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)NB, (unsigned)nm, 1);
-        if (pl.RY == 8) launch_fused3d_nw<8>(pl.aligned, uni, ext, grid, st, a);
-        else if (pl.RY == 12) launch_fused3d_nw<12>(pl.aligned, uni, ext, grid, st, a);
-        else launch_fused3d_nw<16>(pl.aligned, uni, ext, grid, st, a);
+        xinv_launch_fused3d(pl.RY, pl.aligned, uni, ext, grid, st, a);
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;
@@ -320,27 +212,11 @@ static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, 
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)a.nwg, (unsigned)nm, 1), block(256, 1, 1);
-        if (pl.bih_zbe) {
-            if (per) hipLaunchKernelGGL((k_fusedbih<true, true>), grid, block, 0, st, a);
-            else     hipLaunchKernelGGL((k_fusedbih<false, true>), grid, block, 0, st, a);
-        } else {
-            if (per) hipLaunchKernelGGL((k_fusedbih<true, false>), grid, block, 0, st, a);
-            else     hipLaunchKernelGGL((k_fusedbih<false, false>), grid, block, 0, st, a);
-        }
+        (void)block;
+        xinv_launch_fusedbih(per, pl.bih_zbe, grid, st, a, nullptr);
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;
-}
-
-// ---- general 3-D fused launch (every coefficient array x-uniform) --------------------------------
-template <int NW>
-static void launch_fused3dg_nw(bool al, bool ext, dim3 grid, hipStream_t st, const Fused3GArgs &a)
-{
-    dim3 block(NW * 64, 1, 1);
-    if (al) { if (ext) hipLaunchKernelGGL((k_fused3dg<NW, true, true>), grid, block, 0, st, a);
-              else     hipLaunchKernelGGL((k_fused3dg<NW, true, false>), grid, block, 0, st, a); }
-    else    { if (ext) hipLaunchKernelGGL((k_fused3dg<NW, false, true>), grid, block, 0, st, a);
-              else     hipLaunchKernelGGL((k_fused3dg<NW, false, false>), grid, block, 0, st, a); }
 }
 
 static int launch_fused3dg(const Problem &p, const Plan &pl, const double *src, double *dst,
@@ -364,9 +240,7 @@ static int launch_fused3dg(const Problem &p, const Plan &pl, const double *src, 
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)NB, (unsigned)nm, 1);
-        if (pl.RY == 8) launch_fused3dg_nw<8>(pl.aligned, ext, grid, st, a);
-        else if (pl.RY == 16) launch_fused3dg_nw<16>(pl.aligned, ext, grid, st, a);
-        else launch_fused3dg_nw<12>(pl.aligned, ext, grid, st, a);
+        xinv_launch_fused3dg(pl.RY, pl.aligned, ext, grid, st, a);
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;
