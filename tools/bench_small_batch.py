@@ -1,30 +1,23 @@
 #!/usr/bin/env python3
-"""Many small slices in one call (the reference's typical use: a year of daily 2.5-degree fields)."""
-import ctypes, json, os, sys, time
+"""Many small slices in one call (the reference's typical use: a year of daily 2.5-degree fields).
+  python tools/bench_small_batch.py [--path 0|2|3]      0 = engine's choice, 2 = streaming kernels, 3 = register-resident solver"""
+import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import torch
-from xinvert_amd import _lib, synthetic
-import util
-L = _lib.require_gpu()
-dev = torch.device('cuda', 0)
-for (ny, nx, nb) in [(73, 144, 1), (73, 144, 365), (180, 360, 365), (73, 144, 3650)]:
-    p = synthetic.gill_matsuno(ny, nx, nb)
-    n = ny * nx
-    S0 = torch.from_numpy(np.ascontiguousarray(p['S0'])).to(dev); S = S0.clone()
-    cs = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.float64)).to(dev) for c in p['coefs']]
-    strides = [n] + [0 if k in p['shared'] else n for k in range(len(cs))]
-    fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
-    sw = 400
-    opt = _lib.options(timing=1)
-    args = [ctypes.c_void_p(S.data_ptr())] + [ctypes.c_void_p(c.data_ptr()) for c in cs] + \
-           [nb, _lib.strides_arg(strides)] + util._scal(p, fl, sw - 1, 0.0) + [ctypes.byref(opt), None]
+sys.path.insert(0, ROOT)
+from xinvert_amd import synthetic
+from xinvert_amd.resident import ResidentProblem
+ap = argparse.ArgumentParser(); ap.add_argument('--path', type=int, default=0); ap.add_argument('--sweeps', type=int, default=400)
+a = ap.parse_args()
+CASES = [('gm', 73, 144, 1), ('gm', 73, 144, 365), ('gm', 73, 144, 3650), ('poisson', 72, 144, 365),
+         ('poisson', 180, 360, 1), ('poisson', 180, 360, 64), ('gm', 180, 360, 365)]
+for (kind, ny, nx, nb) in CASES:
+    p = synthetic.gill_matsuno(ny, nx, nb) if kind == 'gm' else synthetic.poisson_latlon(ny, nx, mask=False, BCs=('extend', 'periodic'), members=nb)
+    rp = ResidentProblem(p)
     best = 1e9
     for rep in range(3):
-        S.copy_(S0); torch.cuda.synchronize()
-        t = time.perf_counter(); _lib.check(L.xinv_general_2d_f64_dev(*args)); best = min(best, time.perf_counter() - t)
-    st = _lib.last_stats()
-    print(json.dumps({'shape': [nb, ny, nx], 'point_sweeps_per_s': nb * n * sw / best, 'solve_ms': best * 1e3,
-                      'launch_us': st['sweep_ms'] / st['sweep_launches'] * 1e3, 'rows_per_tile': st['rows_per_tile'],
-                      'um': st['xuniform_mask']}))
+        rp.reset()
+        t = time.perf_counter(); fl, st = rp.solve(a.sweeps - 1, 0.0, timing=1, path=a.path); best = min(best, time.perf_counter() - t)
+    print(json.dumps({'case': kind, 'shape': [nb, ny, nx], 'point_sweeps_per_s': nb * ny * nx * a.sweeps / best, 'solve_ms': best * 1e3,
+                      'us_per_sweep': best * 1e6 / a.sweeps, 'path': st['path'], 'rows_per_tile': st['rows_per_tile'], 'um': st['xuniform_mask']}), flush=True)
+    del rp
