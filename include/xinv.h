@@ -81,7 +81,22 @@ typedef struct xinv_options {
                                    thread per GPU, no collective: slices are independent, reference
                                    core.py:129-139); -1 = every visible GPU.  Ignored by *_dev entries.  */
     int32_t device_ids[XINV_MAX_DEVICES];
+    /* Front-end passes done on the device by the host-pointer batched entries (ignored by *_dev):
+       what apps.__mask_FS, the builders' `F * cos(lat)` + re-mask and the output de-mask do with
+       numpy in the reference (apps.py:2112-2159, 1409-1411, 1389-1392).                              */
+    int32_t prep_flags;         /* XINV_PREP_* bits                                                  */
+    int32_t pad0_;
+    double  prep_undef;         /* XINV_PREP_MASK_VALUE: the caller's undefined value                 */
+    double  demask_value;       /* XINV_PREP_DEMASK: written to S where the forcing is masked         */
+    const double *prep_rowscale;/* XINV_PREP_ROWSCALE: [yc] host doubles, defined forcing values of
+                                   row j (of every plane / member) are multiplied by prep_rowscale[j] */
 } xinv_options;
+
+#define XINV_PREP_MASK_NAN   1  /* the forcing (last coefficient array) marks masked points with NaN   */
+#define XINV_PREP_MASK_VALUE 2  /* ... with prep_undef                                                 */
+#define XINV_PREP_ROWSCALE   4
+#define XINV_PREP_S_ZERO     8  /* the initial guess is zero: S is not read from the host              */
+#define XINV_PREP_DEMASK    16
 
 typedef struct xinv_stats {
     int32_t path;               /* path actually used                                           */

@@ -137,6 +137,24 @@ def test_invert_bretherton_synthetic_topography():
     assert util.rel_l2(Sh[0], Sl) < 1e-6
 
 
+def test_invert_bretherton_reference_ke_pin():
+    """reference tests/test_Bretherton.py:13-42 as written: Data/topo.nc, `invert_BrethertonHaidvogel`
+    + `cal_flow`, KE = sum(u^2 + v^2) / 2 must satisfy np.isclose(KE, 0.0812731) -- the reference's
+    own assert, on the HIP path."""
+    import xinvert_amd as xa
+    g = util.golden('topo.npz')
+    topo = g['topo'] - g['topo'].mean()
+    h = xa.Field(topo, ('y', 'x'), {'y': g['y'], 'x': g['x']})
+    assert h.dims == ('y', 'x') and h.shape == (201, 301)
+    iParams = {'BCs': ['fixed', 'fixed'], 'mxLoop': 3000, 'tolerance': 1e-16, 'undef': np.nan, 'printInfo': False}
+    mParams1 = {'f0': 1e-4, 'D': 1000, 'lambda': 1e-15}
+    S1 = xa.invert_BrethertonHaidvogel(h, dims=['y', 'x'], coords='cartesian', mParams=mParams1, iParams=iParams)
+    u1, v1 = xa.cal_flow(S1, dims=['y', 'x'], coords='cartesian')
+    assert S1.dims == h.dims and S1.shape == h.shape and u1.dims == h.dims and u1.shape == h.shape
+    KE = float((u1.values ** 2 + v1.values ** 2).sum() / 2)
+    assert np.isclose(KE, 0.0812731), KE
+
+
 def test_invert_ishida_mask_periodic_odd_width():
     """reference tests/test_Ishida.py:13-63 (h1, h2): value-undef mask, periodic x, xc = 251."""
     import xinvert_amd as xa
@@ -655,3 +673,57 @@ def test_abs_norm_dev():
     rc = L.xinv_abs_norm_f64_dev(ctypes.c_void_p(t.data_ptr()), a.size, U, ctypes.byref(out), None)
     _lib.check(rc)
     assert abs(out.value / orc.abs_norm(a, U) - 1) < 1e-13
+
+
+# ------------------------------------------------------------------ front-end passes on the device
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize('undef', [np.nan, -9999.0])
+def test_device_side_mask_scale_demask_equals_host_front_end(undef):
+    """apps.__mask_FS, the builders' F * cos(lat) + re-mask and the output de-mask (reference
+    apps.py:2112-2159, 1409-1411, 1389-1392) done by the host entry on the device
+    (xinv_options.prep_flags) must give exactly what the numpy front end gives: lat-lon Poisson
+    (NaN and value masks, a time axis, chunked members), Gill-Matsuno, 3-D omega."""
+    import xinvert_amd as xa
+    rng = np.random.default_rng(11)
+    lat = np.linspace(-88.75, 88.75, 72); lon = np.arange(0, 360, 2.5)
+    la, lo = np.deg2rad(lat)[:, None], np.deg2rad(lon)[None, :]
+    vor = np.stack([1e-5 * (np.sin(3 * lo + t) * np.cos(2 * la) + 0.1 * rng.standard_normal((72, 144))) for t in range(5)])
+    land = (np.sin(4 * lo + 2 * la) > 0.5) & (np.abs(la) < 1.2)
+    vor[:, land] = undef
+    vor[3, 10:20, 30:50] = undef                                   # a member-specific mask
+    F = xa.Field(vor, ('time', 'lat', 'lon'), {'lat': lat, 'lon': lon})
+    for BCs in (['fixed', 'periodic'], ['extend', 'periodic']):
+        iP = {'BCs': BCs, 'mxLoop': 60, 'tolerance': 0.0, 'printInfo': False, 'undef': undef, 'host_chunk': 2}
+        Sd = xa.invert_Poisson(F, ['lat', 'lon'], iParams=iP)
+        Sh = xa.invert_Poisson(F, ['lat', 'lon'], iParams=dict(iP, device_prep=False))
+        assert Sd.iParams['stats']['host_chunks'] == 3
+        assert _same(Sd.values, Sh.values) and np.array_equal(Sd.iParams['flags'], Sh.iParams['flags'])
+        msk = np.isnan(vor) if np.isnan(undef) else (vor == undef)
+        assert _same(Sd.values[msk], np.full(msk.sum(), undef)) and np.isfinite(Sd.values[~msk]).all()
+        assert np.abs(Sd.values[~msk]).max() > 0
+    # cartesian Poisson: no scale
+    y = np.linspace(0, 7.1e6, 72); x = np.linspace(0, 1.43e7, 144)
+    Fc = xa.Field(vor[1], ('y', 'x'), {'y': y, 'x': x})
+    iP = {'BCs': ['fixed', 'fixed'], 'mxLoop': 40, 'tolerance': 0.0, 'printInfo': False, 'undef': undef}
+    assert _same(xa.invert_Poisson(Fc, ['y', 'x'], coords='cartesian', iParams=iP).values,
+                 xa.invert_Poisson(Fc, ['y', 'x'], coords='cartesian', iParams=dict(iP, device_prep=False)).values)
+    # Gill-Matsuno (forcing = Q, no scale) on the same grid
+    Q = xa.Field(np.where(np.isnan(vor) | (vor == undef), undef, 0.05 * np.exp(-(la * 6) ** 2 - ((lo - 3) * 3) ** 2)),
+                 ('time', 'lat', 'lon'), {'lat': lat, 'lon': lon})
+    iP = {'BCs': ['fixed', 'periodic'], 'mxLoop': 50, 'tolerance': 0.0, 'optArg': 1.4, 'printInfo': False, 'undef': undef}
+    mP = {'epsilon': 1e-5, 'Phi': 5000}
+    assert _same(xa.invert_GillMatsuno(Q, ['lat', 'lon'], mParams=mP, iParams=iP).values,
+                 xa.invert_GillMatsuno(Q, ['lat', 'lon'], mParams=mP, iParams=dict(iP, device_prep=False)).values)
+    # omega: 3-D, the scale runs along the middle core dim
+    lev = np.linspace(1e5, 1e4, 9)
+    frc = 1e-17 * rng.standard_normal((2, 9, 72, 144))
+    frc[:, :3, land] = undef
+    W = xa.Field(frc, ('time', 'lev', 'lat', 'lon'), {'lev': lev, 'lat': lat, 'lon': lon})
+    iP = {'BCs': ['fixed', 'fixed', 'periodic'], 'mxLoop': 20, 'tolerance': 0.0, 'printInfo': False, 'undef': undef}
+    mP = {'N2': 2e-6}
+    Wd = xa.invert_omega(W, ['lev', 'lat', 'lon'], mParams=mP, iParams=iP)
+    Wh = xa.invert_omega(W, ['lev', 'lat', 'lon'], mParams=mP, iParams=dict(iP, device_prep=False))
+    assert _same(Wd.values, Wh.values) and np.abs(Wd.values[np.isfinite(Wd.values)]).max() > 0

@@ -292,3 +292,34 @@ def test_fofonoff_notebook_pin(oracle):
     p, _, _, _ = fofonoff_problem()
     S, fl = util.run_oracle(p, 4000, 1e-14, LEX)
     assert '{0:4.0f} and tolerance is {1:e}'.format(fl[2], fl[1]) == '1174 and tolerance is 9.362824e-15'
+
+
+def bretherton_problem():
+    """reference tests/test_Bretherton.py:13-31: Data/topo.nc (201 x 301, here tests/golden/topo.npz --
+    the file's three arrays), topography anomaly, f0 = 1e-4, D = 1000, lambda = 1e-15."""
+    from xinvert_amd import apps
+    from xinvert_amd.field import Field
+    g = util.golden('topo.npz')
+    topo = g['topo'] - g['topo'].mean()
+    h = Field(topo, ('y', 'x'), {'y': g['y'], 'x': g['x']})
+    iP = apps._update(apps.default_iParams, {'BCs': ['fixed', 'fixed'], 'mxLoop': 3000, 'tolerance': 1e-16})
+    mP = apps._update(apps.default_mParams, {'f0': 1e-4, 'D': 1000, 'lambda': 1e-15})
+    Fm, initS, cs = apps._coeffs_Bretherton(h, ['y', 'x'], 'cartesian', mP, iP, None)
+    ps = apps._cal_params2D(g['y'], g['x'], 'cartesian')
+    p = dict(kind='std2dt', yc=201, xc=301, BCy='fixed', BCx='fixed', dely=ps['del2'], delx=ps['del1'],
+             delxSqr=ps['del1Sqr'], ratio=ps['ratio'], ratioQtr=ps['ratioQtr'], ratioSqr=ps['ratioSqr'],
+             optArg=ps['optArg'], undef=U, S0=np.zeros((201, 301)),
+             coefs=[np.ascontiguousarray(c) for c in cs] + [Fm.values])
+    return p, h
+
+
+def test_bretherton_ke_pin(oracle):
+    """tests/test_Bretherton.py:42: `np.isclose(KE, 0.0812731)` with KE = sum(u^2 + v^2) / 2 of
+    cal_flow(S1) after invert_BrethertonHaidvogel(topo) -- the reference's own known answer, reproduced
+    by the oracle's lexicographic ordering through the host-side coefficient builder and cal_flow."""
+    from xinvert_amd import apps
+    p, h = bretherton_problem()
+    S, fl = util.run_oracle(p, 3000, 1e-16, LEX)
+    u, v = apps.cal_flow(h.like(S), ['y', 'x'], coords='cartesian')
+    KE = float((u.values ** 2 + v.values ** 2).sum() / 2)
+    assert np.isclose(KE, 0.0812731), KE

@@ -13,6 +13,7 @@ SO = os.environ.get('XINV_SO') or os.path.join(HERE, 'libxinv_hip.so')
 
 BC_CODES = {'fixed': 0, 'extend': 1, 'periodic': 2}
 PATH_AUTO, PATH_COLOUR, PATH_FUSED, PATH_SMALL = 0, 1, 2, 3
+PREP_MASK_NAN, PREP_MASK_VALUE, PREP_ROWSCALE, PREP_S_ZERO, PREP_DEMASK = 1, 2, 4, 8, 16     # XINV_PREP_*
 MAX_DEVICES = 16                      # XINV_MAX_DEVICES
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -26,7 +27,10 @@ class XinvOptions(ctypes.Structure):
                 ('rows_per_tile', ctypes.c_int32), ('timing', ctypes.c_int32),
                 ('flags', ctypes.c_int32), ('rowconst_mask', ctypes.c_int32),
                 ('host_chunk', ctypes.c_int32), ('ndev', ctypes.c_int32),
-                ('device_ids', ctypes.c_int32 * MAX_DEVICES)]
+                ('device_ids', ctypes.c_int32 * MAX_DEVICES),
+                ('prep_flags', ctypes.c_int32), ('pad0_', ctypes.c_int32),
+                ('prep_undef', ctypes.c_double), ('demask_value', ctypes.c_double),
+                ('prep_rowscale', ctypes.POINTER(ctypes.c_double))]
 
 
 class XinvStats(ctypes.Structure):
@@ -135,7 +139,7 @@ def check(rc):
 
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
             timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0,
-            host_chunk=0, devices=None):
+            host_chunk=0, devices=None, prep=None):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
@@ -144,6 +148,26 @@ def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_
     o.flags = (1 if no_xuniform else 0) | (2 if no_tile_skip else 0) | (4 if force_tile_skip else 0)
     o.rowconst_mask = int(rowconst_mask)
     o.host_chunk = int(host_chunk)
+    # prep: front-end passes on the device -- dict(mask='nan' | value, rowscale=vec | None,
+    # s_zero=bool, demask=value | None); the row-scale array is kept alive on the options object
+    if prep:
+        fl = 0
+        if isinstance(prep.get('mask'), str):
+            fl |= PREP_MASK_NAN
+        elif prep.get('mask') is not None:
+            fl |= PREP_MASK_VALUE
+            o.prep_undef = float(prep['mask'])
+        if prep.get('rowscale') is not None:
+            rs = np.ascontiguousarray(prep['rowscale'], dtype=np.float64)
+            o._rowscale_keepalive = rs
+            o.prep_rowscale = rs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            fl |= PREP_ROWSCALE
+        if prep.get('s_zero'):
+            fl |= PREP_S_ZERO
+        if 'demask' in prep and prep['demask'] is not None:
+            fl |= PREP_DEMASK
+            o.demask_value = float(prep['demask'])
+        o.prep_flags = fl
     # devices: None = the single device `device`; 'all' = every visible GPU; a list = those GPUs
     if devices is None:
         o.ndev = 0

@@ -23,7 +23,7 @@ import copy
 import numpy as np
 
 from . import core
-from .field import Field, aligned, along, from_any, full, to_like
+from .field import Field, LazyForcing, aligned, along, from_any, full, to_like
 
 # default undefined value (reference apps.py:18, core.py:15)
 _undeftmp = -9.99e8
@@ -426,8 +426,11 @@ def _template(coef_func, inv_func, dimLen, F, dims, coords='lat-lon', icbc=None,
     iParams = _update(default_iParams, iParams)
     mParams = _update(default_mParams, mParams, list(validParams))
 
-    # 1. coefficients
+    # 1. coefficients (`_lazy`: builders that can may describe the forcing instead of computing it;
+    #    iParams['device_prep'] = False keeps everything on the host, as the reference)
+    iParams['_lazy'] = True
     maskF, initS, coeffs = coef_func(F, dims, coords, mParams, iParams, icbc)
+    iParams.pop('_lazy', None)
 
     # 2. parameters
     if dimLen == 2:
@@ -443,11 +446,14 @@ def _template(coef_func, inv_func, dimLen, F, dims, coords='lat-lon', icbc=None,
     if iParams['debug']:
         print({k: v for k, v in iParams.items() if k != 'flags'})
 
-    # 3. invert (HIP kernels; in place on initS)
+    # 3. invert (HIP kernels; in place on initS -- or, with a lazy forcing, from zeros on the device
+    #    with the forcing masked / scaled and the output de-masked there too)
     S = inv_func(*coeffs, maskF, initS, dims, iParams)
 
     # 4. de-mask
-    if icbc is None:
+    if iParams.pop('_demasked', False):
+        S = S.like(S.values, 'inverted')
+    elif icbc is None:
         out = np.where(maskF.values != _undeftmp, S.values, iParams['undef'])
         S = S.like(out, 'inverted')
     else:
@@ -456,8 +462,17 @@ def _template(coef_func, inv_func, dimLen, F, dims, coords='lat-lon', icbc=None,
     return to_like(S, tmpl) if not isinstance(tmpl, Field) else S
 
 
-def _mask_FS(F, dims, iParams, icbc):
-    """Mask forcing with _undeftmp, build the initial guess (reference apps.py:2112-2159)."""
+def _mask_FS(F, dims, iParams, icbc, lazy=False):
+    """Mask forcing with _undeftmp, build the initial guess (reference apps.py:2112-2159).
+
+    lazy (builders whose forcing is `mask, then scale along one core dim`; no icbc): nothing is
+    computed here -- the forcing comes back as a LazyForcing, the initial guess as None (zeros),
+    and the solver's host entry does the masking / scaling / zero-fill / output de-mask on the
+    device.  An infinity in the forcing then starts from S = 0 instead of the reference's
+    `maskF - maskF` = NaN; both runs overflow at once."""
+    if lazy and icbc is None and iParams.get('_lazy', False) and iParams.get('device_prep', True) \
+            and np.asarray(F.values).dtype == np.float64:
+        return LazyForcing(F.values, F.dims, F.coords, iParams['undef'], _undeftmp, name=F.name), None, None
     vals = np.asarray(F.values, dtype=np.float64)
     undef = iParams['undef']
     if np.isnan(undef):
@@ -495,9 +510,21 @@ def _remask(values, maskF):
     return np.where(maskF.values != _undeftmp, values, _undeftmp)
 
 
+def _scale_remask(maskF, vec, dim):
+    """`maskF * vec` along `dim`, masked points kept at _undeftmp (the builders' `F * cos(lat)` and
+    re-mask) -- described, not computed, when the forcing is lazy."""
+    if isinstance(maskF, LazyForcing):
+        return maskF.scaled(vec, dim)
+    return maskF.like(_remask(maskF.values * along(vec, maskF, dim), maskF))
+
+
+def _as_forcing(maskF):
+    return maskF if isinstance(maskF, LazyForcing) else maskF.like(maskF.values)
+
+
 def _coeffs_Poisson(force, dims, coords, mParams, iParams, icbc):
     """reference apps.py:1397-1437.  Returns core-shaped (batch-shared) coefficients."""
-    maskF, initS, zero = _mask_FS(force, dims, iParams, icbc)
+    maskF, initS, zero = _mask_FS(force, dims, iParams, icbc, lazy=coords.lower() != 'z-lat')
     z2 = _core_zero(maskF, dims)
     c = coords.lower()
     if c == 'lat-lon':
@@ -509,22 +536,22 @@ def _coeffs_Poisson(force, dims, coords, mParams, iParams, icbc):
         A = z2 + cosH[:, None]
         B = _zero_like(z2)
         C = z2 + (1.0 / cosG)[:, None]
-        Fv = _remask(maskF.values * along(cosG, maskF, dims[0]), maskF)
+        Fv = _scale_remask(maskF, cosG, dims[0])
     elif c == 'z-lat':
         cosG = np.cos(np.deg2rad(np.asarray(maskF[dims[1]], dtype=np.float64)))
         A = z2 + 1.0
         B = _zero_like(z2)
         C = z2 + 1.0
-        Fv = _remask(maskF.values * along(cosG, maskF, dims[1]), maskF)
+        Fv = _scale_remask(maskF, cosG, dims[1])
     elif c in ('z-lon', 'cartesian'):
         A = z2 + 1.0
         B = _zero_like(z2)
         C = z2 + 1.0
-        Fv = maskF.values
+        Fv = _as_forcing(maskF)
     else:
         raise Exception('unsupported coords ' + coords +
                         ', should be in [lat-lon, z-lat, z-lon, cartesian]')
-    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C)
+    return Fv, initS, _cs(maskF, dims, A, B, C)
 
 
 def _coeffs_Stommel(curl, dims, coords, mParams, iParams, icbc):
@@ -661,7 +688,7 @@ def _coeffs_GillMatsuno(Q, dims, coords, mParams, iParams, icbc):
     Phi, epsilon = mParams['Phi'], mParams['epsilon']
     f0, beta = mParams['f0'], mParams['beta']
     Omega, Rearth = mParams['Omega'], mParams['Rearth']
-    maskF, initS, zero = _mask_FS(Q, dims, iParams, icbc)
+    maskF, initS, zero = _mask_FS(Q, dims, iParams, icbc, lazy=True)
     z2 = _core_zero(maskF, dims)
     yv = np.asarray(Q[dims[0]], dtype=np.float64)
     c = coords.lower()
@@ -690,13 +717,13 @@ def _coeffs_GillMatsuno(Q, dims, coords, mParams, iParams, icbc):
         Fc = z2 - epsilon
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
-    return maskF.like(maskF.values), initS, _cs(maskF, dims, A, B, C, D, E, Fc)
+    return _as_forcing(maskF), initS, _cs(maskF, dims, A, B, C, D, E, Fc)
 
 
 def _coeffs_omega(force, dims, coords, mParams, iParams, icbc):
     """reference apps.py:2016-2052.  N2 may be a scalar or a profile over dims[0] (lev)."""
     f0, beta, N2, Omega = mParams['f0'], mParams['beta'], mParams['N2'], mParams['Omega']
-    maskF, initS, zero = _mask_FS(force, dims, iParams, icbc)
+    maskF, initS, zero = _mask_FS(force, dims, iParams, icbc, lazy=True)
     zc, yc, xc = (maskF.shape[maskF.axis(d)] for d in dims)
     z3 = np.zeros((zc, yc, 1))
     if np.isscalar(N2):
@@ -716,16 +743,16 @@ def _coeffs_omega(force, dims, coords, mParams, iParams, icbc):
         A = z3 + (f**2 * cosG)[None, :, None]
         B = z3 + n2 * cosH[None, :, None]
         C = z3 + n2 / cosG[None, :, None]
-        Fv = _remask(maskF.values * along(cosG, maskF, dims[1]), maskF)
+        Fv = _scale_remask(maskF, cosG, dims[1])
     elif c == 'cartesian':
         f = f0 + beta * yv
         A = z3 + (f**2.)[None, :, None]
         B = z3 + n2
         C = z3 + n2
-        Fv = maskF.values
+        Fv = _as_forcing(maskF)
     else:
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
-    return maskF.like(Fv), initS, _cs(maskF, dims, A, B, C)
+    return Fv, initS, _cs(maskF, dims, A, B, C)
 
 
 def _half_shift(v):
@@ -875,7 +902,7 @@ def _coeffs_StommelArons(Q, dims, coords, mParams, iParams, icbc):
         raise Exception('unsupported coords ' + coords + ', should be in [lat-lon, cartesian]')
     B = full(0.0, maskF)
     Fc = full(0.0, maskF)
-    return maskF.like(maskF.values), initS, _cs(maskF, dims, A, B, C, D, E, Fc)
+    return _as_forcing(maskF), initS, _cs(maskF, dims, A, B, C, D, E, Fc)
 
 
 def _coeffs_geostrophic(lapPhi, dims, coords, mParams, iParams, icbc):

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .field import Field, aligned
+from .field import Field, LazyForcing, aligned
 
 # default undefined value (reference core.py:15)
 _undeftmp = -9.99e8
@@ -148,19 +148,33 @@ def _info(sel):
 
 
 def _solve(kind, coefs, F, S, dims, iParams):
-    if not isinstance(F, Field) or not isinstance(S, Field):
+    if not isinstance(F, Field) or not (isinstance(S, Field) or S is None):
         raise Exception('forcing and solution must be Field objects (see xinvert_amd.field)')
     perm, bdims, bshape = _batch_layout(F, dims)
     core_shape = tuple(F.shape[F.axis(d)] for d in dims)
     nbatch = int(np.prod(bshape)) if bshape else 1
     n = int(np.prod(core_shape))
     if nbatch == 0:                # an empty non-core axis: the reference's loop_noncore yields nothing
-        return S
+        return S if S is not None else F.like(np.zeros(F.shape))
     L = _lib.require_gpu()
 
-    Sv = np.ascontiguousarray(np.transpose(np.asarray(S.values, dtype=np.float64), perm)
-                              ).reshape((nbatch,) + core_shape)
-    Fv = np.ascontiguousarray(np.transpose(np.asarray(F.values, dtype=np.float64), perm)
+    # A lazy forcing travels as the caller's raw array; masking, the per-row scale, the zero initial
+    # guess and the output de-mask then happen on the device (xinv_options.prep_flags).  Conditions:
+    # the scale runs along the y core dim (row index), the forcing is the last array of the call.
+    prep = None
+    if isinstance(F, LazyForcing) and S is None and \
+            (F.scale is None or (F.scale_dim in dims and list(dims).index(F.scale_dim) == len(dims) - 2)):
+        prep = dict(mask='nan' if np.isnan(F.undef_in) else float(F.undef_in), rowscale=F.scale, s_zero=True,
+                    demask=iParams['undef'])
+        Fsrc = F.raw
+        Sv = np.empty((nbatch,) + core_shape)
+    else:
+        if S is None:
+            S = F.like(np.zeros(F.shape))
+        Fsrc = F.values
+        Sv = np.ascontiguousarray(np.transpose(np.asarray(S.values, dtype=np.float64), perm)
+                                  ).reshape((nbatch,) + core_shape)
+    Fv = np.ascontiguousarray(np.transpose(np.asarray(Fsrc, dtype=np.float64), perm)
                               ).reshape((nbatch,) + core_shape)
     arrs, strides = [Sv], [n]
     rowconst = 0
@@ -180,7 +194,7 @@ def _solve(kind, coefs, F, S, dims, iParams):
                        sweeps_per_launch=int(iParams.get('sweeps_per_launch', 0)),
                        check_every=int(iParams.get('check_every', 0)), rowconst_mask=rowconst,
                        host_chunk=int(iParams.get('host_chunk', 0)),
-                       devices=_device_list(iParams, nbatch))
+                       devices=_device_list(iParams, nbatch), prep=prep)
     st = _lib.strides_arg(strides)
     ptrs = [_lib.hptr(a) for a in arrs]
     mx, tol = int(iParams['mxLoop']), float(iParams['tolerance'])
@@ -230,7 +244,10 @@ def _solve(kind, coefs, F, S, dims, iParams):
     # in place on S, as the reference (S.loc[sel].values are views of initS, apps.py:2159)
     inv = np.argsort(perm)
     out = np.transpose(Sv.reshape(tuple(bshape) + core_shape), inv)
-    if S.values.dtype == np.float64 and S.values.flags.writeable:
+    if prep is not None:                    # the solution was born on the device: no copy into an initS
+        S = F.like(out if out.flags.c_contiguous else np.ascontiguousarray(out))
+        iParams['_demasked'] = True
+    elif S.values.dtype == np.float64 and S.values.flags.writeable:
         S.values[...] = out
     else:
         S.values = np.ascontiguousarray(out)

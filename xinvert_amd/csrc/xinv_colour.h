@@ -604,6 +604,33 @@ __global__ __launch_bounds__(256) void k_expand_rows(const double *in, double *o
     for (int64_t i = threadIdx.x & 63; i < xc; i += 64) o[i] = v;
 }
 
+// ---- front-end passes on the device (xinv_options.prep_flags) --------------------------------
+// The forcing as the caller holds it -> the forcing the kernels read: masked points (NaN, or equal
+// to the caller's undefined value) become `undef_tmp`, defined ones are multiplied by a per-row
+// factor (cos(lat)) -- reference apps.__mask_FS (apps.py:2112-2159) followed by the builders'
+// `F * cos(lat)` and re-mask (apps.py:1409-1411, 2036-2038).  One pass at HBM rate instead of
+// four numpy passes over the host array.
+__global__ __launch_bounds__(256) void k_prep_forcing(double *F, int64_t n, int64_t yc, int64_t xc,
+                                                      const double *rowscale, int mask_nan,
+                                                      double undef_in, double undef_tmp)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = F[i];
+        const bool masked = (mask_nan ? isnan(v) : (v == undef_in)) || (v == undef_tmp);
+        double w = v;
+        if (rowscale) w = v * rowscale[(i / xc) % yc];
+        F[i] = masked ? undef_tmp : w;
+    }
+}
+
+// output de-mask (apps.py:1389-1392): S = `value` where the forcing is masked
+__global__ __launch_bounds__(256) void k_demask(double *S, const double *F, int64_t n, double undef_tmp,
+                                                double value)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (F[i] == undef_tmp) S[i] = value;
+}
+
 __global__ void k_ctl_init(XinvCtl *ctl, int64_t nbatch)
 {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -783,16 +783,38 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
                           : hipMemcpyAsync((void *)(host + m * hstride), dev + m * n, (size_t)n * sizeof(double), kind, s));
         return XINV_OK;
     };
+    // front-end passes on the device (xinv_options.prep_flags): the forcing is the last array
+    const int fq = p.ncoef - 1;
+    const bool do_prep = (opt.prep_flags & (XINV_PREP_MASK_NAN | XINV_PREP_MASK_VALUE)) != 0;
+    const double *d_rowscale = nullptr;
+    if (do_prep && (opt.prep_flags & XINV_PREP_ROWSCALE)) {
+        if (!opt.prep_rowscale) return fail_arg("XINV_PREP_ROWSCALE without prep_rowscale");
+        double *dr; int64_t dummy;
+        rc = upload(pool, pin, sup, opt.prep_rowscale, 1, 0, p.yc, &dr, &dummy);
+        if (rc) return rc;
+        d_rowscale = dr;
+    }
+    auto prep_forcing = [&](double *dF, int64_t nelem) {
+        const unsigned nblk = (unsigned)std::min<int64_t>(4096, (nelem + 255) / 256);
+        hipLaunchKernelGGL(k_prep_forcing, dim3(nblk), dim3(256), 0, sup, dF, nelem, p.yc, p.xc, d_rowscale,
+                           (opt.prep_flags & XINV_PREP_MASK_NAN) ? 1 : 0, opt.prep_undef, p.sc_.undef);
+    };
+    if (do_prep && !per_member[fq]) prep_forcing(const_cast<double *>(d.c[fq]), n);      // one shared forcing
     // ---- every chunk's upload, queued now ---------------------------------------------------
     std::vector<hipEvent_t> e_chunk((size_t)nchunk);
     for (int64_t c = 0; c < nchunk; c++) {
         const int64_t m0 = c * mc, nm = std::min(mc, p.nbatch - m0);
-        rc = copy_members(d.S, p.S, hsS, m0, nm, true, sup);
-        if (rc) return rc;
+        if (opt.prep_flags & XINV_PREP_S_ZERO)
+            HIPCHK(hipMemsetAsync(d.S + m0 * n, 0, (size_t)nm * n * sizeof(double), sup));
+        else {
+            rc = copy_members(d.S, p.S, hsS, m0, nm, true, sup);
+            if (rc) return rc;
+        }
         for (int q = 0; q < p.ncoef; q++)
             if (per_member[q]) {
                 rc = copy_members(const_cast<double *>(d.c[q]), p.c[q], p.sc[q], m0, nm, true, sup);
                 if (rc) return rc;
+                if (do_prep && q == fq) prep_forcing(const_cast<double *>(d.c[q]) + m0 * n, nm * n);
             }
         if ((rc = ev.make(&e_chunk[(size_t)c], false))) return rc;
         HIPCHK(hipEventRecord(e_chunk[(size_t)c], sup));
@@ -821,6 +843,14 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
             acc.sweep_ms += t_stats.sweep_ms;
         }
         // solve_dev has returned: the chunk's S is final on the device
+        if (opt.prep_flags & XINV_PREP_DEMASK) {
+            for (int64_t m = 0; m < nm; m++) {
+                const double *dF = d.c[fq] + (per_member[fq] ? (m0 + m) * n : 0);
+                hipLaunchKernelGGL(k_demask, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, scp,
+                                   d.S + (m0 + m) * n, dF, n, p.sc_.undef, opt.demask_value);
+            }
+            HIPCHK(hipStreamSynchronize(scp));
+        }
         if (c == 0) { if ((rc = ev.make(&e_dn0, true))) return rc; HIPCHK(hipEventRecord(e_dn0, sdn)); }
         rc = copy_members(d.S, p.S, hsS, m0, nm, false, sdn);
         if (rc) return rc;

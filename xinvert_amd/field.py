@@ -45,6 +45,53 @@ class Field:
         return 'Field(name=%r, dims=%r, shape=%r)' % (self.name, self.dims, self.shape)
 
 
+class LazyForcing(Field):
+    """The forcing the kernels read, described instead of materialised:
+
+        values = where(masked(raw), undef_tmp, raw * scale[along dim])
+
+    with masked(raw) = isnan(raw) (the caller's undef is NaN) or raw == undef.  The host-pointer
+    entry points evaluate this on the device (xinv_options.prep_flags: one pass at HBM rate instead
+    of the reference's numpy passes, apps.py:2112-2159, 1409-1411); `.values` evaluates it with
+    numpy on demand, for every consumer that is not the solver."""
+
+    def __init__(self, raw, dims, coords, undef_in, undef_tmp, scale=None, scale_dim=None, name=None):
+        self.raw = np.asarray(raw)
+        self.dims = tuple(dims)
+        self.coords = {d: np.asarray(coords[d]) for d in self.dims}
+        self.name = name
+        self.undef_in, self.undef_tmp = undef_in, undef_tmp
+        self.scale = None if scale is None else np.asarray(scale, dtype=np.float64)
+        self.scale_dim = scale_dim
+        self._values = None
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    @property
+    def values(self):
+        if self._values is None:
+            r = np.asarray(self.raw, dtype=np.float64)
+            masked = (np.isnan(r) if np.isnan(self.undef_in) else (r == self.undef_in)) | (r == self.undef_tmp)
+            v = r if self.scale is None else r * along(self.scale, self, self.scale_dim)
+            self._values = np.where(masked, self.undef_tmp, v)
+        return self._values
+
+    @values.setter
+    def values(self, v):
+        self._values = np.asarray(v)
+
+    def scaled(self, vec, dim):
+        """The same forcing multiplied along `dim` by `vec` (and re-masked)."""
+        if self.scale is not None:
+            raise ValueError('a lazy forcing takes one scale')
+        return LazyForcing(self.raw, self.dims, self.coords, self.undef_in, self.undef_tmp, vec, dim, self.name)
+
+    def like(self, values, name=None):
+        return Field(values, self.dims, self.coords, name=name if name is not None else self.name)
+
+
 def along(vec, field, dim):
     """Broadcast a 1-D per-`dim` vector against `field` (xarray's alignment by dim name)."""
     shape = [1] * len(field.dims)
