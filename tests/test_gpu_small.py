@@ -130,3 +130,55 @@ def test_small_solver_large_batch_on_device_pointers():
     for m in (0, 255, 256, 599):
         So, flo = run_oracle(qs[m], 39, 0.0, C2)
         assert np.array_equal(S[m], So) and fl[m][2] == 39
+
+
+# ------------------------------------------------------------------ 3-D: two sweeps per pass
+def xuniform3d(zc, yc, xc, BCx, msk, seed):
+    from util import rand3d
+    p = rand3d(zc, yc, xc, 'fixed', BCx, msk, seed=seed)
+    for q in range(3):
+        c = p['coefs'][q]
+        c[:] = c[:, :, :1]                             # constant along x (lat-lon omega coefficients)
+    return p
+
+
+@pytest.mark.parametrize('shape', [(9, 20, 66), (12, 33, 130), (50, 40, 250), (7, 17, 24), (64, 18, 120), (21, 50, 241)])
+@pytest.mark.parametrize('BCx', ['fixed', 'periodic'])
+def test_fused3d_two_sweeps_per_pass_vs_oracle(shape, BCx):
+    """k_fused3d2 (x-uniform coefficients, on request: sweeps_per_launch = 2): passes of two sweeps + a
+    one-sweep tail; must equal the oracle's coloured ordering and the one-sweep-per-pass kernel bit for bit."""
+    zc, yc, xc = shape
+    if BCx == 'periodic' and xc % 2:
+        pytest.skip('odd xc periodic: seam colours, colour path')
+    for msk in (0, 1):
+        p = xuniform3d(zc, yc, xc, BCx, msk, seed=zc + yc + xc + msk)
+        for nsw in (7, 8):                              # odd: 3 passes + tail; even: 4 passes
+            So, flo = run_oracle(p, nsw - 1, 0.0, C2)
+            S, fl, st = util.run_hip_batched([p], nsw - 1, 0.0, sweeps_per_launch=2)
+            assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == 2 and st['xuniform_mask'] == 7, st
+            assert np.array_equal(S[0], So), '%d points differ' % (S[0] != So).sum()
+            assert fl[0][2] == flo[2] and abs(fl[0][1] - flo[1]) <= 1e-12
+        S1, f1, s1 = util.run_hip_batched([p], 7, 0.0, sweeps_per_launch=1)
+        assert s1['sweeps_per_launch'] == 1 and np.array_equal(S1, S)
+
+
+def test_fused3d_two_sweeps_tolerance_stop_inside_a_pass():
+    """Members stop at different sweeps, some on the first sweep of a two-sweep pass (redo from the
+    pass's source buffer)."""
+    ps = [xuniform3d(10, 24, 64, 'periodic', 1, seed=40 + s) for s in range(6)]
+    S, fl, st = util.run_hip_batched(ps, 300, 2e-3, sweeps_per_launch=2)
+    assert st['sweeps_per_launch'] == 2
+    par = set()
+    for m, p in enumerate(ps):
+        So, flo = run_oracle(p, 300, 2e-3, C2)
+        assert np.array_equal(S[m], So) and fl[m][2] == flo[2], (m, fl[m], flo)
+        par.add(int(flo[2]) % 2)
+    assert par == {0, 1}
+
+
+def test_fused3d_two_sweeps_k_chunks_tall_volume():
+    """A tall, narrow volume is split into k chunks (four recomputed halo planes a side)."""
+    p = xuniform3d(200, 20, 100, 'fixed', 1, seed=3)
+    So, flo = run_oracle(p, 5, 0.0, C2)
+    S, fl, st = util.run_hip_batched([p], 5, 0.0, sweeps_per_launch=2)
+    assert st['sweeps_per_launch'] == 2 and np.array_equal(S[0], So) and fl[0][2] == flo[2]

@@ -23,6 +23,7 @@ XINV_HIDDEN int xinv_launch_fused9(bool gen, int K, bool al, bool ext, dim3 grid
                                    const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 grid, hipStream_t st,
                                     const Fused3Args &a);
+XINV_HIDDEN int xinv_launch_fused3d2(int NW, bool al, dim3 grid, hipStream_t st, const Fused3Args &a);
 XINV_HIDDEN int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st,
                                      const Fused3GArgs &a);
 XINV_HIDDEN int xinv_launch_fusedbih(bool per, bool zbe, dim3 grid, hipStream_t st,

@@ -367,6 +367,34 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             pl.nkc = best;
             pl.KC = (int)(cdiv(cdiv(p.zc, best), 4) * 4);
         }
+        // Two sweeps per pass (k_fused3d2: x-uniform coefficients, no 'extend'): the one-sweep kernel is
+        // bound by the fabric's bandwidth, so halving the bytes per sweep pays.  Its own tiling: twelve
+        // wavefronts x two rows = 24 rows per cross-section, 16 owned; 120 owned columns; four halo planes.
+        pl.K2 = false;
+        // ON REQUEST ONLY (sweeps_per_launch = 2): measured at 15 volumes of 50 x 360 x 720 it runs at
+        // 1.45e11 point-sweeps/s with eight wavefronts (no spills, half the rows halo) and 0.7e11 with
+        // twelve (170-register budget: spills) against 1.9e11 for the one-sweep kernel -- the deeper
+        // pipeline is bound by its LDS round trips, not by bytes.
+        if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND && opt.sweeps_per_launch == 2 &&
+            opt.rows_per_tile == 0 && p.stop.mxLoop >= 1) {
+            pl.K2 = true;
+            pl.K = 2;
+            pl.nw2 = 8;
+            if (const char *e = getenv("XINV_3D2_NW")) pl.nw2 = (atoi(e) == 12) ? 12 : 8;
+            pl.nsg2 = (int)cdiv(p.xc, 120);
+            pl.nrb2 = (int)cdiv(p.yc, 2 * pl.nw2 - 8);
+            const int64_t wg1 = (int64_t)pl.nsg2 * pl.nrb2 * p.nbatch;
+            int best = 1; double best_cost = 1e300;
+            for (int nk = 1; nk <= 16; nk++) {
+                const int64_t KC = (int64_t)cdiv(cdiv(p.zc, nk), 4) * 4;
+                if (nk > 1 && (KC < 16 || (int64_t)(nk - 1) * KC >= p.zc)) break;
+                const int64_t rounds = cdiv(wg1 * nk, 256);
+                const double cost = (double)rounds * (double)(KC + (nk > 1 ? 14 : 4));
+                if (cost < best_cost * 0.97) { best_cost = cost; best = nk; }
+            }
+            pl.nkc2 = best;
+            pl.KC2 = (int)(cdiv(cdiv(p.zc, best), 4) * 4);
+        }
     } else
     if (pl.path == XINV_PATH_FUSED) {
         // which coefficient streams are constant along x (lat-lon grids: functions of latitude)
@@ -469,7 +497,10 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     }
     size_t pbytes;
     if (pl.path == XINV_PATH_FUSED)
-        pbytes = (size_t)p.nbatch * XINV_KMAX * (is3d(p.kind) ? (size_t)pl.nsg * pl.nrb * std::max(1, pl.nkc) : (size_t)pl.nsg) *
+        pbytes = (size_t)p.nbatch * XINV_KMAX *
+                 (is3d(p.kind) ? std::max((size_t)pl.nsg * pl.nrb * std::max(1, pl.nkc),
+                                          pl.K2 ? (size_t)pl.nsg2 * pl.nrb2 * std::max(1, pl.nkc2) : (size_t)0)
+                               : (size_t)pl.nsg) *
                  (3 * sizeof(unsigned long long));      // three tagged words per partial
     else
         pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
@@ -523,7 +554,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
                : (p.kind == KIND_GEN3D)
                    ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
                : (p.kind == KIND_STD3D)
-                   ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
+                   ? launch_fused3d(p, pl, k, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
                : pl.nine
                    ? launch_fused9(p, pl, k, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
                    : launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0);
@@ -637,7 +668,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
                          : (p.kind == KIND_GEN3D)
                              ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
                          : (p.kind == KIND_STD3D)
-                             ? launch_fused3d(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
+                             ? launch_fused3d(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
                          : pl.nine
                              ? launch_fused9(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
                              : launch_fused(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1);

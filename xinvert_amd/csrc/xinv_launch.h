@@ -10,6 +10,8 @@ struct Plan {
     int path, base, seam, ncol;
     int K, RY, nsg, nrb;     // nsg: 2-D = workgroups per member (partials sizing); 3-D = x strips
     int nkc, KC;             // 3-D: k chunks and planes per chunk
+    bool K2;                 // 3-D standard form: passes of two sweeps (k_fused3d2) with the tiling below
+    int nsg2, nrb2, nkc2, KC2, nw2;
     bool bih_zbe;            // biharmonic one-pass kernel: B and E identically zero (terms left out)
     bool aligned;
     unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
@@ -144,7 +146,7 @@ static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *
     return XINV_OK;
 }
 
-static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, double *dst,
+static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
                           Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
                           int no_ctl)
 {
@@ -154,6 +156,23 @@ static int launch_fused3d(const Problem &p, const Plan &pl, const double *src, d
     for (int q = 0; q < 4; q++) { a.c[q] = p.c[q]; a.sc[q] = p.sc[q]; }
     a.zc = p.zc; a.yc = p.yc; a.xc = p.xc;
     a.per = (p.BCx == XINV_BC_PERIODIC);
+    if (K == 2) {                                        // two sweeps per pass: its own tiling
+        if (!pl.K2) return fail_arg("internal: two-sweep 3-D pass without its plan");
+        a.nstrip = pl.nsg2; a.njb = pl.nrb2;
+        a.nkc = std::max(1, pl.nkc2); a.KC = pl.KC2;
+        a.force = force; a.no_ctl = no_ctl;
+        a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
+        a.psum = (unsigned long long *)ws->partials;
+        const size_t NB2 = (size_t)a.nstrip * a.njb * a.nkc;
+        for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
+            const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
+            a.member0 = member0 + m0;
+            if (xinv_launch_fused3d2(pl.nw2, pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a))
+                return fail_arg("internal: no two-sweep 3-D kernel variant");
+        }
+        HIPCHK(hipGetLastError());
+        return XINV_OK;
+    }
     a.nstrip = pl.nsg; a.njb = pl.nrb;
     a.nkc = std::max(1, pl.nkc); a.KC = pl.KC;
     a.force = force; a.no_ctl = no_ctl; a.member0 = member0;

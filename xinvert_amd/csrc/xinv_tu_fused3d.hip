@@ -1,6 +1,7 @@
 // xinv_tu_fused3d.hip -- instantiations of k_fused3d (standard 3-D form) and k_fused3dg (general 3-D
 // form with x-uniform coefficients).
 #include "xinv_dispatch.h"
+#include "xinv_fused3d2.h"
 
 // ---- 3-D fused launch ------------------------------------------------------------------------
 template <int NW>
@@ -44,5 +45,18 @@ int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st, c
     if (NW == 8) launch_fused3dg_nw<8>(al, ext, grid, st, a);
     else if (NW == 16) launch_fused3dg_nw<16>(al, ext, grid, st, a);
     else launch_fused3dg_nw<12>(al, ext, grid, st, a);
+    return 0;
+}
+
+// two sweeps per pass, x-uniform coefficients, no 'extend' (xinv_fused3d2.h)
+int xinv_launch_fused3d2(int NW, bool al, dim3 grid, hipStream_t st, const Fused3Args &a)
+{
+    if (NW == 12) {
+        if (al) hipLaunchKernelGGL((k_fused3d2<12, true>), grid, dim3(12 * 64, 1, 1), 0, st, a);
+        else    hipLaunchKernelGGL((k_fused3d2<12, false>), grid, dim3(12 * 64, 1, 1), 0, st, a);
+    } else if (NW == 8) {
+        if (al) hipLaunchKernelGGL((k_fused3d2<8, true>), grid, dim3(8 * 64, 1, 1), 0, st, a);
+        else    hipLaunchKernelGGL((k_fused3d2<8, false>), grid, dim3(8 * 64, 1, 1), 0, st, a);
+    } else return 1;
     return 0;
 }
