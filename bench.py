@@ -48,12 +48,14 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES = {'std2d': 48, 'gen2d': 72, 'std3d': 48}
 # fp64 operations of one point update as the kernels execute it (the relaxation factor and
-# F*delxSqr are hoisted per row / per launch): std2d 4 sub + 4 mul + 2 sub + mul + add + sub + mul + add
-UPD_FLOPS = {'std2d': 16, 'gen2d': 24, 'std3d': 23}
+# F*delxSqr are hoisted per row / per launch): std2d 4 sub + 4 mul + 2 sub + mul + add + sub + mul + add = 16;
+# gen2d (hoisted) 25; std3d (hoisted, f*delxSqr per point) 21
+UPD_FLOPS = {'std2d': 16, 'gen2d': 25, 'std3d': 21}
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8.0 TB/s spec
 # fp64 vector ALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T operations/s (78.6 TFLOP/s
 # datasheet figure counts an FMA as two; tools/fp64_peak.hip measures both on the box)
 FP64_VALU_PEAK_TFLOPS = 39.3
+FP64_VALU_MEASURED_TFLOPS = 34.0                             # profiles/r02_fp64_peak.txt (mul+add chains, no FMA)
 FP64_FMA_SPEC_TFLOPS = 78.6
 
 
@@ -275,6 +277,7 @@ def main():
                              'contraction is off by the bit-exactness contract; datasheet FMA peak %.1f'
                              % FP64_FMA_SPEC_TFLOPS,
                 'frac_of_fma_spec': achieved_tf / FP64_FMA_SPEC_TFLOPS,
+                'frac_of_measured_peak': achieved_tf / FP64_VALU_MEASURED_TFLOPS,
                 'useful_flops_per_point_update': UPD_FLOPS[kind],
                 'kernel': ('k_fused2d<FusedStd2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask'])) if kind == 'std2d'
                           else ('k_fused2d<FusedGen2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask'])) if kind == 'gen2d'
@@ -287,6 +290,17 @@ def main():
             if em:
                 roof['executed_over_useful'] = em
                 roof['frac_executed'] = roof['frac'] * em
+        if kind == 'std3d':
+            # the 3-D kernels are bound by what the fabric delivers, not by the VALU: S read + S write +
+            # the forcing + every coefficient array that is not a per-row scalar, 8 B each
+            nstream = 3 + (3 - bin(s['xuniform_mask'] & 7).count('1'))
+            vb = 8.0 * nstream * upd_per_launch
+            roof.update({'bound': 'hbm', 'achieved': vb / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': vb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'bytes_note': 'bytes the kernel variant must move per point-sweep: %d streams x 8 B '
+                                       '(x-uniform coefficient arrays are per-row scalars); SURVEY 8(d) algorithmic '
+                                       'figure kept as alg_equiv_GBps' % nstream,
+                         'valu_TFLOPs': achieved_tf, 'valu_frac': achieved_tf / FP64_VALU_PEAK_TFLOPS})
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile) and a.config == 'c2' and (a.ny, a.nx) == (1800, 3600) and nb == 1:

@@ -129,36 +129,17 @@ static int solve_small(const Problem &p, Plan &pl, Workspace *ws, double *flags,
     return XINV_OK;
 }
 
-// ------------------------------------------------------------------ the solve (device ptrs)
-static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st)
+// ------------------------------------------------------------------ planning
+// solve_dev = plan (colouring -> path -> tiling of the chosen kernel family) -> sweep loop -> finalise.
+// Every plan_* step fills `Plan`; the once-per-solve detection passes (is B zero? which arrays are
+// constant along x? which tiles are fully masked?) run on the caller's stream and are synchronous.
+
+// red-black when the cross coefficient vanishes, else 4 colours; 9 for the biharmonic form; +seam colours
+static int plan_colouring(const Problem &p, Workspace *ws, hipStream_t st, Plan &pl)
 {
-    int rc = validate(p, flags);
-    if (rc) return rc;
-    xinv_options opt;
-    fill_options(opt, opt_in);
-
-    DeviceGuard dg;
-    HIPCHK(dg.select(opt.device));
-    int device = 0;
-    HIPCHK(hipGetDevice(&device));
-    Workspace *ws = get_ws(device);
-    std::lock_guard<std::recursive_mutex> solve_lock(ws->busy);
-    if (!ws->ev0[0])
-        for (int q = 0; q < 2; q++) {
-            HIPCHK(hipEventCreate(&ws->ev0[q])); HIPCHK(hipEventCreate(&ws->ev1[q]));
-            HIPCHK(hipEventCreateWithFlags(&ws->evc[q], hipEventDisableTiming));
-        }
-    if (!ws->dflag) {
-        HIPCHK(hipMalloc((void **)&ws->dflag, sizeof(int)));
-        HIPCHK(hipHostMalloc((void **)&ws->hflag, sizeof(int), hipHostMallocDefault));
-    }
-
     const int64_t n = p.zc * p.yc * p.xc;
-    memset(&t_stats, 0, sizeof t_stats);
-
-    // ---- colouring: red-black when the cross coefficient vanishes, else 4 colours ----------
-    Plan pl;
-    memset(&pl, 0, sizeof pl);
+    int rc = XINV_OK;
+    (void)n; (void)rc;
     if (is3d(p.kind)) {
         pl.base = 2;
     } else if (p.kind == KIND_BIH2D) {
@@ -192,64 +173,15 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         pl.ncol = pl.base + (pl.seam ? 2 : 0);
     }
 
-    // ---- small slices: the register-resident solver, when the form and the size allow it --------
-    // On request only (path = XINV_PATH_SMALL, or XINV_SMALL_AUTO=1 in the environment): as measured
-    // this round it does not yet beat the streaming kernels (DESIGN.md section 4.7).
-    static const bool small_auto = [] { const char *e = getenv("XINV_SMALL_AUTO"); return e && atoi(e) != 0; }();
-    if ((opt.path == XINV_PATH_AUTO && small_auto) || opt.path == XINV_PATH_SMALL) {
-        int sNW = 0, sRW = 0, sNSEG = 0;
-        bool ok = pl.base == 2 && !pl.seam && !(opt.flags & XINV_FLAG_NO_XUNIFORM) && small_variant(p, &sNW, &sRW, &sNSEG);
-        if (ok) {
-            const int cmapS[2] = {0, 2}, cmapG[5] = {0, 2, 3, 4, 5};
-            const int ns = (p.kind == KIND_STD2D) ? 2 : 5;
-            const double *arr[5]; int64_t strd[5];
-            for (int q = 0; q < ns; q++) {
-                const int sidx = (p.kind == KIND_STD2D) ? cmapS[q] : cmapG[q];
-                arr[q] = p.c[sidx]; strd[q] = p.sc[sidx];
-            }
-            unsigned um = 0;
-            rc = detect_xuniform(ws, st, arr, strd, ns, p.nbatch, p.yc, p.xc, &um);
-            if (rc) return rc;
-            ok = (um == ((1u << ns) - 1u));
-            pl.um = pl.umask = um;
-        }
-        if (ok) return solve_small(p, pl, ws, flags, opt, st, sNW, sRW, sNSEG);
-        if (opt.path == XINV_PATH_SMALL)
-            return fail_arg("the small-slice solver needs the 2-D standard / general form with B == 0, yc <= 96, xc <= 384 and every coefficient array constant along x");
-    }
+    return XINV_OK;
+}
 
-    // ---- path ------------------------------------------------------------------------------
-    const bool fused5_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
-    const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
-                           (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
-    // biharmonic: the one-pass kernel needs A..I as per-row scalars (and xc % 3 == 0 when periodic)
-    bool fusedbih_ok = false;
-    if (p.kind == KIND_BIH2D) {
-        pl.umask = 0;
-        if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-            rc = detect_xuniform(ws, st, p.c, p.sc, 10, p.nbatch, p.yc, p.xc, &pl.umask);
-            if (rc) return rc;
-        }
-        pl.um = pl.umask;
-        fusedbih_ok = ((pl.umask & 0x1ffu) == 0x1ffu) && (p.BCx != XINV_BC_PERIODIC || p.xc % 3 == 0);
-    }
-    // general 3-D: the fused kernel exists for x-uniform coefficients only (every 3DOcean array)
-    bool fused3g_ok = false;
-    if (p.kind == KIND_GEN3D && !pl.seam && opt.path != XINV_PATH_COLOUR && !(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-        rc = detect_xuniform(ws, st, p.c, p.sc, 7, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
-        if (rc) return rc;
-        fused3g_ok = (pl.umask == 0x7fu);
-    }
-    const bool fused_ok = fused5_ok || fused9_ok || fused3g_ok || fusedbih_ok;
-    pl.path = XINV_PATH_COLOUR;
-    pl.nine = false;
-    if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
-    if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("no fused kernel for this form (odd-xc periodic seam, 9-point test form, biharmonic or general 3-D with coefficients that vary along x)");
-    if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
-        return fail_arg("internal: 9-point form without B");
-
-    if (pl.path == XINV_PATH_FUSED && p.kind == KIND_BIH2D) {
+// biharmonic one-pass kernel: row blocks of RB rows (multiple of 3) x strips, four wave-tiles per workgroup
+static int plan_fusedbih(const Problem &p, const xinv_options &opt, Workspace *ws, hipStream_t st, Plan &pl)
+{
+    const int64_t n = p.zc * p.yc * p.xc;
+    int rc = XINV_OK;
+    (void)n; (void)rc;
         // biharmonic: one pass per sweep; row blocks of RB rows (multiple of 3) x 180-column strips,
         // four consecutive wave-tiles per workgroup; RB from the (workgroups per CU) x (steps) model
         pl.K = 1;
@@ -289,8 +221,15 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             rc = plan_tile_skip(p, pl, ws, st, opt, bestRB, XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC));
             if (rc) return rc;
         }
-    } else
-    if (pl.path == XINV_PATH_FUSED && pl.nine) {
+    return XINV_OK;
+}
+
+// 9-point forms: 4-colour fused kernel, all coefficient arrays streamed
+static int plan_fused9(const Problem &p, const xinv_options &opt, Workspace *ws, hipStream_t st, Plan &pl)
+{
+    const int64_t n = p.zc * p.yc * p.xc;
+    int rc = XINV_OK;
+    (void)n; (void)rc;
         // 9-point forms: 4-colour fused kernel, all coefficient arrays streamed
         pl.um = pl.umask = 0;
         {
@@ -328,7 +267,15 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             rc = plan_tile_skip(p, pl, ws, st, opt, 0, 128 - 8 * pl.K, occ9);
             if (rc) return rc;
         }
-    } else if (pl.path == XINV_PATH_FUSED && is3d(p.kind)) {
+    return XINV_OK;
+}
+
+// 3-D forms: cross-sections of NW rows marched through the planes, k chunks
+static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws, hipStream_t st, Plan &pl)
+{
+    const int64_t n = p.zc * p.yc * p.xc;
+    int rc = XINV_OK;
+    (void)n; (void)rc;
         // 3-D: one sweep per launch; cross-section of NW rows per workgroup (rows_per_tile = NW)
         pl.K = 1;
         pl.RY = (opt.rows_per_tile == 8 || opt.rows_per_tile == 12 || opt.rows_per_tile == 16)
@@ -395,8 +342,15 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             pl.nkc2 = best;
             pl.KC2 = (int)(cdiv(cdiv(p.zc, best), 4) * 4);
         }
-    } else
-    if (pl.path == XINV_PATH_FUSED) {
+    return XINV_OK;
+}
+
+// 2-D 5-point forms: x-uniform streams, sweeps per pass, rows per tile, masked-tile skipping
+static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws, hipStream_t st, Plan &pl)
+{
+    const int64_t n = p.zc * p.yc * p.xc;
+    int rc = XINV_OK;
+    (void)n; (void)rc;
         // which coefficient streams are constant along x (lat-lon grids: functions of latitude)
         {
             const int cmapS[3] = {0, 2, 3}, cmapG[6] = {0, 2, 3, 4, 5, 6}, cmapT[4] = {0, 3, 4, 5};
@@ -485,8 +439,84 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             rc = plan_tile_skip(p, pl, ws, st, opt);
             if (rc) return rc;
         }
-    }
+    return XINV_OK;
+}
 
+// which path, then the tiling of its kernel family
+static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, hipStream_t st, Plan &pl)
+{
+    const int64_t n = p.zc * p.yc * p.xc;
+    int rc = XINV_OK;
+    (void)n; (void)rc;
+    // ---- path ------------------------------------------------------------------------------
+    const bool fused5_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
+    const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
+                           (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
+    // biharmonic: the one-pass kernel needs A..I as per-row scalars (and xc % 3 == 0 when periodic)
+    bool fusedbih_ok = false;
+    if (p.kind == KIND_BIH2D) {
+        pl.umask = 0;
+        if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
+            rc = detect_xuniform(ws, st, p.c, p.sc, 10, p.nbatch, p.yc, p.xc, &pl.umask);
+            if (rc) return rc;
+        }
+        pl.um = pl.umask;
+        fusedbih_ok = ((pl.umask & 0x1ffu) == 0x1ffu) && (p.BCx != XINV_BC_PERIODIC || p.xc % 3 == 0);
+    }
+    // general 3-D: the fused kernel exists for x-uniform coefficients only (every 3DOcean array)
+    bool fused3g_ok = false;
+    if (p.kind == KIND_GEN3D && !pl.seam && opt.path != XINV_PATH_COLOUR && !(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
+        rc = detect_xuniform(ws, st, p.c, p.sc, 7, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
+        if (rc) return rc;
+        fused3g_ok = (pl.umask == 0x7fu);
+    }
+    const bool fused_ok = fused5_ok || fused9_ok || fused3g_ok || fusedbih_ok;
+    pl.path = XINV_PATH_COLOUR;
+    pl.nine = false;
+    if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
+    if (opt.path == XINV_PATH_FUSED && !fused_ok)
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam, 9-point test form, biharmonic or general 3-D with coefficients that vary along x)");
+    if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
+        return fail_arg("internal: 9-point form without B");
+
+    if (pl.path != XINV_PATH_FUSED) return XINV_OK;
+    if (p.kind == KIND_BIH2D) return plan_fusedbih(p, opt, ws, st, pl);
+    if (pl.nine) return plan_fused9(p, opt, ws, st, pl);
+    if (is3d(p.kind)) return plan_fused3d(p, opt, ws, st, pl);
+    return plan_fused5(p, opt, ws, st, pl);
+}
+
+// ------------------------------------------------------------------ the sweep loop
+// What the loop leaves for finalise(): where each launch started, the final control blocks.
+struct SweepRun {
+    double *S2 = nullptr;
+    double *buf[2] = {nullptr, nullptr};
+    std::vector<int64_t> bound;                          // bound[i] = sweeps before launch i (fused path)
+    int64_t launched = 0, nlaunch = 0;
+    double ms_total = 0.0;
+    const XinvCtl *hc = nullptr;                         // the slot holding the final control blocks
+    int Kf = 1;
+};
+
+// one sweep launch of the planned kernel (fused: k sweeps from src into dst; colour path: one sweep in place)
+static int launch_planned(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t s, int k,
+                          const double *src, double *dst, int64_t member0, int64_t nmem, int force, int no_ctl)
+{
+    if (pl.path != XINV_PATH_FUSED) return launch_colour_sweep(p, pl, ws, s);
+    return (p.kind == KIND_BIH2D)   ? launch_fusedbih(p, pl, src, dst, ws, s, member0, nmem, force, no_ctl)
+         : (p.kind == KIND_GEN3D)   ? launch_fused3dg(p, pl, src, dst, ws, s, member0, nmem, force, no_ctl)
+         : (p.kind == KIND_STD3D)   ? launch_fused3d(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl)
+         : pl.nine                  ? launch_fused9(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl)
+                                    : launch_fused(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl);
+}
+
+// workspace, then chunks of launches with pipelined polling of the device-side stop flags
+static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt, Workspace *ws, hipStream_t st,
+                      SweepRun &R)
+{
+    const int64_t n = p.zc * p.yc * p.xc;
+    int rc = XINV_OK;
+    (void)n; (void)rc;
     // ---- workspace ---------------------------------------------------------------------------
     rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)p.nbatch * sizeof(XinvCtl));
     if (rc) return rc;
@@ -508,7 +538,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (rc) return rc;
     if (pl.path == XINV_PATH_FUSED)                              // tagged partials: no stale sequence numbers
         HIPCHK(hipMemsetAsync(ws->partials, 0, pbytes, st));
-    double *S2 = nullptr;
+    double *&S2 = R.S2;
     if (pl.path == XINV_PATH_COLOUR && p.kind == KIND_BIH2D) {       // side buffer of the row-class kernel
         rc = ensure_dev(&ws->S2, &ws->S2_cap, (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double));
         if (rc) return rc;
@@ -526,7 +556,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
 
     // ---- sweep loop ----------------------------------------------------------------------------
     const int64_t max_sweeps = p.stop.mxLoop + 1;       // numbas.py:410: loop >= mxLoop stops
-    const int Kf = (pl.path == XINV_PATH_FUSED) ? pl.K : 1;
+    const int Kf = R.Kf = (pl.path == XINV_PATH_FUSED) ? pl.K : 1;
     int check_every = opt.check_every;
     if (check_every <= 0) {
         // poll the device stop flags about every 2 ms of sweeping (fused kernels run at roughly
@@ -536,28 +566,19 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         const double est_us = std::max(4.0, (double)p.nbatch * (double)n * Kf / rate);
         check_every = (int)std::min(256.0, std::max(4.0, 2000.0 / est_us));
     }
-    double *buf[2] = { p.S, S2 };
-    std::vector<int64_t> bound;                          // bound[i] = sweeps before launch i
-    int64_t launched = 0;
+    R.buf[0] = p.S; R.buf[1] = S2;
+    double **buf = R.buf;
+    std::vector<int64_t> &bound = R.bound;
+    int64_t &launched = R.launched, &nlaunch = R.nlaunch;
+    double &ms_total = R.ms_total;
     bool all_done = false;
-    double ms_total = 0.0;
-    int64_t nlaunch = 0;
     // A chunk = `check_every` launches followed by an asynchronous copy of the control blocks.
     // Polling is pipelined: chunk c+1 is queued BEFORE the host waits for chunk c's copy, so the
     // GPU never idles on the host's reaction time; once every member has stopped, the launches
     // already queued are no-ops (each kernel returns on ctl.done).
     // one sweep launch (fused: K sweeps from buf[cur] into buf[cur^1]; colour path: one sweep in place)
     auto launch_one = [&](hipStream_t s, int cur, int k) -> int {
-        if (pl.path != XINV_PATH_FUSED) return launch_colour_sweep(p, pl, ws, s);
-        return (p.kind == KIND_BIH2D)
-                   ? launch_fusedbih(p, pl, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
-               : (p.kind == KIND_GEN3D)
-                   ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
-               : (p.kind == KIND_STD3D)
-                   ? launch_fused3d(p, pl, k, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
-               : pl.nine
-                   ? launch_fused9(p, pl, k, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0)
-                   : launch_fused(p, pl, k, buf[cur], buf[cur ^ 1], ws, s, 0, p.nbatch, 0, 0);
+        return launch_planned(p, pl, ws, s, k, buf[cur], buf[cur ^ 1], 0, p.nbatch, 0, 0);
     };
     // Small problems are bound by the host's launch rate (a 151x251 coloured sweep is six launches
     // of 2-3 us each): a full chunk is captured once into a hipGraph on an engine-owned stream and
@@ -622,7 +643,8 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         HIPCHK(hipEventRecord(ws->evc[slot], st));
         return XINV_OK;
     };
-    const XinvCtl *hc = ws->hctl;                        // the slot holding the final control blocks
+    const XinvCtl *&hc = R.hc;
+    hc = ws->hctl;
     rc = issue_chunk(0);
     if (rc) return rc;
     for (int c = 0;; c++) {
@@ -649,10 +671,21 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             return XINV_ERR_HIP;
         }
 
-    // ---- fused path: put each member's final state into S ------------------------------------
+    return XINV_OK;
+}
+
+// fused path: put each member's final state into S (redo of a pass the stop rule fired inside); flags, stats
+static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st, double *flags, SweepRun &R)
+{
+    const int64_t n = p.zc * p.yc * p.xc;
+    int rc = XINV_OK;
+    (void)n; (void)rc;
+    std::vector<int64_t> &bound = R.bound;
+    double **buf = R.buf;
+    const XinvCtl *hc = R.hc;
     int64_t sweeps_max = 0;
     if (pl.path == XINV_PATH_FUSED) {
-        bound.push_back(launched);
+        bound.push_back(R.launched);
         for (int64_t m = 0; m < p.nbatch; m++) {
             const int64_t sw = hc[m].sweeps;
             // launch i covers sweeps (bound[i], bound[i+1]]; find the one holding sweep `sw`
@@ -663,22 +696,14 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
             } else {                                     // stopped inside a K-sweep launch: redo
                 int cur = (int)(i & 1);
                 for (int64_t s = bound[i]; s < sw; s++) {
-                    rc = (p.kind == KIND_BIH2D)
-                             ? launch_fusedbih(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
-                         : (p.kind == KIND_GEN3D)
-                             ? launch_fused3dg(p, pl, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
-                         : (p.kind == KIND_STD3D)
-                             ? launch_fused3d(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
-                         : pl.nine
-                             ? launch_fused9(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1)
-                             : launch_fused(p, pl, 1, buf[cur], buf[cur ^ 1], ws, st, m, 1, 1, 1);
+                    rc = launch_planned(p, pl, ws, st, 1, buf[cur], buf[cur ^ 1], m, 1, 1, 1);
                     if (rc) return rc;
                     cur ^= 1;
                 }
                 where = cur;
             }
             if (where == 1)
-                HIPCHK(hipMemcpyAsync(p.S + m * p.sS, S2 + m * p.sS, (size_t)n * sizeof(double),
+                HIPCHK(hipMemcpyAsync(p.S + m * p.sS, R.S2 + m * p.sS, (size_t)n * sizeof(double),
                                       hipMemcpyDeviceToDevice, st));
         }
         HIPCHK(hipStreamSynchronize(st));
@@ -691,14 +716,77 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     }
     t_stats.path = pl.path;
     t_stats.colours = pl.ncol;
-    t_stats.sweeps_per_launch = Kf;
+    t_stats.sweeps_per_launch = R.Kf;
     t_stats.rows_per_tile = pl.RY;
     t_stats.xuniform_mask = (pl.path == XINV_PATH_FUSED || p.kind == KIND_BIH2D) ? (int32_t)pl.um : 0;
     t_stats.masked_tile_pct = (pl.path == XINV_PATH_FUSED && pl.skip) ? pl.skip_pct : 0;
-    t_stats.sweep_launches = nlaunch;
+    t_stats.sweep_launches = R.nlaunch;
     t_stats.sweeps_max = sweeps_max;
-    t_stats.sweep_ms = ms_total;
+    t_stats.sweep_ms = R.ms_total;
     return XINV_OK;
+}
+
+// ------------------------------------------------------------------ the solve (device ptrs)
+static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st)
+{
+    int rc = validate(p, flags);
+    if (rc) return rc;
+    xinv_options opt;
+    fill_options(opt, opt_in);
+
+    DeviceGuard dg;
+    HIPCHK(dg.select(opt.device));
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    Workspace *ws = get_ws(device);
+    std::lock_guard<std::recursive_mutex> solve_lock(ws->busy);
+    if (!ws->ev0[0])
+        for (int q = 0; q < 2; q++) {
+            HIPCHK(hipEventCreate(&ws->ev0[q])); HIPCHK(hipEventCreate(&ws->ev1[q]));
+            HIPCHK(hipEventCreateWithFlags(&ws->evc[q], hipEventDisableTiming));
+        }
+    if (!ws->dflag) {
+        HIPCHK(hipMalloc((void **)&ws->dflag, sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&ws->hflag, sizeof(int), hipHostMallocDefault));
+    }
+
+    memset(&t_stats, 0, sizeof t_stats);
+    Plan pl;
+    memset(&pl, 0, sizeof pl);
+    rc = plan_colouring(p, ws, st, pl);
+    if (rc) return rc;
+
+    // ---- small slices: the register-resident solver, when the form and the size allow it --------
+    // On request only (path = XINV_PATH_SMALL, or XINV_SMALL_AUTO=1 in the environment): as measured
+    // this round it does not yet beat the streaming kernels (DESIGN.md section 4.7).
+    static const bool small_auto = [] { const char *e = getenv("XINV_SMALL_AUTO"); return e && atoi(e) != 0; }();
+    if ((opt.path == XINV_PATH_AUTO && small_auto) || opt.path == XINV_PATH_SMALL) {
+        int sNW = 0, sRW = 0, sNSEG = 0;
+        bool ok = pl.base == 2 && !pl.seam && !(opt.flags & XINV_FLAG_NO_XUNIFORM) && small_variant(p, &sNW, &sRW, &sNSEG);
+        if (ok) {
+            const int cmapS[2] = {0, 2}, cmapG[5] = {0, 2, 3, 4, 5};
+            const int ns = (p.kind == KIND_STD2D) ? 2 : 5;
+            const double *arr[5]; int64_t strd[5];
+            for (int q = 0; q < ns; q++) {
+                const int sidx = (p.kind == KIND_STD2D) ? cmapS[q] : cmapG[q];
+                arr[q] = p.c[sidx]; strd[q] = p.sc[sidx];
+            }
+            unsigned um = 0;
+            rc = detect_xuniform(ws, st, arr, strd, ns, p.nbatch, p.yc, p.xc, &um);
+            if (rc) return rc;
+            ok = (um == ((1u << ns) - 1u));
+            pl.um = pl.umask = um;
+        }
+        if (ok) return solve_small(p, pl, ws, flags, opt, st, sNW, sRW, sNSEG);
+        if (opt.path == XINV_PATH_SMALL)
+            return fail_arg("the small-slice solver needs the 2-D standard / general form with B == 0, yc <= 96, xc <= 384 and every coefficient array constant along x");
+    }
+    rc = plan_path(p, opt, ws, st, pl);
+    if (rc) return rc;
+    SweepRun R;
+    rc = run_sweeps(p, pl, opt, ws, st, R);
+    if (rc) return rc;
+    return finalise(p, pl, ws, st, flags, R);
 }
 
 // ------------------------------------------------------------------ the solve (host ptrs)
