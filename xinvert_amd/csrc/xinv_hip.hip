@@ -815,12 +815,17 @@ static int64_t host_chunk_members(const Problem &p, const xinv_options &opt)
 {
     if (p.nbatch <= 1) return 1;
     if (opt.host_chunk > 0) return std::min<int64_t>(opt.host_chunk, p.nbatch);
+    // Chunking hides PCIe time behind sweeps but costs twice: every chunk repeats the once-per-solve
+    // detection / planning passes (~0.5 ms), and a small chunk fills the 256 CUs less evenly than the
+    // whole batch (measured, profiles/r02_host_pipeline.txt: 15 omega volumes, 200 sweeps: one chunk
+    // 293 ms, three 254 ms, eight 281 ms against 202 ms device-resident; 8 Gill-Matsuno members, 500
+    // sweeps: one chunk 17 ms, three 22 ms).  So: one chunk below 1 GiB of per-member data, three above.
     const int64_t n = p.zc * p.yc * p.xc;
-    // at most 8 chunks; a chunk holds at least ~2 M points (one round of workgroups on 256 CUs)
-    // and at least 16 MiB of S, so that neither the sweeps nor the DMA run half-empty
-    int64_t mc = (p.nbatch + 7) / 8;
-    mc = std::max<int64_t>(mc, ((int64_t)1 << 21) / std::max<int64_t>(1, n) + 1);
-    return std::min<int64_t>(mc, p.nbatch);
+    int per_member = 1;                                   // S
+    for (int q = 0; q < p.ncoef; q++) per_member += (p.c[q] && p.sc[q] != 0 && !((p.rowconst >> q) & 1u)) ? 1 : 0;
+    const double bytes = (double)p.nbatch * (double)n * 8.0 * per_member;
+    if (bytes < 1073741824.0 || p.nbatch < 3) return p.nbatch;
+    return (p.nbatch + 2) / 3;
 }
 
 static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bool pin_enabled)
