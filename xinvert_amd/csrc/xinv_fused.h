@@ -79,6 +79,15 @@ struct FusedArgs {
     int nstrip, nrb, RY;       // x strips, row blocks, rows per tile (0: even split)
     int nwg;                   // workgroups per member = ceil(nstrip * nrb / 4)
     int force, no_ctl;
+    int lag;                   // 1: publish the norm partials with `tag` and return; the NEXT launch's extra
+                               //    workgroup (or k_norm_reduce_lag) evaluates them
+    unsigned tag;
+    // the previous launch's partials, evaluated by workgroup `nwg` of this launch (lagp_tag == 0: none)
+    unsigned long long *lagp_psum;
+    const double *lagp_xsum;
+    const long long *lagp_xcnt;
+    int lagp_NB, lagp_K;
+    unsigned lagp_tag;
     int64_t member0;
     XinvScal sc_;
     XinvCtl *ctl;
@@ -416,17 +425,14 @@ __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &i
 // (store, wait, atomic, wait, last one reads) this takes two memory round trips off the tail of
 // EVERY workgroup: 32.8 -> 28.5 us per launch at 3600x1800.  NWV = wavefronts per workgroup.
 #define XINV_PW 3          /* words per partial */
+// publish this workgroup's partial of each of the K fused sweeps (no wait, any arrival order)
 template <int K, int NWV>
-__device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const int (&cnt)[K],
-                                                   int wave, int lane, int NB, int T, unsigned tag,
-                                                   unsigned long long *pw, XinvCtl *ctl,
-                                                   const XinvStop &stop,
-                                                   double xsum = 0.0, long long xcnt = 0)
+__device__ __forceinline__ void xinv_norm_publish(const double (&acc)[K], const int (&cnt)[K],
+                                                  int wave, int lane, int NB, int T, unsigned tag,
+                                                  unsigned long long *pw)
 {
     __shared__ double ls[NWV][K];
     __shared__ long long lcn[NWV][K];
-    __shared__ unsigned s_timeout;
-    if (threadIdx.x == 0) s_timeout = 0u;
 #pragma unroll
     for (int s = 0; s < K; s++) {
         double ws = xinv_wave_sum(acc[s]);
@@ -446,8 +452,20 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
         __hip_atomic_store(q + 2, hi | (unsigned long long)(unsigned)tc, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (blockIdx.x != gridDim.x - 1) return;
+}
 
+// one workgroup of NWV wavefronts: wait until the K * NB partials carry `tag`, add them in a fixed
+// order, apply the reference's stop rule once per fused sweep, advance ctl->seq
+template <int K, int NWV>
+__device__ __forceinline__ void xinv_norm_reduce(int wave, int lane, int NB, unsigned tag,
+                                                 unsigned long long *pw, XinvCtl *ctl, const XinvStop &stop,
+                                                 double xsum, long long xcnt)
+{
+    __shared__ double ls[NWV][K];
+    __shared__ long long lcn[NWV][K];
+    __shared__ unsigned s_timeout;
+    if (threadIdx.x == 0) s_timeout = 0u;
+    const unsigned long long hi = (unsigned long long)tag << 32;
     // reducer: item i = s * NB + t ; thread tid takes i = tid, tid + NT, ... four at a time so
     // that the twelve loads of a pass are in flight together
     constexpr int NT = NWV * XINV_WAVE, C = 4;
@@ -501,7 +519,7 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
             }
         }
     }
-    __syncthreads();                                   // ls / lcn are reused below
+    __syncthreads();
     if (s_timeout) {
         if (tid == 0) {
             ctl->overflow = 2; ctl->done = 1; ctl->sweeps = ctl->loop + 1;
@@ -526,6 +544,55 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
         ctl->seq = tag + 1u;
     }
 }
+
+template <int K, int NWV>
+__device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const int (&cnt)[K],
+                                                   int wave, int lane, int NB, int T, unsigned tag,
+                                                   unsigned long long *pw, XinvCtl *ctl,
+                                                   const XinvStop &stop,
+                                                   double xsum = 0.0, long long xcnt = 0)
+{
+    xinv_norm_publish<K, NWV>(acc, cnt, wave, lane, NB, T, tag, pw);
+    if (blockIdx.x != gridDim.x - 1) return;
+    __syncthreads();                                   // (the publish step's LDS scratch is reused by the reducer)
+    xinv_norm_reduce<K, NWV>(wave, lane, NB, tag, pw, ctl, stop, xsum, xcnt);
+}
+
+// Lagged evaluation (k_fused2d with FusedArgs::lag): the sweep kernel only publishes; the partials are
+// added and the stop rule applied by an extra workgroup of the NEXT launch, while that pass's tiles
+// run -- the reduction (a global round trip after the last tile) leaves the critical path between
+// launches.  This one-workgroup kernel does the same for the last launch of a chunk, before the host
+// reads the control blocks.  Same order of summation as the in-kernel reducer.
+struct NormLagArgs {
+    unsigned long long *psum;  // this launch's partial buffer: [nbatch][XINV_KMAX][NB][XINV_PW]
+    XinvCtl *ctl;
+    XinvStop stop;
+    const double *xsum;        // skipped tiles' share (nullptr: none)
+    const long long *xcnt;
+    int NB, K;
+    unsigned tag;
+    int64_t member0;
+};
+
+#ifdef XINV_AUX_KERNELS
+__global__ __launch_bounds__(256) void k_norm_reduce_lag(NormLagArgs a)
+{
+    const int64_t m = a.member0 + blockIdx.x;
+    XinvCtl *ctl = a.ctl + m;
+    if (ctl->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long *pw = a.psum + (size_t)m * XINV_KMAX * a.NB * XINV_PW;
+    const double xs = a.xsum ? a.xsum[m] : 0.0;
+    const long long xc = a.xcnt ? a.xcnt[m] : 0;
+    switch (a.K) {
+    case 1: xinv_norm_reduce<1, 4>(wave, lane, a.NB, a.tag, pw, ctl, a.stop, xs, xc); break;
+    case 2: xinv_norm_reduce<2, 4>(wave, lane, a.NB, a.tag, pw, ctl, a.stop, xs, xc); break;
+    case 3: xinv_norm_reduce<3, 4>(wave, lane, a.NB, a.tag, pw, ctl, a.stop, xs, xc); break;
+    default: xinv_norm_reduce<4, 4>(wave, lane, a.NB, a.tag, pw, ctl, a.stop, xs, xc); break;
+    }
+}
+
+#endif /* XINV_AUX_KERNELS */
 
 #ifndef XINV_MINWAVES
 #define XINV_MINWAVES 1
@@ -553,7 +620,24 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && ctl->done) return;
-    const unsigned tag = ctl->seq;
+    if (a.lag && (int)blockIdx.x == a.nwg) {
+        // the extra workgroup of a lagged launch: norm + stop rule of the PREVIOUS pass, whose partials
+        // are complete (that kernel has finished), while this pass's tiles run
+        if (a.lagp_tag) {
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+            unsigned long long *pw = a.lagp_psum + (size_t)m * XINV_KMAX * a.lagp_NB * XINV_PW;
+            const double xs = a.lagp_xsum ? a.lagp_xsum[m] : 0.0;
+            const long long xn = a.lagp_xcnt ? a.lagp_xcnt[m] : 0;
+            switch (a.lagp_K) {
+            case 1: xinv_norm_reduce<1, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
+            case 2: xinv_norm_reduce<2, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
+            case 3: xinv_norm_reduce<3, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
+            default: xinv_norm_reduce<4, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
+            }
+        }
+        return;
+    }
+    const unsigned tag = a.lag ? a.tag : ctl->seq;
 
     // ---- tile of this wavefront; workgroup -> tile map keeps each XCD on a band of rows ----
     // A member's wave-tiles are numbered strip-fastest, then row block; workgroup T takes four
@@ -783,6 +867,10 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 
     if (a.no_ctl) return;
 
+    if (a.lag) {
+        xinv_norm_publish<K, 4>(acc, cnt, wave, lane, NB, T, tag, a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW);
+        return;
+    }
     xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, tag,
                              a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop,
                              a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);

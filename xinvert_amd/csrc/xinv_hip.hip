@@ -490,7 +490,9 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
 // What the loop leaves for finalise(): where each launch started, the final control blocks.
 struct SweepRun {
     double *S2 = nullptr;
-    double *buf[2] = {nullptr, nullptr};
+    double *buf[3] = {nullptr, nullptr, nullptr};
+    int nbuf = 2;                                        // 3 with the lagged norm
+    bool lag = false;
     std::vector<int64_t> bound;                          // bound[i] = sweeps before launch i (fused path)
     int64_t launched = 0, nlaunch = 0;
     double ms_total = 0.0;
@@ -534,10 +536,23 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
                  (3 * sizeof(unsigned long long));      // three tagged words per partial
     else
         pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
-    rc = ensure_dev(&ws->partials, &ws->partials_cap, pbytes);
+    // Lagged norm (5-point 2-D kernels): the sweep kernel only publishes its partials; an extra workgroup
+    // of the NEXT launch adds them and applies the stop rule while that pass's tiles run.  Measured at
+    // 3600x1800, K = 4 (profiles/r02_norm_lag_experiment.txt): 47.6 us per launch with the in-kernel
+    // reducer (a global round trip after the last tile), 43.7 us publishing only, 41.7 us without any
+    // norm; a reducer kernel on a second stream (events both ways) was slower than either: 50.6 us.
+    // The decision about pass i arrives while pass i+1 runs, so S rotates through THREE buffers: pass
+    // i+2 -- the first that could overwrite the source of pass i -- starts after reducer i has finished,
+    // finds the member stopped and does nothing, and finalise() re-sweeps from the intact source.
+    static const bool lag_env = [] { const char *e = getenv("XINV_LAG"); return !e || atoi(e) != 0; }();
+    const bool lag_cand = lag_env && pl.path == XINV_PATH_FUSED && !pl.nine &&
+                          (p.kind == KIND_STD2D || p.kind == KIND_GEN2D || p.kind == KIND_STD2DT);
+    pbytes = (pbytes + 255) & ~(size_t)255;
+    ws->partials_half = pbytes;
+    rc = ensure_dev(&ws->partials, &ws->partials_cap, lag_cand ? 2 * pbytes : pbytes);
     if (rc) return rc;
     if (pl.path == XINV_PATH_FUSED)                              // tagged partials: no stale sequence numbers
-        HIPCHK(hipMemsetAsync(ws->partials, 0, pbytes, st));
+        HIPCHK(hipMemsetAsync(ws->partials, 0, lag_cand ? 2 * pbytes : pbytes, st));
     double *&S2 = R.S2;
     if (pl.path == XINV_PATH_COLOUR && p.kind == KIND_BIH2D) {       // side buffer of the row-class kernel
         rc = ensure_dev(&ws->S2, &ws->S2_cap, (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double));
@@ -566,7 +581,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         const double est_us = std::max(4.0, (double)p.nbatch * (double)n * Kf / rate);
         check_every = (int)std::min(256.0, std::max(4.0, 2000.0 / est_us));
     }
-    R.buf[0] = p.S; R.buf[1] = S2;
+    R.buf[0] = p.S; R.buf[1] = S2; R.buf[2] = nullptr;
     double **buf = R.buf;
     std::vector<int64_t> &bound = R.bound;
     int64_t &launched = R.launched, &nlaunch = R.nlaunch;
@@ -577,8 +592,9 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // GPU never idles on the host's reaction time; once every member has stopped, the launches
     // already queued are no-ops (each kernel returns on ctl.done).
     // one sweep launch (fused: K sweeps from buf[cur] into buf[cur^1]; colour path: one sweep in place)
+    static const int exp_noctl = [] { const char *e = getenv("XINV_EXP_NOCTL"); return e ? atoi(e) : 0; }();   // timing experiment only
     auto launch_one = [&](hipStream_t s, int cur, int k) -> int {
-        return launch_planned(p, pl, ws, s, k, buf[cur], buf[cur ^ 1], 0, p.nbatch, 0, 0);
+        return launch_planned(p, pl, ws, s, k, buf[cur], buf[cur ^ 1], 0, p.nbatch, exp_noctl, exp_noctl);
     };
     // Small problems are bound by the host's launch rate (a 151x251 coloured sweep is six launches
     // of 2-3 us each): a full chunk is captured once into a hipGraph on an engine-owned stream and
@@ -610,6 +626,41 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             (void)hipGetLastError();                       // a failed capture falls back to plain launches
         }
     }
+    const bool lag = R.lag = lag_cand && !use_graph && !exp_noctl;
+    NormLagArgs lag_pending;
+    memset(&lag_pending, 0, sizeof lag_pending);
+    if (lag) {
+        const size_t need = (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double);
+        rc = ensure_dev(&ws->S3, &ws->S3_cap, need);
+        if (rc) return rc;
+        if (pl.skip) HIPCHK(hipMemcpyAsync(ws->S3, p.S, need, hipMemcpyDeviceToDevice, st));
+        R.buf[2] = ws->S3; R.nbuf = 3;
+    }
+    // launch number i of the solve (fused path): k sweeps from buf[i % nbuf] into buf[(i+1) % nbuf]
+    auto launch_idx = [&](int64_t i, int k) -> int {
+        const double *src = buf[i % R.nbuf];
+        double *dst = buf[(i + 1) % R.nbuf];
+        if (exp_noctl == 2)                              // (timing experiment: publish only, nobody reduces)
+            return launch_fused(p, pl, k, src, dst, ws, st, 0, p.nbatch, 1, 0, (unsigned)(i + 1), nullptr);
+        if (!lag) return launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, exp_noctl, exp_noctl);
+        NormLagArgs la;
+        int r = launch_fused(p, pl, k, src, dst, ws, st, 0, p.nbatch, 0, 0, (unsigned)(i + 1), &la, &lag_pending);
+        if (r) return r;
+        lag_pending = la;                                // evaluated by the next launch, or by flush_lag()
+        return XINV_OK;
+    };
+    // the last launch of a chunk has no successor yet: its norm is evaluated by a one-workgroup kernel
+    // before the control blocks are copied for the host
+    auto flush_lag = [&]() -> int {
+        if (!lag || !lag_pending.tag) return XINV_OK;
+        for (int64_t m0 = 0; m0 < p.nbatch; m0 += (int64_t)1 << 30) {
+            lag_pending.member0 = m0;
+            hipLaunchKernelGGL(k_norm_reduce_lag, dim3((unsigned)std::min<int64_t>((int64_t)1 << 30, p.nbatch - m0)),
+                               dim3(256), 0, st, lag_pending);
+        }
+        lag_pending.tag = 0;
+        return XINV_OK;
+    };
     auto issue_chunk = [&](int slot) -> int {
         if (opt.timing) HIPCHK(hipEventRecord(ws->ev0[slot], st));
         if (use_graph && max_sweeps - launched >= (int64_t)check_every * Kf &&
@@ -625,8 +676,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             int r;
             if (pl.path == XINV_PATH_FUSED) {
                 const int k = (int)std::min<int64_t>(Kf, max_sweeps - launched);   // the tail: one shorter pass
-                const int cur = (int)(bound.size() & 1);
-                r = launch_one(st, cur, k);
+                r = launch_idx((int64_t)bound.size(), k);
                 if (r) return r;
                 bound.push_back(launched);
                 launched += k;
@@ -637,6 +687,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             }
             nlaunch++;
         }
+        { int r = flush_lag(); if (r) return r; }
         if (opt.timing) HIPCHK(hipEventRecord(ws->ev1[slot], st));
         HIPCHK(hipMemcpyAsync(ws->hctl + (size_t)slot * p.nbatch, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl),
                               hipMemcpyDeviceToHost, st));
@@ -664,6 +715,12 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     }
     if (pl.path != XINV_PATH_FUSED)                      // drain the queued no-op tail (the fused path syncs below)
         HIPCHK(hipStreamSynchronize(st));
+    if (!all_done && exp_noctl) {                        // (experiment: no norm, no stop rule -- report the timing only)
+        HIPCHK(hipStreamSynchronize(st));
+        t_stats.sweep_launches = nlaunch; t_stats.sweep_ms = ms_total; t_stats.sweeps_per_launch = Kf;
+        t_err = "XINV_EXP_NOCTL: timing experiment, no result";
+        return XINV_ERR_ARG;
+    }
     if (!all_done) { t_err = "internal: sweep budget exhausted before the stop rule fired"; return XINV_ERR_HIP; }
     for (int64_t m = 0; m < p.nbatch; m++)
         if (hc[m].overflow == 2) {
@@ -690,20 +747,23 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
             const int64_t sw = hc[m].sweeps;
             // launch i covers sweeps (bound[i], bound[i+1]]; find the one holding sweep `sw`
             size_t i = std::upper_bound(bound.begin(), bound.end(), sw - 1) - bound.begin() - 1;
+            const int nbuf = R.nbuf;
             int where;                                   // buffer index holding the final state
             if (bound[i + 1] == sw) {
-                where = (int)((i + 1) & 1);
-            } else {                                     // stopped inside a K-sweep launch: redo
-                int cur = (int)(i & 1);
+                where = (int)((i + 1) % nbuf);
+            } else {                                     // stopped inside a K-sweep launch: redo from its source
+                int cur = (int)(i % nbuf);               // (intact: with the lagged norm the passes after i+1 did nothing)
+                int nxt = (int)((i + 1) % nbuf);         // the pass's own output: free to overwrite
+                const int spare = (nbuf == 3) ? (int)((i + 2) % nbuf) : cur;
                 for (int64_t s = bound[i]; s < sw; s++) {
-                    rc = launch_planned(p, pl, ws, st, 1, buf[cur], buf[cur ^ 1], m, 1, 1, 1);
+                    rc = launch_planned(p, pl, ws, st, 1, buf[cur], buf[nxt], m, 1, 1, 1);
                     if (rc) return rc;
-                    cur ^= 1;
+                    const int t = cur; cur = nxt; nxt = (nbuf == 3 && t == (int)(i % nbuf)) ? spare : t;
                 }
                 where = cur;
             }
-            if (where == 1)
-                HIPCHK(hipMemcpyAsync(p.S + m * p.sS, R.S2 + m * p.sS, (size_t)n * sizeof(double),
+            if (where != 0)
+                HIPCHK(hipMemcpyAsync(p.S + m * p.sS, buf[where] + m * p.sS, (size_t)n * sizeof(double),
                                       hipMemcpyDeviceToDevice, st));
         }
         HIPCHK(hipStreamSynchronize(st));

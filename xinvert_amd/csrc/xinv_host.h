@@ -48,6 +48,8 @@ struct Workspace {
     double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
     XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
     void *partials = nullptr; size_t partials_cap = 0;  // norm partials
+    size_t partials_half = 0;                           // lagged norm: byte offset of the odd launches' buffer
+    double *S3 = nullptr; size_t S3_cap = 0;            // lagged norm: third S buffer
     int *dflag = nullptr;
     int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl

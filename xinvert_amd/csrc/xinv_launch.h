@@ -22,6 +22,8 @@ struct Plan {
     int ntl, nskip;          // list entries per member (active, multiple of 4 / skipped)
     int skip_pct;            // share of wave-tiles skipped, percent
     double lone = 1.6;       // planner: cost of a workgroup alone on its CU relative to one of a pair
+    bool lag;                // 5-point 2-D kernels: norm + stop rule evaluated by k_norm_reduce_lag on a second stream,
+                             // one pass behind the sweeps (three S buffers); see run_sweeps
 };
 
 // kernel variants instantiated per model: mask of streams read as one scalar per row
@@ -46,7 +48,8 @@ static bool ptr_al16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 static int launch_fused(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
                         Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
-                        int no_ctl)
+                        int no_ctl, unsigned lag_tag = 0, NormLagArgs *lag_out = nullptr,
+                        const NormLagArgs *lag_prev = nullptr)
 {
     FusedArgs a;
     memset(&a, 0, sizeof a);
@@ -77,8 +80,11 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.sc_ = p.sc_;
     a.ctl = ws->ctl;
     a.stop = p.stop;
-    const size_t NBmax = (size_t)pl.nsg;             // workgroups per member, narrowest strips (K = XINV_KMAX)
     a.psum = (unsigned long long *)ws->partials;
+    if (lag_tag) {                                   // lagged norm: partial buffers alternate with the launch parity
+        a.lag = 1; a.tag = lag_tag;
+        a.psum = (unsigned long long *)((char *)ws->partials + (size_t)((lag_tag - 1u) & 1u) * ws->partials_half);
+    }
     if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
         a.tile_list = ws->d_list;
         a.ntl = pl.ntl;
@@ -88,10 +94,19 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
         a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
         a.xcnt = (const long long *)(base + nt * (sizeof(double) + sizeof(long long)) + p.nbatch * sizeof(double));
     }
+    if (lag_tag && lag_prev && lag_prev->tag) {      // the previous launch's partials: this launch's extra workgroup
+        a.lagp_psum = lag_prev->psum; a.lagp_xsum = lag_prev->xsum; a.lagp_xcnt = lag_prev->xcnt;
+        a.lagp_NB = lag_prev->NB; a.lagp_K = lag_prev->K; a.lagp_tag = lag_prev->tag;
+    }
+    if (lag_out) {                                   // what the lagged reducer of this launch needs
+        memset(lag_out, 0, sizeof *lag_out);
+        lag_out->psum = a.psum; lag_out->ctl = ws->ctl; lag_out->stop = p.stop;
+        lag_out->xsum = a.xsum; lag_out->xcnt = a.xcnt; lag_out->NB = a.nwg; lag_out->K = K; lag_out->tag = lag_tag;
+    }
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {      // grid.y is limited to 65535
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
-        dim3 grid((unsigned)a.nwg, (unsigned)nm, 1), block(256, 1, 1);
+        dim3 grid((unsigned)a.nwg + (lag_tag ? 1u : 0u), (unsigned)nm, 1), block(256, 1, 1);
         if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
             return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     }
