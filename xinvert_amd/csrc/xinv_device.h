@@ -68,19 +68,68 @@ __device__ __forceinline__ void xinv_ctl_update(XinvCtl *c, double sum, long lon
     c->loop += 1;
 }
 
-// Deterministic butterfly sum over the 64 lanes of a wavefront.
+// Deterministic sum over the 64 lanes of a wavefront, returned in every lane.  DPP row shifts
+// (1, 2, 4, 8 inside the rows of 16 lanes, zero shifted in), then row_bcast:15 / row_bcast:31 carry
+// the row totals across: the total lands in lane 63 and is broadcast with v_readlane.  18 VALU
+// instructions per double instead of six dependent ds_bpermute round trips (__shfl_xor): the norm
+// partials of K fused sweeps are reduced at the very end of every wavefront, on the critical path.
+// The order of the additions is fixed (run-to-run reproducible), though not the butterfly's.
+#ifndef XINV_DPP_REDUCE
+#define XINV_DPP_REDUCE 1
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double xinv_dpp_add(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    // lanes the row mask leaves out (or that shift in nothing) receive +0.0: v + 0.0 == v
+    return v + __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double xinv_wave_sum(double v)
 {
+#if XINV_DPP_REDUCE
+    v = xinv_dpp_add<0x111, 0xf>(v);       // row_shr:1
+    v = xinv_dpp_add<0x112, 0xf>(v);       // row_shr:2
+    v = xinv_dpp_add<0x114, 0xf>(v);       // row_shr:4
+    v = xinv_dpp_add<0x118, 0xf>(v);       // row_shr:8   -> lane 15 of each row holds the row total
+    v = xinv_dpp_add<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v = xinv_dpp_add<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+#else
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, XINV_WAVE);
     return v;
+#endif
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long xinv_dpp_add_ll(long long v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned long long)v, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)((unsigned long long)v >> 32), CTRL, ROW_MASK, 0xf, true);
+    return v + (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
 __device__ __forceinline__ long long xinv_wave_sum_ll(long long v)
 {
+#if XINV_DPP_REDUCE
+    v = xinv_dpp_add_ll<0x111, 0xf>(v);
+    v = xinv_dpp_add_ll<0x112, 0xf>(v);
+    v = xinv_dpp_add_ll<0x114, 0xf>(v);
+    v = xinv_dpp_add_ll<0x118, 0xf>(v);
+    v = xinv_dpp_add_ll<0x142, 0xa>(v);
+    v = xinv_dpp_add_ll<0x143, 0xc>(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), 63);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+#else
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, XINV_WAVE);
     return v;
+#endif
 }
 
 // Neighbour-lane moves on the VALU (DPP wave shifts, gfx9 family): no LDS round trip, unlike
