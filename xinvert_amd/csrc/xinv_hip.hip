@@ -545,7 +545,10 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // i+2 -- the first that could overwrite the source of pass i -- starts after reducer i has finished,
     // finds the member stopped and does nothing, and finalise() re-sweeps from the intact source.
     static const bool lag_env = [] { const char *e = getenv("XINV_LAG"); return !e || atoi(e) != 0; }();
-    const bool lag_cand = lag_env && pl.path == XINV_PATH_FUSED && !pl.nine &&
+    // Only where a member has many workgroups: the reducing workgroup is one more per member and launch,
+    // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
+    const int64_t wg_member = pl.skip ? pl.ntl / 4 : (int64_t)cdiv((int64_t)cdiv(p.xc, 128 - 4 * pl.K) * pl.nrb, 4);
+    const bool lag_cand = lag_env && pl.path == XINV_PATH_FUSED && !pl.nine && wg_member >= 32 &&
                           (p.kind == KIND_STD2D || p.kind == KIND_GEN2D || p.kind == KIND_STD2DT);
     pbytes = (pbytes + 255) & ~(size_t)255;
     ws->partials_half = pbytes;
