@@ -344,6 +344,10 @@ def main():
                 'value': float(nb) * n * hsw * 5 / th, 'unit_value': 'point-sweeps/s',
                 'avg_launch_ms': h_avg, 'launches': int(hl), 'alg_bytes_per_launch': ALG_BYTES[kind] * float(nb) * n,
                 'traffic': htraffic, 'traffic_source': roof['traffic_source'],
+                'traffic_GBps': (htraffic / (h_avg * 1e-3) / 1e9) if htraffic else None,
+                'traffic_frac_of_hbm_peak': (htraffic / (h_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if htraffic else None,
+                'note': 'S (two buffers) + A + C + F = 259 MB fit the 256 MiB Infinity Cache almost entirely: the measured '
+                        'bytes are fabric traffic, the HBM itself is touched less',
                 'sweeps_per_launch': sh['sweeps_per_launch'], 'xuniform_mask': sh['xuniform_mask'],
                 'masked_tile_pct': sh['masked_tile_pct']}
             del hb
