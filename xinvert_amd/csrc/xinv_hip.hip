@@ -498,6 +498,11 @@ struct SweepRun {
     double ms_total = 0.0;
     const XinvCtl *hc = nullptr;                         // the slot holding the final control blocks
     int Kf = 1;
+    // the replayed chunk of small problems: lives until finalise() has drained the stream (replays
+    // queued after the last poll may still be executing when run_sweeps returns)
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t stream = nullptr;
+    ~SweepRun() { if (graph_exec) { (void)hipStreamSynchronize(stream); (void)hipGraphExecDestroy(graph_exec); } }
 };
 
 // one sweep launch of the planned kernel (fused: k sweeps from src into dst; colour path: one sweep in place)
@@ -548,7 +553,10 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // Only where a member has many workgroups: the reducing workgroup is one more per member and launch,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t wg_member = pl.skip ? pl.ntl / 4 : (int64_t)cdiv((int64_t)cdiv(p.xc, 128 - 4 * pl.K) * pl.nrb, 4);
+    // ... and only where a launch is one or two rounds of workgroups: with many rounds (64 Gill-Matsuno
+    // members: 3.97e11 without, 3.73e11 with) the in-kernel reducer's wait already hides behind other tiles.
     const bool lag_cand = lag_env && pl.path == XINV_PATH_FUSED && !pl.nine && wg_member >= 32 &&
+                          wg_member * p.nbatch <= 1024 &&
                           (p.kind == KIND_STD2D || p.kind == KIND_GEN2D || p.kind == KIND_STD2DT);
     pbytes = (pbytes + 255) & ~(size_t)255;
     ws->partials_half = pbytes;
@@ -603,10 +611,6 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // of 2-3 us each): a full chunk is captured once into a hipGraph on an engine-owned stream and
     // replayed into the caller's stream.  The chunk has an even number of launches, so the
     // ping-pong parity at its start is always 0.
-    struct GraphHolder {
-        hipGraphExec_t exec = nullptr;
-        ~GraphHolder() { if (exec) (void)hipGraphExecDestroy(exec); }
-    } gh;
     bool use_graph = false;
     {
         const char *e = getenv("XINV_GRAPH");
@@ -622,7 +626,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
                 for (int i = 0; i < check_every && r == XINV_OK; i++) r = launch_one(ws->gstream, i & 1, Kf);
                 const hipError_t ce = hipStreamEndCapture(ws->gstream, &g);
                 if (r == XINV_OK && ce == hipSuccess && g &&
-                    hipGraphInstantiate(&gh.exec, g, nullptr, nullptr, 0) == hipSuccess)
+                    hipGraphInstantiate(&R.graph_exec, g, nullptr, nullptr, 0) == hipSuccess)
                     use_graph = true;
                 if (g) (void)hipGraphDestroy(g);
             }
@@ -668,7 +672,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         if (opt.timing) HIPCHK(hipEventRecord(ws->ev0[slot], st));
         if (use_graph && max_sweeps - launched >= (int64_t)check_every * Kf &&
             (pl.path != XINV_PATH_FUSED || (bound.size() & 1) == 0)) {
-            HIPCHK(hipGraphLaunch(gh.exec, st));
+            HIPCHK(hipGraphLaunch(R.graph_exec, st));
             for (int i = 0; i < check_every; i++) {
                 if (pl.path == XINV_PATH_FUSED) bound.push_back(launched);
                 launched += Kf;
@@ -847,6 +851,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     rc = plan_path(p, opt, ws, st, pl);
     if (rc) return rc;
     SweepRun R;
+    R.stream = st;
     rc = run_sweeps(p, pl, opt, ws, st, R);
     if (rc) return rc;
     return finalise(p, pl, ws, st, flags, R);
