@@ -55,6 +55,9 @@ extern "C" {
 #define XINV_FLAG_NO_TILE_SKIP 2 /* run every tile even where the forcing is masked throughout    */
 #define XINV_FLAG_FORCE_TILE_SKIP 4 /* testing aid: skip masked tiles whatever the grid size, keep
                                     the row split                                                */
+#define XINV_FLAG_PIN_HOST 8     /* host-pointer entries: register the caller's arrays in place for the
+                                    call (DMA at PCIe rate).  Off by default: only for buffers that stay
+                                    mapped afterwards (see xinv_host.h)                           */
 
 #define XINV_MAX_DEVICES 16
 

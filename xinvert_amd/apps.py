@@ -244,10 +244,13 @@ def animate_iteration(app_name, F, dims, coords='lat-lon', icbc=None,
     iParams = _update(ps, iParams)
     iParams['mxLoop'] = loop_per_frame
     iParams['printInfo'] = False
+    # the coefficient stack, the forcing and S stay in HBM for all frames (core.Resident): a frame is one
+    # restart of the kernels on the resident batch plus one download of S
+    res = core.Resident(inv_name, coeffs, maskF, initS, dims, iParams)
     frames = []
     for _ in range(max_frames):
-        S = invt_func(*coeffs, maskF, initS, dims, iParams)
-        frames.append(np.array(S.values, copy=True))
+        res.solve(loop_per_frame, float(iParams['tolerance']))
+        frames.append(res.values())
     out = np.stack(frames)
     if icbc is None:
         out = np.where(maskF.values[None] != _undeftmp, out, iParams['undef'])

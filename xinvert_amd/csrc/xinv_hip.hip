@@ -616,7 +616,12 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         const char *e = getenv("XINV_GRAPH");
         const double est_launch_us = (double)p.nbatch * (double)n * Kf /
                                      ((pl.path == XINV_PATH_FUSED) ? 2.0e5 : 4.0e4);
-        const bool want = e ? (atoi(e) != 0) : (est_launch_us < 12.0);
+        // Replay pays on the colour path only (six or more tiny launches per sweep: 25.8 -> 22.2 us per sweep
+        // at 151x251); for the fused kernels it gained nothing (round 1) and the lagged norm -- which
+        // excludes it -- does (C1: 2.3 -> 1.9 ms per 500 sweeps), and the one long fused solve that used it
+        // (a 720x1440 member run to convergence: ~50 back-to-back replays of one executable graph) aborted
+        // inside the runtime about once in thirty runs.  XINV_GRAPH=1 still forces it.
+        const bool want = e ? (atoi(e) != 0) : (est_launch_us < 12.0 && pl.path != XINV_PATH_FUSED);
         if (want && max_sweeps >= 2 * (int64_t)check_every * Kf) {
             check_every = (check_every + 1) & ~1;
             if (!ws->gstream) HIPCHK(hipStreamCreateWithFlags(&ws->gstream, hipStreamNonBlocking));
@@ -888,6 +893,10 @@ static int64_t host_chunk_members(const Problem &p, const xinv_options &opt)
     // whole batch (measured, profiles/r02_host_pipeline.txt: 15 omega volumes, 200 sweeps: one chunk
     // 293 ms, three 254 ms, eight 281 ms against 202 ms device-resident; 8 Gill-Matsuno members, 500
     // sweeps: one chunk 17 ms, three 22 ms).  So: one chunk below 1 GiB of per-member data, three above.
+    // Without in-place pinning (the default, xinv_host.h) the runtime stages pageable copies and the
+    // "asynchronous" copies block the host: nothing overlaps, chunks only add their fixed costs (C5, 15
+    // volumes: one chunk 300 ms, three 319 ms).
+    if (!Pinned::allowed()) return p.nbatch;
     const int64_t n = p.zc * p.yc * p.xc;
     int per_member = 1;                                   // S
     for (int q = 0; q < p.ncoef; q++) per_member += (p.c[q] && p.sc[q] != 0 && !((p.rowconst >> q) & 1u)) ? 1 : 0;
@@ -1068,6 +1077,7 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
 {
     xinv_options opt;
     fill_options(opt, opt_in);
+    g_pin_flag = (opt.flags & XINV_FLAG_PIN_HOST) != 0;
     p.rowconst = (unsigned)opt.rowconst_mask & ((1u << p.ncoef) - 1u);
     int rc = validate(p, flags);
     if (rc) return rc;

@@ -184,14 +184,28 @@ static int pool_alloc(DevPool *pool, size_t bytes, double **out)
     return XINV_OK;
 }
 
+// In-place pinning of the CALLER's arrays (hipHostRegister for the duration of the call: the DMA
+// engines then read them at PCIe rate, 55 GB/s against ~25 GB/s for the runtime's staged copy) is OFF
+// by default since round 2: registering and unregistering ranges of memory the caller's allocator
+// later unmaps and maps again leaves this runtime (ROCm 7.2) in a state in which a LATER pageable
+// copy of another array at the same virtual address aborts the process -- about one run in seven of
+// tests/test_gpu_frontend.py + test_gpu_fullsize.py, never without the registration (28 runs,
+// profiles/r02_pinning_abort.txt).  XINV_FLAG_PIN_HOST (or XINV_PIN=1 in the environment) turns it on
+// for callers whose buffers stay mapped.
+static bool g_pin_flag = false;                     // set per call from xinv_options.flags (one solve per device at a time)
 struct Pinned {                                     // host ranges registered for this call
+    static bool allowed()
+    {
+        static const bool env = [] { const char *e = getenv("XINV_PIN"); return e && atoi(e) != 0; }();
+        return env || g_pin_flag;
+    }
     std::vector<void *> regs;
     std::vector<hipStream_t> streams;               // streams that may still hold copies of these ranges
     bool enabled = true;                            // false: the caller (multi-device parent) pinned already
     unsigned flags = hipHostRegisterDefault;
     bool try_pin(const void *h, size_t bytes)
     {
-        if (!enabled || bytes < (1u << 20)) return false;
+        if (!enabled || !allowed() || bytes < (1u << 20)) return false;
         if (hipHostRegister((void *)h, bytes, flags) != hipSuccess) {
             (void)hipGetLastError();
             return false;
