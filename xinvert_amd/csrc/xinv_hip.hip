@@ -617,10 +617,8 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         const double est_launch_us = (double)p.nbatch * (double)n * Kf /
                                      ((pl.path == XINV_PATH_FUSED) ? 2.0e5 : 4.0e4);
         // Replay pays on the colour path only (six or more tiny launches per sweep: 25.8 -> 22.2 us per sweep
-        // at 151x251); for the fused kernels it gained nothing (round 1) and the lagged norm -- which
-        // excludes it -- does (C1: 2.3 -> 1.9 ms per 500 sweeps), and the one long fused solve that used it
-        // (a 720x1440 member run to convergence: ~50 back-to-back replays of one executable graph) aborted
-        // inside the runtime about once in thirty runs.  XINV_GRAPH=1 still forces it.
+        // at 151x251); for the fused kernels it gained nothing (round 1; C1: 2.5 ms replayed against 1.9 ms
+        // per 500 sweeps with plain launches and the lagged norm, which excludes replay).  XINV_GRAPH=1 forces it.
         const bool want = e ? (atoi(e) != 0) : (est_launch_us < 12.0 && pl.path != XINV_PATH_FUSED);
         if (want && max_sweeps >= 2 * (int64_t)check_every * Kf) {
             check_every = (check_every + 1) & ~1;
