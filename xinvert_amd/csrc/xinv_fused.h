@@ -558,6 +558,37 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
     xinv_norm_reduce<K, NWV>(wave, lane, NB, tag, pw, ctl, stop, xsum, xcnt);
 }
 
+// The extra workgroup of a lagged launch (blockIdx.x == nwg): norm + stop rule of the PREVIOUS pass,
+// whose partials are complete (that kernel has finished), while this pass's tiles run.  `A` is any
+// argument struct with the lagp_* fields and `stop` (FusedArgs, FusedBihArgs).
+template <class A>
+__device__ __forceinline__ void xinv_lag_reduce_prev(const A &a, XinvCtl *ctl, int64_t m)
+{
+    if (!a.lagp_tag) return;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    unsigned long long *pw = a.lagp_psum + (size_t)m * XINV_KMAX * a.lagp_NB * XINV_PW;
+    const double xs = a.lagp_xsum ? a.lagp_xsum[m] : 0.0;
+    const long long xn = a.lagp_xcnt ? a.lagp_xcnt[m] : 0;
+    switch (a.lagp_K) {
+    case 1: xinv_norm_reduce<1, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
+    case 2: xinv_norm_reduce<2, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
+    case 3: xinv_norm_reduce<3, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
+    default: xinv_norm_reduce<4, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
+    }
+}
+
+// end of a sweep kernel: lagged -> publish only; else publish + in-kernel reducer
+template <int K, class A>
+__device__ __forceinline__ void xinv_norm_tail(const A &a, const double (&acc)[K], const int (&cnt)[K], int wave,
+                                               int lane, int NB, int T, unsigned tag, XinvCtl *ctl, int64_t m)
+{
+    unsigned long long *pw = a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW;
+    if (a.lag) { xinv_norm_publish<K, 4>(acc, cnt, wave, lane, NB, T, tag, pw); return; }
+    xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, tag, pw, ctl, a.stop,
+                             a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
+}
+
+
 // Lagged evaluation (k_fused2d with FusedArgs::lag): the sweep kernel only publishes; the partials are
 // added and the stop rule applied by an extra workgroup of the NEXT launch, while that pass's tiles
 // run -- the reduction (a global round trip after the last tile) leaves the critical path between
@@ -620,23 +651,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && ctl->done) return;
-    if (a.lag && (int)blockIdx.x == a.nwg) {
-        // the extra workgroup of a lagged launch: norm + stop rule of the PREVIOUS pass, whose partials
-        // are complete (that kernel has finished), while this pass's tiles run
-        if (a.lagp_tag) {
-            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-            unsigned long long *pw = a.lagp_psum + (size_t)m * XINV_KMAX * a.lagp_NB * XINV_PW;
-            const double xs = a.lagp_xsum ? a.lagp_xsum[m] : 0.0;
-            const long long xn = a.lagp_xcnt ? a.lagp_xcnt[m] : 0;
-            switch (a.lagp_K) {
-            case 1: xinv_norm_reduce<1, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
-            case 2: xinv_norm_reduce<2, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
-            case 3: xinv_norm_reduce<3, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
-            default: xinv_norm_reduce<4, 4>(wv, ln, a.lagp_NB, a.lagp_tag, pw, ctl, a.stop, xs, xn); break;
-            }
-        }
-        return;
-    }
+    if (a.lag && (int)blockIdx.x == a.nwg) { xinv_lag_reduce_prev(a, ctl, m); return; }
     const unsigned tag = a.lag ? a.tag : ctl->seq;
 
     // ---- tile of this wavefront; workgroup -> tile map keeps each XCD on a band of rows ----
@@ -867,13 +882,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 
     if (a.no_ctl) return;
 
-    if (a.lag) {
-        xinv_norm_publish<K, 4>(acc, cnt, wave, lane, NB, T, tag, a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW);
-        return;
-    }
-    xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, tag,
-                             a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop,
-                             a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
+    xinv_norm_tail<K>(a, acc, cnt, wave, lane, NB, T, tag, ctl, m);
 }
 
 #ifdef XINV_AUX_KERNELS   /* non-template helper kernels: compiled into the main translation unit only */

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && ctl->done) return;
-    const unsigned tag = ctl->seq;
+    if (a.lag && (int)blockIdx.x == a.nwg) { xinv_lag_reduce_prev(a, ctl, m); return; }
+    const unsigned tag = a.lag ? a.tag : ctl->seq;
 
     const int NB = a.nwg;
     int T;
@@ -283,7 +284,5 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     }
 
     if (a.no_ctl) return;
-    xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, tag,
-                             a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop,
-                             a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
+    xinv_norm_tail<K>(a, acc, cnt, wave, lane, NB, T, tag, ctl, m);
 }

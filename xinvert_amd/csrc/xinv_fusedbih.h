@@ -98,6 +98,14 @@ struct FusedBihArgs {
     int ntl;
     const double *xsum;
     const long long *xcnt;
+    // lagged norm, as FusedArgs
+    int lag;
+    unsigned tag;
+    unsigned long long *lagp_psum;
+    const double *lagp_xsum;
+    const long long *lagp_xcnt;
+    int lagp_NB, lagp_K;
+    unsigned lagp_tag;
 };
 
 #ifndef XINV_BIH_MINWAVES
@@ -110,7 +118,8 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && ctl->done) return;
-    const unsigned tag = ctl->seq;
+    if (a.lag && (int)blockIdx.x == a.nwg) { xinv_lag_reduce_prev(a, ctl, m); return; }
+    const unsigned tag = a.lag ? a.tag : ctl->seq;
 
     const int NB = a.nwg;
     int T;
@@ -268,7 +277,5 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
     }
 
     if (a.no_ctl) return;
-    xinv_norm_finalize<1, 4>(acc, cnt, wave, lane, NB, T, tag,
-                             a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop,
-                             a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
+    xinv_norm_tail<1>(a, acc, cnt, wave, lane, NB, T, tag, ctl, m);
 }

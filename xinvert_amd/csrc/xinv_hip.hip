@@ -507,14 +507,15 @@ struct SweepRun {
 
 // one sweep launch of the planned kernel (fused: k sweeps from src into dst; colour path: one sweep in place)
 static int launch_planned(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t s, int k,
-                          const double *src, double *dst, int64_t member0, int64_t nmem, int force, int no_ctl)
+                          const double *src, double *dst, int64_t member0, int64_t nmem, int force, int no_ctl,
+                          unsigned lag_tag = 0, NormLagArgs *lag_out = nullptr, const NormLagArgs *lag_prev = nullptr)
 {
     if (pl.path != XINV_PATH_FUSED) return launch_colour_sweep(p, pl, ws, s);
-    return (p.kind == KIND_BIH2D)   ? launch_fusedbih(p, pl, src, dst, ws, s, member0, nmem, force, no_ctl)
+    return (p.kind == KIND_BIH2D)   ? launch_fusedbih(p, pl, src, dst, ws, s, member0, nmem, force, no_ctl, lag_tag, lag_out, lag_prev)
          : (p.kind == KIND_GEN3D)   ? launch_fused3dg(p, pl, src, dst, ws, s, member0, nmem, force, no_ctl)
          : (p.kind == KIND_STD3D)   ? launch_fused3d(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl)
-         : pl.nine                  ? launch_fused9(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl)
-                                    : launch_fused(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl);
+         : pl.nine                  ? launch_fused9(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl, lag_tag, lag_out, lag_prev)
+                                    : launch_fused(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl, lag_tag, lag_out, lag_prev);
 }
 
 // workspace, then chunks of launches with pipelined polling of the device-side stop flags
@@ -552,12 +553,13 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     static const bool lag_env = [] { const char *e = getenv("XINV_LAG"); return !e || atoi(e) != 0; }();
     // Only where a member has many workgroups: the reducing workgroup is one more per member and launch,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
-    const int64_t wg_member = pl.skip ? pl.ntl / 4 : (int64_t)cdiv((int64_t)cdiv(p.xc, 128 - 4 * pl.K) * pl.nrb, 4);
+    const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
+                                                    : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K);
+    const int64_t wg_member = pl.skip ? pl.ntl / 4 : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, 4);
     // ... and only where a launch is one or two rounds of workgroups: with many rounds (64 Gill-Matsuno
     // members: 3.97e11 without, 3.73e11 with) the in-kernel reducer's wait already hides behind other tiles.
-    const bool lag_cand = lag_env && pl.path == XINV_PATH_FUSED && !pl.nine && wg_member >= 32 &&
-                          wg_member * p.nbatch <= 1024 &&
-                          (p.kind == KIND_STD2D || p.kind == KIND_GEN2D || p.kind == KIND_STD2DT);
+    const bool lag_cand = lag_env && pl.path == XINV_PATH_FUSED && wg_member >= 32 &&
+                          wg_member * p.nbatch <= 1024 && !is3d(p.kind);     // every 2-D streaming kernel
     pbytes = (pbytes + 255) & ~(size_t)255;
     ws->partials_half = pbytes;
     rc = ensure_dev(&ws->partials, &ws->partials_cap, lag_cand ? 2 * pbytes : pbytes);
@@ -654,7 +656,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             return launch_fused(p, pl, k, src, dst, ws, st, 0, p.nbatch, 1, 0, (unsigned)(i + 1), nullptr);
         if (!lag) return launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, exp_noctl, exp_noctl);
         NormLagArgs la;
-        int r = launch_fused(p, pl, k, src, dst, ws, st, 0, p.nbatch, 0, 0, (unsigned)(i + 1), &la, &lag_pending);
+        int r = launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, 0, 0, (unsigned)(i + 1), &la, &lag_pending);
         if (r) return r;
         lag_pending = la;                                // evaluated by the next launch, or by flush_lag()
         return XINV_OK;

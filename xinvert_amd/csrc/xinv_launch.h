@@ -46,6 +46,28 @@ static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 
 
 static bool ptr_al16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Lagged norm (run_sweeps): this launch publishes with `lag_tag` into the partial buffer of its parity;
+// its extra workgroup evaluates `lag_prev`; `lag_out` receives what the evaluation of THIS launch needs.
+// `a` is a FusedArgs / FusedBihArgs whose psum / xsum / xcnt / nwg are already final.
+template <class A>
+static void set_lag(A &a, const Workspace *ws, const Problem &p, int K, unsigned lag_tag, NormLagArgs *lag_out,
+                    const NormLagArgs *lag_prev)
+{
+    if (lag_tag) {
+        a.lag = 1; a.tag = lag_tag;
+        a.psum = (unsigned long long *)((char *)ws->partials + (size_t)((lag_tag - 1u) & 1u) * ws->partials_half);
+        if (lag_prev && lag_prev->tag) {
+            a.lagp_psum = lag_prev->psum; a.lagp_xsum = lag_prev->xsum; a.lagp_xcnt = lag_prev->xcnt;
+            a.lagp_NB = lag_prev->NB; a.lagp_K = lag_prev->K; a.lagp_tag = lag_prev->tag;
+        }
+    }
+    if (lag_out) {
+        memset(lag_out, 0, sizeof *lag_out);
+        lag_out->psum = a.psum; lag_out->ctl = ws->ctl; lag_out->stop = p.stop;
+        lag_out->xsum = a.xsum; lag_out->xcnt = a.xcnt; lag_out->NB = a.nwg; lag_out->K = K; lag_out->tag = lag_tag;
+    }
+}
+
 static int launch_fused(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
                         Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
                         int no_ctl, unsigned lag_tag = 0, NormLagArgs *lag_out = nullptr,
@@ -81,10 +103,6 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.ctl = ws->ctl;
     a.stop = p.stop;
     a.psum = (unsigned long long *)ws->partials;
-    if (lag_tag) {                                   // lagged norm: partial buffers alternate with the launch parity
-        a.lag = 1; a.tag = lag_tag;
-        a.psum = (unsigned long long *)((char *)ws->partials + (size_t)((lag_tag - 1u) & 1u) * ws->partials_half);
-    }
     if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
         a.tile_list = ws->d_list;
         a.ntl = pl.ntl;
@@ -94,15 +112,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
         a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
         a.xcnt = (const long long *)(base + nt * (sizeof(double) + sizeof(long long)) + p.nbatch * sizeof(double));
     }
-    if (lag_tag && lag_prev && lag_prev->tag) {      // the previous launch's partials: this launch's extra workgroup
-        a.lagp_psum = lag_prev->psum; a.lagp_xsum = lag_prev->xsum; a.lagp_xcnt = lag_prev->xcnt;
-        a.lagp_NB = lag_prev->NB; a.lagp_K = lag_prev->K; a.lagp_tag = lag_prev->tag;
-    }
-    if (lag_out) {                                   // what the lagged reducer of this launch needs
-        memset(lag_out, 0, sizeof *lag_out);
-        lag_out->psum = a.psum; lag_out->ctl = ws->ctl; lag_out->stop = p.stop;
-        lag_out->xsum = a.xsum; lag_out->xcnt = a.xcnt; lag_out->NB = a.nwg; lag_out->K = K; lag_out->tag = lag_tag;
-    }
+    set_lag(a, ws, p, K, lag_tag, lag_out, lag_prev);
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {      // grid.y is limited to 65535
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
@@ -122,7 +132,8 @@ static int fused9_dispatch(int kind, int K, bool al, bool ext, dim3 grid, hipStr
 
 static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
                          Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
-                         int no_ctl)
+                         int no_ctl, unsigned lag_tag = 0, NormLagArgs *lag_out = nullptr,
+                         const NormLagArgs *lag_prev = nullptr)
 {
     FusedArgs a;
     memset(&a, 0, sizeof a);
@@ -150,10 +161,11 @@ static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *
         a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
         a.xcnt = (const long long *)(base + nt * (sizeof(double) + sizeof(long long)) + p.nbatch * sizeof(double));
     }
+    set_lag(a, ws, p, K, lag_tag, lag_out, lag_prev);
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
-        dim3 grid((unsigned)a.nwg, (unsigned)nm, 1);
+        dim3 grid((unsigned)a.nwg + (lag_tag ? 1u : 0u), (unsigned)nm, 1);
         if (fused9_dispatch(p.kind, K, pl.aligned, a.ext != 0, grid, st, a, nullptr))
             return fail_arg("unsupported sweeps_per_launch for the 9-point kernel");
     }
@@ -208,7 +220,8 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
 // ---- biharmonic one-pass launch (A..I x-uniform) ----------------------------------------------
 static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, double *dst,
                            Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
-                           int no_ctl)
+                           int no_ctl, unsigned lag_tag = 0, NormLagArgs *lag_out = nullptr,
+                           const NormLagArgs *lag_prev = nullptr)
 {
     const bool per = (p.BCx == XINV_BC_PERIODIC);
     if (p.BCy == XINV_BC_EXTEND) {                   // the kernel's own pre-pass, on the source buffer
@@ -242,10 +255,11 @@ static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, 
         a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
         a.xcnt = (const long long *)(base + nt * (sizeof(double) + sizeof(long long)) + p.nbatch * sizeof(double));
     }
+    set_lag(a, ws, p, 1, lag_tag, lag_out, lag_prev);
     for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
-        dim3 grid((unsigned)a.nwg, (unsigned)nm, 1), block(256, 1, 1);
+        dim3 grid((unsigned)a.nwg + (lag_tag ? 1u : 0u), (unsigned)nm, 1), block(256, 1, 1);
         (void)block;
         xinv_launch_fusedbih(per, pl.bih_zbe, grid, st, a, nullptr);
     }
