@@ -59,6 +59,10 @@ extern "C" {
                                     call (DMA at PCIe rate).  Off by default: only for buffers that stay
                                     mapped afterwards (see xinv_host.h)                           */
 
+#define XINV_FLAG_NO_PIPE 16     /* standard form with per-row A and C: keep the four sweeps of a pass inside
+                                    one wavefront (k_fused2d) instead of pipelining them across the four
+                                    wavefronts of a workgroup (k_pipe2d)                          */
+
 #define XINV_MAX_DEVICES 16
 
 typedef struct xinv_options {

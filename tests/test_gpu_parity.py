@@ -27,8 +27,12 @@ PATH_COLOUR, PATH_FUSED = 1, 2
 
 
 def assert_same(S, fl, So, flo, what=''):
-    assert np.array_equal(S, So), '%s: S differs, max |d| = %g at %d points' % (
-        what, np.nanmax(np.abs(S - So)), int((S != So).sum()))
+    if not np.array_equal(S, So):
+        d = (S != So)
+        axes = [np.where(d.any(axis=tuple(a for a in range(d.ndim) if a != k)))[0] for k in range(d.ndim)]
+        where = ' x '.join('%d..%d (%d)' % (a.min(), a.max(), len(a)) for a in axes)
+        raise AssertionError('%s: S differs, max |d| = %g at %d points, index ranges %s' % (
+            what, np.nanmax(np.abs(S - So)), int(d.sum()), where))
     assert fl[2] == flo[2], '%s: loop index %r vs oracle %r' % (what, fl[2], flo[2])
     assert fl[0] == flo[0]
     if np.isnan(flo[1]):

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "xinv_fused.h"
+#include "xinv_pipe2d.h"
 #include "xinv_fused3d.h"
 #include "xinv_fused3dg.h"
 #include "xinv_fusedbih.h"
@@ -19,6 +20,8 @@ XINV_HIDDEN int xinv_launch_fused2d_gen(bool al, bool ext, unsigned um, int K, d
                                         hipStream_t st, const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused2d_std2dt(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                                            hipStream_t st, const FusedArgs &a, int *occ);
+// wave-pipelined four-sweep pass (standard form, per-row A and C): one tile per 256-thread workgroup
+XINV_HIDDEN int xinv_launch_pipe2d(bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused9(bool gen, int K, bool al, bool ext, dim3 grid, hipStream_t st,
                                    const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 grid, hipStream_t st,

@@ -100,6 +100,7 @@ struct FusedArgs {
     int ntl;                   // entries per member (multiple of 4); nwg = ntl / 4
     const double *xsum;        // [nbatch] sum |S| over the skipped tiles (S != undef)
     const long long *xcnt;     // [nbatch] their sample count
+    const void *rowf;          // k_pipe2d: [nbatch][yc] per-row factors (RowFac, xinv_pipe2d.h)
 };
 
 template <class F, int... U>

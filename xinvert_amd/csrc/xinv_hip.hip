@@ -403,6 +403,20 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                 }
             }
         }
+        // Four sweeps per pass of the standard form with per-row A and C: pipelined across the four wavefronts
+        // of a workgroup (xinv_pipe2d.h) -- a quarter of the tiles, four times as tall, half the recomputed halo.
+        static const bool pipe_env = [] { const char *e = getenv("XINV_PIPE"); return !e || atoi(e) != 0; }();
+        pl.pipe = pipe_env && !(opt.flags & XINV_FLAG_NO_PIPE) && p.kind == KIND_STD2D && pl.um == 3u && pl.K == 4;
+        pl.tpw = pl.pipe ? 1 : 4;
+        if (pl.pipe) {
+            rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)p.nbatch * p.yc * sizeof(RowFac));
+            if (rc) return rc;
+            RowFactorArgs ra;
+            memset(&ra, 0, sizeof ra);
+            ra.A = p.c[0]; ra.sA = p.sc[0]; ra.C = p.c[2]; ra.sC = p.sc[2];
+            ra.yc = p.yc; ra.xc = p.xc; ra.sc_ = p.sc_; ra.rowf = (RowFac *)ws->d_rowf;
+            hipLaunchKernelGGL(k_row_factor, dim3(cdiv(p.yc, 256), (unsigned)p.nbatch, 1), dim3(256), 0, st, ra);
+        }
         // Rows per tile (see the cost model below).
         pl.even_split = false;
         if (opt.rows_per_tile > 0) {
@@ -421,20 +435,21 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             int occ = 2;                                   // workgroups of the chosen variant per CU
             {
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-                fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
-                               st, dummy, &occ);
+                if (pl.pipe) xinv_launch_pipe2d(pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
+                else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
+                                    st, dummy, &occ);
             }
             // (pl.lone, set with K above: with one or two vector streams a second workgroup per CU
             // fills idle issue slots; with four or more a pair runs no faster than one, and tall
             // tiles (less halo) win -- 2000x2000 general form, A C G streamed: 40-row tiles 38.3 us,
             // 17-row tiles 44.0 us)
-            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, 128 - 4 * pl.K), p.nbatch, pl.K, occ, pl.lone);
+            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, 128 - 4 * pl.K), p.nbatch, pl.K, occ, pl.lone, pl.pipe);
             pl.nrb = (int)best;
             pl.even_split = true;
             pl.RY = (int)cdiv(p.yc, pl.nrb);
         }
         // workgroups per member with the narrowest strips any K uses: sizes the partials
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, pl.tpw) + 1;
         if (pl.even_split && !(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
             rc = plan_tile_skip(p, pl, ws, st, opt);
             if (rc) return rc;
@@ -555,7 +570,8 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
                                                     : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K);
-    const int64_t wg_member = pl.skip ? pl.ntl / 4 : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, 4);
+    const int tpw = (pl.path == XINV_PATH_FUSED && pl.pipe) ? 1 : 4;
+    const int64_t wg_member = pl.skip ? pl.ntl / tpw : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, tpw);
     // ... and only where a launch is one or two rounds of workgroups: with many rounds (64 Gill-Matsuno
     // members: 3.97e11 without, 3.73e11 with) the in-kernel reducer's wait already hides behind other tiles.
     const bool lag_cand = lag_env && pl.path == XINV_PATH_FUSED && wg_member >= 32 &&

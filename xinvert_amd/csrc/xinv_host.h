@@ -63,6 +63,7 @@ struct Workspace {
     int *d_list = nullptr; size_t d_list_cap = 0;               // [nbatch][ntl] then [nbatch][nskip]
     int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
     double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
+    void *d_rowf = nullptr; size_t d_rowf_cap = 0;              // k_pipe2d: per-row factors [nbatch][yc] (RowFac)
 };
 
 static std::mutex g_ws_mutex;

@@ -22,6 +22,8 @@ struct Plan {
     int ntl, nskip;          // list entries per member (active, multiple of 4 / skipped)
     int skip_pct;            // share of wave-tiles skipped, percent
     double lone = 1.6;       // planner: cost of a workgroup alone on its CU relative to one of a pair
+    bool pipe;               // K == 4 passes run the wave-pipelined kernel (k_pipe2d): one tile per workgroup
+    int tpw;                 // wave-tiles per workgroup of the planned kernel: 4, or 1 with `pipe`
     bool lag;                // 5-point 2-D kernels: norm + stop rule evaluated by k_norm_reduce_lag on a second stream,
                              // one pass behind the sweeps (three S buffers); see run_sweeps
 };
@@ -103,10 +105,12 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.ctl = ws->ctl;
     a.stop = p.stop;
     a.psum = (unsigned long long *)ws->partials;
+    const bool pipe = pl.pipe && K == pl.K;          // wave-pipelined pass: one tile per workgroup
+    if (pipe) { a.nwg = a.nstrip * a.nrb; a.rowf = ws->d_rowf; }
     if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
         a.tile_list = ws->d_list;
         a.ntl = pl.ntl;
-        a.nwg = pl.ntl / 4;
+        a.nwg = pl.ntl / pl.tpw;
         char *base = (char *)ws->d_tsum;
         const size_t nt = (size_t)p.nbatch * pl.nskip;
         a.xsum = (const double *)(base + nt * (sizeof(double) + sizeof(long long)));
@@ -117,6 +121,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)a.nwg + (lag_tag ? 1u : 0u), (unsigned)nm, 1), block(256, 1, 1);
+        if (pipe) { xinv_launch_pipe2d(pl.aligned, a.ext != 0, grid, st, a, nullptr); continue; }
         if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
             return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     }
@@ -416,27 +421,33 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
     return XINV_OK;
 }
 
+static int pipe_occ_cap();
 // Number of row blocks for the fused 2-D kernels.  Tall tiles amortise the 4K recomputed halo
 // rows, but every CU should hold the same number of workgroups: `occ` of the chosen variant fit
 // per CU (register-limited, queried from the runtime).  Minimise (workgroups per CU, in rounds of
 // 256*occ resident ones) x (steps per tile); rows are then split evenly over the blocks.
-static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int K, int occ, double lone = 1.6)
+static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int K, int occ, double lone = 1.6,
+                                 bool pipe = false)
 {
-    occ = std::max(1, std::min(occ, 3));
-    const int64_t cap = 256 * (int64_t)occ, period = 2 * K + 2;
+    occ = std::max(1, std::min(occ, pipe ? pipe_occ_cap() : 3));
+    const int64_t cap = 256 * (int64_t)occ, period = pipe ? 4 : 2 * K + 2;
     int64_t best = 1; double best_cost = 1e300;
-    const int64_t nmin = std::max<int64_t>(1, cdiv(yc, 128)), nmax = std::max<int64_t>(nmin, yc / 4);
+    const int64_t nmin = std::max<int64_t>(1, cdiv(yc, pipe ? 512 : 128)), nmax = std::max<int64_t>(nmin, yc / 4);
     for (int64_t nr = nmin; nr <= nmax; nr++) {
         const int64_t rows = cdiv(yc, nr) + 1;                     // +1: even rounding
-        const int64_t steps = cdiv(rows + 4 * K, period) * period;
-        const int64_t wgs = (int64_t)cdiv(nstrip * nr, 4) * nbatch;
+        const int64_t steps = pipe ? cdiv(rows + 4 + 3 * XINV_PIPE_LAG, 8) * 8
+                                   : cdiv(rows + 4 * K, period) * period;
+        const int64_t wgs = (int64_t)cdiv(nstrip * nr, pipe ? 1 : 4) * nbatch;
         // rounds of `cap` resident workgroups; inside a round a CU holds ceil(w/256) of them,
         // and a lone workgroup on a CU leaves issue slots idle (charged like `lone`: 1.6 for the
         // issue-bound variants with one or two vector streams, ~1 for the bandwidth-bound ones)
         const int64_t rounds = cdiv(wgs, cap);
         const int64_t w_last = wgs - (rounds - 1) * cap;
-        const double full = (occ == 1) ? lone : (double)occ;
-        const double last = (w_last <= 256) ? lone : (double)cdiv(w_last, 256);
+        // (pipelined kernel, measured at 3600x1800: a step of n workgroups on a CU costs ~1.5 + n -- 2, 3, 4
+        //  per CU: 0.346, 0.445, 0.543 us -- the wavefronts wait for each other at the step barriers, and more
+        //  of them per SIMD fill the gaps)
+        const double full = pipe ? 1.5 + occ : ((occ == 1) ? lone : (double)occ);
+        const double last = pipe ? 1.5 + (double)cdiv(w_last, 256) : ((w_last <= 256) ? lone : (double)cdiv(w_last, 256));
         const double cost = ((double)(rounds - 1) * full + last) * (double)steps;
         if (cost <= best_cost * 1.0001) { best_cost = std::min(cost, best_cost); best = nr; }   // ties: more, shorter tiles
     }
@@ -445,15 +456,24 @@ static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int
 
 // Cost of a fused 2-D launch in (workgroups per CU) x (steps per tile) units -- the model behind
 // choose_row_blocks, shared with the masked-tile planner.
-static double tile_cost(int64_t wgs, int64_t rows, int K, int occ, double lone = 1.6)
+// (pipelined kernel: up to XINV_PIPE_OCC workgroups -- one wavefront each per SIMD -- share a CU)
+static int pipe_occ_cap()
 {
-    occ = std::max(1, std::min(occ, 3));
-    const int64_t cap = 256 * (int64_t)occ, period = 2 * K + 2;
-    const int64_t steps = cdiv(rows + 1 + 4 * K, period) * period;
+    static const int cap = [] { const char *e = getenv("XINV_PIPE_OCC"); return e ? std::max(1, atoi(e)) : 5; }();
+    return cap;
+}
+
+static double tile_cost(int64_t wgs, int64_t rows, int K, int occ, double lone = 1.6, bool pipe = false)
+{
+    occ = std::max(1, std::min(occ, pipe ? pipe_occ_cap() : 3));
+    const int64_t cap = 256 * (int64_t)occ, period = pipe ? 4 : 2 * K + 2;
+    // (pipelined: the last wavefront starts 3 x LAG steps late and enters RY + 4 rows)
+    const int64_t steps = pipe ? cdiv(rows + 1 + 4 + 3 * XINV_PIPE_LAG, 8) * 8
+                               : cdiv(rows + 1 + 4 * K, period) * period;
     const int64_t rounds = std::max<int64_t>(1, cdiv(wgs, cap));
     const int64_t w_last = wgs - (rounds - 1) * cap;
-    const double full = (occ == 1) ? lone : (double)occ;
-    const double last = (w_last <= 256) ? lone : (double)cdiv(w_last, 256);
+    const double full = pipe ? 1.5 + occ : ((occ == 1) ? lone : (double)occ);
+    const double last = pipe ? 1.5 + (double)cdiv(w_last, 256) : ((w_last <= 256) ? lone : (double)cdiv(w_last, 256));
     return ((double)(rounds - 1) * full + last) * (double)steps;
 }
 
@@ -469,9 +489,12 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
 {
     pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0;
     const bool forced = (opt.flags & XINV_FLAG_FORCE_TILE_SKIP) != 0;
+    const int tpw = pl.pipe ? 1 : 4;                              // wave-tiles per workgroup
     const int K = pl.K, UW = UW_ ? UW_ : 128 - 4 * K;            // 9-point kernel: 128 - 8K owned columns
     const int nstrip = (int)cdiv(p.xc, UW);
-    if (!forced && ((int64_t)nstrip * pl.nrb * p.nbatch < 1024 || (int64_t)nstrip * pl.nrb < 64 || p.nbatch > 64))
+    const int64_t wscale = 4 / tpw;                       // (thresholds in wavefronts: a pipelined tile has four)
+    if (!forced && ((int64_t)nstrip * pl.nrb * p.nbatch * wscale < 1024 || (int64_t)nstrip * pl.nrb * wscale < 64 ||
+                    p.nbatch > 64))
         return XINV_OK;                                   // small problems: nothing to balance
     const int64_t yc = p.yc, nb = p.nbatch;
     const int64_t cells = yc * nstrip;
@@ -527,7 +550,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
                 const int *q = &pre[(size_t)(m * nstrip * (yc + 1))];
                 for (int s = 0; s < nstrip; s++, q += yc + 1) c += (q[y1] - q[y0] > 0) ? 1 : 0;
             }
-            wgs += cdiv(c, 4); mx = std::max(mx, c);
+            wgs += cdiv(c, tpw); mx = std::max(mx, c);
         }
         if (maxact) *maxact = mx;
         return wgs;
@@ -535,24 +558,26 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     int occ = occ_ > 0 ? occ_ : 2;
     if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-        fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
+        if (pl.pipe) xinv_launch_pipe2d(pl.aligned, ext, dim3(1), st, dummy, &occ);
+        else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
     }
-    const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb, cdiv(yc, pl.nrb), K, occ, pl.lone);
+    const bool pp = pl.pipe;
+    const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, tpw) * nb, cdiv(yc, pl.nrb), K, occ, pl.lone, pp);
     // candidates: the row split that brings the ACTIVE workgroups back to the default count sits
     // near nrb / (active share); search a window around it
     int best = pl.nrb; double best_cost = 1e300;
     int lo = pl.nrb, hi = pl.nrb;
     if (!forced && opt.rows_per_tile == 0 && !fixedRB) {
         const int64_t w0 = active_wgs(pl.nrb, nullptr);
-        const double share = std::max(0.05, (double)w0 / (double)((int64_t)cdiv((int64_t)nstrip * pl.nrb, 4) * nb));
+        const double share = std::max(0.05, (double)w0 / (double)((int64_t)cdiv((int64_t)nstrip * pl.nrb, tpw) * nb));
         const double centre = (double)pl.nrb / share;
         const int64_t cap_rows = std::max<int64_t>(pl.nrb, yc / 4);
         lo = (int)std::min<int64_t>(cap_rows, std::max<int64_t>(pl.nrb, (int64_t)(centre * 0.85)));
         hi = (int)std::min<int64_t>(cap_rows, std::max<int64_t>(lo, (int64_t)(centre * 1.10) + 1));
     }
-    best_cost = tile_cost(active_wgs(pl.nrb, nullptr), cdiv(yc, pl.nrb), K, occ, pl.lone);   // keep the split, skip only
+    best_cost = tile_cost(active_wgs(pl.nrb, nullptr), cdiv(yc, pl.nrb), K, occ, pl.lone, pp);   // keep the split, skip only
     for (int nrb = lo; nrb <= hi; nrb++) {
-        const double c = tile_cost(active_wgs(nrb, nullptr), cdiv(yc, nrb), K, occ, pl.lone);
+        const double c = tile_cost(active_wgs(nrb, nullptr), cdiv(yc, nrb), K, occ, pl.lone, pp);
         if (c < best_cost) { best_cost = c; best = nrb; }
     }
     if (!forced && best_cost > 0.95 * cost0) return XINV_OK;            // (fixed split: skipping must save 5 % of the workgroups)
@@ -561,7 +586,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     int64_t maxact = 0;
     active_wgs(best, &maxact);
     const int64_t ntiles = (int64_t)nstrip * best;
-    const int ntl = (int)(4 * std::max<int64_t>(1, cdiv(maxact, 4)));
+    const int ntl = (int)(tpw * std::max<int64_t>(1, cdiv(maxact, tpw)));
     int64_t maxskip = 0, nskipped = 0;
     std::vector<std::vector<int>> act((size_t)nb), skp((size_t)nb);
     for (int64_t m = 0; m < nb; m++) {
@@ -607,7 +632,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     pl.skip_pct = (int)((100 * nskipped) / (ntiles * nb));
     if (!fixedRB) {
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX) * pl.nrb, 4) + 1;
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX) * pl.nrb, tpw) + 1;
     }
     return XINV_OK;
 }

@@ -1,0 +1,369 @@
+// xinv_pipe2d.h -- wave-pipelined streaming red-black SOR pass: four sweeps per pass over HBM, one sweep
+// per WAVEFRONT (gfx950).  Standard form with per-row A and C (lat-lon Poisson), B == 0.
+//
+// k_fused2d applies K sweeps inside one wavefront; its tile count is tied to the number of wavefront slots
+// (256 CUs x 4 SIMDs x 2), so at 3600x1800 a tile owns ~23 rows and marches 40: half of the point updates
+// it executes are recomputed halo, and the kernel is bound by the fp64 VALU.  Here a workgroup of four
+// wavefronts owns ONE tile (128 columns x RY rows) and the sweeps are pipelined ACROSS the wavefronts:
+// wavefront p applies sweep p+1 to the rows as they stream by and hands every finished row to wavefront
+// p+1 through a ring of rows in LDS.  The same number of wavefronts now needs a quarter of the tiles, each
+// four times as tall (~90 rows at 3600x1800), so the 2K halo rows per side weigh 1.2 instead of 1.7 -- and
+// because every wavefront runs its own loop, sweep s only marches the rows that can still reach an owned
+// row (RY + 2(2K - 2(s-1)) entering rows: the triangle k_fused2d could not skip without breaking its
+// schedule falls away by construction).
+//
+// Schedule.  With r the row that enters wavefront p's four-row register window at a step, the wavefront
+// updates its red points on row r-1 and its black points on row r-2 (sweep p+1), and row r-2 leaves: into
+// the ring (p < 3) or to HBM (p = 3, owned rows only).  Wavefront p+1 asks for that row one step later and
+// enters it the step after (LDS latency hidden behind a step of arithmetic), so it runs LAG = 6 steps
+// behind wavefront p.  One `s_waitcnt lgkmcnt(0); s_barrier` per step keeps the four in step (no vmcnt
+// wait: the global prefetch of wavefront 0 stays in flight across barriers).  Wavefront 0 reads S and every
+// wavefront reads the forcing rows it needs from global memory (the later ones hit in L2) PF rows ahead.
+//
+// The relaxation factor optArg / ((A[j+1] + A[j]) ratioSqr + 2 C[j]) is uniform along a row and the same
+// for every sweep of the solve: k_row_factor evaluates it once per solve (same expression, same bits) with
+// the row's share of the update predicate, and the kernel loads it per row instead of dividing.
+//
+// Operands and operation order per point are those of k_fused2d (FusedStd2D::upd): results are bitwise
+// equal to it and to the oracle.  Norm partials: wavefront p publishes the tile's share of sweep p+1.
+#pragma once
+#include "xinv_fused.h"
+
+#define XINV_PIPE_P 4             /* wavefronts per workgroup = sweeps per pass */
+#ifndef XINV_PIPE_B
+#define XINV_PIPE_B 2             /* steps per workgroup barrier (1 or 2; the four-row LDS ring allows no more) */
+#endif
+#define XINV_PIPE_LAG (XINV_PIPE_B + 5)   /* steps wavefront p+1 runs behind wavefront p */
+#ifndef XINV_PIPE_ROT
+#define XINV_PIPE_ROT 1
+#endif
+#define XINV_PIPE_NS 4            /* ring rows per hand-over */
+#ifndef XINV_PIPE_PF0
+#define XINV_PIPE_PF0 4           /* rows in flight from HBM, wavefront 0 (S and F) */
+#endif
+#ifndef XINV_PIPE_PF
+#define XINV_PIPE_PF 4            /* rows of F in flight, wavefronts 1..3 */
+#endif
+
+// what a row of the lat-lon standard form needs besides S and F: 32 bytes, one load per row and wavefront
+struct RowFac { double a, c, rq, rok; };   // A[j], C[j], relaxation factor of row j, row predicate (1.0 / 0.0:
+                                           // all 64 bits are read, so no half of a load in flight is ever reused)
+
+struct RowFactorArgs {
+    const double *A, *C;
+    int64_t sA, sC;               // batch strides (0 = shared)
+    int64_t yc, xc;
+    XinvScal sc_;
+    RowFac *rowf;                 // [nbatch][yc]
+};
+
+#ifdef XINV_AUX_KERNELS
+// once per solve: per-row relaxation factor and row part of the update predicate (numbas.py:343-369 with
+// A and C constant along x; FusedStd2D::derive, hoisted branch)
+__global__ __launch_bounds__(256) void k_row_factor(RowFactorArgs a)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (j >= a.yc) return;
+    const double u = a.sc_.undef;
+    RowFac f;
+    f.a = a.A[m * a.sA + j * a.xc]; f.c = a.C[m * a.sC + j * a.xc];
+    f.rq = 0.0; f.rok = 0.0;
+    if (j >= 1 && j <= a.yc - 2) {
+        const double aP = a.A[m * a.sA + (j + 1) * a.xc], a0 = f.a, c = f.c;
+        f.rq = a.sc_.optArg / ((aP + a0) * a.sc_.ratioSqr + (c + c));
+        f.rok = ((aP != u) && (a0 != u) && (c != u)) ? 1.0 : 0.0;
+    }
+    a.rowf[m * a.yc + j] = f;
+}
+#endif
+
+__device__ __forceinline__ void xinv_pipe_barrier()
+{
+#if defined(XINV_PIPE_NOBAR)       /* timing experiment only (results are wrong): what do the barriers cost? */
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// per-row factors through the scalar unit: the constant address space makes a uniform load an s_load
+// (one s_load_dwordx8 per row into SGPRs: no vector registers, no VALU)
+typedef const double __attribute__((address_space(4))) *xinv_cdouble_ptr;
+// global address space spelled out: a pointer that has passed through an asm constraint is otherwise
+// treated as generic (flat_load, which also counts on lgkmcnt)
+typedef const char __attribute__((address_space(1))) *xinv_gcptr;
+typedef char __attribute__((address_space(1))) *xinv_gptr;
+typedef double xinv_v2d __attribute__((ext_vector_type(2)));          // (double2 is a class: no address-space overloads)
+typedef const xinv_v2d __attribute__((address_space(1))) *xinv_gcd2ptr;
+typedef const double __attribute__((address_space(1))) *xinv_gcdptr;
+typedef xinv_v2d __attribute__((address_space(1))) *xinv_gd2ptr;
+typedef double __attribute__((address_space(1))) *xinv_gdptr;
+
+// one wavefront of the pipeline: sweep PW+1 on the rows of the tile [yu0, yu1).
+// Registers: ONE ring of R = PF + 4 row records (S, F, per-row factors).  Row r is loaded straight into
+// record r mod R, PF steps before it enters the window (the per-row factors two steps before), and stays
+// there until it has left the window four steps later; the march is unrolled R steps, so every record index
+// is a compile-time register name and no row is ever copied (a separate prefetch ring made the compiler
+// rotate registers across the loop back-edge: ~80 v_mov and a full `s_waitcnt vmcnt(0)` per iteration).
+// Row arithmetic is 32-bit (scalar compares; the 64-bit ones are VALU instructions on this target) and
+// every global access is `uniform row base + 32-bit lane offset` (no per-load address arithmetic).
+template <bool AL, bool EXT, int PW, int PF>
+__device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
+                                               const LaneCols &lc, int64_t st0, int lane,
+                                               double2 (*ring)[XINV_PIPE_NS][XINV_WAVE], int gtot,
+                                               double &acc, int &cnt)
+{
+    constexpr int P = XINV_PIPE_P, H = 2 * P, D = 4, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
+    constexpr int R = PF + D;                            // row records; also the unroll period
+    constexpr int PFR = 2;                               // steps the per-row factors are requested ahead
+    constexpr unsigned UM = 3u;
+    static_assert(R % D == 0 && R % B == 0, "the unroll period must keep row parity, ring slots and barriers compile-time");
+    using M = FusedStd2D;
+    const int ycr = (int)a.yc;
+    const unsigned rowbytes = (unsigned)a.xc * 8u;       // (a row is shorter than 4 GiB)
+    const double u = a.sc_.undef;
+    const xinv_gcptr srcS = (xinv_gcptr)(uintptr_t)(a.src + m * a.sS);
+    const xinv_gptr dstS = (xinv_gptr)(uintptr_t)(a.dst + m * a.sS);
+    const xinv_gcptr cF = (xinv_gcptr)(uintptr_t)(a.c[2] + m * a.sc[2]);
+    const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(reinterpret_cast<const RowFac *>(a.rowf) + m * a.yc);
+    unsigned lo0 = (unsigned)lc.l0 * 8u, lo1 = (unsigned)lc.l1 * 8u;           // byte offsets of the lane's columns
+    unsigned so0 = lc.use_x ? (unsigned)st0 * 8u : 0u;                          // store offset of .x (owned lanes)
+    unsigned so1 = lc.use_y ? (unsigned)(st0 + 1) * 8u : 0u;
+
+    const int in_lo = yu0 - H + 2 * PW;                  // first / last row entering this wavefront's window
+    const int in_hi = yu1 - 1 + H - 2 * PW;
+
+    double2 sw[R];
+    CoefWin<3, R> cw;
+    double rokw[R];
+#pragma unroll
+    for (int t = 0; t < R; t++) {
+        sw[t] = make_double2(0.0, 0.0);
+        cw.rq[t] = 0.0; cw.mx[t] = 0u; cw.my[t] = 0u; rokw[t] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) { cw.v[q][t] = make_double2(0.0, 0.0); cw.s[q][t] = 0.0; }
+    }
+
+    // a row of the lane's two columns: uniform row address (kept in SGPRs: the asm pins it, so that the
+    // access is `global_load v, v_lane_offset, s[row]` and not a 64-bit vector address computed per load)
+    auto ldrow = [&](xinv_gcptr base, uint64_t boff) {
+        xinv_gcptr row = base + boff;
+        asm("" : "+s"(row));
+        asm("" : "+v"(lo0));                             // (laundered in place, so that the zero-extension stays in this
+        if (!AL) asm("" : "+v"(lo1));                    //  block: instruction selection then sees sgpr + zext(vgpr32))
+        double2 v;
+        if (AL) { const xinv_v2d t = *(xinv_gcd2ptr)(row + lo0); v.x = t.x; v.y = t.y; }
+        else { v.x = *(xinv_gcdptr)(row + lo0); v.y = *(xinv_gcdptr)(row + lo1); }
+        return v;
+    };
+    // request row r into record `slot` (S from HBM for wavefront 0 only; later wavefronts get it through LDS)
+    auto request = [&](int r, auto stag) {
+        constexpr int slot = decltype(stag)::value;
+        const unsigned rr = (unsigned)min(max(r, 0), ycr - 1);
+        const uint64_t boff = (uint64_t)rr * rowbytes;
+        if (PW == 0) sw[slot] = ldrow(srcS, boff);
+        cw.v[2][slot] = ldrow(cF, boff);
+    };
+    auto request_rf = [&](int r, auto stag) {
+        constexpr int slot = decltype(stag)::value;
+        const unsigned rr = (unsigned)min(max(r, 0), ycr - 1);    // (rows 0 and yc-1 carry rok = 0: so do the clamped ones)
+        const xinv_cdouble_ptr q = rowf + (uint64_t)rr * 4u;
+        cw.s[0][slot] = q[0]; cw.s[1][slot] = q[1]; cw.rq[slot] = q[2]; rokw[slot] = q[3];
+    };
+    // (in row order, as in the loop: the vmcnt waits of the loop are computed against the worst path into it)
+    xinv_unroll_steps([&](auto ttag) { request(in_lo + decltype(ttag)::value, ttag); asm volatile("" ::: "memory"); },
+                      std::make_integer_sequence<int, PF>{});
+    xinv_unroll_steps([&](auto ttag) { request_rf(in_lo + decltype(ttag)::value, ttag); },
+                      std::make_integer_sequence<int, PFR>{});
+
+    // global step g of the workgroup = local step + LAG * PW; a barrier closes every B-th global step
+    int g = 0;
+    for (; g < LAG * PW; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
+    if (PW > 0) sw[0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][lane];        // row in_lo
+
+    for (int rb_ = in_lo; rb_ <= in_hi; rb_ += R) {
+        xinv_unroll_steps([&](auto utag) {
+            constexpr int U = decltype(utag)::value;     // record of the entering row r
+            constexpr int X = (U & 1) ? 0 : 1;
+#define SLOT(w) ((U - (w) + 4 * R) % R)
+#define RSLOT(w) ((2 * PW + U - (w) + 64 * XINV_PIPE_NS) % XINV_PIPE_NS)  /* LDS ring slot of row r - w */
+            const int r = rb_ + U;
+            request(r + PF, std::integral_constant<int, (U + PF) % R>{});
+            request_rf(r + PFR, std::integral_constant<int, (U + PFR) % R>{});
+            if (PW > 0) sw[(U + 1) % R] = ring[PW - 1][RSLOT(-1)][lane];   // row r+1: written B+1 steps ago
+            {   // row r-1: update predicate and F * delxSqr, once for both half-sweeps
+                constexpr int s1 = SLOT(1);
+                const double fx = cw.v[2][s1].x, fy = cw.v[2][s1].y;
+                const bool rok = rokw[s1] != 0.0;
+                cw.mx[s1] = xinv_lane_word(lc.ok_x && rok && (fx != u));
+                cw.my[s1] = xinv_lane_word(lc.ok_y && rok && (fy != u));
+                cw.v[2][s1].x = fx * a.sc_.delxSqr; cw.v[2][s1].y = fy * a.sc_.delxSqr;
+            }
+            {   // red half-sweep on row r-1
+                const int ja = r - 1;
+                constexpr int sj = SLOT(1), sjp = SLOT(0), sjm = SLOT(2);
+                if (EXT) {
+                    if (ja == 1) fused_extend_fix(sw[sjm], sw[sj], lc, a.tall, u);
+                    if (ja == ycr - 2) fused_extend_fix(sw[sjp], sw[sj], lc, a.tall, u);
+                }
+                double w, e;
+                row_neighbours<X>(sw[sj], w, e);
+                const double v = M::template upd<X, UM, R>(cw, sj, sjp, comp<X>(sw[sj]), comp<X>(sw[sjp]),
+                                                           comp<X>(sw[sjm]), w, e, a.sc_);
+                setc<X>(sw[sj], v);
+            }
+            {   // black half-sweep on row r-2
+                const int jb = r - 2;
+                constexpr int sj = SLOT(2), sjp = SLOT(1), sjm = SLOT(3);
+                double w, e;
+                row_neighbours<X>(sw[sj], w, e);
+                const double v = M::template upd<X, UM, R>(cw, sj, sjp, comp<X>(sw[sj]), comp<X>(sw[sjp]),
+                                                           comp<X>(sw[sjm]), w, e, a.sc_);
+                setc<X>(sw[sj], v);
+                if ((jb >= yu0) && (jb < yu1)) {           // an owned row: its share of mean|S| of this sweep
+                    const double2 t = sw[sj];
+                    const bool cx = lc.use_x & (t.x != u);
+                    const bool cy = lc.use_y & (t.y != u);
+                    acc += (cx ? fabs(t.x) : 0.0);
+                    acc += (cy ? fabs(t.y) : 0.0);
+                    cnt += (cx ? 1 : 0) + (cy ? 1 : 0);
+                }
+                // ---- row r-2 leaves
+                if (PW < P - 1) {
+                    ring[PW][RSLOT(2)][lane] = sw[sj];
+                } else if (jb >= yu0 && jb < yu1) {
+                    const double2 t = sw[sj];
+                    xinv_gptr row = dstS + (uint64_t)(unsigned)jb * rowbytes;
+                    asm("" : "+s"(row));
+                    asm("" : "+v"(so0));
+                    if (!AL) asm("" : "+v"(so1));
+                    if (AL) {
+                        if (lc.use_x) { xinv_v2d tv; tv.x = t.x; tv.y = t.y; *(xinv_gd2ptr)(row + so0) = tv; }
+                    } else {
+                        if (lc.use_x) *(xinv_gdptr)(row + so0) = t.x;
+                        if (lc.use_y) *(xinv_gdptr)(row + so1) = t.y;
+                    }
+                }
+            }
+            if ((LAG * PW + U + 1) % B == 0) xinv_pipe_barrier();
+#undef SLOT
+#undef RSLOT
+        }, std::make_integer_sequence<int, R>{});
+        g += R;
+    }
+    for (; g < gtot; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
+}
+
+template <bool AL, bool EXT>
+__global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
+{
+    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = 128 - 2 * H, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
+    __shared__ double2 ring[P - 1][XINV_PIPE_NS][XINV_WAVE];
+
+    unsigned tag;
+    int T;
+    double acc = 0.0;
+    int cnt = 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int pwi;
+    {
+    // The per-row factors are read through the scalar data cache, and k_row_factor rewrote them (same
+    // workspace address) for this solve: the cache is NOT reliably invalidated between kernels -- measured,
+    // 4 of 14 runs of the GPU suite returned a whole slice relaxed with the previous solve's factors on the
+    // first launch of a kernel variant, 0 of 14 with this invalidate (profiles/r02_pipe2d_bringup.txt).
+    __builtin_amdgcn_s_dcache_inv();
+    const FusedArgs &a = a_;
+    const int64_t m = a.member0 + blockIdx.y;
+    XinvCtl *ctl = a.ctl + m;
+    if (!a.force && ctl->done) return;
+    if (a.lag && (int)blockIdx.x == a.nwg) { xinv_lag_reduce_prev(a, ctl, m); return; }
+    tag = a.lag ? a.tag : ctl->seq;
+
+    const int NB = a.nwg;
+    {
+        const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
+        T = xcd * q + (xcd < rem ? xcd : rem) + idx;
+    }
+    // which sweep this wavefront applies: rotated from workgroup to workgroup, so that the workgroups sharing
+    // a CU do not all start (and drain) their pipelines on the same SIMD
+#if XINV_PIPE_ROT
+    pwi = (wave + (int)(blockIdx.x >> 8)) & (P - 1);       // (dispatch order: 8 XCDs x 32 CUs, then the next round)
+#else
+    pwi = wave;
+#endif
+    int wt = T;
+    bool active = wt < a.nstrip * a.nrb;
+    if (a.tile_list) {
+        wt = a.tile_list[m * a.ntl + T];
+        active = wt >= 0;
+        wt = active ? wt : 0;
+    }
+    const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
+    const int64_t xc = a.xc, yc = a.yc;
+    const int64_t xu0 = (int64_t)strip * UW;
+    int yu0, yu1;
+    if (a.RY > 0) {
+        yu0 = rb * a.RY;
+        yu1 = (yu0 + a.RY < (int)yc) ? yu0 + a.RY : (int)yc;
+    } else {
+        yu0 = (int)((((int64_t)rb * yc) / a.nrb) & ~(int64_t)1);
+        yu1 = (rb + 1 == a.nrb) ? (int)yc : (int)((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
+    }
+    const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
+    const int64_t st0 = xu0 - H + 2 * lane;
+
+    if (active) {
+        // global steps every wavefront goes through: the longest of the four schedules, whole barrier periods
+        const int ry = yu1 - yu0;
+        int gtot = 0;
+#pragma unroll
+        for (int pw = 0; pw < P; pw++) {
+            const int per = (pw == 0 ? XINV_PIPE_PF0 : XINV_PIPE_PF) + 4;      // unroll period of that wavefront
+            const int n = ry + 2 * H - 4 * pw;
+            const int g = LAG * pw + ((n + per - 1) / per) * per;
+            gtot = g > gtot ? g : gtot;
+        }
+        gtot = ((gtot + B - 1) / B) * B;
+        switch (pwi) {
+        case 0: xinv_pipe_wave<AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        case 1: xinv_pipe_wave<AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        case 2: xinv_pipe_wave<AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        default: xinv_pipe_wave<AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        }
+    }
+    }
+    // What follows needs a dozen kernel arguments the march does not: read them again from the argument
+    // block here (through a pointer the optimiser cannot see through) instead of carrying them in SGPRs
+    // across the march, where they pushed loop values out into VGPR lanes (v_readlane in every step).
+    const FusedArgs __attribute__((address_space(4))) *kp =
+        (const FusedArgs __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp) :: "memory");
+    if (kp->no_ctl) return;
+    const int64_t m = kp->member0 + blockIdx.y;
+    XinvCtl *ctl = kp->ctl + m;
+    const int NB = kp->nwg;
+    struct { unsigned long long *psum; const double *xsum; const long long *xcnt; int lag; XinvStop stop; } a;
+    a.psum = kp->psum; a.xsum = kp->xsum; a.xcnt = kp->xcnt; a.lag = kp->lag;
+    a.stop.mxLoop = kp->stop.mxLoop; a.stop.tolerance = kp->stop.tolerance;
+    a.stop.stop_on_zero_norm = kp->stop.stop_on_zero_norm;
+
+    // wavefront `pwi` holds the tile's share of sweep pwi+1: publish it (three tagged words, see xinv_norm_publish)
+    {
+        unsigned long long *pw = a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW;
+        const double ws = xinv_wave_sum(acc);
+        const long long wc = xinv_wave_sum_ll((long long)cnt);
+        if (lane == 0) {
+            const unsigned long long hi = (unsigned long long)tag << 32;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(ws);
+            unsigned long long *q = pw + ((size_t)pwi * NB + T) * XINV_PW;
+            __hip_atomic_store(q + 0, hi | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 1, hi | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 2, hi | (unsigned long long)(unsigned)wc, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.lag || blockIdx.x != gridDim.x - 1) return;
+        __syncthreads();
+        xinv_norm_reduce<K, P>(wave, lane, NB, tag, pw, ctl, a.stop, a.xsum ? a.xsum[m] : 0.0,
+                               a.xcnt ? a.xcnt[m] : 0);
+    }
+}
