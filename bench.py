@@ -151,6 +151,10 @@ def tile_model(s, ny, nx):
     K, RY = s['sweeps_per_launch'], max(1, s['rows_per_tile'])
     if s['path'] != 2 or K < 1:
         return None
+    if s.get('pipelined'):
+        # k_pipe2d: wavefront p marches RY + 4K - 4p rows (p = 0..3) of 128 np columns, 128 np - 4K of them owned
+        np_ = s['pipelined']
+        return (RY + 4 * K - 6.0) * 128.0 * np_ / (RY * (128.0 * np_ - 4 * K))
     D = 2 * K + 2
     steps = -(-(RY + 4 * K) // D) * D
     UW = 128 - 4 * K
@@ -279,7 +283,9 @@ def main():
                 'frac_of_fma_spec': achieved_tf / FP64_FMA_SPEC_TFLOPS,
                 'frac_of_measured_peak': achieved_tf / FP64_VALU_MEASURED_TFLOPS,
                 'useful_flops_per_point_update': UPD_FLOPS[kind],
-                'kernel': ('k_fused2d<FusedStd2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask'])) if kind == 'std2d'
+                'kernel': ('k_pipe2d<NP=%d> (four sweeps per pass, one per wavefront; x-uniform mask=%d)'
+                           % (s['pipelined'], s['xuniform_mask'])) if s.get('pipelined')
+                          else ('k_fused2d<FusedStd2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask'])) if kind == 'std2d'
                           else ('k_fused2d<FusedGen2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask'])) if kind == 'gen2d'
                           else 'k_fused3d',
                 'avg_launch_ms': avg_ms, 'launches': int(launches),
@@ -305,7 +311,8 @@ def main():
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile) and a.config == 'c2' and (a.ny, a.nx) == (1800, 3600) and nb == 1:
             try:
-                traffic = json.load(open(tfile)).get('std2d_spl%d_um%d' % (spl, s['xuniform_mask']))
+                traffic = json.load(open(tfile)).get(('std2d_pipe_um%d' % s['xuniform_mask']) if s.get('pipelined')
+                                                     else 'std2d_spl%d_um%d' % (spl, s['xuniform_mask']))
             except Exception:
                 traffic = None
         roof['traffic'] = traffic

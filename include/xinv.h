@@ -120,6 +120,10 @@ typedef struct xinv_stats {
     double  wall_ms;            /* host-pointer entry points: wall clock of the whole call      */
     int32_t host_chunks;        /* member chunks the call was pipelined over (all devices)      */
     int32_t devices;            /* GPUs the batch was split over                                */
+    int32_t pipelined;          /* fused 2-D path: the full passes ran the wave-pipelined kernel (k_pipe2d:
+                                   one tile per workgroup, one sweep per wavefront); value = column pairs
+                                   per lane (1 or 2), 0 = k_fused2d                              */
+    int32_t pad1_;
 } xinv_stats;
 
 void        xinv_default_options(xinv_options *opt);

@@ -252,6 +252,31 @@ def test_fused_standard_three_and_four_sweeps_per_pass(BCy, BCx, msk, shape, K, 
     assert_same(S[0], fl[0], So, flo, 'fused K=auto %r' % (shape,))
 
 
+@pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'), ('extend', 'fixed')])
+@pytest.mark.parametrize('shape', [(40, 300), (33, 257), (64, 512), (90, 250), (200, 1200)])
+def test_pipelined_pass_equals_single_wavefront_pass(BCy, BCx, shape):
+    """k_pipe2d (four sweeps pipelined across the wavefronts of a workgroup; one or two column pairs per
+    lane) against k_fused2d K = 4 (XINV_FLAG_NO_PIPE) and the oracle: bit for bit, masked tiles skipped or not,
+    several members with their own coefficients, stats.pipelined reporting which kernel ran."""
+    yc, xc = shape
+    if BCx == 'periodic' and xc % 2:
+        pytest.skip('odd-xc periodic seam goes through the colour path')
+    ps = [_uniform2d(rand2d('std2d', yc, xc, BCy, BCx, 0, m & 1, seed=_seed(('pipe', BCy, BCx, shape, m)))) for m in range(3)]
+    ref = [run_oracle(p, 26, 1e-9, COLOUR_2) for p in ps]
+    S0, f0, st0 = run_hip_batched(ps, 26, 1e-9, path=PATH_FUSED, sweeps_per_launch=4, no_pipe=1)
+    assert st0['pipelined'] == 0
+    for np_ in ('1', '2'):
+        import os
+        os.environ['XINV_PIPE_NP'] = np_                  # read once per process by the library: see below
+        for kw in (dict(), dict(rows_per_tile=16), dict(force_tile_skip=1), dict(rows_per_tile=-3)):
+            S, fl, st = run_hip_batched(ps, 26, 1e-9, path=PATH_FUSED, sweeps_per_launch=4, **kw)
+            assert st['pipelined'] in (1, 2) and st['sweeps_per_launch'] == 4, st
+            for m in range(3):
+                assert_same(S[m], fl[m], ref[m][0], ref[m][1], 'pipelined %r member %d %r' % (shape, m, kw))
+            assert np.array_equal(S, S0)
+    os.environ.pop('XINV_PIPE_NP', None)
+
+
 @pytest.mark.parametrize('K', [3, 4])
 @pytest.mark.parametrize('tol', [3e-3, 1e-3, 2e-4, 5e-5])
 def test_fused_early_stop_exact_sweep_deep_passes(K, tol):

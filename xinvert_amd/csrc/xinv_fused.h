@@ -361,12 +361,13 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t row_off, const L
 }
 
 // Lane -> column map of one wavefront's strip: lane owns columns c0 = xu0 - H + 2*lane and c0+1.
+// (np column pairs per lane, this is pair q: k_pipe2d's wide strips; np = 1, q = 0 everywhere else)
 template <bool AL>
 __device__ __forceinline__ LaneCols make_lanecols(int64_t xu0, int H, int UW, int lane, int64_t xc,
-                                                  bool per)
+                                                  bool per, int np = 1, int q = 0)
 {
     LaneCols lc;
-    const int64_t c0 = xu0 - H + 2 * lane, c1 = c0 + 1;
+    const int64_t c0 = xu0 - H + 2 * np * lane + 2 * q, c1 = c0 + 1;
     if (per) {
         int64_t w0 = c0 % xc; if (w0 < 0) w0 += xc;
         int64_t w1 = c1 % xc; if (w1 < 0) w1 += xc;

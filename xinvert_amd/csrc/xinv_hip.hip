@@ -408,6 +408,10 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         static const bool pipe_env = [] { const char *e = getenv("XINV_PIPE"); return !e || atoi(e) != 0; }();
         pl.pipe = pipe_env && !(opt.flags & XINV_FLAG_NO_PIPE) && p.kind == KIND_STD2D && pl.um == 3u && pl.K == 4;
         pl.tpw = pl.pipe ? 1 : 4;
+        // two column pairs per lane (strips of 240 owned columns) where the grid is wide enough to keep the
+        // workgroup count up; XINV_PIPE_NP=1|2 forces the choice
+        const int np_env = [] { const char *e = getenv("XINV_PIPE_NP"); return e ? atoi(e) : 0; }();   // (read per solve: tests switch it)
+        pl.npair = (np_env == 1 || np_env == 2) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
         if (pl.pipe) {
             rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)p.nbatch * p.yc * sizeof(RowFac));
             if (rc) return rc;
@@ -435,7 +439,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             int occ = 2;                                   // workgroups of the chosen variant per CU
             {
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-                if (pl.pipe) xinv_launch_pipe2d(pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
+                if (pl.pipe) xinv_launch_pipe2d(pl.npair, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
                 else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
                                     st, dummy, &occ);
             }
@@ -443,13 +447,16 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             // fills idle issue slots; with four or more a pair runs no faster than one, and tall
             // tiles (less halo) win -- 2000x2000 general form, A C G streamed: 40-row tiles 38.3 us,
             // 17-row tiles 44.0 us)
-            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, 128 - 4 * pl.K), p.nbatch, pl.K, occ, pl.lone, pl.pipe);
+            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, pl.pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * pl.K),
+                                                   p.nbatch, pl.K, occ, pl.lone, pl.pipe);
             pl.nrb = (int)best;
             pl.even_split = true;
             pl.RY = (int)cdiv(p.yc, pl.nrb);
         }
         // workgroups per member with the narrowest strips any K uses: sizes the partials
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, pl.tpw) + 1;
+        // (the shorter tail / redo passes of a pipelined plan run k_fused2d: four 112-column tiles per workgroup)
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
+        if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, XINV_PIPE_UW(pl.npair)) * pl.nrb + 1);
         if (pl.even_split && !(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
             rc = plan_tile_skip(p, pl, ws, st, opt);
             if (rc) return rc;
@@ -569,6 +576,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // Only where a member has many workgroups: the reducing workgroup is one more per member and launch,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
+                           : (pl.path == XINV_PATH_FUSED && pl.pipe) ? XINV_PIPE_UW(pl.npair)
                                                     : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K);
     const int tpw = (pl.path == XINV_PATH_FUSED && pl.pipe) ? 1 : 4;
     const int64_t wg_member = pl.skip ? pl.ntl / tpw : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, tpw);
@@ -808,6 +816,7 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
     t_stats.rows_per_tile = pl.RY;
     t_stats.xuniform_mask = (pl.path == XINV_PATH_FUSED || p.kind == KIND_BIH2D) ? (int32_t)pl.um : 0;
     t_stats.masked_tile_pct = (pl.path == XINV_PATH_FUSED && pl.skip) ? pl.skip_pct : 0;
+    t_stats.pipelined = (pl.path == XINV_PATH_FUSED && pl.pipe) ? pl.npair : 0;
     t_stats.sweep_launches = R.nlaunch;
     t_stats.sweeps_max = sweeps_max;
     t_stats.sweep_ms = R.ms_total;

@@ -24,6 +24,7 @@ struct Plan {
     double lone = 1.6;       // planner: cost of a workgroup alone on its CU relative to one of a pair
     bool pipe;               // K == 4 passes run the wave-pipelined kernel (k_pipe2d): one tile per workgroup
     int tpw;                 // wave-tiles per workgroup of the planned kernel: 4, or 1 with `pipe`
+    int npair;               // `pipe`: column pairs per lane (1 or 2: strips of 112 or 240 owned columns)
     bool lag;                // 5-point 2-D kernels: norm + stop rule evaluated by k_norm_reduce_lag on a second stream,
                              // one pass behind the sweeps (three S buffers); see run_sweeps
 };
@@ -46,6 +47,7 @@ static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 
     return xinv_launch_fused2d_std(al, ext, um, K, grid, block, st, a, occ);
 }
 
+static int pipe_occ_cap();
 static bool ptr_al16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // Lagged norm (run_sweeps): this launch publishes with `lag_tag` into the partial buffer of its parity;
@@ -95,7 +97,8 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.ext = (p.BCy == XINV_BC_EXTEND);
     a.tall = (p.yc > p.xc);
     a.RY = pl.even_split ? 0 : pl.RY;
-    const int UW = 128 - 4 * K;
+    const bool pipe = pl.pipe && K == pl.K;          // wave-pipelined pass: one tile per workgroup
+    const int UW = pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K;
     a.nstrip = (int)cdiv(p.xc, UW);
     a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
     a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
@@ -105,7 +108,6 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.ctl = ws->ctl;
     a.stop = p.stop;
     a.psum = (unsigned long long *)ws->partials;
-    const bool pipe = pl.pipe && K == pl.K;          // wave-pipelined pass: one tile per workgroup
     if (pipe) { a.nwg = a.nstrip * a.nrb; a.rowf = ws->d_rowf; }
     if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
         a.tile_list = ws->d_list;
@@ -121,7 +123,13 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)a.nwg + (lag_tag ? 1u : 0u), (unsigned)nm, 1), block(256, 1, 1);
-        if (pipe) { xinv_launch_pipe2d(pl.aligned, a.ext != 0, grid, st, a, nullptr); continue; }
+        if (pipe) {
+            // (XINV_PIPE_LDSPAD: unused dynamic LDS per workgroup, to cap the workgroups per CU in experiments;
+            //  capping at the planned count changed nothing: the dispatcher already spreads them evenly)
+            static const int pad = [] { const char *e = getenv("XINV_PIPE_LDSPAD"); return e ? std::max(0, atoi(e)) : 0; }();
+            xinv_launch_pipe2d(pl.npair, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad);
+            continue;
+        }
         if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
             return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     }
@@ -421,7 +429,6 @@ static int launch_colour_sweep(const Problem &p, const Plan &pl, Workspace *ws, 
     return XINV_OK;
 }
 
-static int pipe_occ_cap();
 // Number of row blocks for the fused 2-D kernels.  Tall tiles amortise the 4K recomputed halo
 // rows, but every CU should hold the same number of workgroups: `occ` of the chosen variant fit
 // per CU (register-limited, queried from the runtime).  Minimise (workgroups per CU, in rounds of
@@ -490,7 +497,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0;
     const bool forced = (opt.flags & XINV_FLAG_FORCE_TILE_SKIP) != 0;
     const int tpw = pl.pipe ? 1 : 4;                              // wave-tiles per workgroup
-    const int K = pl.K, UW = UW_ ? UW_ : 128 - 4 * K;            // 9-point kernel: 128 - 8K owned columns
+    const int K = pl.K, UW = UW_ ? UW_ : (pl.pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K);   // 9-point kernel: 128 - 8K owned columns
     const int nstrip = (int)cdiv(p.xc, UW);
     const int64_t wscale = 4 / tpw;                       // (thresholds in wavefronts: a pipelined tile has four)
     if (!forced && ((int64_t)nstrip * pl.nrb * p.nbatch * wscale < 1024 || (int64_t)nstrip * pl.nrb * wscale < 64 ||
@@ -558,7 +565,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     int occ = occ_ > 0 ? occ_ : 2;
     if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-        if (pl.pipe) xinv_launch_pipe2d(pl.aligned, ext, dim3(1), st, dummy, &occ);
+        if (pl.pipe) xinv_launch_pipe2d(pl.npair, pl.aligned, ext, dim3(1), st, dummy, &occ);
         else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
     }
     const bool pp = pl.pipe;
@@ -632,7 +639,8 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     pl.skip_pct = (int)((100 * nskipped) / (ntiles * nb));
     if (!fixedRB) {
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX) * pl.nrb, tpw) + 1;
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
+        if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, UW) * pl.nrb + 1);
     }
     return XINV_OK;
 }

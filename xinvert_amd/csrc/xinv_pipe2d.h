@@ -38,6 +38,7 @@
 #define XINV_PIPE_ROT 1
 #endif
 #define XINV_PIPE_NS 4            /* ring rows per hand-over */
+#define XINV_PIPE_UW(np) (128 * (np) - 4 * XINV_PIPE_P)   /* columns a tile owns with np column pairs per lane */
 #ifndef XINV_PIPE_PF0
 #define XINV_PIPE_PF0 4           /* rows in flight from HBM, wavefront 0 (S and F) */
 #endif
@@ -79,8 +80,12 @@ __global__ __launch_bounds__(256) void k_row_factor(RowFactorArgs a)
 
 __device__ __forceinline__ void xinv_pipe_barrier()
 {
-#if defined(XINV_PIPE_NOBAR)       /* timing experiment only (results are wrong): what do the barriers cost? */
+#if defined(XINV_PIPE_NOBAR)       /* timing experiments only (results are wrong): what do the barriers cost? */
+#if XINV_PIPE_NOBAR == 2
+    asm volatile("" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
@@ -99,7 +104,29 @@ typedef const double __attribute__((address_space(1))) *xinv_gcdptr;
 typedef xinv_v2d __attribute__((address_space(1))) *xinv_gd2ptr;
 typedef double __attribute__((address_space(1))) *xinv_gdptr;
 
+// 'extend' pre-pass for one boundary row held in the window (numbas.py:284-310), as fused_extend_fix but with
+// the value of column c0-1 of the inner row handed in (with two column pairs per lane it is the lane's own)
+__device__ __forceinline__ void pipe_extend_fix(double2 &edge, const double2 &inner, double inner_w,
+                                                const LaneCols &lc, bool tall, double u)
+{
+    if (lc.cls_x == 1) { if (inner.x != u) edge.x = inner.x; }
+    else if (lc.cls_x == 2) { if (inner.y != u) edge.x = inner.y; }           // (0,0) <- (1,1)
+    else if (lc.cls_x == 3) {
+        if (tall && inner.x != u) edge.x = inner.x;
+        if (inner_w != u) edge.x = inner_w;                                    // <- column xc-2
+    }
+    if (lc.cls_y == 1) { if (inner.y != u) edge.y = inner.y; }
+    else if (lc.cls_y == 3) {
+        if (tall && inner.y != u) edge.y = inner.y;
+        if (inner.x != u) edge.y = inner.x;                                    // <- column xc-2
+    }
+}
+
 // one wavefront of the pipeline: sweep PW+1 on the rows of the tile [yu0, yu1).
+// A lane holds NP adjacent column pairs (NP = 2: four consecutive columns, strips of 256 columns of which 240
+// are owned): the inner neighbours of a point are then the lane's own registers and only one operand per PAIR
+// of updates crosses lanes (DPP), the row bookkeeping, the barriers and the scalar work are shared by twice the
+// arithmetic, and the column halo weighs 1.07 instead of 1.14.
 // Registers: ONE ring of R = PF + 4 row records (S, F, per-row factors).  Row r is loaded straight into
 // record r mod R, PF steps before it enters the window (the per-row factors two steps before), and stays
 // there until it has left the window four steps later; the march is unrolled R steps, so every record index
@@ -107,10 +134,10 @@ typedef double __attribute__((address_space(1))) *xinv_gdptr;
 // rotate registers across the loop back-edge: ~80 v_mov and a full `s_waitcnt vmcnt(0)` per iteration).
 // Row arithmetic is 32-bit (scalar compares; the 64-bit ones are VALU instructions on this target) and
 // every global access is `uniform row base + 32-bit lane offset` (no per-load address arithmetic).
-template <bool AL, bool EXT, int PW, int PF>
+template <int NP, bool AL, bool EXT, int PW, int PF>
 __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
-                                               const LaneCols &lc, int64_t st0, int lane,
-                                               double2 (*ring)[XINV_PIPE_NS][XINV_WAVE], int gtot,
+                                               const LaneCols (&lc)[NP], const int64_t (&st0)[NP], int lane,
+                                               double2 (*ring)[XINV_PIPE_NS][NP][XINV_WAVE], int gtot,
                                                double &acc, int &cnt)
 {
     constexpr int P = XINV_PIPE_P, H = 2 * P, D = 4, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
@@ -126,34 +153,43 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     const xinv_gptr dstS = (xinv_gptr)(uintptr_t)(a.dst + m * a.sS);
     const xinv_gcptr cF = (xinv_gcptr)(uintptr_t)(a.c[2] + m * a.sc[2]);
     const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(reinterpret_cast<const RowFac *>(a.rowf) + m * a.yc);
-    unsigned lo0 = (unsigned)lc.l0 * 8u, lo1 = (unsigned)lc.l1 * 8u;           // byte offsets of the lane's columns
-    unsigned so0 = lc.use_x ? (unsigned)st0 * 8u : 0u;                          // store offset of .x (owned lanes)
-    unsigned so1 = lc.use_y ? (unsigned)(st0 + 1) * 8u : 0u;
+    unsigned lo0[NP], lo1[NP], so0[NP], so1[NP];         // byte offsets of the lane's columns (loads / owned stores)
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        lo0[q] = (unsigned)lc[q].l0 * 8u; lo1[q] = (unsigned)lc[q].l1 * 8u;
+        so0[q] = lc[q].use_x ? (unsigned)st0[q] * 8u : 0u;
+        so1[q] = lc[q].use_y ? (unsigned)(st0[q] + 1) * 8u : 0u;
+    }
 
     const int in_lo = yu0 - H + 2 * PW;                  // first / last row entering this wavefront's window
     const int in_hi = yu1 - 1 + H - 2 * PW;
 
-    double2 sw[R];
-    CoefWin<3, R> cw;
+    double2 sw[NP][R];
+    CoefWin<3, R> cw[NP];
     double rokw[R];
 #pragma unroll
     for (int t = 0; t < R; t++) {
-        sw[t] = make_double2(0.0, 0.0);
-        cw.rq[t] = 0.0; cw.mx[t] = 0u; cw.my[t] = 0u; rokw[t] = 0.0;
+        rokw[t] = 0.0;
 #pragma unroll
-        for (int q = 0; q < 3; q++) { cw.v[q][t] = make_double2(0.0, 0.0); cw.s[q][t] = 0.0; }
+        for (int q = 0; q < NP; q++) {
+            sw[q][t] = make_double2(0.0, 0.0);
+            cw[q].rq[t] = 0.0; cw[q].mx[t] = 0u; cw[q].my[t] = 0u;
+#pragma unroll
+            for (int c = 0; c < 3; c++) { cw[q].v[c][t] = make_double2(0.0, 0.0); cw[q].s[c][t] = 0.0; }
+        }
     }
 
-    // a row of the lane's two columns: uniform row address (kept in SGPRs: the asm pins it, so that the
-    // access is `global_load v, v_lane_offset, s[row]` and not a 64-bit vector address computed per load)
-    auto ldrow = [&](xinv_gcptr base, uint64_t boff) {
+    // a row of one of the lane's column pairs: uniform row address (kept in SGPRs: the asm pins it, so that
+    // the access is `global_load v, v_lane_offset, s[row]` and not a 64-bit vector address computed per load)
+    auto ldrow = [&](xinv_gcptr base, uint64_t boff, auto qtag) {
+        constexpr int q = decltype(qtag)::value;
         xinv_gcptr row = base + boff;
         asm("" : "+s"(row));
-        asm("" : "+v"(lo0));                             // (laundered in place, so that the zero-extension stays in this
-        if (!AL) asm("" : "+v"(lo1));                    //  block: instruction selection then sees sgpr + zext(vgpr32))
+        asm("" : "+v"(lo0[q]));                          // (laundered in place, so that the zero-extension stays in this
+        if (!AL) asm("" : "+v"(lo1[q]));                 //  block: instruction selection then sees sgpr + zext(vgpr32))
         double2 v;
-        if (AL) { const xinv_v2d t = *(xinv_gcd2ptr)(row + lo0); v.x = t.x; v.y = t.y; }
-        else { v.x = *(xinv_gcdptr)(row + lo0); v.y = *(xinv_gcdptr)(row + lo1); }
+        if (AL) { const xinv_v2d t = *(xinv_gcd2ptr)(row + lo0[q]); v.x = t.x; v.y = t.y; }
+        else { v.x = *(xinv_gcdptr)(row + lo0[q]); v.y = *(xinv_gcdptr)(row + lo1[q]); }
         return v;
     };
     // request row r into record `slot` (S from HBM for wavefront 0 only; later wavefronts get it through LDS)
@@ -161,14 +197,20 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         constexpr int slot = decltype(stag)::value;
         const unsigned rr = (unsigned)min(max(r, 0), ycr - 1);
         const uint64_t boff = (uint64_t)rr * rowbytes;
-        if (PW == 0) sw[slot] = ldrow(srcS, boff);
-        cw.v[2][slot] = ldrow(cF, boff);
+        xinv_unroll_steps([&](auto qtag) {
+            constexpr int q = decltype(qtag)::value;
+            if (PW == 0) sw[q][slot] = ldrow(srcS, boff, qtag);
+            cw[q].v[2][slot] = ldrow(cF, boff, qtag);
+        }, std::make_integer_sequence<int, NP>{});
     };
     auto request_rf = [&](int r, auto stag) {
         constexpr int slot = decltype(stag)::value;
         const unsigned rr = (unsigned)min(max(r, 0), ycr - 1);    // (rows 0 and yc-1 carry rok = 0: so do the clamped ones)
-        const xinv_cdouble_ptr q = rowf + (uint64_t)rr * 4u;
-        cw.s[0][slot] = q[0]; cw.s[1][slot] = q[1]; cw.rq[slot] = q[2]; rokw[slot] = q[3];
+        const xinv_cdouble_ptr p4 = rowf + (uint64_t)rr * 4u;
+        const double fa = p4[0], fc = p4[1], fq = p4[2];
+        rokw[slot] = p4[3];
+#pragma unroll
+        for (int q = 0; q < NP; q++) { cw[q].s[0][slot] = fa; cw[q].s[1][slot] = fc; cw[q].rq[slot] = fq; }
     };
     // (in row order, as in the loop: the vmcnt waits of the loop are computed against the worst path into it)
     xinv_unroll_steps([&](auto ttag) { request(in_lo + decltype(ttag)::value, ttag); asm volatile("" ::: "memory"); },
@@ -176,10 +218,32 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     xinv_unroll_steps([&](auto ttag) { request_rf(in_lo + decltype(ttag)::value, ttag); },
                       std::make_integer_sequence<int, PFR>{});
 
+    // one half-sweep of row record sj (sjp / sjm: the rows below / above) on lane components X
+    auto half_sweep = [&](auto xtag, auto jtag, auto ptag, auto mtag) {
+        constexpr int X = decltype(xtag)::value, sj = decltype(jtag)::value, sjp = decltype(ptag)::value,
+                      sjm = decltype(mtag)::value;
+        // the one operand that crosses lanes: west of the first column / east of the last
+        const double edge = (X == 0) ? xinv_lane_up(sw[NP - 1][sj].y) : xinv_lane_down(sw[0][sj].x);
+        double nv[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            double w, e;
+            if (X == 0) { w = (q == 0) ? edge : sw[q > 0 ? q - 1 : 0][sj].y; e = sw[q][sj].y; }
+            else        { w = sw[q][sj].x; e = (q == NP - 1) ? edge : sw[q < NP - 1 ? q + 1 : q][sj].x; }
+            nv[q] = M::template upd<X, UM, R>(cw[q], sj, sjp, comp<X>(sw[q][sj]), comp<X>(sw[q][sjp]),
+                                              comp<X>(sw[q][sjm]), w, e, a.sc_);
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) setc<X>(sw[q][sj], nv[q]);
+    };
+
     // global step g of the workgroup = local step + LAG * PW; a barrier closes every B-th global step
     int g = 0;
     for (; g < LAG * PW; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
-    if (PW > 0) sw[0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][lane];        // row in_lo
+    if (PW > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][q][lane];      // row in_lo
+    }
 
     for (int rb_ = in_lo; rb_ <= in_hi; rb_ += R) {
         xinv_unroll_steps([&](auto utag) {
@@ -187,78 +251,92 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
             constexpr int X = (U & 1) ? 0 : 1;
 #define SLOT(w) ((U - (w) + 4 * R) % R)
 #define RSLOT(w) ((2 * PW + U - (w) + 64 * XINV_PIPE_NS) % XINV_PIPE_NS)  /* LDS ring slot of row r - w */
+#define ITAG(v) std::integral_constant<int, (v)>{}
             const int r = rb_ + U;
-            request(r + PF, std::integral_constant<int, (U + PF) % R>{});
-            request_rf(r + PFR, std::integral_constant<int, (U + PFR) % R>{});
-            if (PW > 0) sw[(U + 1) % R] = ring[PW - 1][RSLOT(-1)][lane];   // row r+1: written B+1 steps ago
+            request(r + PF, ITAG((U + PF) % R));
+            request_rf(r + PFR, ITAG((U + PFR) % R));
+            if (PW > 0) {
+#pragma unroll
+                for (int q = 0; q < NP; q++) sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q][lane];   // row r+1: written B+1 steps ago
+            }
             {   // row r-1: update predicate and F * delxSqr, once for both half-sweeps
                 constexpr int s1 = SLOT(1);
-                const double fx = cw.v[2][s1].x, fy = cw.v[2][s1].y;
                 const bool rok = rokw[s1] != 0.0;
-                cw.mx[s1] = xinv_lane_word(lc.ok_x && rok && (fx != u));
-                cw.my[s1] = xinv_lane_word(lc.ok_y && rok && (fy != u));
-                cw.v[2][s1].x = fx * a.sc_.delxSqr; cw.v[2][s1].y = fy * a.sc_.delxSqr;
+#pragma unroll
+                for (int q = 0; q < NP; q++) {
+                    const double fx = cw[q].v[2][s1].x, fy = cw[q].v[2][s1].y;
+                    cw[q].mx[s1] = xinv_lane_word(lc[q].ok_x && rok && (fx != u));
+                    cw[q].my[s1] = xinv_lane_word(lc[q].ok_y && rok && (fy != u));
+                    cw[q].v[2][s1].x = fx * a.sc_.delxSqr; cw[q].v[2][s1].y = fy * a.sc_.delxSqr;
+                }
             }
             {   // red half-sweep on row r-1
                 const int ja = r - 1;
                 constexpr int sj = SLOT(1), sjp = SLOT(0), sjm = SLOT(2);
                 if (EXT) {
-                    if (ja == 1) fused_extend_fix(sw[sjm], sw[sj], lc, a.tall, u);
-                    if (ja == ycr - 2) fused_extend_fix(sw[sjp], sw[sj], lc, a.tall, u);
+                    if (ja == 1 || ja == ycr - 2) {
+                        const double wl = xinv_lane_up(sw[NP - 1][sj].y);      // column c0-1 of the first pair
+#pragma unroll
+                        for (int q = 0; q < NP; q++) {
+                            const double iw = (q == 0) ? wl : sw[q > 0 ? q - 1 : 0][sj].y;
+                            if (ja == 1) pipe_extend_fix(sw[q][sjm], sw[q][sj], iw, lc[q], a.tall, u);
+                            if (ja == ycr - 2) pipe_extend_fix(sw[q][sjp], sw[q][sj], iw, lc[q], a.tall, u);
+                        }
+                    }
                 }
-                double w, e;
-                row_neighbours<X>(sw[sj], w, e);
-                const double v = M::template upd<X, UM, R>(cw, sj, sjp, comp<X>(sw[sj]), comp<X>(sw[sjp]),
-                                                           comp<X>(sw[sjm]), w, e, a.sc_);
-                setc<X>(sw[sj], v);
+                half_sweep(ITAG(X), ITAG(sj), ITAG(sjp), ITAG(sjm));
             }
             {   // black half-sweep on row r-2
                 const int jb = r - 2;
                 constexpr int sj = SLOT(2), sjp = SLOT(1), sjm = SLOT(3);
-                double w, e;
-                row_neighbours<X>(sw[sj], w, e);
-                const double v = M::template upd<X, UM, R>(cw, sj, sjp, comp<X>(sw[sj]), comp<X>(sw[sjp]),
-                                                           comp<X>(sw[sjm]), w, e, a.sc_);
-                setc<X>(sw[sj], v);
+                half_sweep(ITAG(X), ITAG(sj), ITAG(sjp), ITAG(sjm));
                 if ((jb >= yu0) && (jb < yu1)) {           // an owned row: its share of mean|S| of this sweep
-                    const double2 t = sw[sj];
-                    const bool cx = lc.use_x & (t.x != u);
-                    const bool cy = lc.use_y & (t.y != u);
-                    acc += (cx ? fabs(t.x) : 0.0);
-                    acc += (cy ? fabs(t.y) : 0.0);
-                    cnt += (cx ? 1 : 0) + (cy ? 1 : 0);
+#pragma unroll
+                    for (int q = 0; q < NP; q++) {
+                        const double2 t = sw[q][sj];
+                        const bool cx = lc[q].use_x & (t.x != u);
+                        const bool cy = lc[q].use_y & (t.y != u);
+                        acc += (cx ? fabs(t.x) : 0.0);
+                        acc += (cy ? fabs(t.y) : 0.0);
+                        cnt += (cx ? 1 : 0) + (cy ? 1 : 0);
+                    }
                 }
                 // ---- row r-2 leaves
                 if (PW < P - 1) {
-                    ring[PW][RSLOT(2)][lane] = sw[sj];
+#pragma unroll
+                    for (int q = 0; q < NP; q++) ring[PW][RSLOT(2)][q][lane] = sw[q][sj];
                 } else if (jb >= yu0 && jb < yu1) {
-                    const double2 t = sw[sj];
                     xinv_gptr row = dstS + (uint64_t)(unsigned)jb * rowbytes;
                     asm("" : "+s"(row));
-                    asm("" : "+v"(so0));
-                    if (!AL) asm("" : "+v"(so1));
-                    if (AL) {
-                        if (lc.use_x) { xinv_v2d tv; tv.x = t.x; tv.y = t.y; *(xinv_gd2ptr)(row + so0) = tv; }
-                    } else {
-                        if (lc.use_x) *(xinv_gdptr)(row + so0) = t.x;
-                        if (lc.use_y) *(xinv_gdptr)(row + so1) = t.y;
-                    }
+                    xinv_unroll_steps([&](auto qtag) {
+                        constexpr int q = decltype(qtag)::value;
+                        const double2 t = sw[q][sj];
+                        asm("" : "+v"(so0[q]));
+                        if (!AL) asm("" : "+v"(so1[q]));
+                        if (AL) {
+                            if (lc[q].use_x) { xinv_v2d tv; tv.x = t.x; tv.y = t.y; *(xinv_gd2ptr)(row + so0[q]) = tv; }
+                        } else {
+                            if (lc[q].use_x) *(xinv_gdptr)(row + so0[q]) = t.x;
+                            if (lc[q].use_y) *(xinv_gdptr)(row + so1[q]) = t.y;
+                        }
+                    }, std::make_integer_sequence<int, NP>{});
                 }
             }
             if ((LAG * PW + U + 1) % B == 0) xinv_pipe_barrier();
 #undef SLOT
 #undef RSLOT
+#undef ITAG
         }, std::make_integer_sequence<int, R>{});
         g += R;
     }
     for (; g < gtot; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
 }
 
-template <bool AL, bool EXT>
+template <int NP, bool AL, bool EXT>
 __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 {
-    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = 128 - 2 * H, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
-    __shared__ double2 ring[P - 1][XINV_PIPE_NS][XINV_WAVE];
+    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = XINV_PIPE_UW(NP), LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
+    __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP][XINV_WAVE];
 
     unsigned tag;
     int T;
@@ -309,8 +387,13 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         yu0 = (int)((((int64_t)rb * yc) / a.nrb) & ~(int64_t)1);
         yu1 = (rb + 1 == a.nrb) ? (int)yc : (int)((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
     }
-    const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
-    const int64_t st0 = xu0 - H + 2 * lane;
+    LaneCols lc[NP];
+    int64_t st0[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        lc[q] = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0, NP, q);
+        st0[q] = xu0 - H + 2 * NP * lane + 2 * q;        // unwrapped store column of the pair's .x
+    }
 
     if (active) {
         // global steps every wavefront goes through: the longest of the four schedules, whole barrier periods
@@ -325,10 +408,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         }
         gtot = ((gtot + B - 1) / B) * B;
         switch (pwi) {
-        case 0: xinv_pipe_wave<AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
-        case 1: xinv_pipe_wave<AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
-        case 2: xinv_pipe_wave<AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
-        default: xinv_pipe_wave<AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        case 0: xinv_pipe_wave<NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        case 1: xinv_pipe_wave<NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        case 2: xinv_pipe_wave<NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        default: xinv_pipe_wave<NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
         }
     }
     }
