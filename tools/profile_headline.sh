@@ -18,9 +18,12 @@ python $R/tools/prof_summary.py counters $(db /tmp/p_w) $out/${tag}_pmc_write_c2
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d /tmp/p_s -o r -- $cmd > /dev/null 2>&1
 python $R/tools/prof_summary.py counters $(db /tmp/p_s) $out/${tag}_pmc_sq_issue_c2.txt
 cp $R/profiles/traffic.json $out/traffic.json 2>/dev/null
-python $R/tools/prof_summary.py traffic $(db /tmp/p_f) $(db /tmp/p_w) "k_fused2d<FusedStd2D, 4" std2d_spl4_um3 $out/traffic.json
+python $R/tools/prof_summary.py traffic $(db /tmp/p_f) $(db /tmp/p_w) "k_pipe2d<1" std2d_pipe_um3 $out/traffic.json
+XINV_PIPE=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f0 -o r -- $cmd --no-hbm > /dev/null 2>&1
+XINV_PIPE=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w0 -o r -- $cmd --no-hbm > /dev/null 2>&1
+python $R/tools/prof_summary.py traffic $(db /tmp/p_f0) $(db /tmp/p_w0) "k_fused2d<FusedStd2D, 4" std2d_spl4_um3 $out/traffic.json
 # the HBM-bound variant of the same run (bench.py roofline_hbm): one sweep per pass, all arrays streamed, every tile
 python $R/tools/prof_summary.py traffic $(db /tmp/p_f) $(db /tmp/p_w) "k_fused2d<FusedStd2D, 1" std2d_spl1_um0_all $out/traffic.json
 head -4 $out/${tag}_kernel_trace_c2.txt | cut -c1-160
-grep k_fused2d $out/${tag}_pmc_sq_issue_c2.txt | cut -c1-30,60-140
+grep "k_fused2d\|k_pipe2d" $out/${tag}_pmc_sq_issue_c2.txt | cut -c1-30,60-140
 cat $out/traffic.json

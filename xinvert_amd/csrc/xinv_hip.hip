@@ -406,7 +406,14 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // Four sweeps per pass of the standard form with per-row A and C: pipelined across the four wavefronts
         // of a workgroup (xinv_pipe2d.h) -- a quarter of the tiles, four times as tall, half the recomputed halo.
         static const bool pipe_env = [] { const char *e = getenv("XINV_PIPE"); return !e || atoi(e) != 0; }();
-        pl.pipe = pipe_env && !(opt.flags & XINV_FLAG_NO_PIPE) && p.kind == KIND_STD2D && pl.um == 3u && pl.K == 4;
+        // ... where the launch is small enough for that to matter: k_fused2d keeps the VALU 96 % busy against
+        // ~75 %, and with several rounds of workgroups its tiles are tall anyway (8 slices of 3600x1800:
+        // 7.0e11 with k_fused2d, 6.2e11 pipelined; one slice: 5.85 against 6.0e11; 180x360: 1.7 against 2.35e10).
+        // XINV_PIPE=2 forces the pipelined pass whatever the size.
+        static const int pipe_mode = [] { const char *e = getenv("XINV_PIPE"); return e ? atoi(e) : 1; }();
+        const bool pipe_size_ok = pipe_mode == 2 || p.nbatch * p.yc * p.xc <= (int64_t)10000000;
+        pl.pipe = pipe_env && pipe_size_ok && !(opt.flags & XINV_FLAG_NO_PIPE) && p.kind == KIND_STD2D && pl.um == 3u &&
+                  pl.K == 4;
         pl.tpw = pl.pipe ? 1 : 4;
         // two column pairs per lane (strips of 240 owned columns) where the grid is wide enough to keep the
         // workgroup count up; XINV_PIPE_NP=1|2 forces the choice

@@ -30,14 +30,30 @@
 #include "xinv_fused.h"
 
 #define XINV_PIPE_P 4             /* wavefronts per workgroup = sweeps per pass */
+#ifndef XINV_PIPE_FLAGS
+#define XINV_PIPE_FLAGS 0         /* 0: one workgroup barrier every XINV_PIPE_B steps (kept);
+                                     1: hand-over by progress counters in LDS, no barrier in the march, the successor
+                                        five steps behind instead of seven.  MEASURED AND NOT KEPT: bit-exact, but
+                                        47.4 us per launch at 3600x1800 against 39.7 -- the polls and the two
+                                        counter stores per step cost more than the barriers they replace (taking
+                                        the barriers out altogether, results wrong, only gains 10 %) */
+#endif
 #ifndef XINV_PIPE_B
 #define XINV_PIPE_B 2             /* steps per workgroup barrier (1 or 2; the four-row LDS ring allows no more) */
 #endif
+#if XINV_PIPE_FLAGS
+#define XINV_PIPE_LAG 5           /* steps wavefront p+1 runs behind wavefront p at the least */
+#else
 #define XINV_PIPE_LAG (XINV_PIPE_B + 5)   /* steps wavefront p+1 runs behind wavefront p */
+#endif
 #ifndef XINV_PIPE_ROT
 #define XINV_PIPE_ROT 1
 #endif
+#if XINV_PIPE_FLAGS
+#define XINV_PIPE_NS 8            /* ring rows per hand-over: the producer may run that far ahead */
+#else
 #define XINV_PIPE_NS 4            /* ring rows per hand-over */
+#endif
 #define XINV_PIPE_UW(np) (128 * (np) - 4 * XINV_PIPE_P)   /* columns a tile owns with np column pairs per lane */
 #ifndef XINV_PIPE_PF0
 #define XINV_PIPE_PF0 4           /* rows in flight from HBM, wavefront 0 (S and F) */
@@ -138,13 +154,14 @@ template <int NP, bool AL, bool EXT, int PW, int PF>
 __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
                                                const LaneCols (&lc)[NP], const int64_t (&st0)[NP], int lane,
                                                double2 (*ring)[XINV_PIPE_NS][NP][XINV_WAVE], int gtot,
-                                               double &acc, int &cnt)
+                                               double &acc, int &cnt, int *prog, XinvCtl *ctl)
 {
     constexpr int P = XINV_PIPE_P, H = 2 * P, D = 4, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     constexpr int R = PF + D;                            // row records; also the unroll period
     constexpr int PFR = 2;                               // steps the per-row factors are requested ahead
     constexpr unsigned UM = 3u;
-    static_assert(R % D == 0 && R % B == 0, "the unroll period must keep row parity, ring slots and barriers compile-time");
+    static_assert(R % D == 0 && R % B == 0 && R % XINV_PIPE_NS == 0,
+                  "the unroll period must keep row parity, ring slots and barriers compile-time");
     using M = FusedStd2D;
     const int ycr = (int)a.yc;
     const unsigned rowbytes = (unsigned)a.xc * 8u;       // (a row is shorter than 4 GiB)
@@ -237,6 +254,43 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         for (int q = 0; q < NP; q++) setc<X>(sw[q][sj], nv[q]);
     };
 
+#if XINV_PIPE_FLAGS
+    // Hand-over by progress counters (LDS words, one writer each): prog[2p] = rows wavefront p has written
+    // into its ring, prog[2p+1] = rows it has taken out of its predecessor's.  A wavefront's LDS operations
+    // execute in order, so a consumer that reads the new count finds the row.  The producer's k-th row
+    // (k = its local step) is the consumer's row k-4; the ring holds NS rows.  Counts are cached in SGPRs
+    // and re-read only when the cached value does not yet allow the next step; a wavefront that waits
+    // sleeps (s_sleep) instead of taking issue slots.  A wait that does not end within ~1 s stops the
+    // member with overflow = 2 (reported as an internal error), as in xinv_norm_reduce.
+    constexpr int NS = XINV_PIPE_NS;
+    const int n_self = ((in_hi - in_lo + 1 + R - 1) / R) * R;                 // steps of this wavefront
+    const int n_prod = (((in_hi + 2) - (in_lo - 2) + 1 + R - 1) / R) * R;     // ... of its predecessor (same PF -> same R)
+    const int n_cons = (((in_hi - 2) - (in_lo + 2) + 1 + R - 1) / R) * R;     // ... of its successor
+    int seen_prod = 0, seen_cons = 0;
+    bool timed_out = false;
+    // (relaxed workgroup-scope atomics: plain ds_read / ds_write -- a `volatile` access makes the compiler
+    //  drain every outstanding load, vmcnt(0), around it: 39.8 -> 54 us per launch)
+    auto wait_ge = [&](int *ctr, int &seen, int need) {
+        if (seen >= need || timed_out) return;
+        for (unsigned spin = 0;; spin++) {
+            seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (seen >= need) break;
+            if (spin > (1u << 21)) { timed_out = true; break; }
+            if (spin >= 4) __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+    };
+    if (PW > 0) {
+#ifndef XINV_PIPE_SLACK
+#define XINV_PIPE_SLACK 2         /* rows the successor lets its predecessor get ahead before it starts: with equal
+                                     rates it then finds its row already there and polls once every few steps */
+#endif
+        wait_ge(prog + 2 * (PW - 1), seen_prod, min(5 + XINV_PIPE_SLACK, n_prod));   // row in_lo is the predecessor's 5th
+#pragma unroll
+        for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % NS][q][lane];
+    }
+    (void)gtot;
+#else
     // global step g of the workgroup = local step + LAG * PW; a barrier closes every B-th global step
     int g = 0;
     for (; g < LAG * PW; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
@@ -244,6 +298,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #pragma unroll
         for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][q][lane];      // row in_lo
     }
+#endif
 
     for (int rb_ = in_lo; rb_ <= in_hi; rb_ += R) {
         xinv_unroll_steps([&](auto utag) {
@@ -255,10 +310,12 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
             const int r = rb_ + U;
             request(r + PF, ITAG((U + PF) % R));
             request_rf(r + PFR, ITAG((U + PFR) % R));
+#if !XINV_PIPE_FLAGS
             if (PW > 0) {
 #pragma unroll
                 for (int q = 0; q < NP; q++) sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q][lane];   // row r+1: written B+1 steps ago
             }
+#endif
             {   // row r-1: update predicate and F * delxSqr, once for both half-sweeps
                 constexpr int s1 = SLOT(1);
                 const bool rok = rokw[s1] != 0.0;
@@ -286,6 +343,14 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 }
                 half_sweep(ITAG(X), ITAG(sj), ITAG(sjp), ITAG(sjm));
             }
+#if XINV_PIPE_FLAGS
+            if (PW > 0) {   // row r+1 for the next step: the predecessor's row (local step + 6), once it is there
+                const int j = r - in_lo;
+                wait_ge(prog + 2 * (PW - 1), seen_prod, min(j + 6, n_prod));
+#pragma unroll
+                for (int q = 0; q < NP; q++) sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q][lane];
+            }
+#endif
             {   // black half-sweep on row r-2
                 const int jb = r - 2;
                 constexpr int sj = SLOT(2), sjp = SLOT(1), sjm = SLOT(3);
@@ -303,8 +368,17 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 }
                 // ---- row r-2 leaves
                 if (PW < P - 1) {
+#if XINV_PIPE_FLAGS
+                    const int j = r - in_lo;                 // this row replaces the one written NS steps ago: the
+                    if (j >= NS + 4)                         // successor's row j - NS - 4 must have been taken out
+                        wait_ge(prog + 2 * (PW + 1) + 1, seen_cons, min(j - NS - 3, n_cons));
+#endif
 #pragma unroll
                     for (int q = 0; q < NP; q++) ring[PW][RSLOT(2)][q][lane] = sw[q][sj];
+#if XINV_PIPE_FLAGS
+                    asm volatile("" ::: "memory");
+                    __hip_atomic_store(prog + 2 * PW, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                 } else if (jb >= yu0 && jb < yu1) {
                     xinv_gptr row = dstS + (uint64_t)(unsigned)jb * rowbytes;
                     asm("" : "+s"(row));
@@ -322,14 +396,27 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                     }, std::make_integer_sequence<int, NP>{});
                 }
             }
+#if XINV_PIPE_FLAGS
+            if (PW > 0)                                      // row r has been taken out of the predecessor's ring
+                __hip_atomic_store(prog + 2 * PW + 1, r - in_lo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+#else
             if ((LAG * PW + U + 1) % B == 0) xinv_pipe_barrier();
+#endif
 #undef SLOT
 #undef RSLOT
 #undef ITAG
         }, std::make_integer_sequence<int, R>{});
+#if !XINV_PIPE_FLAGS
         g += R;
+#endif
     }
+#if XINV_PIPE_FLAGS
+    (void)n_self;
+    if (timed_out && lane == 0) { ctl->overflow = 2; ctl->done = 1; ctl->sweeps = ctl->loop + 1; }
+#else
     for (; g < gtot; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
+#endif
 }
 
 template <int NP, bool AL, bool EXT>
@@ -337,6 +424,7 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 {
     constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = XINV_PIPE_UW(NP), LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP][XINV_WAVE];
+    __shared__ int prog[2 * P];                          // hand-over progress counters (XINV_PIPE_FLAGS)
 
     unsigned tag;
     int T;
@@ -395,6 +483,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         st0[q] = xu0 - H + 2 * NP * lane + 2 * q;        // unwrapped store column of the pair's .x
     }
 
+#if XINV_PIPE_FLAGS
+    if (threadIdx.x < 2 * P) prog[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     if (active) {
         // global steps every wavefront goes through: the longest of the four schedules, whole barrier periods
         const int ry = yu1 - yu0;
@@ -408,10 +500,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         }
         gtot = ((gtot + B - 1) / B) * B;
         switch (pwi) {
-        case 0: xinv_pipe_wave<NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
-        case 1: xinv_pipe_wave<NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
-        case 2: xinv_pipe_wave<NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
-        default: xinv_pipe_wave<NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt); break;
+        case 0: xinv_pipe_wave<NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
+        case 1: xinv_pipe_wave<NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
+        case 2: xinv_pipe_wave<NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
+        default: xinv_pipe_wave<NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
         }
     }
     }
