@@ -33,7 +33,7 @@
 #define XINV_AUX_KERNELS            /* the detection / skip-norm helper kernels live in this unit */
 #include "xinv_dispatch.h"          /* argument structs + launchers of the sweep kernels (xinv_tu_*.hip) */
 
-#define XINV_VERSION 100
+#define XINV_VERSION 200
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
 
 #include "xinv_host.h"
