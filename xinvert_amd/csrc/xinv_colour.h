@@ -57,7 +57,7 @@ template <bool NINE>
 __global__ __launch_bounds__(256) void k_colour_std2d(ColourArgs2D a)
 {
     const int64_t m = a.member0 + blockIdx.z;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
     int64_t j, i;
@@ -91,7 +91,7 @@ template <bool NINE>
 __global__ __launch_bounds__(256) void k_colour_gen2d(ColourArgs2D a)
 {
     const int64_t m = a.member0 + blockIdx.z;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
     int64_t j, i;
@@ -125,7 +125,7 @@ template <bool NINE>
 __global__ __launch_bounds__(256) void k_colour_std2dt(ColourArgs2D a)
 {
     const int64_t m = a.member0 + blockIdx.z;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
     int64_t j, i;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_colour_std3d(ColourArgs3D a)
     const int64_t nk = a.zc - 2;
     const int64_t m = a.member0 + blockIdx.z / nk;
     const int64_t k = 1 + blockIdx.z % nk;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t j = 1 + (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
     if (j > a.yc - 2) return;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_colour_gen3d(ColourArgs3D a)
     const int64_t nk = a.zc - 2;
     const int64_t m = a.member0 + blockIdx.z / nk;
     const int64_t k = 1 + blockIdx.z % nk;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t j = 1 + (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
     if (j > a.yc - 2) return;
@@ -257,7 +257,7 @@ struct ExtendArgs {
 __global__ __launch_bounds__(256) void k_extend(ExtendArgs a)
 {
     const int64_t m = a.member0 + blockIdx.z;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.xc) return;
     const int64_t k = a.kfirst + blockIdx.y;
@@ -309,7 +309,7 @@ template <bool UNI>
 __global__ __launch_bounds__(256) void k_colour_bih2d(ColourArgsBih a)
 {
     const int64_t m = a.member0 + blockIdx.z;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t tj = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
     const int64_t xc = a.xc, yc = a.yc;
@@ -384,7 +384,7 @@ template <bool UNI, bool PER>
 __global__ __launch_bounds__(256) void k_bih_rowclass(ColourArgsBih a)
 {
     const int64_t m = a.member0 + blockIdx.z;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t strip = (int64_t)blockIdx.x * 4 + wave;
     const int64_t xc = a.xc, yc = a.yc;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void k_rows_copy_back(const double *Y, int64_t
                                                         int64_t member0, int force)
 {
     const int64_t m = member0 + blockIdx.y;
-    if (!force && ctl[m].done) return;
+    if (!force && xinv_ctl_done(ctl + m)) return;
     const int64_t n = (yc - 4) * xc;
     const double *y = Y + m * sY + 2 * xc;
     double *s = S + m * sS + 2 * xc;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_rows_copy_back(const double *Y, int64_t
 __global__ __launch_bounds__(256) void k_extend_bih(ExtendArgs a)
 {
     const int64_t m = a.member0 + blockIdx.z;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.xc) return;
     const int64_t xc = a.xc, yc = a.yc;
@@ -532,7 +532,7 @@ struct NormArgs {
 __global__ __launch_bounds__(256) void k_norm_partial(NormArgs a)
 {
     const int64_t m = a.member0 + blockIdx.y;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     const double *S = a.S + m * a.sS;
     double s = 0.0;
     long long c = 0;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void k_norm_partial(NormArgs a)
 __global__ __launch_bounds__(64) void k_norm_final(NormArgs a, int nblocks)
 {
     const int64_t m = a.member0 + blockIdx.x;
-    if (!a.force && a.ctl[m].done) return;
+    if (!a.force && xinv_ctl_done(a.ctl + m)) return;
     double s = 0.0;
     long long c = 0;
     for (int t = threadIdx.x; t < nblocks; t += 64) {

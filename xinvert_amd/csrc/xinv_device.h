@@ -11,6 +11,16 @@
 #include <math.h>
 
 #define XINV_WAVE 64
+
+// The scalar data cache is not reliably invalidated between kernels: on the first launch of a kernel variant
+// k_pipe2d relaxed a whole slice with the previous solve's row factors (read with s_load from a reused workspace
+// address) in 4 of 14 runs of the GPU suite, 0 of 14 with an explicit invalidate (profiles/r02_pipe2d_bringup.txt).
+// So: a kernel that reads solver state through the scalar unit on purpose starts with xinv_fresh_scalar_cache()
+// (k_pipe2d only: invalidating in every workgroup of every kernel cost 3-7 % on the many-round launches, C4 64
+// members 3.94 -> 3.67e11), and the two words every kernel reads of state written by its predecessor -- the stop
+// flag and the sequence number, at a uniform address, hence an s_load if left to the compiler -- are read with
+// agent-scope atomic loads (vector loads through the coherent L2; a stale `done` would silently skip a pass).
+__device__ __forceinline__ void xinv_fresh_scalar_cache() { __builtin_amdgcn_s_dcache_inv(); }
 #ifndef XINV_DPP_ZERO_EDGE
 #define XINV_DPP_ZERO_EDGE 1
 #endif
@@ -42,6 +52,15 @@ struct XinvStop {
     double tolerance;
     int stop_on_zero_norm;  // standard_2D only (numbas.py:410)
 };
+
+__device__ __forceinline__ int xinv_ctl_done(const XinvCtl *c)
+{
+    return __hip_atomic_load(&c->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned xinv_ctl_seq(const XinvCtl *c)
+{
+    return __hip_atomic_load(&c->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // numbas.py:401-414 / 1186-1199 / 197-210, one sweep's worth.
 __device__ __forceinline__ void xinv_ctl_update(XinvCtl *c, double sum, long long count,

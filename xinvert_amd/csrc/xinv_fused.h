@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void k_norm_reduce_lag(NormLagArgs a)
 {
     const int64_t m = a.member0 + blockIdx.x;
     XinvCtl *ctl = a.ctl + m;
-    if (ctl->done) return;
+    if (xinv_ctl_done(ctl)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned long long *pw = a.psum + (size_t)m * XINV_KMAX * a.NB * XINV_PW;
     const double xs = a.xsum ? a.xsum[m] : 0.0;
@@ -652,9 +652,9 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
-    if (!a.force && ctl->done) return;
+    if (!a.force && xinv_ctl_done(ctl)) return;
     if (a.lag && (int)blockIdx.x == a.nwg) { xinv_lag_reduce_prev(a, ctl, m); return; }
-    const unsigned tag = a.lag ? a.tag : ctl->seq;
+    const unsigned tag = a.lag ? a.tag : xinv_ctl_seq(ctl);
 
     // ---- tile of this wavefront; workgroup -> tile map keeps each XCD on a band of rows ----
     // A member's wave-tiles are numbered strip-fastest, then row block; workgroup T takes four

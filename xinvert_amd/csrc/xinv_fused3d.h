@@ -80,8 +80,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
-    if (!a.force && ctl->done) return;
-    const unsigned tag = ctl->seq;
+    if (!a.force && xinv_ctl_done(ctl)) return;
+    const unsigned tag = xinv_ctl_seq(ctl);
 
     const int NB = a.nstrip * a.njb * a.nkc;
     int T;

@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
-    if (!a.force && ctl->done) return;
+    if (!a.force && xinv_ctl_done(ctl)) return;
     if (a.lag && (int)blockIdx.x == a.nwg) { xinv_lag_reduce_prev(a, ctl, m); return; }
-    const unsigned tag = a.lag ? a.tag : ctl->seq;
+    const unsigned tag = a.lag ? a.tag : xinv_ctl_seq(ctl);
 
     const int NB = a.nwg;
     int T;

@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
     constexpr int D = 9;
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
-    if (!a.force && ctl->done) return;
+    if (!a.force && xinv_ctl_done(ctl)) return;
     if (a.lag && (int)blockIdx.x == a.nwg) { xinv_lag_reduce_prev(a, ctl, m); return; }
-    const unsigned tag = a.lag ? a.tag : ctl->seq;
+    const unsigned tag = a.lag ? a.tag : xinv_ctl_seq(ctl);
 
     const int NB = a.nwg;
     int T;

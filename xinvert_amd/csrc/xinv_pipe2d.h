@@ -79,6 +79,7 @@ struct RowFactorArgs {
 // A and C constant along x; FusedStd2D::derive, hoisted branch)
 __global__ __launch_bounds__(256) void k_row_factor(RowFactorArgs a)
 {
+    xinv_fresh_scalar_cache();
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (j >= a.yc) return;
     const double u = a.sc_.undef;
@@ -422,6 +423,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 template <int NP, bool AL, bool EXT>
 __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 {
+    xinv_fresh_scalar_cache();
     constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = XINV_PIPE_UW(NP), LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP][XINV_WAVE];
     __shared__ int prog[2 * P];                          // hand-over progress counters (XINV_PIPE_FLAGS)
@@ -433,17 +435,12 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int pwi;
     {
-    // The per-row factors are read through the scalar data cache, and k_row_factor rewrote them (same
-    // workspace address) for this solve: the cache is NOT reliably invalidated between kernels -- measured,
-    // 4 of 14 runs of the GPU suite returned a whole slice relaxed with the previous solve's factors on the
-    // first launch of a kernel variant, 0 of 14 with this invalidate (profiles/r02_pipe2d_bringup.txt).
-    __builtin_amdgcn_s_dcache_inv();
     const FusedArgs &a = a_;
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
-    if (!a.force && ctl->done) return;
+    if (!a.force && xinv_ctl_done(ctl)) return;
     if (a.lag && (int)blockIdx.x == a.nwg) { xinv_lag_reduce_prev(a, ctl, m); return; }
-    tag = a.lag ? a.tag : ctl->seq;
+    tag = a.lag ? a.tag : xinv_ctl_seq(ctl);
 
     const int NB = a.nwg;
     {
