@@ -42,6 +42,30 @@ def test_c2_poisson_3600x1800_default_engine_vs_oracle():
     q = synthetic.member(synthetic.poisson_latlon(1800, 3600, mask=True), 0)
     st = _bitwise(q, 22, COLOUR_2)
     assert st['sweeps_per_launch'] == 4 and st['xuniform_mask'] == 3 and st['masked_tile_pct'] >= 15
+    assert st['pipelined'] == 1                           # k_pipe2d: launches of up to 1e7 points
+
+
+def test_c2_poisson_3600x1800_stops_inside_a_pipelined_pass():
+    """The stop rule firing inside a four-sweep pass of the pipelined kernel with the lagged norm (three S
+    buffers, decision one pass late, redo from the pass's intact source with the single-sweep kernel): the
+    returned field is exactly the stopping sweep of the coloured oracle, for stops at every position in a pass."""
+    from xinvert_amd import synthetic
+    q = synthetic.member(synthetic.poisson_latlon(1800, 3600, mask=True), 0)
+    _, flo = run_oracle(q, 40, 0.0, COLOUR_2)
+    # relative change of mean|S| per sweep falls monotonically here: pick tolerances that stop at sweeps 17..20
+    hist = []
+    for n in range(16, 21):
+        _, f = run_oracle(q, n, 0.0, COLOUR_2)
+        hist.append(f[1])
+    for k in range(1, 5):
+        tol = 0.5 * (hist[k - 1] + hist[k])              # first sweep whose change is below: loop index 16 + k
+        So, fo = run_oracle(q, 40, tol, COLOUR_2)
+        assert fo[2] == 16 + k, (fo, hist)
+        S, fl, st = util.run_hip_dev([q], 40, tol)
+        assert st['pipelined'] == 1 and st['sweeps_per_launch'] == 4, st
+        assert fl[0][2] == fo[2] and st['sweeps_max'] == fo[2] + 1, (fl, fo, st)
+        assert np.array_equal(S[0], So), 'stop at loop %d: %d points differ' % (fo[2], int((S[0] != So).sum()))
+    assert flo[2] == 40
 
 
 def test_c2_poisson_3600x1800_hbm_variant_vs_oracle():
