@@ -6,38 +6,44 @@ lat-lon Poisson problem with a land/sea mask (configs[1]).  One *step* is one co
 pass: `xinv_standard_2d_f64_dev` over one batch of synthetic input already resident in HBM,
 running a fixed number of sweeps (tolerance = 0, mxLoop = sweeps - 1), norm + stopping rule
 evaluated on the device after every sweep exactly as in production.  Every point of the grid is
-counted, masked (land) points included -- `value_active` counts only tiles the kernel ran.
+counted in `value`, masked (land) points included; `value_active` and every roofline fraction count
+only the tiles the kernel actually ran.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c5] [--sweeps S] ...
 
---config c2 (default): N > 1 = every rank solves its own member(s) (weak scaling).
---config c4 / c5: the REAL batch of BASELINE configs[3] / [4] (64 Gill-Matsuno members /
-120 omega volumes) split in contiguous blocks over the ranks (strong scaling).
-N > 1 is launched by torch.distributed.run, one rank per GPU; no data-path collective, the
-per-slice flags are all-gathered over RCCL after each step.  Rank 0 prints ONE JSON line.
+--gpus N > 1 started WITHOUT a torchrun environment launches its own N ranks (torch.distributed.run,
+rendezvous on 127.0.0.1) and fails loudly when fewer than N GPUs are visible; started under torchrun it
+joins the job.  One rank per GPU, backend nccl (= RCCL); no data-path collective: the batch axis is split
+in contiguous blocks and the per-slice flags are all-gathered after each step.  `n_gpus` in the JSON line
+is the number of ranks that took part in that RCCL all-gather (`rccl_ranks`), not the number asked for.
+--config c2 (default): every rank solves its own member(s) (weak scaling).
+--config c4 / c5: the REAL batch of BASELINE configs[3] / [4] (64 Gill-Matsuno members / 120 omega
+volumes) split over the ranks (strong scaling).
+--inproc: additionally time the other multi-GPU mode: ONE process, host pointers,
+xinv_options.ndev = N (one host thread per GPU inside the call); PCIe-inclusive, reported as `inproc`.
 
-Extra objects in the JSON line (N = 1, c2):
-  roofline       the resource that bounds the dominant kernel: the fp64 vector ALU.  achieved =
-                 useful point updates x 16 fp64 operations / mean launch duration (HIP events on the
-                 solve's stream over the timed region); peak = fp64 VALU issue rate WITHOUT FMA
-                 (the bit-exactness contract forbids contraction); `executed_over_useful` is the
-                 recomputed-halo factor of the tiling actually used.  `alg_equiv_GBps` is SURVEY
-                 8(d)'s 48 B/point figure over the same time -- a comparable number, NOT a fraction
-                 of anything (the kernel elides B, reads A and C as per-row scalars and fuses K
-                 sweeps per pass); `traffic` is the PMC-measured bytes per launch of the same kernel
-                 variant, read from profiles/traffic.json (static: counters cannot be read in-process).
-  roofline_hbm   the HBM-bound variant north_star names, measured in the same run: one sweep per
-                 pass, every coefficient array streamed in full, every tile run.  achieved =
-                 48 B x points / launch duration; frac <= 1 by construction.
-  parity         after the timed loop the same solve is repeated from the initial state and compared
-                 BIT FOR BIT with the CPU oracle's coloured ordering run for the same sweeps.
-  cpu_baseline   the oracle's lexicographic sweep (the reference's execution model) built with
-                 -march=native on this box, 1 core and all cores.
+Extra objects in the ONE JSON line rank 0 prints (N = 1, c2):
+  roofline       the resource that bounds the dominant kernel: the fp64 vector ALU.  achieved = point updates
+                 of the tiles that RAN (skipped, fully masked tiles are not counted) x 16 fp64 operations /
+                 mean launch duration (HIP events on the solve's stream over the timed region); peak = fp64
+                 VALU issue rate WITHOUT FMA (the bit-exactness contract forbids contraction).
+                 `alg_equiv_GBps` is SURVEY 8(d)'s 48 B/point figure over the same time -- a comparable
+                 number, NOT a fraction of anything; `traffic` is the PMC-measured bytes per launch of the
+                 same kernel variant (profiles/traffic.json; counters cannot be read in-process).
+  roofline_hbm   the HBM-bound variant north_star names on a working set far beyond the 256 MiB Infinity
+                 Cache: 8 members with their own A, C, F (2.1 GB), one sweep per pass, every array streamed,
+                 every tile run.  `achieved` prices the 40 B per point the variant really streams (S read +
+                 write, A, C, F; B is identically zero and never read); `alg48_*` is SURVEY 8(d)'s 48 B figure.
+  configs        one line per other BASELINE configuration (C1, C3 Stommel, C3 Munk, C4, C5) on this GPU:
+                 value, kernel, bound, fraction, and a bitwise parity flag against the oracle over >= 10 sweeps.
+  parity         the timed solve repeated from the initial state and compared BIT FOR BIT with the oracle.
+  cpu_baseline   the oracle's lexicographic sweep (the reference's execution model), -march=native build.
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,13 +52,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_BYTES = {'std2d': 48, 'gen2d': 72, 'std3d': 48}
-# fp64 operations of one point update as the kernels execute it (the relaxation factor and
-# F*delxSqr are hoisted per row / per launch): std2d 4 sub + 4 mul + 2 sub + mul + add + sub + mul + add = 16;
-# gen2d (hoisted) 25; std3d (hoisted, f*delxSqr per point) 21
-UPD_FLOPS = {'std2d': 16, 'gen2d': 25, 'std3d': 21}
-HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8.0 TB/s spec
-# fp64 vector ALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T operations/s (78.6 TFLOP/s
+ALG_BYTES = {'std2d': 48, 'gen2d': 72, 'std3d': 48, 'bih2d': 96}       # SURVEY.md section 8(d) / DESIGN 4.3
+# fp64 operations of one point update as the kernels execute it (relaxation factor and F*delxSqr hoisted per
+# row / per launch where the coefficients allow): std2d 4 sub + 4 mul + 2 sub + mul + add + sub + mul + add = 16;
+# gen2d (hoisted) 25; std3d (hoisted) 21; bih2d (row scalars, B = E = 0) 45
+UPD_FLOPS = {'std2d': 16, 'gen2d': 25, 'std3d': 21, 'bih2d': 45}
+HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+# fp64 vector ALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T operations/s (the 78.6 TFLOP/s
 # datasheet figure counts an FMA as two; tools/fp64_peak.hip measures both on the box)
 FP64_VALU_PEAK_TFLOPS = 39.3
 FP64_VALU_MEASURED_TFLOPS = 34.0                             # profiles/r02_fp64_peak.txt (mul+add chains, no FMA)
@@ -71,12 +77,40 @@ def parse():
     ap.add_argument('--members', type=int, default=0, help='c2: batch members per GPU (default 1); c4/c5: total batch (default 64 / 120)')
     ap.add_argument('--ny', type=int, default=1800)
     ap.add_argument('--nx', type=int, default=3600)
+    ap.add_argument('--mask', default='continents', choices=['continents', 'coastline', 'none'],
+                    help='c2 land mask: continent-size blobs (default, SURVEY 8(d)), coastline-scale, or none')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-parity', action='store_true', help='skip the post-run oracle parity check')
     ap.add_argument('--no-hbm', action='store_true', help='skip the HBM-bound variant')
+    ap.add_argument('--no-configs', action='store_true', help='skip the per-configuration lines')
+    ap.add_argument('--inproc', action='store_true', help='also time the in-process multi-device mode (host pointers, ndev = N)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--parity-sweeps', type=int, default=0, help='sweeps of the parity check (0 = the timed count)')
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------ the oracle (checker / CPU baseline only)
+def oracle_solve(q, mxLoop, tol, order):
+    import oracle as orc
+    S = np.array(q['S0'], dtype=np.float64, copy=True)
+    fl = np.array([0., 1., 0.])
+    c = [np.ascontiguousarray(a, dtype=np.float64) for a in q['coefs']]
+    k = q['kind']
+    if k == 'std2d':
+        orc.standard_2d(S, *c, q['yc'], q['xc'], q['dely'], q['delx'], q['BCy'], q['BCx'], q['delxSqr'],
+                        q['ratioQtr'], q['ratioSqr'], q['optArg'], q['undef'], fl, mxLoop, tol, order)
+    elif k == 'gen2d':
+        orc.general_2d(S, *c, q['yc'], q['xc'], q['dely'], q['delx'], q['BCy'], q['BCx'], q['delxSqr'],
+                       q['ratio'], q['ratioQtr'], q['ratioSqr'], q['optArg'], q['undef'], fl, mxLoop, tol, order)
+    elif k == 'bih2d':
+        orc.general_bih_2d(S, *c, q['yc'], q['xc'], q['dely'], q['delx'], q['BCy'], q['BCx'], q['delxSSr'],
+                           q['delxTr'], q['delxSqr'], q['ratio'], q['ratioSSr'], q['ratioQtr'], q['ratioSqr'],
+                           q['optArg'], q['undef'], fl, mxLoop, tol, order)
+    else:
+        orc.standard_3d(S, *c, q['zc'], q['yc'], q['xc'], q['delz'], q['dely'], q['delx'], q['BCz'], q['BCy'],
+                        q['BCx'], q['delxSqr'], q['ratio2Sqr'], q['ratio1Sqr'], q['optArg'], q['undef'], fl,
+                        mxLoop, tol, order)
+    return S, fl
 
 
 def cpu_baseline(q, budget_s):
@@ -85,16 +119,11 @@ def cpu_baseline(q, budget_s):
     build of the oracle made on THIS box; falls back to the travelling build."""
     import oracle as orc
     native = orc.use_native()
-    c = [np.ascontiguousarray(a, dtype=np.float64) for a in q['coefs']]
     npts = q['yc'] * q['xc']
 
     def run(nsweeps):
-        S = np.array(q['S0'], dtype=np.float64, copy=True)
-        fl = np.array([0., 1., 0.])
         t = time.perf_counter()
-        orc.standard_2d(S, *c, q['yc'], q['xc'], q['dely'], q['delx'], q['BCy'], q['BCx'],
-                        q['delxSqr'], q['ratioQtr'], q['ratioSqr'], q['optArg'], q['undef'], fl,
-                        nsweeps - 1, 0.0, orc.LEX)
+        oracle_solve(q, nsweeps - 1, 0.0, orc.LEX)
         return time.perf_counter() - t
 
     t2 = run(2)
@@ -122,30 +151,28 @@ def cpu_baseline(q, budget_s):
                                 'sample': '%d threads x %d sweeps, one slice each (%.1f s)' % (nthr, nsw, ta)}
     except Exception as e:                                   # the 1-core figure stands on its own
         out['all_cores'] = {'error': str(e)}
+    orc.use_portable()
     return out
 
 
-def oracle_parity(q, S_hip, flags_hip, sweeps):
+def oracle_parity(q, S_hip, flags_hip, sweeps, order=None):
     """Bitwise comparison of the HIP result with the oracle's coloured ordering (same input, same
     sweep count).  The checker, run after the timed region."""
     import oracle as orc
     orc.use_portable()                   # parity is defined against the -ffp-contract=off portable build
-    c = [np.ascontiguousarray(a, dtype=np.float64) for a in q['coefs']]
-    S = np.array(q['S0'], dtype=np.float64, copy=True)
-    fl = np.array([0., 1., 0.])
+    order = orc.COLOUR_2 if order is None else order
     t = time.perf_counter()
-    orc.standard_2d(S, *c, q['yc'], q['xc'], q['dely'], q['delx'], q['BCy'], q['BCx'], q['delxSqr'],
-                    q['ratioQtr'], q['ratioSqr'], q['optArg'], q['undef'], fl, sweeps - 1, 0.0, orc.COLOUR_2)
+    S, fl = oracle_solve(q, sweeps - 1, 0.0, order)
     dt = time.perf_counter() - t
-    same = bool(np.array_equal(S, S_hip))
-    nbad = int((S != S_hip).sum())
-    return {'bitwise': same, 'sweeps': int(sweeps), 'mismatching_points': nbad,
+    return {'bitwise': bool(np.array_equal(S, S_hip)), 'sweeps': int(sweeps),
+            'mismatching_points': int((S != S_hip).sum()),
             'loop_equal': bool(fl[2] == flags_hip[2]),
             'flag1_abs_diff': float(abs(fl[1] - flags_hip[1])),
-            'against': 'oracle/xinv_oracle.c coloured (red-black) ordering, %.1f s on 1 core' % dt}
+            'against': 'oracle/xinv_oracle.c coloured ordering, %.1f s on 1 core' % dt}
 
 
-def tile_model(s, ny, nx):
+# ------------------------------------------------------------------ what a launch must do / move
+def tile_model(s):
     """executed / useful point updates of the fused 2-D tiling actually used (recomputed halo rows
     and columns, pipeline steps rounded to the unroll)."""
     K, RY = s['sweeps_per_launch'], max(1, s['rows_per_tile'])
@@ -161,14 +188,85 @@ def tile_model(s, ny, nx):
     return steps * 128.0 / (RY * UW)
 
 
+def kernel_name(kind, s):
+    K, um = s['sweeps_per_launch'], s['xuniform_mask']
+    if s['path'] == 1:
+        return 'colour-pass kernels (%d colours)' % s['colours']
+    if s['path'] == 3:
+        return 'k_small2d'
+    if kind == 'bih2d':
+        return 'k_fusedbih (one pass per sweep, A..I per-row scalars)'
+    if kind == 'std3d':
+        return 'k_fused3d<K=%d, x-uniform mask=%d>' % (K, um)
+    model = {'std2d': 'Std2D', 'gen2d': 'Gen2D'}[kind]
+    if s.get('pipelined'):
+        return 'k_pipe2d<%s, NP=%d> (four sweeps per pass, one per wavefront; x-uniform mask=%d)' % (model, s['pipelined'], um)
+    if s['colours'] == 4:
+        return 'k_fused9<%s, K=%d>' % (model, K)
+    return 'k_fused2d<Fused%s, K=%d, x-uniform mask=%d>' % (model, K, um)
+
+
+def streamed_bytes_per_point_sweep(kind, s):
+    """bytes the kernel variant must move per point-sweep: S read + S write + every coefficient array
+    that is not a per-row scalar (and not an identically-zero B), 8 B each, over the K sweeps of a pass"""
+    K, um = max(1, s['sweeps_per_launch']), s['xuniform_mask']
+    if s['path'] != 2:
+        return None
+    if kind == 'std2d':
+        nvec = 3 - bin(um & 7).count('1')                   # A, C, F
+    elif kind == 'gen2d':
+        nvec = 6 - bin(um & 63).count('1')                  # A, C, D, E, F, G
+    elif kind == 'std3d':
+        nvec = 4 - bin(um & 7).count('1')                   # A, B, C + forcing
+    else:
+        nvec = 1                                            # biharmonic one-pass kernel: forcing J only
+    return 8.0 * (2 + nvec) / K
+
+
+def roofline_of(kind, s, pts_per_launch_all, avg_ms):
+    """VALU and bandwidth fractions of the dominant kernel on the tiles that RAN; bound = the larger."""
+    active = 1.0 - s.get('masked_tile_ppm', 0) / 1e6
+    upd = pts_per_launch_all * active
+    tf = UPD_FLOPS[kind] * upd / (avg_ms * 1e-3) / 1e12
+    bpp = streamed_bytes_per_point_sweep(kind, s)
+    gbs = (bpp * upd / (avg_ms * 1e-3) / 1e9) if bpp else None
+    vf = tf / FP64_VALU_PEAK_TFLOPS
+    hf = (gbs / HBM_PEAK_GBS) if gbs else 0.0
+    r = {'valu_TFLOPs': tf, 'valu_frac': vf, 'streamed_GBps': gbs, 'streamed_frac_of_hbm_peak': hf if gbs else None,
+         'streamed_bytes_per_point_sweep': bpp, 'active_tile_share': active, 'avg_launch_ms': avg_ms}
+    # a launch whose buffers (S twice + the vector streams) fit the 256 MiB Infinity Cache is served by the fabric,
+    # not by HBM (measured: 7 TB/s on the 259 MB K = 1 variant): its bytes are not priced against the HBM roof
+    nvec = (bpp * max(1, s['sweeps_per_launch']) / 8.0 - 2) if bpp else 0
+    ws = pts_per_launch_all / max(1.0, float(s['sweeps_per_launch'])) * 8.0 * (2 + nvec)
+    r['working_set_bytes'] = ws
+    r['in_infinity_cache'] = bool(ws < 230e6)
+    if hf > vf and not r['in_infinity_cache']:
+        r.update({'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hf})
+    else:
+        r.update({'bound': 'valu_fp64', 'achieved': tf, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': vf})
+    return r
+
+
+# ------------------------------------------------------------------ problems
+def c2_problem(a, rank=0, members=1, shared=True):
+    from xinvert_amd import synthetic
+    mask = {'continents': True, 'coastline': 'coastline', 'none': False}[a.mask]
+    p = synthetic.poisson_latlon(a.ny, a.nx, mask=mask, seed=synthetic.SEED + rank, members=members)
+    if not shared:                                           # every member its own A and C (HBM leg: nothing shared
+        p = dict(p)                                          # but the identically-zero B, which travels as NULL)
+        p['coefs'] = [np.broadcast_to(c, (members,) + c.shape) if k in (0, 2) else c for k, c in enumerate(p['coefs'])]
+        p['shared'] = (1,)
+    return p
+
+
 def build_problem(a, rank, world):
-    """-> (problem dict restricted to this rank's members, total members over all ranks, scaling)."""
+    """-> (problem dict restricted to this rank's members, total members over all ranks, scaling, name)."""
     from xinvert_amd import synthetic
     from xinvert_amd import dist as xdist
     if a.config == 'c2':
         nb = a.members or 1
-        p = synthetic.poisson_latlon(a.ny, a.nx, mask=True, seed=synthetic.SEED + rank, members=nb)
-        return p, nb * world, 'weak', 'invert_Poisson %dx%d lat-lon, land/sea mask, periodic-x, fixed-y (BASELINE configs[1])' % (a.nx, a.ny)
+        p = c2_problem(a, rank, nb)
+        return p, nb * world, 'weak', 'invert_Poisson %dx%d lat-lon, land/sea mask (%s), periodic-x, fixed-y (BASELINE configs[1])' % (a.nx, a.ny, a.mask)
     total = a.members or (64 if a.config == 'c4' else 120)
     lo, hi = xdist.shard_range(total, rank, world)
     if a.config == 'c4':
@@ -188,8 +286,130 @@ def build_problem(a, rank, world):
     return p, total, 'strong', 'invert_omega 720x360x50, %d time steps (BASELINE configs[4])' % total
 
 
+def time_resident(rp, sweeps, steps, warmup, **opts):
+    """-> (wall seconds of `steps` solves, sum of HIP-event ms over the sweep launches, launches, last stats, flags)"""
+    import torch
+    for _ in range(warmup):
+        rp.reset(); rp.solve(sweeps - 1, 0.0, **opts)
+    rp.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms, nl = 0.0, 0
+    for _ in range(steps):
+        fl, s = rp.solve(sweeps - 1, 0.0, **opts)
+        ms += s['sweep_ms']; nl += s['sweep_launches']
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ms, nl, s, fl
+
+
+def config_lines(local):
+    """The other BASELINE configurations on this GPU, one short timed run + an oracle parity check each."""
+    import oracle as orc
+    from xinvert_amd import synthetic
+    from xinvert_amd.resident import ResidentProblem
+    todo = [
+        ('C1', 'invert_Poisson 360x180 lat-lon, one slice (BASELINE configs[0])',
+         lambda: synthetic.poisson_latlon(180, 360, mask=False), 500, 10, orc.COLOUR_2, 25),
+        ('C3-Stommel', 'invert_Stommel 2000x2000 Cartesian, R(x,y) varying (BASELINE configs[2])',
+         lambda: synthetic.stommel_cartesian(2000, 2000), 300, 3, orc.COLOUR_2, 12),
+        ('C3-Munk', 'invert_StommelMunk 2000x2000 Cartesian, biharmonic form (BASELINE configs[2])',
+         lambda: synthetic.munk_cartesian(2000, 2000), 100, 3, orc.COLOUR_AUTO, 10),
+        ('C4', 'invert_GillMatsuno 1440x720, 8 of the 64 forcing members (BASELINE configs[3]; --config c4 runs all 64)',
+         lambda: synthetic.gill_matsuno(720, 1440, 8), 200, 3, orc.COLOUR_2, 12),
+        ('C5', 'invert_omega 720x360x50, 2 of the 120 time steps (BASELINE configs[4]; --config c5 runs all 120)',
+         lambda: synthetic.omega_latlon(50, 360, 720, steps=2), 60, 3, orc.COLOUR_2, 10),
+    ]
+    out = []
+    for name, wl, make, sweeps, steps, order, psw in todo:
+        t_all = time.perf_counter()
+        p = make()
+        kind = p['kind']
+        rp = ResidentProblem(p, device=local)
+        dt, ms, nl, s, fl = time_resident(rp, sweeps, steps, 1, timing=1)
+        ok = bool((fl[:, 2] == sweeps - 1).all() and not fl[:, 0].any())
+        n_all = float(rp.nb) * rp.n
+        avg_ms = ms / max(nl, 1)
+        spl_mean = float(sweeps) * steps / max(nl, 1)
+        r = roofline_of(kind, s, n_all * spl_mean, avg_ms)
+        rp.reset()
+        flp, _ = rp.solve(psw - 1, 0.0)
+        res = rp.result()
+        m_chk = sorted({0, rp.nb - 1})
+        par = [oracle_parity(synthetic.member(p, m), res[m], flp[m], psw, order) for m in m_chk]
+        out.append({'name': name, 'workload': wl, 'value': n_all * sweeps * steps / dt, 'unit': 'point-sweeps/s',
+                    'members': rp.nb, 'sweeps_per_step': sweeps, 'steps': steps, 'ran_all_sweeps': ok,
+                    'kernel': kernel_name(kind, s), 'sweeps_per_launch': s['sweeps_per_launch'],
+                    'rows_per_tile': s['rows_per_tile'], 'bound': r['bound'], 'frac': r['frac'], 'achieved': r['achieved'],
+                    'peak': r['peak'], 'unit_roofline': r['unit'], 'valu_frac': r['valu_frac'],
+                    'streamed_frac_of_hbm_peak': r['streamed_frac_of_hbm_peak'],
+                    'streamed_bytes_per_point_sweep': r['streamed_bytes_per_point_sweep'],
+                    'alg_bytes_per_point_sweep': ALG_BYTES[kind], 'avg_launch_us': avg_ms * 1e3,
+                    'parity_bitwise': bool(all(q['bitwise'] and q['loop_equal'] for q in par)),
+                    'parity_sweeps': psw, 'parity_members': m_chk,
+                    'seconds': time.perf_counter() - t_all})
+        del rp
+    return out
+
+
+def inproc_leg(a, ngpu):
+    """The in-process multi-device mode: host pointers, one call, xinv_options.ndev = ngpu."""
+    import ctypes
+    from xinvert_amd import _lib, synthetic
+    from xinvert_amd.resident import FN, scalars
+    L = _lib.require_gpu()
+    nb = max(ngpu, a.members or ngpu) if a.config == 'c2' else (a.members or 8 * ngpu)
+    p = synthetic.poisson_latlon(a.ny, a.nx, mask=True, members=nb) if a.config == 'c2' else \
+        (synthetic.gill_matsuno(720, 1440, nb) if a.config == 'c4' else synthetic.omega_latlon(50, 360, 720, steps=nb))
+    sweeps = a.sweeps or (200 if a.config == 'c5' else 500)
+    n = int(np.prod(p['S0'].shape[1:]))
+    arrs, strides = [np.ascontiguousarray(p['S0'], dtype=np.float64)], [n]
+    for k, c in enumerate(p['coefs']):
+        if k == 1 and p['kind'] in ('std2d', 'gen2d') and not np.asarray(c).any():
+            arrs.append(None); strides.append(0)
+        else:
+            arrs.append(np.ascontiguousarray(c, dtype=np.float64)); strides.append(0 if k in p['shared'] else n)
+    fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
+    o = _lib.options(devices=list(range(ngpu)), timing=1)
+    q = {k: v for k, v in p.items() if k not in ('S0', 'coefs')}
+    best = None
+    for _ in range(3):
+        S = arrs[0].copy()
+        t = time.perf_counter()
+        rc = getattr(L, FN[p['kind']] + '_batched')(_lib.hptr(S), *[_lib.hptr(x) for x in arrs[1:]], nb,
+                                                    _lib.strides_arg(strides), *scalars(q), _lib.hptr(fl),
+                                                    sweeps - 1, 0.0, ctypes.byref(o))
+        dt = time.perf_counter() - t
+        _lib.check(rc)
+        best = dt if best is None else min(best, dt)
+    st = _lib.last_stats()
+    return {'mode': 'one process, host pointers, xinv_options.ndev = %d (one host thread per GPU, no collective)' % ngpu,
+            'devices_used': st['devices'], 'members': nb, 'sweeps': sweeps,
+            'value_pcie_inclusive': float(nb) * n * sweeps / best, 'unit': 'point-sweeps/s',
+            'wall_ms': best * 1e3, 'h2d_ms': st['h2d_ms'], 'd2h_ms': st['d2h_ms'], 'sweep_ms': st['sweep_ms'],
+            'note': 'upload + sweeps + download of host arrays: never the headline `value`'}
+
+
+def self_launch(a):
+    """--gpus N > 1 outside torchrun: start the N ranks ourselves and relay their exit status."""
+    import torch
+    forced = 'XINV_FORCE_DEVICE' in os.environ              # testing aid: several ranks share one GPU (gloo)
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and not forced:
+        raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible; refusing to run fewer ranks than asked '
+                         '(set XINV_FORCE_DEVICE=0 XINV_DIST_BACKEND=gloo to share one GPU in a test)' % (a.gpus, ndev))
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     from xinvert_amd import _lib, synthetic
     from xinvert_amd import dist as xdist
@@ -197,7 +417,7 @@ def main():
 
     rank, local, world = xdist.init_process_group()
     joined = torch.distributed.is_available() and torch.distributed.is_initialized()
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, a.gpus))
     _lib.require_gpu()
     # XINV_FORCE_DEVICE: testing aid (several ranks on one GPU with the gloo backend)
@@ -240,12 +460,18 @@ def main():
         ms_sweeps += s['sweep_ms']; launches += s['sweep_launches']
     barrier()
     dt = time.perf_counter() - t0
+    ranks_done, backend = 1, None
     if joined:
-        tdev = dev if torch.distributed.get_backend() == 'nccl' else torch.device('cpu')
+        backend = torch.distributed.get_backend()
+        tdev = dev if backend == 'nccl' else torch.device('cpu')
         tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+        one = torch.ones(1, dtype=torch.float64, device=tdev)          # ranks that really took part
+        torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
+        ranks_done = int(round(float(one.item())))
     assert (allf[:, 2] == sweeps - 1).all() and not allf[:, 0].any(), allf[:4]
+    assert allf.shape[0] == total_members
 
     if rank == 0:
         total_ps = float(total_members) * n * sweeps * a.steps
@@ -254,62 +480,47 @@ def main():
         # the timed launches: full K-sweep passes plus one shorter tail pass per step when K does
         # not divide the sweep count; per-launch figures below use the mean over all of them
         sweeps_per_launch_mean = float(sweeps) * a.steps / max(launches, 1)
-        upd_per_launch = float(nb) * n * sweeps_per_launch_mean
+        pts_per_launch = float(nb) * n * sweeps_per_launch_mean
+        active = 1.0 - s['masked_tile_ppm'] / 1e6
         out = {
             'metric': 'SOR grid-points*iters/sec (fp64) at %dx%d%s, masked points counted'
                       % ((a.nx, a.ny, '') if a.config == 'c2' else
                          ((1440, 720, ' x %d members' % total_members) if a.config == 'c4' else
                           (720, 360, 'x50 x %d steps' % total_members))),
             'value': total_ps / dt, 'unit': 'point-sweeps/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'n_gpus': ranks_done, 'gpus_requested': a.gpus, 'rccl_ranks': ranks_done if backend == 'nccl' else 0,
+            'collective_backend': backend, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': wl_name, 'sweeps_per_step': sweeps,
                        'members_total': total_members, 'members_this_gpu': nb,
                        'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'],
                        'xuniform_mask': s['xuniform_mask'], 'masked_tile_pct': s['masked_tile_pct'],
-                       'path': {1: 'colour', 2: 'fused'}.get(s['path'], '?'),
+                       'masked_tile_share': 1.0 - active,
+                       'path': {1: 'colour', 2: 'fused', 3: 'small'}.get(s['path'], '?'),
                        'parallelism': 'batch-axis shard x%d' % world},
         }
-        if s['masked_tile_pct']:
-            out['value_active'] = out['value'] * (1.0 - s['masked_tile_pct'] / 100.0)
-        flops = UPD_FLOPS[kind] * upd_per_launch
-        achieved_tf = flops / (avg_ms * 1e-3) / 1e12
-        roof = {'bound': 'valu_fp64', 'achieved': achieved_tf, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved_tf / FP64_VALU_PEAK_TFLOPS,
-                'peak_note': 'fp64 vector issue rate without FMA (256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz); '
-                             'contraction is off by the bit-exactness contract; datasheet FMA peak %.1f'
-                             % FP64_FMA_SPEC_TFLOPS,
-                'frac_of_fma_spec': achieved_tf / FP64_FMA_SPEC_TFLOPS,
-                'frac_of_measured_peak': achieved_tf / FP64_VALU_MEASURED_TFLOPS,
-                'useful_flops_per_point_update': UPD_FLOPS[kind],
-                'kernel': ('k_pipe2d<NP=%d> (four sweeps per pass, one per wavefront; x-uniform mask=%d)'
-                           % (s['pipelined'], s['xuniform_mask'])) if s.get('pipelined')
-                          else ('k_fused2d<FusedStd2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask'])) if kind == 'std2d'
-                          else ('k_fused2d<FusedGen2D, K=%d, x-uniform mask=%d>' % (spl, s['xuniform_mask'])) if kind == 'gen2d'
-                          else 'k_fused3d',
-                'avg_launch_ms': avg_ms, 'launches': int(launches),
-                'alg_bytes_per_launch': ALG_BYTES[kind] * upd_per_launch,
-                'alg_equiv_GBps': ALG_BYTES[kind] * upd_per_launch / (avg_ms * 1e-3) / 1e9}
-        if kind != 'std3d':
-            em = tile_model(s, p['yc'], p['xc'])
-            if em:
-                roof['executed_over_useful'] = em
-                roof['frac_executed'] = roof['frac'] * em
-        if kind == 'std3d':
-            # the 3-D kernels are bound by what the fabric delivers, not by the VALU: S read + S write +
-            # the forcing + every coefficient array that is not a per-row scalar, 8 B each
-            nstream = 3 + (3 - bin(s['xuniform_mask'] & 7).count('1'))
-            vb = 8.0 * nstream * upd_per_launch
-            roof.update({'bound': 'hbm', 'achieved': vb / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': vb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'bytes_note': 'bytes the kernel variant must move per point-sweep: %d streams x 8 B '
-                                       '(x-uniform coefficient arrays are per-row scalars); SURVEY 8(d) algorithmic '
-                                       'figure kept as alg_equiv_GBps' % nstream,
-                         'valu_TFLOPs': achieved_tf, 'valu_frac': achieved_tf / FP64_VALU_PEAK_TFLOPS})
+        out['value_active'] = out['value'] * active
+        rr = roofline_of(kind, s, pts_per_launch, avg_ms)
+        roof = dict(rr)
+        roof.update({
+            'note': 'point updates of the tiles that RAN (skipped, fully masked tiles are not counted: active_tile_share) '
+                    'x useful fp64 operations / mean launch duration; `streamed_*`: bytes this kernel variant must move',
+            'peak_note': 'valu_fp64: fp64 vector issue rate without FMA (256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz; '
+                         'contraction is off by the bit-exactness contract; datasheet FMA peak %.1f); hbm: 8 TB/s spec'
+                         % FP64_FMA_SPEC_TFLOPS,
+            'frac_of_measured_valu_peak': rr['valu_TFLOPs'] / FP64_VALU_MEASURED_TFLOPS,
+            'useful_flops_per_point_update': UPD_FLOPS[kind],
+            'kernel': kernel_name(kind, s),
+            'launches': int(launches),
+            'alg_bytes_per_launch': ALG_BYTES[kind] * pts_per_launch,
+            'alg_equiv_GBps': ALG_BYTES[kind] * pts_per_launch / (avg_ms * 1e-3) / 1e9})
+        em = tile_model(s) if kind in ('std2d', 'gen2d') else None
+        if em:
+            roof['executed_over_useful'] = em
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile) and a.config == 'c2' and (a.ny, a.nx) == (1800, 3600) and nb == 1:
+        if os.path.exists(tfile) and a.config == 'c2' and (a.ny, a.nx) == (1800, 3600) and nb == 1 and a.mask == 'continents':
             try:
                 traffic = json.load(open(tfile)).get(('std2d_pipe_um%d' % s['xuniform_mask']) if s.get('pipelined')
                                                      else 'std2d_spl%d_um%d' % (spl, s['xuniform_mask']))
@@ -322,54 +533,66 @@ def main():
             roof['traffic_frac_of_hbm_peak'] = roof['traffic_GBps'] / HBM_PEAK_GBS
         out['roofline'] = roof
 
-        if a.config == 'c2' and world == 1 and not a.no_hbm:
-            # ---- the HBM-bound variant: K = 1, every array streamed, every tile run -----------
-            hb = ResidentProblem(p, device=local, null_zero_B=False)
+        single = (world == 1)
+        if a.config == 'c2' and single and not a.no_hbm:
+            # ---- the HBM-bound variant on a working set far beyond the Infinity Cache -----------------
+            hm = 8
+            ph = c2_problem(a, 0, hm, shared=False)
+            hb = ResidentProblem(ph, device=local)
             hopts = dict(sweeps_per_launch=1, timing=1, no_xuniform=1, no_tile_skip=1)
-            hsw = 100
-            hb.solve(hsw - 1, 0.0, **hopts)
-            hb.reset()
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            hms, hl = 0.0, 0
-            for _ in range(5):
-                fl_h, sh = hb.solve(hsw - 1, 0.0, **hopts)
-                hms += sh['sweep_ms']; hl += sh['sweep_launches']
-            torch.cuda.synchronize()
-            th = time.perf_counter() - th
+            hsw = 60
+            th, hms, hl, sh, fl_h = time_resident(hb, hsw, 3, 1, **hopts)
             h_avg = hms / max(hl, 1)
-            h_ach = ALG_BYTES[kind] * float(nb) * n / (h_avg * 1e-3) / 1e9
-            htraffic = None
-            try:
-                htraffic = json.load(open(tfile)).get('std2d_spl1_um0_all')
-            except Exception:
-                pass
+            pts = float(hm) * n
+            ws_bytes = pts * 8.0 * 5                         # S, S2 (ping-pong twin), A, C, F per member
+            h40 = 40.0 * pts / (h_avg * 1e-3) / 1e9
+            h48 = 48.0 * pts / (h_avg * 1e-3) / 1e9
+            hb.reset()
+            flq, _ = hb.solve(9, 0.0, **hopts)
+            hpar = oracle_parity(synthetic.member(ph, hm - 1), hb.result()[hm - 1], flq[hm - 1], 10)
             out['roofline_hbm'] = {
-                'bound': 'hbm', 'achieved': h_ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': h_ach / HBM_PEAK_GBS,
-                'variant': 'k_fused2d<FusedStd2D, K=1, x-uniform mask=0>: one sweep per pass, S A C F streamed in full '
-                           '(B is identically zero: detected, not re-read per sweep; still counted in the 48 B), no tile skipping',
-                'value': float(nb) * n * hsw * 5 / th, 'unit_value': 'point-sweeps/s',
-                'avg_launch_ms': h_avg, 'launches': int(hl), 'alg_bytes_per_launch': ALG_BYTES[kind] * float(nb) * n,
-                'traffic': htraffic, 'traffic_source': roof['traffic_source'],
-                'traffic_GBps': (htraffic / (h_avg * 1e-3) / 1e9) if htraffic else None,
-                'traffic_frac_of_hbm_peak': (htraffic / (h_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if htraffic else None,
-                'note': 'S (two buffers) + A + C + F = 259 MB fit the 256 MiB Infinity Cache almost entirely: the measured '
-                        'bytes are fabric traffic, the HBM itself is touched less',
+                'bound': 'hbm', 'achieved': h40, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': h40 / HBM_PEAK_GBS,
+                'frac_of_achievable_6300': h40 / 6300.0,
+                'bytes_counted_per_point_sweep': 40,
+                'alg48_GBps': h48, 'alg48_frac': h48 / HBM_PEAK_GBS,
+                'variant': 'k_fused2d<FusedStd2D, K=1, x-uniform mask=0>, %d members each with its own A, C, F: one sweep per pass, '
+                           'S (read + write) A C F streamed in full = 40 B per point (B is identically zero: detected once, never '
+                           'read; SURVEY 8(d) counts it: the 48 B figure is alg48_*), no tile skipping' % hm,
+                'working_set_bytes': ws_bytes, 'members': hm,
+                'value': pts * hsw * 3 / th, 'unit_value': 'point-sweeps/s',
+                'avg_launch_ms': h_avg, 'launches': int(hl),
                 'sweeps_per_launch': sh['sweeps_per_launch'], 'xuniform_mask': sh['xuniform_mask'],
-                'masked_tile_pct': sh['masked_tile_pct']}
+                'masked_tile_pct': sh['masked_tile_pct'], 'parity_bitwise_10_sweeps': hpar['bitwise'] and hpar['loop_equal'],
+                'traffic': None}
             del hb
 
-        if a.config == 'c2' and world == 1 and not a.no_parity:
+        if a.config == 'c2' and single and not a.no_parity:
             psw = a.parity_sweeps or sweeps
             rp.reset()
             fl_p, sp_ = rp.solve(psw - 1, 0.0, **opts)
             same_cfg = all(sp_[k] == s[k] for k in ('path', 'sweeps_per_launch', 'rows_per_tile',
-                                                    'xuniform_mask', 'masked_tile_pct'))
-            q = synthetic.member(p, 0)
-            par = oracle_parity(q, rp.result()[0], fl_p[0], psw)
+                                                    'xuniform_mask', 'masked_tile_pct', 'pipelined'))
+            par = oracle_parity(synthetic.member(p, 0), rp.result()[0], fl_p[0], psw)
             par['same_kernel_config_as_timed'] = bool(same_cfg)
             out['parity'] = par
-        if a.config == 'c2' and world == 1 and not a.no_cpu:
+        if a.config == 'c2' and single and a.mask == 'continents' and not a.no_configs:
+            # mask sensitivity of the headline: the same solve with a coastline-scale mask
+            # (few whole tiles to skip) and with tile skipping off
+            alt = {}
+            for tag, mk, o2 in (('coastline_mask', 'coastline', {}), ('no_tile_skip', None, {'no_tile_skip': 1})):
+                p2 = synthetic.poisson_latlon(a.ny, a.nx, mask=mk, members=nb) if mk else p
+                r2 = ResidentProblem(p2, device=local) if mk else rp
+                t2, m2, l2, s2, _ = time_resident(r2, sweeps, 5, 1, timing=1, **o2)
+                alt[tag] = {'value': float(nb) * n * sweeps * 5 / t2, 'masked_tile_share': s2['masked_tile_ppm'] / 1e6,
+                            'land_share': float(np.mean(p2['coefs'][3] == p2['undef'])),
+                            'avg_launch_us': m2 / max(l2, 1) * 1e3, 'kernel': kernel_name(kind, s2)}
+            out['mask_sensitivity'] = alt
+        del rp
+        if a.config == 'c2' and single and not a.no_configs:
+            out['configs'] = config_lines(local)
+        if a.inproc and single:
+            out['inproc'] = inproc_leg(a, a.gpus)
+        if a.config == 'c2' and single and not a.no_cpu:
             out['cpu_baseline'] = cpu_baseline(synthetic.member(p, 0), a.cpu_seconds)
         print(json.dumps(out))
     if joined:

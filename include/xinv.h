@@ -123,7 +123,8 @@ typedef struct xinv_stats {
     int32_t pipelined;          /* fused 2-D path: the full passes ran the wave-pipelined kernel (k_pipe2d:
                                    one tile per workgroup, one sweep per wavefront); value = column pairs
                                    per lane (1 or 2), 0 = k_fused2d                              */
-    int32_t pad1_;
+    int32_t masked_tile_ppm;    /* masked_tile_pct at full resolution: skipped wave-tiles per million (bench.py prices
+                                   its roofline on the tiles that ran)                           */
 } xinv_stats;
 
 void        xinv_default_options(xinv_options *opt);

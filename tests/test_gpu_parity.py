@@ -252,29 +252,57 @@ def test_fused_standard_three_and_four_sweeps_per_pass(BCy, BCx, msk, shape, K, 
     assert_same(S[0], fl[0], So, flo, 'fused K=auto %r' % (shape,))
 
 
+def _uniform2d_all(p):
+    """every coefficient array but the forcing constant along x (lat-lon Gill-Matsuno: A, C, D, E, F per row)"""
+    q = dict(p); cs = [np.array(c, copy=True) for c in p['coefs']]
+    for k in range(len(cs) - 1):
+        if k != 1:                                    # (B stays what it is: identically zero here)
+            cs[k] = np.repeat(cs[k][:, :1], cs[k].shape[1], axis=1)
+    q['coefs'] = cs
+    return q
+
+
 @pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'), ('extend', 'fixed')])
 @pytest.mark.parametrize('shape', [(40, 300), (33, 257), (64, 512), (90, 250), (200, 1200)])
-def test_pipelined_pass_equals_single_wavefront_pass(BCy, BCx, shape):
-    """k_pipe2d (four sweeps pipelined across the wavefronts of a workgroup; one or two column pairs per
-    lane) against k_fused2d K = 4 (XINV_FLAG_NO_PIPE) and the oracle: bit for bit, masked tiles skipped or not,
-    several members with their own coefficients, stats.pipelined reporting which kernel ran."""
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+def test_pipelined_pass_equals_single_wavefront_pass(BCy, BCx, shape, kind):
+    """k_pipe2d (four sweeps pipelined across the wavefronts of a workgroup; standard form with per-row A, C --
+    one or two column pairs per lane -- and general form with per-row A, C, D, E, F) against k_fused2d
+    (XINV_FLAG_NO_PIPE) and the oracle: bit for bit, masked tiles skipped or not, several members with
+    their own coefficients, stats.pipelined reporting which kernel ran."""
+    import os
     yc, xc = shape
     if BCx == 'periodic' and xc % 2:
         pytest.skip('odd-xc periodic seam goes through the colour path')
-    ps = [_uniform2d(rand2d('std2d', yc, xc, BCy, BCx, 0, m & 1, seed=_seed(('pipe', BCy, BCx, shape, m)))) for m in range(3)]
+    uni = _uniform2d if kind == 'std2d' else _uniform2d_all
+    ps = [uni(rand2d(kind, yc, xc, BCy, BCx, 0, m & 1, seed=_seed(('pipe', kind, BCy, BCx, shape, m)))) for m in range(3)]
     ref = [run_oracle(p, 26, 1e-9, COLOUR_2) for p in ps]
     S0, f0, st0 = run_hip_batched(ps, 26, 1e-9, path=PATH_FUSED, sweeps_per_launch=4, no_pipe=1)
-    assert st0['pipelined'] == 0
-    for np_ in ('1', '2'):
-        import os
-        os.environ['XINV_PIPE_NP'] = np_                  # read once per process by the library: see below
-        for kw in (dict(), dict(rows_per_tile=16), dict(force_tile_skip=1), dict(rows_per_tile=-3)):
-            S, fl, st = run_hip_batched(ps, 26, 1e-9, path=PATH_FUSED, sweeps_per_launch=4, **kw)
-            assert st['pipelined'] in (1, 2) and st['sweeps_per_launch'] == 4, st
+    assert st0['pipelined'] == 0 and st0['xuniform_mask'] == (3 if kind == 'std2d' else 31), st0
+    for np_ in (('1', '2') if kind == 'std2d' else ('1',)):
+        os.environ['XINV_PIPE_NP'] = np_                  # read per solve by the library
+        for kw in (dict(), dict(rows_per_tile=16), dict(force_tile_skip=1), dict(rows_per_tile=-3), dict(sweeps_per_launch=4)):
+            o = dict(path=PATH_FUSED); o.update(kw)
+            S, fl, st = run_hip_batched(ps, 26, 1e-9, **o)
+            assert st['pipelined'] == int(np_) and st['sweeps_per_launch'] == 4, st
             for m in range(3):
-                assert_same(S[m], fl[m], ref[m][0], ref[m][1], 'pipelined %r member %d %r' % (shape, m, kw))
+                assert_same(S[m], fl[m], ref[m][0], ref[m][1], 'pipelined %s %r member %d %r' % (kind, shape, m, kw))
             assert np.array_equal(S, S0)
     os.environ.pop('XINV_PIPE_NP', None)
+
+
+@pytest.mark.parametrize('tol', [3e-3, 1e-3, 2e-4, 5e-5])
+def test_pipelined_general_form_early_stop_exact_sweep(tol):
+    """The stop rule firing inside a four-sweep pipelined pass of the general form returns exactly the oracle's
+    stopping sweep (redo from the pass's source with the single-sweep kernel), lagged norm or not."""
+    p = _uniform2d_all(rand2d('gen2d', 40, 300, 'fixed', 'periodic', 0, 1, seed=7))
+    So, flo = run_oracle(p, 500, tol, COLOUR_2)
+    assert 2 < flo[2] < 499
+    for kw in (dict(rows_per_tile=8, check_every=5), dict(), dict(force_tile_skip=1)):
+        S, fl, st = run_hip_batched([p], 500, tol, path=PATH_FUSED, **kw)
+        assert st['pipelined'] == 1 and st['sweeps_per_launch'] == 4, st
+        assert_same(S[0], fl[0], So, flo, 'general form, early stop %r' % (kw,))
+        assert st['sweeps_max'] == flo[2] + 1
 
 
 @pytest.mark.parametrize('K', [3, 4])

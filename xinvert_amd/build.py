@@ -37,7 +37,13 @@ UNITS = [
 SOURCES = sorted({u[1] for u in UNITS})
 # -ffp-contract=off: no FMA contraction, so device results are bitwise those of the
 # CPU restatement of the same sweep ordering (see DESIGN.md "Arithmetic").
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC'] + EXTRA
+# -amdgpu-scalarize-global-loads=0: the compiler must not turn a uniform load from GLOBAL memory into an
+# s_load.  The scalar data cache is not coherent with vector stores and was seen serving a previous solve's
+# data from a reused workspace address; with this switch only loads the source spells out
+# through the constant address space (kernel arguments; k_pipe2d's per-row records, behind its
+# s_dcache_inv) use the scalar unit.  tools/smem_audit.py checks the built objects for exactly that.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+         '-mllvm', '-amdgpu-scalarize-global-loads=0'] + EXTRA
 
 
 def hipcc():

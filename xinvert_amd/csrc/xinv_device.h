@@ -20,7 +20,12 @@
 // members 3.94 -> 3.67e11), and the two words every kernel reads of state written by its predecessor -- the stop
 // flag and the sequence number, at a uniform address, hence an s_load if left to the compiler -- are read with
 // agent-scope atomic loads (vector loads through the coherent L2; a stale `done` would silently skip a pass).
-__device__ __forceinline__ void xinv_fresh_scalar_cache() { __builtin_amdgcn_s_dcache_inv(); }
+// The invalidate returns on the LGKM counter like a scalar load: wait for it before anything else is issued
+// (the compiler barrier keeps later loads below it; tools/smem_audit.py checks the order in the binary).
+__device__ __forceinline__ void xinv_fresh_scalar_cache()
+{
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
 #ifndef XINV_DPP_ZERO_EDGE
 #define XINV_DPP_ZERO_EDGE 1
 #endif

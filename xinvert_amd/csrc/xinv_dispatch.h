@@ -20,10 +20,11 @@ XINV_HIDDEN int xinv_launch_fused2d_gen(bool al, bool ext, unsigned um, int K, d
                                         hipStream_t st, const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused2d_std2dt(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                                            hipStream_t st, const FusedArgs &a, int *occ);
-// wave-pipelined four-sweep pass (standard form, per-row A and C): one tile per 256-thread workgroup
+// wave-pipelined four-sweep pass (standard form with per-row A and C; gen: general form with per-row A, C, D, E, F):
+// one tile per 256-thread workgroup
 // (np = 1 or 2 column pairs per lane: strips of XINV_PIPE_UW(np) owned columns)
 // lds_pad: unused dynamic LDS per workgroup, which caps how many of them share a CU (see launch_fused)
-XINV_HIDDEN int xinv_launch_pipe2d(int np, bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ,
+XINV_HIDDEN int xinv_launch_pipe2d(bool gen, int np, bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ,
                                    int lds_pad = 0);
 XINV_HIDDEN int xinv_launch_fused9(bool gen, int K, bool al, bool ext, dim3 grid, hipStream_t st,
                                    const FusedArgs &a, int *occ);

@@ -167,6 +167,15 @@ __device__ __forceinline__ double cget(const CoefWin<NC, D> &w, int slot)
 struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
     static constexpr int NC = 3;    // A, C, F
     template <unsigned UM> static constexpr bool hoist() { return (UM & 3u) == 3u; }   // A and C uniform
+    // wave-pipelined pass (xinv_pipe2d.h): per-row record {A[j], C[j], relaxation factor of row j, row predicate}
+    static constexpr unsigned PIPE_UM = 3u;
+    static constexpr int PIPE_RW = 4, PIPE_FQ = 2, PIPE_PFR = 2;
+    static constexpr bool PIPE_PREMUL = true;             // the forcing enters the update as F * delxSqr
+    template <int D>
+    static __device__ __forceinline__ void pipe_row(CoefWin<NC, D> &w, int slot, const double (&rec)[PIPE_RW], double &rok)
+    {
+        w.s[0][slot] = rec[0]; w.s[1][slot] = rec[1]; w.rq[slot] = rec[2]; rok = rec[3];
+    }
 
     // called once per step after row r entered slot `sr`; `s1` = slot of row r-1, whose operands
     // (A[r], A[r-1], C[r-1], F[r-1]) are all in the window now: relaxation factor when it is
@@ -287,6 +296,18 @@ struct FusedStd2DT {                // numbas.invert_standard_2D_test, B == 0 an
 struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     static constexpr int NC = 6;    // A, C, D, E, F, G
     template <unsigned UM> static constexpr bool hoist() { return (UM & 0x13u) == 0x13u; }  // A, C, F uniform
+    // wave-pipelined pass: per-row record {A, C, D, E, F of row j, relaxation factor, row predicate, -}; the update of
+    // a row reads only its own record, so it is asked for one step ahead (fewer records live in SGPRs)
+    static constexpr unsigned PIPE_UM = 0x1fu;
+    static constexpr int PIPE_RW = 8, PIPE_FQ = 5, PIPE_PFR = 1;
+    static constexpr bool PIPE_PREMUL = false;            // G enters as (F S - G) * delxSqr
+    template <int D>
+    static __device__ __forceinline__ void pipe_row(CoefWin<NC, D> &w, int slot, const double (&rec)[PIPE_RW], double &rok)
+    {
+#pragma unroll
+        for (int q = 0; q < 5; q++) w.s[q][slot] = rec[q];
+        w.rq[slot] = rec[5]; rok = rec[6];
+    }
 
     // every operand of the predicate (numbas.py:1126-1129) sits on the point itself: row r-1 is
     // handled here like in the other models (its first half-sweep runs in this very step)

@@ -33,7 +33,7 @@
 #define XINV_AUX_KERNELS            /* the detection / skip-norm helper kernels live in this unit */
 #include "xinv_dispatch.h"          /* argument structs + launchers of the sweep kernels (xinv_tu_*.hip) */
 
-#define XINV_VERSION 200
+#define XINV_VERSION 300
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
 
 #include "xinv_host.h"
@@ -387,11 +387,28 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         //    3600x1800: 2.65 -> 3.9e11), K = 4 does not (one wavefront per SIMD: 3.4e11).
         const int nvec = 1 + nc - __builtin_popcount(pl.um & ((1u << nc) - 1u));
         pl.lone = nvec <= 2 ? 1.6 : (nvec == 3 ? 1.3 : 1.0);
+        // Four sweeps per pass pipelined across the four wavefronts of a workgroup (xinv_pipe2d.h) -- a quarter of
+        // the tiles, four times as tall, half the recomputed halo -- for the forms whose coefficients are per-row
+        // records: the standard form with per-row A and C (lat-lon Poisson) and the general form with per-row
+        // A, C, D, E, F (lat-lon Gill-Matsuno).
+        static const int pipe_mode = [] { const char *e = getenv("XINV_PIPE"); return e ? atoi(e) : 1; }();
+        const bool pipe_form = (p.kind == KIND_STD2D && pl.um == FusedStd2D::PIPE_UM) ||
+                               (p.kind == KIND_GEN2D && pl.um == FusedGen2D::PIPE_UM);
+        // Standard form: only where the launch is small enough for the halo saving to matter -- k_fused2d keeps the
+        // VALU 96 % busy against ~75 %, and with several rounds of workgroups its tiles are tall anyway (8 slices
+        // of 3600x1800: 7.0e11 with k_fused2d, 6.2e11 pipelined; one slice: 5.85 against 6.0e11; 180x360: 1.7
+        // against 2.35e10).  General form: k_fused2d stops at two sweeps per pass (registers) and is bound by
+        // HBM at C4, so the pipelined pass is taken at every size.  XINV_PIPE=2 forces it whatever the size.
+        const bool pipe_size_ok = pipe_mode == 2 || p.kind == KIND_GEN2D || p.nbatch * p.yc * p.xc <= (int64_t)10000000;
+        const bool pipe_want = pipe_mode != 0 && pipe_form && pipe_size_ok && !(opt.flags & XINV_FLAG_NO_PIPE) &&
+                               (opt.sweeps_per_launch == 0 || opt.sweeps_per_launch == XINV_PIPE_P);
         {
             const bool hoisted_gen = (p.kind == KIND_GEN2D && nvec <= 2);
             const int ksup = (p.kind == KIND_STD2D && nvec <= 2) ? XINV_KMAX : (hoisted_gen ? 2 : 3);
             const int occ_needed = nvec >= 4 ? 1 : 2;
-            if (opt.sweeps_per_launch > 0)
+            if (pipe_want)
+                pl.K = XINV_PIPE_P;
+            else if (opt.sweeps_per_launch > 0)
                 pl.K = std::min(opt.sweeps_per_launch, (p.kind == KIND_STD2D) ? XINV_KMAX : 3);
             else {
                 pl.K = 2;
@@ -403,29 +420,27 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                 }
             }
         }
-        // Four sweeps per pass of the standard form with per-row A and C: pipelined across the four wavefronts
-        // of a workgroup (xinv_pipe2d.h) -- a quarter of the tiles, four times as tall, half the recomputed halo.
-        static const bool pipe_env = [] { const char *e = getenv("XINV_PIPE"); return !e || atoi(e) != 0; }();
-        // ... where the launch is small enough for that to matter: k_fused2d keeps the VALU 96 % busy against
-        // ~75 %, and with several rounds of workgroups its tiles are tall anyway (8 slices of 3600x1800:
-        // 7.0e11 with k_fused2d, 6.2e11 pipelined; one slice: 5.85 against 6.0e11; 180x360: 1.7 against 2.35e10).
-        // XINV_PIPE=2 forces the pipelined pass whatever the size.
-        static const int pipe_mode = [] { const char *e = getenv("XINV_PIPE"); return e ? atoi(e) : 1; }();
-        const bool pipe_size_ok = pipe_mode == 2 || p.nbatch * p.yc * p.xc <= (int64_t)10000000;
-        pl.pipe = pipe_env && pipe_size_ok && !(opt.flags & XINV_FLAG_NO_PIPE) && p.kind == KIND_STD2D && pl.um == 3u &&
-                  pl.K == 4;
+        pl.pipe = pipe_want && pl.K == XINV_PIPE_P;
         pl.tpw = pl.pipe ? 1 : 4;
         // two column pairs per lane (strips of 240 owned columns) where the grid is wide enough to keep the
         // workgroup count up; XINV_PIPE_NP=1|2 forces the choice
         const int np_env = [] { const char *e = getenv("XINV_PIPE_NP"); return e ? atoi(e) : 0; }();   // (read per solve: tests switch it)
-        pl.npair = (np_env == 1 || np_env == 2) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
+        pl.npair = ((np_env == 1 || np_env == 2) && p.kind == KIND_STD2D) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
         if (pl.pipe) {
-            rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)p.nbatch * p.yc * sizeof(RowFac));
+            const bool gen = (p.kind == KIND_GEN2D);
+            const int rw = gen ? FusedGen2D::PIPE_RW : FusedStd2D::PIPE_RW;
+            rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)p.nbatch * p.yc * rw * sizeof(double));
             if (rc) return rc;
             RowFactorArgs ra;
             memset(&ra, 0, sizeof ra);
-            ra.A = p.c[0]; ra.sA = p.sc[0]; ra.C = p.c[2]; ra.sC = p.sc[2];
-            ra.yc = p.yc; ra.xc = p.xc; ra.sc_ = p.sc_; ra.rowf = (RowFac *)ws->d_rowf;
+            if (gen) {
+                ra.c[0] = p.c[0]; ra.sc[0] = p.sc[0];                                     // A
+                for (int q = 2; q < 6; q++) { ra.c[q - 1] = p.c[q]; ra.sc[q - 1] = p.sc[q]; }   // C, D, E, F
+            } else {
+                ra.c[0] = p.c[0]; ra.sc[0] = p.sc[0]; ra.c[1] = p.c[2]; ra.sc[1] = p.sc[2];   // A, C
+            }
+            ra.gen = gen ? 1 : 0;
+            ra.yc = p.yc; ra.xc = p.xc; ra.sc_ = p.sc_; ra.rowf = (double *)ws->d_rowf;
             hipLaunchKernelGGL(k_row_factor, dim3(cdiv(p.yc, 256), (unsigned)p.nbatch, 1), dim3(256), 0, st, ra);
         }
         // Rows per tile (see the cost model below).
@@ -446,7 +461,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             int occ = 2;                                   // workgroups of the chosen variant per CU
             {
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-                if (pl.pipe) xinv_launch_pipe2d(pl.npair, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
+                if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.npair, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
                 else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
                                     st, dummy, &occ);
             }
@@ -823,6 +838,7 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
     t_stats.rows_per_tile = pl.RY;
     t_stats.xuniform_mask = (pl.path == XINV_PATH_FUSED || p.kind == KIND_BIH2D) ? (int32_t)pl.um : 0;
     t_stats.masked_tile_pct = (pl.path == XINV_PATH_FUSED && pl.skip) ? pl.skip_pct : 0;
+    t_stats.masked_tile_ppm = (pl.path == XINV_PATH_FUSED && pl.skip) ? pl.skip_ppm : 0;
     t_stats.pipelined = (pl.path == XINV_PATH_FUSED && pl.pipe) ? pl.npair : 0;
     t_stats.sweep_launches = R.nlaunch;
     t_stats.sweeps_max = sweeps_max;

@@ -21,6 +21,7 @@ struct Plan {
     bool skip;               // masked-tile skipping: launches of K == Plan::K run the listed tiles only
     int ntl, nskip;          // list entries per member (active, multiple of 4 / skipped)
     int skip_pct;            // share of wave-tiles skipped, percent
+    int skip_ppm;            // ... per million
     double lone = 1.6;       // planner: cost of a workgroup alone on its CU relative to one of a pair
     bool pipe;               // K == 4 passes run the wave-pipelined kernel (k_pipe2d): one tile per workgroup
     int tpw;                 // wave-tiles per workgroup of the planned kernel: 4, or 1 with `pipe`
@@ -127,7 +128,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
             // (XINV_PIPE_LDSPAD: unused dynamic LDS per workgroup, to cap the workgroups per CU in experiments;
             //  capping at the planned count changed nothing: the dispatcher already spreads them evenly)
             static const int pad = [] { const char *e = getenv("XINV_PIPE_LDSPAD"); return e ? std::max(0, atoi(e)) : 0; }();
-            xinv_launch_pipe2d(pl.npair, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad);
+            xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.npair, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad);
             continue;
         }
         if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
@@ -494,7 +495,7 @@ static double tile_cost(int64_t wgs, int64_t rows, int K, int occ, double lone =
 static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t st,
                           const xinv_options &opt, int fixedRB = 0, int UW_ = 0, int occ_ = 0)
 {
-    pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0;
+    pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0; pl.skip_ppm = 0;
     const bool forced = (opt.flags & XINV_FLAG_FORCE_TILE_SKIP) != 0;
     const int tpw = pl.pipe ? 1 : 4;                              // wave-tiles per workgroup
     const int K = pl.K, UW = UW_ ? UW_ : (pl.pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K);   // 9-point kernel: 128 - 8K owned columns
@@ -565,7 +566,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     int occ = occ_ > 0 ? occ_ : 2;
     if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-        if (pl.pipe) xinv_launch_pipe2d(pl.npair, pl.aligned, ext, dim3(1), st, dummy, &occ);
+        if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.npair, pl.aligned, ext, dim3(1), st, dummy, &occ);
         else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
     }
     const bool pp = pl.pipe;
@@ -637,6 +638,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
 
     pl.skip = true; pl.ntl = ntl; pl.nskip = nskip;
     pl.skip_pct = (int)((100 * nskipped) / (ntiles * nb));
+    pl.skip_ppm = (int)((1000000 * nskipped) / (ntiles * nb));
     if (!fixedRB) {
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
         pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX) * pl.nrb, pl.pipe ? 4 : tpw) + 1;

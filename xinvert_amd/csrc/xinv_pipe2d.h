@@ -1,5 +1,6 @@
 // xinv_pipe2d.h -- wave-pipelined streaming red-black SOR pass: four sweeps per pass over HBM, one sweep
-// per WAVEFRONT (gfx950).  Standard form with per-row A and C (lat-lon Poisson), B == 0.
+// per WAVEFRONT (gfx950).  Standard form with per-row A and C (lat-lon Poisson) and general form with per-row
+// A, C, D, E, F (lat-lon Gill-Matsuno), B == 0: the model M supplies the update and its per-row record.
 //
 // k_fused2d applies K sweeps inside one wavefront; its tile count is tied to the number of wavefront slots
 // (256 CUs x 4 SIMDs x 2), so at 3600x1800 a tile owns ~23 rows and marches 40: half of the point updates
@@ -62,36 +63,55 @@
 #define XINV_PIPE_PF 4            /* rows of F in flight, wavefronts 1..3 */
 #endif
 
-// what a row of the lat-lon standard form needs besides S and F: 32 bytes, one load per row and wavefront
-struct RowFac { double a, c, rq, rok; };   // A[j], C[j], relaxation factor of row j, row predicate (1.0 / 0.0:
-                                           // all 64 bits are read, so no half of a load in flight is ever reused)
-
+// What a row needs besides S and the forcing, one record of M::PIPE_RW doubles per row, read through the scalar
+// unit: standard form {A[j], C[j], relaxation factor, row predicate} (32 bytes), general form {A, C, D, E, F,
+// relaxation factor, row predicate, -} (64 bytes).  The predicate is 1.0 / 0.0: all 64 bits are read, so no half
+// of a load in flight is ever reused.
 struct RowFactorArgs {
-    const double *A, *C;
-    int64_t sA, sC;               // batch strides (0 = shared)
+    const double *c[5];           // the x-uniform coefficient arrays in FusedArgs order (std: A, C; gen: A, C, D, E, F)
+    int64_t sc[5];                // batch strides (0 = shared)
     int64_t yc, xc;
+    int gen;
     XinvScal sc_;
-    RowFac *rowf;                 // [nbatch][yc]
+    double *rowf;                 // [nbatch][yc][PIPE_RW]
 };
 
 #ifdef XINV_AUX_KERNELS
-// once per solve: per-row relaxation factor and row part of the update predicate (numbas.py:343-369 with
-// A and C constant along x; FusedStd2D::derive, hoisted branch)
+// once per solve: per-row relaxation factor and row part of the update predicate (numbas.py:343-369 /
+// 1125-1153 with the coefficients constant along x; FusedStd2D::derive / FusedGen2D::derive, hoisted branch:
+// same expressions, same bits)
 __global__ __launch_bounds__(256) void k_row_factor(RowFactorArgs a)
 {
-    xinv_fresh_scalar_cache();
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (j >= a.yc) return;
     const double u = a.sc_.undef;
-    RowFac f;
-    f.a = a.A[m * a.sA + j * a.xc]; f.c = a.C[m * a.sC + j * a.xc];
-    f.rq = 0.0; f.rok = 0.0;
-    if (j >= 1 && j <= a.yc - 2) {
-        const double aP = a.A[m * a.sA + (j + 1) * a.xc], a0 = f.a, c = f.c;
-        f.rq = a.sc_.optArg / ((aP + a0) * a.sc_.ratioSqr + (c + c));
-        f.rok = ((aP != u) && (a0 != u) && (c != u)) ? 1.0 : 0.0;
+    const bool inner = (j >= 1 && j <= a.yc - 2);
+    if (!a.gen) {
+        double *f = a.rowf + (m * a.yc + j) * FusedStd2D::PIPE_RW;
+        const double a0 = a.c[0][m * a.sc[0] + j * a.xc], c = a.c[1][m * a.sc[1] + j * a.xc];
+        double rq = 0.0, rok = 0.0;
+        if (inner) {
+            const double aP = a.c[0][m * a.sc[0] + (j + 1) * a.xc];
+            rq = a.sc_.optArg / ((aP + a0) * a.sc_.ratioSqr + (c + c));
+            rok = ((aP != u) && (a0 != u) && (c != u)) ? 1.0 : 0.0;
+        }
+        f[0] = a0; f[1] = c; f[2] = rq; f[3] = rok;
+    } else {
+        double *f = a.rowf + (m * a.yc + j) * FusedGen2D::PIPE_RW;
+        double v[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) v[q] = a.c[q][m * a.sc[q] + j * a.xc];
+        const double A = v[0], C = v[1], F = v[4];
+        double rq = 0.0, rok = 0.0;
+        if (inner) {
+            rq = a.sc_.optArg / ((A * a.sc_.ratioSqr + C) * 2.0
+                                 - F * a.sc_.delxSqr);
+            rok = ((A != u) && (C != u) && (F != u) && (v[2] != u) && (v[3] != u)) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; q++) f[q] = v[q];
+        f[5] = rq; f[6] = rok; f[7] = 0.0;
     }
-    a.rowf[m * a.yc + j] = f;
 }
 #endif
 
@@ -151,7 +171,7 @@ __device__ __forceinline__ void pipe_extend_fix(double2 &edge, const double2 &in
 // rotate registers across the loop back-edge: ~80 v_mov and a full `s_waitcnt vmcnt(0)` per iteration).
 // Row arithmetic is 32-bit (scalar compares; the 64-bit ones are VALU instructions on this target) and
 // every global access is `uniform row base + 32-bit lane offset` (no per-load address arithmetic).
-template <int NP, bool AL, bool EXT, int PW, int PF>
+template <class M, int NP, bool AL, bool EXT, int PW, int PF>
 __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
                                                const LaneCols (&lc)[NP], const int64_t (&st0)[NP], int lane,
                                                double2 (*ring)[XINV_PIPE_NS][NP][XINV_WAVE], int gtot,
@@ -159,18 +179,18 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 {
     constexpr int P = XINV_PIPE_P, H = 2 * P, D = 4, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     constexpr int R = PF + D;                            // row records; also the unroll period
-    constexpr int PFR = 2;                               // steps the per-row factors are requested ahead
-    constexpr unsigned UM = 3u;
+    constexpr int PFR = M::PIPE_PFR;                     // steps the per-row record is requested ahead
+    constexpr unsigned UM = M::PIPE_UM;
+    constexpr int NC = M::NC, FQ = M::PIPE_FQ, RW = M::PIPE_RW;
     static_assert(R % D == 0 && R % B == 0 && R % XINV_PIPE_NS == 0,
                   "the unroll period must keep row parity, ring slots and barriers compile-time");
-    using M = FusedStd2D;
     const int ycr = (int)a.yc;
     const unsigned rowbytes = (unsigned)a.xc * 8u;       // (a row is shorter than 4 GiB)
     const double u = a.sc_.undef;
     const xinv_gcptr srcS = (xinv_gcptr)(uintptr_t)(a.src + m * a.sS);
     const xinv_gptr dstS = (xinv_gptr)(uintptr_t)(a.dst + m * a.sS);
-    const xinv_gcptr cF = (xinv_gcptr)(uintptr_t)(a.c[2] + m * a.sc[2]);
-    const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(reinterpret_cast<const RowFac *>(a.rowf) + m * a.yc);
+    const xinv_gcptr cF = (xinv_gcptr)(uintptr_t)(a.c[FQ] + m * a.sc[FQ]);
+    const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(reinterpret_cast<const double *>(a.rowf) + m * a.yc * RW);
     unsigned lo0[NP], lo1[NP], so0[NP], so1[NP];         // byte offsets of the lane's columns (loads / owned stores)
 #pragma unroll
     for (int q = 0; q < NP; q++) {
@@ -183,7 +203,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     const int in_hi = yu1 - 1 + H - 2 * PW;
 
     double2 sw[NP][R];
-    CoefWin<3, R> cw[NP];
+    CoefWin<NC, R> cw[NP];
     double rokw[R];
 #pragma unroll
     for (int t = 0; t < R; t++) {
@@ -193,7 +213,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
             sw[q][t] = make_double2(0.0, 0.0);
             cw[q].rq[t] = 0.0; cw[q].mx[t] = 0u; cw[q].my[t] = 0u;
 #pragma unroll
-            for (int c = 0; c < 3; c++) { cw[q].v[c][t] = make_double2(0.0, 0.0); cw[q].s[c][t] = 0.0; }
+            for (int c = 0; c < NC; c++) { cw[q].v[c][t] = make_double2(0.0, 0.0); cw[q].s[c][t] = 0.0; }
         }
     }
 
@@ -218,17 +238,18 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         xinv_unroll_steps([&](auto qtag) {
             constexpr int q = decltype(qtag)::value;
             if (PW == 0) sw[q][slot] = ldrow(srcS, boff, qtag);
-            cw[q].v[2][slot] = ldrow(cF, boff, qtag);
+            cw[q].v[FQ][slot] = ldrow(cF, boff, qtag);
         }, std::make_integer_sequence<int, NP>{});
     };
     auto request_rf = [&](int r, auto stag) {
         constexpr int slot = decltype(stag)::value;
         const unsigned rr = (unsigned)min(max(r, 0), ycr - 1);    // (rows 0 and yc-1 carry rok = 0: so do the clamped ones)
-        const xinv_cdouble_ptr p4 = rowf + (uint64_t)rr * 4u;
-        const double fa = p4[0], fc = p4[1], fq = p4[2];
-        rokw[slot] = p4[3];
+        const xinv_cdouble_ptr pr = rowf + (uint64_t)rr * (unsigned)RW;
+        double rec[RW];
 #pragma unroll
-        for (int q = 0; q < NP; q++) { cw[q].s[0][slot] = fa; cw[q].s[1][slot] = fc; cw[q].rq[slot] = fq; }
+        for (int k = 0; k < RW; k++) rec[k] = pr[k];
+#pragma unroll
+        for (int q = 0; q < NP; q++) M::template pipe_row<R>(cw[q], slot, rec, rokw[slot]);
     };
     // (in row order, as in the loop: the vmcnt waits of the loop are computed against the worst path into it)
     xinv_unroll_steps([&](auto ttag) { request(in_lo + decltype(ttag)::value, ttag); asm volatile("" ::: "memory"); },
@@ -322,10 +343,10 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 const bool rok = rokw[s1] != 0.0;
 #pragma unroll
                 for (int q = 0; q < NP; q++) {
-                    const double fx = cw[q].v[2][s1].x, fy = cw[q].v[2][s1].y;
+                    const double fx = cw[q].v[FQ][s1].x, fy = cw[q].v[FQ][s1].y;
                     cw[q].mx[s1] = xinv_lane_word(lc[q].ok_x && rok && (fx != u));
                     cw[q].my[s1] = xinv_lane_word(lc[q].ok_y && rok && (fy != u));
-                    cw[q].v[2][s1].x = fx * a.sc_.delxSqr; cw[q].v[2][s1].y = fy * a.sc_.delxSqr;
+                    if (M::PIPE_PREMUL) { cw[q].v[FQ][s1].x = fx * a.sc_.delxSqr; cw[q].v[FQ][s1].y = fy * a.sc_.delxSqr; }
                 }
             }
             {   // red half-sweep on row r-1
@@ -420,7 +441,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #endif
 }
 
-template <int NP, bool AL, bool EXT>
+template <class M, int NP, bool AL, bool EXT>
 __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 {
     xinv_fresh_scalar_cache();
@@ -497,10 +518,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         }
         gtot = ((gtot + B - 1) / B) * B;
         switch (pwi) {
-        case 0: xinv_pipe_wave<NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
-        case 1: xinv_pipe_wave<NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
-        case 2: xinv_pipe_wave<NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
-        default: xinv_pipe_wave<NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
+        case 0: xinv_pipe_wave<M, NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
+        case 1: xinv_pipe_wave<M, NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
+        case 2: xinv_pipe_wave<M, NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
+        default: xinv_pipe_wave<M, NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
         }
     }
     }

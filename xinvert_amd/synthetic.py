@@ -26,7 +26,8 @@ def _modes(rng, lat, lon, nmodes, kmax, lmax):
 
 
 def poisson_latlon(ny, nx, mask=True, seed=SEED, BCs=('fixed', 'periodic'), members=1):
-    """Config 1 / 2: invert_Poisson on a global lat-lon grid (ny x nx), optional land mask.
+    """Config 1 / 2: invert_Poisson on a global lat-lon grid (ny x nx), optional land mask
+    (mask=True: continent-size blobs; mask='coastline': the same plus coastline-scale structure).
 
     Returns dict(kind='std2d', S0 [m,ny,nx], coefs=[A,B,C (shared), F [m,ny,nx]], scalars...)."""
     rng = np.random.default_rng(seed)
@@ -42,8 +43,20 @@ def poisson_latlon(ny, nx, mask=True, seed=SEED, BCs=('fixed', 'periodic'), memb
     zeta = np.stack(zs)
     if mask:
         land = _modes(rng, lat, lon, 16, 6, 5)
+        if mask == 'coastline':
+            # coastline-scale structure on top of the continents (wavenumbers up to 60) and a few hundred small
+            # islands: few wave-tiles are land throughout, so masked-tile skipping finds little to skip.
+            # (Drawn from a second generator: the default mask above stays what the committed fixtures saw.)
+            rng2 = np.random.default_rng(seed + 1000)
+            land = land + 0.5 * _modes(rng2, lat, lon, 64, 60, 50)
         thr = np.quantile(land[::7, ::7], 0.70)
         land_mask = (land > thr) | (np.abs(lat)[:, None] > 85.0)
+        if mask == 'coastline':
+            jj, ii = np.arange(ny)[:, None], np.arange(nx)[None, :]
+            for _ in range(300):
+                j0, i0, r = rng2.integers(0, ny), rng2.integers(0, nx), rng2.integers(2, 7) * max(1, ny // 900)
+                di = np.minimum(np.abs(ii - i0), nx - np.abs(ii - i0))
+                land_mask |= ((jj - j0) ** 2 + di ** 2) <= r * r
         zeta[:, land_mask] = np.nan
     F = Field(zeta, ('member', 'lat', 'lon'), {'lat': lat, 'lon': lon})
     iP = apps._update(apps.default_iParams, {'BCs': list(BCs)})
