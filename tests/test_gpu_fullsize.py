@@ -191,3 +191,33 @@ def test_c5_omega_converged_within_1e6_of_reference_ordering():
     from xinvert_amd import synthetic
     q = synthetic.member(synthetic.omega_latlon(50, 360, 720, 1), 0)
     _converged('c5', q, q['coefs'][-1] != util.U)
+
+
+# ------------------------------------------------------------------ pipelined pass, many rounds of workgroups
+@pytest.mark.parametrize('kind', ['gen2d', 'std2d'])
+@pytest.mark.parametrize('rows', [16, 30, 0])
+def test_pipelined_pass_many_rounds_of_workgroups(kind, rows):
+    """k_pipe2d on launches of several thousand workgroups (8 members, short tiles: every CU holds as many
+    workgroups as fit and the later ones start beside running ones): bit for bit the single-wavefront kernel,
+    repeatedly.  Until round 3 the third wavefront of a tile took its first row out of the LDS ring one barrier
+    interval late -- the interval of the producer's slot reuse -- and under this load the first owned row of a
+    few per cent of the tiles came out wrong in its last half-sweep (profiles/r03_pipe2d_ring_race.txt);
+    launches of one round, all that the standard form ran pipelined before, never showed it."""
+    from xinvert_amd import synthetic
+    if kind == 'gen2d':
+        p = synthetic.gill_matsuno(720, 1440, 8)
+    else:                                                 # (9.7e6 points: the largest batch the planner still pipelines)
+        p = synthetic.poisson_latlon(900, 1800, mask=True, members=6)
+    nm = p['S0'].shape[0]
+    qs = [synthetic.member(p, m) for m in range(nm)]
+    Sref, fref, s0 = util.run_hip_dev(qs, 11, 0.0, shared=p['shared'], no_pipe=1)
+    assert s0['pipelined'] == 0
+    So, flo = run_oracle(qs[5], 11, 0.0, COLOUR_2)
+    assert np.array_equal(Sref[5], So)
+    ran_pipelined = 0
+    for rep in range(4):
+        S, fl, st = util.run_hip_dev(qs, 11, 0.0, shared=p['shared'], rows_per_tile=rows)
+        ran_pipelined += st['pipelined']
+        bad = [int((S[m] != Sref[m]).sum()) for m in range(nm)]
+        assert not any(bad), 'repetition %d: mismatching points per member %r (%r)' % (rep, bad, st)
+    assert ran_pipelined == 4

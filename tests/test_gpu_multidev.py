@@ -98,3 +98,116 @@ def test_host_chunks_large_batch_strided_members():
         So, flo = run_oracle(r, 25, 0.0, C2)
         assert np.array_equal(Sbuf[m * pad:m * pad + n].reshape(yc, xc), So)
         assert (Sbuf[m * pad + n:(m + 1) * pad] == 0).all()          # the gaps are never touched
+
+
+# ------------------------------------------------------------------ distinct GPUs, when the box has them
+def test_distinct_devices_split_and_report():
+    """With more than one GPU visible the device list names DIFFERENT GPUs: same bits as one device, the
+    statistics say how many were used, every device's block lands in the caller's arrays."""
+    from xinvert_amd import _lib
+    ndev = _lib.load().xinv_device_count()
+    if ndev < 2:
+        pytest.skip('one GPU visible: distinct device ids need a multi-GPU node (device 0 named twice is covered above)')
+    nb = 2 * ndev + 1
+    ps = _members(nb)
+    S1, f1, s1 = util.run_hip_batched(ps, 60, 1e-6)
+    S2, f2, s2 = util.run_hip_batched(ps, 60, 1e-6, devices=list(range(ndev)))
+    S3, f3, s3 = util.run_hip_batched(ps, 60, 1e-6, devices='all')
+    assert s1['devices'] == 1 and s2['devices'] == ndev and s3['devices'] == ndev
+    assert np.array_equal(S1, S2) and np.array_equal(f1, f2) and np.array_equal(S1, S3) and np.array_equal(f1, f3)
+    assert s2['wall_ms'] > 0 and s2['h2d_ms'] > 0 and s2['sweep_ms'] >= 0
+
+
+# ------------------------------------------------------------------ one process per GPU: RCCL and bench.py
+def _run(cmd, env_extra, timeout=900):
+    import os
+    import subprocess
+    env = dict(os.environ); env.update(env_extra)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env,
+                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def test_gather_flags_over_rccl_single_rank():
+    """The one collective of the path (all_gather of the per-slice flags) on the backend production uses:
+    a 1-rank `nccl` (= RCCL) group on this GPU, in a subprocess (xinvert_amd.dist, XINV_DIST_FORCE_INIT)."""
+    import sys
+    code = (
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "from xinvert_amd import dist as xdist\n"
+        "rank, local, world = xdist.init_process_group()\n"
+        "assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1\n"
+        "f = np.arange(21.0).reshape(7, 3)\n"
+        "g = xdist.gather_flags(f, 7)\n"
+        "assert np.array_equal(g, f)\n"
+        "blk = torch.arange(70.0, dtype=torch.float64, device='cuda').reshape(7, 2, 5)\n"
+        "full = xdist.gather_blocks(blk, 7)\n"
+        "assert full.is_cuda and torch.equal(full, blk)\n"
+        "t = torch.ones(1, device='cuda'); dist.all_reduce(t); assert float(t.item()) == 1.0\n"
+        "dist.destroy_process_group(); print('RCCL_OK')\n")
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = _run([sys.executable, '-c', code], dict(XINV_DIST_FORCE_INIT='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
+                                                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)))
+    assert out.returncode == 0 and 'RCCL_OK' in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+def test_bench_self_launches_two_ranks():
+    """`bench.py --gpus 2` started WITHOUT a torchrun environment starts its own two ranks; here they share the
+    one GPU (XINV_FORCE_DEVICE=0) and exchange the flags over gloo.  The JSON line reports the ranks that
+    took part, the real C4 batch split in two blocks, every member swept to the end."""
+    import json
+    import os
+    import sys
+    env = {k: None for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    e = dict(XINV_FORCE_DEVICE='0', XINV_DIST_BACKEND='gloo')
+    full = dict(os.environ); full.update(e)
+    for k in env:
+        full.pop(k, None)
+    import subprocess
+    out = subprocess.run([sys.executable, 'bench.py', '--config', 'c4', '--members', '4', '--gpus', '2', '--steps', '2',
+                          '--warmup', '1', '--sweeps', '40'], capture_output=True, text=True, timeout=900, env=full,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['gpus_requested'] == 2 and d['collective_backend'] == 'gloo' and d['rccl_ranks'] == 0
+    assert d['scaling'] == 'strong' and d['config']['members_total'] == 4 and d['config']['members_this_gpu'] == 2
+    assert d['value'] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import os
+    import subprocess
+    import sys
+    from xinvert_amd import _lib
+    ndev = _lib.load().xinv_device_count()
+    full = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'XINV_FORCE_DEVICE'):
+        full.pop(k, None)
+    out = subprocess.run([sys.executable, 'bench.py', '--gpus', str(ndev + 1), '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=600, env=full,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode != 0 and 'refusing to run fewer ranks than asked' in (out.stderr + out.stdout)
+
+
+def test_bench_single_rank_through_rccl():
+    """bench.py's N > 1 code path -- barrier, flag all-gather, max-over-ranks timing -- over RCCL on this GPU:
+    one rank joined as a process group (XINV_DIST_FORCE_INIT=1); the JSON line counts the ranks RCCL saw."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    full = dict(os.environ)
+    full.update(XINV_DIST_FORCE_INIT='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+                MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, 'bench.py', '--ny', '360', '--nx', '720', '--steps', '2', '--warmup', '1',
+                          '--sweeps', '40', '--no-cpu', '--no-hbm', '--no-configs', '--no-parity'],
+                         capture_output=True, text=True, timeout=900, env=full,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['collective_backend'] == 'nccl' and d['rccl_ranks'] == 1 and d['n_gpus'] == 1

@@ -100,7 +100,8 @@ struct FusedArgs {
     int ntl;                   // entries per member (multiple of 4); nwg = ntl / 4
     const double *xsum;        // [nbatch] sum |S| over the skipped tiles (S != undef)
     const long long *xcnt;     // [nbatch] their sample count
-    const void *rowf;          // k_pipe2d: [nbatch][yc] per-row factors (RowFac, xinv_pipe2d.h)
+    const void *rowf;          // k_pipe2d: [nbatch][yc] per-row records (M::PIPE_RW doubles each, xinv_pipe2d.h)
+    double *dbg;               // debugging builds only (XINV_PIPE_DEBUG): rows as the pipeline stages received them
 };
 
 template <class F, int... U>

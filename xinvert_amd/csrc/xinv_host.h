@@ -185,6 +185,153 @@ static int pool_alloc(DevPool *pool, size_t bytes, double **out)
     return XINV_OK;
 }
 
+// ------------------------------------------------------------------ library-owned pinned staging
+// Host <-> HBM traffic of the host-pointer entries goes through pinned buffers the LIBRARY owns (hipHostMalloc,
+// a ring of slots per direction and device): a helper thread copies the caller's pageable memory into a slot
+// (memcpy split over a few worker threads), queues the DMA out of the slot, and moves on to the next slot while
+// the DMA runs; downloads mirror it.  The caller's memory is never registered (round 2: registering and
+// unregistering caller ranges left the runtime in a state that aborted a LATER pageable copy of another array,
+// profiles/r02_pinning_abort.txt), the thread that drives the solves is never blocked by a copy, and chunk c+1
+// travels while chunk c sweeps ("staged through hipHostMalloc pinned buffers").
+struct CopyPool {                                   // process-wide memcpy workers
+    struct Batch { std::atomic<int> left{0}; std::mutex mu; std::condition_variable cv; };
+    struct Task { char *d; const char *s; size_t n; Batch *b; };
+    std::vector<std::thread> th;
+    std::mutex mu; std::condition_variable cv;
+    std::deque<Task> q;
+    bool stop = false;
+    int nworker = 0;
+    void start()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (nworker) return;
+        unsigned hc = std::thread::hardware_concurrency();
+        if (const char *e = getenv("XINV_COPY_THREADS")) hc = 2u * (unsigned)std::max(1, atoi(e));
+        nworker = (int)std::max(1u, std::min(8u, hc / 2u));
+        for (int i = 0; i < nworker; i++)
+            th.emplace_back([this] {
+                for (;;) {
+                    Task t;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this] { return stop || !q.empty(); });
+                        if (stop && q.empty()) return;
+                        t = q.front(); q.pop_front();
+                    }
+                    memcpy(t.d, t.s, t.n);
+                    if (t.b->left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(t.b->mu); t.b->cv.notify_all(); }
+                }
+            });
+    }
+    // copy n bytes with the workers + the calling thread; returns when every byte has landed
+    void copy(void *d, const void *s, size_t n)
+    {
+        if (n < ((size_t)4 << 20) || nworker < 1) { memcpy(d, s, n); return; }
+        const int parts = nworker + 1;
+        const size_t piece = ((n / parts) + 4095) & ~(size_t)4095;
+        Batch b;
+        std::vector<Task> mine;
+        size_t off = 0;
+        int k = 0;
+        for (; off < n; off += piece, k++) {
+            Task t{(char *)d + off, (const char *)s + off, std::min(piece, n - off), &b};
+            mine.push_back(t);
+        }
+        b.left.store((int)mine.size() - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 1; i < mine.size(); i++) q.push_back(mine[i]);
+        }
+        cv.notify_all();
+        memcpy(mine[0].d, mine[0].s, mine[0].n);
+        if (mine.size() > 1) {
+            std::unique_lock<std::mutex> lk(b.mu);
+            b.cv.wait(lk, [&] { return b.left.load() == 0; });
+        }
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();
+    }
+};
+static CopyPool g_copy_pool;
+
+struct StageRing {                                  // pinned slots of one direction on one device
+    static constexpr int NSLOT = 4;
+    static constexpr size_t SLOT = (size_t)32 << 20;
+    char *buf[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    bool inflight[NSLOT] = {false, false, false, false};
+    char *dst[NSLOT] = {nullptr, nullptr, nullptr, nullptr};      // downloads: where the slot's bytes go on the host
+    size_t len[NSLOT] = {0, 0, 0, 0};
+    int next = 0;
+    int ensure()
+    {
+        for (int k = 0; k < NSLOT; k++) {
+            if (!buf[k]) HIPCHK(hipHostMalloc((void **)&buf[k], SLOT, hipHostMallocDefault));
+            if (!ev[k]) HIPCHK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        return XINV_OK;
+    }
+};
+
+// host -> device through the ring (called on the uploader thread)
+static int stage_h2d(StageRing &r, hipStream_t s, double *dev, const double *host, size_t bytes)
+{
+    if (bytes < ((size_t)1 << 20)) {                 // small: the runtime's own staged copy
+        HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
+        return XINV_OK;
+    }
+    int rc = r.ensure();
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += StageRing::SLOT) {
+        const size_t n = std::min(StageRing::SLOT, bytes - off);
+        const int k = r.next;
+        if (r.inflight[k]) { HIPCHK(hipEventSynchronize(r.ev[k])); r.inflight[k] = false; }
+        g_copy_pool.copy(r.buf[k], (const char *)host + off, n);
+        HIPCHK(hipMemcpyAsync((char *)dev + off, r.buf[k], n, hipMemcpyHostToDevice, s));
+        HIPCHK(hipEventRecord(r.ev[k], s));
+        r.inflight[k] = true;
+        r.next = (k + 1) % StageRing::NSLOT;
+    }
+    return XINV_OK;
+}
+
+static int stage_d2h_retire(StageRing &r, int k)
+{
+    if (!r.inflight[k]) return XINV_OK;
+    HIPCHK(hipEventSynchronize(r.ev[k]));
+    g_copy_pool.copy(r.dst[k], r.buf[k], r.len[k]);
+    r.inflight[k] = false;
+    return XINV_OK;
+}
+
+// device -> host through the ring (called on the downloader thread); returns when the bytes are in `host`
+static int stage_d2h(StageRing &r, hipStream_t s, double *host, const double *dev, size_t bytes)
+{
+    if (bytes < ((size_t)1 << 20)) {
+        HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return XINV_OK;
+    }
+    int rc = r.ensure();
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += StageRing::SLOT) {
+        const size_t n = std::min(StageRing::SLOT, bytes - off);
+        const int k = r.next;
+        if ((rc = stage_d2h_retire(r, k))) return rc;
+        HIPCHK(hipMemcpyAsync(r.buf[k], (const char *)dev + off, n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(r.ev[k], s));
+        r.inflight[k] = true; r.dst[k] = (char *)host + off; r.len[k] = n;
+        r.next = (k + 1) % StageRing::NSLOT;
+    }
+    for (int i = 0; i < StageRing::NSLOT; i++)       // oldest first
+        if ((rc = stage_d2h_retire(r, (r.next + i) % StageRing::NSLOT))) return rc;
+    return XINV_OK;
+}
+
 // In-place pinning of the CALLER's arrays (hipHostRegister for the duration of the call: the DMA
 // engines then read them at PCIe rate, 55 GB/s against ~25 GB/s for the runtime's staged copy) is OFF
 // by default since round 2: registering and unregistering ranges of memory the caller's allocator
@@ -193,20 +340,19 @@ static int pool_alloc(DevPool *pool, size_t bytes, double **out)
 // tests/test_gpu_frontend.py + test_gpu_fullsize.py, never without the registration (28 runs,
 // profiles/r02_pinning_abort.txt).  XINV_FLAG_PIN_HOST (or XINV_PIN=1 in the environment) turns it on
 // for callers whose buffers stay mapped.
-static bool g_pin_flag = false;                     // set per call from xinv_options.flags (one solve per device at a time)
-struct Pinned {                                     // host ranges registered for this call
-    static bool allowed()
+struct Pinned {                                     // host ranges registered for this call (opt-in, see above)
+    static bool env_allowed()
     {
         static const bool env = [] { const char *e = getenv("XINV_PIN"); return e && atoi(e) != 0; }();
-        return env || g_pin_flag;
+        return env;
     }
     std::vector<void *> regs;
     std::vector<hipStream_t> streams;               // streams that may still hold copies of these ranges
-    bool enabled = true;                            // false: the caller (multi-device parent) pinned already
+    bool enabled = false;                           // this call registers ranges (XINV_FLAG_PIN_HOST / XINV_PIN=1)
     unsigned flags = hipHostRegisterDefault;
     bool try_pin(const void *h, size_t bytes)
     {
-        if (!enabled || !allowed() || bytes < (1u << 20)) return false;
+        if (!enabled || bytes < (1u << 20)) return false;
         if (hipHostRegister((void *)h, bytes, flags) != hipSuccess) {
             (void)hipGetLastError();
             return false;
@@ -214,35 +360,17 @@ struct Pinned {                                     // host ranges registered fo
         regs.push_back((void *)h);
         return true;
     }
+    bool covers(const void *h) const
+    {
+        for (void *r : regs) if (r == h) return true;
+        return false;
+    }
     // Every return path -- error paths included -- drains the copy streams before the ranges are
     // unregistered: an async copy still in flight must not lose its pinning.
     ~Pinned()
     {
-        if (!regs.empty()) for (hipStream_t s : streams) (void)hipStreamSynchronize(s);
+        for (hipStream_t s : streams) (void)hipStreamSynchronize(s);
         for (void *h : regs) (void)hipHostUnregister(h);
     }
 };
-
-static int upload(DevPool *pool, Pinned &pin, hipStream_t st, const double *h, int64_t nbatch,
-                  int64_t stride, int64_t n, double **out, int64_t *dstride)
-{
-    if (!h) { *out = nullptr; *dstride = 0; return XINV_OK; }
-    const int64_t members = (stride == 0) ? 1 : nbatch;
-    double *d = nullptr;
-    int rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &d);
-    if (rc) return rc;
-    if (members == 1 || stride == n) {
-        const size_t bytes = (size_t)members * n * sizeof(double);
-        pin.try_pin(h, bytes);
-        HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
-    } else {
-        pin.try_pin(h, (size_t)((members - 1) * stride + n) * sizeof(double));
-        for (int64_t m = 0; m < members; m++)
-            HIPCHK(hipMemcpyAsync(d + m * n, h + m * stride, (size_t)n * sizeof(double),
-                                  hipMemcpyHostToDevice, st));
-    }
-    *out = d;
-    *dstride = (stride == 0) ? 0 : n;
-    return XINV_OK;
-}
 

@@ -110,6 +110,9 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.stop = p.stop;
     a.psum = (unsigned long long *)ws->partials;
     if (pipe) { a.nwg = a.nstrip * a.nrb; a.rowf = ws->d_rowf; }
+#ifdef XINV_PIPE_DEBUG
+    if (pipe) { const char *e = getenv("XINV_DBG_PTR"); a.dbg = e ? (double *)(uintptr_t)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
         a.tile_list = ws->d_list;
         a.ntl = pl.ntl;

@@ -52,7 +52,7 @@
 #endif
 #if XINV_PIPE_FLAGS
 #define XINV_PIPE_NS 8            /* ring rows per hand-over: the producer may run that far ahead */
-#else
+#elif !defined(XINV_PIPE_NS)
 #define XINV_PIPE_NS 4            /* ring rows per hand-over */
 #endif
 #define XINV_PIPE_UW(np) (128 * (np) - 4 * XINV_PIPE_P)   /* columns a tile owns with np column pairs per lane */
@@ -123,6 +123,8 @@ __device__ __forceinline__ void xinv_pipe_barrier()
 #else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+#elif defined(XINV_PIPE_SYNCTHREADS)
+    __syncthreads();
 #else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
@@ -175,7 +177,7 @@ template <class M, int NP, bool AL, bool EXT, int PW, int PF>
 __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
                                                const LaneCols (&lc)[NP], const int64_t (&st0)[NP], int lane,
                                                double2 (*ring)[XINV_PIPE_NS][NP][XINV_WAVE], int gtot,
-                                               double &acc, int &cnt, int *prog, XinvCtl *ctl)
+                                               double &acc, int &cnt, int *prog, XinvCtl *ctl, int dbg_tile = 0)
 {
     constexpr int P = XINV_PIPE_P, H = 2 * P, D = 4, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     constexpr int R = PF + D;                            // row records; also the unroll period
@@ -256,6 +258,12 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                       std::make_integer_sequence<int, PF>{});
     xinv_unroll_steps([&](auto ttag) { request_rf(in_lo + decltype(ttag)::value, ttag); },
                       std::make_integer_sequence<int, PFR>{});
+#ifndef XINV_PIPE_DRAIN
+#define XINV_PIPE_DRAIN 0
+#endif
+#if XINV_PIPE_DRAIN & 1
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 
     // one half-sweep of row record sj (sjp / sjm: the rows below / above) on lane components X
     auto half_sweep = [&](auto xtag, auto jtag, auto ptag, auto mtag) {
@@ -313,13 +321,29 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     }
     (void)gtot;
 #else
-    // global step g of the workgroup = local step + LAG * PW; a barrier closes every B-th global step
+    // global step g of the workgroup = local step + LAG * PW; a barrier closes every B-th global step.
+    // Row in_lo is taken out of the ring in global step LAG * PW - 1 -- the step before this wavefront's first,
+    // like every later row (one step before it enters) -- and BEFORE the barrier that may close that step: the
+    // producer wrote it two steps earlier and reuses the slot two steps later, so the read has to sit in the
+    // barrier interval between.  (Read after the pre-loop, as this code did until round 3, it fell into the
+    // NEXT interval for even PW -- LAG * PW - 1 odd -- which is the interval of the producer's overwrite: under
+    // load the third wavefront sometimes got row in_lo + 4 for row in_lo, and the one point of the tile whose
+    // dependency cone touches it, the first owned row's last half-sweep, came out wrong by a few ulps to 1e-4.
+    // Found on 64 x 1440 x 720 Gill-Matsuno members; profiles/r03_pipe2d_ring_race.txt.)
     int g = 0;
-    for (; g < LAG * PW; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
-    if (PW > 0) {
 #pragma unroll
-        for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][q][lane];      // row in_lo
+    for (; g < LAG * PW; g++) {
+        if (PW > 0 && g == LAG * PW - 1) {
+#pragma unroll
+            for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][q][lane];      // row in_lo
+        }
+        if ((g + 1) % B == 0) xinv_pipe_barrier();
     }
+#endif
+#ifdef XINV_PIPE_DEBUG
+    // [member][tile][stage][k = 0..3][lane][2]: the first four rows stage PW took out of its predecessor's ring
+    double *dbgp = a.dbg ? a.dbg + ((((size_t)m * a.nwg + dbg_tile) * 4 + PW) * 4) * 128 : nullptr;
+    if (PW > 0 && dbgp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbgp[lane * 2] = sw[0][0].x; dbgp[lane * 2 + 1] = sw[0][0].y; }
 #endif
 
     for (int rb_ = in_lo; rb_ <= in_hi; rb_ += R) {
@@ -330,12 +354,22 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #define RSLOT(w) ((2 * PW + U - (w) + 64 * XINV_PIPE_NS) % XINV_PIPE_NS)  /* LDS ring slot of row r - w */
 #define ITAG(v) std::integral_constant<int, (v)>{}
             const int r = rb_ + U;
+#if XINV_PIPE_DRAIN & 2
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
             request(r + PF, ITAG((U + PF) % R));
             request_rf(r + PFR, ITAG((U + PFR) % R));
 #if !XINV_PIPE_FLAGS
             if (PW > 0) {
 #pragma unroll
                 for (int q = 0; q < NP; q++) sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q][lane];   // row r+1: written B+1 steps ago
+#ifdef XINV_PIPE_DEBUG
+                if (dbgp && r - in_lo < 3) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    double *d = dbgp + (r - in_lo + 1) * 128;
+                    d[lane * 2] = sw[0][(U + 1) % R].x; d[lane * 2 + 1] = sw[0][(U + 1) % R].y;
+                }
+#endif
             }
 #endif
             {   // row r-1: update predicate and F * delxSqr, once for both half-sweeps
@@ -444,7 +478,12 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 template <class M, int NP, bool AL, bool EXT>
 __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 {
+#ifndef XINV_PIPE_INV
+#define XINV_PIPE_INV 1
+#endif
+#if XINV_PIPE_INV
     xinv_fresh_scalar_cache();
+#endif
     constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = XINV_PIPE_UW(NP), LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP][XINV_WAVE];
     __shared__ int prog[2 * P];                          // hand-over progress counters (XINV_PIPE_FLAGS)
@@ -518,10 +557,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         }
         gtot = ((gtot + B - 1) / B) * B;
         switch (pwi) {
-        case 0: xinv_pipe_wave<M, NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
-        case 1: xinv_pipe_wave<M, NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
-        case 2: xinv_pipe_wave<M, NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
-        default: xinv_pipe_wave<M, NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl); break;
+        case 0: xinv_pipe_wave<M, NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        case 1: xinv_pipe_wave<M, NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        case 2: xinv_pipe_wave<M, NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        default: xinv_pipe_wave<M, NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
         }
     }
     }
