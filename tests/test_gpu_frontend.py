@@ -372,6 +372,13 @@ def test_animate_iteration_poisson_real_data():
                             iParams={'BCs': ['fixed', 'periodic'], 'tolerance': 1e-30, 'mxLoop': 79,
                                      'printInfo': False})
     assert np.array_equal(sf.values[-1], one.values)           # 40 frames x 2 sweeps == 80 sweeps
+    # flags and statistics of the frames are left where the inv_* calls leave them: in the caller's iParams
+    assert iParams['frame_flags'].shape == (40, 3) and (iParams['frame_flags'][:, 2] == 1).all()
+    assert np.array_equal(iParams['flags'], iParams['frame_flags'][-1]) and iParams['stats']['path'] in (1, 2)
+    # engine options in iParams reach the resident solves too: the colour path, same bits
+    ip2 = {'BCs': ['fixed', 'periodic'], 'tolerance': 1e-30, 'engine_path': 1}
+    sf2 = xa.animate_iteration('Poisson', vor, dims=['lat', 'lon'], iParams=ip2, loop_per_frame=1, max_frames=5)
+    assert ip2['stats']['path'] == 1 and np.array_equal(sf2.values, sf.values[:5])
     with pytest.raises(Exception, match='unsupported problem'):
         xa.animate_iteration('nonsense', vor, dims=['lat', 'lon'])
 

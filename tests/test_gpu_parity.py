@@ -274,21 +274,25 @@ def test_pipelined_pass_equals_single_wavefront_pass(BCy, BCx, shape, kind):
     yc, xc = shape
     if BCx == 'periodic' and xc % 2:
         pytest.skip('odd-xc periodic seam goes through the colour path')
-    uni = _uniform2d if kind == 'std2d' else _uniform2d_all
+    uni = {'std2d': _uniform2d, 'gen2d': _uniform2d_all}[kind]          # per-row A, C / A, C, D, E, F
+    um = {'std2d': 3, 'gen2d': 31}[kind]
     ps = [uni(rand2d(kind, yc, xc, BCy, BCx, 0, m & 1, seed=_seed(('pipe', kind, BCy, BCx, shape, m)))) for m in range(3)]
     ref = [run_oracle(p, 26, 1e-9, COLOUR_2) for p in ps]
     S0, f0, st0 = run_hip_batched(ps, 26, 1e-9, path=PATH_FUSED, sweeps_per_launch=4, no_pipe=1)
-    assert st0['pipelined'] == 0 and st0['xuniform_mask'] == (3 if kind == 'std2d' else 31), st0
-    for np_ in (('1', '2') if kind == 'std2d' else ('1',)):
-        os.environ['XINV_PIPE_NP'] = np_                  # read per solve by the library
+    assert st0['pipelined'] == 0 and st0['xuniform_mask'] == um, st0
+    # one / two column pairs per lane; the forcing re-read from memory by every wavefront / riding the LDS ring
+    for np_, fr in ((('1', '0'), ('1', '1'), ('2', '0')) if kind == 'std2d' else (('1', '0'), ('1', '1'))):
+        os.environ['XINV_PIPE_NP'] = np_                  # (both read per solve by the library)
+        os.environ['XINV_PIPE_FR'] = fr
         for kw in (dict(), dict(rows_per_tile=16), dict(force_tile_skip=1), dict(rows_per_tile=-3), dict(sweeps_per_launch=4)):
             o = dict(path=PATH_FUSED); o.update(kw)
             S, fl, st = run_hip_batched(ps, 26, 1e-9, **o)
             assert st['pipelined'] == int(np_) and st['sweeps_per_launch'] == 4, st
             for m in range(3):
-                assert_same(S[m], fl[m], ref[m][0], ref[m][1], 'pipelined %s %r member %d %r' % (kind, shape, m, kw))
+                assert_same(S[m], fl[m], ref[m][0], ref[m][1], 'pipelined %s %r member %d %r np %s fr %s' % (kind, shape, m, kw, np_, fr))
             assert np.array_equal(S, S0)
     os.environ.pop('XINV_PIPE_NP', None)
+    os.environ.pop('XINV_PIPE_FR', None)
 
 
 @pytest.mark.parametrize('tol', [3e-3, 1e-3, 2e-4, 5e-5])

@@ -229,6 +229,7 @@ def animate_iteration(app_name, F, dims, coords='lat-lon', icbc=None,
                         '\n'.join(repr(k) for k in _ANIMATE))
     coef_name, inv_name, validMPs = _ANIMATE[name]
     coef_func, invt_func = globals()[coef_name], getattr(core, inv_name)
+    iParams_in = iParams
     iParams = _update(default_iParams, iParams)
     mParams = _update(default_mParams, mParams, validMPs)
     if icbc is not None:
@@ -244,13 +245,28 @@ def animate_iteration(app_name, F, dims, coords='lat-lon', icbc=None,
     iParams = _update(ps, iParams)
     iParams['mxLoop'] = loop_per_frame
     iParams['printInfo'] = False
-    # the coefficient stack, the forcing and S stay in HBM for all frames (core.Resident): a frame is one
-    # restart of the kernels on the resident batch plus one download of S
-    res = core.Resident(inv_name, coeffs, maskF, initS, dims, iParams)
-    frames = []
+    # the coefficient stack, the forcing and S stay in HBM for all frames (core.Resident: torch holds the device
+    # memory): a frame is one restart of the kernels on the resident batch plus one download of S.  Without torch
+    # the frames go through the host-pointer inv_* call, as the reference does (apps.py:1031-1044).
+    frames, frame_flags = [], []
+    try:
+        import torch  # noqa: F401
+        res = core.Resident(inv_name, coeffs, maskF, initS, dims, iParams)
+    except ImportError:
+        res = None
     for _ in range(max_frames):
-        res.solve(loop_per_frame, float(iParams['tolerance']))
-        frames.append(res.values())
+        if res is not None:
+            res.solve(loop_per_frame, float(iParams['tolerance']))
+            frames.append(res.values())
+        else:
+            initS = invt_func(*coeffs, maskF, initS, dims, iParams)
+            frames.append(np.array(initS.values, copy=True))
+        frame_flags.append(np.array(iParams['flags'], copy=True))
+    iParams['frame_flags'] = np.stack(frame_flags)       # flags of every frame (iParams['flags'] holds the last)
+    if isinstance(iParams_in, dict) and iParams_in is not default_iParams:
+        for k in ('flags', 'stats', 'frame_flags'):      # where the inv_* calls leave them for the caller
+            if k in iParams:
+                iParams_in[k] = iParams[k]
     out = np.stack(frames)
     if icbc is None:
         out = np.where(maskF.values[None] != _undeftmp, out, iParams['undef'])

@@ -28,7 +28,8 @@ UNITS = [
     ('xinv_tu_fused2d_std', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=0']),
     ('xinv_tu_fused2d_gen', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=1']),
     ('xinv_tu_fused2d_std2dt', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=2']),
-    ('xinv_tu_pipe2d', 'xinv_tu_pipe2d.hip', []),
+    ('xinv_tu_pipe2d_std', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=0']),
+    ('xinv_tu_pipe2d_gen', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=1']),
     ('xinv_tu_fused9', 'xinv_tu_fused9.hip', []),
     ('xinv_tu_fused3d', 'xinv_tu_fused3d.hip', []),
     ('xinv_tu_bih', 'xinv_tu_bih.hip', []),

@@ -177,6 +177,7 @@ class Resident:
                      ratio2Sqr=float(ip['ratio2Sqr']), ratio1Sqr=float(ip['ratio1Sqr']))
             if kind == 'gen3d':
                 p.update(ratio2=float(ip['ratio2']), ratio1=float(ip['ratio1']))
+        self.iParams = iParams
         dev = int(iParams.get('device', -1))
         if dev < 0:
             import torch
@@ -184,8 +185,16 @@ class Resident:
         self.rp = ResidentProblem(p, device=dev)
 
     def solve(self, mxLoop, tolerance, **opt):
-        """One more call of the hot path on the resident batch -> flags [nbatch, 3]."""
-        fl, self.stats = self.rp.solve(mxLoop, tolerance, **opt)
+        """One more call of the hot path on the resident batch -> flags [nbatch, 3].  Engine options the
+        caller put into iParams (engine_path, sweeps_per_launch, check_every) apply as in the inv_* calls;
+        flags and statistics are left in iParams as those calls leave them."""
+        o = dict(path=int(self.iParams.get('engine_path', 0)),
+                 sweeps_per_launch=int(self.iParams.get('sweeps_per_launch', 0)),
+                 check_every=int(self.iParams.get('check_every', 0)))
+        o.update(opt)
+        fl, self.stats = self.rp.solve(mxLoop, tolerance, **o)
+        self.iParams['flags'] = np.array(fl if self.rp.nb > 1 else fl[0], copy=True)
+        self.iParams['stats'] = self.stats
         return fl
 
     def values(self):
@@ -194,18 +203,29 @@ class Resident:
         return np.ascontiguousarray(np.transpose(out, np.argsort(self.perm)))
 
 
-def _device_list(iParams, nbatch):
+# in-process multi-GPU is the default only when every device gets a worthwhile share: below this much
+# per-member data per device, the contexts, workspaces and re-uploaded coefficient stacks cost more than
+# the extra GPUs give (a 3-slice 73 x 144 call stays on the caller's device)
+_MULTI_GPU_MIN_BYTES_PER_DEVICE = 256 << 20
+
+
+def _device_list(iParams, nbatch, batch_bytes=0):
     """GPUs the batch axis is split over inside this one call (contiguous blocks, the order of the
-    reference's slice loop core.py:129).  iParams['devices']: a list of ordinals or 'all'; unset =
-    every visible GPU, except when one device was asked for (iParams['device']), when the process
-    is one rank of a one-process-per-GPU job (WORLD_SIZE > 1: xinvert_amd.dist shards instead), or
-    when there is a single slice."""
+    reference's slice loop core.py:129).  iParams['devices']: a list of ordinals or 'all' -- the explicit
+    form.  Unset: the caller's current device, unless the batch is large enough to give every visible GPU
+    at least _MULTI_GPU_MIN_BYTES_PER_DEVICE of per-member data; never when one device was asked for
+    (iParams['device']), when the process is one rank of a one-process-per-GPU job (WORLD_SIZE > 1:
+    xinvert_amd.dist shards instead), or for a single slice."""
     d = iParams.get('devices')
     if d is not None:
         return d
     if nbatch <= 1 or iParams.get('device') is not None or int(os.environ.get('WORLD_SIZE', '1')) > 1:
         return None
-    return 'all'
+    ndev = _lib.load().xinv_device_count()
+    if ndev < 2 or batch_bytes < _MULTI_GPU_MIN_BYTES_PER_DEVICE * 2:
+        return None
+    use = int(min(ndev, nbatch, batch_bytes // _MULTI_GPU_MIN_BYTES_PER_DEVICE))
+    return list(range(use)) if use >= 2 else None
 
 
 def _info(sel):
@@ -262,7 +282,8 @@ def _solve(kind, coefs, F, S, dims, iParams):
                        sweeps_per_launch=int(iParams.get('sweeps_per_launch', 0)),
                        check_every=int(iParams.get('check_every', 0)), rowconst_mask=rowconst,
                        host_chunk=int(iParams.get('host_chunk', 0)),
-                       devices=_device_list(iParams, nbatch), prep=prep)
+                       devices=_device_list(iParams, nbatch, sum(a.nbytes for a, st_ in zip(arrs, strides) if a is not None and st_)),
+                       prep=prep)
     st = _lib.strides_arg(strides)
     ptrs = [_lib.hptr(a) for a in arrs]
     mx, tol = int(iParams['mxLoop']), float(iParams['tolerance'])

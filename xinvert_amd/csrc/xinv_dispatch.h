@@ -20,12 +20,21 @@ XINV_HIDDEN int xinv_launch_fused2d_gen(bool al, bool ext, unsigned um, int K, d
                                         hipStream_t st, const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused2d_std2dt(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                                            hipStream_t st, const FusedArgs &a, int *occ);
-// wave-pipelined four-sweep pass (standard form with per-row A and C; gen: general form with per-row A, C, D, E, F):
-// one tile per 256-thread workgroup
-// (np = 1 or 2 column pairs per lane: strips of XINV_PIPE_UW(np) owned columns)
+// wave-pipelined four-sweep pass, one tile per 256-thread workgroup: standard form (um = 3: A and C per row, np = 1
+// or 2 column pairs per lane) and general form (um = 0x1f: A C D E F per row).  Returns 1 for a variant that is
+// not instantiated (coefficient arrays varying along x: measured slower than k_fused2d, see plan_fused5).
 // lds_pad: unused dynamic LDS per workgroup, which caps how many of them share a CU (see launch_fused)
-XINV_HIDDEN int xinv_launch_pipe2d(bool gen, int np, bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ,
-                                   int lds_pad = 0);
+// fr: the forcing row rides the LDS ring with S (per-row-coefficient variants, one column pair per lane)
+XINV_HIDDEN int xinv_launch_pipe2d_std(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
+                                       const FusedArgs &a, int *occ, int lds_pad);
+XINV_HIDDEN int xinv_launch_pipe2d_gen(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
+                                       const FusedArgs &a, int *occ, int lds_pad);
+static inline int xinv_launch_pipe2d(bool gen, unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
+                                     const FusedArgs &a, int *occ, int lds_pad = 0)
+{
+    return gen ? xinv_launch_pipe2d_gen(um, np, fr, al, ext, grid, st, a, occ, lds_pad)
+               : xinv_launch_pipe2d_std(um, np, fr, al, ext, grid, st, a, occ, lds_pad);
+}
 XINV_HIDDEN int xinv_launch_fused9(bool gen, int K, bool al, bool ext, dim3 grid, hipStream_t st,
                                    const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 grid, hipStream_t st,

@@ -168,20 +168,17 @@ __device__ __forceinline__ double cget(const CoefWin<NC, D> &w, int slot)
 struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
     static constexpr int NC = 3;    // A, C, F
     template <unsigned UM> static constexpr bool hoist() { return (UM & 3u) == 3u; }   // A and C uniform
-    // wave-pipelined pass (xinv_pipe2d.h): per-row record {A[j], C[j], relaxation factor of row j, row predicate}
-    static constexpr unsigned PIPE_UM = 3u;
-    static constexpr int PIPE_RW = 4, PIPE_FQ = 2, PIPE_PFR = 2;
-    static constexpr bool PIPE_PREMUL = true;             // the forcing enters the update as F * delxSqr
-    template <int D>
-    static __device__ __forceinline__ void pipe_row(CoefWin<NC, D> &w, int slot, const double (&rec)[PIPE_RW], double &rok)
-    {
-        w.s[0][slot] = rec[0]; w.s[1][slot] = rec[1]; w.rq[slot] = rec[2]; rok = rec[3];
-    }
+    // wave-pipelined pass (xinv_pipe2d.h): the update of row j reads A[j+1], so the per-row record is asked for
+    // two steps ahead
+    static constexpr int PIPE_PFR = 2;
 
     // called once per step after row r entered slot `sr`; `s1` = slot of row r-1, whose operands
     // (A[r], A[r-1], C[r-1], F[r-1]) are all in the window now: relaxation factor when it is
     // x-uniform, the update predicate (numbas.py:344-348), and F*delxSqr in place of F.
-    template <unsigned UM, int D>
+    // PRE: F * delxSqr replaces F in the window here (each row is touched by 2K half-sweeps: k_fused2d); false:
+    // the window keeps F and `upd<.., false>` multiplies at use (k_pipe2d: one sweep per wavefront, the same
+    // two multiplications per row, and the original F can ride the LDS ring to the next wavefront)
+    template <unsigned UM, int D, bool PRE = true>
     static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int s1, bool okx, bool oky,
                                                   const XinvScal &sc)
     {
@@ -203,12 +200,14 @@ struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
         }
         w.mx[s1] = xinv_lane_word(bx);
         w.my[s1] = xinv_lane_word(by);
-        if (!((UM >> 2) & 1u)) { w.v[2][s1].x = fx * sc.delxSqr; w.v[2][s1].y = fy * sc.delxSqr; }
-        else                   w.s[2][s1] = fx * sc.delxSqr;
+        if (PRE) {
+            if (!((UM >> 2) & 1u)) { w.v[2][s1].x = fx * sc.delxSqr; w.v[2][s1].y = fy * sc.delxSqr; }
+            else                   w.s[2][s1] = fx * sc.delxSqr;
+        }
     }
 
     // sj = slot of row j, sjp = slot of row j+1.
-    template <int X, unsigned UM, int D>
+    template <int X, unsigned UM, int D, bool PRE = true>
     static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
                                                  double sP, double sM, double sW, double sE,
                                                  const XinvScal &sc)
@@ -220,7 +219,8 @@ struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
         if ((UM >> 1) & 1u) cE = w.s[1][sj];
         else if (X == 0)    cE = w.v[1][sj].y;
         else                cE = xinv_lane_down(w.v[1][sj].x);
-        const double fd = cget<X, UM, 2>(w, sj);             // F * delxSqr (see derive)
+        const double fd = PRE ? cget<X, UM, 2>(w, sj)        // F * delxSqr (see derive)
+                              : cget<X, UM, 2>(w, sj) * sc.delxSqr;
         double temp = (
             (
                 aP * (sP - sC) -
@@ -297,22 +297,13 @@ struct FusedStd2DT {                // numbas.invert_standard_2D_test, B == 0 an
 struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     static constexpr int NC = 6;    // A, C, D, E, F, G
     template <unsigned UM> static constexpr bool hoist() { return (UM & 0x13u) == 0x13u; }  // A, C, F uniform
-    // wave-pipelined pass: per-row record {A, C, D, E, F of row j, relaxation factor, row predicate, -}; the update of
-    // a row reads only its own record, so it is asked for one step ahead (fewer records live in SGPRs)
-    static constexpr unsigned PIPE_UM = 0x1fu;
-    static constexpr int PIPE_RW = 8, PIPE_FQ = 5, PIPE_PFR = 1;
-    static constexpr bool PIPE_PREMUL = false;            // G enters as (F S - G) * delxSqr
-    template <int D>
-    static __device__ __forceinline__ void pipe_row(CoefWin<NC, D> &w, int slot, const double (&rec)[PIPE_RW], double &rok)
-    {
-#pragma unroll
-        for (int q = 0; q < 5; q++) w.s[q][slot] = rec[q];
-        w.rq[slot] = rec[5]; rok = rec[6];
-    }
+    // wave-pipelined pass: the update of a row reads only its own per-row record, so it is asked for one step
+    // ahead (fewer records live in SGPRs)
+    static constexpr int PIPE_PFR = 1;
 
     // every operand of the predicate (numbas.py:1126-1129) sits on the point itself: row r-1 is
     // handled here like in the other models (its first half-sweep runs in this very step)
-    template <unsigned UM, int D>
+    template <unsigned UM, int D, bool PRE = true>       // (PRE: nothing is premultiplied in this form)
     static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int, int s1, bool okx, bool oky,
                                                   const XinvScal &sc)
     {
@@ -336,7 +327,7 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
         w.my[s1] = xinv_lane_word(by);
     }
 
-    template <int X, unsigned UM, int D>
+    template <int X, unsigned UM, int D, bool PRE = true>
     static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int, double sC,
                                                  double sP, double sM, double sW, double sE,
                                                  const XinvScal &sc)

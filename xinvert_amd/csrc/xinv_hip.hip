@@ -20,7 +20,11 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <exception>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -392,8 +396,11 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // records: the standard form with per-row A and C (lat-lon Poisson) and the general form with per-row
         // A, C, D, E, F (lat-lon Gill-Matsuno).
         static const int pipe_mode = [] { const char *e = getenv("XINV_PIPE"); return e ? atoi(e) : 1; }();
-        const bool pipe_form = (p.kind == KIND_STD2D && pl.um == FusedStd2D::PIPE_UM) ||
-                               (p.kind == KIND_GEN2D && pl.um == FusedGen2D::PIPE_UM);
+        // (Only the variants whose relaxation factor is a per-row record.  With coefficient arrays that vary along
+        // x every wavefront of the pipeline streams them and divides per point: built, bit-exact, and slower than
+        // k_fused2d at three sweeps per pass -- C3 Stommel 2.09 against 2.56e11, C2 with every array streamed 2.95
+        // against 4.06e11, profiles/r03_pipe_vector_streams.txt -- so those forms stay on k_fused2d.)
+        const bool pipe_form = (p.kind == KIND_STD2D && pl.um == 3u) || (p.kind == KIND_GEN2D && pl.um == 0x1fu);
         // Standard form: only where the launch is small enough for the halo saving to matter -- k_fused2d keeps the
         // VALU 96 % busy against ~75 %, and with several rounds of workgroups its tiles are tall anyway (8 slices
         // of 3600x1800: 7.0e11 with k_fused2d, 6.2e11 pipelined; one slice: 5.85 against 6.0e11; 180x360: 1.7
@@ -426,22 +433,32 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // workgroup count up; XINV_PIPE_NP=1|2 forces the choice
         const int np_env = [] { const char *e = getenv("XINV_PIPE_NP"); return e ? atoi(e) : 0; }();   // (read per solve: tests switch it)
         pl.npair = ((np_env == 1 || np_env == 2) && p.kind == KIND_STD2D) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
+        // the forcing through the LDS ring where the launch's streams (S read + write + forcing, every member) no
+        // longer fit the caches and the later wavefronts' forcing requests would go back to HBM; XINV_PIPE_FR=0|1 forces
+        {
+            const int fr_env = [] { const char *e = getenv("XINV_PIPE_FR"); return e ? atoi(e) : -1; }();   // (read per solve: tests switch it)
+            const bool fr_form = (p.kind == KIND_STD2D && pl.um == 3u) || (p.kind == KIND_GEN2D && pl.um == 0x1fu);
+            const bool fr_size = (double)p.nbatch * (double)p.yc * (double)p.xc * 24.0 > 2.0e8;
+            pl.pipe_fr = pl.pipe && fr_form && pl.npair == 1 && (fr_env < 0 ? fr_size : fr_env != 0);
+        }
         if (pl.pipe) {
+            // per-row records of the x-uniform streams (+ relaxation factor and row predicate when the model hoists)
             const bool gen = (p.kind == KIND_GEN2D);
-            const int rw = gen ? FusedGen2D::PIPE_RW : FusedStd2D::PIPE_RW;
-            rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)p.nbatch * p.yc * rw * sizeof(double));
-            if (rc) return rc;
-            RowFactorArgs ra;
-            memset(&ra, 0, sizeof ra);
-            if (gen) {
+            const int nco = gen ? 5 : 2;
+            const bool hoist = gen ? ((pl.um & 0x13u) == 0x13u) : ((pl.um & 3u) == 3u);
+            const int nw = __builtin_popcount(pl.um & ((1u << nco) - 1u)) + (hoist ? 2 : 0);
+            const int rw = nw == 0 ? 0 : (nw <= 4 ? 4 : 8);
+            if (rw) {
+                rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)p.nbatch * p.yc * rw * sizeof(double));
+                if (rc) return rc;
+                RowFactorArgs ra;
+                memset(&ra, 0, sizeof ra);
                 ra.c[0] = p.c[0]; ra.sc[0] = p.sc[0];                                     // A
-                for (int q = 2; q < 6; q++) { ra.c[q - 1] = p.c[q]; ra.sc[q - 1] = p.sc[q]; }   // C, D, E, F
-            } else {
-                ra.c[0] = p.c[0]; ra.sc[0] = p.sc[0]; ra.c[1] = p.c[2]; ra.sc[1] = p.sc[2];   // A, C
+                for (int q = 2; q < (gen ? 6 : 3); q++) { ra.c[q - 1] = p.c[q]; ra.sc[q - 1] = p.sc[q]; }   // C (, D, E, F)
+                ra.gen = gen ? 1 : 0; ra.um = pl.um; ra.hoist = hoist ? 1 : 0; ra.rw = rw;
+                ra.yc = p.yc; ra.xc = p.xc; ra.sc_ = p.sc_; ra.rowf = (double *)ws->d_rowf;
+                hipLaunchKernelGGL(k_row_factor, dim3(cdiv(p.yc, 256), (unsigned)p.nbatch, 1), dim3(256), 0, st, ra);
             }
-            ra.gen = gen ? 1 : 0;
-            ra.yc = p.yc; ra.xc = p.xc; ra.sc_ = p.sc_; ra.rowf = (double *)ws->d_rowf;
-            hipLaunchKernelGGL(k_row_factor, dim3(cdiv(p.yc, 256), (unsigned)p.nbatch, 1), dim3(256), 0, st, ra);
         }
         // Rows per tile (see the cost model below).
         pl.even_split = false;
@@ -461,7 +478,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             int occ = 2;                                   // workgroups of the chosen variant per CU
             {
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-                if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.npair, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
+                if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
                 else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
                                     st, dummy, &occ);
             }
@@ -932,28 +949,91 @@ struct HostEvents {                                   // destroyed on every retu
     }
 };
 
-static int64_t host_chunk_members(const Problem &p, const xinv_options &opt)
+// Member chunks of the upload / solve / download pipeline: sizes in members, in batch order.
+// Chunking hides PCIe time behind sweeps (chunk c+1 travels and chunk c-1 returns while chunk c sweeps) but
+// costs twice: every chunk repeats the once-per-solve detection / planning passes (~0.5 ms), and a chunk fills
+// the 256 CUs less evenly than the whole batch.  The 3-D kernels tile a volume in fixed cross-sections, one
+// workgroup per CU, so a chunk costs ceil(workgroups / 256) rounds: the split is chosen among those whose
+// rounds add up to (about) the rounds of the whole batch, with the first and last chunk -- whose upload and
+// download are exposed -- as small as that allows (C5, 15 volumes of 180 workgroups: [4, 7, 4] = 3 + 5 + 3
+// rounds = the 11 of one chunk; equal thirds would be 4 + 4 + 4).  The 2-D kernels re-tile every chunk to the
+// CU count, so equal chunks of at least 192 MiB of per-member data do.
+static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &opt)
 {
-    if (p.nbatch <= 1) return 1;
-    if (opt.host_chunk > 0) return std::min<int64_t>(opt.host_chunk, p.nbatch);
-    // Chunking hides PCIe time behind sweeps but costs twice: every chunk repeats the once-per-solve
-    // detection / planning passes (~0.5 ms), and a small chunk fills the 256 CUs less evenly than the
-    // whole batch (measured, profiles/r02_host_pipeline.txt: 15 omega volumes, 200 sweeps: one chunk
-    // 293 ms, three 254 ms, eight 281 ms against 202 ms device-resident; 8 Gill-Matsuno members, 500
-    // sweeps: one chunk 17 ms, three 22 ms).  So: one chunk below 1 GiB of per-member data, three above.
-    // Without in-place pinning (the default, xinv_host.h) the runtime stages pageable copies and the
-    // "asynchronous" copies block the host: nothing overlaps, chunks only add their fixed costs (C5, 15
-    // volumes: one chunk 300 ms, three 319 ms).
-    if (!Pinned::allowed()) return p.nbatch;
+    const int64_t nb = p.nbatch;
+    std::vector<int64_t> out;
+    if (nb <= 1) { out.push_back(nb); return out; }
+    if (opt.host_chunk > 0) {
+        const int64_t mc = std::min<int64_t>(opt.host_chunk, nb);
+        for (int64_t m0 = 0; m0 < nb; m0 += mc) out.push_back(std::min(mc, nb - m0));
+        return out;
+    }
     const int64_t n = p.zc * p.yc * p.xc;
     int per_member = 1;                                   // S
     for (int q = 0; q < p.ncoef; q++) per_member += (p.c[q] && p.sc[q] != 0 && !((p.rowconst >> q) & 1u)) ? 1 : 0;
-    const double bytes = (double)p.nbatch * (double)n * 8.0 * per_member;
-    if (bytes < 1073741824.0 || p.nbatch < 3) return p.nbatch;
-    return (p.nbatch + 2) / 3;
+    const double member_bytes = (double)n * 8.0 * per_member;
+    const double total = member_bytes * (double)nb;
+    if (total < 268435456.0 || nb < 3) { out.push_back(nb); return out; }
+    if (is3d(p.kind)) {
+        const int64_t w = (int64_t)cdiv(p.xc, 124) * cdiv(p.yc, 12);          // workgroups per volume (16-row cross-sections)
+        auto rounds = [&](int64_t m) { return (int64_t)cdiv(w * m, 256); };
+        const int64_t r1 = rounds(nb);
+        int64_t best_a = nb, best_b = 0, best_c = 0;
+        double best = 1e300;
+        for (int64_t a = 1; a < nb; a++)
+            for (int64_t c = 0; a + c < nb; c++) {        // [a, nb - a - c, c]; c == 0: two chunks
+                const int64_t mid = nb - a - c;
+                const int64_t r = rounds(a) + rounds(mid) + (c ? rounds(c) : 0);
+                if ((double)r > (double)r1 * 1.04 + 0.01) continue;
+                // exposed transfer: first chunk's upload + last chunk's download (a third of the upload's bytes
+                // when S alone returns); one round of sweeps is taken as worth one member's transfer
+                const double exposed = (double)a + (double)(c ? c : mid) * 0.5 + 0.25 * (double)(r - r1) + 0.05 * (c ? 3 : 2);
+                if (exposed < best) { best = exposed; best_a = a; best_b = mid; best_c = c; }
+            }
+        if (best < (double)nb + 0.5 * (double)nb) {
+            out.push_back(best_a); out.push_back(best_b);
+            if (best_c) out.push_back(best_c);
+            return out;
+        }
+        out.push_back(nb);
+        return out;
+    }
+    const int64_t want = std::min<int64_t>(4, std::max<int64_t>(1, (int64_t)(total / 201326592.0)));
+    const int64_t nch = std::min<int64_t>(want, nb);
+    for (int64_t c = 0; c < nch; c++) out.push_back(nb / nch + (c < nb % nch ? 1 : 0));
+    return out;
 }
 
-static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bool pin_enabled)
+// One device: upload -> solve -> download, pipelined over member chunks by three actors:
+//   the UPLOADER thread stages every upload through the library's pinned ring (xinv_host.h) in batch order --
+//     shared coefficient arrays first, then S and the per-member arrays chunk by chunk, an event after each chunk;
+//   the CALLING thread solves chunk c as soon as its event is recorded (the compute stream waits for it);
+//   the DOWNLOADER thread brings each solved chunk's S back through its own ring.
+// Both DMA directions and the CUs are busy at once; what stays exposed is the first chunk's upload and the
+// last chunk's download.  Members are independent (reference core.py:129: no cross-slice state), so the
+// chunking cannot change any result.
+struct HostActors {                                   // joins the helper threads and drains the streams on EVERY return path
+    std::thread up, down;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> chunk_ready;                    // set by the uploader once chunk c's event is recorded
+    std::deque<std::function<int()>> dq;              // download jobs
+    bool d_closed = false, abort = false;
+    int u_rc = 0, d_rc = 0;
+    std::string u_err, d_err;
+    std::vector<hipStream_t> streams;
+    void close_downloads() { { std::lock_guard<std::mutex> lk(mu); d_closed = true; } cv.notify_all(); }
+    ~HostActors()
+    {
+        { std::lock_guard<std::mutex> lk(mu); abort = true; d_closed = true; }
+        cv.notify_all();
+        if (up.joinable()) up.join();
+        if (down.joinable()) down.join();
+        for (hipStream_t s : streams) (void)hipStreamSynchronize(s);      // nothing of this call stays in flight
+    }
+};
+
+static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bool may_register)
 {
     const auto wall0 = std::chrono::steady_clock::now();
     DeviceGuard dg;
@@ -961,7 +1041,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
     int device = 0;
     HIPCHK(hipGetDevice(&device));
     const int64_t n = p.zc * p.yc * p.xc;
-    // the staging pool and the solver workspace are per device: hold the device for the whole
+    // the staging rings, the device pool and the solver workspace are per device: hold the device for the whole
     // upload -> solve -> download sequence
     Workspace *ws = get_ws(device);
     std::lock_guard<std::recursive_mutex> host_lock(ws->busy);
@@ -970,113 +1050,207 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
     hipStream_t sup = ws->s_up, sdn = ws->s_down, scp = ws->s_compute;
     DevPool *pool = get_pool(device);
     pool->reset();
-    Pinned pin;                                       // (declared after the lock: drained + unpinned before it is released)
-    pin.enabled = pin_enabled;
+    g_copy_pool.start();
+    Pinned pin;                                       // opt-in registration of the caller's arrays (off by default)
+    pin.enabled = may_register && (Pinned::env_allowed() || (opt.flags & XINV_FLAG_PIN_HOST));
     pin.streams = { sup, sdn, scp };
     HostEvents ev;
-    hipEvent_t e_up0, e_up1, e_dn0 = nullptr, e_dn1;
+    hipEvent_t e_up0, e_up1, e_dn0, e_dn1;
     int rc;
-    if ((rc = ev.make(&e_up0, true)) || (rc = ev.make(&e_up1, true)) || (rc = ev.make(&e_dn1, true))) return rc;
+    if ((rc = ev.make(&e_up0, true)) || (rc = ev.make(&e_up1, true)) || (rc = ev.make(&e_dn0, true)) ||
+        (rc = ev.make(&e_dn1, true))) return rc;
 
     const int64_t hsS = p.nbatch > 1 ? p.sS : n;
-    const int64_t mc = host_chunk_members(p, opt);
-    const int64_t nchunk = (p.nbatch + mc - 1) / mc;
+    const std::vector<int64_t> chunks = host_chunks(p, opt);
+    const int64_t nchunk = (int64_t)chunks.size();
+    std::vector<int64_t> first((size_t)nchunk + 1, 0);
+    for (int64_t c = 0; c < nchunk; c++) first[(size_t)c + 1] = first[(size_t)c] + chunks[(size_t)c];
 
-    // ---- device buffers, shared (stride-0) arrays and per-row arrays first ------------------
+    // ---- device buffers now; what travels is queued for the uploader ----------------------------
+    std::vector<std::function<int()>> shared_ops;     // before the first chunk
+    std::vector<std::vector<std::function<int()>>> chunk_ops((size_t)nchunk);
+    // host range -> device, `members` pieces of `len` elements (host stride hstride, device stride len)
+    auto h2d = [&](double *dev, const double *host, int64_t members, int64_t hstride, int64_t len) -> int {
+        const bool direct = pin.covers(host);          // registered in place: the DMA reads the caller's memory
+        auto one = [&](double *d, const double *h, size_t bytes) -> int {
+            if (direct) { HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, sup)); return XINV_OK; }
+            return stage_h2d(ws->ring_up, sup, d, h, bytes);
+        };
+        if (members == 1 || hstride == len) return one(dev, host, (size_t)members * len * sizeof(double));
+        for (int64_t m = 0; m < members; m++) {
+            int r = one(dev + m * len, host + m * hstride, (size_t)len * sizeof(double));
+            if (r) return r;
+        }
+        return XINV_OK;
+    };
     Problem d = p;
     d.rowconst = 0;
     d.sS = n;
     rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &d.S);
     if (rc) return rc;
     pin.try_pin(p.S, (size_t)((p.nbatch - 1) * hsS + n) * sizeof(double));
-    HIPCHK(hipEventRecord(e_up0, sup));
     bool per_member[10];
     for (int q = 0; q < p.ncoef; q++) {
         per_member[q] = false;
         if (!p.c[q]) { d.c[q] = nullptr; d.sc[q] = 0; continue; }
         const int64_t hst = p.nbatch > 1 ? p.sc[q] : 0;
+        const double *hq = p.c[q];
         double *dc;
         if ((p.rowconst >> q) & 1u) {                 // one value per row: upload rows, expand on the device
             const int64_t rows = p.zc * p.yc;
-            double *drow; int64_t rstride;
-            rc = upload(pool, pin, sup, p.c[q], p.nbatch, hst, rows, &drow, &rstride);
+            const int64_t members = (hst == 0) ? 1 : p.nbatch;
+            double *drow;
+            rc = pool_alloc(pool, (size_t)members * rows * sizeof(double), &drow);
             if (rc) return rc;
-            const int64_t members = (rstride == 0) ? 1 : p.nbatch;
             rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &dc);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_expand_rows, dim3(cdiv(rows * members, 4)), dim3(256), 0, sup,
-                               (const double *)drow, dc, rows, p.xc, members);
-            d.sc[q] = (rstride == 0) ? 0 : n;
+            const int64_t xc = p.xc;
+            shared_ops.push_back([=, &h2d]() -> int {
+                int r = h2d(drow, hq, members, hst, rows);
+                if (r) return r;
+                hipLaunchKernelGGL(k_expand_rows, dim3(cdiv(rows * members, 4)), dim3(256), 0, sup,
+                                   (const double *)drow, dc, rows, xc, members);
+                return XINV_OK;
+            });
+            d.sc[q] = (hst == 0) ? 0 : n;
         } else if (hst == 0) {
-            rc = upload(pool, pin, sup, p.c[q], 1, 0, n, &dc, &d.sc[q]);
+            rc = pool_alloc(pool, (size_t)n * sizeof(double), &dc);
             if (rc) return rc;
+            pin.try_pin(hq, (size_t)n * sizeof(double));
+            shared_ops.push_back([=, &h2d]() -> int { return h2d(dc, hq, 1, 0, n); });
+            d.sc[q] = 0;
         } else {                                      // per member: travels with its chunk
             rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &dc);
             if (rc) return rc;
-            pin.try_pin(p.c[q], (size_t)((p.nbatch - 1) * hst + n) * sizeof(double));
+            pin.try_pin(hq, (size_t)((p.nbatch - 1) * hst + n) * sizeof(double));
             d.sc[q] = n;
             per_member[q] = true;
         }
         d.c[q] = dc;
     }
-    auto copy_members = [&](double *dev, const double *host, int64_t hstride, int64_t m0, int64_t nm,
-                            bool up, hipStream_t s) -> int {
-        const hipMemcpyKind kind = up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
-        if (hstride == n || nm == 1) {
-            double *dp = dev + m0 * n; const double *hp = host + m0 * hstride;
-            HIPCHK(up ? hipMemcpyAsync(dp, hp, (size_t)nm * n * sizeof(double), kind, s)
-                      : hipMemcpyAsync((void *)hp, dp, (size_t)nm * n * sizeof(double), kind, s));
-        } else
-            for (int64_t m = m0; m < m0 + nm; m++)
-                HIPCHK(up ? hipMemcpyAsync(dev + m * n, host + m * hstride, (size_t)n * sizeof(double), kind, s)
-                          : hipMemcpyAsync((void *)(host + m * hstride), dev + m * n, (size_t)n * sizeof(double), kind, s));
-        return XINV_OK;
-    };
     // front-end passes on the device (xinv_options.prep_flags): the forcing is the last array
     const int fq = p.ncoef - 1;
     const bool do_prep = (opt.prep_flags & (XINV_PREP_MASK_NAN | XINV_PREP_MASK_VALUE)) != 0;
-    const double *d_rowscale = nullptr;
+    double *d_rowscale = nullptr;
     if (do_prep && (opt.prep_flags & XINV_PREP_ROWSCALE)) {
         if (!opt.prep_rowscale) return fail_arg("XINV_PREP_ROWSCALE without prep_rowscale");
-        double *dr; int64_t dummy;
-        rc = upload(pool, pin, sup, opt.prep_rowscale, 1, 0, p.yc, &dr, &dummy);
+        rc = pool_alloc(pool, (size_t)p.yc * sizeof(double), &d_rowscale);
         if (rc) return rc;
-        d_rowscale = dr;
+        const double *hrs = opt.prep_rowscale;
+        const int64_t yc = p.yc;
+        shared_ops.push_back([=, &h2d]() -> int { return h2d(d_rowscale, hrs, 1, 0, yc); });
     }
-    auto prep_forcing = [&](double *dF, int64_t nelem) {
+    const int prep_nan = (opt.prep_flags & XINV_PREP_MASK_NAN) ? 1 : 0;
+    const double prep_undef = opt.prep_undef, undef_tmp = p.sc_.undef;
+    const int64_t pyc = p.yc, pxc = p.xc;
+    auto prep_forcing = [=](double *dF, int64_t nelem) {
         const unsigned nblk = (unsigned)std::min<int64_t>(4096, (nelem + 255) / 256);
-        hipLaunchKernelGGL(k_prep_forcing, dim3(nblk), dim3(256), 0, sup, dF, nelem, p.yc, p.xc, d_rowscale,
-                           (opt.prep_flags & XINV_PREP_MASK_NAN) ? 1 : 0, opt.prep_undef, p.sc_.undef);
+        hipLaunchKernelGGL(k_prep_forcing, dim3(nblk), dim3(256), 0, sup, dF, nelem, pyc, pxc, (const double *)d_rowscale,
+                           prep_nan, prep_undef, undef_tmp);
     };
-    if (do_prep && !per_member[fq]) prep_forcing(const_cast<double *>(d.c[fq]), n);      // one shared forcing
-    // ---- every chunk's upload, queued now ---------------------------------------------------
+    if (do_prep && !per_member[fq]) {
+        double *dF = const_cast<double *>(d.c[fq]);
+        shared_ops.push_back([=]() -> int { prep_forcing(dF, n); return XINV_OK; });      // one shared forcing
+    }
     std::vector<hipEvent_t> e_chunk((size_t)nchunk);
     for (int64_t c = 0; c < nchunk; c++) {
-        const int64_t m0 = c * mc, nm = std::min(mc, p.nbatch - m0);
+        const int64_t m0 = first[(size_t)c], nm = chunks[(size_t)c];
+        if ((rc = ev.make(&e_chunk[(size_t)c], false))) return rc;
+        auto &ops = chunk_ops[(size_t)c];
+        double *dS = d.S;
+        const double *hS = p.S;
         if (opt.prep_flags & XINV_PREP_S_ZERO)
-            HIPCHK(hipMemsetAsync(d.S + m0 * n, 0, (size_t)nm * n * sizeof(double), sup));
-        else {
-            rc = copy_members(d.S, p.S, hsS, m0, nm, true, sup);
-            if (rc) return rc;
-        }
+            ops.push_back([=]() -> int { HIPCHK(hipMemsetAsync(dS + m0 * n, 0, (size_t)nm * n * sizeof(double), sup)); return XINV_OK; });
+        else
+            ops.push_back([=, &h2d]() -> int { return h2d(dS + m0 * n, hS + m0 * hsS, nm, hsS, n); });
         for (int q = 0; q < p.ncoef; q++)
             if (per_member[q]) {
-                rc = copy_members(const_cast<double *>(d.c[q]), p.c[q], p.sc[q], m0, nm, true, sup);
-                if (rc) return rc;
-                if (do_prep && q == fq) prep_forcing(const_cast<double *>(d.c[q]) + m0 * n, nm * n);
+                double *dq_ = const_cast<double *>(d.c[q]);
+                const double *hq = p.c[q];
+                const int64_t hst = p.sc[q];
+                const bool prep_here = do_prep && q == fq;
+                ops.push_back([=, &h2d]() -> int {
+                    int r = h2d(dq_ + m0 * n, hq + m0 * hst, nm, hst, n);
+                    if (r) return r;
+                    if (prep_here) prep_forcing(dq_ + m0 * n, nm * n);
+                    return XINV_OK;
+                });
             }
-        if ((rc = ev.make(&e_chunk[(size_t)c], false))) return rc;
-        HIPCHK(hipEventRecord(e_chunk[(size_t)c], sup));
     }
-    HIPCHK(hipEventRecord(e_up1, sup));
 
-    // ---- solve chunk by chunk; downloads trail on their own stream -------------------------
+    // ---- the actors -----------------------------------------------------------------------------
+    HostActors act;
+    act.streams = { sup, sdn, scp };
+    act.chunk_ready.assign((size_t)nchunk, 0);
+    act.up = std::thread([&]() {
+        int r = (hipSetDevice(device) == hipSuccess) ? XINV_OK : XINV_ERR_HIP;
+        auto run = [&](std::vector<std::function<int()>> &ops) {
+            for (auto &f : ops) {
+                { std::lock_guard<std::mutex> lk(act.mu); if (act.abort) r = r ? r : XINV_ERR_HIP; }
+                if (r) return;
+                try { r = f(); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
+            }
+        };
+        if (!r && hipEventRecord(e_up0, sup) != hipSuccess) r = XINV_ERR_HIP;
+        if (!r) run(shared_ops);
+        for (int64_t c = 0; c < nchunk; c++) {
+            if (!r) run(chunk_ops[(size_t)c]);
+            if (!r && hipEventRecord(e_chunk[(size_t)c], sup) != hipSuccess) r = XINV_ERR_HIP;
+            if (!r && c == nchunk - 1 && hipEventRecord(e_up1, sup) != hipSuccess) r = XINV_ERR_HIP;
+            { std::lock_guard<std::mutex> lk(act.mu); act.chunk_ready[(size_t)c] = 1; if (r) { act.u_rc = r; act.u_err = t_err; } }
+            act.cv.notify_all();
+        }
+    });
+    act.down = std::thread([&]() {
+        int r = (hipSetDevice(device) == hipSuccess) ? XINV_OK : XINV_ERR_HIP;
+        bool first_job = true;
+        for (;;) {
+            std::function<int()> job;
+            {
+                std::unique_lock<std::mutex> lk(act.mu);
+                act.cv.wait(lk, [&] { return act.d_closed || !act.dq.empty(); });
+                if (act.dq.empty()) break;
+                job = std::move(act.dq.front()); act.dq.pop_front();
+                if (act.abort) continue;
+            }
+            if (r) continue;
+            if (first_job) { if (hipEventRecord(e_dn0, sdn) != hipSuccess) r = XINV_ERR_HIP; first_job = false; }
+            if (!r) { try { r = job(); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; } }
+        }
+        if (!r && first_job && hipEventRecord(e_dn0, sdn) != hipSuccess) r = XINV_ERR_HIP;
+        if (!r && hipEventRecord(e_dn1, sdn) != hipSuccess) r = XINV_ERR_HIP;
+        if (!r && hipStreamSynchronize(sdn) != hipSuccess) r = XINV_ERR_HIP;
+        std::lock_guard<std::mutex> lk(act.mu);
+        act.d_rc = r; if (r) act.d_err = t_err;
+    });
+
+    // ---- solve chunk by chunk; downloads trail on their own thread ------------------------------
+    // the per-device workspace grows on demand: size it for the LARGEST chunk now, so that a later, larger chunk
+    // does not pay a free + malloc of the ping-pong buffer (or of the pinned control-block mirror) mid-pipeline
+    {
+        const int64_t mmax = *std::max_element(chunks.begin(), chunks.end());
+        if (nchunk > 1 && p.kind != KIND_BIH2D) {
+            if ((rc = ensure_dev(&ws->S2, &ws->S2_cap, (size_t)mmax * n * sizeof(double)))) return rc;
+            if ((rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)mmax * sizeof(XinvCtl)))) return rc;
+            if (ws->hctl_cap < (size_t)mmax) {
+                if (ws->hctl) HIPCHK(hipHostFree(ws->hctl));
+                ws->hctl = nullptr; ws->hctl_cap = 0;
+                HIPCHK(hipHostMalloc((void **)&ws->hctl, 2 * (size_t)mmax * sizeof(XinvCtl), hipHostMallocDefault));
+                ws->hctl_cap = (size_t)mmax;
+            }
+        }
+    }
     xinv_stats acc;
     memset(&acc, 0, sizeof acc);
     xinv_options o1 = opt;
     o1.device = device; o1.ndev = 0;
     for (int64_t c = 0; c < nchunk; c++) {
-        const int64_t m0 = c * mc, nm = std::min(mc, p.nbatch - m0);
+        const int64_t m0 = first[(size_t)c], nm = chunks[(size_t)c];
+        {
+            std::unique_lock<std::mutex> lk(act.mu);
+            act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)c] != 0; });
+            if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
+        }
         HIPCHK(hipStreamWaitEvent(scp, e_chunk[(size_t)c], 0));
         Problem dc = d;
         dc.nbatch = nm;
@@ -1100,12 +1274,30 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
             }
             HIPCHK(hipStreamSynchronize(scp));
         }
-        if (c == 0) { if ((rc = ev.make(&e_dn0, true))) return rc; HIPCHK(hipEventRecord(e_dn0, sdn)); }
-        rc = copy_members(d.S, p.S, hsS, m0, nm, false, sdn);
-        if (rc) return rc;
+        {
+            double *hS = p.S; const double *dS = d.S;
+            const bool direct = pin.covers(p.S);
+            std::lock_guard<std::mutex> lk(act.mu);
+            act.dq.push_back([=]() -> int {
+                auto one = [&](double *h, const double *dv, size_t bytes) -> int {
+                    if (direct) { HIPCHK(hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, sdn)); return XINV_OK; }
+                    return stage_d2h(ws->ring_down, sdn, h, dv, bytes);
+                };
+                if (hsS == n || nm == 1) return one(hS + m0 * hsS, dS + m0 * n, (size_t)nm * n * sizeof(double));
+                for (int64_t m = m0; m < m0 + nm; m++) {
+                    int r = one(hS + m * hsS, dS + m * n, (size_t)n * sizeof(double));
+                    if (r) return r;
+                }
+                return XINV_OK;
+            });
+        }
+        act.cv.notify_all();
     }
-    HIPCHK(hipEventRecord(e_dn1, sdn));
-    HIPCHK(hipEventSynchronize(e_dn1));
+    act.close_downloads();
+    act.up.join();
+    act.down.join();
+    if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
+    if (act.d_rc) { t_err = act.d_err; return act.d_rc; }
     HIPCHK(hipStreamSynchronize(sup));
     float a = 0.f, b = 0.f;
     HIPCHK(hipEventElapsedTime(&a, e_up0, e_up1));
@@ -1125,7 +1317,6 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
 {
     xinv_options opt;
     fill_options(opt, opt_in);
-    g_pin_flag = (opt.flags & XINV_FLAG_PIN_HOST) != 0;
     p.rowconst = (unsigned)opt.rowconst_mask & ((1u << p.ncoef) - 1u);
     int rc = validate(p, flags);
     if (rc) return rc;
@@ -1156,7 +1347,8 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
     const int64_t n = p.zc * p.yc * p.xc;
     // host ranges pinned ONCE for every device (portable registration); the per-device threads
     // then copy straight out of / into the caller's arrays
-    Pinned pin;
+    Pinned pin;                                        // (opt-in: the per-device calls stage through their own rings otherwise)
+    pin.enabled = Pinned::env_allowed() || (opt.flags & XINV_FLAG_PIN_HOST);
     pin.flags = hipHostRegisterPortable;
     pin.try_pin(p.S, (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double));
     for (int q = 0; q < p.ncoef; q++) {

@@ -40,151 +40,6 @@ struct DeviceGuard {
     ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
 };
 
-// ------------------------------------------------------------------ per-device workspace
-// Grown on demand, reused across solves (no hipMalloc in steady state).
-struct Workspace {
-    int device = -1;
-    std::recursive_mutex busy;                          // one solve at a time per device
-    double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
-    XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
-    void *partials = nullptr; size_t partials_cap = 0;  // norm partials
-    size_t partials_half = 0;                           // lagged norm: byte offset of the odd launches' buffer
-    double *S3 = nullptr; size_t S3_cap = 0;            // lagged norm: third S buffer
-    int *dflag = nullptr;
-    int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
-    XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
-    int *hflag = nullptr;
-    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
-    hipStream_t gstream = nullptr;                      // capture stream for the small-problem hipGraph
-    hipStream_t s_up = nullptr, s_down = nullptr, s_compute = nullptr;   // host-pointer entries: copy / sweep overlap
-    // masked-tile skipping
-    unsigned char *d_act = nullptr; size_t d_act_cap = 0;
-    unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
-    int *d_list = nullptr; size_t d_list_cap = 0;               // [nbatch][ntl] then [nbatch][nskip]
-    int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
-    double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
-    void *d_rowf = nullptr; size_t d_rowf_cap = 0;              // k_pipe2d: per-row factors [nbatch][yc] (RowFac)
-};
-
-static std::mutex g_ws_mutex;
-static std::vector<Workspace *> g_ws;
-
-static Workspace *get_ws(int device)
-{
-    std::lock_guard<std::mutex> lk(g_ws_mutex);
-    for (auto *w : g_ws) if (w->device == device) return w;
-    Workspace *w = new Workspace();
-    w->device = device;
-    g_ws.push_back(w);
-    return w;
-}
-
-template <class T>
-static int ensure_dev(T **p, size_t *cap, size_t need_bytes)
-{
-    if (*cap >= need_bytes && *p) return XINV_OK;
-    if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
-    HIPCHK(hipMalloc((void **)p, need_bytes));
-    *cap = need_bytes;
-    return XINV_OK;
-}
-
-// ------------------------------------------------------------------ problem description
-enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3, KIND_STD2DT = 4, KIND_GEN3D = 5 };
-static inline bool is3d(int kind) { return kind == KIND_STD3D || kind == KIND_GEN3D; }
-
-struct Problem {
-    int kind;
-    int64_t nbatch, zc, yc, xc;
-    double *S;
-    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J ; std2dt: A..F ; gen3d: A..H
-    int64_t sS, sc[10];
-    int ncoef;
-    unsigned rowconst;           // host entries: arrays given as one value per row (see xinv.h)
-    int BCz, BCy, BCx;
-    XinvScal sc_;
-    XinvStop stop;
-};
-
-static int bc_ok(int b) { return b == XINV_BC_FIXED || b == XINV_BC_EXTEND || b == XINV_BC_PERIODIC; }
-
-static int validate(const Problem &p, const double *flags)
-{
-    if (!p.S || !flags) return fail_arg("null S or flags");
-    for (int q = 0; q < p.ncoef; q++)
-        if (!p.c[q] && !(q == 1 && (p.kind == KIND_STD2D || p.kind == KIND_GEN2D)))   // B may be NULL: identically 0
-            return fail_arg("null coefficient array");
-    if (p.nbatch < 1) return fail_arg("nbatch < 1");
-    if (p.yc < 3 || p.xc < 3 || (is3d(p.kind) && p.zc < 3))
-        return fail_arg("every core dimension needs at least 3 points");
-    if (!bc_ok(p.BCy) || !bc_ok(p.BCx) || (is3d(p.kind) && !bc_ok(p.BCz)))
-        return fail_arg("unknown boundary-condition code");
-    if (p.kind == KIND_BIH2D && (p.yc < 5 || p.xc < 7))
-        return fail_arg("the biharmonic form needs yc >= 5 and xc >= 7");
-    if (p.stop.mxLoop < 0) return fail_arg("mxLoop < 0");
-    const int64_t n = p.zc * p.yc * p.xc;
-    if (p.nbatch > 1 && p.sS < n) return fail_arg("S batch stride smaller than one slice");
-    for (int q = 0; q < p.ncoef; q++) {
-        const int64_t need = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
-        if (p.c[q] && p.sc[q] != 0 && p.sc[q] < need)
-            return fail_arg("coefficient batch stride must be 0 (shared) or >= slice size");
-    }
-    return XINV_OK;
-}
-
-static void fill_options(xinv_options &o, const xinv_options *in)
-{
-    xinv_default_options(&o);
-    if (in) o = *in;
-}
-
-
-// ------------------------------------------------------------------ host-pointer staging
-// Host <-> HBM path of the *_f64 / *_batched entry points.  Device buffers come from a
-// per-device pool that is kept across calls (the coefficient stack of a repeated solve is
-// re-uploaded but never re-allocated).  Large host arrays are pinned IN PLACE for the duration
-// of the call (hipHostRegister) so the DMA engines read them directly at PCIe rate and all
-// uploads are queued asynchronously on one stream; small arrays, or hosts where registration
-// fails, take the runtime's staged copy.
-struct DevPool {
-    std::vector<std::pair<void *, size_t>> bufs;   // (ptr, capacity)
-    size_t next = 0;
-    void reset() { next = 0; }
-};
-static std::mutex g_pool_mutex;
-static std::vector<std::pair<int, DevPool *>> g_pools;
-
-static DevPool *get_pool(int device)
-{
-    std::lock_guard<std::mutex> lk(g_pool_mutex);
-    for (auto &e : g_pools) if (e.first == device) return e.second;
-    DevPool *p = new DevPool();
-    g_pools.push_back({device, p});
-    return p;
-}
-
-static int pool_alloc(DevPool *pool, size_t bytes, double **out)
-{
-    if (pool->next < pool->bufs.size()) {
-        auto &b = pool->bufs[pool->next];
-        if (b.second < bytes) {
-            HIPCHK(hipFree(b.first));
-            b.first = nullptr; b.second = 0;
-            HIPCHK(hipMalloc(&b.first, bytes));
-            b.second = bytes;
-        }
-        *out = (double *)b.first;
-        pool->next++;
-        return XINV_OK;
-    }
-    void *d = nullptr;
-    HIPCHK(hipMalloc(&d, bytes));
-    pool->bufs.push_back({d, bytes});
-    pool->next++;
-    *out = (double *)d;
-    return XINV_OK;
-}
-
 // ------------------------------------------------------------------ library-owned pinned staging
 // Host <-> HBM traffic of the host-pointer entries goes through pinned buffers the LIBRARY owns (hipHostMalloc,
 // a ring of slots per direction and device): a helper thread copies the caller's pageable memory into a slot
@@ -329,6 +184,152 @@ static int stage_d2h(StageRing &r, hipStream_t s, double *host, const double *de
     }
     for (int i = 0; i < StageRing::NSLOT; i++)       // oldest first
         if ((rc = stage_d2h_retire(r, (r.next + i) % StageRing::NSLOT))) return rc;
+    return XINV_OK;
+}
+
+// ------------------------------------------------------------------ per-device workspace
+// Grown on demand, reused across solves (no hipMalloc in steady state).
+struct Workspace {
+    int device = -1;
+    std::recursive_mutex busy;                          // one solve at a time per device
+    double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
+    XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
+    void *partials = nullptr; size_t partials_cap = 0;  // norm partials
+    size_t partials_half = 0;                           // lagged norm: byte offset of the odd launches' buffer
+    double *S3 = nullptr; size_t S3_cap = 0;            // lagged norm: third S buffer
+    int *dflag = nullptr;
+    int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
+    XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
+    int *hflag = nullptr;
+    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
+    hipStream_t gstream = nullptr;                      // capture stream for the small-problem hipGraph
+    hipStream_t s_up = nullptr, s_down = nullptr, s_compute = nullptr;   // host-pointer entries: copy / sweep overlap
+    // masked-tile skipping
+    unsigned char *d_act = nullptr; size_t d_act_cap = 0;
+    unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
+    int *d_list = nullptr; size_t d_list_cap = 0;               // [nbatch][ntl] then [nbatch][nskip]
+    int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
+    double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
+    void *d_rowf = nullptr; size_t d_rowf_cap = 0;              // k_pipe2d: per-row records [nbatch][yc][PIPE_RW]
+    StageRing ring_up, ring_down;                               // host-pointer entries: the library's pinned staging
+};
+
+static std::mutex g_ws_mutex;
+static std::vector<Workspace *> g_ws;
+
+static Workspace *get_ws(int device)
+{
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    for (auto *w : g_ws) if (w->device == device) return w;
+    Workspace *w = new Workspace();
+    w->device = device;
+    g_ws.push_back(w);
+    return w;
+}
+
+template <class T>
+static int ensure_dev(T **p, size_t *cap, size_t need_bytes)
+{
+    if (*cap >= need_bytes && *p) return XINV_OK;
+    if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIPCHK(hipMalloc((void **)p, need_bytes));
+    *cap = need_bytes;
+    return XINV_OK;
+}
+
+// ------------------------------------------------------------------ problem description
+enum { KIND_STD2D = 0, KIND_GEN2D = 1, KIND_STD3D = 2, KIND_BIH2D = 3, KIND_STD2DT = 4, KIND_GEN3D = 5 };
+static inline bool is3d(int kind) { return kind == KIND_STD3D || kind == KIND_GEN3D; }
+
+struct Problem {
+    int kind;
+    int64_t nbatch, zc, yc, xc;
+    double *S;
+    const double *c[10];         // std2d/std3d: A,B,C,F ; gen2d: A..G ; bih2d: A..J ; std2dt: A..F ; gen3d: A..H
+    int64_t sS, sc[10];
+    int ncoef;
+    unsigned rowconst;           // host entries: arrays given as one value per row (see xinv.h)
+    int BCz, BCy, BCx;
+    XinvScal sc_;
+    XinvStop stop;
+};
+
+static int bc_ok(int b) { return b == XINV_BC_FIXED || b == XINV_BC_EXTEND || b == XINV_BC_PERIODIC; }
+
+static int validate(const Problem &p, const double *flags)
+{
+    if (!p.S || !flags) return fail_arg("null S or flags");
+    for (int q = 0; q < p.ncoef; q++)
+        if (!p.c[q] && !(q == 1 && (p.kind == KIND_STD2D || p.kind == KIND_GEN2D)))   // B may be NULL: identically 0
+            return fail_arg("null coefficient array");
+    if (p.nbatch < 1) return fail_arg("nbatch < 1");
+    if (p.yc < 3 || p.xc < 3 || (is3d(p.kind) && p.zc < 3))
+        return fail_arg("every core dimension needs at least 3 points");
+    if (!bc_ok(p.BCy) || !bc_ok(p.BCx) || (is3d(p.kind) && !bc_ok(p.BCz)))
+        return fail_arg("unknown boundary-condition code");
+    if (p.kind == KIND_BIH2D && (p.yc < 5 || p.xc < 7))
+        return fail_arg("the biharmonic form needs yc >= 5 and xc >= 7");
+    if (p.stop.mxLoop < 0) return fail_arg("mxLoop < 0");
+    const int64_t n = p.zc * p.yc * p.xc;
+    if (p.nbatch > 1 && p.sS < n) return fail_arg("S batch stride smaller than one slice");
+    for (int q = 0; q < p.ncoef; q++) {
+        const int64_t need = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
+        if (p.c[q] && p.sc[q] != 0 && p.sc[q] < need)
+            return fail_arg("coefficient batch stride must be 0 (shared) or >= slice size");
+    }
+    return XINV_OK;
+}
+
+static void fill_options(xinv_options &o, const xinv_options *in)
+{
+    xinv_default_options(&o);
+    if (in) o = *in;
+}
+
+
+// ------------------------------------------------------------------ host-pointer staging
+// Host <-> HBM path of the *_f64 / *_batched entry points.  Device buffers come from a
+// per-device pool that is kept across calls (the coefficient stack of a repeated solve is
+// re-uploaded but never re-allocated).  Large host arrays are pinned IN PLACE for the duration
+// of the call (hipHostRegister) so the DMA engines read them directly at PCIe rate and all
+// uploads are queued asynchronously on one stream; small arrays, or hosts where registration
+// fails, take the runtime's staged copy.
+struct DevPool {
+    std::vector<std::pair<void *, size_t>> bufs;   // (ptr, capacity)
+    size_t next = 0;
+    void reset() { next = 0; }
+};
+static std::mutex g_pool_mutex;
+static std::vector<std::pair<int, DevPool *>> g_pools;
+
+static DevPool *get_pool(int device)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    for (auto &e : g_pools) if (e.first == device) return e.second;
+    DevPool *p = new DevPool();
+    g_pools.push_back({device, p});
+    return p;
+}
+
+static int pool_alloc(DevPool *pool, size_t bytes, double **out)
+{
+    if (pool->next < pool->bufs.size()) {
+        auto &b = pool->bufs[pool->next];
+        if (b.second < bytes) {
+            HIPCHK(hipFree(b.first));
+            b.first = nullptr; b.second = 0;
+            HIPCHK(hipMalloc(&b.first, bytes));
+            b.second = bytes;
+        }
+        *out = (double *)b.first;
+        pool->next++;
+        return XINV_OK;
+    }
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, bytes));
+    pool->bufs.push_back({d, bytes});
+    pool->next++;
+    *out = (double *)d;
     return XINV_OK;
 }
 

@@ -26,6 +26,7 @@ struct Plan {
     bool pipe;               // K == 4 passes run the wave-pipelined kernel (k_pipe2d): one tile per workgroup
     int tpw;                 // wave-tiles per workgroup of the planned kernel: 4, or 1 with `pipe`
     int npair;               // `pipe`: column pairs per lane (1 or 2: strips of 112 or 240 owned columns)
+    bool pipe_fr;            // `pipe`: the forcing rides the LDS ring (launches whose arrays exceed the caches)
     bool lag;                // 5-point 2-D kernels: norm + stop rule evaluated by k_norm_reduce_lag on a second stream,
                              // one pass behind the sweeps (three S buffers); see run_sweeps
 };
@@ -131,7 +132,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
             // (XINV_PIPE_LDSPAD: unused dynamic LDS per workgroup, to cap the workgroups per CU in experiments;
             //  capping at the planned count changed nothing: the dispatcher already spreads them evenly)
             static const int pad = [] { const char *e = getenv("XINV_PIPE_LDSPAD"); return e ? std::max(0, atoi(e)) : 0; }();
-            xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.npair, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad);
+            xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad);
             continue;
         }
         if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
@@ -569,7 +570,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     int occ = occ_ > 0 ? occ_ : 2;
     if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-        if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.npair, pl.aligned, ext, dim3(1), st, dummy, &occ);
+        if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, ext, dim3(1), st, dummy, &occ);
         else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
     }
     const bool pp = pl.pipe;

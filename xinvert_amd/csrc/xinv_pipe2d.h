@@ -63,55 +63,67 @@
 #define XINV_PIPE_PF 4            /* rows of F in flight, wavefronts 1..3 */
 #endif
 
-// What a row needs besides S and the forcing, one record of M::PIPE_RW doubles per row, read through the scalar
-// unit: standard form {A[j], C[j], relaxation factor, row predicate} (32 bytes), general form {A, C, D, E, F,
-// relaxation factor, row predicate, -} (64 bytes).  The predicate is 1.0 / 0.0: all 64 bits are read, so no half
-// of a load in flight is ever reused.
+// What a row needs besides S and the vector streams: one record per row, read through the scalar unit --
+// the values of the coefficient streams that are constant along x (bit q of UM), in stream order, then, when the
+// model's denominator is x-uniform (M::hoist<UM>()), the row's relaxation factor and the row part of the update
+// predicate (1.0 / 0.0: all 64 bits are read, so no half of a load in flight is ever reused).  Padded to 4 or 8
+// doubles.  Standard form, A and C per row: {A[j], C[j], rq, rok}; general form, A C D E F per row:
+// {A, C, D, E, F, rq, rok, -}; general form, D E F per row (A, C, G streamed): {D, E, F, -}; no record when
+// nothing is uniform.
+template <class M, unsigned UM> struct PipeRec {
+    static constexpr int NCO = M::NC - 1;                                    // coefficient streams (the forcing is last)
+    static constexpr int NUNI = __builtin_popcount(UM & ((1u << NCO) - 1u));
+    static constexpr bool HOIST = M::template hoist<UM>();
+    static constexpr int NW = NUNI + (HOIST ? 2 : 0);
+    static constexpr int RW = NW == 0 ? 0 : (NW <= 4 ? 4 : 8);
+};
+
 struct RowFactorArgs {
-    const double *c[5];           // the x-uniform coefficient arrays in FusedArgs order (std: A, C; gen: A, C, D, E, F)
+    const double *c[5];           // the coefficient streams in FusedArgs order (std: A, C; gen: A, C, D, E, F)
     int64_t sc[5];                // batch strides (0 = shared)
     int64_t yc, xc;
-    int gen;
+    int gen;                      // 0: standard form, 1: general form
+    unsigned um;                  // which streams are per-row values
+    int hoist, rw;                // record carries rq / rok; doubles per record
     XinvScal sc_;
-    double *rowf;                 // [nbatch][yc][PIPE_RW]
+    double *rowf;                 // [nbatch][yc][rw]
 };
 
 #ifdef XINV_AUX_KERNELS
-// once per solve: per-row relaxation factor and row part of the update predicate (numbas.py:343-369 /
-// 1125-1153 with the coefficients constant along x; FusedStd2D::derive / FusedGen2D::derive, hoisted branch:
-// same expressions, same bits)
+// once per solve: the per-row records (numbas.py:343-369 / 1125-1153 with the coefficients constant along x;
+// FusedStd2D::derive / FusedGen2D::derive, hoisted branch: same expressions, same bits)
 __global__ __launch_bounds__(256) void k_row_factor(RowFactorArgs a)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (j >= a.yc) return;
     const double u = a.sc_.undef;
     const bool inner = (j >= 1 && j <= a.yc - 2);
-    if (!a.gen) {
-        double *f = a.rowf + (m * a.yc + j) * FusedStd2D::PIPE_RW;
-        const double a0 = a.c[0][m * a.sc[0] + j * a.xc], c = a.c[1][m * a.sc[1] + j * a.xc];
-        double rq = 0.0, rok = 0.0;
-        if (inner) {
-            const double aP = a.c[0][m * a.sc[0] + (j + 1) * a.xc];
-            rq = a.sc_.optArg / ((aP + a0) * a.sc_.ratioSqr + (c + c));
-            rok = ((aP != u) && (a0 != u) && (c != u)) ? 1.0 : 0.0;
-        }
-        f[0] = a0; f[1] = c; f[2] = rq; f[3] = rok;
-    } else {
-        double *f = a.rowf + (m * a.yc + j) * FusedGen2D::PIPE_RW;
-        double v[5];
-#pragma unroll
-        for (int q = 0; q < 5; q++) v[q] = a.c[q][m * a.sc[q] + j * a.xc];
-        const double A = v[0], C = v[1], F = v[4];
-        double rq = 0.0, rok = 0.0;
-        if (inner) {
-            rq = a.sc_.optArg / ((A * a.sc_.ratioSqr + C) * 2.0
-                                 - F * a.sc_.delxSqr);
-            rok = ((A != u) && (C != u) && (F != u) && (v[2] != u) && (v[3] != u)) ? 1.0 : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 5; q++) f[q] = v[q];
-        f[5] = rq; f[6] = rok; f[7] = 0.0;
+    const int nco = a.gen ? 5 : 2;
+    double *f = a.rowf + (m * a.yc + j) * a.rw;
+    double v[5];
+    int k = 0;
+    bool def = true;
+    for (int q = 0; q < nco; q++) {
+        v[q] = 0.0;
+        if ((a.um >> q) & 1u) { v[q] = a.c[q][m * a.sc[q] + j * a.xc]; f[k++] = v[q]; def = def && (v[q] != u); }
     }
+    if (a.hoist) {
+        double rq = 0.0, rok = 0.0;
+        if (inner) {
+            if (!a.gen) {
+                const double aP = a.c[0][m * a.sc[0] + (j + 1) * a.xc], a0 = v[0], c = v[1];
+                rq = a.sc_.optArg / ((aP + a0) * a.sc_.ratioSqr + (c + c));
+                rok = (def && (aP != u)) ? 1.0 : 0.0;
+            } else {
+                const double A = v[0], C = v[1], F = v[4];
+                rq = a.sc_.optArg / ((A * a.sc_.ratioSqr + C) * 2.0
+                                     - F * a.sc_.delxSqr);
+                rok = def ? 1.0 : 0.0;
+            }
+        }
+        f[k++] = rq; f[k++] = rok;
+    }
+    for (; k < a.rw; k++) f[k] = 0.0;
 }
 #endif
 
@@ -173,17 +185,23 @@ __device__ __forceinline__ void pipe_extend_fix(double2 &edge, const double2 &in
 // rotate registers across the loop back-edge: ~80 v_mov and a full `s_waitcnt vmcnt(0)` per iteration).
 // Row arithmetic is 32-bit (scalar compares; the 64-bit ones are VALU instructions on this target) and
 // every global access is `uniform row base + 32-bit lane offset` (no per-load address arithmetic).
-template <class M, int NP, bool AL, bool EXT, int PW, int PF>
+// FR: the forcing row travels with S through the ring -- wavefront 0 reads it from HBM, the others take it out of
+// LDS instead of asking the L2 for it again.  For launches whose arrays exceed the caches (a batch of members) the
+// later wavefronts' requests, ~20 rows behind the first, had fallen out of the L2 by then: C4, 64 members: 8.3 B
+// per point-sweep measured against 6 B the variant must move (profiles/r03_pmc_*_c4.txt).
+template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT, int PW, int PF>
 __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
                                                const LaneCols (&lc)[NP], const int64_t (&st0)[NP], int lane,
-                                               double2 (*ring)[XINV_PIPE_NS][NP][XINV_WAVE], int gtot,
+                                               double2 (*ring)[XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE], int gtot,
                                                double &acc, int &cnt, int *prog, XinvCtl *ctl, int dbg_tile = 0)
 {
     constexpr int P = XINV_PIPE_P, H = 2 * P, D = 4, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     constexpr int R = PF + D;                            // row records; also the unroll period
     constexpr int PFR = M::PIPE_PFR;                     // steps the per-row record is requested ahead
-    constexpr unsigned UM = M::PIPE_UM;
-    constexpr int NC = M::NC, FQ = M::PIPE_FQ, RW = M::PIPE_RW;
+    using REC = PipeRec<M, UM>;
+    constexpr int NC = M::NC, FQ = M::NC - 1, RW = REC::RW;
+    constexpr bool HOIST = REC::HOIST;
+    constexpr int RS = FR ? 2 : 1;                       // ring entries per column pair: S (, forcing)
     static_assert(R % D == 0 && R % B == 0 && R % XINV_PIPE_NS == 0,
                   "the unroll period must keep row parity, ring slots and barriers compile-time");
     const int ycr = (int)a.yc;
@@ -191,7 +209,9 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     const double u = a.sc_.undef;
     const xinv_gcptr srcS = (xinv_gcptr)(uintptr_t)(a.src + m * a.sS);
     const xinv_gptr dstS = (xinv_gptr)(uintptr_t)(a.dst + m * a.sS);
-    const xinv_gcptr cF = (xinv_gcptr)(uintptr_t)(a.c[FQ] + m * a.sc[FQ]);
+    xinv_gcptr cq[NC];                                   // vector streams (x-uniform ones come through the record)
+#pragma unroll
+    for (int q = 0; q < NC; q++) cq[q] = (xinv_gcptr)(uintptr_t)(a.c[q] + m * a.sc[q]);
     const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(reinterpret_cast<const double *>(a.rowf) + m * a.yc * RW);
     unsigned lo0[NP], lo1[NP], so0[NP], so1[NP];         // byte offsets of the lane's columns (loads / owned stores)
 #pragma unroll
@@ -240,18 +260,29 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         xinv_unroll_steps([&](auto qtag) {
             constexpr int q = decltype(qtag)::value;
             if (PW == 0) sw[q][slot] = ldrow(srcS, boff, qtag);
-            cw[q].v[FQ][slot] = ldrow(cF, boff, qtag);
+            xinv_unroll_steps([&](auto ctag) {
+                constexpr int c = decltype(ctag)::value;
+                if (!((UM >> c) & 1u) && !(FR && c == FQ && PW > 0)) cw[q].v[c][slot] = ldrow(cq[c], boff, qtag);
+            }, std::make_integer_sequence<int, NC>{});
         }, std::make_integer_sequence<int, NP>{});
     };
     auto request_rf = [&](int r, auto stag) {
         constexpr int slot = decltype(stag)::value;
         const unsigned rr = (unsigned)min(max(r, 0), ycr - 1);    // (rows 0 and yc-1 carry rok = 0: so do the clamped ones)
-        const xinv_cdouble_ptr pr = rowf + (uint64_t)rr * (unsigned)RW;
-        double rec[RW];
+        if constexpr (RW > 0) {
+            const xinv_cdouble_ptr pr = rowf + (uint64_t)rr * (unsigned)RW;
+            double rec[RW];
 #pragma unroll
-        for (int k = 0; k < RW; k++) rec[k] = pr[k];
+            for (int k = 0; k < RW; k++) rec[k] = pr[k];
 #pragma unroll
-        for (int q = 0; q < NP; q++) M::template pipe_row<R>(cw[q], slot, rec, rokw[slot]);
+            for (int q = 0; q < NP; q++) {
+                int k = 0;
+#pragma unroll
+                for (int c = 0; c < NC - 1; c++)
+                    if ((UM >> c) & 1u) cw[q].s[c][slot] = rec[k++];
+                if (HOIST) { cw[q].rq[slot] = rec[k]; rokw[slot] = rec[k + 1]; }
+            }
+        }
     };
     // (in row order, as in the loop: the vmcnt waits of the loop are computed against the worst path into it)
     xinv_unroll_steps([&](auto ttag) { request(in_lo + decltype(ttag)::value, ttag); asm volatile("" ::: "memory"); },
@@ -277,7 +308,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
             double w, e;
             if (X == 0) { w = (q == 0) ? edge : sw[q > 0 ? q - 1 : 0][sj].y; e = sw[q][sj].y; }
             else        { w = sw[q][sj].x; e = (q == NP - 1) ? edge : sw[q < NP - 1 ? q + 1 : q][sj].x; }
-            nv[q] = M::template upd<X, UM, R>(cw[q], sj, sjp, comp<X>(sw[q][sj]), comp<X>(sw[q][sjp]),
+            nv[q] = M::template upd<X, UM, R, false>(cw[q], sj, sjp, comp<X>(sw[q][sj]), comp<X>(sw[q][sjp]),
                                               comp<X>(sw[q][sjm]), w, e, a.sc_);
         }
 #pragma unroll
@@ -317,7 +348,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #endif
         wait_ge(prog + 2 * (PW - 1), seen_prod, min(5 + XINV_PIPE_SLACK, n_prod));   // row in_lo is the predecessor's 5th
 #pragma unroll
-        for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % NS][q][lane];
+        for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % NS][q * RS][lane];
     }
     (void)gtot;
 #else
@@ -335,7 +366,10 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     for (; g < LAG * PW; g++) {
         if (PW > 0 && g == LAG * PW - 1) {
 #pragma unroll
-            for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][q][lane];      // row in_lo
+            for (int q = 0; q < NP; q++) {
+                sw[q][0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][q * RS][lane];      // row in_lo
+                if (FR) cw[q].v[FQ][0] = ring[PW - 1][(2 * PW) % XINV_PIPE_NS][q * RS + 1][lane];
+            }
         }
         if ((g + 1) % B == 0) xinv_pipe_barrier();
     }
@@ -362,7 +396,10 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #if !XINV_PIPE_FLAGS
             if (PW > 0) {
 #pragma unroll
-                for (int q = 0; q < NP; q++) sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q][lane];   // row r+1: written B+1 steps ago
+                for (int q = 0; q < NP; q++) {
+                    sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q * RS][lane];   // row r+1: written B+1 steps ago
+                    if (FR) cw[q].v[FQ][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q * RS + 1][lane];
+                }
 #ifdef XINV_PIPE_DEBUG
                 if (dbgp && r - in_lo < 3) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -372,7 +409,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #endif
             }
 #endif
-            {   // row r-1: update predicate and F * delxSqr, once for both half-sweeps
+            if constexpr (HOIST) {   // row r-1: update predicate and F * delxSqr, once for both half-sweeps
                 constexpr int s1 = SLOT(1);
                 const bool rok = rokw[s1] != 0.0;
 #pragma unroll
@@ -380,8 +417,12 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                     const double fx = cw[q].v[FQ][s1].x, fy = cw[q].v[FQ][s1].y;
                     cw[q].mx[s1] = xinv_lane_word(lc[q].ok_x && rok && (fx != u));
                     cw[q].my[s1] = xinv_lane_word(lc[q].ok_y && rok && (fy != u));
-                    if (M::PIPE_PREMUL) { cw[q].v[FQ][s1].x = fx * a.sc_.delxSqr; cw[q].v[FQ][s1].y = fy * a.sc_.delxSqr; }
                 }
+            } else {                 // coefficient arrays that vary along x: the model's own predicate (and F * delxSqr)
+                const bool rv = (r - 1 >= 1) && (r - 1 <= ycr - 2);
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+                    M::template derive<UM, R, false>(cw[q], SLOT(0), SLOT(1), rv && lc[q].ok_x, rv && lc[q].ok_y, a.sc_);
             }
             {   // red half-sweep on row r-1
                 const int ja = r - 1;
@@ -404,7 +445,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 const int j = r - in_lo;
                 wait_ge(prog + 2 * (PW - 1), seen_prod, min(j + 6, n_prod));
 #pragma unroll
-                for (int q = 0; q < NP; q++) sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q][lane];
+                for (int q = 0; q < NP; q++) sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q * RS][lane];
             }
 #endif
             {   // black half-sweep on row r-2
@@ -430,7 +471,10 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                         wait_ge(prog + 2 * (PW + 1) + 1, seen_cons, min(j - NS - 3, n_cons));
 #endif
 #pragma unroll
-                    for (int q = 0; q < NP; q++) ring[PW][RSLOT(2)][q][lane] = sw[q][sj];
+                    for (int q = 0; q < NP; q++) {
+                        ring[PW][RSLOT(2)][q * RS][lane] = sw[q][sj];
+                        if (FR) ring[PW][RSLOT(2)][q * RS + 1][lane] = cw[q].v[FQ][sj];
+                    }
 #if XINV_PIPE_FLAGS
                     asm volatile("" ::: "memory");
                     __hip_atomic_store(prog + 2 * PW, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -475,7 +519,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #endif
 }
 
-template <class M, int NP, bool AL, bool EXT>
+template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT>
 __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 {
 #ifndef XINV_PIPE_INV
@@ -485,7 +529,7 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
     xinv_fresh_scalar_cache();
 #endif
     constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = XINV_PIPE_UW(NP), LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
-    __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP][XINV_WAVE];
+    __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE];
     __shared__ int prog[2 * P];                          // hand-over progress counters (XINV_PIPE_FLAGS)
 
     unsigned tag;
@@ -557,10 +601,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         }
         gtot = ((gtot + B - 1) / B) * B;
         switch (pwi) {
-        case 0: xinv_pipe_wave<M, NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        case 1: xinv_pipe_wave<M, NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        case 2: xinv_pipe_wave<M, NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        default: xinv_pipe_wave<M, NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
         }
     }
     }
