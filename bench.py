@@ -564,6 +564,14 @@ def main():
                 'sweeps_per_launch': sh['sweeps_per_launch'], 'xuniform_mask': sh['xuniform_mask'],
                 'masked_tile_pct': sh['masked_tile_pct'], 'parity_bitwise_10_sweeps': hpar['bitwise'] and hpar['loop_equal'],
                 'traffic': None}
+            try:                                             # PMC bytes per launch of this very variant (8 members), static
+                ht = json.load(open(tfile)).get('std2d_spl1_um0_all')
+                if ht and (a.ny, a.nx) == (1800, 3600) and ht > 1.5e9:
+                    out['roofline_hbm'].update({'traffic': ht, 'traffic_GBps': ht / (h_avg * 1e-3) / 1e9,
+                                                'traffic_frac_of_hbm_peak': ht / (h_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                'traffic_source': roof['traffic_source']})
+            except Exception:
+                pass
             del hb
 
         if a.config == 'c2' and single and not a.no_parity:

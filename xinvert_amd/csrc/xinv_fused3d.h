@@ -252,13 +252,19 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         // start a multiple of D planes below k0 - 2 (slot indices are compile-time), run until the
         // black half-sweep of plane k1 - 1 (step k1 + 1)
         const int64_t rstart = (k0 >= D) ? k0 - D : 0;
-        Pack p0 = load(rstart), p1 = load(rstart + 1);
+#ifndef XINV_3D_PF
+#define XINV_3D_PF 2              /* planes in flight per wavefront (2 or 4: divides the window depth) */
+#endif
+        constexpr int PF = XINV_3D_PF;
+        Pack pf[PF];
+#pragma unroll
+        for (int t = 0; t < PF; t++) pf[t] = load(rstart + t);
         const int64_t rlast = k1 - 1 + 2;
         for (int64_t rb_ = rstart; rb_ <= rlast; rb_ += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
-                if (U & 1) { step(rb_ + U, p1, utag, jtag); p1 = load(rb_ + U + 2); }
-                else       { step(rb_ + U, p0, utag, jtag); p0 = load(rb_ + U + 2); }
+                step(rb_ + U, pf[U % PF], utag, jtag);
+                pf[U % PF] = load(rb_ + U + PF);
             }, std::make_integer_sequence<int, D>{});
         }
     };
