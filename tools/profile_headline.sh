@@ -18,7 +18,7 @@ python $R/tools/prof_summary.py counters $(db /tmp/p_w) $out/${tag}_pmc_write_c2
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d /tmp/p_s -o r -- $cmd > /dev/null 2>&1
 python $R/tools/prof_summary.py counters $(db /tmp/p_s) $out/${tag}_pmc_sq_issue_c2.txt
 cp $R/profiles/traffic.json $out/traffic.json 2>/dev/null
-python $R/tools/prof_summary.py traffic $(db /tmp/p_f) $(db /tmp/p_w) "k_pipe2d<FusedStd2D, 1" std2d_pipe_um3 $out/traffic.json
+python $R/tools/prof_summary.py traffic $(db /tmp/p_f) $(db /tmp/p_w) "k_pipe2d<FusedStd2D, 3u, false, 1" std2d_pipe_um3 $out/traffic.json
 XINV_PIPE=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f0 -o r -- $cmd --no-hbm > /dev/null 2>&1
 XINV_PIPE=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w0 -o r -- $cmd --no-hbm > /dev/null 2>&1
 python $R/tools/prof_summary.py traffic $(db /tmp/p_f0) $(db /tmp/p_w0) "k_fused2d<FusedStd2D, 4" std2d_spl4_um3 $out/traffic.json
@@ -32,7 +32,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f4 -o r -- $c4 > /dev/null 2
 python $R/tools/prof_summary.py counters $(db /tmp/p_f4) $out/${tag}_pmc_fetch_c4.txt > /dev/null
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w4 -o r -- $c4 > /dev/null 2>&1
 python $R/tools/prof_summary.py counters $(db /tmp/p_w4) $out/${tag}_pmc_write_c4.txt > /dev/null
-python $R/tools/prof_summary.py traffic $(db /tmp/p_f4) $(db /tmp/p_w4) "k_pipe2d<FusedGen2D, 1" gen2d_pipe_um31_c4x64 $out/traffic.json
+python $R/tools/prof_summary.py traffic $(db /tmp/p_f4) $(db /tmp/p_w4) "k_pipe2d<FusedGen2D, 31u, true, 1" gen2d_pipe_um31_fr_c4x64 $out/traffic.json
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d /tmp/p_s4 -o r -- $c4 > /dev/null 2>&1
 python $R/tools/prof_summary.py counters $(db /tmp/p_s4) $out/${tag}_pmc_sq_issue_c4.txt > /dev/null
 # the HBM leg of bench.py (8 members with their own A, C, F: 2 GB): its kernel has grid_y = 8
