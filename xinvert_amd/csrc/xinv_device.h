@@ -187,6 +187,46 @@ __device__ __forceinline__ double xinv_lane_down(double v)     // lane i <- lane
     return __hiloint2double(hi, lo);
 }
 
+// a + b in the lanes of `mask`, a in the others: the add runs with the mask as EXEC -- two scalar instructions around one
+// vector instruction, where `cond ? a + b : a` costs the add and two v_cndmask_b32 on a unit that is the bound of
+// the pipelined pass (the same bits: a masked lane keeps a).  (+|b| for the norm share: a lane that does not count
+// adds nothing instead of +0.0 -- the accumulator is a sum of magnitudes, never -0.0, so the same bits again.)
+__device__ __forceinline__ double xinv_add_where(double a, double b, unsigned long long mask)
+{
+    unsigned long long sv;
+    asm("s_and_saveexec_b64 %1, %3\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, %1"
+        : "+v"(a), "=&s"(sv) : "v"(b), "s"(mask) : "scc");
+    return a;
+}
+__device__ __forceinline__ double xinv_add_abs_where(double a, double b, unsigned long long mask)
+{
+    unsigned long long sv;
+    asm("s_and_saveexec_b64 %1, %3\n\tv_add_f64 %0, %0, |%2|\n\ts_mov_b64 exec, %1"
+        : "+v"(a), "=&s"(sv) : "v"(b), "s"(mask) : "scc");
+    return a;
+}
+
+// The same with the compare folded in: a + b in the lanes of `rowmask` whose f differs from u (the reference's
+// `F[j,i] != undef` of the update predicate), a in the others -- v_cmpx writes the compare's result into EXEC, so
+// the predicate costs no scalar logic at all: s_and_saveexec, v_cmpx, v_add, s_mov.
+__device__ __forceinline__ double xinv_add_where_ne(double a, double b, double f, double u, unsigned long long rowmask)
+{
+    unsigned long long sv;
+    asm("s_and_saveexec_b64 %1, %5\n\tv_cmpx_neq_f64_e32 vcc, %4, %3\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, %1"
+        : "+v"(a), "=&s"(sv) : "v"(b), "v"(f), "s"(u), "s"(rowmask) : "scc", "vcc");
+    return a;
+}
+// a row's share of mean|S|: sum += |x| and n += 1 in the lanes whose x differs from u, for both columns of the lane
+// (per-lane accumulators; the caller discards the lanes that do not own their column).  Nine instructions.
+__device__ __forceinline__ void xinv_norm_row(double &sx, double &sy, int &nx, int &ny, double x, double y, double u)
+{
+    unsigned long long sv;
+    asm("s_mov_b64 %4, exec\n\t"
+        "v_cmpx_neq_f64_e32 vcc, %7, %5\n\tv_add_f64 %0, %0, |%5|\n\tv_add_u32 %2, %2, 1\n\ts_mov_b64 exec, %4\n\t"
+        "v_cmpx_neq_f64_e32 vcc, %7, %6\n\tv_add_f64 %1, %1, |%6|\n\tv_add_u32 %3, %3, 1\n\ts_mov_b64 exec, %4"
+        : "+v"(sx), "+v"(sy), "+v"(nx), "+v"(ny), "=&s"(sv) : "v"(x), "v"(y), "s"(u) : "vcc");
+}
+
 // Scalars of one solve (same for every member), passed by value to the kernels.
 struct XinvScal {
     double delx, delxSqr, ratio, ratioQtr, ratioSqr;   // 2-D

@@ -206,9 +206,10 @@ struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
         }
     }
 
-    // sj = slot of row j, sjp = slot of row j+1.
+    // sj = slot of row j, sjp = slot of row j+1.  inc: the increment of the point (numbas.py:350-369 without the
+    // final `S[j,i] += temp`); upd: the point's new value, or the old one where the predicate fails.
     template <int X, unsigned UM, int D, bool PRE = true>
-    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+    static __device__ __forceinline__ double inc(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
                                                  double sP, double sM, double sW, double sE,
                                                  const XinvScal &sc)
     {
@@ -232,6 +233,14 @@ struct FusedStd2D {                 // numbas.invert_standard_2D, B == 0
         ) - fd;
         if (hoist<UM>()) temp *= w.rq[sj];
         else             temp *= sc.optArg / ((aP + a0) * sc.ratioSqr + (cE + c0));
+        return temp;
+    }
+    template <int X, unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 const XinvScal &sc)
+    {
+        const double temp = inc<X, UM, D, PRE>(w, sj, sjp, sC, sP, sM, sW, sE, sc);
         return xinv_bitsel(X ? w.my[sj] : w.mx[sj], sC + temp, sC);
     }
 };
@@ -328,7 +337,7 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     }
 
     template <int X, unsigned UM, int D, bool PRE = true>
-    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int, double sC,
+    static __device__ __forceinline__ double inc(const CoefWin<NC, D> &w, int sj, int, double sC,
                                                  double sP, double sM, double sW, double sE,
                                                  const XinvScal &sc)
     {
@@ -353,6 +362,14 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
         if (hoist<UM>()) temp *= w.rq[sj];
         else             temp *= sc.optArg / ((A * sc.ratioSqr + C) * 2.0
                                               - F * sc.delxSqr);
+        return temp;
+    }
+    template <int X, unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 const XinvScal &sc)
+    {
+        const double temp = inc<X, UM, D, PRE>(w, sj, sjp, sC, sP, sM, sW, sE, sc);
         return xinv_bitsel(X ? w.my[sj] : w.mx[sj], sC + temp, sC);
     }
 };

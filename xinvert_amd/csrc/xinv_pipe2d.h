@@ -31,6 +31,10 @@
 #include "xinv_fused.h"
 
 #define XINV_PIPE_P 4             /* wavefronts per workgroup = sweeps per pass */
+#ifndef XINV_PIPE_EXECSEL
+#define XINV_PIPE_EXECSEL 1       /* the update and the norm share add under a lane mask in EXEC instead of selecting
+                                     (xinv_add_where): 5-6 of ~29 VALU instructions per point update less */
+#endif
 #ifndef XINV_PIPE_FLAGS
 #define XINV_PIPE_FLAGS 0         /* 0: one workgroup barrier every XINV_PIPE_B steps (kept);
                                      1: hand-over by progress counters in LDS, no barrier in the march, the successor
@@ -66,7 +70,7 @@
 // What a row needs besides S and the vector streams: one record per row, read through the scalar unit --
 // the values of the coefficient streams that are constant along x (bit q of UM), in stream order, then, when the
 // model's denominator is x-uniform (M::hoist<UM>()), the row's relaxation factor and the row part of the update
-// predicate (1.0 / 0.0: all 64 bits are read, so no half of a load in flight is ever reused).  Padded to 4 or 8
+// predicate (all ones / zero: all 64 bits are read, so no half of a load in flight is ever reused).  Padded to 4 or 8
 // doubles.  Standard form, A and C per row: {A[j], C[j], rq, rok}; general form, A C D E F per row:
 // {A, C, D, E, F, rq, rok, -}; general form, D E F per row (A, C, G streamed): {D, E, F, -}; no record when
 // nothing is uniform.
@@ -99,6 +103,9 @@ __global__ __launch_bounds__(256) void k_row_factor(RowFactorArgs a)
     const double u = a.sc_.undef;
     const bool inner = (j >= 1 && j <= a.yc - 2);
     const int nco = a.gen ? 5 : 2;
+    // the row predicate as a 64-bit word, all ones or zero: the kernel ANDs it into its lane masks (one s_and_b64;
+    // as a double the all-ones pattern is a NaN, which also compares != 0.0)
+    const double ones = __longlong_as_double(-1LL);
     double *f = a.rowf + (m * a.yc + j) * a.rw;
     double v[5];
     int k = 0;
@@ -113,12 +120,12 @@ __global__ __launch_bounds__(256) void k_row_factor(RowFactorArgs a)
             if (!a.gen) {
                 const double aP = a.c[0][m * a.sc[0] + (j + 1) * a.xc], a0 = v[0], c = v[1];
                 rq = a.sc_.optArg / ((aP + a0) * a.sc_.ratioSqr + (c + c));
-                rok = (def && (aP != u)) ? 1.0 : 0.0;
+                rok = (def && (aP != u)) ? ones : 0.0;
             } else {
                 const double A = v[0], C = v[1], F = v[4];
                 rq = a.sc_.optArg / ((A * a.sc_.ratioSqr + C) * 2.0
                                      - F * a.sc_.delxSqr);
-                rok = def ? 1.0 : 0.0;
+                rok = def ? ones : 0.0;
             }
         }
         f[k++] = rq; f[k++] = rok;
@@ -221,6 +228,17 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         so1[q] = lc[q].use_y ? (unsigned)(st0[q] + 1) * 8u : 0u;
     }
 
+#if XINV_PIPE_EXECSEL
+    unsigned long long okx64[NP], oky64[NP];             // "column may be updated" as 64-bit lane masks (SGPR pairs)
+    double nsx[NP], nsy[NP];                             // norm share per lane and column
+    int nnx[NP], nny[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        okx64[q] = __builtin_amdgcn_ballot_w64(lc[q].ok_x); oky64[q] = __builtin_amdgcn_ballot_w64(lc[q].ok_y);
+        nsx[q] = nsy[q] = 0.0; nnx[q] = nny[q] = 0;
+    }
+#endif
+
     const int in_lo = yu0 - H + 2 * PW;                  // first / last row entering this wavefront's window
     const int in_hi = yu1 - 1 + H - 2 * PW;
 
@@ -239,11 +257,23 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         }
     }
 
+    // request row r into record `slot` (S from HBM for wavefront 0 only; later wavefronts get it through LDS).
+    // Rows are requested in order, so every stream keeps the address of its NEXT row (clamped to [0, yc-1], as the
+    // rows of a tile at the top or bottom of the slice are) in an SGPR pair and moves it on by one row or not at
+    // all: a compare, a select and an add with carry per stream instead of clamp, 64-bit multiply and add per row.
+    xinv_gcptr nxS = srcS, nxC[NC];
+    xinv_cdouble_ptr nxR = rowf;
+    {
+        const uint64_t b0 = (uint64_t)(unsigned)min(max(yu0 - H + 2 * PW, 0), ycr - 1) * rowbytes;
+        nxS += b0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) nxC[c] = cq[c] + b0;
+        nxR += (uint64_t)(unsigned)min(max(yu0 - H + 2 * PW, 0), ycr - 1) * (unsigned)RW;
+    }
     // a row of one of the lane's column pairs: uniform row address (kept in SGPRs: the asm pins it, so that
     // the access is `global_load v, v_lane_offset, s[row]` and not a 64-bit vector address computed per load)
-    auto ldrow = [&](xinv_gcptr base, uint64_t boff, auto qtag) {
+    auto ldrow = [&](xinv_gcptr row, auto qtag) {
         constexpr int q = decltype(qtag)::value;
-        xinv_gcptr row = base + boff;
         asm("" : "+s"(row));
         asm("" : "+v"(lo0[q]));                          // (laundered in place, so that the zero-extension stays in this
         if (!AL) asm("" : "+v"(lo1[q]));                 //  block: instruction selection then sees sgpr + zext(vgpr32))
@@ -252,25 +282,29 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         else { v.x = *(xinv_gcdptr)(row + lo0[q]); v.y = *(xinv_gcdptr)(row + lo1[q]); }
         return v;
     };
-    // request row r into record `slot` (S from HBM for wavefront 0 only; later wavefronts get it through LDS)
     auto request = [&](int r, auto stag) {
         constexpr int slot = decltype(stag)::value;
-        const unsigned rr = (unsigned)min(max(r, 0), ycr - 1);
-        const uint64_t boff = (uint64_t)rr * rowbytes;
         xinv_unroll_steps([&](auto qtag) {
             constexpr int q = decltype(qtag)::value;
-            if (PW == 0) sw[q][slot] = ldrow(srcS, boff, qtag);
+            if (PW == 0) sw[q][slot] = ldrow(nxS, qtag);
             xinv_unroll_steps([&](auto ctag) {
                 constexpr int c = decltype(ctag)::value;
-                if (!((UM >> c) & 1u) && !(FR && c == FQ && PW > 0)) cw[q].v[c][slot] = ldrow(cq[c], boff, qtag);
+                if (!((UM >> c) & 1u) && !(FR && c == FQ && PW > 0)) cw[q].v[c][slot] = ldrow(nxC[c], qtag);
             }, std::make_integer_sequence<int, NC>{});
         }, std::make_integer_sequence<int, NP>{});
+        unsigned adv = ((unsigned)r < (unsigned)(ycr - 1)) ? rowbytes : 0u;            // row r+1 lies in [1, yc-1]
+        asm("" : "+s"(adv));                             // (a 32-bit select, then add with carry: not a 64-bit select)
+        if (PW == 0) nxS += adv;
+        xinv_unroll_steps([&](auto ctag) {
+            constexpr int c = decltype(ctag)::value;
+            if (!((UM >> c) & 1u) && !(FR && c == FQ && PW > 0)) nxC[c] += adv;
+        }, std::make_integer_sequence<int, NC>{});
     };
     auto request_rf = [&](int r, auto stag) {
         constexpr int slot = decltype(stag)::value;
-        const unsigned rr = (unsigned)min(max(r, 0), ycr - 1);    // (rows 0 and yc-1 carry rok = 0: so do the clamped ones)
-        if constexpr (RW > 0) {
-            const xinv_cdouble_ptr pr = rowf + (uint64_t)rr * (unsigned)RW;
+        if constexpr (RW > 0) {                          // (rows 0 and yc-1 carry rok = 0: so do the clamped ones)
+            const xinv_cdouble_ptr pr = nxR;
+            nxR += ((unsigned)r < (unsigned)(ycr - 1)) ? (unsigned)RW : 0u;
             double rec[RW];
 #pragma unroll
             for (int k = 0; k < RW; k++) rec[k] = pr[k];
@@ -308,8 +342,24 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
             double w, e;
             if (X == 0) { w = (q == 0) ? edge : sw[q > 0 ? q - 1 : 0][sj].y; e = sw[q][sj].y; }
             else        { w = sw[q][sj].x; e = (q == NP - 1) ? edge : sw[q < NP - 1 ? q + 1 : q][sj].x; }
+#if XINV_PIPE_EXECSEL
+            // the increment, added under the update predicate as EXEC (xinv_add_where: no select on the VALU)
+            const double t = M::template inc<X, UM, R, false>(cw[q], sj, sjp, comp<X>(sw[q][sj]), comp<X>(sw[q][sjp]),
+                                              comp<X>(sw[q][sjm]), w, e, a.sc_);
+            if constexpr (HOIST) {
+                // the predicate: (column may be updated) & (row may be updated: the record's predicate word is all
+                // ones or zero, k_row_factor) as a 64-bit lane mask on the scalar unit, (forcing defined) by the
+                // compare that writes EXEC
+                const unsigned long long rm = (X ? oky64[q] : okx64[q]) & (unsigned long long)__double_as_longlong(rokw[sj]);
+                nv[q] = xinv_add_where_ne(comp<X>(sw[q][sj]), t, comp<X>(cw[q].v[FQ][sj]), u, rm);
+            } else {
+                const unsigned long long pm = __builtin_amdgcn_ballot_w64((X ? cw[q].my[sj] : cw[q].mx[sj]) != 0u);
+                nv[q] = xinv_add_where(comp<X>(sw[q][sj]), t, pm);
+            }
+#else
             nv[q] = M::template upd<X, UM, R, false>(cw[q], sj, sjp, comp<X>(sw[q][sj]), comp<X>(sw[q][sjp]),
                                               comp<X>(sw[q][sjm]), w, e, a.sc_);
+#endif
         }
 #pragma unroll
         for (int q = 0; q < NP; q++) setc<X>(sw[q][sj], nv[q]);
@@ -391,6 +441,16 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #if XINV_PIPE_DRAIN & 2
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
+#if defined(XINV_PIPE_PAD_SALU)       /* timing experiments only: what does an extra scalar / vector instruction per step cost? */
+            { int t_ = r;
+#pragma unroll
+              for (int k_ = 0; k_ < XINV_PIPE_PAD_SALU; k_++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(t_) :: "scc"); }
+#endif
+#if defined(XINV_PIPE_PAD_VALU)
+            { int t_ = lane;
+#pragma unroll
+              for (int k_ = 0; k_ < XINV_PIPE_PAD_VALU; k_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(t_)); }
+#endif
             request(r + PF, ITAG((U + PF) % R));
             request_rf(r + PFR, ITAG((U + PFR) % R));
 #if !XINV_PIPE_FLAGS
@@ -409,7 +469,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #endif
             }
 #endif
-            if constexpr (HOIST) {   // row r-1: update predicate and F * delxSqr, once for both half-sweeps
+            if constexpr (HOIST && !XINV_PIPE_EXECSEL) {   // row r-1: update predicate, once for both half-sweeps
                 constexpr int s1 = SLOT(1);
                 const bool rok = rokw[s1] != 0.0;
 #pragma unroll
@@ -418,7 +478,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                     cw[q].mx[s1] = xinv_lane_word(lc[q].ok_x && rok && (fx != u));
                     cw[q].my[s1] = xinv_lane_word(lc[q].ok_y && rok && (fy != u));
                 }
-            } else {                 // coefficient arrays that vary along x: the model's own predicate (and F * delxSqr)
+            } else if constexpr (!HOIST) {   // coefficient arrays that vary along x: the model's own predicate
                 const bool rv = (r - 1 >= 1) && (r - 1 <= ycr - 2);
 #pragma unroll
                 for (int q = 0; q < NP; q++)
@@ -452,15 +512,21 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 const int jb = r - 2;
                 constexpr int sj = SLOT(2), sjp = SLOT(1), sjm = SLOT(3);
                 half_sweep(ITAG(X), ITAG(sj), ITAG(sjp), ITAG(sjm));
-                if ((jb >= yu0) && (jb < yu1)) {           // an owned row: its share of mean|S| of this sweep
+                if ((unsigned)(jb - yu0) < (unsigned)(yu1 - yu0)) {   // an owned row: its share of mean|S| of this sweep
 #pragma unroll
                     for (int q = 0; q < NP; q++) {
                         const double2 t = sw[q][sj];
+#if XINV_PIPE_EXECSEL
+                        // magnitudes and samples per lane and column under `S != undef` as EXEC; the lanes that
+                        // do not own their column are discarded after the march
+                        xinv_norm_row(nsx[q], nsy[q], nnx[q], nny[q], t.x, t.y, u);
+#else
                         const bool cx = lc[q].use_x & (t.x != u);
                         const bool cy = lc[q].use_y & (t.y != u);
                         acc += (cx ? fabs(t.x) : 0.0);
                         acc += (cy ? fabs(t.y) : 0.0);
                         cnt += (cx ? 1 : 0) + (cy ? 1 : 0);
+#endif
                     }
                 }
                 // ---- row r-2 leaves
@@ -479,7 +545,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                     asm volatile("" ::: "memory");
                     __hip_atomic_store(prog + 2 * PW, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-                } else if (jb >= yu0 && jb < yu1) {
+                } else if ((unsigned)(jb - yu0) < (unsigned)(yu1 - yu0)) {
                     xinv_gptr row = dstS + (uint64_t)(unsigned)jb * rowbytes;
                     asm("" : "+s"(row));
                     xinv_unroll_steps([&](auto qtag) {
@@ -516,6 +582,14 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     if (timed_out && lane == 0) { ctl->overflow = 2; ctl->done = 1; ctl->sweeps = ctl->loop + 1; }
 #else
     for (; g < gtot; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
+#endif
+#if XINV_PIPE_EXECSEL
+#pragma unroll
+    for (int q = 0; q < NP; q++) {                       // only the columns this lane owns count
+        acc += (lc[q].use_x ? nsx[q] : 0.0);
+        acc += (lc[q].use_y ? nsy[q] : 0.0);
+        cnt += (lc[q].use_x ? nnx[q] : 0) + (lc[q].use_y ? nny[q] : 0);
+    }
 #endif
 }
 
