@@ -40,6 +40,8 @@ struct Fused3Args {
     XinvCtl *ctl;
     XinvStop stop;
     unsigned long long *psum;  // [nbatch][NB]
+    const double *rowf;        // k_pipe3d: per-(plane, row) records [nb][zc][yc][8] (xinv_pipe3d.h)
+    int64_t srowf;             // member stride of the table in doubles (0: one table for the batch)
 };
 
 // 7-point update with the mask folded into a select (numbas.py:146-169).

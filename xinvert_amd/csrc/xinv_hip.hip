@@ -330,10 +330,27 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
             opt.rows_per_tile == 0 && p.stop.mxLoop >= 1) {
             pl.K2 = true;
             pl.K = 2;
-            pl.nw2 = 8;
-            if (const char *e = getenv("XINV_3D2_NW")) pl.nw2 = (atoi(e) == 12) ? 12 : 8;
+            // 16: k_pipe3d (two groups of eight wavefronts, one sweep each, xinv_pipe3d.h); 8 / 12: k_fused3d2
+            pl.nw2 = 16;
+            if (const char *e = getenv("XINV_3D2_NW")) { const int v = atoi(e); pl.nw2 = (v == 12 || v == 8) ? v : 16; }
+            if (p.zc * p.yc * 64 >= ((int64_t)1 << 31)) pl.nw2 = 8;       // (k_pipe3d: 32-bit offsets into its record table)
             pl.nsg2 = (int)cdiv(p.xc, 120);
-            pl.nrb2 = (int)cdiv(p.yc, 2 * pl.nw2 - 8);
+            pl.nrb2 = (int)cdiv(p.yc, pl.nw2 == 16 ? 8 * XINV_P3_RR - 8 : 2 * pl.nw2 - 8);
+            if (pl.nw2 == 16) {
+                // per-(plane, row) records of the x-uniform coefficients, relaxation factor and predicate: once per solve
+                const bool shared = (p.sc[0] == 0 && p.sc[1] == 0 && p.sc[2] == 0);
+                const int64_t tab = p.zc * p.yc * 8;
+                rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)(shared ? 1 : p.nbatch) * tab * sizeof(double));
+                if (rc) return rc;
+                RowFactor3Args ra;
+                memset(&ra, 0, sizeof ra);
+                for (int q = 0; q < 3; q++) { ra.c[q] = p.c[q]; ra.sc[q] = p.sc[q]; }
+                ra.zc = p.zc; ra.yc = p.yc; ra.xc = p.xc; ra.sc_ = p.sc_;
+                ra.rowf = (double *)ws->d_rowf; ra.srowf = shared ? 0 : tab;
+                pl.srowf2 = ra.srowf;
+                hipLaunchKernelGGL(k_row_factor3d, dim3((unsigned)cdiv(p.zc * p.yc, 256), (unsigned)(shared ? 1 : p.nbatch), 1),
+                                   dim3(256), 0, st, ra);
+            }
             const int64_t wg1 = (int64_t)pl.nsg2 * pl.nrb2 * p.nbatch;
             int best = 1; double best_cost = 1e300;
             for (int nk = 1; nk <= 16; nk++) {
@@ -407,8 +424,10 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // against 2.35e10).  General form: k_fused2d stops at two sweeps per pass (registers) and is bound by
         // HBM at C4, so the pipelined pass is taken at every size.  XINV_PIPE=2 forces it whatever the size.
         const bool pipe_size_ok = pipe_mode == 2 || p.kind == KIND_GEN2D || p.nbatch * p.yc * p.xc <= (int64_t)10000000;
+        // (k_pipe2d addresses a slice through buffer resources with signed 32-bit row offsets: slices below 2 GiB)
         const bool pipe_want = pipe_mode != 0 && pipe_form && pipe_size_ok && !(opt.flags & XINV_FLAG_NO_PIPE) &&
-                               (opt.sweeps_per_launch == 0 || opt.sweeps_per_launch == XINV_PIPE_P);
+                               (opt.sweeps_per_launch == 0 || opt.sweeps_per_launch == XINV_PIPE_P) &&
+                               (p.yc + 16) * p.xc * 8 < ((int64_t)1 << 31);
         {
             const bool hoisted_gen = (p.kind == KIND_GEN2D && nvec <= 2);
             const int ksup = (p.kind == KIND_STD2D && nvec <= 2) ? XINV_KMAX : (hoisted_gen ? 2 : 3);

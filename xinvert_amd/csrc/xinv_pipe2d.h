@@ -214,18 +214,24 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     const int ycr = (int)a.yc;
     const unsigned rowbytes = (unsigned)a.xc * 8u;       // (a row is shorter than 4 GiB)
     const double u = a.sc_.undef;
-    const xinv_gcptr srcS = (xinv_gcptr)(uintptr_t)(a.src + m * a.sS);
-    const xinv_gptr dstS = (xinv_gptr)(uintptr_t)(a.dst + m * a.sS);
-    xinv_gcptr cq[NC];                                   // vector streams (x-uniform ones come through the record)
+    // Every array of the member is addressed through a raw buffer resource (base, size of the slice) with the ROW as
+    // the instruction's scalar offset and the lane's columns as its vector offset: `buffer_load_dwordx4 v, v_lane,
+    // s[rsrc], s_row offen` -- no address arithmetic per load, and the row offset of all streams is ONE running
+    // 32-bit value (the planner admits slices below 2 GiB).
+    const int slice_bytes = (int)(rowbytes * (unsigned)ycr);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)(a.src + m * a.sS), 0, slice_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dst + m * a.sS), 0, slice_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsC[NC];                      // vector streams (x-uniform ones come through the record)
 #pragma unroll
-    for (int q = 0; q < NC; q++) cq[q] = (xinv_gcptr)(uintptr_t)(a.c[q] + m * a.sc[q]);
+    for (int q = 0; q < NC; q++)
+        rsC[q] = __builtin_amdgcn_make_buffer_rsrc((void *)(a.c[q] + m * a.sc[q]), 0, slice_bytes, 0x00020000);
     const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(reinterpret_cast<const double *>(a.rowf) + m * a.yc * RW);
     unsigned lo0[NP], lo1[NP], so0[NP], so1[NP];         // byte offsets of the lane's columns (loads / owned stores)
 #pragma unroll
     for (int q = 0; q < NP; q++) {
         lo0[q] = (unsigned)lc[q].l0 * 8u; lo1[q] = (unsigned)lc[q].l1 * 8u;
-        so0[q] = lc[q].use_x ? (unsigned)st0[q] * 8u : 0u;
-        so1[q] = lc[q].use_y ? (unsigned)(st0[q] + 1) * 8u : 0u;
+        so0[q] = lc[q].use_x ? (unsigned)st0[q] * 8u : 0xffffffffu;      // (a column the lane does not own: beyond the
+        so1[q] = lc[q].use_y ? (unsigned)(st0[q] + 1) * 8u : 0xffffffffu;  //  resource's range -- the store is dropped)
     }
 
 #if XINV_PIPE_EXECSEL
@@ -258,53 +264,47 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     }
 
     // request row r into record `slot` (S from HBM for wavefront 0 only; later wavefronts get it through LDS).
-    // Rows are requested in order, so every stream keeps the address of its NEXT row (clamped to [0, yc-1], as the
-    // rows of a tile at the top or bottom of the slice are) in an SGPR pair and moves it on by one row or not at
-    // all: a compare, a select and an add with carry per stream instead of clamp, 64-bit multiply and add per row.
-    xinv_gcptr nxS = srcS, nxC[NC];
-    xinv_cdouble_ptr nxR = rowf;
-    {
-        const uint64_t b0 = (uint64_t)(unsigned)min(max(yu0 - H + 2 * PW, 0), ycr - 1) * rowbytes;
-        nxS += b0;
-#pragma unroll
-        for (int c = 0; c < NC; c++) nxC[c] = cq[c] + b0;
-        nxR += (uint64_t)(unsigned)min(max(yu0 - H + 2 * PW, 0), ycr - 1) * (unsigned)RW;
-    }
-    // a row of one of the lane's column pairs: uniform row address (kept in SGPRs: the asm pins it, so that
-    // the access is `global_load v, v_lane_offset, s[row]` and not a 64-bit vector address computed per load)
-    auto ldrow = [&](xinv_gcptr row, auto qtag) {
+    // Rows are requested in order: nxo is the byte offset of the NEXT row in the slice, unclamped (negative above
+    // the slice); the rows of a tile at the top or bottom of the slice are clamped to [0, yc-1] as before (their
+    // updates are switched off by the row predicate).  Three scalar instructions per step for all streams.
+    const int maxo = (int)(rowbytes * (unsigned)(ycr - 1));
+    int nxo = (yu0 - H + 2 * PW) * (int)rowbytes;
+    int nxr = (yu0 - H + 2 * PW) * (RW * 8);             // the same for the per-row records
+    // a row of one of the lane's column pairs
+    auto ldrow = [&](__amdgpu_buffer_rsrc_t rs, int soff, auto qtag) {
         constexpr int q = decltype(qtag)::value;
-        asm("" : "+s"(row));
-        asm("" : "+v"(lo0[q]));                          // (laundered in place, so that the zero-extension stays in this
-        if (!AL) asm("" : "+v"(lo1[q]));                 //  block: instruction selection then sees sgpr + zext(vgpr32))
         double2 v;
-        if (AL) { const xinv_v2d t = *(xinv_gcd2ptr)(row + lo0[q]); v.x = t.x; v.y = t.y; }
-        else { v.x = *(xinv_gcdptr)(row + lo0[q]); v.y = *(xinv_gcdptr)(row + lo1[q]); }
+        if (AL) {
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo0[q], soff, 0);
+            v.x = __hiloint2double((int)t[1], (int)t[0]); v.y = __hiloint2double((int)t[3], (int)t[2]);
+        } else {
+            const auto t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lo0[q], soff, 0);
+            const auto t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lo1[q], soff, 0);
+            v.x = __hiloint2double((int)t0[1], (int)t0[0]); v.y = __hiloint2double((int)t1[1], (int)t1[0]);
+        }
         return v;
     };
-    auto request = [&](int r, auto stag) {
+    auto request = [&](int, auto stag) {
         constexpr int slot = decltype(stag)::value;
+        const int soff = min(max(nxo, 0), maxo);
+        nxo += (int)rowbytes;
+        asm("" : "+s"(nxo));                             // (kept as ONE running value: the unrolled steps would otherwise
+                                                         //  hold eight multiples of the row pitch in SGPRs)
         xinv_unroll_steps([&](auto qtag) {
             constexpr int q = decltype(qtag)::value;
-            if (PW == 0) sw[q][slot] = ldrow(nxS, qtag);
+            if (PW == 0) sw[q][slot] = ldrow(rsS, soff, qtag);
             xinv_unroll_steps([&](auto ctag) {
                 constexpr int c = decltype(ctag)::value;
-                if (!((UM >> c) & 1u) && !(FR && c == FQ && PW > 0)) cw[q].v[c][slot] = ldrow(nxC[c], qtag);
+                if (!((UM >> c) & 1u) && !(FR && c == FQ && PW > 0)) cw[q].v[c][slot] = ldrow(rsC[c], soff, qtag);
             }, std::make_integer_sequence<int, NC>{});
         }, std::make_integer_sequence<int, NP>{});
-        unsigned adv = ((unsigned)r < (unsigned)(ycr - 1)) ? rowbytes : 0u;            // row r+1 lies in [1, yc-1]
-        asm("" : "+s"(adv));                             // (a 32-bit select, then add with carry: not a 64-bit select)
-        if (PW == 0) nxS += adv;
-        xinv_unroll_steps([&](auto ctag) {
-            constexpr int c = decltype(ctag)::value;
-            if (!((UM >> c) & 1u) && !(FR && c == FQ && PW > 0)) nxC[c] += adv;
-        }, std::make_integer_sequence<int, NC>{});
     };
-    auto request_rf = [&](int r, auto stag) {
+    auto request_rf = [&](int, auto stag) {
         constexpr int slot = decltype(stag)::value;
         if constexpr (RW > 0) {                          // (rows 0 and yc-1 carry rok = 0: so do the clamped ones)
-            const xinv_cdouble_ptr pr = nxR;
-            nxR += ((unsigned)r < (unsigned)(ycr - 1)) ? (unsigned)RW : 0u;
+            const unsigned roff = (unsigned)min(max(nxr, 0), (ycr - 1) * (RW * 8));
+            nxr += RW * 8;
+            const xinv_cdouble_ptr pr = (xinv_cdouble_ptr)((const char __attribute__((address_space(4))) *)rowf + roff);
             double rec[RW];
 #pragma unroll
             for (int k = 0; k < RW; k++) rec[k] = pr[k];
@@ -546,18 +546,21 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                     __hip_atomic_store(prog + 2 * PW, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
                 } else if ((unsigned)(jb - yu0) < (unsigned)(yu1 - yu0)) {
-                    xinv_gptr row = dstS + (uint64_t)(unsigned)jb * rowbytes;
-                    asm("" : "+s"(row));
+                    const int doff = jb * (int)rowbytes;
                     xinv_unroll_steps([&](auto qtag) {
                         constexpr int q = decltype(qtag)::value;
                         const double2 t = sw[q][sj];
-                        asm("" : "+v"(so0[q]));
-                        if (!AL) asm("" : "+v"(so1[q]));
-                        if (AL) {
-                            if (lc[q].use_x) { xinv_v2d tv; tv.x = t.x; tv.y = t.y; *(xinv_gd2ptr)(row + so0[q]) = tv; }
+                        typedef unsigned xinv_v4u __attribute__((__vector_size__(16)));
+                        typedef unsigned xinv_v2u __attribute__((__vector_size__(8)));
+                        if (AL) {                            // (use_x == use_y on aligned strips; un-owned lanes are out of range)
+                            const xinv_v4u tv = {(unsigned)__double2loint(t.x), (unsigned)__double2hiint(t.x),
+                                                 (unsigned)__double2loint(t.y), (unsigned)__double2hiint(t.y)};
+                            __builtin_amdgcn_raw_buffer_store_b128(tv, rsD, (int)so0[q], doff, 0);
                         } else {
-                            if (lc[q].use_x) *(xinv_gdptr)(row + so0[q]) = t.x;
-                            if (lc[q].use_y) *(xinv_gdptr)(row + so1[q]) = t.y;
+                            const xinv_v2u tx = {(unsigned)__double2loint(t.x), (unsigned)__double2hiint(t.x)};
+                            const xinv_v2u ty = {(unsigned)__double2loint(t.y), (unsigned)__double2hiint(t.y)};
+                            __builtin_amdgcn_raw_buffer_store_b64(tx, rsD, (int)so0[q], doff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(ty, rsD, (int)so1[q], doff, 0);
                         }
                     }, std::make_integer_sequence<int, NP>{});
                 }

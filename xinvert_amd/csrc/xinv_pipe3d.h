@@ -1,0 +1,289 @@
+// xinv_pipe3d.h -- TWO red-black sweeps per pass for the 3-D standard form with x-uniform coefficients
+// (every lat-lon omega coefficient, apps.py:2033-2035; numbas.invert_standard_3D, numbas.py:15-212), the
+// sweeps pipelined ACROSS two groups of wavefronts of a workgroup (gfx950).  BASELINE configs[4].
+//
+// k_fused3d (one sweep per pass) moves ~27 B per point-sweep and sits at what HBM delivers; only fewer bytes
+// help.  k_fused3d2 applied both sweeps inside every wavefront (four dependent stages with an LDS exchange
+// between each: bound by its own latency chain, slower).  Here the idea of k_pipe2d is carried to the k march:
+// a workgroup of 2 G wavefronts owns a cross-section of NR = G * RR rows x one 128-column strip and marches it
+// through the planes;
+//   group 0 (wavefronts 0..G-1)  streams S and the forcing from HBM and applies sweep 1 -- the K = 1 step of
+//                                k_fused3d: with r the plane entering, red points of plane r-1, black points of
+//                                plane r-2 -- and hands every finished plane on through a two-slot ring in LDS;
+//   group 1 (wavefronts G..2G-1) takes the plane out of the ring one workgroup barrier later (three planes
+//                                behind), applies sweep 2 the same way and writes the owned rows back.
+// S and the forcing are read once and S written once per TWO sweeps.  A wavefront owns RR adjacent rows (RR = 3:
+// 24 rows per cross-section, 16 owned -- the halo is four rows / columns / planes a side, recomputed, never
+// exchanged), so two of its four j neighbours per row pair are its own registers; the rows above / below its block
+// come from the adjacent wavefronts of its group through LDS exactly as in k_fused3d (published for the NEXT step,
+// double-buffered by step parity): ONE workgroup barrier per plane.
+//
+// Coefficients are one value per (plane, row); with them the relaxation factor
+//   optArg / ((A[k+1,j] + A[k,j]) ratio2Sqr + (B[k,j+1] + B[k,j]) ratio1Sqr + 2 C[k,j])
+// and the (plane, row) part of the update predicate are the same for every point of a row and every sweep of
+// the solve: k_row_factor3d evaluates them once per solve (same expression as k_fused3d<UNI>, same bits) into
+// 64-byte records {A[k+1], A[k], B[j+1], B[j], C, factor, predicate word, -} and the wavefronts read one record
+// per (plane, row) through the scalar unit (behind s_dcache_inv: the scalar-cache rule).
+// The update and the norm share are added under EXEC masks (xinv_add_where_ne / xinv_norm_row).
+// Same point arithmetic and ordering as two passes of k_fused3d: bitwise equal to it and to the oracle.
+#pragma once
+#include "xinv_fused3d.h"
+#include "xinv_pipe2d.h"
+
+#ifndef XINV_P3_RR
+#define XINV_P3_RR 3              /* rows per wavefront */
+#endif
+
+struct RowFactor3Args {
+    const double *c[3];           // A, B, C
+    int64_t sc[3];                // batch strides (0 = shared)
+    int64_t zc, yc, xc;
+    XinvScal sc_;
+    double *rowf;                 // [nb][zc][yc][8]
+    int64_t srowf;                // member stride of the table in doubles (0: one table for the batch)
+};
+
+#ifdef XINV_AUX_KERNELS
+// once per solve: the per-(plane, row) records (numbas.py:146-169 with the coefficients constant along x;
+// the hoisted branch of k_fused3d<UNI>: same expressions, same bits)
+__global__ __launch_bounds__(256) void k_row_factor3d(RowFactor3Args a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (idx >= a.zc * a.yc) return;
+    const int64_t k = idx / a.yc, j = idx - k * a.yc;
+    const double u = a.sc_.undef;
+    const int64_t kp = k + 1 > a.zc - 1 ? a.zc - 1 : k + 1, jp = j + 1 > a.yc - 1 ? a.yc - 1 : j + 1;
+    const double *pA = a.c[0] + m * a.sc[0], *pB = a.c[1] + m * a.sc[1], *pC = a.c[2] + m * a.sc[2];
+    const double aP = pA[(kp * a.yc + j) * a.xc], a0 = pA[(k * a.yc + j) * a.xc];
+    const double bP = pB[(k * a.yc + jp) * a.xc], b0 = pB[(k * a.yc + j) * a.xc];
+    const double c = pC[(k * a.yc + j) * a.xc];
+    const bool inner = (k >= 1) && (k <= a.zc - 2) && (j >= 1) && (j <= a.yc - 2);
+    double rq = 0.0, rok = 0.0;
+    if (inner) {
+        rq = a.sc_.optArg / ((aP + a0) * a.sc_.ratio2Sqr +
+                             (bP + b0) * a.sc_.ratio1Sqr +
+                             (c + c));
+        rok = ((aP != u) && (a0 != u) && (bP != u) && (b0 != u) && (c != u)) ? __longlong_as_double(-1LL) : 0.0;
+    }
+    double *f = a.rowf + m * a.srowf + idx * 8;
+    f[0] = aP; f[1] = a0; f[2] = bP; f[3] = b0; f[4] = c; f[5] = rq; f[6] = rok; f[7] = 0.0;
+}
+#endif
+
+template <int G, int RR, bool AL>
+__global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
+{
+    xinv_fresh_scalar_cache();
+    constexpr int K = 2, H = 2 * K, UW = 128 - 2 * H, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
+
+    const int64_t m = a.member0 + blockIdx.y;
+    XinvCtl *ctl = a.ctl + m;
+    if (!a.force && xinv_ctl_done(ctl)) return;
+    const unsigned tag = xinv_ctl_seq(ctl);
+
+    const int NB = a.nstrip * a.njb * a.nkc;
+    int T;
+    {
+        const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
+        T = xcd * q + (xcd < rem ? xcd : rem) + idx;
+    }
+    const int kc = T / (a.nstrip * a.njb), Tj = T - kc * (a.nstrip * a.njb);
+    const int jb = Tj / a.nstrip, st = Tj - jb * a.nstrip;
+    const int zc = (int)a.zc, yc = (int)a.yc;
+    const int k0 = kc * a.KC;
+    const int k1 = (kc + 1 == a.nkc) ? zc : k0 + a.KC;
+    // (the wavefront index as a scalar: rows, record addresses and row predicates are then wave-uniform values)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int grp = wave >= G ? 1 : 0, gw = wave - grp * G;
+    const int64_t xc = a.xc;
+    const int64_t xu0 = (int64_t)st * UW;
+    const double u = a.sc_.undef;
+    const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
+    const int64_t st0 = xu0 - H + 2 * lane;
+    const unsigned long long okx64 = __builtin_amdgcn_ballot_w64(lc.ok_x), oky64 = __builtin_amdgcn_ballot_w64(lc.ok_y);
+
+    // the RR rows of this wavefront (the same rows in both groups)
+    const int j0 = jb * RJ - H + gw * RR;
+    int jr[RR];
+    bool row_use[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; rr++) {
+        const int j = j0 + rr;
+        jr[rr] = j < 0 ? 0 : (j > yc - 1 ? yc - 1 : j);
+        row_use[rr] = (gw * RR + rr >= H) && (gw * RR + rr < NR - H) && (j < yc);
+    }
+    // neighbouring wavefronts of the group (the first / last one reads itself: those rows are halo)
+    const int wm = gw > 0 ? wave - 1 : wave, wp = gw < G - 1 ? wave + 1 : wave;
+
+    const double *srcS = a.src + m * a.sS;
+    double *dstS = a.dst + m * a.sS;
+    const double *pF = a.c[3] + m * a.sc[3];
+    const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(a.rowf + m * a.srowf);
+
+    __shared__ double xch[2][2][NW][2][64];              // [step parity][as loaded | red-updated][wave][top | bottom row][lane]
+    __shared__ double2 ring[2][G][RR][64];               // [slot][wave of the group][row][lane]: planes with sweep 1 complete
+
+    double nsx = 0.0, nsy = 0.0;                         // norm share per lane and column (un-owned lanes discarded below)
+    int nnx = 0, nny = 0;
+
+    double2 sw[RR][D], fw[RR][2], pfS[RR], pfF[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; rr++) {
+#pragma unroll
+        for (int t = 0; t < D; t++) sw[rr][t] = make_double2(0.0, 0.0);
+        fw[rr][0] = fw[rr][1] = pfS[rr] = pfF[rr] = make_double2(0.0, 0.0);
+    }
+
+    auto plane_off = [&](int p, int rr) {                // element offset of the lane's row in plane p (clamped)
+        const int pr = p > zc - 1 ? zc - 1 : (p < 0 ? 0 : p);
+        return ((int64_t)pr * yc + jr[rr]) * xc;
+    };
+    // the (plane, row) record through the scalar unit: {A[k+1], A[k], B[j+1], B[j], C, factor, predicate, -}
+    struct Rec { double aP, a0, bP, b0, c, rq; unsigned long long rok; };
+    auto record = [&](int p, int rr) {
+        const int pr = p > zc - 1 ? zc - 1 : (p < 0 ? 0 : p);
+        const xinv_cdouble_ptr q = rowf + (unsigned)((pr * yc + jr[rr]) * 8);
+        Rec e;
+        e.aP = q[0]; e.a0 = q[1]; e.bP = q[2]; e.b0 = q[3]; e.c = q[4]; e.rq = q[5];
+        e.rok = (unsigned long long)__double_as_longlong(q[6]);
+        return e;
+    };
+
+    // one point update of component X of row rr on the plane in slot sk (k+1 in skp, k-1 in skm): the expression
+    // of k_fused3d<UNI>, the increment added under the predicate as EXEC
+    auto update = [&](auto rtag, auto xt, int sk, int skp, int skm, const Rec &e, double jP, double jM) {
+        constexpr int rr = decltype(rtag)::value;
+        constexpr int X = decltype(xt)::value;
+        double w, ee;
+        row_neighbours<X>(sw[rr][sk], w, ee);
+        const double sC = comp<X>(sw[rr][sk]), sKP = comp<X>(sw[rr][skp]), sKM = comp<X>(sw[rr][skm]);
+        const double f = comp<X>(fw[rr][sk & 1]);
+        double temp = (
+            (
+                e.aP * (sKP - sC) -
+                e.a0 * (sC - sKM)
+            ) * a.sc_.ratio2Sqr + (
+                e.bP * (jP - sC) -
+                e.b0 * (sC - jM)
+            ) * a.sc_.ratio1Sqr + (
+                e.c * (ee - sC) -
+                e.c * (sC - w)
+            )
+        ) - f * a.sc_.delxSqr;
+        temp *= e.rq;
+        const double v = xinv_add_where_ne(sC, temp, f, u, (X ? oky64 : okx64) & e.rok);
+        setc<X>(sw[rr][sk], v);
+        return v;
+    };
+
+    // one pipeline step of group GRP: plane r enters slot U; JP = parity of the wavefront's first row
+    auto step = [&](int r, auto gtag, auto utag, auto jtag) {
+        constexpr int GRP = decltype(gtag)::value, U = decltype(utag)::value, JP = decltype(jtag)::value;
+        constexpr int S1 = (U + 3) % D, S2 = (U + 2) % D, S3 = (U + 1) % D;
+        constexpr int bw = U & 1, br = (U + 1) & 1;
+#define XROW(rr) ((1 + (U & 1) + JP + (rr)) & 1)          /* component row rr touches in this step */
+
+        // ---- plane r enters; the forcing of plane r-1 arrives (it is first read in this step); requests one plane ahead
+#pragma unroll
+        for (int rr = 0; rr < RR; rr++) {
+            if (GRP == 0) {
+                sw[rr][U] = pfS[rr];
+                pfS[rr] = ld2<AL>(srcS, plane_off(r + 1, rr), lc);
+            } else {
+                sw[rr][U] = ring[U & 1][gw][rr][lane];
+            }
+            fw[rr][S1 & 1] = pfF[rr];
+            pfF[rr] = ld2<AL>(pF, plane_off(r, rr), lc);
+        }
+        // as loaded: what the neighbouring wavefronts' next red half-sweep reads of the first / last row
+        xch[bw][0][wave][0][lane] = XROW(0) ? sw[0][U].y : sw[0][U].x;
+        xch[bw][0][wave][1][lane] = XROW(RR - 1) ? sw[RR - 1][U].y : sw[RR - 1][U].x;
+
+        // ---- red half-sweep on plane r-1
+        {
+            const double jMe = xch[br][0][wm][1][lane], jPe = xch[br][0][wp][0][lane];
+            xinv_unroll_steps([&](auto rtag) {
+                constexpr int rr = decltype(rtag)::value;
+                constexpr int X = XROW(rr);
+                using XT = std::integral_constant<int, X>;
+                const Rec e = record(r - 1, rr);
+                const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S1]) : jMe;
+                const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S1]) : jPe;
+                const double v = update(rtag, XT{}, S1, U, S2, e, jP, jM);
+                if (rr == 0) xch[bw][1][wave][0][lane] = v;          // red-updated: the neighbours' next black half-sweep
+                if (rr == RR - 1) xch[bw][1][wave][1][lane] = v;
+            }, std::make_integer_sequence<int, RR>{});
+        }
+        // ---- black half-sweep on plane r-2; plane r-2 leaves
+        {
+            const int kk = r - 2;
+            const bool pin = (kk >= k0) && (kk < k1);
+            const double jMe = xch[br][1][wm][1][lane], jPe = xch[br][1][wp][0][lane];
+            xinv_unroll_steps([&](auto rtag) {
+                constexpr int rr = decltype(rtag)::value;
+                constexpr int X = XROW(rr);
+                using XT = std::integral_constant<int, X>;
+                const Rec e = record(kk, rr);
+                const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S2]) : jMe;
+                const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S2]) : jPe;
+                update(rtag, XT{}, S2, S1, S3, e, jP, jM);
+            }, std::make_integer_sequence<int, RR>{});
+#pragma unroll
+            for (int rr = 0; rr < RR; rr++) {
+                const double2 t = sw[rr][S2];
+                if (GRP == 0) ring[U & 1][gw][rr][lane] = t;
+                if (pin && row_use[rr]) {                // wave-uniform: an owned row of an owned plane
+                    xinv_norm_row(nsx, nsy, nnx, nny, t.x, t.y, u);
+                    if (GRP == 1) {
+                        double *d = dstS + ((int64_t)kk * yc + (j0 + rr)) * xc + st0;
+                        if (AL) { if (lc.use_x) *reinterpret_cast<double2 *>(d) = t; }
+                        else { if (lc.use_x) d[0] = t.x; if (lc.use_y) d[1] = t.y; }
+                    }
+                }
+            }
+        }
+#undef XROW
+        xinv_pipe_barrier();
+    };
+
+    // Global steps g = 0, 1, ...: group 0 enters plane rstart + g, group 1 plane rstart + g - 3 (the plane group 0
+    // finished in step g - 1).  rstart is a multiple of D planes below k0 - H (slot indices are compile-time; k0 is
+    // a multiple of D); the last owned plane, k1 - 1, leaves group 1 in step k1 + 4 - rstart.
+    const int rstart = (k0 >= D) ? k0 - D : 0;
+    const int gend = k1 + 4 - rstart;
+    auto march = [&](auto gtag, auto jtag) {
+        constexpr int GRP = decltype(gtag)::value;
+        if (GRP == 0) {
+#pragma unroll
+            for (int rr = 0; rr < RR; rr++) pfS[rr] = ld2<AL>(srcS, plane_off(rstart, rr), lc);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RR; rr++) pfF[rr] = ld2<AL>(pF, plane_off(rstart - 1 - 3 * GRP, rr), lc);
+        for (int gb = 0; gb <= gend; gb += D) {
+            xinv_unroll_steps([&](auto utag) {
+                constexpr int Ug = decltype(utag)::value;                // global step mod D
+                constexpr int U = (Ug + (GRP ? 1 : 0)) % D;              // slot of the entering plane: (g - 3) mod D for group 1
+                step(rstart + gb + Ug - 3 * GRP, gtag, std::integral_constant<int, U>{}, jtag);
+            }, std::make_integer_sequence<int, D>{});
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (grp == 0) { if (j0 & 1) march(I0{}, I1{}); else march(I0{}, I0{}); }
+    else          { if (j0 & 1) march(I1{}, I1{}); else march(I1{}, I0{}); }
+
+    if (a.no_ctl) return;
+    // wavefronts of group g hold the tile's share of sweep g+1 (only the columns a lane owns count)
+    double acc[K] = {0.0, 0.0};
+    int cnt[K] = {0, 0};
+    {
+        double s = 0.0;
+        s += (lc.use_x ? nsx : 0.0);
+        s += (lc.use_y ? nsy : 0.0);
+        const int n = (lc.use_x ? nnx : 0) + (lc.use_y ? nny : 0);
+        acc[0] = grp == 0 ? s : 0.0; acc[1] = grp == 1 ? s : 0.0;
+        cnt[0] = grp == 0 ? n : 0;   cnt[1] = grp == 1 ? n : 0;
+    }
+    xinv_norm_finalize<K, NW>(acc, cnt, wave, lane, NB, T, tag,
+                              a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop);
+}
