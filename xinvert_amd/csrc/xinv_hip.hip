@@ -326,7 +326,12 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         // 1.45e11 point-sweeps/s with eight wavefronts (no spills, half the rows halo) and 0.7e11 with
         // twelve (170-register budget: spills) against 1.9e11 for the one-sweep kernel -- the deeper
         // pipeline is bound by its LDS round trips, not by bytes.
-        if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND && opt.sweeps_per_launch == 2 &&
+        // Round 3: k_pipe3d (the two sweeps pipelined across two groups of wavefronts) is chosen by the planner:
+        // 15 volumes of 50 x 360 x 720: 2.83e11 against 1.88e11, 2 volumes 1.85 against 1.46, 601 x 300 x 300
+        // 2.40 against 1.57 (profiles/r03_pipe3d_first.txt); sweeps_per_launch = 1 keeps the one-sweep kernel.
+        static const int k2_auto = [] { const char *e = getenv("XINV_3D_K2"); return e ? atoi(e) : 1; }();
+        if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND &&
+            (opt.sweeps_per_launch == 2 || (opt.sweeps_per_launch == 0 && k2_auto)) &&
             opt.rows_per_tile == 0 && p.stop.mxLoop >= 1) {
             pl.K2 = true;
             pl.K = 2;
