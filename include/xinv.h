@@ -125,6 +125,9 @@ typedef struct xinv_stats {
                                    per lane (1 or 2), 0 = k_fused2d                              */
     int32_t masked_tile_ppm;    /* masked_tile_pct at full resolution: skipped wave-tiles per million (bench.py prices
                                    its roofline on the tiles that ran)                           */
+    int32_t recovered_members;  /* members whose in-kernel norm reduction timed out (watchdog) and that were finished
+                                   sweep by sweep with the separate norm kernels; 0 in every run seen so far      */
+    int32_t pad1_;
 } xinv_stats;
 
 void        xinv_default_options(xinv_options *opt);

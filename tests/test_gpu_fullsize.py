@@ -194,7 +194,7 @@ def test_c5_omega_converged_within_1e6_of_reference_ordering():
 
 
 # ------------------------------------------------------------------ pipelined pass, many rounds of workgroups
-@pytest.mark.parametrize('kind', ['gen2d', 'std2d'])
+@pytest.mark.parametrize('kind', ['gen2d', 'std2d', 'std2d_c2x3'])
 @pytest.mark.parametrize('rows', [16, 30, 0])
 def test_pipelined_pass_many_rounds_of_workgroups(kind, rows):
     """k_pipe2d on launches of several thousand workgroups (8 members, short tiles: every CU holds as many
@@ -206,14 +206,16 @@ def test_pipelined_pass_many_rounds_of_workgroups(kind, rows):
     from xinvert_amd import synthetic
     if kind == 'gen2d':
         p = synthetic.gill_matsuno(720, 1440, 8)
-    else:                                                 # (9.7e6 points: the largest batch the planner still pipelines)
+    elif kind == 'std2d':                                 # (9.7e6 points: the planner's crossover to k_fused2d until round 3)
         p = synthetic.poisson_latlon(900, 1800, mask=True, members=6)
+    else:                                                 # three C2 slices: 1.9e7 points, pipelined at every size now,
+        p = synthetic.poisson_latlon(1800, 3600, mask=True, members=3)   # the forcing through the LDS ring
     nm = p['S0'].shape[0]
     qs = [synthetic.member(p, m) for m in range(nm)]
     Sref, fref, s0 = util.run_hip_dev(qs, 11, 0.0, shared=p['shared'], no_pipe=1)
     assert s0['pipelined'] == 0
-    So, flo = run_oracle(qs[5], 11, 0.0, COLOUR_2)
-    assert np.array_equal(Sref[5], So)
+    So, flo = run_oracle(qs[nm - 1], 11, 0.0, COLOUR_2)
+    assert np.array_equal(Sref[nm - 1], So)
     ran_pipelined = 0
     for rep in range(4):
         S, fl, st = util.run_hip_dev(qs, 11, 0.0, shared=p['shared'], rows_per_tile=rows)

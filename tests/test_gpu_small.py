@@ -145,7 +145,7 @@ def xuniform3d(zc, yc, xc, BCx, msk, seed):
 @pytest.mark.parametrize('shape', [(9, 20, 66), (12, 33, 130), (50, 40, 250), (7, 17, 24), (64, 18, 120), (21, 50, 241)])
 @pytest.mark.parametrize('BCx', ['fixed', 'periodic'])
 def test_fused3d_two_sweeps_per_pass_vs_oracle(shape, BCx):
-    """k_fused3d2 (x-uniform coefficients, on request: sweeps_per_launch = 2): passes of two sweeps + a
+    """k_pipe3d (x-uniform coefficients; the planner's choice, asked for explicitly here: sweeps_per_launch = 2): passes of two sweeps + a
     one-sweep tail; must equal the oracle's coloured ordering and the one-sweep-per-pass kernel bit for bit."""
     zc, yc, xc = shape
     if BCx == 'periodic' and xc % 2:

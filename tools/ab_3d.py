@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of the 3-D standard form (BASELINE configs[4] shape): one sweep per pass against two.
-  python tools/ab_3d.py [members ...]      XINV_SO / XINV_3D2_NW select the build / the two-sweep kernel"""
+  python tools/ab_3d.py [members ...]      XINV_SO selects the build, XINV_3D_K2=0 the one-sweep kernel"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -40,7 +40,6 @@ XINV_HIDDEN int xinv_launch_fused9(bool gen, int K, bool al, bool ext, dim3 grid
                                    const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 grid, hipStream_t st,
                                     const Fused3Args &a);
-XINV_HIDDEN int xinv_launch_fused3d2(int NW, bool al, dim3 grid, hipStream_t st, const Fused3Args &a);
 // two sweeps per pass pipelined across two groups of eight wavefronts (xinv_pipe3d.h): x-uniform coefficients, no 'extend'
 XINV_HIDDEN int xinv_launch_pipe3d(bool al, dim3 grid, hipStream_t st, const Fused3Args &a);
 XINV_HIDDEN int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st,

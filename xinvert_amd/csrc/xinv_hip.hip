@@ -296,11 +296,14 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
                 if (rc) return rc;
             }
             pl.um = (pl.umask == 7u) ? 7u : 0u;
-            // 16 waves x 64 lanes leaves 128 VGPRs per lane: enough only for the x-uniform variant
-            if (pl.RY == 0) pl.RY = (pl.um == 7u && p.BCy != XINV_BC_EXTEND) ? 16 : 12;
+            // 16 waves x 64 lanes leaves 128 VGPRs per lane: enough only for the x-uniform variant (the others
+            // spilled and are not instantiated: a request for sixteen gets twelve)
+            const bool nw16_ok = (pl.um == 7u && p.BCy != XINV_BC_EXTEND);
+            if (pl.RY == 0) pl.RY = nw16_ok ? 16 : 12;
+            if (pl.RY == 16 && !nw16_ok) pl.RY = 12;
         } else {
             pl.um = pl.umask;                               // 0x7f: A..G are per-row scalars
-            if (pl.RY == 0) pl.RY = 12;                     // seven coefficient windows: 12 waves x 170 VGPRs
+            if (pl.RY == 0 || pl.RY == 16) pl.RY = 12;      // seven coefficient windows: 12 waves x 170 VGPRs
         }
         pl.nrb = (int)cdiv(p.yc, pl.RY - 4);
         // k chunks: one workgroup per CU is resident (16 / 12 waves); pick the chunk count that
@@ -318,30 +321,23 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
             pl.nkc = best;
             pl.KC = (int)(cdiv(cdiv(p.zc, best), 4) * 4);
         }
-        // Two sweeps per pass (k_fused3d2: x-uniform coefficients, no 'extend'): the one-sweep kernel is
-        // bound by the fabric's bandwidth, so halving the bytes per sweep pays.  Its own tiling: twelve
-        // wavefronts x two rows = 24 rows per cross-section, 16 owned; 120 owned columns; four halo planes.
+        // Two sweeps per pass, x-uniform coefficients, no 'extend': k_pipe3d (the two sweeps pipelined across two
+        // groups of eight wavefronts, xinv_pipe3d.h) -- the one-sweep kernel sits at what HBM delivers, so halving the
+        // bytes per sweep pays: 15 volumes of 50 x 360 x 720: 2.83e11 against 1.88e11, 2 volumes 1.85 against 1.46,
+        // 601 x 300 x 300 2.40 against 1.57 (profiles/r03_pipe3d_first.txt); sweeps_per_launch = 1 keeps the one-sweep
+        // kernel.  (Round 2's k_fused3d2, both sweeps inside every wavefront, was bound by its own latency chain
+        // -- 1.45e11 -- and is gone.)
         pl.K2 = false;
-        // ON REQUEST ONLY (sweeps_per_launch = 2): measured at 15 volumes of 50 x 360 x 720 it runs at
-        // 1.45e11 point-sweeps/s with eight wavefronts (no spills, half the rows halo) and 0.7e11 with
-        // twelve (170-register budget: spills) against 1.9e11 for the one-sweep kernel -- the deeper
-        // pipeline is bound by its LDS round trips, not by bytes.
-        // Round 3: k_pipe3d (the two sweeps pipelined across two groups of wavefronts) is chosen by the planner:
-        // 15 volumes of 50 x 360 x 720: 2.83e11 against 1.88e11, 2 volumes 1.85 against 1.46, 601 x 300 x 300
-        // 2.40 against 1.57 (profiles/r03_pipe3d_first.txt); sweeps_per_launch = 1 keeps the one-sweep kernel.
         static const int k2_auto = [] { const char *e = getenv("XINV_3D_K2"); return e ? atoi(e) : 1; }();
         if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND &&
             (opt.sweeps_per_launch == 2 || (opt.sweeps_per_launch == 0 && k2_auto)) &&
-            opt.rows_per_tile == 0 && p.stop.mxLoop >= 1) {
+            opt.rows_per_tile == 0 && p.stop.mxLoop >= 1 &&
+            p.zc * p.yc * 64 < ((int64_t)1 << 31)) {                      // (32-bit offsets into the record table)
             pl.K2 = true;
             pl.K = 2;
-            // 16: k_pipe3d (two groups of eight wavefronts, one sweep each, xinv_pipe3d.h); 8 / 12: k_fused3d2
-            pl.nw2 = 16;
-            if (const char *e = getenv("XINV_3D2_NW")) { const int v = atoi(e); pl.nw2 = (v == 12 || v == 8) ? v : 16; }
-            if (p.zc * p.yc * 64 >= ((int64_t)1 << 31)) pl.nw2 = 8;       // (k_pipe3d: 32-bit offsets into its record table)
             pl.nsg2 = (int)cdiv(p.xc, 120);
-            pl.nrb2 = (int)cdiv(p.yc, pl.nw2 == 16 ? 8 * XINV_P3_RR - 8 : 2 * pl.nw2 - 8);
-            if (pl.nw2 == 16) {
+            pl.nrb2 = (int)cdiv(p.yc, 8 * XINV_P3_RR - 8);
+            {
                 // per-(plane, row) records of the x-uniform coefficients, relaxation factor and predicate: once per solve
                 const bool shared = (p.sc[0] == 0 && p.sc[1] == 0 && p.sc[2] == 0);
                 const int64_t tab = p.zc * p.yc * 8;
@@ -423,12 +419,13 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // k_fused2d at three sweeps per pass -- C3 Stommel 2.09 against 2.56e11, C2 with every array streamed 2.95
         // against 4.06e11, profiles/r03_pipe_vector_streams.txt -- so those forms stay on k_fused2d.)
         const bool pipe_form = (p.kind == KIND_STD2D && pl.um == 3u) || (p.kind == KIND_GEN2D && pl.um == 0x1fu);
-        // Standard form: only where the launch is small enough for the halo saving to matter -- k_fused2d keeps the
-        // VALU 96 % busy against ~75 %, and with several rounds of workgroups its tiles are tall anyway (8 slices
-        // of 3600x1800: 7.0e11 with k_fused2d, 6.2e11 pipelined; one slice: 5.85 against 6.0e11; 180x360: 1.7
-        // against 2.35e10).  General form: k_fused2d stops at two sweeps per pass (registers) and is bound by
-        // HBM at C4, so the pipelined pass is taken at every size.  XINV_PIPE=2 forces it whatever the size.
-        const bool pipe_size_ok = pipe_mode == 2 || p.kind == KIND_GEN2D || p.nbatch * p.yc * p.xc <= (int64_t)10000000;
+        // At every size (round 3, profiles/r03_pipe_size_crossover.txt).  Until the pass lost a quarter of its
+        // instructions per step and the forcing rode the LDS ring, k_fused2d (VALU 96 % busy against ~75 %) won on
+        // launches of several rounds of workgroups and the standard form switched at 1e7 points; re-measured on
+        // 1 / 2 / 3 / 4 / 8 slices of 3600x1800: 6.17 / 6.76 / 7.25 / 7.21 / 7.72e11 pipelined (forcing through the
+        // ring from two slices on) against 5.31 / 6.33 / 6.53 / 6.64 / 7.31e11.  The general form stops at two sweeps
+        // per pass on k_fused2d (registers) and is bound by HBM at C4.  XINV_PIPE=3 restores the old crossover.
+        const bool pipe_size_ok = pipe_mode != 3 || p.kind == KIND_GEN2D || p.nbatch * p.yc * p.xc <= (int64_t)10000000;
         // (k_pipe2d addresses a slice through buffer resources with signed 32-bit row offsets: slices below 2 GiB)
         const bool pipe_want = pipe_mode != 0 && pipe_form && pipe_size_ok && !(opt.flags & XINV_FLAG_NO_PIPE) &&
                                (opt.sweeps_per_launch == 0 || opt.sweeps_per_launch == XINV_PIPE_P) &&
@@ -582,6 +579,7 @@ struct SweepRun {
     int64_t launched = 0, nlaunch = 0;
     double ms_total = 0.0;
     const XinvCtl *hc = nullptr;                         // the slot holding the final control blocks
+    std::vector<int> rec_where;                          // watchdog recovery: buffer index of a recovered member's final state (-1: not recovered)
     int Kf = 1;
     // the replayed chunk of small problems: lives until finalise() has drained the stream (replays
     // queued after the last poll may still be executing when run_sweeps returns)
@@ -736,7 +734,16 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         R.buf[2] = ws->S3; R.nbuf = 3;
     }
     // launch number i of the solve (fused path): k sweeps from buf[i % nbuf] into buf[(i+1) % nbuf]
+    // test hook: XINV_EXP_WATCHDOG="i[,m]" leaves member m (default 0), before launch i, in the state a reducer that
+    // timed out leaves behind (read per solve: tests switch it)
+    int64_t wd_at = -1, wd_member = 0;
+    if (const char *e = getenv("XINV_EXP_WATCHDOG")) {
+        wd_at = atoll(e);
+        if (const char *c = strchr(e, ',')) wd_member = atoll(c + 1);
+        if (wd_member < 0 || wd_member >= p.nbatch) wd_at = -1;
+    }
     auto launch_idx = [&](int64_t i, int k) -> int {
+        if (i == wd_at) hipLaunchKernelGGL(k_ctl_fake_timeout, dim3(1), dim3(1), 0, st, ws->ctl + wd_member);
         const double *src = buf[i % R.nbuf];
         double *dst = buf[(i + 1) % R.nbuf];
         if (exp_noctl == 2)                              // (timing experiment: publish only, nobody reduces)
@@ -821,10 +828,60 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         return XINV_ERR_ARG;
     }
     if (!all_done) { t_err = "internal: sweep budget exhausted before the stop rule fired"; return XINV_ERR_HIP; }
+    // A member whose in-kernel norm reduction gave up waiting for a partial (watchdog, overflow == 2; never seen in
+    // a run so far) is finished here instead of failing the call: the reducer stops the member BEFORE applying the
+    // stop rule to any sweep of its launch, so the control block still describes the state at the start of that
+    // launch and the launch's source buffer is intact (every later launch was a no-op for the member).  From there:
+    // one sweep per launch without in-kernel norm, then the two separate norm kernels of the colour path
+    // (k_norm_partial / k_norm_final: no waiting on other workgroups) -- the same sweeps and the same stop rule; the
+    // partial sums are added in another order than the tiles' (flags[1] agrees to rounding).
     for (int64_t m = 0; m < p.nbatch; m++)
         if (hc[m].overflow == 2) {
-            t_err = "internal: norm partials of a sweep launch never arrived (watchdog)";
-            return XINV_ERR_HIP;
+            if (pl.path != XINV_PATH_FUSED) { t_err = "internal: watchdog flag outside the fused path"; return XINV_ERR_HIP; }
+            HIPCHK(hipStreamSynchronize(st));            // (queued no-op launches)
+            XinvCtl *hcm = const_cast<XinvCtl *>(hc) + m;
+            const int64_t L = hcm->loop;
+            const size_t i = std::lower_bound(bound.begin(), bound.end(), L) - bound.begin();
+            if (i >= bound.size() || bound[i] != L) {
+                t_err = "internal: norm partials of a sweep launch never arrived (watchdog) and the control block is not at a launch boundary";
+                return XINV_ERR_HIP;
+            }
+            rc = ensure_dev(&ws->wd_part, &ws->wd_part_cap, (size_t)XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long)));
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_ctl_resume, dim3(1), dim3(1), 0, st, ws->ctl + m);
+            NormArgs na;
+            memset(&na, 0, sizeof na);
+            na.sS = p.sS; na.n = n; na.undef = p.sc_.undef;
+            na.psum = (double *)ws->wd_part - m * XINV_NORM_BLOCKS;          // (the kernels index by member)
+            na.pcnt = (long long *)((char *)ws->wd_part + XINV_NORM_BLOCKS * sizeof(double)) - m * XINV_NORM_BLOCKS;
+            na.ctl = ws->ctl; na.stop = p.stop; na.force = 0; na.member0 = m;
+            const int nblk = (int)std::min<int64_t>(XINV_NORM_BLOCKS, std::max<int64_t>(1, n / 2048));
+            const int b0 = (int)(i % R.nbuf), b1 = (int)((i + 1) % R.nbuf);
+            int a = b0, b = b1;
+            int64_t s = L;
+            bool fin = false;
+            while (!fin && s < max_sweeps) {
+                const int64_t burst = std::min<int64_t>(32, max_sweeps - s);
+                for (int64_t q = 0; q < burst; q++, s++) {
+                    rc = launch_planned(p, pl, ws, st, 1, buf[a], buf[b], m, 1, 0, 1);
+                    if (rc) return rc;
+                    na.S = buf[b];
+                    hipLaunchKernelGGL(k_norm_partial, dim3(nblk, 1, 1), dim3(256, 1, 1), 0, st, na);
+                    hipLaunchKernelGGL(k_norm_final, dim3(1, 1, 1), dim3(64, 1, 1), 0, st, na, nblk);
+                    std::swap(a, b);
+                }
+                HIPCHK(hipMemcpyAsync(hcm, ws->ctl + m, sizeof(XinvCtl), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                fin = hcm->done != 0;
+            }
+            if (!fin || hcm->overflow == 2) {
+                t_err = "internal: norm partials of a sweep launch never arrived (watchdog) and the recovery did not finish";
+                return XINV_ERR_HIP;
+            }
+            if (R.rec_where.empty()) R.rec_where.assign((size_t)p.nbatch, -1);
+            // sweeps the recovery applied before the stop rule fired (launches after that were no-ops): parity = buffer
+            R.rec_where[(size_t)m] = ((hcm->sweeps - L) & 1) ? b1 : b0;
+            t_stats.recovered_members++;
         }
 
     return XINV_OK;
@@ -843,6 +900,13 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
     if (pl.path == XINV_PATH_FUSED) {
         bound.push_back(R.launched);
         for (int64_t m = 0; m < p.nbatch; m++) {
+            if (!R.rec_where.empty() && R.rec_where[(size_t)m] >= 0) {       // finished by the watchdog recovery
+                const int where = R.rec_where[(size_t)m];
+                if (where != 0)
+                    HIPCHK(hipMemcpyAsync(p.S + m * p.sS, buf[where] + m * p.sS, (size_t)n * sizeof(double),
+                                          hipMemcpyDeviceToDevice, st));
+                continue;
+            }
             const int64_t sw = hc[m].sweeps;
             // launch i covers sweeps (bound[i], bound[i+1]]; find the one holding sweep `sw`
             size_t i = std::upper_bound(bound.begin(), bound.end(), sw - 1) - bound.begin() - 1;
@@ -1288,6 +1352,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
             acc.sweep_launches += t_stats.sweep_launches;
             acc.sweeps_max = std::max(acc.sweeps_max, t_stats.sweeps_max);
             acc.sweep_ms += t_stats.sweep_ms;
+            acc.recovered_members += t_stats.recovered_members;
         }
         // solve_dev has returned: the chunk's S is final on the device
         if (opt.prep_flags & XINV_PREP_DEMASK) {
@@ -1413,6 +1478,7 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
         t_stats.h2d_ms = std::max(t_stats.h2d_ms, s.h2d_ms);
         t_stats.d2h_ms = std::max(t_stats.d2h_ms, s.d2h_ms);
         t_stats.host_chunks += s.host_chunks;
+        t_stats.recovered_members += s.recovered_members;
     }
     t_stats.devices = nd;
     t_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();

@@ -211,6 +211,7 @@ struct Workspace {
     int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
     double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
     void *d_rowf = nullptr; size_t d_rowf_cap = 0;              // k_pipe2d: per-row records [nbatch][yc][PIPE_RW]
+    void *wd_part = nullptr; size_t wd_part_cap = 0;            // watchdog recovery: partials of the separate norm kernels
     StageRing ring_up, ring_down;                               // host-pointer entries: the library's pinned staging
 };
 

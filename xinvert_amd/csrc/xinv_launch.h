@@ -10,8 +10,8 @@ struct Plan {
     int path, base, seam, ncol;
     int K, RY, nsg, nrb;     // nsg: 2-D = workgroups per member (partials sizing); 3-D = x strips
     int nkc, KC;             // 3-D: k chunks and planes per chunk
-    bool K2;                 // 3-D standard form: passes of two sweeps (k_fused3d2) with the tiling below
-    int nsg2, nrb2, nkc2, KC2, nw2;
+    bool K2;                 // 3-D standard form: passes of two sweeps (k_pipe3d) with the tiling below
+    int nsg2, nrb2, nkc2, KC2;
     int64_t srowf2;          // k_pipe3d: member stride of the record table (0: shared by the batch)
     bool bih_zbe;            // biharmonic one-pass kernel: B and E identically zero (terms left out)
     bool aligned;
@@ -213,11 +213,8 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
         for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
             const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
             a.member0 = member0 + m0;
-            if (pl.nw2 == 16) {
-                a.rowf = (const double *)ws->d_rowf; a.srowf = pl.srowf2;
-                xinv_launch_pipe3d(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a);
-            } else if (xinv_launch_fused3d2(pl.nw2, pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a))
-                return fail_arg("internal: no two-sweep 3-D kernel variant");
+            a.rowf = (const double *)ws->d_rowf; a.srowf = pl.srowf2;
+            xinv_launch_pipe3d(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a);
         }
         HIPCHK(hipGetLastError());
         return XINV_OK;
@@ -233,7 +230,8 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)NB, (unsigned)nm, 1);
-        xinv_launch_fused3d(pl.RY, pl.aligned, uni, ext, grid, st, a);
+        if (xinv_launch_fused3d(pl.RY, pl.aligned, uni, ext, grid, st, a))
+            return fail_arg("internal: no 3-D kernel variant for this cross-section");
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;
@@ -310,7 +308,8 @@ static int launch_fused3dg(const Problem &p, const Plan &pl, const double *src, 
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)NB, (unsigned)nm, 1);
-        xinv_launch_fused3dg(pl.RY, pl.aligned, ext, grid, st, a);
+        if (xinv_launch_fused3dg(pl.RY, pl.aligned, ext, grid, st, a))
+            return fail_arg("internal: no general 3-D kernel variant for this cross-section");
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;

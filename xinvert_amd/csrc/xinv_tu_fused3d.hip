@@ -1,7 +1,6 @@
-// xinv_tu_fused3d.hip -- instantiations of k_fused3d (standard 3-D form) and k_fused3dg (general 3-D
-// form with x-uniform coefficients).
+// xinv_tu_fused3d.hip -- instantiations of k_fused3d (standard 3-D form), k_pipe3d (two sweeps per pass) and
+// k_fused3dg (general 3-D form with x-uniform coefficients).
 #include "xinv_dispatch.h"
-#include "xinv_fused3d2.h"
 
 // ---- 3-D fused launch ------------------------------------------------------------------------
 template <int NW>
@@ -24,8 +23,16 @@ static int launch_fused3d_nw(bool al, bool uni, bool ext, dim3 grid, hipStream_t
 int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 grid, hipStream_t st, const Fused3Args &a)
 {
     if (NW == 8) return launch_fused3d_nw<8>(al, uni, ext, grid, st, a);
-    if (NW == 12) return launch_fused3d_nw<12>(al, uni, ext, grid, st, a);
-    return launch_fused3d_nw<16>(al, uni, ext, grid, st, a);
+    if (NW == 16 && uni && !ext) {
+        // sixteen wavefronts leave 128 VGPRs per lane: enough for the x-uniform variant without 'extend' only (the
+        // other sixteen-wavefront variants spilled 76-203 bytes per lane and are not instantiated: the planner
+        // gives them twelve)
+        if (al) hipLaunchKernelGGL((k_fused3d<16, true, true, false>), grid, dim3(16 * 64, 1, 1), 0, st, a);
+        else    hipLaunchKernelGGL((k_fused3d<16, false, true, false>), grid, dim3(16 * 64, 1, 1), 0, st, a);
+        return 0;
+    }
+    if (NW != 12) return 1;
+    return launch_fused3d_nw<12>(al, uni, ext, grid, st, a);
 }
 
 // ---- general 3-D fused launch (every coefficient array x-uniform) --------------------------------
@@ -42,22 +49,9 @@ static void launch_fused3dg_nw(bool al, bool ext, dim3 grid, hipStream_t st, con
 
 int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st, const Fused3GArgs &a)
 {
-    if (NW == 8) launch_fused3dg_nw<8>(al, ext, grid, st, a);
-    else if (NW == 16) launch_fused3dg_nw<16>(al, ext, grid, st, a);
-    else launch_fused3dg_nw<12>(al, ext, grid, st, a);
-    return 0;
-}
-
-// two sweeps per pass, x-uniform coefficients, no 'extend' (xinv_fused3d2.h)
-int xinv_launch_fused3d2(int NW, bool al, dim3 grid, hipStream_t st, const Fused3Args &a)
-{
-    if (NW == 12) {
-        if (al) hipLaunchKernelGGL((k_fused3d2<12, true>), grid, dim3(12 * 64, 1, 1), 0, st, a);
-        else    hipLaunchKernelGGL((k_fused3d2<12, false>), grid, dim3(12 * 64, 1, 1), 0, st, a);
-    } else if (NW == 8) {
-        if (al) hipLaunchKernelGGL((k_fused3d2<8, true>), grid, dim3(8 * 64, 1, 1), 0, st, a);
-        else    hipLaunchKernelGGL((k_fused3d2<8, false>), grid, dim3(8 * 64, 1, 1), 0, st, a);
-    } else return 1;
+    if (NW == 8) launch_fused3dg_nw<8>(al, ext, grid, st, a);      // (sixteen wavefronts: 128 VGPRs, spills -- not instantiated)
+    else if (NW == 12) launch_fused3dg_nw<12>(al, ext, grid, st, a);
+    else return 1;
     return 0;
 }
 
