@@ -15,7 +15,7 @@ def test_no_scalar_load_of_mutable_memory_without_invalidate():
     rows, bad = smem_audit.audit(os.path.join(ROOT, 'build', 'obj'))
     assert len(rows) > 200, 'the audit saw only %d kernels' % len(rows)
     assert not bad, 'scalar loads outside the argument segment without s_dcache_inv first: %r' % bad[:5]
-    # the only kernels that use the scalar unit for solver data are the ones written to (k_pipe2d, k_pipe3d: per-row
-    # records, behind their s_dcache_inv)
+    # the only kernels that use the scalar unit for solver data are the ones written to (k_pipe2d, k_pipe3d,
+    # k_fusedbih: per-row records, behind their s_dcache_inv)
     users = sorted({name.split('<')[0].replace('void ', '') for _, name, d, ok in rows if d['nonkarg']})
-    assert users == ['k_pipe2d', 'k_pipe3d'], users
+    assert users == ['k_fusedbih', 'k_pipe2d', 'k_pipe3d'], users

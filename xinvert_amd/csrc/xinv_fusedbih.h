@@ -27,6 +27,7 @@
 // nine colour launches: bitwise equal results.
 #pragma once
 #include "xinv_fused.h"
+#include "xinv_pipe2d.h"      /* xinv_cdouble_ptr: loads through the scalar unit */
 
 #define XINV_BIH_OWN(per) ((per) ? 159 : 165)   /* owned columns: lanes 3..57 (5..57 when periodic) x 3 */
 
@@ -106,7 +107,50 @@ struct FusedBihArgs {
     const long long *lagp_xcnt;
     int lagp_NB, lagp_K;
     unsigned lagp_tag;
+    const double *rowf;        // per-row records [nbatch][yc][XINV_BIH_RW] (k_row_factor_bih), read through the scalar unit
 };
+
+// Per-row record of the one-pass kernel (round 3): A..I of the row, the row's relaxation factor
+// -optArg / denominator (numbas.py:1474-1477: every operand is a per-row value here) and the row part of the update
+// predicate as an all-ones / zero word -- evaluated once per solve by k_row_factor_bih (the expression the kernel used
+// per row and sweep: same bits) and read through the scalar unit one row ahead of its use.  Until then every row
+// update began with nine dependent vector loads of the coefficients and an IEEE divide, and the VALU sat idle 60 %
+// of the time (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.40 at one wavefront per SIMD).
+#define XINV_BIH_RW 12
+#ifndef XINV_BIH_REC
+#define XINV_BIH_REC 1
+#endif
+
+struct RowFactorBihArgs {
+    const double *c[9];
+    int64_t sc[9];
+    int64_t yc, xc;
+    XinvScal sc_;
+    double *rowf;
+};
+
+#ifdef XINV_AUX_KERNELS
+__global__ __launch_bounds__(256) void k_row_factor_bih(RowFactorBihArgs a)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (j >= a.yc) return;
+    const double u = a.sc_.undef;
+    double cs[9];
+    bool rowok = (j >= 2 && j <= a.yc - 3);              // rows 0, 1, yc-2, yc-1 are never updated
+#pragma unroll
+    for (int q = 0; q < 9; q++) { cs[q] = a.c[q][m * a.sc[q] + j * a.xc]; rowok = rowok && (cs[q] != u); }
+    const double rq = -a.sc_.optArg / ((cs[0]*a.sc_.ratioSSr + cs[2]) * 6.0 +
+                                         cs[1]*a.sc_.ratioSqr / 4.0 +
+                                       -(cs[3]*a.sc_.ratioSqr + cs[5]) * 2.0 * a.sc_.delxSqr +
+                                         cs[8]*a.sc_.delxSSr);
+    double *f = a.rowf + (m * a.yc + j) * XINV_BIH_RW;
+#pragma unroll
+    for (int q = 0; q < 9; q++) f[q] = cs[q];
+    f[9] = rq;
+    f[10] = rowok ? __longlong_as_double(-1LL) : 0.0;
+    f[11] = 0.0;
+}
+#endif
 
 #ifndef XINV_BIH_MINWAVES
 #define XINV_BIH_MINWAVES 2
@@ -115,6 +159,9 @@ template <bool PER, bool ZBE>
 __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArgs a)
 {
     constexpr int D = 9;
+#if XINV_BIH_REC
+    xinv_fresh_scalar_cache();                         // (the per-row records come through the scalar unit: DESIGN.md 4.8)
+#endif
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && xinv_ctl_done(ctl)) return;
@@ -134,6 +181,12 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
         wt = a.tile_list[m * a.ntl + wt];
         active = wt >= 0;
     }
+#if XINV_BIH_REC
+    // the tile is the wavefront's: its index in an SGPR makes every row quantity below scalar (row bases as SGPR
+    // pairs, the march's compares on the scalar unit, the record loads s_loads)
+    wt = __builtin_amdgcn_readfirstlane(active ? wt : 0);
+    active = __builtin_amdgcn_readfirstlane((int)active) != 0;
+#endif
     const int rb = active ? wt / a.nstrip : 0, strip = active ? wt - rb * a.nstrip : 0;
     const int64_t xc = a.xc, yc = a.yc;
     const int64_t y0 = (int64_t)rb * a.RB;
@@ -172,6 +225,25 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
         for (int q = 0; q < 9; q++) cp[q] = a.c[q] + m * a.sc[q];
         const double *pJ = a.c[9] + m * a.sc[9];
 
+#if XINV_BIH_REC
+        // rows as 32-bit scalars (clamps on the scalar unit: 64-bit compares are VALU instructions on this target, and
+        // each one a round trip VALU -> scalar unit), the lane's columns as 32-bit byte offsets: every access is
+        // `uniform row base (SGPR pair) + 32-bit lane offset`, no 64-bit address arithmetic per load
+        typedef int row_t;
+        const int yci = (int)yc;
+        unsigned boff[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) boff[k] = (unsigned)lcol[k] * 8u;
+        auto load_row = [&](const double *base, int r) {
+            const int rr = min(max(r, 0), yci - 1);
+            const char *row = reinterpret_cast<const char *>(base + (int64_t)rr * xc);
+            Tri t;
+#pragma unroll
+            for (int k = 0; k < 3; k++) t.v[k] = *reinterpret_cast<const double *>(row + boff[k]);
+            return t;
+        };
+#else
+        typedef int64_t row_t;
         auto load_row = [&](const double *base, int64_t r) {
             const int64_t rr = r < 0 ? 0 : (r > yc - 1 ? yc - 1 : r);
             const double *row = base + rr * xc;
@@ -180,7 +252,22 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
             for (int k = 0; k < 3; k++) t.v[k] = row[lcol[k]];
             return t;
         };
+#endif
 
+#ifndef XINV_BIH_VSCAL
+#define XINV_BIH_VSCAL XINV_BIH_REC
+#endif
+        // The solve's scalars in VECTOR registers (every lane the same value): with them, the records, the lane masks and
+        // the row pointers in SGPRs the compiler ran out (106) and re-read kernel arguments from memory, waiting for
+        // each, a dozen times per group of three rows.
+        XinvScal scl = a.sc_;
+#if XINV_BIH_VSCAL
+        asm("" : "+v"(scl.ratioSSr), "+v"(scl.ratioSqr), "+v"(scl.delxSqr), "+v"(scl.delxTr), "+v"(scl.ratio),
+                 "+v"(scl.delxSSr), "+v"(scl.ratioQtr));
+        double uv = u;
+        asm("" : "+v"(uv));
+#define u uv
+#endif
         Tri W[D];
 #pragma unroll
         for (int t = 0; t < D; t++) { W[t].v[0] = 0.0; W[t].v[1] = 0.0; W[t].v[2] = 0.0; }
@@ -188,7 +275,29 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
 #pragma unroll
         for (int t = 0; t < 3; t++) Jst[t] = W[0];
 
+#if XINV_BIH_REC
+        struct Rec { double cs[9]; double rq; double rok; };
+        const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(a.rowf + m * yc * XINV_BIH_RW);
+        // the record of row j (clamped: rows outside 2 .. yc-3 carry a zero predicate and are left alone)
+        auto ldrec = [&](int j) {
+            const int jj = min(max(j, 0), (int)yc - 1);
+            const xinv_cdouble_ptr pr = rowf + (int64_t)jj * XINV_BIH_RW;
+            Rec R;
+#pragma unroll
+            for (int q = 0; q < 9; q++) R.cs[q] = pr[q];
+            R.rq = pr[9]; R.rok = pr[10];
+            return R;
+        };
+#endif
         // the three column colours of row j (window slot SJ), forcing row Jt
+#if XINV_BIH_REC
+        auto upd_row = [&](auto sjtag, int, const Tri &Jt, const Rec &R) {
+            constexpr int SJ = decltype(sjtag)::value;
+            constexpr int SM2 = (SJ + 7) % D, SM1 = (SJ + 8) % D, SP1 = (SJ + 1) % D, SP2 = (SJ + 2) % D;
+            const double (&cs)[9] = R.cs;
+            const double rq = R.rq;
+            const bool rowok = __double_as_longlong(R.rok) != 0;
+#else
         auto upd_row = [&](auto sjtag, int64_t j, const Tri &Jt) {
             constexpr int SJ = decltype(sjtag)::value;
             constexpr int SM2 = (SJ + 7) % D, SM1 = (SJ + 8) % D, SP1 = (SJ + 1) % D, SP2 = (SJ + 2) % D;
@@ -203,6 +312,7 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
                                                  cs[1]*a.sc_.ratioSqr / 4.0 +
                                                -(cs[3]*a.sc_.ratioSqr + cs[5]) * 2.0 * a.sc_.delxSqr +
                                                  cs[8]*a.sc_.delxSSr);
+#endif
             double em2[7], em1[7], ep1[7], ep2[7];
             bih_ext(W[SM2], em2); bih_ext(W[SM1], em1); bih_ext(W[SP1], ep1); bih_ext(W[SP2], ep2);
             double fm2[2] = {0.0, 0.0}, fp2[2] = {0.0, 0.0};
@@ -223,18 +333,26 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
                     e0[o], e0[o + 1], e0[o - 1], e0[o + 2], e0[o - 2], r0_b,
                     em1[o], em1[o + 1], em1[o - 1], em2[o], em2[o + 2], m2_b,
                     cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[7], cs[8],
-                    Jt.v[k], rq, upd[k] && rowok && (Jt.v[k] != u), edge[k], a.sc_);
+                    Jt.v[k], rq, upd[k] && rowok && (Jt.v[k] != u), edge[k], scl);
             }
         };
-        auto retire = [&](auto stag, int64_t j) {
+        auto retire = [&](auto stag, row_t j) {
             constexpr int SL = decltype(stag)::value;
-            if (j < y0 || j >= y1) return;
+            if (j < (row_t)y0 || j >= (row_t)y1) return;
+#if XINV_BIH_REC
+            char *row = reinterpret_cast<char *>(dstS + (int64_t)j * xc);
+#else
             double *row = dstS + j * xc;
+#endif
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const double v = W[SL].v[k];
                 if (own[k]) {
+#if XINV_BIH_REC
+                    *reinterpret_cast<double *>(row + boff[k]) = v;
+#else
                     row[lcol[k]] = v;
+#endif
                     if (v != u) { acc[0] += fabs(v); cnt[0] += 1; }
                 }
             }
@@ -246,16 +364,19 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
         // r = base + 2 = 2 (mod 3), rows r-2 / r-4 / r-6 are slots 6 / 4 / 2 and rows r-8..r-6
         // (slots 0..2) retire.  The next group's three rows and forcing rows are requested before
         // the updates of this one.
-        const int64_t rstart = y0 - 3, rlast = y1 + 7;           // row j retires by step j + 8
+        const row_t rstart = (row_t)y0 - 3, rlast = (row_t)y1 + 7;   // row j retires by step j + 8
 #ifndef XINV_BIH_PREFETCH
-#define XINV_BIH_PREFETCH 0
+#define XINV_BIH_PREFETCH XINV_BIH_REC
 #endif
 #if XINV_BIH_PREFETCH
         Tri N0 = load_row(srcS, rstart), N1 = load_row(srcS, rstart + 1), N2 = load_row(srcS, rstart + 2);
 #endif
         Jst[0] = load_row(pJ, rstart + 2 - 2); Jst[1] = load_row(pJ, rstart + 2 - 4); Jst[2] = load_row(pJ, rstart + 2 - 6);
-        for (int64_t base = rstart; base <= rlast; base += 3) {
-            const int64_t r = base + 2;
+#if XINV_BIH_REC
+        Rec R0 = ldrec(rstart + 2 - 2);
+#endif
+        for (row_t base = rstart; base <= rlast; base += 3) {
+            const row_t r = base + 2;
 #pragma unroll
             for (int t = 0; t < 6; t++) W[t] = W[t + 3];
 #if XINV_BIH_PREFETCH
@@ -267,15 +388,26 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
             const Tri J0 = Jst[0], J1 = Jst[1], J2 = Jst[2];
 #endif
             Jst[0] = load_row(pJ, r + 3 - 2); Jst[1] = load_row(pJ, r + 3 - 4); Jst[2] = load_row(pJ, r + 3 - 6);
+#if XINV_BIH_REC
+            // each row's record is asked for one row update (~1000 cycles of arithmetic) before it is used
+            const Rec R1 = ldrec(r - 4);
+            upd_row(std::integral_constant<int, 6>{}, r - 2, J0, R0);   // class 0
+            const Rec R2 = ldrec(r - 6);
+            upd_row(std::integral_constant<int, 4>{}, r - 4, J1, R1);   // class 1
+            R0 = ldrec(r + 3 - 2);
+            upd_row(std::integral_constant<int, 2>{}, r - 6, J2, R2);   // class 2
+#else
             upd_row(std::integral_constant<int, 6>{}, r - 2, J0);   // class 0
             upd_row(std::integral_constant<int, 4>{}, r - 4, J1);   // class 1
             upd_row(std::integral_constant<int, 2>{}, r - 6, J2);   // class 2
+#endif
             retire(std::integral_constant<int, 0>{}, r - 8);
             retire(std::integral_constant<int, 1>{}, r - 7);
             retire(std::integral_constant<int, 2>{}, r - 6);
         }
     }
 
+#undef u
     if (a.no_ctl) return;
     xinv_norm_tail<1>(a, acc, cnt, wave, lane, NB, T, tag, ctl, m);
 }

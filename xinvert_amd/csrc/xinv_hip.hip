@@ -206,6 +206,15 @@ static int plan_fusedbih(const Problem &p, const xinv_options &opt, Workspace *w
             FusedBihArgs dummy; memset(&dummy, 0, sizeof dummy);
             xinv_launch_fusedbih(false, false, dim3(1), st, dummy, &occ);
         }
+        {   // per-row records (A..I, relaxation factor, row predicate), once per solve: xinv_fusedbih.h
+            rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)p.nbatch * p.yc * XINV_BIH_RW * sizeof(double));
+            if (rc) return rc;
+            RowFactorBihArgs ra;
+            memset(&ra, 0, sizeof ra);
+            for (int q = 0; q < 9; q++) { ra.c[q] = p.c[q]; ra.sc[q] = p.sc[q]; }
+            ra.yc = p.yc; ra.xc = p.xc; ra.sc_ = p.sc_; ra.rowf = (double *)ws->d_rowf;
+            hipLaunchKernelGGL(k_row_factor_bih, dim3((unsigned)cdiv(p.yc, 256), (unsigned)p.nbatch, 1), dim3(256), 0, st, ra);
+        }
         int bestRB = 3; double best = 1e300;
         for (int RB = 3; RB <= 192; RB += 3) {
             if (opt.rows_per_tile > 0 && RB != std::max(3, (opt.rows_per_tile / 3) * 3)) continue;

@@ -264,6 +264,7 @@ static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, 
     a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
     a.force = force; a.no_ctl = no_ctl;
     a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
+    a.rowf = (const double *)ws->d_rowf;
     const size_t NBmax = (size_t)pl.nsg;
     a.psum = (unsigned long long *)ws->partials;
     if (pl.skip) {                                   // fully masked tiles are left out (plan_tile_skip)
