@@ -32,7 +32,9 @@ UNITS = [
     ('xinv_tu_pipe2d_gen', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=1']),
     ('xinv_tu_fused9', 'xinv_tu_fused9.hip', []),
     ('xinv_tu_fused3d', 'xinv_tu_fused3d.hip', []),
-    ('xinv_tu_bih', 'xinv_tu_bih.hip', []),
+    # the biharmonic update is 51 dependent-chain flops per point and colour stage at one or two wavefronts per SIMD: the
+    # default (occupancy-first) scheduler serialises the chains; max-ILP interleaves them (Munk 2000x2000: 1.04 -> 1.15e11)
+    ('xinv_tu_bih', 'xinv_tu_bih.hip', ['-mllvm', '-amdgpu-sched-strategy=max-ilp']),
     ('xinv_tu_small2d', 'xinv_tu_small2d.hip', []),
 ]
 SOURCES = sorted({u[1] for u in UNITS})

@@ -234,12 +234,20 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
         unsigned boff[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) boff[k] = (unsigned)lcol[k] * 8u;
+        // (a raw buffer resource per row -- base = the row, range = its bytes -- makes the access
+        //  `buffer_load_dwordx2 v, v_off, s[rsrc], 0 offen`: three scalar instructions per row instead of a 64-bit
+        //  vector add per load; no limit on the size of the slice)
+        const int rowbytes = (int)(xc * 8);
         auto load_row = [&](const double *base, int r) {
             const int rr = min(max(r, 0), yci - 1);
-            const char *row = reinterpret_cast<const char *>(base + (int64_t)rr * xc);
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(base + (int64_t)rr * xc), 0, rowbytes, 0x00020000);
             Tri t;
 #pragma unroll
-            for (int k = 0; k < 3; k++) t.v[k] = *reinterpret_cast<const double *>(row + boff[k]);
+            for (int k = 0; k < 3; k++) {
+                const auto w = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)boff[k], 0, 0);
+                t.v[k] = __hiloint2double((int)w[1], (int)w[0]);
+            }
             return t;
         };
 #else
@@ -336,27 +344,41 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
                     Jt.v[k], rq, upd[k] && rowok && (Jt.v[k] != u), edge[k], scl);
             }
         };
+#if XINV_BIH_REC
+        unsigned sof[3];                                     // store offsets: a column the lane does not own lies beyond the
+#pragma unroll                                               // row's range and the store is dropped (no branch)
+        for (int k = 0; k < 3; k++) sof[k] = own[k] ? boff[k] : 0xffffffffu;
         auto retire = [&](auto stag, row_t j) {
             constexpr int SL = decltype(stag)::value;
             if (j < (row_t)y0 || j >= (row_t)y1) return;
-#if XINV_BIH_REC
-            char *row = reinterpret_cast<char *>(dstS + (int64_t)j * xc);
+            const __amdgpu_buffer_rsrc_t rsd =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(dstS + (int64_t)j * xc), 0, rowbytes, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double v = W[SL].v[k];
+                typedef unsigned xinv_v2u_ __attribute__((__vector_size__(8)));
+                const xinv_v2u_ tv = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+                __builtin_amdgcn_raw_buffer_store_b64(tv, rsd, (int)sof[k], 0, 0);
+                const bool c = own[k] && (v != u);
+                acc[0] += c ? fabs(v) : 0.0;                 // (+0.0 leaves a sum of magnitudes unchanged bit for bit)
+                cnt[0] += c ? 1 : 0;
+            }
+        };
 #else
+        auto retire = [&](auto stag, row_t j) {
+            constexpr int SL = decltype(stag)::value;
+            if (j < (row_t)y0 || j >= (row_t)y1) return;
             double *row = dstS + j * xc;
-#endif
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const double v = W[SL].v[k];
                 if (own[k]) {
-#if XINV_BIH_REC
-                    *reinterpret_cast<double *>(row + boff[k]) = v;
-#else
                     row[lcol[k]] = v;
-#endif
                     if (v != u) { acc[0] += fabs(v); cnt[0] += 1; }
                 }
             }
         };
+#endif
 
         // Rows y0-3 .. y1+7 stream through the window three at a time.  The window is shifted by
         // three rows per group (18 register moves against ~900 instructions of updates), so the
