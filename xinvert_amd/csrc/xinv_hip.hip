@@ -215,16 +215,24 @@ static int plan_fusedbih(const Problem &p, const xinv_options &opt, Workspace *w
             ra.yc = p.yc; ra.xc = p.xc; ra.sc_ = p.sc_; ra.rowf = (double *)ws->d_rowf;
             hipLaunchKernelGGL(k_row_factor_bih, dim3((unsigned)cdiv(p.yc, 256), (unsigned)p.nbatch, 1), dim3(256), 0, st, ra);
         }
+        // Time of a launch ~ (steps per tile) x f(workgroups per CU).  f measured on the round-3 kernel at 2000 x 2000
+        // (profiles/r03_bih_rework.txt: rows 9 .. 33): one workgroup per CU 1.0; the second costs little (the
+        // wavefronts fill each other's dependency stalls): 1.2 just above one per CU, 1.35 at two; a third 1.6 .. 1.75.
+        auto wg_cost = [](double x) {
+            if (x <= 1.0) return 1.0;
+            if (x <= 2.0) return 1.15 + 0.10 * x;
+            return 1.30 + 0.15 * x;
+        };
         int bestRB = 3; double best = 1e300;
         for (int RB = 3; RB <= 192; RB += 3) {
             if (opt.rows_per_tile > 0 && RB != std::max(3, (opt.rows_per_tile / 3) * 3)) continue;
             const int64_t nrb = cdiv(p.yc, RB);
             const int64_t wgs = (int64_t)cdiv((int64_t)nstrip * nrb, 4) * p.nbatch;
-            const int64_t cap = 256 * (int64_t)std::min(occ, 3);
+            const int n = std::min(occ, 3);
+            const int64_t cap = 256 * (int64_t)n;
             const int64_t rounds = cdiv(wgs, cap);
             const int64_t w_last = wgs - (rounds - 1) * cap;
-            const double last = (w_last <= 256) ? 1.3 : (double)cdiv(w_last, 256);
-            const double cost = ((double)(rounds - 1) * std::min(occ, 3) + last) * (double)(RB + 11 + 8);
+            const double cost = ((double)(rounds - 1) * wg_cost((double)n) + wg_cost((double)w_last / 256.0)) * (double)(RB + 11 + 8);
             if (cost < best) { best = cost; bestRB = RB; }
         }
         pl.RY = bestRB;
