@@ -21,3 +21,5 @@ python tools/bench_small_batch.py 2>/dev/null | grep '^{' > gpurun_out/r03_small
 python tools/bench_frontend.py 2>/dev/null | grep invert_Poisson > gpurun_out/r03_frontend_end_to_end.txt; cat gpurun_out/r03_frontend_end_to_end.txt
 ( python tools/bench_host_pipeline.py c5 --members 15 --sweeps 200; python tools/bench_host_pipeline.py c4 --members 8 --sweeps 500 ) 2>/dev/null | grep '^{' > gpurun_out/r03_host_pipeline.txt; cut -c1-230 gpurun_out/r03_host_pipeline.txt
 bash tools/profile_headline.sh r03 > gpurun_out/r03_profile.log 2>&1; tail -5 gpurun_out/r03_profile.log | cut -c1-200
+# C3 (Stommel, Munk) kernel trace + SQ issue counters of the reworked biharmonic kernel
+bash tools/r03_run14.sh > gpurun_out/r03_profile_c3m.log 2>&1; tail -12 gpurun_out/r03_profile_c3m.log | cut -c1-160
