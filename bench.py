@@ -195,8 +195,10 @@ def kernel_name(kind, s):
     if s['path'] == 3:
         return 'k_small2d'
     if kind == 'bih2d':
-        return 'k_fusedbih (one pass per sweep, A..I per-row scalars)'
+        return 'k_fusedbih (one pass per sweep, A..I and the relaxation factor as per-row records)'
     if kind == 'std3d':
+        if K == 2:
+            return 'k_pipe3d (two sweeps per pass, one per group of eight wavefronts; x-uniform mask=%d)' % um
         return 'k_fused3d<K=%d, x-uniform mask=%d>' % (K, um)
     model = {'std2d': 'Std2D', 'gen2d': 'Gen2D'}[kind]
     if s.get('pipelined'):
@@ -524,6 +526,11 @@ def main():
             try:
                 traffic = json.load(open(tfile)).get(('std2d_pipe_um%d' % s['xuniform_mask']) if s.get('pipelined')
                                                      else 'std2d_spl%d_um%d' % (spl, s['xuniform_mask']))
+            except Exception:
+                traffic = None
+        elif os.path.exists(tfile) and a.config == 'c4' and nb == 64 and s.get('pipelined') and s['xuniform_mask'] == 31:
+            try:                                                 # (the 64-member launch profiled by tools/profile_headline.sh)
+                traffic = json.load(open(tfile)).get('gen2d_pipe_um31_fr_c4x64')
             except Exception:
                 traffic = None
         roof['traffic'] = traffic
