@@ -458,13 +458,22 @@ __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &i
 // EVERY workgroup: 32.8 -> 28.5 us per launch at 3600x1800.  NWV = wavefronts per workgroup.
 #define XINV_PW 3          /* words per partial */
 // publish this workgroup's partial of each of the K fused sweeps (no wait, any arrival order)
-template <int K, int NWV>
+// (EXTS: the LDS scratch -- NWV * K * 16 bytes, + 8 for the reducer -- is the caller's `scr` instead of static
+//  arrays of its own: k_pipe3d's rings fill the 160 KiB to the byte and lend a finished buffer)
+template <int K, int NWV, bool EXTS = false>
 __device__ __forceinline__ void xinv_norm_publish(const double (&acc)[K], const int (&cnt)[K],
                                                   int wave, int lane, int NB, int T, unsigned tag,
-                                                  unsigned long long *pw)
+                                                  unsigned long long *pw, char *scr = nullptr)
 {
-    __shared__ double ls[NWV][K];
-    __shared__ long long lcn[NWV][K];
+    double (*ls)[K]; long long (*lcn)[K];
+    if constexpr (EXTS) {
+        ls = reinterpret_cast<double (*)[K]>(scr);
+        lcn = reinterpret_cast<long long (*)[K]>(scr + sizeof(double) * NWV * K);
+    } else {
+        __shared__ double ls_[NWV][K];
+        __shared__ long long lcn_[NWV][K];
+        ls = ls_; lcn = lcn_;
+    }
 #pragma unroll
     for (int s = 0; s < K; s++) {
         double ws = xinv_wave_sum(acc[s]);
@@ -488,14 +497,23 @@ __device__ __forceinline__ void xinv_norm_publish(const double (&acc)[K], const 
 
 // one workgroup of NWV wavefronts: wait until the K * NB partials carry `tag`, add them in a fixed
 // order, apply the reference's stop rule once per fused sweep, advance ctl->seq
-template <int K, int NWV>
+template <int K, int NWV, bool EXTS = false>
 __device__ __forceinline__ void xinv_norm_reduce(int wave, int lane, int NB, unsigned tag,
                                                  unsigned long long *pw, XinvCtl *ctl, const XinvStop &stop,
-                                                 double xsum, long long xcnt)
+                                                 double xsum, long long xcnt, char *scr = nullptr)
 {
-    __shared__ double ls[NWV][K];
-    __shared__ long long lcn[NWV][K];
-    __shared__ unsigned s_timeout;
+    double (*ls)[K]; long long (*lcn)[K]; unsigned *s_timeout_p;
+    if constexpr (EXTS) {
+        ls = reinterpret_cast<double (*)[K]>(scr);
+        lcn = reinterpret_cast<long long (*)[K]>(scr + sizeof(double) * NWV * K);
+        s_timeout_p = reinterpret_cast<unsigned *>(scr + 2 * sizeof(double) * NWV * K);
+    } else {
+        __shared__ double ls_[NWV][K];
+        __shared__ long long lcn_[NWV][K];
+        __shared__ unsigned s_timeout_;
+        ls = ls_; lcn = lcn_; s_timeout_p = &s_timeout_;
+    }
+#define s_timeout (*s_timeout_p)
     if (threadIdx.x == 0) s_timeout = 0u;
     const unsigned long long hi = (unsigned long long)tag << 32;
     // reducer: item i = s * NB + t ; thread tid takes i = tid, tid + NT, ... four at a time so
@@ -575,19 +593,20 @@ __device__ __forceinline__ void xinv_norm_reduce(int wave, int lane, int NB, uns
         }
         ctl->seq = tag + 1u;
     }
+#undef s_timeout
 }
 
-template <int K, int NWV>
+template <int K, int NWV, bool EXTS = false>
 __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const int (&cnt)[K],
                                                    int wave, int lane, int NB, int T, unsigned tag,
                                                    unsigned long long *pw, XinvCtl *ctl,
                                                    const XinvStop &stop,
-                                                   double xsum = 0.0, long long xcnt = 0)
+                                                   double xsum = 0.0, long long xcnt = 0, char *scr = nullptr)
 {
-    xinv_norm_publish<K, NWV>(acc, cnt, wave, lane, NB, T, tag, pw);
+    xinv_norm_publish<K, NWV, EXTS>(acc, cnt, wave, lane, NB, T, tag, pw, scr);
     if (blockIdx.x != gridDim.x - 1) return;
     __syncthreads();                                   // (the publish step's LDS scratch is reused by the reducer)
-    xinv_norm_reduce<K, NWV>(wave, lane, NB, tag, pw, ctl, stop, xsum, xcnt);
+    xinv_norm_reduce<K, NWV, EXTS>(wave, lane, NB, tag, pw, ctl, stop, xsum, xcnt, scr);
 }
 
 // The extra workgroup of a lagged launch (blockIdx.x == nwg): norm + stop rule of the PREVIOUS pass,

@@ -349,7 +349,8 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND &&
             (opt.sweeps_per_launch == 2 || (opt.sweeps_per_launch == 0 && k2_auto)) &&
             opt.rows_per_tile == 0 && p.stop.mxLoop >= 1 &&
-            p.zc * p.yc * 64 < ((int64_t)1 << 31)) {                      // (32-bit offsets into the record table)
+            p.zc * p.yc * 64 < ((int64_t)1 << 31) &&                      // (32-bit offsets into the record table)
+            n * 8 < ((int64_t)1 << 31)) {                                 // (k_pipe3d addresses a volume through buffer resources: below 2 GiB)
             pl.K2 = true;
             pl.K = 2;
             pl.nsg2 = (int)cdiv(p.xc, 120);

@@ -121,7 +121,20 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(a.rowf + m * a.srowf);
 
     __shared__ double xch[2][2][NW][2][64];              // [step parity][as loaded | red-updated][wave][top | bottom row][lane]
-    __shared__ double2 ring[2][G][RR][64];               // [slot][wave of the group][row][lane]: planes with sweep 1 complete
+#ifndef XINV_P3_FRING
+#define XINV_P3_FRING 0           /* MEASURED AND NOT KEPT (round 3, profiles/r03_pipe3d_fring.txt).  1: the forcing rides the
+                                     ring with S, as in k_pipe2d's FR variant -- group 1 runs three planes behind group 0 and
+                                     its own forcing requests have mostly left the L2 by then (21.5 B of HBM-side traffic per
+                                     point-sweep against 12 + halo).  Bit-exact, reads -24 %, xch + ring = 160 KiB to the byte
+                                     (the norm tail borrows xch) -- and 15 % SLOWER: at sixteen wavefronts the kernel has 128
+                                     VGPRs and no SGPR left, and the variant spills 48-104 bytes per lane in group 1's march
+                                     (C5 15 volumes 2.52 against 2.97e11). */
+#endif
+    // [wave of the group][row][slot][S (| forcing)][lane]: planes with sweep 1 complete.
+    // (laid out [wave][row][slot][S | forcing][lane]: every access of a wavefront is ONE base register + an immediate
+    //  offset below 64 KiB -- with the slot outermost the last quarter lay beyond the 16-bit offset and cost a second
+    //  base register, which the 128-register budget did not have: spills)
+    __shared__ double2 ring[G][RR][2][1 + XINV_P3_FRING][64];
 
     double nsx = 0.0, nsy = 0.0;                         // norm share per lane and column (un-owned lanes discarded below)
     int nnx = 0, nny = 0;
@@ -134,9 +147,40 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         fw[rr][0] = fw[rr][1] = pfS[rr] = pfF[rr] = make_double2(0.0, 0.0);
     }
 
-    auto plane_off = [&](int p, int rr) {                // element offset of the lane's row in plane p (clamped)
+#ifndef XINV_P3_NT
+#define XINV_P3_NT 1
+#endif
+    // Every array of the member is addressed through a raw buffer resource (base, bytes of the volume) with the row as
+    // the instruction's scalar offset and the lane's columns as its 32-bit vector offset -- no 64-bit vector address per
+    // load in flight (twelve VGPRs of the 128 this kernel has), stores of columns a lane does not own dropped by range
+    // (the planner admits volumes below 2 GiB).  S is read once and written once: streamed (non-temporal), so that the
+    // L2 keeps what is asked for again (measured: -7.5 % fetched bytes, +3 %).
+    const int vol_bytes = (int)((int64_t)zc * yc * xc * 8);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)srcS, 0, vol_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)pF, 0, vol_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)dstS, 0, vol_bytes, 0x00020000);
+    const unsigned lo0 = (unsigned)lc.l0 * 8u, lo1 = (unsigned)lc.l1 * 8u;
+    const unsigned so0 = lc.use_x ? (unsigned)st0 * 8u : 0xffffffffu, so1 = lc.use_y ? (unsigned)(st0 + 1) * 8u : 0xffffffffu;
+    constexpr int NTAUX = XINV_P3_NT ? 2 : 0;            // cache-policy operand: bit 1 = nt on this target
+    auto ldrow = [&](__amdgpu_buffer_rsrc_t rs, int soff, auto auxtag) {
+        constexpr int AUX = decltype(auxtag)::value;
+        double2 v;
+        if (AL) {
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo0, soff, AUX);
+            v.x = __hiloint2double((int)t[1], (int)t[0]); v.y = __hiloint2double((int)t[3], (int)t[2]);
+        } else {
+            const auto t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lo0, soff, AUX);
+            const auto t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lo1, soff, AUX);
+            v.x = __hiloint2double((int)t0[1], (int)t0[0]); v.y = __hiloint2double((int)t1[1], (int)t1[0]);
+        }
+        return v;
+    };
+    auto ldS = [&](int soff) { return ldrow(rsS, soff, std::integral_constant<int, NTAUX>{}); };
+    auto ldF = [&](int soff) { return ldrow(rsF, soff, std::integral_constant<int, 0>{}); };
+    const int rowbytes = (int)(xc * 8);
+    auto plane_off = [&](int p, int rr) {                // byte offset of the lane's row in plane p (clamped), a scalar
         const int pr = p > zc - 1 ? zc - 1 : (p < 0 ? 0 : p);
-        return ((int64_t)pr * yc + jr[rr]) * xc;
+        return (pr * yc + jr[rr]) * rowbytes;
     };
     // the (plane, row) record through the scalar unit: {A[k+1], A[k], B[j+1], B[j], C, factor, predicate, -}
     struct Rec { double aP, a0, bP, b0, c, rq; unsigned long long rok; };
@@ -188,12 +232,17 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         for (int rr = 0; rr < RR; rr++) {
             if (GRP == 0) {
                 sw[rr][U] = pfS[rr];
-                pfS[rr] = ld2<AL>(srcS, plane_off(r + 1, rr), lc);
+                pfS[rr] = ldS(plane_off(r + 1, rr));
             } else {
-                sw[rr][U] = ring[U & 1][gw][rr][lane];
+                sw[rr][U] = ring[gw][rr][U & 1][0][lane];
             }
             fw[rr][S1 & 1] = pfF[rr];
-            pfF[rr] = ld2<AL>(pF, plane_off(r, rr), lc);
+#if XINV_P3_FRING
+            if (GRP == 0) pfF[rr] = ldF(plane_off(r, rr));
+            else pfF[rr] = ring[gw][rr][U & 1][1][lane];
+#else
+            pfF[rr] = ldF(plane_off(r, rr));
+#endif
         }
         // as loaded: what the neighbouring wavefronts' next red half-sweep reads of the first / last row
         xch[bw][0][wave][0][lane] = XROW(0) ? sw[0][U].y : sw[0][U].x;
@@ -231,13 +280,28 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 #pragma unroll
             for (int rr = 0; rr < RR; rr++) {
                 const double2 t = sw[rr][S2];
-                if (GRP == 0) ring[U & 1][gw][rr][lane] = t;
+                if (GRP == 0) {
+                    ring[gw][rr][U & 1][0][lane] = t;
+#if XINV_P3_FRING
+                    ring[gw][rr][U & 1][1][lane] = fw[rr][S2 & 1];   // the forcing of the leaving plane r-2 (still in the window)
+#endif
+                }
                 if (pin && row_use[rr]) {                // wave-uniform: an owned row of an owned plane
                     xinv_norm_row(nsx, nsy, nnx, nny, t.x, t.y, u);
                     if (GRP == 1) {
-                        double *d = dstS + ((int64_t)kk * yc + (j0 + rr)) * xc + st0;
-                        if (AL) { if (lc.use_x) *reinterpret_cast<double2 *>(d) = t; }
-                        else { if (lc.use_x) d[0] = t.x; if (lc.use_y) d[1] = t.y; }
+                        const int doff = (kk * yc + (j0 + rr)) * rowbytes;
+                        typedef unsigned xinv_v4u_ __attribute__((__vector_size__(16)));
+                        typedef unsigned xinv_v2u_ __attribute__((__vector_size__(8)));
+                        if (AL) {                            // (use_x == use_y on aligned strips)
+                            const xinv_v4u_ tv = {(unsigned)__double2loint(t.x), (unsigned)__double2hiint(t.x),
+                                                  (unsigned)__double2loint(t.y), (unsigned)__double2hiint(t.y)};
+                            __builtin_amdgcn_raw_buffer_store_b128(tv, rsD, (int)so0, doff, NTAUX);
+                        } else {
+                            const xinv_v2u_ tx = {(unsigned)__double2loint(t.x), (unsigned)__double2hiint(t.x)};
+                            const xinv_v2u_ ty = {(unsigned)__double2loint(t.y), (unsigned)__double2hiint(t.y)};
+                            __builtin_amdgcn_raw_buffer_store_b64(tx, rsD, (int)so0, doff, NTAUX);
+                            __builtin_amdgcn_raw_buffer_store_b64(ty, rsD, (int)so1, doff, NTAUX);
+                        }
                     }
                 }
             }
@@ -255,10 +319,10 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         constexpr int GRP = decltype(gtag)::value;
         if (GRP == 0) {
 #pragma unroll
-            for (int rr = 0; rr < RR; rr++) pfS[rr] = ld2<AL>(srcS, plane_off(rstart, rr), lc);
+            for (int rr = 0; rr < RR; rr++) pfS[rr] = ldS(plane_off(rstart, rr));
         }
 #pragma unroll
-        for (int rr = 0; rr < RR; rr++) pfF[rr] = ld2<AL>(pF, plane_off(rstart - 1 - 3 * GRP, rr), lc);
+        for (int rr = 0; rr < RR; rr++) pfF[rr] = ldF(plane_off(rstart - 1 - 3 * GRP, rr));
         for (int gb = 0; gb <= gend; gb += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int Ug = decltype(utag)::value;                // global step mod D
@@ -284,6 +348,8 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         acc[0] = grp == 0 ? s : 0.0; acc[1] = grp == 1 ? s : 0.0;
         cnt[0] = grp == 0 ? n : 0;   cnt[1] = grp == 1 ? n : 0;
     }
-    xinv_norm_finalize<K, NW>(acc, cnt, wave, lane, NB, T, tag,
-                              a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop);
+    __syncthreads();                                     // (every wavefront is done with xch: the norm tail's scratch)
+    xinv_norm_finalize<K, NW, true>(acc, cnt, wave, lane, NB, T, tag,
+                                    a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop, 0.0, 0,
+                                    reinterpret_cast<char *>(&xch[0][0][0][0][0]));
 }
