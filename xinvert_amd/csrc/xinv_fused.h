@@ -1000,11 +1000,27 @@ __global__ __launch_bounds__(64) void k_skip_norm_tile(SkipNormArgs a)
         const int64_t c0 = (int64_t)strip * a.UW;
         const int64_t c1 = (c0 + a.UW < a.xc) ? c0 + a.UW : a.xc;
         const double *S = a.S + m * a.sS;
-        for (int64_t j = yu0; j < yu1; j++)
-            for (int64_t i = c0 + lane; i < c1; i += 64) {
-                const double v = S[j * a.xc + i];
-                if (v != a.undef) { acc += fabs(v); cnt++; }
+        // (four rows' loads in flight at a time, added in the same order as one by one: the loop was a chain of ~90
+        //  dependent memory round trips per tile, 35 us per solve at 3600x1800; a tile is at most 256 columns wide)
+        for (int64_t j = yu0; j < yu1; j += 4) {
+            double v[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t jj = (j + q < yu1) ? j + q : yu1 - 1;
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const int64_t i = c0 + lane + 64 * h;
+                    v[q][h] = (i < c1) ? S[jj * a.xc + i] : a.undef;
+                }
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (j + q < yu1) {
+#pragma unroll
+                    for (int h = 0; h < 4; h++)
+                        if (v[q][h] != a.undef) { acc += fabs(v[q][h]); cnt++; }
+                }
+        }
     }
     acc = xinv_wave_sum(acc);
     cnt = xinv_wave_sum_ll(cnt);

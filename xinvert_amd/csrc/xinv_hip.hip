@@ -693,7 +693,10 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         // poll the device stop flags about every 2 ms of sweeping (fused kernels run at roughly
         // 2e5 points per microsecond, the colour path at a quarter of that); launches issued after
         // a member has stopped are no-ops of a few microseconds each
-        const double rate = (pl.path == XINV_PATH_FUSED) ? 2.0e5 : 4.0e4;
+        // (round 3: the pipelined 2-D pass runs at 6-7e5 points per microsecond; with the round-1 constant a 500-sweep
+        //  solve at 3600x1800 was polled 18 times -- each poll ends a chunk: one-workgroup norm reduction of the lagged
+        //  launch + control-block copy, ~10 us of idle GPU -- 4 % of the solve)
+        const double rate = (pl.path != XINV_PATH_FUSED) ? 4.0e4 : (pl.pipe ? 6.0e5 : (is3d(p.kind) ? 2.5e5 : 3.0e5));
         const double est_us = std::max(4.0, (double)p.nbatch * (double)n * Kf / rate);
         check_every = (int)std::min(256.0, std::max(4.0, 2000.0 / est_us));
     }
