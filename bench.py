@@ -533,6 +533,12 @@ def main():
                 traffic = json.load(open(tfile)).get('gen2d_pipe_um31_fr_c4x64')
             except Exception:
                 traffic = None
+        if traffic is None and os.path.exists(tfile) and a.config == 'c5' and spl == 2:
+            try:                                                 # per point-sweep, from the 15-volume launch profiled by
+                det = json.load(open(tfile)).get('std3d_pipe3d_c5x15_detail')      # tools/r03_run15.sh, scaled to this launch
+                traffic = det['bytes_per_point_sweep'] * pts_per_launch if det else None
+            except Exception:
+                traffic = None
         roof['traffic'] = traffic
         roof['traffic_source'] = 'static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel variant (profiles/traffic.json), not read in this run'
         if traffic:

@@ -354,7 +354,7 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
             pl.K2 = true;
             pl.K = 2;
             pl.nsg2 = (int)cdiv(p.xc, 120);
-            pl.nrb2 = (int)cdiv(p.yc, 8 * XINV_P3_RR - 8);
+            pl.nrb2 = (int)cdiv(p.yc, XINV_P3_G * XINV_P3_RR - 8);
             {
                 // per-(plane, row) records of the x-uniform coefficients, relaxation factor and predicate: once per solve
                 const bool shared = (p.sc[0] == 0 && p.sc[1] == 0 && p.sc[2] == 0);

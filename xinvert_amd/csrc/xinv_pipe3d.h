@@ -33,6 +33,9 @@
 #ifndef XINV_P3_RR
 #define XINV_P3_RR 3              /* rows per wavefront */
 #endif
+#ifndef XINV_P3_G
+#define XINV_P3_G 8               /* wavefronts per group (two groups per workgroup) */
+#endif
 
 struct RowFactor3Args {
     const double *c[3];           // A, B, C

@@ -58,7 +58,7 @@ int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st, c
 // two sweeps per pass, pipelined across two groups of wavefronts (xinv_pipe3d.h)
 int xinv_launch_pipe3d(bool al, dim3 grid, hipStream_t st, const Fused3Args &a)
 {
-    constexpr int G = 8, RR = XINV_P3_RR;
+    constexpr int G = XINV_P3_G, RR = XINV_P3_RR;
     if (al) hipLaunchKernelGGL((k_pipe3d<G, RR, true>), grid, dim3(2 * G * 64, 1, 1), 0, st, a);
     else    hipLaunchKernelGGL((k_pipe3d<G, RR, false>), grid, dim3(2 * G * 64, 1, 1), 0, st, a);
     return 0;
