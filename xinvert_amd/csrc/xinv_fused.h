@@ -1064,7 +1064,15 @@ __global__ __launch_bounds__(256) void k_xuniform(XUniArgs a)
         const int64_t mm = row / a.yc, j = row - mm * a.yc;
         const unsigned long long *p = base + mm * a.stride[q] + j * a.xc;
         const unsigned long long first = p[0];
-        for (int64_t i = lane; i < a.xc; i += 64) bad |= (p[i] != first);
+        // (four loads in flight per lane: one wavefront walks a row, and the loop was a chain of memory round trips --
+        //  53 us per solve for the two 52 MB coefficient arrays of a 3600x1800 lat-lon Poisson problem)
+        for (int64_t i = lane; i < a.xc; i += 256) {
+            unsigned long long v[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) v[h] = (i + 64 * h < a.xc) ? p[i + 64 * h] : first;
+#pragma unroll
+            for (int h = 0; h < 4; h++) bad |= (v[h] != first);
+        }
         if (__any(bad)) break;
     }
     if (__any(bad) && lane == 0) atomicOr(a.flag + q, 1);
