@@ -135,6 +135,9 @@ int         xinv_last_stats(xinv_stats *out);       /* stats of the calling thre
 const char *xinv_last_error(void);
 int         xinv_device_count(void);
 int         xinv_version(void);
+/* sizeof(xinv_options) and sizeof(xinv_stats) as this build of the library sees them: a binding compares them with its
+ * own declarations before the first call (xinvert_amd/_lib.py does; a stale mirror would otherwise corrupt memory). */
+void        xinv_abi_sizes(int32_t *options_bytes, int32_t *stats_bytes);
 
 /* ---- single slice, HOST pointers: positional twins of the numba kernels -------------------
  * xinv_standard_2d_f64  replaces numbas.invert_standard_2D  called at core.py:130-139

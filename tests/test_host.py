@@ -21,6 +21,11 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert getattr(L, name) is not None
     assert L.xinv_version() >= 100
+    # the hand-written ctypes mirrors of xinv_options / xinv_stats have the library's sizes (load() enforces it too)
+    import ctypes
+    so, ss = ctypes.c_int32(0), ctypes.c_int32(0)
+    L.xinv_abi_sizes(ctypes.byref(so), ctypes.byref(ss))
+    assert (so.value, ss.value) == (ctypes.sizeof(_lib.XinvOptions), ctypes.sizeof(_lib.XinvStats))
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -52,7 +52,7 @@ class XinvError(RuntimeError):
 # every symbol include/xinv.h declares (tests check the library exports all of them)
 EXPORTS = [
     'xinv_default_options', 'xinv_last_stats', 'xinv_last_error', 'xinv_device_count',
-    'xinv_version',
+    'xinv_version', 'xinv_abi_sizes',
     'xinv_standard_2d_f64', 'xinv_general_2d_f64', 'xinv_standard_3d_f64',
     'xinv_standard_2d_f64_batched', 'xinv_general_2d_f64_batched',
     'xinv_standard_3d_f64_batched',
@@ -122,6 +122,14 @@ def load():
     L.xinv_default_options.restype = None
     L.xinv_default_options.argtypes = [_opt]
     L.xinv_last_stats.argtypes = [ctypes.POINTER(XinvStats)]
+    # the structs above mirror include/xinv.h by hand: refuse a library whose layout differs
+    so, ss = ctypes.c_int32(0), ctypes.c_int32(0)
+    L.xinv_abi_sizes.restype = None
+    L.xinv_abi_sizes(ctypes.byref(so), ctypes.byref(ss))
+    if (so.value, ss.value) != (ctypes.sizeof(XinvOptions), ctypes.sizeof(XinvStats)):
+        raise XinvError('%s was built from another include/xinv.h: xinv_options %d / xinv_stats %d bytes there, %d / %d '
+                        'in xinvert_amd/_lib.py' % (SO, so.value, ss.value, ctypes.sizeof(XinvOptions),
+                                                    ctypes.sizeof(XinvStats)))
     _lib = L
     return L
 

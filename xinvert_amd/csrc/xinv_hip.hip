@@ -37,7 +37,7 @@
 #define XINV_AUX_KERNELS            /* the detection / skip-norm helper kernels live in this unit */
 #include "xinv_dispatch.h"          /* argument structs + launchers of the sweep kernels (xinv_tu_*.hip) */
 
-#define XINV_VERSION 300
+#define XINV_VERSION 310
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
 
 #include "xinv_host.h"
@@ -1665,6 +1665,11 @@ int xinv_device_count(void)
 }
 
 int xinv_version(void) { return XINV_VERSION; }
+void xinv_abi_sizes(int32_t *options_bytes, int32_t *stats_bytes)
+{
+    if (options_bytes) *options_bytes = (int32_t)sizeof(xinv_options);
+    if (stats_bytes) *stats_bytes = (int32_t)sizeof(xinv_stats);
+}
 
 #define GUARD(expr) try { return (expr); } catch (const std::exception &e) { t_err = e.what(); return XINV_ERR_HIP; } catch (...) { t_err = "unknown C++ exception"; return XINV_ERR_HIP; }
 
