@@ -23,3 +23,5 @@ python tools/bench_frontend.py 2>/dev/null | grep invert_Poisson > gpurun_out/r0
 bash tools/profile_headline.sh r03 > gpurun_out/r03_profile.log 2>&1; tail -5 gpurun_out/r03_profile.log | cut -c1-200
 # C3 (Stommel, Munk) kernel trace + SQ issue counters of the reworked biharmonic kernel
 bash tools/r03_run14.sh > gpurun_out/r03_profile_c3m.log 2>&1; tail -12 gpurun_out/r03_profile_c3m.log | cut -c1-160
+# k_pipe3d on 15 omega volumes: kernel trace, SQ counters, HBM-side traffic
+bash tools/r03_run15.sh > gpurun_out/r03_profile_c5.log 2>&1; tail -6 gpurun_out/r03_profile_c5.log | cut -c1-150
