@@ -27,15 +27,20 @@ Extra objects in the ONE JSON line rank 0 prints (N = 1, c2):
                  of the tiles that RAN (skipped, fully masked tiles are not counted) x 16 fp64 operations /
                  mean launch duration (HIP events on the solve's stream over the timed region); peak = fp64
                  VALU issue rate WITHOUT FMA (the bit-exactness contract forbids contraction).
-                 `alg_equiv_GBps` is SURVEY 8(d)'s 48 B/point figure over the same time -- a comparable
-                 number, NOT a fraction of anything; `traffic` is the PMC-measured bytes per launch of the
+                 `alg_GBps` / `alg_frac` is SURVEY 8(d)'s 48 B/point figure over the same time -- a comparable
+                 number, NOT an HBM fraction when > 1; `traffic` is the PMC-measured bytes per launch of the
                  same kernel variant (profiles/traffic.json; counters cannot be read in-process).
+                 `hbm_frac` / `hbm_variant` repeat roofline_hbm's figures (the one true HBM fraction of the line) and
+                 `configs` a compact copy of the per-configuration table.
   roofline_hbm   the HBM-bound variant north_star names on a working set far beyond the 256 MiB Infinity
                  Cache: 8 members with their own A, C, F (2.1 GB), one sweep per pass, every array streamed,
                  every tile run.  `achieved` prices the 40 B per point the variant really streams (S read +
                  write, A, C, F; B is identically zero and never read); `alg48_*` is SURVEY 8(d)'s 48 B figure.
-  configs        one line per other BASELINE configuration (C1, C3 Stommel, C3 Munk, C4, C5) on this GPU:
-                 value, kernel, bound, fraction, and a bitwise parity flag against the oracle over >= 10 sweeps.
+  configs        one line per other BASELINE configuration (C1, C3 Stommel, C3 Munk, C4, C5) on this GPU at SURVEY
+                 8(d)'s sweep counts (500; C5 200) and one GPU's share of the batch (C4 8 of 64, C5 15 of 120):
+                 value, kernel, bound, fraction, alg_frac, PMC traffic, and a bitwise parity flag against the oracle.
+  rank_values    (N > 1) every rank's own rate on its block; n1_value: rank 0 alone on its block with the others idle
+                 (the N = 1 rate for the same per-GPU work); flags_sha256: digest of the gathered per-slice flags.
   parity         the timed solve repeated from the initial state and compared BIT FOR BIT with the oracle.
   cpu_baseline   the oracle's lexicographic sweep (the reference's execution model), -march=native build.
 """
@@ -277,15 +282,26 @@ def build_problem(a, rank, world):
         p['S0'] = p['S0'][lo:hi]
         p['coefs'] = [c if k in p['shared'] else c[lo:hi] for k, c in enumerate(p['coefs'])]
         return p, total, 'strong', 'invert_GillMatsuno 1440x720, %d forcing members (BASELINE configs[3])' % total
-    # c5: generated block by block (a 120-step forcing is 12 GB per array on the host)
+    return c5_members(lo, hi), total, 'strong', 'invert_omega 720x360x50, %d time steps (BASELINE configs[4])' % total
+
+
+def c5_members(lo, hi):
+    """Volumes lo..hi-1 of the 120-step omega batch.  Generated in FIXED blocks of eight steps (a 120-step forcing is
+    12 GB per array on the host), block b always from seed + 8 b with eight steps, so that volume m holds the same
+    numbers however the batch is split over ranks (the two-rank / one-rank flag comparison of the tests)."""
+    from xinvert_amd import synthetic
     parts = []
-    for m0 in range(lo, hi, 8):
-        parts.append(synthetic.omega_latlon(50, 360, 720, steps=min(8, hi - m0), seed=synthetic.SEED + m0))
+    for b in range(lo // 8, (hi + 7) // 8):
+        q = synthetic.omega_latlon(50, 360, 720, steps=8, seed=synthetic.SEED + 8 * b)
+        a, e = max(lo, 8 * b) - 8 * b, min(hi, 8 * b + 8) - 8 * b
+        q['S0'] = q['S0'][a:e]
+        q['coefs'] = [c if k in q['shared'] else c[a:e] for k, c in enumerate(q['coefs'])]
+        parts.append(q)
     p = dict(parts[0])
     p['S0'] = np.concatenate([q['S0'] for q in parts])
     p['coefs'] = [c if k in p['shared'] else np.concatenate([q['coefs'][k] for q in parts])
                   for k, c in enumerate(p['coefs'])]
-    return p, total, 'strong', 'invert_omega 720x360x50, %d time steps (BASELINE configs[4])' % total
+    return p
 
 
 def time_resident(rp, sweeps, steps, warmup, **opts):
@@ -304,8 +320,25 @@ def time_resident(rp, sweeps, steps, warmup, **opts):
     return time.perf_counter() - t0, ms, nl, s, fl
 
 
+def load_traffic():
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    except Exception:
+        return {}
+
+
+def alg_figures(kind, pts_per_launch, avg_ms):
+    """SURVEY 8(d)'s comparable number: the reference kernel's operand set (48 / 72 B per point-sweep) over the
+    launch time.  Labelled, because it is a fraction of the HBM roof only for a variant that streams all of it."""
+    g = ALG_BYTES[kind] * pts_per_launch / (avg_ms * 1e-3) / 1e9
+    return {'alg_bytes_per_point_sweep': ALG_BYTES[kind], 'alg_GBps': g, 'alg_frac': g / HBM_PEAK_GBS,
+            'alg_frac_note': 'SURVEY 8(d) bytes x point-sweeps of the launch / launch time / 8 TB/s: a comparable figure, '
+                             'NOT an HBM fraction when > 1 (fused sweeps, per-row coefficients, skipped tiles, Infinity Cache)'}
+
+
 def config_lines(local):
-    """The other BASELINE configurations on this GPU, one short timed run + an oracle parity check each."""
+    """The other BASELINE configurations on this GPU at SURVEY 8(d)'s sweep counts and one GPU's share of the
+    batch (of eight): a timed run + an oracle parity check each."""
     import oracle as orc
     from xinvert_amd import synthetic
     from xinvert_amd.resident import ResidentProblem
@@ -313,15 +346,18 @@ def config_lines(local):
         ('C1', 'invert_Poisson 360x180 lat-lon, one slice (BASELINE configs[0])',
          lambda: synthetic.poisson_latlon(180, 360, mask=False), 500, 10, orc.COLOUR_2, 25),
         ('C3-Stommel', 'invert_Stommel 2000x2000 Cartesian, R(x,y) varying (BASELINE configs[2])',
-         lambda: synthetic.stommel_cartesian(2000, 2000), 300, 3, orc.COLOUR_2, 12),
+         lambda: synthetic.stommel_cartesian(2000, 2000), 500, 5, orc.COLOUR_2, 12),
         ('C3-Munk', 'invert_StommelMunk 2000x2000 Cartesian, biharmonic form (BASELINE configs[2])',
-         lambda: synthetic.munk_cartesian(2000, 2000), 100, 3, orc.COLOUR_AUTO, 10),
-        ('C4', 'invert_GillMatsuno 1440x720, 8 of the 64 forcing members (BASELINE configs[3]; --config c4 runs all 64)',
-         lambda: synthetic.gill_matsuno(720, 1440, 8), 200, 3, orc.COLOUR_2, 12),
-        ('C5', 'invert_omega 720x360x50, 2 of the 120 time steps (BASELINE configs[4]; --config c5 runs all 120)',
-         lambda: synthetic.omega_latlon(50, 360, 720, steps=2), 60, 3, orc.COLOUR_2, 10),
+         lambda: synthetic.munk_cartesian(2000, 2000), 500, 3, orc.COLOUR_AUTO, 10),
+        ('C4', 'invert_GillMatsuno 1440x720, 8 of the 64 forcing members = one GPU\'s share of eight (BASELINE configs[3]; '
+               '--config c4 runs all 64)',
+         lambda: synthetic.gill_matsuno(720, 1440, 8), 500, 5, orc.COLOUR_2, 12),
+        ('C5', 'invert_omega 720x360x50, 15 of the 120 time steps = one GPU\'s share of eight (BASELINE configs[4]; '
+               '--config c5 runs all 120)',
+         lambda: c5_members(0, 15), 200, 3, orc.COLOUR_2, 10),
     ]
     out = []
+    traffic = load_traffic().get('configs', {})
     for name, wl, make, sweeps, steps, order, psw in todo:
         t_all = time.perf_counter()
         p = make()
@@ -338,14 +374,26 @@ def config_lines(local):
         res = rp.result()
         m_chk = sorted({0, rp.nb - 1})
         par = [oracle_parity(synthetic.member(p, m), res[m], flp[m], psw, order) for m in m_chk]
-        out.append({'name': name, 'workload': wl, 'value': n_all * sweeps * steps / dt, 'unit': 'point-sweeps/s',
+        line = alg_figures(kind, n_all * spl_mean, avg_ms)
+        # HBM-side bytes of this kernel on this workload (PMC passes, profiles/traffic.json: per point-sweep, static)
+        tr = traffic.get(name)
+        if tr and tr.get('kernel_prefix') and kernel_name(kind, s).startswith(tr['kernel_prefix']) and tr.get('members') == rp.nb:
+            tb = tr['bytes_per_point_sweep'] * n_all * spl_mean
+            line.update({'traffic': tb, 'traffic_bytes_per_point_sweep': tr['bytes_per_point_sweep'],
+                         'traffic_GBps': tb / (avg_ms * 1e-3) / 1e9,
+                         'traffic_frac_of_hbm_peak': tb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'traffic_source': 'static: ' + tr.get('source', 'profiles/traffic.json')})
+        else:
+            line['traffic'] = None
+        out.append(line)
+        line.update({'name': name, 'workload': wl, 'value': n_all * sweeps * steps / dt, 'unit': 'point-sweeps/s',
                     'members': rp.nb, 'sweeps_per_step': sweeps, 'steps': steps, 'ran_all_sweeps': ok,
                     'kernel': kernel_name(kind, s), 'sweeps_per_launch': s['sweeps_per_launch'],
                     'rows_per_tile': s['rows_per_tile'], 'bound': r['bound'], 'frac': r['frac'], 'achieved': r['achieved'],
                     'peak': r['peak'], 'unit_roofline': r['unit'], 'valu_frac': r['valu_frac'],
                     'streamed_frac_of_hbm_peak': r['streamed_frac_of_hbm_peak'],
                     'streamed_bytes_per_point_sweep': r['streamed_bytes_per_point_sweep'],
-                    'alg_bytes_per_point_sweep': ALG_BYTES[kind], 'avg_launch_us': avg_ms * 1e3,
+                    'avg_launch_us': avg_ms * 1e3,
                     'parity_bitwise': bool(all(q['bitwise'] and q['loop_equal'] for q in par)),
                     'parity_sweeps': psw, 'parity_members': m_chk,
                     'seconds': time.perf_counter() - t_all})
@@ -460,9 +508,12 @@ def main():
     for _ in range(a.steps):
         s, allf = step()
         ms_sweeps += s['sweep_ms']; launches += s['sweep_launches']
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0              # this rank's own K steps (before it waits for the others)
     barrier()
     dt = time.perf_counter() - t0
     ranks_done, backend = 1, None
+    rank_values, n1 = None, None
     if joined:
         backend = torch.distributed.get_backend()
         tdev = dev if backend == 'nccl' else torch.device('cpu')
@@ -472,6 +523,23 @@ def main():
         one = torch.ones(1, dtype=torch.float64, device=tdev)          # ranks that really took part
         torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
         ranks_done = int(round(float(one.item())))
+        # every rank's own rate on its own block (its K steps, its clock): a straggler GPU shows here
+        mine = torch.tensor([float(nb) * n * sweeps * a.steps / dt_own, float(nb)], dtype=torch.float64, device=tdev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        rank_values = [{'rank': r, 'members': int(round(float(e[1].item()))), 'value': float(e[0].item())}
+                       for r, e in enumerate(every)]
+        # rank 0 ALONE on its share, the others idle at the barrier: what N = 1 gives for the same per-GPU work
+        # (weak scaling: directly comparable with the N = 1 run; strong scaling: x world = the linear-scaling line)
+        if rank == 0:
+            rp.reset()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                rp.solve(sweeps - 1, 0.0, **opts)
+            torch.cuda.synchronize()
+            n1 = float(nb) * n * sweeps * a.steps / (time.perf_counter() - t1)
+        barrier()
     assert (allf[:, 2] == sweeps - 1).all() and not allf[:, 0].any(), allf[:4]
     assert allf.shape[0] == total_members
 
@@ -494,6 +562,10 @@ def main():
             'collective_backend': backend, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'rank_values': rank_values, 'n1_value': n1,
+            'n1_value_note': None if n1 is None else 'rank 0 alone on its own block (%d member(s)), the other ranks idle: the '
+                             'N = 1 rate for the same per-GPU work; linear scaling = n1_value x n_gpus' % nb,
+            'flags_sha256': __import__('hashlib').sha256(np.ascontiguousarray(allf, dtype=np.float64).tobytes()).hexdigest(),
             'config': {'workload': wl_name, 'sweeps_per_step': sweeps,
                        'members_total': total_members, 'members_this_gpu': nb,
                        'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'],
@@ -515,8 +587,8 @@ def main():
             'useful_flops_per_point_update': UPD_FLOPS[kind],
             'kernel': kernel_name(kind, s),
             'launches': int(launches),
-            'alg_bytes_per_launch': ALG_BYTES[kind] * pts_per_launch,
-            'alg_equiv_GBps': ALG_BYTES[kind] * pts_per_launch / (avg_ms * 1e-3) / 1e9})
+            'alg_bytes_per_launch': ALG_BYTES[kind] * pts_per_launch})
+        roof.update(alg_figures(kind, pts_per_launch, avg_ms))
         em = tile_model(s) if kind in ('std2d', 'gen2d') else None
         if em:
             roof['executed_over_useful'] = em
@@ -585,6 +657,14 @@ def main():
                                                 'traffic_source': roof['traffic_source']})
             except Exception:
                 pass
+            # the one figure of this line that IS a fraction of the HBM roof, next to the headline kernel's own bound
+            out['roofline']['hbm_variant'] = {k: out['roofline_hbm'][k] for k in
+                                              ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_of_achievable_6300',
+                                               'bytes_counted_per_point_sweep', 'alg48_frac', 'avg_launch_ms', 'members',
+                                               'working_set_bytes', 'traffic', 'parity_bitwise_10_sweeps')}
+            out['roofline']['hbm_variant'].update({k: out['roofline_hbm'][k] for k in ('traffic_GBps', 'traffic_frac_of_hbm_peak')
+                                                   if k in out['roofline_hbm']})
+            out['roofline']['hbm_frac'] = out['roofline_hbm']['frac']
             del hb
 
         if a.config == 'c2' and single and not a.no_parity:
@@ -611,6 +691,11 @@ def main():
         del rp
         if a.config == 'c2' and single and not a.no_configs:
             out['configs'] = config_lines(local)
+            # (the driver's record keeps the contract keys: a compact copy of the table rides inside `roofline`)
+            out['roofline']['configs'] = [{k: c.get(k) for k in ('name', 'value', 'members', 'sweeps_per_step', 'kernel', 'bound',
+                                                                  'frac', 'valu_frac', 'streamed_frac_of_hbm_peak', 'alg_frac',
+                                                                  'traffic_bytes_per_point_sweep', 'traffic_frac_of_hbm_peak',
+                                                                  'parity_bitwise')} for c in out['configs']]
         if a.inproc and single:
             out['inproc'] = inproc_leg(a, a.gpus)
         if a.config == 'c2' and single and not a.no_cpu:

@@ -177,6 +177,33 @@ def test_bench_self_launches_two_ranks():
     assert d['value'] > 0
 
 
+def test_bench_c5_two_ranks_equal_one_rank():
+    """The C5 strong-scaling split (`--config c5 --members 4 --gpus 2`, two ranks sharing this GPU over gloo): the
+    flags gathered from the two blocks are, bit for bit, those of a single rank solving all four volumes; the line
+    carries every rank's own rate and rank 0's stand-alone rate (what the driver's N = 1 run is compared with)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    full = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        full.pop(k, None)
+    full.update(XINV_FORCE_DEVICE='0', XINV_DIST_BACKEND='gloo')
+    got = {}
+    for ng in (2, 1):
+        out = subprocess.run([sys.executable, 'bench.py', '--config', 'c5', '--members', '4', '--gpus', str(ng), '--steps', '1',
+                              '--warmup', '0', '--sweeps', '11'], capture_output=True, text=True, timeout=1500, env=full,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+        got[ng] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    two, one = got[2], got[1]
+    assert two['n_gpus'] == 2 and two['scaling'] == 'strong' and two['config']['members_total'] == 4
+    assert two['config']['members_this_gpu'] == 2 and one['config']['members_this_gpu'] == 4
+    assert two['flags_sha256'] == one['flags_sha256']
+    assert [r['members'] for r in two['rank_values']] == [2, 2] and all(r['value'] > 0 for r in two['rank_values'])
+    assert two['n1_value'] > 0 and one['n1_value'] is None and one['rank_values'] is None
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     import os
     import subprocess

@@ -124,8 +124,13 @@ def load():
     L.xinv_last_stats.argtypes = [ctypes.POINTER(XinvStats)]
     # the structs above mirror include/xinv.h by hand: refuse a library whose layout differs
     so, ss = ctypes.c_int32(0), ctypes.c_int32(0)
-    L.xinv_abi_sizes.restype = None
-    L.xinv_abi_sizes(ctypes.byref(so), ctypes.byref(ss))
+    try:
+        abi_sizes = L.xinv_abi_sizes
+    except AttributeError:
+        raise XinvError('%s predates xinv_abi_sizes (a stale prebuilt library): rebuild it with '
+                        '`python -m xinvert_amd.build --force`' % SO) from None
+    abi_sizes.restype = None
+    abi_sizes(ctypes.byref(so), ctypes.byref(ss))
     if (so.value, ss.value) != (ctypes.sizeof(XinvOptions), ctypes.sizeof(XinvStats)):
         raise XinvError('%s was built from another include/xinv.h: xinv_options %d / xinv_stats %d bytes there, %d / %d '
                         'in xinvert_amd/_lib.py' % (SO, so.value, ss.value, ctypes.sizeof(XinvOptions),

@@ -221,8 +221,10 @@ def _device_list(iParams, nbatch, batch_bytes=0):
         return d
     if nbatch <= 1 or iParams.get('device') is not None or int(os.environ.get('WORLD_SIZE', '1')) > 1:
         return None
+    if batch_bytes < _MULTI_GPU_MIN_BYTES_PER_DEVICE * 2:     # (decided by the size alone: no device query)
+        return None
     ndev = _lib.load().xinv_device_count()
-    if ndev < 2 or batch_bytes < _MULTI_GPU_MIN_BYTES_PER_DEVICE * 2:
+    if ndev < 2:
         return None
     use = int(min(ndev, nbatch, batch_bytes // _MULTI_GPU_MIN_BYTES_PER_DEVICE))
     return list(range(use)) if use >= 2 else None

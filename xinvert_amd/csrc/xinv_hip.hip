@@ -1142,8 +1142,9 @@ struct HostActors {                                   // joins the helper thread
     }
 };
 
-static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bool may_register)
+static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, const Pinned *outer)
 {
+    const bool may_register = (outer == nullptr);     // a per-device call of a multi-device solve uses the parent's registrations
     const auto wall0 = std::chrono::steady_clock::now();
     DeviceGuard dg;
     HIPCHK(dg.select(opt.device));
@@ -1162,7 +1163,14 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
     g_copy_pool.start();
     Pinned pin;                                       // opt-in registration of the caller's arrays (off by default)
     pin.enabled = may_register && (Pinned::env_allowed() || (opt.flags & XINV_FLAG_PIN_HOST));
+    pin.outer = outer;
     pin.streams = { sup, sdn, scp };
+    // a previous call that returned on an error may have left slots of the staging rings marked in flight, with
+    // `dst` pointing into ITS host array: drain the (normally idle) copy streams and forget them
+    HIPCHK(hipStreamSynchronize(sup));
+    HIPCHK(hipStreamSynchronize(sdn));
+    ws->ring_up.reset();
+    ws->ring_down.reset();
     HostEvents ev;
     hipEvent_t e_up0, e_up1, e_dn0, e_dn1;
     int rc;
@@ -1180,9 +1188,8 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
     std::vector<std::vector<std::function<int()>>> chunk_ops((size_t)nchunk);
     // host range -> device, `members` pieces of `len` elements (host stride hstride, device stride len)
     auto h2d = [&](double *dev, const double *host, int64_t members, int64_t hstride, int64_t len) -> int {
-        const bool direct = pin.covers(host);          // registered in place: the DMA reads the caller's memory
         auto one = [&](double *d, const double *h, size_t bytes) -> int {
-            if (direct) { HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, sup)); return XINV_OK; }
+            if (pin.covers(h, bytes)) {                // registered in place: the DMA reads the caller's memory HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, sup)); return XINV_OK; }
             return stage_h2d(ws->ring_up, sup, d, h, bytes);
         };
         if (members == 1 || hstride == len) return one(dev, host, (size_t)members * len * sizeof(double));
@@ -1386,11 +1393,11 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, bo
         }
         {
             double *hS = p.S; const double *dS = d.S;
-            const bool direct = pin.covers(p.S);
+            const Pinned *pinp = &pin;
             std::lock_guard<std::mutex> lk(act.mu);
             act.dq.push_back([=]() -> int {
                 auto one = [&](double *h, const double *dv, size_t bytes) -> int {
-                    if (direct) { HIPCHK(hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, sdn)); return XINV_OK; }
+                    if (pinp->covers(h, bytes)) { HIPCHK(hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, sdn)); return XINV_OK; }
                     return stage_d2h(ws->ring_down, sdn, h, dv, bytes);
                 };
                 if (hsS == n || nm == 1) return one(hS + m0 * hsS, dS + m0 * n, (size_t)nm * n * sizeof(double));
@@ -1449,7 +1456,7 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
     if ((int64_t)devs.size() > p.nbatch) devs.resize((size_t)p.nbatch);
     if (devs.size() <= 1) {
         if (devs.size() == 1) opt.device = devs[0];
-        return solve_host_one(p, flags, opt, true);
+        return solve_host_one(p, flags, opt, nullptr);
     }
 
     const auto wall0 = std::chrono::steady_clock::now();
@@ -1481,7 +1488,7 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
             xinv_options o1 = opt;
             o1.device = devs[(size_t)i]; o1.ndev = 0;
             int r;
-            try { r = solve_host_one(sub, flags + 3 * lo, o1, false); }
+            try { r = solve_host_one(sub, flags + 3 * lo, o1, &pin); }
             catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
             catch (...) { t_err = "unknown C++ exception"; r = XINV_ERR_HIP; }
             res[(size_t)i].rc = r; res[(size_t)i].err = t_err; res[(size_t)i].st = t_stats;

@@ -49,7 +49,9 @@ struct DeviceGuard {
 // profiles/r02_pinning_abort.txt), the thread that drives the solves is never blocked by a copy, and chunk c+1
 // travels while chunk c sweeps ("staged through hipHostMalloc pinned buffers").
 struct CopyPool {                                   // process-wide memcpy workers
-    struct Batch { std::atomic<int> left{0}; std::mutex mu; std::condition_variable cv; };
+    // `left` is only touched under `mu`: the waiter owns the Batch (its stack frame) and may destroy it the moment it
+    // sees left == 0, so the last worker must still hold the mutex when it publishes the zero and notifies.
+    struct Batch { int left = 0; std::mutex mu; std::condition_variable cv; };
     struct Task { char *d; const char *s; size_t n; Batch *b; };
     std::vector<std::thread> th;
     std::mutex mu; std::condition_variable cv;
@@ -74,7 +76,10 @@ struct CopyPool {                                   // process-wide memcpy worke
                         t = q.front(); q.pop_front();
                     }
                     memcpy(t.d, t.s, t.n);
-                    if (t.b->left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(t.b->mu); t.b->cv.notify_all(); }
+                    {
+                        std::lock_guard<std::mutex> lk(t.b->mu);
+                        if (--t.b->left == 0) t.b->cv.notify_all();
+                    }                                    // (nothing of *t.b is touched after the unlock)
                 }
             });
     }
@@ -92,7 +97,7 @@ struct CopyPool {                                   // process-wide memcpy worke
             Task t{(char *)d + off, (const char *)s + off, std::min(piece, n - off), &b};
             mine.push_back(t);
         }
-        b.left.store((int)mine.size() - 1);
+        b.left = (int)mine.size() - 1;               // (before the tasks are visible to the workers)
         {
             std::lock_guard<std::mutex> lk(mu);
             for (size_t i = 1; i < mine.size(); i++) q.push_back(mine[i]);
@@ -101,7 +106,7 @@ struct CopyPool {                                   // process-wide memcpy worke
         memcpy(mine[0].d, mine[0].s, mine[0].n);
         if (mine.size() > 1) {
             std::unique_lock<std::mutex> lk(b.mu);
-            b.cv.wait(lk, [&] { return b.left.load() == 0; });
+            b.cv.wait(lk, [&] { return b.left == 0; });
         }
     }
     ~CopyPool()
@@ -122,6 +127,13 @@ struct StageRing {                                  // pinned slots of one direc
     char *dst[NSLOT] = {nullptr, nullptr, nullptr, nullptr};      // downloads: where the slot's bytes go on the host
     size_t len[NSLOT] = {0, 0, 0, 0};
     int next = 0;
+    // Forget every slot in flight (after the stream they were queued on has been drained): an error return from a
+    // staged copy must not leave `dst` / `len` pointing into that call's host array for the next call to retire.
+    void reset()
+    {
+        for (int k = 0; k < NSLOT; k++) { inflight[k] = false; dst[k] = nullptr; len[k] = 0; }
+        next = 0;
+    }
     int ensure()
     {
         for (int k = 0; k < NSLOT; k++) {
@@ -348,7 +360,8 @@ struct Pinned {                                     // host ranges registered fo
         static const bool env = [] { const char *e = getenv("XINV_PIN"); return e && atoi(e) != 0; }();
         return env;
     }
-    std::vector<void *> regs;
+    std::vector<std::pair<char *, size_t>> regs;    // (base, bytes) of every registered range
+    const Pinned *outer = nullptr;                  // multi-device call: the parent's portable registrations
     std::vector<hipStream_t> streams;               // streams that may still hold copies of these ranges
     bool enabled = false;                           // this call registers ranges (XINV_FLAG_PIN_HOST / XINV_PIN=1)
     unsigned flags = hipHostRegisterDefault;
@@ -359,20 +372,23 @@ struct Pinned {                                     // host ranges registered fo
             (void)hipGetLastError();
             return false;
         }
-        regs.push_back((void *)h);
+        regs.push_back({(char *)h, bytes});
         return true;
     }
-    bool covers(const void *h) const
+    // [h, h + bytes) lies inside a range registered by this call (or by the parent of a per-device call): every chunk
+    // and member of a registered array copies straight out of / into the caller's memory, not only its first bytes
+    bool covers(const void *h, size_t bytes) const
     {
-        for (void *r : regs) if (r == h) return true;
-        return false;
+        const char *c = (const char *)h;
+        for (const auto &r : regs) if (c >= r.first && c + bytes <= r.first + r.second) return true;
+        return outer ? outer->covers(h, bytes) : false;
     }
     // Every return path -- error paths included -- drains the copy streams before the ranges are
     // unregistered: an async copy still in flight must not lose its pinning.
     ~Pinned()
     {
         for (hipStream_t s : streams) (void)hipStreamSynchronize(s);
-        for (void *h : regs) (void)hipHostUnregister(h);
+        for (const auto &r : regs) (void)hipHostUnregister(r.first);
     }
 };
 
