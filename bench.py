@@ -607,7 +607,7 @@ def main():
                 traffic = None
         if traffic is None and os.path.exists(tfile) and a.config == 'c5' and spl == 2:
             try:                                                 # per point-sweep, from the 15-volume launch profiled by
-                det = json.load(open(tfile)).get('std3d_pipe3d_c5x15_detail')      # tools/r03_run15.sh, scaled to this launch
+                det = json.load(open(tfile)).get('std3d_pipe3d_c5x15_detail')      # a 15-volume launch, scaled to this one
                 traffic = det['bytes_per_point_sweep'] * pts_per_launch if det else None
             except Exception:
                 traffic = None

@@ -37,6 +37,10 @@ UNITS = [
     ('xinv_tu_bih', 'xinv_tu_bih.hip', ['-mllvm', '-amdgpu-sched-strategy=max-ilp']),
     ('xinv_tu_small2d', 'xinv_tu_small2d.hip', []),
 ]
+# XINV_VARIANT_UNITS="xinv_tu_fused3d,..." (with XINV_BUILD_TAG): only these units are compiled with the extra flags; every
+# other object is taken from the shipped build's build/obj (a variant of one kernel family links in seconds)
+VARIANT_UNITS = [u for u in os.environ.get('XINV_VARIANT_UNITS', '').split(',') if u] if TAG else []
+MAIN_OBJ = os.path.join(HERE, '..', 'build', 'obj')
 SOURCES = sorted({u[1] for u in UNITS})
 # -ffp-contract=off: no FMA contraction, so device results are bitwise those of the
 # CPU restatement of the same sweep ordering (see DESIGN.md "Arithmetic").
@@ -95,6 +99,8 @@ def build(force=False, verbose=False, jobs=None):
     cc = hipcc()
     todo = []
     for name, src, extra in _units():
+        if VARIANT_UNITS and name not in VARIANT_UNITS:
+            continue
         srcp = os.path.join(CSRC, src)
         obj, st = os.path.join(OBJ, name + '.o'), os.path.join(OBJ, name + '.stamp')
         stamp = _stamp(srcp, extra)
@@ -113,7 +119,8 @@ def build(force=False, verbose=False, jobs=None):
     with ThreadPoolExecutor(jobs) as ex:
         list(ex.map(run, todo))
     link = [cc, '--offload-arch=gfx950', '-shared', '-fPIC'] + \
-           [os.path.join(OBJ, u[0] + '.o') for u in _units()] + ['-o', SO]
+           [os.path.join(OBJ if (not VARIANT_UNITS or u[0] in VARIANT_UNITS) else MAIN_OBJ, u[0] + '.o') for u in _units()] + \
+           ['-o', SO]
     if verbose:
         print(' '.join(link), flush=True)
     subprocess.check_call(link)

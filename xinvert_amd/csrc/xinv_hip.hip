@@ -1189,7 +1189,10 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // host range -> device, `members` pieces of `len` elements (host stride hstride, device stride len)
     auto h2d = [&](double *dev, const double *host, int64_t members, int64_t hstride, int64_t len) -> int {
         auto one = [&](double *d, const double *h, size_t bytes) -> int {
-            if (pin.covers(h, bytes)) {                // registered in place: the DMA reads the caller's memory HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, sup)); return XINV_OK; }
+            if (pin.covers(h, bytes)) {                // registered in place: the DMA reads the caller's memory
+                HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, sup));
+                return XINV_OK;
+            }
             return stage_h2d(ws->ring_up, sup, d, h, bytes);
         };
         if (members == 1 || hstride == len) return one(dev, host, (size_t)members * len * sizeof(double));

@@ -79,19 +79,37 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     xinv_fresh_scalar_cache();
     constexpr int K = 2, H = 2 * K, UW = 128 - 2 * H, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
 
-    const int64_t m = a.member0 + blockIdx.y;
-    XinvCtl *ctl = a.ctl + m;
-    if (!a.force && xinv_ctl_done(ctl)) return;
-    const unsigned tag = xinv_ctl_seq(ctl);
-
+#ifndef XINV_P3_ORDER
+#define XINV_P3_ORDER 0
+#endif
     const int NB = a.nstrip * a.njb * a.nkc;
-    int T;
+    int T, my;
+#if XINV_P3_ORDER == 0
     {
         const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
         T = xcd * q + (xcd < rem ? xcd : rem) + idx;
+        my = blockIdx.y;
     }
     const int kc = T / (a.nstrip * a.njb), Tj = T - kc * (a.nstrip * a.njb);
     const int jb = Tj / a.nstrip, st = Tj - jb * a.nstrip;
+#else
+    // EXPERIMENT: the launch's tiles as ONE list (member, k chunk, strip, row block -- row block fastest), cut in eight
+    // contiguous ranges, one per XCD (workgroups go to the XCDs round robin in dispatch order): the workgroups
+    // resident on an XCD at one time are j-neighbours of the same strip, whose halo rows then meet in that XCD's L2
+    {
+        const int total = NB * (int)gridDim.y;
+        const int L = (int)blockIdx.y * NB + (int)blockIdx.x, q = total >> 3, rem = total & 7, xcd = L & 7, idx = L >> 3;
+        const int Tg = xcd * q + (xcd < rem ? xcd : rem) + idx;
+        my = Tg / NB;
+        T = Tg - my * NB;
+    }
+    const int kc = T / (a.nstrip * a.njb), Tj = T - kc * (a.nstrip * a.njb);
+    const int st = Tj / a.njb, jb = Tj - st * a.njb;
+#endif
+    const int64_t m = a.member0 + my;
+    XinvCtl *ctl = a.ctl + m;
+    if (!a.force && xinv_ctl_done(ctl)) return;
+    const unsigned tag = xinv_ctl_seq(ctl);
     const int zc = (int)a.zc, yc = (int)a.yc;
     const int k0 = kc * a.KC;
     const int k1 = (kc + 1 == a.nkc) ? zc : k0 + a.KC;
