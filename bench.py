@@ -197,8 +197,6 @@ def kernel_name(kind, s):
     K, um = s['sweeps_per_launch'], s['xuniform_mask']
     if s['path'] == 1:
         return 'colour-pass kernels (%d colours)' % s['colours']
-    if s['path'] == 3:
-        return 'k_small2d'
     if kind == 'bih2d':
         return 'k_fusedbih (one pass per sweep, A..I and the relaxation factor as per-row records)'
     if kind == 'std3d':
@@ -571,7 +569,7 @@ def main():
                        'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'],
                        'xuniform_mask': s['xuniform_mask'], 'masked_tile_pct': s['masked_tile_pct'],
                        'masked_tile_share': 1.0 - active,
-                       'path': {1: 'colour', 2: 'fused', 3: 'small'}.get(s['path'], '?'),
+                       'path': {1: 'colour', 2: 'fused'}.get(s['path'], '?'),
                        'parallelism': 'batch-axis shard x%d' % world},
         }
         out['value_active'] = out['value'] * active

@@ -47,8 +47,8 @@ extern "C" {
 #define XINV_PATH_AUTO   0
 #define XINV_PATH_COLOUR 1   /* one launch per colour, in place (general fallback)              */
 #define XINV_PATH_FUSED  2   /* streaming kernels: a whole sweep (or two) per pass, ping-pong buffers */
-#define XINV_PATH_SMALL  3   /* small slices (yc <= 96, xc <= 384, coefficients constant along x): one
-                                workgroup keeps the slice in registers for the whole solve, one launch  */
+/* (3 was XINV_PATH_SMALL, a register-resident solver for small slices: removed in version 400, it
+   never beat the streaming kernels on the shapes it was built for -- DESIGN.md 4.7) */
 
 #define XINV_FLAG_NO_XUNIFORM 1  /* stream every coefficient array in full: do not look for rows
                                     that are constant along x                                    */

@@ -98,8 +98,6 @@ def families():
                               {}, dict(path=1), orc.COLOUR_AUTO)
     F['colour_std3d_ext'] = (lambda s: util.rand3d(9, 30, 121, 'extend', 'periodic', seed=s),
                              {}, dict(path=1), orc.COLOUR_AUTO)
-    F['small2d'] = (lambda s: xuni(util.rand2d('std2d', 73, 144, 'fixed', 'periodic', seed=s), (0, 2)),
-                    dict(path=_lib.PATH_SMALL), dict(path=3), orc.COLOUR_2)
     return F
 
 

@@ -1,7 +1,7 @@
-"""The register-resident solver for small slices (xinvert_amd/csrc/xinv_small2d.h, path 3): one
-workgroup per slice, the whole solve in one launch.  Same red-black ordering as the streaming
-kernels, so the checker is the same: the CPU oracle's coloured ordering, bit for bit, and the
-streaming path on the same input."""
+"""Small slices -- the reference's own regime, 73 x 144 fields and a few hundred of them -- on the engine's own
+choice of kernel (the streaming kernels; the register-resident one-launch solver of rounds 2-3, path 3, was measured
+2.7 x slower on exactly these shapes and removed in round 4), and the 3-D two-sweep pass.  The checker is the CPU
+oracle's coloured ordering, bit for bit."""
 import numpy as np
 import pytest
 
@@ -10,7 +10,7 @@ from util import rand2d, run_oracle
 
 pytestmark = pytest.mark.gpu
 C2 = 2
-PATH_FUSED, PATH_SMALL = 2, 3
+PATH_FUSED = 2
 
 
 def xuniform(kind, yc, xc, BCy, BCx, msk, seed, omega=1.3):
@@ -25,54 +25,34 @@ def xuniform(kind, yc, xc, BCy, BCx, msk, seed, omega=1.3):
     return p
 
 
-def small_rw(yc, xc, ext, gen=False):
-    """The variant rule of xinv_hip.hip:small_variant -> (wavefronts, rows per wavefront), or None."""
-    if xc > 384 or yc > 96 or (ext and xc % 2):
-        return None
-    nseg = -(-xc // 128)
-    nr = 6 if gen else 4
-    for nw in (16, 8):
-        rws, cap = ((2, 4, 6), 12) if nw == 16 else ((4, 6, 8, 10, 12), 20)
-        for rw in rws:
-            if nw * rw < yc or rw * nseg > cap or (ext and (yc - 1) % rw == 0):
-                continue
-            if nseg == 3 and rw > (4 if nw == 16 else 6):
-                continue
-            lds = (nw + 2) * 2 * nseg * 2 * 64 * 8 + nw * rw * (nr * 8 + 4) + nw * 16 + 64 + yc * 2 * ((xc + 1) // 2) * 8
-            if lds > 160 * 1024:
-                continue
-            return nw, rw
-    return None
-
-
 SHAPES = [(73, 144), (37, 50), (96, 384), (9, 16), (64, 300), (91, 130), (16, 128), (33, 256), (5, 8), (80, 129)]
 
 
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
 @pytest.mark.parametrize('BCy,BCx', [('fixed', 'fixed'), ('fixed', 'periodic'), ('extend', 'periodic'), ('extend', 'fixed')])
 @pytest.mark.parametrize('shape', SHAPES)
-def test_small_solver_vs_oracle(kind, BCy, BCx, shape):
+def test_small_slices_vs_oracle(kind, BCy, BCx, shape):
     yc, xc = shape
-    if BCx == 'periodic' and xc % 2:
-        pytest.skip('odd xc periodic: seam colours, colour path')
     for msk in (0, 1):
         p = xuniform(kind, yc, xc, BCy, BCx, msk, seed=yc * 7 + xc + msk)
         So, flo = run_oracle(p, 30, 1e-9, C2)
-        S, fl, st = util.run_hip_batched([p], 30, 1e-9, path=PATH_SMALL if small_rw(yc, xc, BCy == 'extend', kind == 'gen2d') else 0)
-        applicable = small_rw(yc, xc, BCy == 'extend', kind == 'gen2d') is not None
-        assert (st['path'] == PATH_SMALL) == applicable, (st, applicable)     # (path 3 is on request: not yet the engine's own choice)
+        S, fl, st = util.run_hip_batched([p], 30, 1e-9)
         assert np.array_equal(S[0], So), 'mask %d: %d points differ' % (msk, (S[0] != So).sum())
         assert fl[0][2] == flo[2] and fl[0][0] == flo[0] and abs(fl[0][1] - flo[1]) <= 1e-12
-        if applicable:
-            S2, f2, s2 = util.run_hip_batched([p], 30, 1e-9, path=PATH_FUSED)
-            assert s2['path'] == PATH_FUSED and np.array_equal(S, S2)
 
 
-def test_small_solver_stops_at_the_exact_sweep_per_member():
+def test_removed_small_path_is_refused():
+    """xinv_options.path = 3 named the removed solver: a clear error, not a silent other kernel."""
+    from xinvert_amd import _lib
+    p = xuniform('std2d', 20, 40, 'fixed', 'fixed', 0, seed=5)
+    with pytest.raises(_lib.XinvError, match='removed'):
+        util.run_hip_batched([p], 5, 0.0, path=3)
+
+
+def test_small_slices_stop_at_the_exact_sweep_per_member():
     """Members converge after different numbers of sweeps; each returns the state of ITS stopping sweep."""
     ps = [xuniform('gen2d', 40, 96, 'fixed', 'periodic', 1, seed=100 + s, omega=1.3) for s in range(9)]
-    S, fl, st = util.run_hip_batched(ps, 400, 3e-4, path=PATH_SMALL)
-    assert st['path'] == PATH_SMALL
+    S, fl, st = util.run_hip_batched(ps, 400, 3e-4)
     loops = set()
     for m, p in enumerate(ps):
         So, flo = run_oracle(p, 400, 3e-4, C2)
@@ -81,52 +61,34 @@ def test_small_solver_stops_at_the_exact_sweep_per_member():
     assert len(loops) > 3 and max(loops) < 400
 
 
-def test_small_solver_real_reference_shapes():
+def test_small_slices_real_reference_shapes():
     """The reference's own regime: Gill-Matsuno on 73 x 144 (tests/test_GillMatsuno.py) and lat-lon Poisson
     with ['extend', 'periodic'] (tests/test_Poisson.py), through the synthetic front-end builders."""
     from xinvert_amd import synthetic
     p = synthetic.gill_matsuno(73, 144, 5)
     qs = [synthetic.member(p, m) for m in range(5)]
-    S, fl, st = util.run_hip_batched(qs, 600, 1e-5, shared=p['shared'], path=PATH_SMALL)
-    assert st['path'] == PATH_SMALL and st['xuniform_mask'] == 31
+    S, fl, st = util.run_hip_batched(qs, 600, 1e-5, shared=p['shared'])
+    assert st['path'] == PATH_FUSED and st['xuniform_mask'] == 31
     for m in (0, 4):
         So, flo = run_oracle(qs[m], 600, 1e-5, C2)
         assert np.array_equal(S[m], So) and fl[m][2] == flo[2]
     for BCs in (('extend', 'periodic'), ('fixed', 'periodic')):
         p = synthetic.poisson_latlon(72, 144, mask=True, BCs=BCs, members=3)
         qs = [synthetic.member(p, m) for m in range(3)]
-        S, fl, st = util.run_hip_batched(qs, 199, 0.0, shared=p['shared'], path=PATH_SMALL)
-        assert st['path'] == PATH_SMALL and st['xuniform_mask'] == 3
+        S, fl, st = util.run_hip_batched(qs, 199, 0.0, shared=p['shared'])
+        assert st['path'] == PATH_FUSED and st['xuniform_mask'] == 3
         for m in range(3):
             So, flo = run_oracle(qs[m], 199, 0.0, C2)
             assert np.array_equal(S[m], So) and fl[m][2] == flo[2] == 199
 
 
-def test_small_solver_degenerate_and_overflow():
-    p = xuniform('std2d', 20, 40, 'fixed', 'fixed', 0, seed=5)
-    for mx in (0, 1):
-        So, flo = run_oracle(p, mx, 0.0, C2)
-        S, fl, st = util.run_hip_batched([p], mx, 0.0, path=PATH_SMALL)
-        assert st['path'] == PATH_SMALL and np.array_equal(S[0], So) and np.allclose(fl[0], flo, rtol=0, atol=1e-12)
-    q = dict(p); q['coefs'] = [c.copy() for c in p['coefs']]
-    q['coefs'][3][7, 9] = np.nan                       # NaN forcing: participates (NaN != undef), poisons S
-    So, flo = run_oracle(q, 50, 0.0, C2)
-    S, fl, st = util.run_hip_batched([q], 50, 0.0, path=PATH_SMALL)
-    assert st['path'] == PATH_SMALL and flo[0] == 1 and fl[0][0] == 1 and fl[0][2] == flo[2]
-    z = dict(p); z['coefs'] = [c.copy() for c in p['coefs']]; z['S0'] = np.zeros_like(p['S0'])
-    z['coefs'][3][:] = 0.0                             # zero forcing, zero guess: norm == 0 stops standard_2D
-    So, flo = run_oracle(z, 50, 0.0, C2)
-    S, fl, st = util.run_hip_batched([z], 50, 0.0, path=PATH_SMALL)
-    assert st['path'] == PATH_SMALL and np.array_equal(S[0], So) and np.allclose(fl[0], flo, rtol=0, atol=1e-12)
-
-
-def test_small_solver_large_batch_on_device_pointers():
+def test_small_slices_large_batch_on_device_pointers():
     """More slices than CUs (several rounds of workgroups), device-resident, shared coefficients."""
     from xinvert_amd import synthetic
     p = synthetic.gill_matsuno(73, 144, 600)
     qs = [synthetic.member(p, m) for m in range(600)]
-    S, fl, st = util.run_hip_dev(qs, 39, 0.0, shared=p['shared'], path=PATH_SMALL)
-    assert st['path'] == PATH_SMALL and st['sweep_launches'] == 1
+    S, fl, st = util.run_hip_dev(qs, 39, 0.0, shared=p['shared'])
+    assert st['path'] == PATH_FUSED
     for m in (0, 255, 256, 599):
         So, flo = run_oracle(qs[m], 39, 0.0, C2)
         assert np.array_equal(S[m], So) and fl[m][2] == 39

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Many small slices in one call (the reference's typical use: a year of daily 2.5-degree fields).
-  python tools/bench_small_batch.py [--path 0|2|3]      0 = engine's choice, 2 = streaming kernels, 3 = register-resident solver"""
+  python tools/bench_small_batch.py [--path 0|1|2]      0 = engine's choice, 1 = colour passes, 2 = streaming kernels"""
 import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

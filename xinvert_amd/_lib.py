@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.environ.get('XINV_SO') or os.path.join(HERE, 'libxinv_hip.so')
 
 BC_CODES = {'fixed': 0, 'extend': 1, 'periodic': 2}
-PATH_AUTO, PATH_COLOUR, PATH_FUSED, PATH_SMALL = 0, 1, 2, 3
+PATH_AUTO, PATH_COLOUR, PATH_FUSED = 0, 1, 2
 PREP_MASK_NAN, PREP_MASK_VALUE, PREP_ROWSCALE, PREP_S_ZERO, PREP_DEMASK = 1, 2, 4, 8, 16     # XINV_PREP_*
 MAX_DEVICES = 16                      # XINV_MAX_DEVICES
 

@@ -35,7 +35,6 @@ UNITS = [
     # the biharmonic update is 51 dependent-chain flops per point and colour stage at one or two wavefronts per SIMD: the
     # default (occupancy-first) scheduler serialises the chains; max-ILP interleaves them (Munk 2000x2000: 1.04 -> 1.15e11)
     ('xinv_tu_bih', 'xinv_tu_bih.hip', ['-mllvm', '-amdgpu-sched-strategy=max-ilp']),
-    ('xinv_tu_small2d', 'xinv_tu_small2d.hip', []),
 ]
 # XINV_VARIANT_UNITS="xinv_tu_fused3d,..." (with XINV_BUILD_TAG): only these units are compiled with the extra flags; every
 # other object is taken from the shipped build's build/obj (a variant of one kernel family links in seconds)

@@ -11,7 +11,6 @@
 #include "xinv_fused3dg.h"
 #include "xinv_pipe3d.h"
 #include "xinv_fusedbih.h"
-#include "xinv_small2d.h"
 
 #define XINV_HIDDEN __attribute__((visibility("hidden")))
 
@@ -46,8 +45,3 @@ XINV_HIDDEN int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipSt
                                      const Fused3GArgs &a);
 XINV_HIDDEN int xinv_launch_fusedbih(bool per, bool zbe, dim3 grid, hipStream_t st,
                                      const FusedBihArgs &a, int *occ);
-// NW wavefronts x RW rows x NSEG segments of 128 columns; the instantiated (NW, RW, NSEG) are listed in
-// xinv_tu_small2d.hip (returns 1 for any other); xinv_small2d_lds = LDS bytes the variant needs
-XINV_HIDDEN int xinv_launch_small2d(bool gen, int NW, int RW, int NSEG, dim3 grid, hipStream_t st,
-                                    const SmallArgs &a);
-XINV_HIDDEN size_t xinv_small2d_lds(bool gen, int NW, int RW, int NSEG, int64_t yc, int64_t xc);

@@ -37,101 +37,11 @@
 #define XINV_AUX_KERNELS            /* the detection / skip-norm helper kernels live in this unit */
 #include "xinv_dispatch.h"          /* argument structs + launchers of the sweep kernels (xinv_tu_*.hip) */
 
-#define XINV_VERSION 310
+#define XINV_VERSION 400
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
 
 #include "xinv_host.h"
 #include "xinv_launch.h"
-
-// ------------------------------------------------------------------ small slices: one launch
-// Is the register-resident solver (xinv_small2d.h) applicable, and with which variant?
-//   2-D standard / general form with B == 0 (red-black, no odd-xc periodic seam), the slice small
-//   enough for one workgroup's registers (eight wavefronts x RW rows x NSEG segments of 128
-//   columns, RW * NSEG <= 24), 'extend' only with even xc and with row yc-1 not the first row of a
-//   band; every coefficient array constant along x (checked by the caller's detection pass).
-static bool small_variant(const Problem &p, int *NW_out, int *RW_out, int *NSEG_out)
-{
-    if (p.kind != KIND_STD2D && p.kind != KIND_GEN2D) return false;
-    if (p.xc > 384 || p.yc > 96) return false;
-    const bool ext = (p.BCy == XINV_BC_EXTEND), gen = (p.kind == KIND_GEN2D);
-    if (ext && (p.xc & 1)) return false;
-    const int NSEG = (int)cdiv(p.xc, 128);
-    const size_t lds_max = 160 * 1024;
-    // sixteen wavefronts (four per SIMD hide the LDS / barrier latencies) when their 128 registers
-    // hold the band and the edge rows fit LDS next to the forcing; else eight wavefronts
-    for (int NW = 16; NW >= 8; NW -= 8) {
-        const int rw_lo = (NW == 16) ? 2 : 4, rw_hi = (NW == 16) ? 6 : 12, cap = (NW == 16) ? 12 : 20;
-        for (int RW = rw_lo; RW <= rw_hi; RW += 2) {
-            if ((int64_t)NW * RW < p.yc || RW * NSEG > cap) continue;
-            if (NW == 16 && NSEG == 3 && RW > 4) continue;          // (not instantiated)
-            if (NW == 8 && NSEG == 3 && RW > 6) continue;
-            if (ext && ((p.yc - 1) % RW) == 0) continue;
-            if (xinv_small2d_lds(gen, NW, RW, NSEG, p.yc, p.xc) > lds_max) continue;
-            *NW_out = NW; *RW_out = RW; *NSEG_out = NSEG;
-            return true;
-        }
-    }
-    return false;
-}
-
-// The whole solve of every member in ONE launch (one workgroup per slice); S is final in place.
-static int solve_small(const Problem &p, Plan &pl, Workspace *ws, double *flags, const xinv_options &opt,
-                       hipStream_t st, int NW, int RW, int NSEG)
-{
-    int rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)p.nbatch * sizeof(XinvCtl));
-    if (rc) return rc;
-    if (ws->hctl_cap < (size_t)p.nbatch) {
-        if (ws->hctl) HIPCHK(hipHostFree(ws->hctl));
-        HIPCHK(hipHostMalloc((void **)&ws->hctl, 2 * (size_t)p.nbatch * sizeof(XinvCtl), hipHostMallocDefault));
-        ws->hctl_cap = (size_t)p.nbatch;
-    }
-    SmallArgs a;
-    memset(&a, 0, sizeof a);
-    a.S = p.S; a.sS = p.sS;
-    if (p.kind == KIND_STD2D) {
-        a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
-        a.c[1] = p.c[2]; a.sc[1] = p.sc[2];      // C
-        a.c[2] = p.c[3]; a.sc[2] = p.sc[3];      // F
-    } else {
-        a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
-        for (int q = 2; q < 7; q++) { a.c[q - 1] = p.c[q]; a.sc[q - 1] = p.sc[q]; }   // C..G
-    }
-    a.yc = p.yc; a.xc = p.xc;
-    a.per = (p.BCx == XINV_BC_PERIODIC); a.ext = (p.BCy == XINV_BC_EXTEND); a.tall = (p.yc > p.xc);
-    a.sc_ = p.sc_; a.stop = p.stop; a.ctl = ws->ctl;
-    if (opt.timing) HIPCHK(hipEventRecord(ws->ev0[0], st));
-    const int64_t chunk = (int64_t)1 << 30;              // grid.x
-    int64_t nlaunch = 0;
-    for (int64_t m0 = 0; m0 < p.nbatch; m0 += chunk, nlaunch++) {
-        a.member0 = m0;
-        if (xinv_launch_small2d(p.kind == KIND_GEN2D, NW, RW, NSEG,
-                                dim3((unsigned)std::min<int64_t>(chunk, p.nbatch - m0)), st, a))
-            return fail_arg("internal: no small-slice kernel variant");
-    }
-    HIPCHK(hipGetLastError());
-    if (opt.timing) HIPCHK(hipEventRecord(ws->ev1[0], st));
-    HIPCHK(hipMemcpyAsync(ws->hctl, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    int64_t sweeps_max = 0;
-    for (int64_t m = 0; m < p.nbatch; m++) {
-        const XinvCtl &c = ws->hctl[m];
-        if (c.overflow) flags[3 * m + 0] = 1.0;
-        if (c.wrote) { flags[3 * m + 1] = c.flag1; flags[3 * m + 2] = c.flag2; }
-        sweeps_max = std::max<int64_t>(sweeps_max, c.sweeps);
-    }
-    float ms = 0.f;
-    if (opt.timing) HIPCHK(hipEventElapsedTime(&ms, ws->ev0[0], ws->ev1[0]));
-    t_stats.path = XINV_PATH_SMALL;
-    t_stats.colours = pl.ncol;
-    t_stats.sweeps_per_launch = (int32_t)std::min<int64_t>(sweeps_max, 0x7fffffff);
-    t_stats.rows_per_tile = RW;
-    t_stats.colours = NW;                                 // (wavefronts per slice, for the small path)
-    t_stats.xuniform_mask = (int32_t)pl.um;
-    t_stats.sweep_launches = nlaunch;
-    t_stats.sweeps_max = sweeps_max;
-    t_stats.sweep_ms = ms;
-    return XINV_OK;
-}
 
 // ------------------------------------------------------------------ planning
 // solve_dev = plan (colouring -> path -> tiling of the chosen kernel family) -> sweep loop -> finalise.
@@ -1002,31 +912,9 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     rc = plan_colouring(p, ws, st, pl);
     if (rc) return rc;
 
-    // ---- small slices: the register-resident solver, when the form and the size allow it --------
-    // On request only (path = XINV_PATH_SMALL, or XINV_SMALL_AUTO=1 in the environment): as measured
-    // this round it does not yet beat the streaming kernels.
-    static const bool small_auto = [] { const char *e = getenv("XINV_SMALL_AUTO"); return e && atoi(e) != 0; }();
-    if ((opt.path == XINV_PATH_AUTO && small_auto) || opt.path == XINV_PATH_SMALL) {
-        int sNW = 0, sRW = 0, sNSEG = 0;
-        bool ok = pl.base == 2 && !pl.seam && !(opt.flags & XINV_FLAG_NO_XUNIFORM) && small_variant(p, &sNW, &sRW, &sNSEG);
-        if (ok) {
-            const int cmapS[2] = {0, 2}, cmapG[5] = {0, 2, 3, 4, 5};
-            const int ns = (p.kind == KIND_STD2D) ? 2 : 5;
-            const double *arr[5]; int64_t strd[5];
-            for (int q = 0; q < ns; q++) {
-                const int sidx = (p.kind == KIND_STD2D) ? cmapS[q] : cmapG[q];
-                arr[q] = p.c[sidx]; strd[q] = p.sc[sidx];
-            }
-            unsigned um = 0;
-            rc = detect_xuniform(ws, st, arr, strd, ns, p.nbatch, p.yc, p.xc, &um);
-            if (rc) return rc;
-            ok = (um == ((1u << ns) - 1u));
-            pl.um = pl.umask = um;
-        }
-        if (ok) return solve_small(p, pl, ws, flags, opt, st, sNW, sRW, sNSEG);
-        if (opt.path == XINV_PATH_SMALL)
-            return fail_arg("the small-slice solver needs the 2-D standard / general form with B == 0, yc <= 96, xc <= 384 and every coefficient array constant along x");
-    }
+    if (opt.path == 3)                                  // (the value of round 2-3's XINV_PATH_SMALL)
+        return fail_arg("path 3 (the register-resident small-slice solver) was removed in version 400: it never beat the "
+                        "streaming kernels; use XINV_PATH_AUTO");
     rc = plan_path(p, opt, ws, st, pl);
     if (rc) return rc;
     SweepRun R;
