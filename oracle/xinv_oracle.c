@@ -299,6 +299,18 @@ static inline int colour2d(int64_t j, int64_t i, int64_t xc, int base, int seam)
     return (int)(2 * (j & 1) + (i & 1));
 }
 
+/* Order of the colour passes of one sweep.  Without a seam: 0 .. base-1.  With the seam (periodic x, odd xc) each
+ * seam colour runs RIGHT AFTER the base colour its points would otherwise belong to -- column xc-1 is an even column,
+ * so rows of parity p of it follow colour (p, 0): red, red', black, black' (base 2), c0, c0', c1, c2, c2', c3 (base
+ * 4).  (Until round 3 the two seam colours ran after all base colours; the fused kernels update the seam column
+ * inside the half-sweep of its own colour, right after column 0, which is this order.) */
+static inline int seq_colour(int pos, int base, int seam)
+{
+    static const int s2[4] = { 0, 2, 1, 3 }, s4[6] = { 0, 4, 1, 2, 5, 3 };
+    if (!seam) return pos;
+    return base == 2 ? s2[pos] : s4[pos];
+}
+
 static int all_zero(const double *B, int64_t n)
 {
     for (int64_t t = 0; t < n; t++) if (B[t] != 0.0) return 0;
@@ -343,7 +355,7 @@ int xo_standard_2d(double *S, const double *A, const double *B, const double *C,
             for (int c = 0; c < ncol; c++)
                 for (int64_t j = 1; j < yc - 1; j++)
                     for (int64_t i = i0; i < i1; i++) {
-                        if (colour2d(j, i, xc, base, seam) != c) continue;
+                        if (colour2d(j, i, xc, base, seam) != seq_colour(c, base, seam)) continue;
                         int64_t im = i == 0 ? xc - 1 : i - 1;
                         int64_t ip = i == xc - 1 ? 0 : i + 1;
                         upd_std2d(S, A, B, C, F, xc, j, i, im, ip, i == 0,
@@ -395,7 +407,7 @@ int xo_general_2d(double *S, const double *A, const double *B, const double *C,
             for (int c = 0; c < ncol; c++)
                 for (int64_t j = 1; j < yc - 1; j++)
                     for (int64_t i = i0; i < i1; i++) {
-                        if (colour2d(j, i, xc, base, seam) != c) continue;
+                        if (colour2d(j, i, xc, base, seam) != seq_colour(c, base, seam)) continue;
                         int64_t im = i == 0 ? xc - 1 : i - 1;
                         int64_t ip = i == xc - 1 ? 0 : i + 1;
                         upd_gen2d(S, A, B, C, D, E, F, G, xc, j, i, im, ip,
@@ -448,7 +460,7 @@ int xo_standard_3d(double *S, const double *A, const double *B, const double *C,
                         for (int64_t i = i0; i < i1; i++) {
                             int col = (seam && i == xc - 1) ? 2 + (int)((k + j) & 1)
                                                              : (int)((k + j + i) & 1);
-                            if (col != c) continue;
+                            if (col != seq_colour(c, 2, seam)) continue;
                             int64_t im = i == 0 ? xc - 1 : i - 1;
                             int64_t ip = i == xc - 1 ? 0 : i + 1;
                             upd_std3d(S, A, B, C, F, P, xc, k, j, i, im, ip,
@@ -505,7 +517,7 @@ int xo_general_3d(double *S, const double *A, const double *B, const double *C, 
                         for (int64_t i = i0; i < i1; i++) {
                             int col = (seam && i == xc - 1) ? 2 + (int)((k + j) & 1)
                                                              : (int)((k + j + i) & 1);
-                            if (col != cc) continue;
+                            if (col != seq_colour(cc, 2, seam)) continue;
                             int64_t im = i == 0 ? xc - 1 : i - 1;
                             int64_t ip = i == xc - 1 ? 0 : i + 1;
                             upd_gen3d(S, c, P, xc, k, j, i, im, ip, per && i == 0, delx, delxSqr,
@@ -737,7 +749,7 @@ int xo_standard_2d_test(double *S, const double *A, const double *B, const doubl
         for (int c = 0; c < npass; c++)
             for (int64_t j = 1; j < yc - 1; j++)
                 for (int64_t i = i0; i < i1; i++) {
-                    if (order != XO_LEX && colour2d(j, i, xc, base, seam) != c) continue;
+                    if (order != XO_LEX && colour2d(j, i, xc, base, seam) != seq_colour(c, base, seam)) continue;
                     int64_t im = i == 0 ? xc - 1 : i - 1;
                     int64_t ip = i == xc - 1 ? 0 : i + 1;
                     upd_std2dt(S, A, B, C, D, E, F, xc, j, i, im, ip, i == 0,

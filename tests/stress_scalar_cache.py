@@ -93,7 +93,12 @@ def families():
                            {}, dict(path=1), orc.COLOUR_AUTO)
     # colour-pass kernels (odd-xc periodic seam; 'extend' runs k_extend, whose corner reads are block-uniform)
     F['colour_std2d_ext'] = (lambda s: util.rand2d('std2d', 60, 251, 'extend', 'periodic', msk=True, seed=s),
-                             {}, dict(path=1), orc.COLOUR_AUTO)
+                             dict(path=1), dict(path=1), orc.COLOUR_AUTO)
+    # the odd-xc periodic seam inside the streaming kernels (round 4): full arrays, and per-row A and C
+    F['fused2d_seam'] = (lambda s: util.rand2d('std2d', 60, 251, 'extend', 'periodic', msk=True, seed=s),
+                         {}, dict(path=2), orc.COLOUR_2)
+    F['fused2d_seam_um3'] = (lambda s: xuni(util.rand2d('std2d', 96, 385, 'fixed', 'periodic', seed=s), (0, 2)),
+                             {}, dict(path=2, xuniform_mask=3), orc.COLOUR_2)
     F['colour_gen2d_nine'] = (lambda s: util.rand2d('gen2d', 60, 251, 'extend', 'periodic', bnz=True, seed=s),
                               {}, dict(path=1), orc.COLOUR_AUTO)
     F['colour_std3d_ext'] = (lambda s: util.rand3d(9, 30, 121, 'extend', 'periodic', seed=s),

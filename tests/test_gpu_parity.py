@@ -198,8 +198,8 @@ FUSED_SHAPES = [(17, 24), (12, 20), (40, 300), (70, 130), (33, 257), (8, 4), (3,
 @pytest.mark.parametrize('K', [1, 2, 3, 4])
 def test_fused_path(kind, BCy, BCx, msk, shape, K):
     yc, xc = shape
-    if BCx == 'periodic' and xc % 2:
-        pytest.skip('odd-xc periodic seam goes through the colour path (covered there)')
+    if BCx == 'periodic' and xc % 2 and xc < 64:
+        pytest.skip('odd-xc periodic seam on rows shorter than 64 columns goes through the colour path (covered there)')
     p = rand2d(kind, yc, xc, BCy, BCx, 0, msk, seed=_seed((kind, BCy, BCx, msk, shape)))
     So, flo = run_oracle(p, 24, 1e-9, COLOUR_2)
     S, fl, st = run_hip_batched([p], 24, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=16)
@@ -241,8 +241,8 @@ def test_fused_standard_three_and_four_sweeps_per_pass(BCy, BCx, msk, shape, K, 
     """K = 3, 4 (standard form with per-row A, C): same ordering, so bit for bit the oracle;
     nsw + 1 sweeps leave a tail of 1 (25 = 6x4 + 1 = 8x3 + 1) or 3 / 2 (23) for a shorter last pass."""
     yc, xc = shape
-    if BCx == 'periodic' and xc % 2:
-        pytest.skip('odd-xc periodic seam goes through the colour path (covered there)')
+    if BCx == 'periodic' and xc % 2 and xc < 64:
+        pytest.skip('odd-xc periodic seam on rows shorter than 64 columns goes through the colour path (covered there)')
     p = _uniform2d(rand2d('std2d', yc, xc, BCy, BCx, 0, msk, seed=_seed(('k34', BCy, BCx, msk, shape))))
     So, flo = run_oracle(p, nsw, 1e-9, COLOUR_2)
     for rows in (16, 0):

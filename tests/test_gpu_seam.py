@@ -1,0 +1,89 @@
+"""Periodic x with ODD xc (the reference's own tests/test_Ishida.py: xnum = 251) on the streaming kernels.
+
+Columns 0 and xc-1 are neighbours of one colour there.  The coloured ordering (oracle: seq_colour) updates column
+xc-1 inside the half-sweep of its own colour, right after column 0 -- red, red', black, black' -- and the fused
+kernels do the same with lane-masked passes in the tiles that wrap around the seam (xinv_fused.h: SEAM).  Bit for bit
+against the oracle and the colour launches, single-strip rows (65 ... 127 columns: the strip wraps on both sides),
+multi-strip rows, every sweeps-per-pass, masks, 'extend', x-uniform and full coefficient arrays, batches."""
+import zlib
+
+import numpy as np
+import pytest
+
+from util import rand2d, rand2dt, run_oracle, run_hip_batched
+
+pytestmark = pytest.mark.gpu
+COLOUR_2, PATH_COLOUR, PATH_FUSED = 2, 1, 2
+SHAPES = [(20, 65), (70, 101), (30, 127), (25, 129), (40, 301), (33, 257), (12, 641)]
+
+
+def _seed(t):
+    return zlib.crc32(repr(t).encode()) % 100000
+
+
+def _same(S, fl, So, flo, what):
+    assert np.array_equal(S, So), '%s: %d points differ' % (what, (S != So).sum())
+    assert fl[2] == flo[2] and fl[0] == flo[0] and abs(fl[1] - flo[1]) <= 1e-12, (what, fl, flo)
+
+
+def _uniform(p, which):
+    q = dict(p)
+    q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k in which else c
+                  for k, c in enumerate(p['coefs'])]
+    return q
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_seam_fused_full_arrays(kind, BCy, msk, shape):
+    yc, xc = shape
+    p = rand2d(kind, yc, xc, BCy, 'periodic', 0, msk, seed=_seed((kind, BCy, msk, shape)))
+    So, flo = run_oracle(p, 13, 1e-9, COLOUR_2)
+    Sc, fc, sc = run_hip_batched([p], 13, 1e-9, path=PATH_COLOUR)
+    assert sc['path'] == PATH_COLOUR and sc['colours'] == 4
+    _same(Sc[0], fc[0], So, flo, 'colour launches')
+    for K in (1, 2, 3, 4) if kind == 'std2d' else (1, 2, 3):
+        for rows in (16, 0):
+            S, fl, st = run_hip_batched([p], 13, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=rows)
+            assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == K, st
+            _same(S[0], fl[0], So, flo, 'fused K=%d rows=%d %s %r' % (K, rows, kind, shape))
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('shape', SHAPES + [(151, 251)])
+def test_seam_fused_x_uniform_and_batches(kind, BCy, shape):
+    """Per-row coefficients (lat-lon Poisson / Gill-Matsuno; the Ishida case is a general form with constants): the
+    engine's own choice of kernel, three members with different masks, tolerance stops inside a pass."""
+    yc, xc = shape
+    which = (0, 2) if kind == 'std2d' else (0, 2, 3, 4, 5)
+    ps = [_uniform(rand2d(kind, yc, xc, BCy, 'periodic', 0, m & 1, seed=_seed((kind, BCy, shape, m))), which) for m in range(3)]
+    ref = [run_oracle(p, 200, 2e-4, COLOUR_2) for p in ps]
+    for kw in (dict(), dict(no_pipe=1), dict(sweeps_per_launch=2), dict(force_tile_skip=1)):
+        S, fl, st = run_hip_batched(ps, 200, 2e-4, **kw)
+        assert st['path'] == PATH_FUSED and st['xuniform_mask'] == (3 if kind == 'std2d' else 31), st
+        for m in range(3):
+            _same(S[m], fl[m], ref[m][0], ref[m][1], '%s %r member %d %r' % (kind, shape, m, kw))
+
+
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('shape', [(30, 261), (20, 77)])
+def test_seam_fused_test_form(BCy, shape):
+    p = rand2dt(shape[0], shape[1], BCy, 'periodic', 0, 1, seed=_seed((BCy, shape)))
+    So, flo = run_oracle(p, 20, 1e-9, COLOUR_2)
+    for K in (1, 2, 3):
+        S, fl, st = run_hip_batched([p], 20, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=10)
+        assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == K
+        _same(S[0], fl[0], So, flo, 'std2dt K=%d' % K)
+
+
+def test_short_odd_rows_keep_the_colour_launches():
+    p = rand2d('std2d', 20, 33, 'fixed', 'periodic', 0, 1, seed=5)
+    So, flo = run_oracle(p, 30, 1e-9, COLOUR_2)
+    S, fl, st = run_hip_batched([p], 30, 1e-9)
+    assert st['path'] == PATH_COLOUR
+    _same(S[0], fl[0], So, flo, 'xc = 33')
+    with pytest.raises(Exception, match='no fused kernel'):
+        run_hip_batched([p], 3, 0.0, path=PATH_FUSED)

@@ -28,6 +28,10 @@ UNITS = [
     ('xinv_tu_fused2d_std', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=0']),
     ('xinv_tu_fused2d_gen', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=1']),
     ('xinv_tu_fused2d_std2dt', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=2']),
+    # the odd-xc periodic seam variants of the same kernels (unaligned strips only)
+    ('xinv_tu_fused2d_std_seam', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=0', '-DXINV_TU_SEAM=1']),
+    ('xinv_tu_fused2d_gen_seam', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=1', '-DXINV_TU_SEAM=1']),
+    ('xinv_tu_fused2d_std2dt_seam', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=2', '-DXINV_TU_SEAM=1']),
     ('xinv_tu_pipe2d_std', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=0']),
     ('xinv_tu_pipe2d_gen', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=1']),
     ('xinv_tu_fused9', 'xinv_tu_fused9.hip', []),

@@ -20,6 +20,13 @@ XINV_HIDDEN int xinv_launch_fused2d_gen(bool al, bool ext, unsigned um, int K, d
                                         hipStream_t st, const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused2d_std2dt(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                                            hipStream_t st, const FusedArgs &a, int *occ);
+// the odd-xc periodic seam variants (unaligned strips only; xinv_tu_fused2d.hip with -DXINV_TU_SEAM=1)
+XINV_HIDDEN int xinv_launch_fused2d_std_seam(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                             hipStream_t st, const FusedArgs &a, int *occ);
+XINV_HIDDEN int xinv_launch_fused2d_gen_seam(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                             hipStream_t st, const FusedArgs &a, int *occ);
+XINV_HIDDEN int xinv_launch_fused2d_std2dt_seam(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                                hipStream_t st, const FusedArgs &a, int *occ);
 // wave-pipelined four-sweep pass, one tile per 256-thread workgroup: standard form (um = 3: A and C per row, np = 1
 // or 2 column pairs per lane) and general form (um = 0x1f: A C D E F per row).  Returns 1 for a variant that is
 // not instantiated (coefficient arrays varying along x: measured slower than k_fused2d, see plan_fused5).

@@ -679,9 +679,39 @@ __global__ __launch_bounds__(256) void k_norm_reduce_lag(NormLagArgs a)
 #ifndef XINV_MINWAVES
 #define XINV_MINWAVES 1
 #endif
-template <class M, int K, bool AL, unsigned UM, bool EXT, int PFD = 0>
+// SEAM (periodic x with ODD xc; strips are never aligned then).  Columns 0 and xc-1 are neighbours of the same colour,
+// and a strip that wraps around the seam holds the wrapped columns with the parity of their lane slots flipped (the
+// .x slots hold odd columns there).  The coloured ordering for this case (oracle: seq_colour) updates column xc-1 inside
+// the half-sweep of its own colour, right after column 0; the kernel runs a half-sweep of such a tile as up to three
+// lane-masked passes -- the wrapped lanes east of the seam (their OTHER component carries this colour, column 0 among
+// them), the unwrapped lanes, the wrapped lanes west of the seam (column xc-1's halo copy last) -- each pass the plain
+// update on one component, kept where the lane class matches.  Tiles that do not touch the seam run one pass.
+// The planner admits xc >= 64 (a strip then spans at most three wraps).
+struct SeamLanes {
+    unsigned reg[2], fe[2], fw[2];     // per component: all-ones where the lane's column is unwrapped / wrapped east / west
+    bool has_e, has_w;                 // wave-uniform: any lane of that class
+};
+__device__ __forceinline__ SeamLanes make_seamlanes(int64_t c0, const LaneCols &lc, int64_t xc)
+{
+    SeamLanes s;
+    const int64_t c[2] = {c0, c0 + 1}, l[2] = {lc.l0, lc.l1};
+    bool any_e = false, any_w = false;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const bool flip = ((c[q] ^ l[q]) & 1) != 0;      // xc odd: one wrap flips the column's parity
+        const bool e = flip && c[q] >= xc, w = flip && c[q] < 0;
+        s.reg[q] = flip ? 0u : ~0u; s.fe[q] = e ? ~0u : 0u; s.fw[q] = w ? ~0u : 0u;
+        any_e = any_e || e; any_w = any_w || w;
+    }
+    s.has_e = __builtin_amdgcn_ballot_w64(any_e) != 0ull;
+    s.has_w = __builtin_amdgcn_ballot_w64(any_w) != 0ull;
+    return s;
+}
+
+template <class M, int K, bool AL, unsigned UM, bool EXT, int PFD = 0, bool SEAM = false>
 __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 {
+    static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
     constexpr int NC = M::NC;
     constexpr int H = 2 * K;            // halo (rows and columns) consumed by K sweeps
     constexpr int UW = 128 - 2 * H;     // columns owned by one wavefront
@@ -756,6 +786,8 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 
     const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
     const int64_t st0 = xu0 - H + 2 * lane;          // unwrapped store column of .x
+    SeamLanes sl;
+    if constexpr (SEAM) sl = make_seamlanes(st0, lc, xc);
 
     const double *srcS = a.src + m * a.sS;
     double *dstS = a.dst + m * a.sS;
@@ -837,6 +869,24 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                 const bool rv = (r - 1 >= 1) && (r - 1 <= ycr - 2);
                 M::template derive<UM, D>(cw, U, SLOT(1), rv && lc.ok_x, rv && lc.ok_y, a.sc_);
             }
+            // SEAM: one half-sweep as lane-masked passes (east-wrapped lanes' other component, unwrapped lanes, west-wrapped)
+            auto seam_pass = [&](auto xt, int sj, int sjp, int sjm, unsigned lw) {
+                constexpr int XX = decltype(xt)::value;
+                double w, e;
+                row_neighbours<XX>(sw[sj], w, e);
+                const double old = comp<XX>(sw[sj]);
+                const double v = M::template upd<XX, UM, D>(cw, sj, sjp, old, comp<XX>(sw[sjp]), comp<XX>(sw[sjm]),
+                                                            w, e, a.sc_);
+                setc<XX>(sw[sj], xinv_bitsel(lw, v, old));
+            };
+            auto seam_half = [&](int sj, int sjp, int sjm) {
+                using XA = std::integral_constant<int, X>;
+                using XB = std::integral_constant<int, 1 - X>;
+                if (sl.has_e) seam_pass(XB{}, sj, sjp, sjm, sl.fe[1 - X]);
+                seam_pass(XA{}, sj, sjp, sjm, sl.reg[X]);
+                if (sl.has_w) seam_pass(XB{}, sj, sjp, sjm, sl.fw[1 - X]);
+            };
+            (void)seam_half;
 #pragma unroll
             for (int s = 1; s <= K; s++) {
                 {   // red half-sweep of sweep s on row ja = r-2s+1
@@ -850,13 +900,15 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                     const row_t da = (yu0 - ja > ja - (yu1 - 1)) ? yu0 - ja : ja - (yu1 - 1);
                     if (da <= 2 * K - (2 * s - 1) && ja >= 1 && ja <= ycr - 2)
 #endif
-                    {
+                    if constexpr (!SEAM) {
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
                     const double v = M::template upd<X, UM, D>(cw, sj, sjp, comp<X>(sw[sj]),
                                                                comp<X>(sw[sjp]), comp<X>(sw[sjm]),
                                                                w, e, a.sc_);
                     setc<X>(sw[sj], v);
+                    } else {
+                        seam_half(sj, sjp, sjm);
                     }
                 }
                 {   // black half-sweep of sweep s on row jb = r-2s
@@ -866,13 +918,15 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                     const row_t db = (yu0 - jb > jb - (yu1 - 1)) ? yu0 - jb : jb - (yu1 - 1);
                     if (db <= 2 * K - 2 * s && jb >= 1 && jb <= ycr - 2)
 #endif
-                    {
+                    if constexpr (!SEAM) {
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
                     const double v = M::template upd<X, UM, D>(cw, sj, sjp, comp<X>(sw[sj]),
                                                                comp<X>(sw[sjp]), comp<X>(sw[sjm]),
                                                                w, e, a.sc_);
                     setc<X>(sw[sj], v);
+                    } else {
+                        seam_half(sj, sjp, sjm);
                     }
                     // row jb now holds sweep s: its share of mean|S| (branch-free)
 #if XINV_NORM_BRANCH

@@ -355,7 +355,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // per pass on k_fused2d (registers) and is bound by HBM at C4.  XINV_PIPE=3 restores the old crossover.
         const bool pipe_size_ok = pipe_mode != 3 || p.kind == KIND_GEN2D || p.nbatch * p.yc * p.xc <= (int64_t)10000000;
         // (k_pipe2d addresses a slice through buffer resources with signed 32-bit row offsets: slices below 2 GiB)
-        const bool pipe_want = pipe_mode != 0 && pipe_form && pipe_size_ok && !(opt.flags & XINV_FLAG_NO_PIPE) &&
+        const bool pipe_want = pipe_mode != 0 && pipe_form && pipe_size_ok && !pl.seam && !(opt.flags & XINV_FLAG_NO_PIPE) &&
                                (opt.sweeps_per_launch == 0 || opt.sweeps_per_launch == XINV_PIPE_P) &&
                                (p.yc + 16) * p.xc * 8 < ((int64_t)1 << 31);
         {
@@ -372,7 +372,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                     int o = 0;
                     FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
                     if (fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, k, dim3(1), dim3(256),
-                                       st, dummy, &o) == 0 && o >= occ_needed) { pl.K = k; break; }
+                                       st, dummy, &o, pl.seam != 0) == 0 && o >= occ_needed) { pl.K = k; break; }
                 }
             }
         }
@@ -429,7 +429,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
                 if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
                 else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
-                                    st, dummy, &occ);
+                                    st, dummy, &occ, pl.seam != 0);
             }
             // (pl.lone, set with K above: with one or two vector streams a second workgroup per CU
             // fills idle issue slots; with four or more a pair runs no faster than one, and tall
@@ -459,7 +459,10 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     int rc = XINV_OK;
     (void)n; (void)rc;
     // ---- path ------------------------------------------------------------------------------
-    const bool fused5_ok = pl.base == 2 && !pl.seam && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
+    // (the odd-xc periodic seam runs inside the 2-D 5-point streaming kernels -- xinv_fused.h: SEAM -- when a strip
+    //  spans at most three wraps of the row: xc >= 64; the 3-D, 9-point and biharmonic forms keep the colour launches)
+    const bool seam5_ok = !pl.seam || (!is3d(p.kind) && p.xc >= 64);
+    const bool fused5_ok = pl.base == 2 && seam5_ok && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
     const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
                            (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
     // biharmonic: the one-pass kernel needs A..I as per-row scalars (and xc % 3 == 0 when periodic)
@@ -485,7 +488,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     pl.nine = false;
     if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("no fused kernel for this form (odd-xc periodic seam, 9-point test form, biharmonic or general 3-D with coefficients that vary along x)");
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam in 3-D, with B != 0 or with xc < 64; 9-point test form; biharmonic or general 3-D with coefficients that vary along x)");
     if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 

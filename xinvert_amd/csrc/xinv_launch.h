@@ -43,8 +43,13 @@ static unsigned pick_um(int kind, unsigned umask)
 }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
-                          hipStream_t st, const FusedArgs &a, int *occ)
+                          hipStream_t st, const FusedArgs &a, int *occ, bool seam = false)
 {
+    if (seam) {                                          // odd-xc periodic seam variants (xinv_fused.h: SEAM)
+        if (kind == KIND_GEN2D) return xinv_launch_fused2d_gen_seam(al, ext, um, K, grid, block, st, a, occ);
+        if (kind == KIND_STD2DT) return xinv_launch_fused2d_std2dt_seam(al, ext, um, K, grid, block, st, a, occ);
+        return xinv_launch_fused2d_std_seam(al, ext, um, K, grid, block, st, a, occ);
+    }
     if (kind == KIND_GEN2D) return xinv_launch_fused2d_gen(al, ext, um, K, grid, block, st, a, occ);
     if (kind == KIND_STD2DT) return xinv_launch_fused2d_std2dt(al, ext, um, K, grid, block, st, a, occ);
     return xinv_launch_fused2d_std(al, ext, um, K, grid, block, st, a, occ);
@@ -136,7 +141,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
             xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad);
             continue;
         }
-        if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr))
+        if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr, pl.seam != 0))
             return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     }
     HIPCHK(hipGetLastError());
@@ -317,6 +322,15 @@ static int launch_fused3dg(const Problem &p, const Plan &pl, const double *src, 
 }
 
 // one full coloured sweep (+ norm + stop rule) in place on p.S
+// Order of the colour launches of one sweep (the oracle's seq_colour): with the odd-xc periodic seam each seam colour
+// (column xc-1, rows of one parity) runs right after the base colour its points would otherwise belong to.
+static inline int seam_sequence(int pos, int base, int seam)
+{
+    static const int s2[4] = {0, 2, 1, 3}, s4[6] = {0, 4, 1, 2, 5, 3};
+    if (!seam) return pos;
+    return base == 2 ? s2[pos] : s4[pos];
+}
+
 static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st,
                                int64_t m0, int64_t nm)
 {
@@ -384,8 +398,8 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
         a.nbatch = p.nbatch; a.member0 = m0;
         dim3 b(64, 4, 1);
         dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)(nm * (p.zc - 2)));
-        for (int cc = 0; cc < pl.ncol; cc++) {
-            a.colour = cc;
+        for (int pos = 0; pos < pl.ncol; pos++) {
+            a.colour = seam_sequence(pos, 2, pl.seam);
             if (p.kind == KIND_GEN3D) hipLaunchKernelGGL(k_colour_gen3d, g, b, 0, st, a);
             else                      hipLaunchKernelGGL(k_colour_std3d, g, b, 0, st, a);
         }
@@ -400,8 +414,8 @@ static int launch_colour_chunk(const Problem &p, const Plan &pl, Workspace *ws, 
         dim3 b(64, 4, 1);
         dim3 g(cdiv(cdiv(p.xc, 2) + 1, 64), cdiv(p.yc - 2, 4), (unsigned)nm);
         const bool nine = (pl.base == 4);
-        for (int cc = 0; cc < pl.ncol; cc++) {
-            a.colour = cc;
+        for (int pos = 0; pos < pl.ncol; pos++) {
+            a.colour = seam_sequence(pos, pl.base, pl.seam);
             if (p.kind == KIND_STD2D) {
                 if (nine) hipLaunchKernelGGL(k_colour_std2d<true>, g, b, 0, st, a);
                 else      hipLaunchKernelGGL(k_colour_std2d<false>, g, b, 0, st, a);
@@ -575,7 +589,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
         if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, ext, dim3(1), st, dummy, &occ);
-        else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ);
+        else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ, pl.seam != 0);
     }
     const bool pp = pl.pipe;
     const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, tpw) * nb, cdiv(yc, pl.nrb), K, occ, pl.lone, pp);

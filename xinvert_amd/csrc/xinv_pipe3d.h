@@ -79,22 +79,23 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     xinv_fresh_scalar_cache();
     constexpr int K = 2, H = 2 * K, UW = 128 - 2 * H, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
 
+    const int64_t m = a.member0 + blockIdx.y;
+    XinvCtl *ctl = a.ctl + m;
+    if (!a.force && xinv_ctl_done(ctl)) return;
+    const unsigned tag = xinv_ctl_seq(ctl);
+
     const int NB = a.nstrip * a.njb * a.nkc;
     int T;
     {
         const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
         T = xcd * q + (xcd < rem ? xcd : rem) + idx;
     }
-    // (MEASURED AND NOT KEPT, round 4: the launch's tiles as one list with the row block fastest, cut in eight contiguous
-    //  ranges, so that the workgroups resident on an XCD are j-neighbours of one strip and their halo rows could meet in
-    //  that XCD's L2 -- 15 volumes: 7.37 against 7.72 GB per launch with S streamed non-temporally, 7.96 against 8.36
-    //  without: the L2 does not absorb the halo, the workgroups of a round do not march in step)
+    // (MEASURED AND NOT KEPT, round 4, profiles/r04_pipe3d_variants.txt: the launch's tiles as one list with the row block
+    //  fastest, cut in eight contiguous ranges, so that the workgroups resident on an XCD are j-neighbours of one strip and
+    //  their halo rows could meet in that XCD's L2 -- 15 volumes: 7.37 against 7.72 GB per launch: the L2 does not absorb the
+    //  halo, the workgroups of a round do not march in step)
     const int kc = T / (a.nstrip * a.njb), Tj = T - kc * (a.nstrip * a.njb);
     const int jb = Tj / a.nstrip, st = Tj - jb * a.nstrip;
-    const int64_t m = a.member0 + blockIdx.y;
-    XinvCtl *ctl = a.ctl + m;
-    if (!a.force && xinv_ctl_done(ctl)) return;
-    const unsigned tag = xinv_ctl_seq(ctl);
     const int zc = (int)a.zc, yc = (int)a.yc;
     const int k0 = kc * a.KC;
     const int k1 = (kc + 1 == a.nkc) ? zc : k0 + a.KC;
@@ -134,7 +135,10 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                                      point-sweep against 12 + halo).  Bit-exact, reads -24 %, xch + ring = 160 KiB to the byte
                                      (the norm tail borrows xch) -- and 15 % SLOWER: at sixteen wavefronts the kernel has 128
                                      VGPRs and no SGPR left, and the variant spills 48-104 bytes per lane in group 1's march
-                                     (C5 15 volumes 2.52 against 2.97e11). */
+                                     (C5 15 volumes 2.52 against 2.97e11).  Round 4 (profiles/r04_pipe3d_variants.txt): with
+                                     the spills cut to 2-5 registers (12 or 8 wavefronts) it is still 13-19 % slower at 19 %
+                                     fewer bytes: only group 0 has loads in flight then, one plane ahead, and a step becomes
+                                     one memory latency (4.4 TB/s against 5.9); a deeper prefetch has no registers or LDS left. */
 #endif
     // [wave of the group][row][slot][S (| forcing)][lane]: planes with sweep 1 complete.
     // (laid out [wave][row][slot][S | forcing][lane]: every access of a wavefront is ONE base register + an immediate
@@ -145,16 +149,12 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     double nsx = 0.0, nsy = 0.0;                         // norm share per lane and column (un-owned lanes discarded below)
     int nnx = 0, nny = 0;
 
-    // the forcing of the plane in its red stage (both components: the other one is the black stage's) and of the plane
-    // in its black stage (the one component that stage still reads)
-    double2 sw[RR][D], fwr[RR], pfS[RR], pfF[RR];
-    double fwb[RR];
+    double2 sw[RR][D], fw[RR][2], pfS[RR], pfF[RR];
 #pragma unroll
     for (int rr = 0; rr < RR; rr++) {
 #pragma unroll
         for (int t = 0; t < D; t++) sw[rr][t] = make_double2(0.0, 0.0);
-        fwr[rr] = pfS[rr] = pfF[rr] = make_double2(0.0, 0.0);
-        fwb[rr] = 0.0;
+        fw[rr][0] = fw[rr][1] = pfS[rr] = pfF[rr] = make_double2(0.0, 0.0);
     }
 
 #ifndef XINV_P3_NT
@@ -205,12 +205,13 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 
     // one point update of component X of row rr on the plane in slot sk (k+1 in skp, k-1 in skm): the expression
     // of k_fused3d<UNI>, the increment added under the predicate as EXEC
-    auto update = [&](auto rtag, auto xt, int sk, int skp, int skm, const Rec &e, double jP, double jM, double f) {
+    auto update = [&](auto rtag, auto xt, int sk, int skp, int skm, const Rec &e, double jP, double jM) {
         constexpr int rr = decltype(rtag)::value;
         constexpr int X = decltype(xt)::value;
         double w, ee;
         row_neighbours<X>(sw[rr][sk], w, ee);
         const double sC = comp<X>(sw[rr][sk]), sKP = comp<X>(sw[rr][skp]), sKM = comp<X>(sw[rr][skm]);
+        const double f = comp<X>(fw[rr][sk & 1]);
         double temp = (
             (
                 e.aP * (sKP - sC) -
@@ -245,13 +246,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             } else {
                 sw[rr][U] = ring[gw][rr][U & 1][0][lane];
             }
-            // plane r-2 goes from its red to its black stage: its forcing travels on to group 1 (slot U & 1 was read by
-            // group 1 in the previous step and is rewritten with S at the end of this one) and keeps one component
-#if XINV_P3_FRING
-            if (GRP == 0) ring[gw][rr][U & 1][1][lane] = fwr[rr];
-#endif
-            fwb[rr] = XROW(rr) ? fwr[rr].y : fwr[rr].x;
-            fwr[rr] = pfF[rr];
+            fw[rr][S1 & 1] = pfF[rr];
 #if XINV_P3_FRING
             if (GRP == 0) pfF[rr] = ldF(plane_off(r, rr));
             else pfF[rr] = ring[gw][rr][U & 1][1][lane];
@@ -273,7 +268,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                 const Rec e = record(r - 1, rr);
                 const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S1]) : jMe;
                 const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S1]) : jPe;
-                const double v = update(rtag, XT{}, S1, U, S2, e, jP, jM, comp<X>(fwr[rr]));
+                const double v = update(rtag, XT{}, S1, U, S2, e, jP, jM);
                 if (rr == 0) xch[bw][1][wave][0][lane] = v;          // red-updated: the neighbours' next black half-sweep
                 if (rr == RR - 1) xch[bw][1][wave][1][lane] = v;
             }, std::make_integer_sequence<int, RR>{});
@@ -290,13 +285,16 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                 const Rec e = record(kk, rr);
                 const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S2]) : jMe;
                 const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S2]) : jPe;
-                update(rtag, XT{}, S2, S1, S3, e, jP, jM, fwb[rr]);
+                update(rtag, XT{}, S2, S1, S3, e, jP, jM);
             }, std::make_integer_sequence<int, RR>{});
 #pragma unroll
             for (int rr = 0; rr < RR; rr++) {
                 const double2 t = sw[rr][S2];
                 if (GRP == 0) {
                     ring[gw][rr][U & 1][0][lane] = t;
+#if XINV_P3_FRING
+                    ring[gw][rr][U & 1][1][lane] = fw[rr][S2 & 1];   // the forcing of the leaving plane r-2 (still in the window)
+#endif
                 }
                 if (pin && row_use[rr]) {                // wave-uniform: an owned row of an owned plane
                     xinv_norm_row(nsx, nsy, nnx, nny, t.x, t.y, u);

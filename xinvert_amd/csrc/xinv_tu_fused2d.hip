@@ -1,21 +1,27 @@
 // xinv_tu_fused2d.hip -- instantiations of k_fused2d for ONE model (compiled three times:
-// -DXINV_TU_MODEL=0 standard form, 1 general form, 2 standard "test" form).
+// -DXINV_TU_MODEL=0 standard form, 1 general form, 2 standard "test" form; and each once more with -DXINV_TU_SEAM=1:
+// the odd-xc periodic seam variants, unaligned strips only).
 #include <type_traits>
 #include "xinv_dispatch.h"
 
 // Launch one instantiation -- or, when `occ` is given, only report how many of its workgroups
 // fit on a CU (register-limited: 1 to 3), which the tiling heuristic needs.
+#ifndef XINV_TU_SEAM
+#define XINV_TU_SEAM 0
+#endif
+constexpr bool SEAM = XINV_TU_SEAM != 0;
+
 template <class M, int K, bool AL, unsigned UM, bool EXT>
 static int fused_one(dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a, int *occ)
 {
     if (occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused2d<M, K, AL, UM, EXT>, 256, 0) != hipSuccess)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused2d<M, K, AL, UM, EXT, 0, SEAM>, 256, 0) != hipSuccess)
             n = 1;
         *occ = n < 1 ? 1 : n;
         return 0;
     }
-    hipLaunchKernelGGL((k_fused2d<M, K, AL, UM, EXT>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((k_fused2d<M, K, AL, UM, EXT, 0, SEAM>), grid, block, 0, st, a);
     return 0;
 }
 
@@ -58,13 +64,20 @@ template <class M>
 static int launch_fused_m(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
                           const FusedArgs &a, int *occ)
 {
-    if (al) return ext ? launch_fused_um<M, true, true>(um, K, grid, block, st, a, occ)
-                       : launch_fused_um<M, true, false>(um, K, grid, block, st, a, occ);
+    if constexpr (!SEAM) {
+        if (al) return ext ? launch_fused_um<M, true, true>(um, K, grid, block, st, a, occ)
+                           : launch_fused_um<M, true, false>(um, K, grid, block, st, a, occ);
+    } else if (al) return 1;
     return ext ? launch_fused_um<M, false, true>(um, K, grid, block, st, a, occ)
                : launch_fused_um<M, false, false>(um, K, grid, block, st, a, occ);
 }
 
 
+#if XINV_TU_SEAM
+#define xinv_launch_fused2d_std xinv_launch_fused2d_std_seam
+#define xinv_launch_fused2d_gen xinv_launch_fused2d_gen_seam
+#define xinv_launch_fused2d_std2dt xinv_launch_fused2d_std2dt_seam
+#endif
 #if XINV_TU_MODEL == 0
 int xinv_launch_fused2d_std(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
                             const FusedArgs &a, int *occ)
