@@ -34,6 +34,8 @@ UNITS = [
     ('xinv_tu_fused2d_std2dt_seam', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=2', '-DXINV_TU_SEAM=1']),
     ('xinv_tu_pipe2d_std', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=0']),
     ('xinv_tu_pipe2d_gen', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=1']),
+    ('xinv_tu_pipe2d_std_seam', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=0', '-DXINV_TU_SEAM=1']),
+    ('xinv_tu_pipe2d_gen_seam', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=1', '-DXINV_TU_SEAM=1']),
     ('xinv_tu_fused9', 'xinv_tu_fused9.hip', []),
     ('xinv_tu_fused3d', 'xinv_tu_fused3d.hip', []),
     # the biharmonic update is 51 dependent-chain flops per point and colour stage at one or two wavefronts per SIMD: the

@@ -36,9 +36,15 @@ XINV_HIDDEN int xinv_launch_pipe2d_std(unsigned um, int np, bool fr, bool al, bo
                                        const FusedArgs &a, int *occ, int lds_pad);
 XINV_HIDDEN int xinv_launch_pipe2d_gen(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
                                        const FusedArgs &a, int *occ, int lds_pad);
+XINV_HIDDEN int xinv_launch_pipe2d_std_seam(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
+                                            const FusedArgs &a, int *occ, int lds_pad);
+XINV_HIDDEN int xinv_launch_pipe2d_gen_seam(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
+                                            const FusedArgs &a, int *occ, int lds_pad);
 static inline int xinv_launch_pipe2d(bool gen, unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
-                                     const FusedArgs &a, int *occ, int lds_pad = 0)
+                                     const FusedArgs &a, int *occ, int lds_pad = 0, bool seam = false)
 {
+    if (seam) return gen ? xinv_launch_pipe2d_gen_seam(um, np, fr, al, ext, grid, st, a, occ, lds_pad)
+                         : xinv_launch_pipe2d_std_seam(um, np, fr, al, ext, grid, st, a, occ, lds_pad);
     return gen ? xinv_launch_pipe2d_gen(um, np, fr, al, ext, grid, st, a, occ, lds_pad)
                : xinv_launch_pipe2d_std(um, np, fr, al, ext, grid, st, a, occ, lds_pad);
 }

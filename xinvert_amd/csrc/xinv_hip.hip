@@ -355,7 +355,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // per pass on k_fused2d (registers) and is bound by HBM at C4.  XINV_PIPE=3 restores the old crossover.
         const bool pipe_size_ok = pipe_mode != 3 || p.kind == KIND_GEN2D || p.nbatch * p.yc * p.xc <= (int64_t)10000000;
         // (k_pipe2d addresses a slice through buffer resources with signed 32-bit row offsets: slices below 2 GiB)
-        const bool pipe_want = pipe_mode != 0 && pipe_form && pipe_size_ok && !pl.seam && !(opt.flags & XINV_FLAG_NO_PIPE) &&
+        const bool pipe_want = pipe_mode != 0 && pipe_form && pipe_size_ok && !(opt.flags & XINV_FLAG_NO_PIPE) &&
                                (opt.sweeps_per_launch == 0 || opt.sweeps_per_launch == XINV_PIPE_P) &&
                                (p.yc + 16) * p.xc * 8 < ((int64_t)1 << 31);
         {
@@ -381,7 +381,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // two column pairs per lane (strips of 240 owned columns) where the grid is wide enough to keep the
         // workgroup count up; XINV_PIPE_NP=1|2 forces the choice
         const int np_env = [] { const char *e = getenv("XINV_PIPE_NP"); return e ? atoi(e) : 0; }();   // (read per solve: tests switch it)
-        pl.npair = ((np_env == 1 || np_env == 2) && p.kind == KIND_STD2D) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
+        pl.npair = ((np_env == 1 || np_env == 2) && p.kind == KIND_STD2D && !pl.seam) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
         // the forcing through the LDS ring where the launch's streams (S read + write + forcing, every member) no
         // longer fit the caches and the later wavefronts' forcing requests would go back to HBM; XINV_PIPE_FR=0|1 forces
         {
@@ -427,7 +427,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             int occ = 2;                                   // workgroups of the chosen variant per CU
             {
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-                if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
+                if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ, 0, pl.seam != 0);
                 else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
                                     st, dummy, &occ, pl.seam != 0);
             }

@@ -138,7 +138,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
             // (XINV_PIPE_LDSPAD: unused dynamic LDS per workgroup, to cap the workgroups per CU in experiments;
             //  capping at the planned count changed nothing: the dispatcher already spreads them evenly)
             static const int pad = [] { const char *e = getenv("XINV_PIPE_LDSPAD"); return e ? std::max(0, atoi(e)) : 0; }();
-            xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad);
+            xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad, pl.seam != 0);
             continue;
         }
         if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr, pl.seam != 0))
@@ -588,7 +588,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     int occ = occ_ > 0 ? occ_ : 2;
     if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-        if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, ext, dim3(1), st, dummy, &occ);
+        if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, ext, dim3(1), st, dummy, &occ, 0, pl.seam != 0);
         else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ, pl.seam != 0);
     }
     const bool pp = pl.pipe;

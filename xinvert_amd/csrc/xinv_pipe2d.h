@@ -196,7 +196,10 @@ __device__ __forceinline__ void pipe_extend_fix(double2 &edge, const double2 &in
 // LDS instead of asking the L2 for it again.  For launches whose arrays exceed the caches (a batch of members) the
 // later wavefronts' requests, ~20 rows behind the first, had fallen out of the L2 by then: C4, 64 members: 8.3 B
 // per point-sweep measured against 6 B the variant must move (profiles/r03_pmc_*_c4.txt).
-template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT, int PW, int PF>
+// SEAM (periodic x, odd xc: xinv_fused.h): a half-sweep of a tile that wraps around the seam is up to three passes
+// under 64-bit lane masks ANDed into the update's EXEC mask -- east-wrapped lanes' other component, unwrapped lanes,
+// west-wrapped lanes' other component.
+template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT, int PW, int PF, bool SEAM = false>
 __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
                                                const LaneCols (&lc)[NP], const int64_t (&st0)[NP], int lane,
                                                double2 (*ring)[XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE], int gtot,
@@ -244,6 +247,18 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         nsx[q] = nsy[q] = 0.0; nnx[q] = nny[q] = 0;
     }
 #endif
+
+    // SEAM: lane classes of the two components as 64-bit masks (wave-uniform: SGPR pairs)
+    unsigned long long sfe[2] = {0ull, 0ull}, sfw[2] = {0ull, 0ull};
+    if constexpr (SEAM) {
+        static_assert(!SEAM || (NP == 1 && !AL && PipeRec<M, UM>::HOIST), "seam variants: one column pair per lane, per-row records");
+        const SeamLanes sl = make_seamlanes(st0[0], lc[0], a.xc);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            sfe[c] = __builtin_amdgcn_ballot_w64(sl.fe[c] != 0u);
+            sfw[c] = __builtin_amdgcn_ballot_w64(sl.fw[c] != 0u);
+        }
+    }
 
     const int in_lo = yu0 - H + 2 * PW;                  // first / last row entering this wavefront's window
     const int in_hi = yu1 - 1 + H - 2 * PW;
@@ -331,9 +346,10 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #endif
 
     // one half-sweep of row record sj (sjp / sjm: the rows below / above) on lane components X
-    auto half_sweep = [&](auto xtag, auto jtag, auto ptag, auto mtag) {
+    auto half_pass = [&](auto xtag, auto jtag, auto ptag, auto mtag, unsigned long long lanes) {
         constexpr int X = decltype(xtag)::value, sj = decltype(jtag)::value, sjp = decltype(ptag)::value,
                       sjm = decltype(mtag)::value;
+        (void)lanes;
         // the one operand that crosses lanes: west of the first column / east of the last
         const double edge = (X == 0) ? xinv_lane_up(sw[NP - 1][sj].y) : xinv_lane_down(sw[0][sj].x);
         double nv[NP];
@@ -350,7 +366,8 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 // the predicate: (column may be updated) & (row may be updated: the record's predicate word is all
                 // ones or zero, k_row_factor) as a 64-bit lane mask on the scalar unit, (forcing defined) by the
                 // compare that writes EXEC
-                const unsigned long long rm = (X ? oky64[q] : okx64[q]) & (unsigned long long)__double_as_longlong(rokw[sj]);
+                unsigned long long rm = (X ? oky64[q] : okx64[q]) & (unsigned long long)__double_as_longlong(rokw[sj]);
+                if constexpr (SEAM) rm &= lanes;
                 nv[q] = xinv_add_where_ne(comp<X>(sw[q][sj]), t, comp<X>(cw[q].v[FQ][sj]), u, rm);
             } else {
                 const unsigned long long pm = __builtin_amdgcn_ballot_w64((X ? cw[q].my[sj] : cw[q].mx[sj]) != 0u);
@@ -363,6 +380,17 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         }
 #pragma unroll
         for (int q = 0; q < NP; q++) setc<X>(sw[q][sj], nv[q]);
+    };
+    auto half_sweep = [&](auto xtag, auto jtag, auto ptag, auto mtag) {
+        constexpr int X = decltype(xtag)::value;
+        if constexpr (!SEAM) {
+            half_pass(xtag, jtag, ptag, mtag, ~0ull);
+        } else {
+            using XB = std::integral_constant<int, 1 - X>;
+            if (sfe[1 - X]) half_pass(XB{}, jtag, ptag, mtag, sfe[1 - X]);
+            half_pass(xtag, jtag, ptag, mtag, ~(sfe[X] | sfw[X]));
+            if (sfw[1 - X]) half_pass(XB{}, jtag, ptag, mtag, sfw[1 - X]);
+        }
     };
 
 #if XINV_PIPE_FLAGS
@@ -596,7 +624,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #endif
 }
 
-template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT>
+template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT, bool SEAM = false>
 __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 {
 #ifndef XINV_PIPE_INV
@@ -678,10 +706,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         }
         gtot = ((gtot + B - 1) / B) * B;
         switch (pwi) {
-        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0, SEAM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF, SEAM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF, SEAM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF, SEAM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
         }
     }
     }

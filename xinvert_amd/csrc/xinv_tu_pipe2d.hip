@@ -1,34 +1,47 @@
 // xinv_tu_pipe2d.hip -- instantiations of k_pipe2d (wave-pipelined four-sweep pass, xinv_pipe2d.h) for ONE model
-// (compiled twice: -DXINV_TU_MODEL=0 standard form, 1 general form).
+// (compiled twice: -DXINV_TU_MODEL=0 standard form, 1 general form; each once more with -DXINV_TU_SEAM=1: the odd-xc
+// periodic seam variants -- unaligned strips, one column pair per lane).
 #include "xinv_dispatch.h"
+
+#ifndef XINV_TU_SEAM
+#define XINV_TU_SEAM 0
+#endif
+constexpr bool SEAM = XINV_TU_SEAM != 0;
 
 template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT>
 static int pipe_one(dim3 grid, hipStream_t st, const FusedArgs &a, int *occ, int lds_pad)
 {
     if (occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_pipe2d<M, UM, FR, NP, AL, EXT>, 64 * XINV_PIPE_P, 0) != hipSuccess)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_pipe2d<M, UM, FR, NP, AL, EXT, SEAM>, 64 * XINV_PIPE_P, 0) != hipSuccess)
             n = 1;
         *occ = n < 1 ? 1 : n;
         return 0;
     }
-    hipLaunchKernelGGL((k_pipe2d<M, UM, FR, NP, AL, EXT>), grid, dim3(64 * XINV_PIPE_P, 1, 1), (size_t)lds_pad, st, a);
+    hipLaunchKernelGGL((k_pipe2d<M, UM, FR, NP, AL, EXT, SEAM>), grid, dim3(64 * XINV_PIPE_P, 1, 1), (size_t)lds_pad, st, a);
     return 0;
 }
 
 template <class M, unsigned UM, bool FR, int NP>
 static int pipe_np(bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ, int lds_pad)
 {
-    if (al) return ext ? pipe_one<M, UM, FR, NP, true, true>(grid, st, a, occ, lds_pad) : pipe_one<M, UM, FR, NP, true, false>(grid, st, a, occ, lds_pad);
+    if constexpr (!SEAM) {
+        if (al) return ext ? pipe_one<M, UM, FR, NP, true, true>(grid, st, a, occ, lds_pad) : pipe_one<M, UM, FR, NP, true, false>(grid, st, a, occ, lds_pad);
+    } else if (al) return 1;
     return ext ? pipe_one<M, UM, FR, NP, false, true>(grid, st, a, occ, lds_pad) : pipe_one<M, UM, FR, NP, false, false>(grid, st, a, occ, lds_pad);
 }
 
+#if XINV_TU_SEAM
+#define xinv_launch_pipe2d_std xinv_launch_pipe2d_std_seam
+#define xinv_launch_pipe2d_gen xinv_launch_pipe2d_gen_seam
+#endif
 #if XINV_TU_MODEL == 0
 int xinv_launch_pipe2d_std(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ, int lds_pad)
 {
     if (um == 3u && fr) return pipe_np<FusedStd2D, 3u, true, 1>(al, ext, grid, st, a, occ, lds_pad);
-    if (um == 3u) return np == 2 ? pipe_np<FusedStd2D, 3u, false, 2>(al, ext, grid, st, a, occ, lds_pad)
-                                 : pipe_np<FusedStd2D, 3u, false, 1>(al, ext, grid, st, a, occ, lds_pad);
+    if constexpr (SEAM) { if (um == 3u && np == 1) return pipe_np<FusedStd2D, 3u, false, 1>(al, ext, grid, st, a, occ, lds_pad); }
+    else if (um == 3u) return np == 2 ? pipe_np<FusedStd2D, 3u, false, 2>(al, ext, grid, st, a, occ, lds_pad)
+                                      : pipe_np<FusedStd2D, 3u, false, 1>(al, ext, grid, st, a, occ, lds_pad);
     return 1;
 }
 #else
