@@ -686,6 +686,22 @@ def main():
                             'land_share': float(np.mean(p2['coefs'][3] == p2['undef'])),
                             'avg_launch_us': m2 / max(l2, 1) * 1e3, 'kernel': kernel_name(kind, s2)}
             out['mask_sensitivity'] = alt
+        if a.config == 'c2' and single and not a.no_configs:
+            # ---- the opt-in contracted arithmetic (XINV_FLAG_FMA) on the same workload: NOT the headline (the default
+            # path is the reference's arithmetic bit for bit); checked bit for bit against the oracle's XO_FMA restatement
+            import oracle as orc
+            tf, mf, lf, sf, _ = time_resident(rp, sweeps, 5, 1, timing=1, fma=1)
+            fsw = min(sweeps, 100)
+            rp.reset()
+            fl_f, _ = rp.solve(fsw - 1, 0.0, fma=1)
+            fpar = oracle_parity(synthetic.member(p, 0), rp.result()[0], fl_f[0], fsw, orc.COLOUR_2 | orc.FMA)
+            out['contracted'] = {'flag': 'XINV_FLAG_FMA (opt-in; explicit fma at fixed positions of the update)',
+                                 'value': float(nb) * n * sweeps * 5 / tf, 'unit': 'point-sweeps/s',
+                                 'vs_default': float(nb) * n * sweeps * 5 / tf / out['value'],
+                                 'avg_launch_us': mf / max(lf, 1) * 1e3, 'kernel': kernel_name(kind, sf),
+                                 'parity_vs_fma_oracle': fpar,
+                                 'tied_to_reference': 'tests/test_fma_oracle.py: <= 1e-12 relative to the reference\'s golden '
+                                                      'vectors after their sweeps, <= 1e-6 rel-L2 converged'}
         del rp
         if a.config == 'c2' and single and not a.no_configs:
             out['configs'] = config_lines(local)

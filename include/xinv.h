@@ -55,6 +55,14 @@ extern "C" {
 #define XINV_FLAG_NO_TILE_SKIP 2 /* run every tile even where the forcing is masked throughout    */
 #define XINV_FLAG_FORCE_TILE_SKIP 4 /* testing aid: skip masked tiles whatever the grid size, keep
                                     the row split                                                */
+#define XINV_FLAG_FMA 32         /* OPT-IN contracted arithmetic: the point update with fused multiply-adds at fixed
+                                    positions (about a fifth fewer vector instructions).  NOT the reference's
+                                    arithmetic -- numba evaluates the update without contraction, and so does the
+                                    default path, bit for bit -- but within 1e-12 (relative) of it after tens of
+                                    sweeps and within north_star's 1e-6 rel-L2 at convergence; the oracle restates
+                                    it (XO_FMA) and the kernels with the flag are bitwise THAT.  Available for the
+                                    per-row-coefficient variants of the streaming kernels (lat-lon Poisson,
+                                    Gill-Matsuno, omega); XINV_ERR_ARG elsewhere.                              */
 #define XINV_FLAG_PIN_HOST 8     /* host-pointer entries: register the caller's arrays in place for the
                                     call (DMA at PCIe rate).  Off by default: only for buffers that stay
                                     mapped afterwards (see xinv_host.h)                           */

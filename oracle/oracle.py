@@ -11,6 +11,7 @@ import subprocess
 import numpy as np
 
 LEX, COLOUR_AUTO, COLOUR_2, COLOUR_4 = 0, 1, 2, 4
+FMA = 0x100        # ORed into `order`: the contracted arithmetic of the HIP kernels' opt-in mode (xinv_oracle.c: XO_FMA)
 BC_CODES = {'fixed': 0, 'extend': 1, 'periodic': 2}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -42,6 +42,11 @@
 #define XO_COLOUR_AUTO 1
 #define XO_COLOUR_2 2
 #define XO_COLOUR_4 4
+/* ORed into `order` (standard 2-D, general 2-D and standard 3-D forms; B must be identically zero in 2-D): the
+ * contracted arithmetic of the HIP kernels' opt-in mode XINV_FLAG_FMA -- explicit fma() at fixed positions of the update,
+ * the relaxation factor as before.  NOT the reference's arithmetic: tied to it by tests (<= 1e-12 relative after tens
+ * of sweeps, <= 1e-6 rel-L2 converged); the HIP kernels with the flag are bitwise this. */
+#define XO_FMA 0x100
 
 #define BC_FIXED 0
 #define BC_EXTEND 1
@@ -150,7 +155,7 @@ static void extend3d(double *S, int64_t zc, int64_t yc, int64_t xc, int BCx, dou
 static inline void upd_std2d(double *S, const double *A, const double *B, const double *C,
                              const double *F, int64_t xc, int64_t j, int64_t i, int64_t im,
                              int64_t ip, int west, double delxSqr, double ratioQtr,
-                             double ratioSqr, double optArg, double undef)
+                             double ratioSqr, double optArg, double undef, int fm)
 {
     const int64_t r = j * xc, rp = (j + 1) * xc, rm = (j - 1) * xc;
     const int64_t bn = west ? ip : i, sq = west ? i : ip;
@@ -160,6 +165,16 @@ static inline void upd_std2d(double *S, const double *A, const double *B, const 
                 B[rp + i] != undef && B[rm + i] != undef &&
                 C[r + ip] != undef && C[r + i] != undef);
     if (!cond) return;
+    if (fm) {           /* XO_FMA (B == 0, checked by the caller): the contracted form of the HIP kernels' opt-in mode */
+        const double sC = S[r + i];
+        const double y = fma(A[rp + i], S[rp + i] - sC, -(A[r + i] * (sC - S[rm + i])));
+        const double x = fma(C[r + ip], S[r + ip] - sC, -(C[r + i] * (sC - S[r + im])));
+        double t = fma(y, ratioSqr, x);
+        t = fma(-F[r + i], delxSqr, t);
+        const double rq = optArg / ((A[rp + i] + A[r + i]) * ratioSqr + (C[r + ip] + C[r + i]));
+        S[r + i] = fma(t, rq, sC);
+        return;
+    }
     double temp = (
         (
             A[rp + i] * (S[rp + i] - S[r + i]) -
@@ -184,7 +199,7 @@ static inline void upd_gen2d(double *S, const double *A, const double *B, const 
                              const double *D, const double *E, const double *F, const double *G,
                              int64_t xc, int64_t j, int64_t i, int64_t im, int64_t ip,
                              double delx, double delxSqr, double ratio, double ratioQtr,
-                             double ratioSqr, double optArg, double undef)
+                             double ratioSqr, double optArg, double undef, int fm)
 {
     const int64_t r = j * xc, rp = (j + 1) * xc, rm = (j - 1) * xc;
     int cond = (G[r + i] != undef &&
@@ -192,6 +207,19 @@ static inline void upd_gen2d(double *S, const double *A, const double *B, const 
                 C[r + i] != undef && D[r + i] != undef &&
                 E[r + i] != undef && F[r + i] != undef);
     if (!cond) return;
+    if (fm) {           /* XO_FMA (B == 0, checked by the caller) */
+        const double sC = S[r + i], sP = S[rp + i], sM = S[rm + i], sE = S[r + ip], sW = S[r + im];
+        double t = (A[r + i] * ((sP - sC) - (sC - sM))) * ratioSqr;
+        t = fma(C[r + i], (sE - sC) - (sC - sW), t);
+        double v = (D[r + i] * (sP - sM)) * ratio;
+        v = fma(E[r + i], sE - sW, v);
+        t = fma(v * delx, 0.5, t);
+        t = fma(fma(F[r + i], sC, -G[r + i]), delxSqr, t);
+        const double rq = optArg / ((A[r + i] * ratioSqr + C[r + i]) * 2.0
+                                    - F[r + i] * delxSqr);
+        S[r + i] = fma(t, rq, sC);
+        return;
+    }
     double temp = (
         A[r + i] * (
             (S[rp + i] - S[r + i]) - (S[r + i] - S[rm + i])
@@ -219,7 +247,7 @@ static inline void upd_gen2d(double *S, const double *A, const double *B, const 
 static inline void upd_std3d(double *S, const double *A, const double *B, const double *C,
                              const double *F, int64_t P, int64_t xc, int64_t k, int64_t j,
                              int64_t i, int64_t im, int64_t ip, double delxSqr,
-                             double ratio2Sqr, double ratio1Sqr, double optArg, double undef)
+                             double ratio2Sqr, double ratio1Sqr, double optArg, double undef, int fm)
 {
     const int64_t r = k * P + j * xc;
     const int64_t c = r + i;
@@ -228,6 +256,19 @@ static inline void upd_std3d(double *S, const double *A, const double *B, const 
                 B[c + xc] != undef && B[c] != undef &&
                 C[r + ip] != undef && C[c] != undef);
     if (!cond) return;
+    if (fm) {           /* XO_FMA */
+        const double sC = S[c];
+        const double ya = fma(A[c + P], S[c + P] - sC, -(A[c] * (sC - S[c - P])));
+        const double yb = fma(B[c + xc], S[c + xc] - sC, -(B[c] * (sC - S[c - xc])));
+        const double yc_ = fma(C[r + ip], S[r + ip] - sC, -(C[c] * (sC - S[r + im])));
+        double t = fma(ya, ratio2Sqr, fma(yb, ratio1Sqr, yc_));
+        t = fma(-F[c], delxSqr, t);
+        const double rq = optArg / ((A[c + P] + A[c]) * ratio2Sqr +
+                                    (B[c + xc] + B[c]) * ratio1Sqr +
+                                    (C[r + ip] + C[c]));
+        S[c] = fma(t, rq, sC);
+        return;
+    }
     double temp = (
         (
             A[c + P] * (S[c + P] - S[c]) -
@@ -326,6 +367,9 @@ int xo_standard_2d(double *S, const double *A, const double *B, const double *C,
 {
     (void)dely; (void)delx;
     if (yc < 3 || xc < 3) return -1;
+    const int fm = (order & XO_FMA) != 0;
+    order &= ~XO_FMA;
+    if (fm && !all_zero(B, yc * xc)) return -2;
     xo_ctl ctl = { 0, DBL_MAX };
     const int per = (BCx == BC_PERIODIC);
     int base = 0, seam = 0;
@@ -343,13 +387,13 @@ int xo_standard_2d(double *S, const double *A, const double *B, const double *C,
             for (int64_t j = 1; j < yc - 1; j++) {
                 if (per)
                     upd_std2d(S, A, B, C, F, xc, j, 0, xc - 1, 1, 1,
-                              delxSqr, ratioQtr, ratioSqr, optArg, undef);
+                              delxSqr, ratioQtr, ratioSqr, optArg, undef, fm);
                 for (int64_t i = 1; i < xc - 1; i++)
                     upd_std2d(S, A, B, C, F, xc, j, i, i - 1, i + 1, 0,
-                              delxSqr, ratioQtr, ratioSqr, optArg, undef);
+                              delxSqr, ratioQtr, ratioSqr, optArg, undef, fm);
                 if (per)
                     upd_std2d(S, A, B, C, F, xc, j, xc - 1, xc - 2, 0, 0,
-                              delxSqr, ratioQtr, ratioSqr, optArg, undef);
+                              delxSqr, ratioQtr, ratioSqr, optArg, undef, fm);
             }
         } else {
             for (int c = 0; c < ncol; c++)
@@ -359,7 +403,7 @@ int xo_standard_2d(double *S, const double *A, const double *B, const double *C,
                         int64_t im = i == 0 ? xc - 1 : i - 1;
                         int64_t ip = i == xc - 1 ? 0 : i + 1;
                         upd_std2d(S, A, B, C, F, xc, j, i, im, ip, i == 0,
-                                  delxSqr, ratioQtr, ratioSqr, optArg, undef);
+                                  delxSqr, ratioQtr, ratioSqr, optArg, undef, fm);
                     }
         }
 
@@ -378,6 +422,9 @@ int xo_general_2d(double *S, const double *A, const double *B, const double *C,
 {
     (void)dely;
     if (yc < 3 || xc < 3) return -1;
+    const int fm = (order & XO_FMA) != 0;
+    order &= ~XO_FMA;
+    if (fm && !all_zero(B, yc * xc)) return -2;
     xo_ctl ctl = { 0, DBL_MAX };
     const int per = (BCx == BC_PERIODIC);
     int base = 0, seam = 0;
@@ -395,13 +442,13 @@ int xo_general_2d(double *S, const double *A, const double *B, const double *C,
             for (int64_t j = 1; j < yc - 1; j++) {
                 if (per)
                     upd_gen2d(S, A, B, C, D, E, F, G, xc, j, 0, xc - 1, 1,
-                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef, fm);
                 for (int64_t i = 1; i < xc - 1; i++)
                     upd_gen2d(S, A, B, C, D, E, F, G, xc, j, i, i - 1, i + 1,
-                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef, fm);
                 if (per)
                     upd_gen2d(S, A, B, C, D, E, F, G, xc, j, xc - 1, xc - 2, 0,
-                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+                              delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef, fm);
             }
         } else {
             for (int c = 0; c < ncol; c++)
@@ -411,7 +458,7 @@ int xo_general_2d(double *S, const double *A, const double *B, const double *C,
                         int64_t im = i == 0 ? xc - 1 : i - 1;
                         int64_t ip = i == xc - 1 ? 0 : i + 1;
                         upd_gen2d(S, A, B, C, D, E, F, G, xc, j, i, im, ip,
-                                  delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef);
+                                  delx, delxSqr, ratio, ratioQtr, ratioSqr, optArg, undef, fm);
                     }
         }
 
@@ -430,6 +477,8 @@ int xo_standard_3d(double *S, const double *A, const double *B, const double *C,
 {
     (void)delz; (void)dely; (void)delx; (void)BCz;
     if (zc < 3 || yc < 3 || xc < 3) return -1;
+    const int fm = (order & XO_FMA) != 0;
+    order &= ~XO_FMA;
     xo_ctl ctl = { 0, DBL_MAX };
     const int per = (BCx == BC_PERIODIC);
     const int seam = (order != XO_LEX) && per && (xc & 1);
@@ -445,13 +494,13 @@ int xo_standard_3d(double *S, const double *A, const double *B, const double *C,
                 for (int64_t j = 1; j < yc - 1; j++) {
                     if (per)
                         upd_std3d(S, A, B, C, F, P, xc, k, j, 0, xc - 1, 1,
-                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef, fm);
                     for (int64_t i = 1; i < xc - 1; i++)
                         upd_std3d(S, A, B, C, F, P, xc, k, j, i, i - 1, i + 1,
-                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef, fm);
                     if (per)
                         upd_std3d(S, A, B, C, F, P, xc, k, j, xc - 1, xc - 2, 0,
-                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                                  delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef, fm);
                 }
         } else {
             for (int c = 0; c < ncol; c++)
@@ -464,7 +513,7 @@ int xo_standard_3d(double *S, const double *A, const double *B, const double *C,
                             int64_t im = i == 0 ? xc - 1 : i - 1;
                             int64_t ip = i == xc - 1 ? 0 : i + 1;
                             upd_std3d(S, A, B, C, F, P, xc, k, j, i, im, ip,
-                                      delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef);
+                                      delxSqr, ratio2Sqr, ratio1Sqr, optArg, undef, fm);
                         }
         }
 

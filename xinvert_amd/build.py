@@ -34,10 +34,15 @@ UNITS = [
     ('xinv_tu_fused2d_std2dt_seam', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=2', '-DXINV_TU_SEAM=1']),
     ('xinv_tu_pipe2d_std', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=0']),
     ('xinv_tu_pipe2d_gen', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=1']),
+    # contracted arithmetic (XINV_FLAG_FMA): the per-row-coefficient variants on the F models
+    ('xinv_tu_fused2d_stdf', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=3']),
+    ('xinv_tu_fused2d_genf', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=4']),
+    ('xinv_tu_pipe2d_fma', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=2']),
     ('xinv_tu_pipe2d_std_seam', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=0', '-DXINV_TU_SEAM=1']),
     ('xinv_tu_pipe2d_gen_seam', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=1', '-DXINV_TU_SEAM=1']),
     ('xinv_tu_fused9', 'xinv_tu_fused9.hip', []),
     ('xinv_tu_fused3d', 'xinv_tu_fused3d.hip', []),
+    ('xinv_tu_fused3d_fma', 'xinv_tu_fused3d_fma.hip', []),
     # the biharmonic update is 51 dependent-chain flops per point and colour stage at one or two wavefronts per SIMD: the
     # default (occupancy-first) scheduler serialises the chains; max-ILP interleaves them (Munk 2000x2000: 1.04 -> 1.15e11)
     ('xinv_tu_bih', 'xinv_tu_bih.hip', ['-mllvm', '-amdgpu-sched-strategy=max-ilp']),

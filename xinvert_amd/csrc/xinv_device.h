@@ -216,6 +216,15 @@ __device__ __forceinline__ double xinv_add_where_ne(double a, double b, double f
         : "+v"(a), "=&s"(sv) : "v"(b), "v"(f), "s"(u), "s"(rowmask) : "scc", "vcc");
     return a;
 }
+// the same with the contracted finish of XINV_FLAG_FMA: a = fma(t, rq, a) in those lanes (rq: the row's relaxation
+// factor, wave-uniform, read through the scalar unit)
+__device__ __forceinline__ double xinv_fma_where_ne(double a, double t, double rq, double f, double u, unsigned long long rowmask)
+{
+    unsigned long long sv;
+    asm("s_and_saveexec_b64 %1, %6\n\tv_cmpx_neq_f64_e32 vcc, %5, %4\n\tv_fma_f64 %0, %2, %3, %0\n\ts_mov_b64 exec, %1"
+        : "+v"(a), "=&s"(sv) : "v"(t), "s"(rq), "v"(f), "s"(u), "s"(rowmask) : "scc", "vcc");
+    return a;
+}
 // a row's share of mean|S|: sum += |x| and n += 1 in the lanes whose x differs from u, for both columns of the lane
 // (per-lane accumulators; the caller discards the lanes that do not own their column).  Nine instructions.
 __device__ __forceinline__ void xinv_norm_row(double &sx, double &sy, int &nx, int &ny, double x, double y, double u)

@@ -27,6 +27,13 @@ XINV_HIDDEN int xinv_launch_fused2d_gen_seam(bool al, bool ext, unsigned um, int
                                              hipStream_t st, const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused2d_std2dt_seam(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                                                 hipStream_t st, const FusedArgs &a, int *occ);
+// contracted arithmetic (XINV_FLAG_FMA): per-row-coefficient variants of k_fused2d / k_pipe2d on the F models
+XINV_HIDDEN int xinv_launch_fused2d_stdf(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                         hipStream_t st, const FusedArgs &a, int *occ);
+XINV_HIDDEN int xinv_launch_fused2d_genf(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                         hipStream_t st, const FusedArgs &a, int *occ);
+XINV_HIDDEN int xinv_launch_pipe2d_fma(bool gen, unsigned um, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
+                                       const FusedArgs &a, int *occ, int lds_pad);
 // wave-pipelined four-sweep pass, one tile per 256-thread workgroup: standard form (um = 3: A and C per row, np = 1
 // or 2 column pairs per lane) and general form (um = 0x1f: A C D E F per row).  Returns 1 for a variant that is
 // not instantiated (coefficient arrays varying along x: measured slower than k_fused2d, see plan_fused5).
@@ -41,8 +48,9 @@ XINV_HIDDEN int xinv_launch_pipe2d_std_seam(unsigned um, int np, bool fr, bool a
 XINV_HIDDEN int xinv_launch_pipe2d_gen_seam(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
                                             const FusedArgs &a, int *occ, int lds_pad);
 static inline int xinv_launch_pipe2d(bool gen, unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
-                                     const FusedArgs &a, int *occ, int lds_pad = 0, bool seam = false)
+                                     const FusedArgs &a, int *occ, int lds_pad = 0, bool seam = false, bool fma = false)
 {
+    if (fma) return (seam || np != 1) ? 1 : xinv_launch_pipe2d_fma(gen, um, fr, al, ext, grid, st, a, occ, lds_pad);
     if (seam) return gen ? xinv_launch_pipe2d_gen_seam(um, np, fr, al, ext, grid, st, a, occ, lds_pad)
                          : xinv_launch_pipe2d_std_seam(um, np, fr, al, ext, grid, st, a, occ, lds_pad);
     return gen ? xinv_launch_pipe2d_gen(um, np, fr, al, ext, grid, st, a, occ, lds_pad)
@@ -54,6 +62,9 @@ XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 gr
                                     const Fused3Args &a);
 // two sweeps per pass pipelined across two groups of eight wavefronts (xinv_pipe3d.h): x-uniform coefficients, no 'extend'
 XINV_HIDDEN int xinv_launch_pipe3d(bool al, dim3 grid, hipStream_t st, const Fused3Args &a);
+// contracted arithmetic (XINV_FLAG_FMA): x-uniform coefficients only (xinv_tu_fused3d_fma.hip)
+XINV_HIDDEN int xinv_launch_fused3d_fma(int NW, bool al, bool ext, dim3 grid, hipStream_t st, const Fused3Args &a);
+XINV_HIDDEN int xinv_launch_pipe3d_fma(bool al, dim3 grid, hipStream_t st, const Fused3Args &a);
 XINV_HIDDEN int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st,
                                      const Fused3GArgs &a);
 XINV_HIDDEN int xinv_launch_fusedbih(bool per, bool zbe, dim3 grid, hipStream_t st,

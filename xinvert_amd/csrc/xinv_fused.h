@@ -374,6 +374,71 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     }
 };
 
+// ---- opt-in contracted arithmetic (XINV_FLAG_FMA): the per-row-coefficient forms with explicit fma at fixed positions
+// of the update -- the oracle's XO_FMA restatement, bit for bit; NOT the reference's arithmetic (tied to it by tests:
+// <= 1e-12 relative after tens of sweeps, <= 1e-6 rel-L2 converged).  The relaxation factor and the predicate are the
+// plain models' (same per-row records).  inc() returns the bracket BEFORE the relaxation factor: the callers finish
+// with one fma(bracket, rq, S) (k_pipe2d: under the EXEC mask, xinv_fma_where_ne).
+struct FusedStd2DF : FusedStd2D {
+    static constexpr bool FMA = true;
+    template <unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int sr, int s1, bool okx, bool oky,
+                                                  const XinvScal &sc)
+    { FusedStd2D::derive<UM, D, false>(w, sr, s1, okx, oky, sc); }     // (F stays F: multiplied inside an fma at use)
+    template <int X, unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ double inc(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 const XinvScal &sc)
+    {
+        static_assert(hoist<UM>(), "contracted arithmetic: per-row A and C only");
+        const double aP = w.s[0][sjp], a0 = w.s[0][sj], c = w.s[1][sj];
+        const double y = __builtin_fma(aP, sP - sC, -(a0 * (sC - sM)));
+        const double x = __builtin_fma(c, sE - sC, -(c * (sC - sW)));
+        double t = __builtin_fma(y, sc.ratioSqr, x);
+        t = __builtin_fma(-cget<X, UM, 2>(w, sj), sc.delxSqr, t);
+        return t;
+    }
+    template <int X, unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 const XinvScal &sc)
+    {
+        const double t = inc<X, UM, D, PRE>(w, sj, sjp, sC, sP, sM, sW, sE, sc);
+        return xinv_bitsel(X ? w.my[sj] : w.mx[sj], __builtin_fma(t, w.rq[sj], sC), sC);
+    }
+};
+
+struct FusedGen2DF : FusedGen2D {
+    static constexpr bool FMA = true;
+    template <int X, unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ double inc(const CoefWin<NC, D> &w, int sj, int, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 const XinvScal &sc)
+    {
+        static_assert((UM & 0x1fu) == 0x1fu, "contracted arithmetic: per-row A, C, D, E, F only");
+        const double A = w.s[0][sj], C = w.s[1][sj], Dd = w.s[2][sj], E = w.s[3][sj], F = w.s[4][sj];
+        const double G = cget<X, UM, 5>(w, sj);
+        double t = (A * ((sP - sC) - (sC - sM))) * sc.ratioSqr;
+        t = __builtin_fma(C, (sE - sC) - (sC - sW), t);
+        double v = (Dd * (sP - sM)) * sc.ratio;
+        v = __builtin_fma(E, sE - sW, v);
+        t = __builtin_fma(v * sc.delx, 0.5, t);
+        t = __builtin_fma(__builtin_fma(F, sC, -G), sc.delxSqr, t);
+        return t;
+    }
+    template <int X, unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 const XinvScal &sc)
+    {
+        const double t = inc<X, UM, D, PRE>(w, sj, sjp, sC, sP, sM, sW, sE, sc);
+        return xinv_bitsel(X ? w.my[sj] : w.mx[sj], __builtin_fma(t, w.rq[sj], sC), sC);
+    }
+};
+
+template <class M, class = void> struct ModelFma { static constexpr bool value = false; };
+template <class M> struct ModelFma<M, std::void_t<decltype(M::FMA)>> { static constexpr bool value = M::FMA; };
+
 template <int NC> struct RowPack { double2 s; double2 c[NC]; double cs[NC]; };
 
 struct LaneCols {

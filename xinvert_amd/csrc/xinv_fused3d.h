@@ -75,9 +75,11 @@ template <bool UNI> struct Coef3Pack;
 template <> struct Coef3Pack<false> { double2 A, B, B1, C; };
 template <> struct Coef3Pack<true>  { double A, B, B1, C; };
 
-template <int NW, bool AL, bool UNI, bool EXT>
+// FMA: the opt-in contracted arithmetic of XINV_FLAG_FMA (x-uniform coefficients only; oracle: XO_FMA, bit for bit).
+template <int NW, bool AL, bool UNI, bool EXT, bool FMA = false>
 __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
 {
+    static_assert(!FMA || UNI, "contracted arithmetic: x-uniform coefficients only");
     constexpr int H = 2, UW = 128 - 2 * H, D = 4, RJ = NW - 4;
 
     const int64_t m = a.member0 + blockIdx.y;
@@ -179,7 +181,15 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         const double aP = gA(skp, xt), a0 = gA(sk, xt), bP = gB1(sk, xt), b0 = gB(sk, xt);
         const double cE = gCE(sk, xt), c0 = gC(sk, xt), f = comp<X>(fw[sk]);
         double v;
-        if constexpr (UNI) {
+        if constexpr (FMA) {
+            const bool cond = inr && rok[sk] && (f != u);
+            const double ya = __builtin_fma(aP, sKP - sC, -(a0 * (sC - sKM)));
+            const double yb = __builtin_fma(bP, jP - sC, -(b0 * (sC - jM)));
+            const double yc_ = __builtin_fma(cE, e - sC, -(c0 * (sC - w)));
+            double t = __builtin_fma(ya, a.sc_.ratio2Sqr, __builtin_fma(yb, a.sc_.ratio1Sqr, yc_));
+            t = __builtin_fma(-f, a.sc_.delxSqr, t);
+            v = cond ? __builtin_fma(t, rq[sk], sC) : sC;
+        } else if constexpr (UNI) {
             const bool cond = inr && rok[sk] && (f != u);
             double temp = (
                 (

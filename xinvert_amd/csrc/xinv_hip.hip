@@ -372,7 +372,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                     int o = 0;
                     FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
                     if (fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, k, dim3(1), dim3(256),
-                                       st, dummy, &o, pl.seam != 0) == 0 && o >= occ_needed) { pl.K = k; break; }
+                                       st, dummy, &o, pl.seam != 0, pl.fma) == 0 && o >= occ_needed) { pl.K = k; break; }
                 }
             }
         }
@@ -381,7 +381,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // two column pairs per lane (strips of 240 owned columns) where the grid is wide enough to keep the
         // workgroup count up; XINV_PIPE_NP=1|2 forces the choice
         const int np_env = [] { const char *e = getenv("XINV_PIPE_NP"); return e ? atoi(e) : 0; }();   // (read per solve: tests switch it)
-        pl.npair = ((np_env == 1 || np_env == 2) && p.kind == KIND_STD2D && !pl.seam) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
+        pl.npair = ((np_env == 1 || np_env == 2) && p.kind == KIND_STD2D && !pl.seam && !pl.fma) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
         // the forcing through the LDS ring where the launch's streams (S read + write + forcing, every member) no
         // longer fit the caches and the later wavefronts' forcing requests would go back to HBM; XINV_PIPE_FR=0|1 forces
         {
@@ -427,9 +427,9 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             int occ = 2;                                   // workgroups of the chosen variant per CU
             {
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-                if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ, 0, pl.seam != 0);
+                if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ, 0, pl.seam != 0, pl.fma);
                 else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
-                                    st, dummy, &occ, pl.seam != 0);
+                                    st, dummy, &occ, pl.seam != 0, pl.fma);
             }
             // (pl.lone, set with K above: with one or two vector streams a second workgroup per CU
             // fills idle issue slots; with four or more a pair runs no faster than one, and tall
@@ -918,8 +918,21 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     if (opt.path == 3)                                  // (the value of round 2-3's XINV_PATH_SMALL)
         return fail_arg("path 3 (the register-resident small-slice solver) was removed in version 400: it never beat the "
                         "streaming kernels; use XINV_PATH_AUTO");
+    pl.fma = (opt.flags & XINV_FLAG_FMA) != 0;
     rc = plan_path(p, opt, ws, st, pl);
     if (rc) return rc;
+    if (pl.fma) {
+        // contracted arithmetic exists for the per-row-coefficient variants of the standard 2-D, general 2-D and
+        // standard 3-D streaming kernels (every lat-lon Poisson / Gill-Matsuno / omega problem): say so instead of
+        // silently running the plain arithmetic
+        const bool ok = pl.path == XINV_PATH_FUSED && !pl.nine && !pl.seam &&
+                        ((p.kind == KIND_STD2D && pl.um == 3u) || (p.kind == KIND_GEN2D && pl.um == 0x1fu) ||
+                         (p.kind == KIND_STD3D && pl.um == 7u));
+        if (!ok)
+            return fail_arg("XINV_FLAG_FMA: contracted arithmetic is available for the streaming kernels' per-row-coefficient "
+                            "variants only (standard 2-D with A, C constant along x; general 2-D with A, C, D, E, F constant "
+                            "along x; standard 3-D with A, B, C constant along x; B == 0; no odd-xc periodic seam)");
+    }
     SweepRun R;
     R.stream = st;
     rc = run_sweeps(p, pl, opt, ws, st, R);

@@ -28,6 +28,7 @@ struct Plan {
     int tpw;                 // wave-tiles per workgroup of the planned kernel: 4, or 1 with `pipe`
     int npair;               // `pipe`: column pairs per lane (1 or 2: strips of 112 or 240 owned columns)
     bool pipe_fr;            // `pipe`: the forcing rides the LDS ring (launches whose arrays exceed the caches)
+    bool fma;                // XINV_FLAG_FMA: the contracted-arithmetic kernel variants (per-row-coefficient forms only)
     bool lag;                // 5-point 2-D kernels: norm + stop rule evaluated by k_norm_reduce_lag on a second stream,
                              // one pass behind the sweeps (three S buffers); see run_sweeps
 };
@@ -43,8 +44,13 @@ static unsigned pick_um(int kind, unsigned umask)
 }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
-                          hipStream_t st, const FusedArgs &a, int *occ, bool seam = false)
+                          hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false)
 {
+    if (fma) {                                           // contracted arithmetic (xinv_fused.h: FusedStd2DF / FusedGen2DF)
+        if (seam || kind == KIND_STD2DT) return 1;
+        return kind == KIND_GEN2D ? xinv_launch_fused2d_genf(al, ext, um, K, grid, block, st, a, occ)
+                                  : xinv_launch_fused2d_stdf(al, ext, um, K, grid, block, st, a, occ);
+    }
     if (seam) {                                          // odd-xc periodic seam variants (xinv_fused.h: SEAM)
         if (kind == KIND_GEN2D) return xinv_launch_fused2d_gen_seam(al, ext, um, K, grid, block, st, a, occ);
         if (kind == KIND_STD2DT) return xinv_launch_fused2d_std2dt_seam(al, ext, um, K, grid, block, st, a, occ);
@@ -138,10 +144,10 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
             // (XINV_PIPE_LDSPAD: unused dynamic LDS per workgroup, to cap the workgroups per CU in experiments;
             //  capping at the planned count changed nothing: the dispatcher already spreads them evenly)
             static const int pad = [] { const char *e = getenv("XINV_PIPE_LDSPAD"); return e ? std::max(0, atoi(e)) : 0; }();
-            xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad, pl.seam != 0);
+            xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad, pl.seam != 0, pl.fma);
             continue;
         }
-        if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr, pl.seam != 0))
+        if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr, pl.seam != 0, pl.fma))
             return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     }
     HIPCHK(hipGetLastError());
@@ -219,7 +225,8 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
             const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
             a.member0 = member0 + m0;
             a.rowf = (const double *)ws->d_rowf; a.srowf = pl.srowf2;
-            xinv_launch_pipe3d(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a);
+            if (pl.fma) xinv_launch_pipe3d_fma(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a);
+            else        xinv_launch_pipe3d(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a);
         }
         HIPCHK(hipGetLastError());
         return XINV_OK;
@@ -235,7 +242,8 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)NB, (unsigned)nm, 1);
-        if (xinv_launch_fused3d(pl.RY, pl.aligned, uni, ext, grid, st, a))
+        if (pl.fma ? xinv_launch_fused3d_fma(pl.RY, pl.aligned, ext, grid, st, a)
+                   : xinv_launch_fused3d(pl.RY, pl.aligned, uni, ext, grid, st, a))
             return fail_arg("internal: no 3-D kernel variant for this cross-section");
     }
     HIPCHK(hipGetLastError());
@@ -588,8 +596,8 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     int occ = occ_ > 0 ? occ_ : 2;
     if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-        if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, ext, dim3(1), st, dummy, &occ, 0, pl.seam != 0);
-        else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ, pl.seam != 0);
+        if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, ext, dim3(1), st, dummy, &occ, 0, pl.seam != 0, pl.fma);
+        else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ, pl.seam != 0, pl.fma);
     }
     const bool pp = pl.pipe;
     const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, tpw) * nb, cdiv(yc, pl.nrb), K, occ, pl.lone, pp);

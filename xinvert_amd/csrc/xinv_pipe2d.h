@@ -368,7 +368,10 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 // compare that writes EXEC
                 unsigned long long rm = (X ? oky64[q] : okx64[q]) & (unsigned long long)__double_as_longlong(rokw[sj]);
                 if constexpr (SEAM) rm &= lanes;
-                nv[q] = xinv_add_where_ne(comp<X>(sw[q][sj]), t, comp<X>(cw[q].v[FQ][sj]), u, rm);
+                if constexpr (ModelFma<M>::value)          // (t is the bracket before the relaxation factor: one fma finishes)
+                    nv[q] = xinv_fma_where_ne(comp<X>(sw[q][sj]), t, cw[q].rq[sj], comp<X>(cw[q].v[FQ][sj]), u, rm);
+                else
+                    nv[q] = xinv_add_where_ne(comp<X>(sw[q][sj]), t, comp<X>(cw[q].v[FQ][sj]), u, rm);
             } else {
                 const unsigned long long pm = __builtin_amdgcn_ballot_w64((X ? cw[q].my[sj] : cw[q].mx[sj]) != 0u);
                 nv[q] = xinv_add_where(comp<X>(sw[q][sj]), t, pm);

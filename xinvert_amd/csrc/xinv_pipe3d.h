@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_row_factor3d(RowFactor3Args a)
 }
 #endif
 
-template <int G, int RR, bool AL>
+template <int G, int RR, bool AL, bool FMA = false>
 __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 {
     xinv_fresh_scalar_cache();
@@ -212,6 +212,16 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         row_neighbours<X>(sw[rr][sk], w, ee);
         const double sC = comp<X>(sw[rr][sk]), sKP = comp<X>(sw[rr][skp]), sKM = comp<X>(sw[rr][skm]);
         const double f = comp<X>(fw[rr][sk & 1]);
+        if constexpr (FMA) {                             // XINV_FLAG_FMA: the oracle's XO_FMA form, finished by one fma under EXEC
+            const double ya = __builtin_fma(e.aP, sKP - sC, -(e.a0 * (sC - sKM)));
+            const double yb = __builtin_fma(e.bP, jP - sC, -(e.b0 * (sC - jM)));
+            const double yc_ = __builtin_fma(e.c, ee - sC, -(e.c * (sC - w)));
+            double t = __builtin_fma(ya, a.sc_.ratio2Sqr, __builtin_fma(yb, a.sc_.ratio1Sqr, yc_));
+            t = __builtin_fma(-f, a.sc_.delxSqr, t);
+            const double v = xinv_fma_where_ne(sC, t, e.rq, f, u, (X ? oky64 : okx64) & e.rok);
+            setc<X>(sw[rr][sk], v);
+            return v;
+        }
         double temp = (
             (
                 e.aP * (sKP - sC) -

@@ -1,6 +1,7 @@
 // xinv_tu_fused2d.hip -- instantiations of k_fused2d for ONE model (compiled three times:
 // -DXINV_TU_MODEL=0 standard form, 1 general form, 2 standard "test" form; and each once more with -DXINV_TU_SEAM=1:
-// the odd-xc periodic seam variants, unaligned strips only).
+// the odd-xc periodic seam variants, unaligned strips only; 3 / 4: the contracted-arithmetic models of XINV_FLAG_FMA,
+// per-row-coefficient variants only).
 #include <type_traits>
 #include "xinv_dispatch.h"
 
@@ -37,7 +38,7 @@ static int launch_fused_k(int K, dim3 grid, dim3 block, hipStream_t st, const Fu
         return fused_one<M, 3, AL, UM, EXT>(grid, block, st, a, occ);
         break;
     case 4:
-        if constexpr (std::is_same<M, FusedStd2D>::value)
+        if constexpr (std::is_base_of<FusedStd2D, M>::value)
             return fused_one<M, 4, AL, UM, EXT>(grid, block, st, a, occ);
         break;
     default: break;
@@ -49,15 +50,21 @@ template <class M, bool AL, bool EXT>
 static int launch_fused_um(unsigned um, int K, dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a,
                            int *occ)
 {
-    if constexpr (std::is_same<M, FusedStd2D>::value) {
-        if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a, occ);
-    } else if constexpr (std::is_same<M, FusedStd2DT>::value) {
-        if (um == 7u) return launch_fused_k<M, AL, 7u, EXT>(K, grid, block, st, a, occ);
+    if constexpr (ModelFma<M>::value) {                  // contracted arithmetic: the per-row-coefficient variants only
+        constexpr unsigned UMF = std::is_base_of<FusedStd2D, M>::value ? 3u : 0x1fu;
+        if (um == UMF) return launch_fused_k<M, AL, UMF, EXT>(K, grid, block, st, a, occ);
+        return 1;
     } else {
-        if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a, occ);
-        if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a, occ);
+        if constexpr (std::is_same<M, FusedStd2D>::value) {
+            if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a, occ);
+        } else if constexpr (std::is_same<M, FusedStd2DT>::value) {
+            if (um == 7u) return launch_fused_k<M, AL, 7u, EXT>(K, grid, block, st, a, occ);
+        } else {
+            if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a, occ);
+            if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a, occ);
+        }
+        return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a, occ);
     }
-    return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a, occ);
 }
 
 template <class M>
@@ -86,8 +93,16 @@ int xinv_launch_fused2d_std(bool al, bool ext, unsigned um, int K, dim3 grid, di
 int xinv_launch_fused2d_gen(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
                             const FusedArgs &a, int *occ)
 { return launch_fused_m<FusedGen2D>(al, ext, um, K, grid, block, st, a, occ); }
-#else
+#elif XINV_TU_MODEL == 2
 int xinv_launch_fused2d_std2dt(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
                                const FusedArgs &a, int *occ)
 { return launch_fused_m<FusedStd2DT>(al, ext, um, K, grid, block, st, a, occ); }
+#elif XINV_TU_MODEL == 3
+int xinv_launch_fused2d_stdf(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
+                             const FusedArgs &a, int *occ)
+{ return launch_fused_m<FusedStd2DF>(al, ext, um, K, grid, block, st, a, occ); }
+#else
+int xinv_launch_fused2d_genf(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
+                             const FusedArgs &a, int *occ)
+{ return launch_fused_m<FusedGen2DF>(al, ext, um, K, grid, block, st, a, occ); }
 #endif

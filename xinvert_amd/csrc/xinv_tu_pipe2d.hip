@@ -35,7 +35,16 @@ static int pipe_np(bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs
 #define xinv_launch_pipe2d_std xinv_launch_pipe2d_std_seam
 #define xinv_launch_pipe2d_gen xinv_launch_pipe2d_gen_seam
 #endif
-#if XINV_TU_MODEL == 0
+#if XINV_TU_MODEL == 2        /* contracted arithmetic (XINV_FLAG_FMA), both forms in one unit: one column pair per lane */
+int xinv_launch_pipe2d_fma(bool gen, unsigned um, bool fr, bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ, int lds_pad)
+{
+    if (!gen && um == 3u) return fr ? pipe_np<FusedStd2DF, 3u, true, 1>(al, ext, grid, st, a, occ, lds_pad)
+                                    : pipe_np<FusedStd2DF, 3u, false, 1>(al, ext, grid, st, a, occ, lds_pad);
+    if (gen && um == 0x1fu) return fr ? pipe_np<FusedGen2DF, 0x1fu, true, 1>(al, ext, grid, st, a, occ, lds_pad)
+                                      : pipe_np<FusedGen2DF, 0x1fu, false, 1>(al, ext, grid, st, a, occ, lds_pad);
+    return 1;
+}
+#elif XINV_TU_MODEL == 0
 int xinv_launch_pipe2d_std(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ, int lds_pad)
 {
     if (um == 3u && fr) return pipe_np<FusedStd2D, 3u, true, 1>(al, ext, grid, st, a, occ, lds_pad);
