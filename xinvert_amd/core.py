@@ -285,7 +285,8 @@ def _solve(kind, coefs, F, S, dims, iParams):
                        check_every=int(iParams.get('check_every', 0)), rowconst_mask=rowconst,
                        host_chunk=int(iParams.get('host_chunk', 0)),
                        devices=_device_list(iParams, nbatch, sum(a.nbytes for a, st_ in zip(arrs, strides) if a is not None and st_)),
-                       prep=prep)
+                       prep=prep,
+                       fma=1 if iParams.get('contracted') else 0)      # opt-in XINV_FLAG_FMA (include/xinv.h): NOT the reference's arithmetic
     st = _lib.strides_arg(strides)
     ptrs = [_lib.hptr(a) for a in arrs]
     mx, tol = int(iParams['mxLoop']), float(iParams['tolerance'])
