@@ -43,6 +43,9 @@ UNITS = [
     ('xinv_tu_fused9', 'xinv_tu_fused9.hip', []),
     ('xinv_tu_fused3d', 'xinv_tu_fused3d.hip', []),
     ('xinv_tu_fused3d_fma', 'xinv_tu_fused3d_fma.hip', []),
+    # k_pipe3d: sixteen wavefronts x 128 VGPRs; the default scheduler's interleaving spills, minimum-register scheduling
+    # fits the ring variant in 123 (C5, 15 volumes: 2.98 -> 3.26e11, profiles/r04_pipe3d_variants.txt)
+    ('xinv_tu_pipe3d', 'xinv_tu_pipe3d.hip', ['-mllvm', '-amdgpu-sched-strategy=iterative-minreg']),
     # the biharmonic update is 51 dependent-chain flops per point and colour stage at one or two wavefronts per SIMD: the
     # default (occupancy-first) scheduler serialises the chains; max-ILP interleaves them (Munk 2000x2000: 1.04 -> 1.15e11)
     ('xinv_tu_bih', 'xinv_tu_bih.hip', ['-mllvm', '-amdgpu-sched-strategy=max-ilp']),

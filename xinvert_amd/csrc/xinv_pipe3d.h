@@ -129,16 +129,20 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 
     __shared__ double xch[2][2][NW][2][64];              // [step parity][as loaded | red-updated][wave][top | bottom row][lane]
 #ifndef XINV_P3_FRING
-#define XINV_P3_FRING 0           /* MEASURED AND NOT KEPT (round 3, profiles/r03_pipe3d_fring.txt).  1: the forcing rides the
-                                     ring with S, as in k_pipe2d's FR variant -- group 1 runs three planes behind group 0 and
-                                     its own forcing requests have mostly left the L2 by then (21.5 B of HBM-side traffic per
-                                     point-sweep against 12 + halo).  Bit-exact, reads -24 %, xch + ring = 160 KiB to the byte
-                                     (the norm tail borrows xch) -- and 15 % SLOWER: at sixteen wavefronts the kernel has 128
-                                     VGPRs and no SGPR left, and the variant spills 48-104 bytes per lane in group 1's march
-                                     (C5 15 volumes 2.52 against 2.97e11).  Round 4 (profiles/r04_pipe3d_variants.txt): with
-                                     the spills cut to 2-5 registers (12 or 8 wavefronts) it is still 13-19 % slower at 19 %
-                                     fewer bytes: only group 0 has loads in flight then, one plane ahead, and a step becomes
-                                     one memory latency (4.4 TB/s against 5.9); a deeper prefetch has no registers or LDS left. */
+#define XINV_P3_FRING 1           /* The forcing rides the ring with S, as in k_pipe2d's FR variant: group 1 runs three planes behind
+                                     group 0 and its own forcing requests had mostly left the L2 by then (19.8 B of HBM-side
+                                     traffic per point-sweep against 12 + halo).  Round 3: bit-exact, reads -24 %, xch + ring =
+                                     160 KiB to the byte (the norm tail borrows xch) -- and 15 % slower: 128 VGPRs, and group 1's
+                                     march spilled 48-104 bytes per lane.  Round 4 (profiles/r04_pipe3d_variants.txt): the
+                                     forcing window trimmed (the plane in its black stage keeps ONE component) and this unit
+                                     compiled with -amdgpu-sched-strategy=iterative-minreg: 123 VGPRs, no spill; C5, 15 volumes:
+                                     7.69 -> 6.13 GB per launch (15.7 B per point-sweep), 2.98 -> 3.26e11.  Now only group 0 has
+                                     loads in flight, one plane ahead (48 KB per CU): 5.3 TB/s, a step is one memory latency.
+                                     Measured and not kept on top of it: two planes of S in flight for one or two of a
+                                     wavefront's three rows (7-12 registers spilled, 3.24 / 3.16e11), forcing loads
+                                     non-temporal (6.70 GB, 3.02e11), S loads cached (5.57 GB = 14.3 B per point-sweep, but
+                                     3.0e11: latency), 12 or 8 wavefronts with two planes in flight (2.3-2.4e11), 8-byte loads
+                                     (2.9e11).  0: both groups read the forcing from HBM (round 3's kernel). */
 #endif
     // [wave of the group][row][slot][S (| forcing)][lane]: planes with sweep 1 complete.
     // (laid out [wave][row][slot][S | forcing][lane]: every access of a wavefront is ONE base register + an immediate
@@ -149,6 +153,19 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     double nsx = 0.0, nsy = 0.0;                         // norm share per lane and column (un-owned lanes discarded below)
     int nnx = 0, nny = 0;
 
+#if XINV_P3_FRING
+    // (ring variant: the forcing of the plane in its red stage as both components, of the plane in its black stage as
+    //  the one component that stage still reads: six registers less than two full planes)
+    double2 sw[RR][D], fwr[RR], pfS[RR], pfF[RR];
+    double fwb[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; rr++) {
+#pragma unroll
+        for (int t = 0; t < D; t++) sw[rr][t] = make_double2(0.0, 0.0);
+        fwr[rr] = pfS[rr] = pfF[rr] = make_double2(0.0, 0.0);
+        fwb[rr] = 0.0;
+    }
+#else
     double2 sw[RR][D], fw[RR][2], pfS[RR], pfF[RR];
 #pragma unroll
     for (int rr = 0; rr < RR; rr++) {
@@ -156,6 +173,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         for (int t = 0; t < D; t++) sw[rr][t] = make_double2(0.0, 0.0);
         fw[rr][0] = fw[rr][1] = pfS[rr] = pfF[rr] = make_double2(0.0, 0.0);
     }
+#endif
 
 #ifndef XINV_P3_NT
 #define XINV_P3_NT 1
@@ -186,7 +204,10 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         return v;
     };
     auto ldS = [&](int soff) { return ldrow(rsS, soff, std::integral_constant<int, NTAUX>{}); };
-    auto ldF = [&](int soff) { return ldrow(rsF, soff, std::integral_constant<int, 0>{}); };
+#ifndef XINV_P3_NTF
+#define XINV_P3_NTF 0             /* forcing loads non-temporal (ring variant: the forcing is read once per pass, like S) */
+#endif
+    auto ldF = [&](int soff) { return ldrow(rsF, soff, std::integral_constant<int, XINV_P3_NTF ? 2 : 0>{}); };
     const int rowbytes = (int)(xc * 8);
     auto plane_off = [&](int p, int rr) {                // byte offset of the lane's row in plane p (clamped), a scalar
         const int pr = p > zc - 1 ? zc - 1 : (p < 0 ? 0 : p);
@@ -205,13 +226,12 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 
     // one point update of component X of row rr on the plane in slot sk (k+1 in skp, k-1 in skm): the expression
     // of k_fused3d<UNI>, the increment added under the predicate as EXEC
-    auto update = [&](auto rtag, auto xt, int sk, int skp, int skm, const Rec &e, double jP, double jM) {
+    auto update = [&](auto rtag, auto xt, int sk, int skp, int skm, const Rec &e, double jP, double jM, double f) {
         constexpr int rr = decltype(rtag)::value;
         constexpr int X = decltype(xt)::value;
         double w, ee;
         row_neighbours<X>(sw[rr][sk], w, ee);
         const double sC = comp<X>(sw[rr][sk]), sKP = comp<X>(sw[rr][skp]), sKM = comp<X>(sw[rr][skm]);
-        const double f = comp<X>(fw[rr][sk & 1]);
         if constexpr (FMA) {                             // XINV_FLAG_FMA: the oracle's XO_FMA form, finished by one fma under EXEC
             const double ya = __builtin_fma(e.aP, sKP - sC, -(e.a0 * (sC - sKM)));
             const double yb = __builtin_fma(e.bP, jP - sC, -(e.b0 * (sC - jM)));
@@ -256,11 +276,16 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             } else {
                 sw[rr][U] = ring[gw][rr][U & 1][0][lane];
             }
-            fw[rr][S1 & 1] = pfF[rr];
 #if XINV_P3_FRING
+            // plane r-2 goes from its red to its black stage: its forcing travels on to group 1 (slot U & 1 was read by
+            // group 1 in the previous step and is rewritten with S at the end of this one) and keeps one component
+            if (GRP == 0) ring[gw][rr][U & 1][1][lane] = fwr[rr];
+            fwb[rr] = XROW(rr) ? fwr[rr].y : fwr[rr].x;
+            fwr[rr] = pfF[rr];
             if (GRP == 0) pfF[rr] = ldF(plane_off(r, rr));
             else pfF[rr] = ring[gw][rr][U & 1][1][lane];
 #else
+            fw[rr][S1 & 1] = pfF[rr];
             pfF[rr] = ldF(plane_off(r, rr));
 #endif
         }
@@ -278,7 +303,11 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                 const Rec e = record(r - 1, rr);
                 const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S1]) : jMe;
                 const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S1]) : jPe;
-                const double v = update(rtag, XT{}, S1, U, S2, e, jP, jM);
+#if XINV_P3_FRING
+                const double v = update(rtag, XT{}, S1, U, S2, e, jP, jM, comp<X>(fwr[rr]));
+#else
+                const double v = update(rtag, XT{}, S1, U, S2, e, jP, jM, comp<X>(fw[rr][S1 & 1]));
+#endif
                 if (rr == 0) xch[bw][1][wave][0][lane] = v;          // red-updated: the neighbours' next black half-sweep
                 if (rr == RR - 1) xch[bw][1][wave][1][lane] = v;
             }, std::make_integer_sequence<int, RR>{});
@@ -295,16 +324,17 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                 const Rec e = record(kk, rr);
                 const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S2]) : jMe;
                 const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S2]) : jPe;
-                update(rtag, XT{}, S2, S1, S3, e, jP, jM);
+#if XINV_P3_FRING
+                update(rtag, XT{}, S2, S1, S3, e, jP, jM, fwb[rr]);
+#else
+                update(rtag, XT{}, S2, S1, S3, e, jP, jM, comp<X>(fw[rr][S2 & 1]));
+#endif
             }, std::make_integer_sequence<int, RR>{});
 #pragma unroll
             for (int rr = 0; rr < RR; rr++) {
                 const double2 t = sw[rr][S2];
                 if (GRP == 0) {
                     ring[gw][rr][U & 1][0][lane] = t;
-#if XINV_P3_FRING
-                    ring[gw][rr][U & 1][1][lane] = fw[rr][S2 & 1];   // the forcing of the leaving plane r-2 (still in the window)
-#endif
                 }
                 if (pin && row_use[rr]) {                // wave-uniform: an owned row of an owned plane
                     xinv_norm_row(nsx, nsy, nnx, nny, t.x, t.y, u);

@@ -1,5 +1,5 @@
-// xinv_tu_fused3d.hip -- instantiations of k_fused3d (standard 3-D form), k_pipe3d (two sweeps per pass) and
-// k_fused3dg (general 3-D form with x-uniform coefficients).
+// xinv_tu_fused3d.hip -- instantiations of k_fused3d (standard 3-D form) and k_fused3dg (general 3-D form with x-uniform
+// coefficients).  k_pipe3d (two sweeps per pass) has its own unit, xinv_tu_pipe3d.hip.
 #include "xinv_dispatch.h"
 
 // ---- 3-D fused launch ------------------------------------------------------------------------
@@ -52,14 +52,5 @@ int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st, c
     if (NW == 8) launch_fused3dg_nw<8>(al, ext, grid, st, a);      // (sixteen wavefronts: 128 VGPRs, spills -- not instantiated)
     else if (NW == 12) launch_fused3dg_nw<12>(al, ext, grid, st, a);
     else return 1;
-    return 0;
-}
-
-// two sweeps per pass, pipelined across two groups of wavefronts (xinv_pipe3d.h)
-int xinv_launch_pipe3d(bool al, dim3 grid, hipStream_t st, const Fused3Args &a)
-{
-    constexpr int G = XINV_P3_G, RR = XINV_P3_RR;
-    if (al) hipLaunchKernelGGL((k_pipe3d<G, RR, true>), grid, dim3(2 * G * 64, 1, 1), 0, st, a);
-    else    hipLaunchKernelGGL((k_pipe3d<G, RR, false>), grid, dim3(2 * G * 64, 1, 1), 0, st, a);
     return 0;
 }

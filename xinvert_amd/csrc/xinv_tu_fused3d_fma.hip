@@ -1,5 +1,5 @@
 // xinv_tu_fused3d_fma.hip -- the contracted-arithmetic variants (XINV_FLAG_FMA) of the 3-D standard-form kernels:
-// k_fused3d with x-uniform coefficients and k_pipe3d (two sweeps per pass).
+// k_fused3d with x-uniform coefficients (k_pipe3d's: xinv_tu_pipe3d.hip).
 #include "xinv_dispatch.h"
 
 template <int NW>
@@ -23,12 +23,4 @@ int xinv_launch_fused3d_fma(int NW, bool al, bool ext, dim3 grid, hipStream_t st
     }
     if (NW != 12) return 1;
     return launch_fused3d_fma_nw<12>(al, ext, grid, st, a);
-}
-
-int xinv_launch_pipe3d_fma(bool al, dim3 grid, hipStream_t st, const Fused3Args &a)
-{
-    constexpr int G = XINV_P3_G, RR = XINV_P3_RR;
-    if (al) hipLaunchKernelGGL((k_pipe3d<G, RR, true, true>), grid, dim3(2 * G * 64, 1, 1), 0, st, a);
-    else    hipLaunchKernelGGL((k_pipe3d<G, RR, false, true>), grid, dim3(2 * G * 64, 1, 1), 0, st, a);
-    return 0;
 }
