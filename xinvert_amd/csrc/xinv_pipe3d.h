@@ -142,7 +142,9 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                                      wavefront's three rows (7-12 registers spilled, 3.24 / 3.16e11), forcing loads
                                      non-temporal (6.70 GB, 3.02e11), S loads cached (5.57 GB = 14.3 B per point-sweep, but
                                      3.0e11: latency), 12 or 8 wavefronts with two planes in flight (2.3-2.4e11), 8-byte loads
-                                     (2.9e11).  0: both groups read the forcing from HBM (round 3's kernel). */
+                                     (2.9e11), one 4-byte load per line of the plane after next to pull it into the L2
+                                     ahead of the real request (one register: 11 spilled, 2.7e11).
+                                     0: both groups read the forcing from HBM (round 3's kernel). */
 #endif
     // [wave of the group][row][slot][S (| forcing)][lane]: planes with sweep 1 complete.
     // (laid out [wave][row][slot][S | forcing][lane]: every access of a wavefront is ONE base register + an immediate
