@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# tests/hooks_suite needs build/libxinv_hooks.so (the test-hooks variant: XINV_SO selects the library at import time),
+# so it runs in its own process -- tests/test_gpu_watchdog.py starts it -- and is not collected with the rest.
+collect_ignore_glob = [] if os.environ.get('XINV_HOOKS_SUITE') == '1' else ['hooks_suite/*']
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.parametrize('lag', ['1', '0'])
 @pytest.mark.parametrize('cfg', ['c2', 'c5'])
 def test_tolerance_within_an_ulp_of_a_sweeps_change(cfg, lag):
-    env = dict(os.environ); env['XINV_LAG'] = lag
+    from xinvert_amd import build as xbuild                  # (the watchdog-recovery path needs the test-hooks library)
+    assert os.path.exists(xbuild.HOOKS_SO), 'build/libxinv_hooks.so is missing: python -m xinvert_amd.build --hooks'
+    env = dict(os.environ); env['XINV_LAG'] = lag; env['XINV_SO'] = os.path.abspath(xbuild.HOOKS_SO)
     out = subprocess.run([sys.executable, os.path.join(HERE, 'stop_rule_edge.py'), cfg], capture_output=True, text=True,
                          timeout=1500, env=env)
     assert out.returncode == 0 and ': 0 wrong' in out.stdout, (out.stdout[-4000:], out.stderr[-3000:])

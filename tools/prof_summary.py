@@ -3,6 +3,9 @@
 
   python tools/prof_summary.py kernels  <results.db> [out.txt]     per-kernel calls / avg / min / max us
   python tools/prof_summary.py counters <results.db> [out.txt]     per-kernel mean of each PMC counter
+  python tools/prof_summary.py config   <fetch.db> <write.db> <kernel-substring> <config name> <bench.py kernel prefix>
+                                        <members> <point-sweeps per launch> <traffic.json> [source text]
+        the same per point-sweep, stored under traffic.json['configs'][name] (bench.py's per-configuration lines)
   python tools/prof_summary.py traffic  <fetch.db> <write.db> <kernel-substring> <key> [traffic.json]
         HBM-side bytes per launch of one kernel = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes).
         The factor 2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM section):
@@ -75,6 +78,18 @@ def main():
             d[key + '_detail'] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'fetch_correction': 2.0,
                                   'calibration_kernel': calname, 'calibration_FETCH_KiB': cal}
             json.dump(d, open(path, 'w'), indent=1, sort_keys=True)
+    elif cmd == 'config':
+        fdb, wdb, ksub, name, prefix, members, psl, path = sys.argv[2:10]
+        src = sys.argv[10] if len(sys.argv) > 10 else 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes'
+        f, nf = mean_counter(fdb, 'FETCH_SIZE', ksub)
+        w, nw = mean_counter(wdb, 'WRITE_SIZE', ksub)
+        traffic = (2.0 * f + w) * 1024.0
+        d = json.load(open(path)) if os.path.exists(path) else {}
+        d.setdefault('configs', {})[name] = {'kernel_prefix': prefix, 'members': int(members),
+                                             'bytes_per_point_sweep': traffic / float(psl), 'bytes_per_launch': traffic,
+                                             'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'launches_profiled': nf, 'source': src}
+        json.dump(d, open(path, 'w'), indent=1, sort_keys=True)
+        print('%s: %s  %.4e B per launch = %.2f B per point-sweep (n=%d)' % (name, ksub, traffic, traffic / float(psl), nf))
     else:
         raise SystemExit(__doc__)
 

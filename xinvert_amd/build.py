@@ -20,8 +20,6 @@ CSRC = os.path.join(HERE, 'csrc')
 # XINV_BUILD_TAG=noskip  ->  build/libxinv_noskip.so (objects in build/obj_noskip); run it with XINV_SO=...
 TAG = os.environ.get('XINV_BUILD_TAG', '')
 EXTRA = os.environ.get('XINV_EXTRA_FLAGS', '').split()
-SO = os.path.join(HERE, 'libxinv_hip.so') if not TAG else os.path.join(HERE, '..', 'build', 'libxinv_%s.so' % TAG)
-OBJ = os.path.join(HERE, '..', 'build', 'obj' + ('_' + TAG if TAG else ''))
 # (object name, source, extra flags)
 UNITS = [
     ('xinv_hip', 'xinv_hip.hip', []),
@@ -62,8 +60,8 @@ SOURCES = sorted({u[1] for u in UNITS})
 # data from a reused workspace address; with this switch only loads the source spells out
 # through the constant address space (kernel arguments; k_pipe2d's per-row records, behind its
 # s_dcache_inv) use the scalar unit.  tools/smem_audit.py checks the built objects for exactly that.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
-         '-mllvm', '-amdgpu-scalarize-global-loads=0'] + EXTRA
+BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+              '-mllvm', '-amdgpu-scalarize-global-loads=0']
 
 
 def hipcc():
@@ -79,13 +77,13 @@ def _headers():
     return hs
 
 
-def _stamp(src, extra):
+def _stamp(src, flags):
     """Content hash of everything a unit depends on (its source, every header, its flags)."""
     h = hashlib.sha256()
     for f in [src] + _headers():
         with open(f, 'rb') as fh:
             h.update(fh.read())
-    h.update(' '.join(FLAGS + extra).encode())
+    h.update(' '.join(flags).encode())
     return h.hexdigest()
 
 
@@ -93,32 +91,48 @@ def _units():
     return [u for u in UNITS if os.path.exists(os.path.join(CSRC, u[1]))]
 
 
-def stale():
-    if not os.path.exists(SO):
+def _paths(tag):
+    so = os.path.join(HERE, 'libxinv_hip.so') if not tag else os.path.join(HERE, '..', 'build', 'libxinv_%s.so' % tag)
+    obj = os.path.join(HERE, '..', 'build', 'obj' + ('_' + tag if tag else ''))
+    return so, obj
+
+
+def stale(tag=TAG, extra=EXTRA, variant_units=VARIANT_UNITS):
+    so, obj = _paths(tag)
+    if not os.path.exists(so):
         return True
-    for name, src, extra in _units():
-        st = os.path.join(OBJ, name + '.stamp')
-        if not os.path.exists(os.path.join(OBJ, name + '.o')) or not os.path.exists(st):
+    if tag and os.path.getmtime(so) < os.path.getmtime(_paths('')[0]):
+        return True                                     # (a variant links the shipped build's other objects)
+    for name, src, uflags in _units():
+        if variant_units and name not in variant_units:
+            continue
+        st = os.path.join(obj, name + '.stamp')
+        if not os.path.exists(os.path.join(obj, name + '.o')) or not os.path.exists(st):
             return True
-        if open(st).read() != _stamp(os.path.join(CSRC, src), extra):
+        if open(st).read() != _stamp(os.path.join(CSRC, src), BASE_FLAGS + list(extra) + uflags):
             return True
     return False
 
 
-def build(force=False, verbose=False, jobs=None):
-    if not force and not stale():
-        return SO
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=False, jobs=None, tag=TAG, extra=EXTRA, variant_units=VARIANT_UNITS):
+    """The shipped library (tag ''), or a variant build/libxinv_<tag>.so: `extra` flags on `variant_units` (every unit
+    when empty), the other objects taken from the shipped build's build/obj."""
+    so, obj = _paths(tag)
+    variant_units = list(variant_units) if tag else []
+    if not force and not stale(tag, extra, variant_units):
+        return so
+    os.makedirs(obj, exist_ok=True)
     cc = hipcc()
     todo = []
-    for name, src, extra in _units():
-        if VARIANT_UNITS and name not in VARIANT_UNITS:
+    for name, src, uflags in _units():
+        if variant_units and name not in variant_units:
             continue
         srcp = os.path.join(CSRC, src)
-        obj, st = os.path.join(OBJ, name + '.o'), os.path.join(OBJ, name + '.stamp')
-        stamp = _stamp(srcp, extra)
-        if force or not os.path.exists(obj) or not os.path.exists(st) or open(st).read() != stamp:
-            todo.append((name, [cc] + FLAGS + extra + ['-c', srcp, '-o', obj], st, stamp))
+        o, st = os.path.join(obj, name + '.o'), os.path.join(obj, name + '.stamp')
+        flags = BASE_FLAGS + list(extra) + uflags
+        stamp = _stamp(srcp, flags)
+        if force or not os.path.exists(o) or not os.path.exists(st) or open(st).read() != stamp:
+            todo.append((name, [cc] + flags + ['-c', srcp, '-o', o], st, stamp))
 
     def run(job):
         name, cmd, st, stamp = job
@@ -132,14 +146,30 @@ def build(force=False, verbose=False, jobs=None):
     with ThreadPoolExecutor(jobs) as ex:
         list(ex.map(run, todo))
     link = [cc, '--offload-arch=gfx950', '-shared', '-fPIC'] + \
-           [os.path.join(OBJ if (not VARIANT_UNITS or u[0] in VARIANT_UNITS) else MAIN_OBJ, u[0] + '.o') for u in _units()] + \
-           ['-o', SO]
+           [os.path.join(obj if (not variant_units or u[0] in variant_units) else MAIN_OBJ, u[0] + '.o') for u in _units()] + \
+           ['-o', so]
     if verbose:
         print(' '.join(link), flush=True)
     subprocess.check_call(link)
-    return SO
+    return so
+
+
+# The test-hooks variant (tests/hooks_suite, run by tests/test_gpu_watchdog.py in a subprocess with XINV_SO set): the
+# shipped library plus -DXINV_TEST_HOOKS=1 on the host driver and the kernel families the hooks live in (k_fused2d standard / general, k_pipe2d standard) -- a test
+# can make one tile withhold its norm partial (a REAL reducer timeout, with a 30 ms watchdog) or leave a member in the
+# state a timed-out reducer leaves behind.  The shipped library has neither hook nor environment switch.
+HOOKS_TAG = 'hooks'
+HOOKS_UNITS = ['xinv_hip', 'xinv_tu_fused2d_std', 'xinv_tu_fused2d_gen', 'xinv_tu_pipe2d_std']
+HOOKS_SO = os.path.join(HERE, '..', 'build', 'libxinv_%s.so' % HOOKS_TAG)
+
+
+def build_hooks(force=False, verbose=False):
+    build(force=False, verbose=verbose, tag='', extra=[], variant_units=[])        # (the objects it links)
+    return build(force=force, verbose=verbose, tag=HOOKS_TAG, extra=['-DXINV_TEST_HOOKS=1'], variant_units=HOOKS_UNITS)
 
 
 if __name__ == '__main__':
     j = [int(a[2:]) for a in sys.argv if a.startswith('-j') and a[2:].isdigit()]
     print(build(force='--force' in sys.argv, verbose=True, jobs=j[0] if j else None))
+    if '--hooks' in sys.argv:
+        print(build_hooks(force='--force' in sys.argv, verbose=True))

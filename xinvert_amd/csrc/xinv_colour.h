@@ -645,12 +645,14 @@ __global__ void k_ctl_init(XinvCtl *ctl, int64_t nbatch)
 
 // Watchdog recovery (run_sweeps): the member goes on from the control state the timed-out reducer left untouched.
 __global__ void k_ctl_resume(XinvCtl *c) { c->overflow = 0; c->done = 0; }
-// Test hook (XINV_EXP_WATCHDOG): the control state a reducer that timed out leaves behind -- it stops the member
-// without having applied the stop rule to any sweep of its launch.
+#if XINV_TEST_HOOKS
+// Test hook (XINV_EXP_WATCHDOG, test-hooks build only): the control state a reducer that timed out leaves behind -- it
+// stops the member without having applied the stop rule to any sweep of its launch.
 __global__ void k_ctl_fake_timeout(XinvCtl *c)
 {
     if (!c->done) { c->overflow = 2; c->done = 1; c->sweeps = c->loop + 1; }
 }
+#endif
 
 // ------------------------------------------------------------------ Gill-Matsuno flow (u, v)
 // reference apps.cal_flow(vtype='GillMatsuno') (apps.py:1277-1317): pointwise combination of

@@ -39,6 +39,30 @@
 #include <utility>
 
 #define XINV_KMAX 4             /* most sweeps fused into one pass (standard form with per-row A, C); 2 elsewhere */
+#ifndef XINV_TEST_HOOKS
+#define XINV_TEST_HOOKS 0       /* 1: build/libxinv_hooks.so only (xinvert_amd/build.py: build_hooks) -- a tile can be told to
+                                   withhold its norm partial, the reducer's watchdog is 30 ms instead of 2 s, and the host
+                                   driver reads the XINV_EXP_WATCHDOG / XINV_HOOK_SKIP_PUBLISH switches.  The shipped library
+                                   has none of it. */
+#endif
+#if XINV_TEST_HOOKS
+#define XINV_WATCHDOG_TICKS 3000000ull          /* s_memrealtime ticks at 100 MHz: 30 ms */
+#else
+#define XINV_WATCHDOG_TICKS 200000000ull        /* 2 s */
+#endif
+// test-hooks build: does this tile of this launch withhold its partial?  (hook = FusedArgs::dbg as int[3])
+__device__ __forceinline__ bool xinv_hook_withhold(const void *hook, int T, unsigned tag, int64_t m)
+{
+#if XINV_TEST_HOOKS
+    const int *h = reinterpret_cast<const int *>(hook);
+    return h && __hip_atomic_load(h + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == T &&
+           (unsigned)__hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag &&
+           (int64_t)__hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == m;
+#else
+    (void)hook; (void)T; (void)tag; (void)m;
+    return false;
+#endif
+}
 #ifndef XINV_VGPR_MASK
 #define XINV_VGPR_MASK 0
 #endif
@@ -101,7 +125,9 @@ struct FusedArgs {
     const double *xsum;        // [nbatch] sum |S| over the skipped tiles (S != undef)
     const long long *xcnt;     // [nbatch] their sample count
     const void *rowf;          // k_pipe2d: [nbatch][yc] per-row records (M::PIPE_RW doubles each, xinv_pipe2d.h)
-    double *dbg;               // debugging builds only (XINV_PIPE_DEBUG): rows as the pipeline stages received them
+    double *dbg;               // debugging builds only (XINV_PIPE_DEBUG): rows as the pipeline stages received them;
+                               // test-hooks build (XINV_TEST_HOOKS): three ints {tile, launch tag, member} -- that tile of
+                               // that launch withholds its norm partial, so that the reducer REALLY times out
 };
 
 template <class F, int... U>
@@ -528,7 +554,7 @@ __device__ __forceinline__ void fused_extend_fix(double2 &edge, const double2 &i
 template <int K, int NWV, bool EXTS = false>
 __device__ __forceinline__ void xinv_norm_publish(const double (&acc)[K], const int (&cnt)[K],
                                                   int wave, int lane, int NB, int T, unsigned tag,
-                                                  unsigned long long *pw, char *scr = nullptr)
+                                                  unsigned long long *pw, char *scr = nullptr, bool withhold = false)
 {
     double (*ls)[K]; long long (*lcn)[K];
     if constexpr (EXTS) {
@@ -547,7 +573,7 @@ __device__ __forceinline__ void xinv_norm_publish(const double (&acc)[K], const 
     }
     __syncthreads();
     const unsigned long long hi = (unsigned long long)tag << 32;
-    if (threadIdx.x < K) {
+    if (threadIdx.x < K && !withhold) {
         const int s = threadIdx.x;
         double ts = 0.0; long long tc = 0;
         for (int q = 0; q < NWV; q++) { ts += ls[q][s]; tc += lcn[q][s]; }
@@ -618,7 +644,7 @@ __device__ __forceinline__ void xinv_norm_reduce(int wave, int lane, int NB, uns
             if (!ready) {
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (t0 == 0) t0 = now;
-                else if (now - t0 > 200000000ull) { timed_out = true; s_timeout = 1u; }
+                else if (now - t0 > XINV_WATCHDOG_TICKS) { timed_out = true; s_timeout = 1u; }
             }
         } while (!ready && !timed_out);
 #pragma unroll
@@ -666,9 +692,10 @@ __device__ __forceinline__ void xinv_norm_finalize(const double (&acc)[K], const
                                                    int wave, int lane, int NB, int T, unsigned tag,
                                                    unsigned long long *pw, XinvCtl *ctl,
                                                    const XinvStop &stop,
-                                                   double xsum = 0.0, long long xcnt = 0, char *scr = nullptr)
+                                                   double xsum = 0.0, long long xcnt = 0, char *scr = nullptr,
+                                                   bool withhold = false)
 {
-    xinv_norm_publish<K, NWV, EXTS>(acc, cnt, wave, lane, NB, T, tag, pw, scr);
+    xinv_norm_publish<K, NWV, EXTS>(acc, cnt, wave, lane, NB, T, tag, pw, scr, withhold);
     if (blockIdx.x != gridDim.x - 1) return;
     __syncthreads();                                   // (the publish step's LDS scratch is reused by the reducer)
     xinv_norm_reduce<K, NWV, EXTS>(wave, lane, NB, tag, pw, ctl, stop, xsum, xcnt, scr);
@@ -693,15 +720,20 @@ __device__ __forceinline__ void xinv_lag_reduce_prev(const A &a, XinvCtl *ctl, i
     }
 }
 
+// (test-hooks build: the hook record travels in FusedArgs::dbg; the other argument structs have none)
+template <class A> __device__ __forceinline__ const void *xinv_hook_of(const A &) { return nullptr; }
+__device__ __forceinline__ const void *xinv_hook_of(const FusedArgs &a) { return a.dbg; }
+
 // end of a sweep kernel: lagged -> publish only; else publish + in-kernel reducer
 template <int K, class A>
 __device__ __forceinline__ void xinv_norm_tail(const A &a, const double (&acc)[K], const int (&cnt)[K], int wave,
                                                int lane, int NB, int T, unsigned tag, XinvCtl *ctl, int64_t m)
 {
     unsigned long long *pw = a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW;
-    if (a.lag) { xinv_norm_publish<K, 4>(acc, cnt, wave, lane, NB, T, tag, pw); return; }
+    const bool wh = xinv_hook_withhold(xinv_hook_of(a), T, tag, m);
+    if (a.lag) { xinv_norm_publish<K, 4>(acc, cnt, wave, lane, NB, T, tag, pw, nullptr, wh); return; }
     xinv_norm_finalize<K, 4>(acc, cnt, wave, lane, NB, T, tag, pw, ctl, a.stop,
-                             a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0);
+                             a.xsum ? a.xsum[m] : 0.0, a.xcnt ? a.xcnt[m] : 0, nullptr, wh);
 }
 
 

@@ -668,16 +668,35 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         R.buf[2] = ws->S3; R.nbuf = 3;
     }
     // launch number i of the solve (fused path): k sweeps from buf[i % nbuf] into buf[(i+1) % nbuf]
-    // test hook: XINV_EXP_WATCHDOG="i[,m]" leaves member m (default 0), before launch i, in the state a reducer that
-    // timed out leaves behind (read per solve: tests switch it)
     int64_t wd_at = -1, wd_member = 0;
+#if XINV_TEST_HOOKS
+    // TEST-HOOKS BUILD ONLY (build/libxinv_hooks.so; the shipped library reads neither switch):
+    // XINV_EXP_WATCHDOG="i[,m]" leaves member m (default 0), before launch i, in the state a reducer that timed out leaves
+    // behind; XINV_HOOK_SKIP_PUBLISH="i,tile[,m]" makes that tile of launch i withhold its norm partial, so that the
+    // reducer of launch i -- the launch's last workgroup, or with the lagged norm the extra workgroup of launch i+1 /
+    // k_norm_reduce_lag -- REALLY runs into its (30 ms) watchdog while the later launches are queued behind it.
     if (const char *e = getenv("XINV_EXP_WATCHDOG")) {
         wd_at = atoll(e);
         if (const char *c = strchr(e, ',')) wd_member = atoll(c + 1);
         if (wd_member < 0 || wd_member >= p.nbatch) wd_at = -1;
     }
+    struct HookGuard { ~HookGuard() { t_hook_record = nullptr; } } hook_guard;
+    t_hook_record = nullptr;
+    if (const char *e = getenv("XINV_HOOK_SKIP_PUBLISH")) {
+        long long li = -1, tile = -1, mem = 0;
+        if (sscanf(e, "%lld,%lld,%lld", &li, &tile, &mem) >= 2 && li >= 0 && tile >= 0 && mem >= 0 && mem < p.nbatch) {
+            if (!ws->d_hook) HIPCHK(hipMalloc((void **)&ws->d_hook, 3 * sizeof(int)));
+            const int rec[3] = {(int)tile, (int)(li + 1), (int)mem};      // (launch i publishes with tag i + 1)
+            HIPCHK(hipMemcpyAsync(ws->d_hook, rec, sizeof rec, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            t_hook_record = ws->d_hook;
+        }
+    }
+#endif
     auto launch_idx = [&](int64_t i, int k) -> int {
+#if XINV_TEST_HOOKS
         if (i == wd_at) hipLaunchKernelGGL(k_ctl_fake_timeout, dim3(1), dim3(1), 0, st, ws->ctl + wd_member);
+#endif
         const double *src = buf[i % R.nbuf];
         double *dst = buf[(i + 1) % R.nbuf];
         if (exp_noctl == 2)                              // (timing experiment: publish only, nobody reduces)

@@ -210,6 +210,7 @@ struct Workspace {
     size_t partials_half = 0;                           // lagged norm: byte offset of the odd launches' buffer
     double *S3 = nullptr; size_t S3_cap = 0;            // lagged norm: third S buffer
     int *dflag = nullptr;
+    int *d_hook = nullptr;                              // test-hooks build: {tile, launch tag, member} (FusedArgs::dbg)
     int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
     int *hflag = nullptr;

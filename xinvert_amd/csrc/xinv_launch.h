@@ -6,6 +6,10 @@
 // ------------------------------------------------------------------ launch helpers
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+#if XINV_TEST_HOOKS
+static thread_local int *t_hook_record = nullptr;    // device int[3] {tile, launch tag, member}, or nullptr
+#endif
+
 struct Plan {
     int path, base, seam, ncol;
     int K, RY, nsg, nrb;     // nsg: 2-D = workgroups per member (partials sizing); 3-D = x strips
@@ -125,6 +129,9 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     if (pipe) { a.nwg = a.nstrip * a.nrb; a.rowf = ws->d_rowf; }
 #ifdef XINV_PIPE_DEBUG
     if (pipe) { const char *e = getenv("XINV_DBG_PTR"); a.dbg = e ? (double *)(uintptr_t)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+#if XINV_TEST_HOOKS
+    a.dbg = (double *)t_hook_record;                 // (run_sweeps: XINV_HOOK_SKIP_PUBLISH; nullptr otherwise)
 #endif
     if (pl.skip && K == pl.K) {                      // the lists were built for this K's strips
         a.tile_list = ws->d_list;

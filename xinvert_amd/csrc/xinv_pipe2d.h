@@ -726,8 +726,9 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
     const int64_t m = kp->member0 + blockIdx.y;
     XinvCtl *ctl = kp->ctl + m;
     const int NB = kp->nwg;
-    struct { unsigned long long *psum; const double *xsum; const long long *xcnt; int lag; XinvStop stop; } a;
+    struct { unsigned long long *psum; const double *xsum; const long long *xcnt; int lag; XinvStop stop; const void *hook; } a;
     a.psum = kp->psum; a.xsum = kp->xsum; a.xcnt = kp->xcnt; a.lag = kp->lag;
+    a.hook = XINV_TEST_HOOKS ? (const void *)kp->dbg : nullptr;
     a.stop.mxLoop = kp->stop.mxLoop; a.stop.tolerance = kp->stop.tolerance;
     a.stop.stop_on_zero_norm = kp->stop.stop_on_zero_norm;
 
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         unsigned long long *pw = a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW;
         const double ws = xinv_wave_sum(acc);
         const long long wc = xinv_wave_sum_ll((long long)cnt);
-        if (lane == 0) {
+        if (lane == 0 && !xinv_hook_withhold(a.hook, T, tag, m)) {
             const unsigned long long hi = (unsigned long long)tag << 32;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(ws);
             unsigned long long *q = pw + ((size_t)pwi * NB + T) * XINV_PW;
