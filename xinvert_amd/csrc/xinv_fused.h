@@ -159,6 +159,8 @@ template <int NC, int D> struct CoefWin {
     double2 v[NC][D];
     double s[NC][D];
     double rq[D];
+    double2 rqv[D];            // general form, coefficients varying along x: the point's relaxation factor, divided
+                               // ONCE when the row enters the window (derive) instead of in each of the 2K half-sweeps
     unsigned mx[D], my[D];
 };
 
@@ -329,6 +331,12 @@ struct FusedStd2DT {                // numbas.invert_standard_2D_test, B == 0 an
     }
 };
 
+#ifndef XINV_GEN_RQ_WINDOW
+#define XINV_GEN_RQ_WINDOW 1        /* general form with coefficients that vary along x: the relaxation factor of a point is
+                                       divided once, when its row enters the window, and kept there (four registers per
+                                       row) -- each of the 2K half-sweeps that touch the row then multiplies.  The variants
+                                       run one wavefront per SIMD anyway (290-360 VGPRs), so the registers cost nothing. */
+#endif
 struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     static constexpr int NC = 6;    // A, C, D, E, F, G
     template <unsigned UM> static constexpr bool hoist() { return (UM & 0x13u) == 0x13u; }  // A, C, F uniform
@@ -357,6 +365,13 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
                  (cget<0, UM, 2>(w, s1) != u) && (cget<0, UM, 3>(w, s1) != u) && (cget<0, UM, 4>(w, s1) != u);
             by = by && (cget<1, UM, 0>(w, s1) != u) && (cget<1, UM, 1>(w, s1) != u) &&
                  (cget<1, UM, 2>(w, s1) != u) && (cget<1, UM, 3>(w, s1) != u) && (cget<1, UM, 4>(w, s1) != u);
+#if XINV_GEN_RQ_WINDOW
+            // (same expression as inc()'s: same bits; every operand sits on the point itself)
+            w.rqv[s1].x = sc.optArg / ((cget<0, UM, 0>(w, s1) * sc.ratioSqr + cget<0, UM, 1>(w, s1)) * 2.0
+                                       - cget<0, UM, 4>(w, s1) * sc.delxSqr);
+            w.rqv[s1].y = sc.optArg / ((cget<1, UM, 0>(w, s1) * sc.ratioSqr + cget<1, UM, 1>(w, s1)) * 2.0
+                                       - cget<1, UM, 4>(w, s1) * sc.delxSqr);
+#endif
         }
         w.mx[s1] = xinv_lane_word(bx);
         w.my[s1] = xinv_lane_word(by);
@@ -386,6 +401,9 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
             F * sC - G) * sc.delxSqr
         );
         if (hoist<UM>()) temp *= w.rq[sj];
+#if XINV_GEN_RQ_WINDOW
+        else if (PRE)    temp *= comp<X>(w.rqv[sj]);     // (k_fused2d: divided once per row entry; k_pipe2d: PRE = false)
+#endif
         else             temp *= sc.optArg / ((A * sc.ratioSqr + C) * 2.0
                                               - F * sc.delxSqr);
         return temp;
@@ -943,7 +961,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #pragma unroll
         for (int t = 0; t < D; t++) {
             sw[t] = make_double2(0.0, 0.0);
-            cw.rq[t] = 0.0; cw.mx[t] = 0u; cw.my[t] = 0u;
+            cw.rq[t] = 0.0; cw.rqv[t] = make_double2(0.0, 0.0); cw.mx[t] = 0u; cw.my[t] = 0u;
 #pragma unroll
             for (int q = 0; q < NC; q++) { cw.v[q][t] = make_double2(0.0, 0.0); cw.s[q][t] = 0.0; }
         }
