@@ -15,6 +15,10 @@ from util import rand2d, rand2dt, run_oracle, run_hip_batched
 pytestmark = pytest.mark.gpu
 COLOUR_2, PATH_COLOUR, PATH_FUSED = 2, 1, 2
 SHAPES = [(20, 65), (70, 101), (30, 127), (25, 129), (40, 301), (33, 257), (12, 641)]
+# widths that put a FULL strip next to the seam for one of the tilings (seam strips own 128 - 4K - 2 columns: 122, 118,
+# 114, 110): column xc-1 is updated after column 0 inside one half-sweep, so the dependency cone of the columns west of
+# the seam reaches 2K + 1 columns east across it -- one more than the plain halo (found in round 4 with 361 = 3 x 120 + 1)
+EDGE_WIDTHS = [(24, 245), (24, 237), (24, 229), (24, 221), (24, 331), (24, 343), (24, 361), (24, 363), (24, 359), (24, 241)]
 
 
 def _seed(t):
@@ -36,7 +40,7 @@ def _uniform(p, which):
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
 @pytest.mark.parametrize('BCy', ['fixed', 'extend'])
 @pytest.mark.parametrize('msk', [0, 1])
-@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('shape', SHAPES + EDGE_WIDTHS)
 def test_seam_fused_full_arrays(kind, BCy, msk, shape):
     yc, xc = shape
     p = rand2d(kind, yc, xc, BCy, 'periodic', 0, msk, seed=_seed((kind, BCy, msk, shape)))
@@ -53,7 +57,7 @@ def test_seam_fused_full_arrays(kind, BCy, msk, shape):
 
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
 @pytest.mark.parametrize('BCy', ['fixed', 'extend'])
-@pytest.mark.parametrize('shape', SHAPES + [(151, 251)])
+@pytest.mark.parametrize('shape', SHAPES + [(151, 251)] + EDGE_WIDTHS)
 def test_seam_fused_x_uniform_and_batches(kind, BCy, shape):
     """Per-row coefficients (lat-lon Poisson / Gill-Matsuno; the Ishida case is a general form with constants): the
     engine's own choice of kernel, three members with different masks, tolerance stops inside a pass."""
@@ -77,6 +81,29 @@ def test_seam_fused_test_form(BCy, shape):
         S, fl, st = run_hip_batched([p], 20, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=10)
         assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == K
         _same(S[0], fl[0], So, flo, 'std2dt K=%d' % K)
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+@pytest.mark.parametrize('shape', [(300, 257), (180, 361), (402, 113), (96, 1201)])
+def test_seam_edge_strips_in_half_height_tiles(kind, shape):
+    """Tall row blocks: the edge strips' row blocks are cut in two (their workgroups run two or three passes per
+    half-sweep and would otherwise end a one-round launch alone) -- tile ids beyond nstrip x nrb, in the launches, in the
+    masked-tile lists and in the skipped tiles' norm share; fixed and even row splits, one strip spanning the row (113)
+    and many."""
+    yc, xc = shape
+    which = (0, 2) if kind == 'std2d' else (0, 2, 3, 4, 5)
+    ps = [_uniform(rand2d(kind, yc, xc, 'fixed', 'periodic', 0, 1, seed=_seed((kind, shape, m))), which) for m in range(2)]
+    for q in ps:                                       # blank blocks of the forcing: whole tiles (and halves) to skip
+        F = q['coefs'][-1]
+        F[yc // 3:yc // 3 + yc // 4, :xc // 2] = q['undef']
+        F[:, xc - 40:xc - 8][yc // 2:] = q['undef']
+    ref = [run_oracle(p, 29, 1e-9, COLOUR_2) for p in ps]
+    for kw in (dict(), dict(force_tile_skip=1), dict(rows_per_tile=64), dict(rows_per_tile=-3, force_tile_skip=1),
+               dict(no_pipe=1, force_tile_skip=1), dict(sweeps_per_launch=3)):
+        S, fl, st = run_hip_batched(ps, 29, 1e-9, **kw)
+        assert st['path'] == PATH_FUSED, st
+        for m in range(2):
+            _same(S[m], fl[m], ref[m][0], ref[m][1], '%s %r member %d %r' % (kind, shape, m, kw))
 
 
 def test_short_odd_rows_keep_the_colour_launches():

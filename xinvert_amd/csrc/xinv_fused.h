@@ -124,11 +124,44 @@ struct FusedArgs {
     int ntl;                   // entries per member (multiple of 4); nwg = ntl / 4
     const double *xsum;        // [nbatch] sum |S| over the skipped tiles (S != undef)
     const long long *xcnt;     // [nbatch] their sample count
+    int nsplit;                // odd-xc periodic seam: 0, or the number of edge strips (1: one strip spans the row; 2: the
+                               // last and the first) whose row blocks are cut in two (xinv_tile_rows)
     const void *rowf;          // k_pipe2d: [nbatch][yc] per-row records (M::PIPE_RW doubles each, xinv_pipe2d.h)
     double *dbg;               // debugging builds only (XINV_PIPE_DEBUG): rows as the pipeline stages received them;
                                // test-hooks build (XINV_TEST_HOOKS): three ints {tile, launch tag, member} -- that tile of
                                // that launch withholds its norm partial, so that the reducer REALLY times out
 };
+
+// Tile id -> strip and owned rows [y0, y1).  Ids [0, nstrip nrb): row block rb = id / nstrip of strip id % nstrip (fixed
+// height RY, or RY == 0: the yc rows split evenly, boundaries rounded to even rows).  With the odd-xc periodic seam the
+// tiles of the EDGE strips run up to three passes per half-sweep (SEAM, below) and a launch of one round of workgroups
+// ends with them; their row blocks are therefore cut in two (nsplit = number of edge strips): id (rb, edge strip) is
+// the first half, ids nstrip nrb + e nrb + rb the second half of edge strip e (e = 0: the last strip, 1: strip 0).
+// Halves start on even rows like every tile; a half without rows is an idle tile (y0 >= y1).
+struct TileRows { int strip; int64_t y0, y1; };
+__host__ __device__ inline TileRows xinv_tile_rows(int wt, int nstrip, int nrb, int nsplit, int64_t yc, int RY)
+{
+    TileRows t;
+    int rb, half = -1;
+    if (wt < nstrip * nrb) {
+        rb = wt / nstrip; t.strip = wt - rb * nstrip;
+        if (nsplit > 0 && (t.strip == nstrip - 1 || (nsplit == 2 && t.strip == 0))) half = 0;
+    } else {
+        const int q = wt - nstrip * nrb, e = q / nrb;
+        rb = q - e * nrb; t.strip = (e == 0) ? nstrip - 1 : 0; half = 1;
+    }
+    if (RY > 0) { t.y0 = (int64_t)rb * RY; t.y1 = (t.y0 + RY < yc) ? t.y0 + RY : yc; }
+    else {
+        t.y0 = (((int64_t)rb * yc) / nrb) & ~(int64_t)1;
+        t.y1 = (rb + 1 == nrb) ? yc : ((((int64_t)(rb + 1) * yc) / nrb) & ~(int64_t)1);
+    }
+    if (half >= 0) {
+        const int64_t mid = t.y0 + ((((t.y1 - t.y0) / 2) + 1) & ~(int64_t)1);
+        const int64_t m2 = mid < t.y1 ? mid : t.y1;
+        if (half == 0) t.y1 = m2; else t.y0 = m2;
+    }
+    return t;
+}
 
 template <class F, int... U>
 __device__ __forceinline__ void xinv_unroll_steps(F &&f, std::integer_sequence<int, U...>)
@@ -829,7 +862,10 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
     constexpr int NC = M::NC;
     constexpr int H = 2 * K;            // halo (rows and columns) consumed by K sweeps
-    constexpr int UW = 128 - 2 * H;     // columns owned by one wavefront
+    // columns owned by one wavefront.  SEAM: one column pair less -- column xc-1 is updated AFTER column 0 inside the
+    // half-sweep of their colour, so the dependency cone of a column west of the seam reaches one column further east
+    // across it (xc-2 <- xc-1 <- 0 in ONE half-sweep): the east halo must hold 2K + 1 columns (it gets 2K + 2)
+    constexpr int UW = 128 - 2 * H - (SEAM ? 2 : 0);
     constexpr int D = 2 * K + 2;        // rows held in the register window
 #ifndef XINV_PF_MODE
 #define XINV_PF_MODE 0
@@ -868,7 +904,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #endif
     int wt = T * 4 + wave;
-    bool active = wt < a.nstrip * a.nrb;
+    bool active = wt < a.nstrip * a.nrb + (SEAM ? a.nsplit * a.nrb : 0);
     if (a.tile_list) {
         wt = a.tile_list[m * a.ntl + wt];
         active = wt >= 0;
@@ -877,14 +913,18 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #if XINV_WAVE_UNIFORM
     wt = __builtin_amdgcn_readfirstlane(wt);       // row bookkeeping on the scalar unit
 #endif
-    const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
+    int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
     const int64_t xc = a.xc, yc = a.yc;
     const row_t ycr = (row_t)yc;
-    const int64_t xu0 = (int64_t)strip * UW;
     // rows owned by this tile: fixed height RY, or (RY == 0) the yc rows split evenly over the
     // nrb row blocks, boundaries rounded to even rows
     row_t yu0, yu1;
-    if (a.RY > 0) {
+    if constexpr (SEAM) {                            // (edge strips' row blocks cut in two: xinv_tile_rows)
+        const TileRows tr = xinv_tile_rows(active ? wt : 0, a.nstrip, a.nrb, a.nsplit, yc, a.RY);
+        strip = tr.strip; yu0 = (row_t)tr.y0; yu1 = (row_t)tr.y1;
+        active = active && (yu0 < yu1);
+        rb = 0;
+    } else if (a.RY > 0) {
         yu0 = (row_t)rb * a.RY;
         yu1 = (yu0 + a.RY < ycr) ? yu0 + a.RY : ycr;
     } else {
@@ -898,6 +938,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     yu1 = (row_t)__builtin_amdgcn_readfirstlane((int)yu1);
 #endif
     const double u = a.sc_.undef;
+    const int64_t xu0 = (int64_t)strip * UW;
 
     const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
     const int64_t st0 = xu0 - H + 2 * lane;          // unwrapped store column of .x
@@ -1140,6 +1181,7 @@ struct SkipNormArgs {
     const double *S;
     int64_t sS, yc, xc;
     int nstrip, nrb, UW;
+    int nsplit;                // odd-xc periodic seam: edge strips whose row blocks are cut in two (xinv_tile_rows)
     int RB;                    // > 0: row blocks of exactly RB rows (biharmonic kernel); 0: even split
     double undef;
     const int *skip_list;      // [nbatch][nskip_max] wave-tile ids, -1 = none
@@ -1157,15 +1199,9 @@ __global__ __launch_bounds__(64) void k_skip_norm_tile(SkipNormArgs a)
     const int wt = a.skip_list[m * a.nskip_max + blockIdx.x];
     double acc = 0.0; long long cnt = 0;
     if (wt >= 0) {
-        const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
-        int64_t yu0, yu1;
-        if (a.RB > 0) {
-            yu0 = (int64_t)rb * a.RB;
-            yu1 = (yu0 + a.RB < a.yc) ? yu0 + a.RB : a.yc;
-        } else {
-            yu0 = (((int64_t)rb * a.yc) / a.nrb) & ~(int64_t)1;
-            yu1 = (rb + 1 == a.nrb) ? a.yc : ((((int64_t)(rb + 1) * a.yc) / a.nrb) & ~(int64_t)1);
-        }
+        const TileRows tr = xinv_tile_rows(wt, a.nstrip, a.nrb, a.nsplit, a.yc, a.RB);
+        const int strip = tr.strip;
+        const int64_t yu0 = tr.y0, yu1 = tr.y1;
         const int64_t c0 = (int64_t)strip * a.UW;
         const int64_t c1 = (c0 + a.UW < a.xc) ? c0 + a.UW : a.xc;
         const double *S = a.S + m * a.sS;

@@ -435,7 +435,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             // fills idle issue slots; with four or more a pair runs no faster than one, and tall
             // tiles (less halo) win -- 2000x2000 general form, A C G streamed: 40-row tiles 38.3 us,
             // 17-row tiles 44.0 us)
-            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, pl.pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * pl.K),
+            const int64_t best = choose_row_blocks(p.yc, cdiv(p.xc, strip_uw(pl, pl.K, pl.pipe)),
                                                    p.nbatch, pl.K, occ, pl.lone, pl.pipe);
             pl.nrb = (int)best;
             pl.even_split = true;
@@ -443,8 +443,12 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         }
         // workgroups per member with the narrowest strips any K uses: sizes the partials
         // (the shorter tail / redo passes of a pipelined plan run k_fused2d: four 112-column tiles per workgroup)
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 4 * XINV_KMAX) * pl.nrb, 4) + 1;
-        if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, XINV_PIPE_UW(pl.npair)) * pl.nrb + 1);
+        // odd-xc periodic seam: the edge strips' tiles run two or three passes per half-sweep; where the row blocks are
+        // tall enough their row blocks are cut in two, so that a launch of one round of workgroups does not end with them
+        pl.split = pl.seam && cdiv(p.yc, pl.nrb) >= 16 && cdiv(p.xc, strip_uw(pl, pl.K, pl.pipe)) >= 8;   // (and the edge strips a minority)
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, strip_uw(pl, XINV_KMAX, false)) * pl.nrb, 4) + 1;
+        if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, strip_uw(pl, pl.K, true)) * pl.nrb + 1);
+        if (pl.split) pl.nsg += 2 * pl.nrb;
         if (pl.even_split && !(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
             rc = plan_tile_skip(p, pl, ws, st, opt);
             if (rc) return rc;
@@ -568,8 +572,8 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // Only where a member has many workgroups: the reducing workgroup is one more per member and launch,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
-                           : (pl.path == XINV_PATH_FUSED && pl.pipe) ? XINV_PIPE_UW(pl.npair)
-                                                    : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K);
+                           : (pl.path == XINV_PATH_FUSED && pl.pipe) ? strip_uw(pl, pl.K, true)
+                                                    : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K) - ((pl.seam && !pl.nine) ? 2 : 0);
     const int tpw = (pl.path == XINV_PATH_FUSED && pl.pipe) ? 1 : 4;
     const int64_t wg_member = pl.skip ? pl.ntl / tpw : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, tpw);
     // ... and only where a launch is one or two rounds of workgroups: with many rounds (64 Gill-Matsuno

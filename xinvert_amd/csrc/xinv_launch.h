@@ -32,6 +32,8 @@ struct Plan {
     int tpw;                 // wave-tiles per workgroup of the planned kernel: 4, or 1 with `pipe`
     int npair;               // `pipe`: column pairs per lane (1 or 2: strips of 112 or 240 owned columns)
     bool pipe_fr;            // `pipe`: the forcing rides the LDS ring (launches whose arrays exceed the caches)
+    bool split;              // odd-xc periodic seam: the edge strips' row blocks are cut in two (xinv_tile_rows): their
+                             // workgroups run up to three passes per half-sweep and would otherwise end a launch alone
     bool fma;                // XINV_FLAG_FMA: the contracted-arithmetic kernel variants (per-row-coefficient forms only)
     bool lag;                // 5-point 2-D kernels: norm + stop rule evaluated by k_norm_reduce_lag on a second stream,
                              // one pass behind the sweeps (three S buffers); see run_sweeps
@@ -46,6 +48,15 @@ static unsigned pick_um(int kind, unsigned umask)
     if ((umask & 0x1cu) == 0x1cu) return 0x1cu;                                // D, E, F
     return 0u;
 }
+
+// edge strips whose row blocks are cut in two for a tiling of `nstrip` strips (one strip spans the row: it is both)
+// columns a tile owns: 128 minus the 2K halo columns a side; the wave-pipelined pass has K = 4 and np column pairs per
+// lane; the odd-xc periodic seam variants own one pair less (k_fused2d: SEAM)
+static inline int strip_uw(const Plan &pl, int K, bool pipe)
+{
+    return (pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K) - (pl.seam ? 2 : 0);
+}
+static inline int seam_nsplit(const Plan &pl, int nstrip) { return !pl.split ? 0 : (nstrip == 1 ? 1 : 2); }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                           hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false)
@@ -116,17 +127,19 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.tall = (p.yc > p.xc);
     a.RY = pl.even_split ? 0 : pl.RY;
     const bool pipe = pl.pipe && K == pl.K;          // wave-pipelined pass: one tile per workgroup
-    const int UW = pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K;
+    const int UW = strip_uw(pl, K, pipe);
     a.nstrip = (int)cdiv(p.xc, UW);
     a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
-    a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
+    a.nsplit = seam_nsplit(pl, a.nstrip);
+    const int64_t ntiles = (int64_t)a.nstrip * a.nrb + (int64_t)a.nsplit * a.nrb;
+    a.nwg = (int)cdiv(ntiles, 4);
     a.force = force; a.no_ctl = no_ctl;
     a.member0 = member0;
     a.sc_ = p.sc_;
     a.ctl = ws->ctl;
     a.stop = p.stop;
     a.psum = (unsigned long long *)ws->partials;
-    if (pipe) { a.nwg = a.nstrip * a.nrb; a.rowf = ws->d_rowf; }
+    if (pipe) { a.nwg = (int)ntiles; a.rowf = ws->d_rowf; }
 #ifdef XINV_PIPE_DEBUG
     if (pipe) { const char *e = getenv("XINV_DBG_PTR"); a.dbg = e ? (double *)(uintptr_t)strtoull(e, nullptr, 0) : nullptr; }
 #endif
@@ -535,7 +548,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     pl.skip = false; pl.ntl = pl.nskip = 0; pl.skip_pct = 0; pl.skip_ppm = 0;
     const bool forced = (opt.flags & XINV_FLAG_FORCE_TILE_SKIP) != 0;
     const int tpw = pl.pipe ? 1 : 4;                              // wave-tiles per workgroup
-    const int K = pl.K, UW = UW_ ? UW_ : (pl.pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K);   // 9-point kernel: 128 - 8K owned columns
+    const int K = pl.K, UW = UW_ ? UW_ : strip_uw(pl, K, pl.pipe);   // 9-point kernel: 128 - 8K owned columns
     const int nstrip = (int)cdiv(p.xc, UW);
     const int64_t wscale = 4 / tpw;                       // (thresholds in wavefronts: a pipelined tile has four)
     if (!forced && ((int64_t)nstrip * pl.nrb * p.nbatch * wscale < 1024 || (int64_t)nstrip * pl.nrb * wscale < 64 ||
@@ -573,28 +586,25 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     if (!forced && (double)nact > 0.92 * (double)(nb * cells)) return XINV_OK;     // little to skip
 
     const bool ext = (p.BCy == XINV_BC_EXTEND);
-    auto bounds = [&](int nrb, int rb, int64_t &y0, int64_t &y1) {
-        if (fixedRB) { y0 = (int64_t)rb * fixedRB; y1 = std::min<int64_t>(yc, y0 + fixedRB); return; }
-        y0 = (((int64_t)rb * yc) / nrb) & ~(int64_t)1;
-        y1 = (rb + 1 == nrb) ? yc : ((((int64_t)(rb + 1) * yc) / nrb) & ~(int64_t)1);
-    };
-    auto tile_active = [&](int64_t m, int nrb, int rb, int s) {
+    // (tile ids and their rows: xinv_tile_rows -- with the odd-xc periodic seam the edge strips' row blocks are two tiles)
+    const int nsplit = fixedRB ? 0 : seam_nsplit(pl, nstrip);
+    auto ntile_ids = [&](int nrb) { return nstrip * nrb + nsplit * nrb; };
+    auto id_rb = [&](int nrb, int id) { return id < nstrip * nrb ? id / nstrip : (id - nstrip * nrb) % nrb; };
+    auto tile_active = [&](int64_t m, int nrb, int id) {
+        const int rb = id_rb(nrb, id);
+        const TileRows t = xinv_tile_rows(id, nstrip, nrb, nsplit, yc, fixedRB);
+        if (t.y0 >= t.y1) return false;                                        // (an empty half)
         if (ext && (rb == 0 || rb >= nrb - (fixedRB ? 2 : 1))) return true;    // the boundary rows get their copy
                                                                // (a last block of one row: yc-2 sits in the one before)
-        int64_t y0, y1; bounds(nrb, rb, y0, y1);
-        const int *q = &pre[(size_t)((m * nstrip + s) * (yc + 1))];
-        return q[y1] - q[y0] > 0;
+        const int *q = &pre[(size_t)((m * nstrip + t.strip) * (yc + 1))];
+        return q[t.y1] - q[t.y0] > 0;
     };
     auto active_wgs = [&](int nrb, int64_t *maxact) {
         int64_t wgs = 0, mx = 0;
+        const int nid = ntile_ids(nrb);
         for (int64_t m = 0; m < nb; m++) {
             int64_t c = 0;
-            for (int rb = 0; rb < nrb; rb++) {
-                if (ext && (rb == 0 || rb >= nrb - (fixedRB ? 2 : 1))) { c += nstrip; continue; }
-                int64_t y0, y1; bounds(nrb, rb, y0, y1);
-                const int *q = &pre[(size_t)(m * nstrip * (yc + 1))];
-                for (int s = 0; s < nstrip; s++, q += yc + 1) c += (q[y1] - q[y0] > 0) ? 1 : 0;
-            }
+            for (int id = 0; id < nid; id++) c += tile_active(m, nrb, id) ? 1 : 0;
             wgs += cdiv(c, tpw); mx = std::max(mx, c);
         }
         if (maxact) *maxact = mx;
@@ -630,14 +640,16 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     // lists for the chosen split
     int64_t maxact = 0;
     active_wgs(best, &maxact);
-    const int64_t ntiles = (int64_t)nstrip * best;
+    const int64_t ntiles = (int64_t)ntile_ids(best);
     const int ntl = (int)(tpw * std::max<int64_t>(1, cdiv(maxact, tpw)));
     int64_t maxskip = 0, nskipped = 0;
     std::vector<std::vector<int>> act((size_t)nb), skp((size_t)nb);
     for (int64_t m = 0; m < nb; m++) {
-        for (int rb = 0; rb < best; rb++)
-            for (int s = 0; s < nstrip; s++)
-                (tile_active(m, best, rb, s) ? act[(size_t)m] : skp[(size_t)m]).push_back(rb * nstrip + s);
+        for (int id = 0; id < (int)ntiles; id++) {
+            const TileRows t = xinv_tile_rows(id, nstrip, best, nsplit, yc, fixedRB);
+            if (t.y0 >= t.y1) continue;                                        // (an empty half: neither run nor summed)
+            (tile_active(m, best, id) ? act[(size_t)m] : skp[(size_t)m]).push_back(id);
+        }
         maxskip = std::max<int64_t>(maxskip, (int64_t)skp[(size_t)m].size());
         nskipped += (int64_t)skp[(size_t)m].size();
     }
@@ -663,6 +675,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     if (rc) return rc;
     SkipNormArgs na;
     na.S = p.S; na.sS = p.sS; na.yc = yc; na.xc = p.xc; na.nstrip = nstrip; na.nrb = best; na.UW = UW; na.RB = fixedRB;
+    na.nsplit = nsplit;
     na.undef = p.sc_.undef; na.skip_list = ws->d_list + (size_t)nb * ntl; na.nskip_max = nskip;
     char *base = (char *)ws->d_tsum;
     na.tsum = (double *)base;
@@ -678,8 +691,9 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     pl.skip_ppm = (int)((1000000 * nskipped) / (ntiles * nb));
     if (!fixedRB) {
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX - (pl.seam ? 2 : 0)) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
         if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, UW) * pl.nrb + 1);
+        if (pl.split) pl.nsg += 2 * pl.nrb;                                   // (the second halves of the edge strips' row blocks)
     }
     return XINV_OK;
 }

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 #if XINV_PIPE_INV
     xinv_fresh_scalar_cache();
 #endif
-    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = XINV_PIPE_UW(NP), LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
+    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = XINV_PIPE_UW(NP) - (SEAM ? 2 : 0), LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;   // (SEAM: k_fused2d's note)
     __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE];
     __shared__ int prog[2 * P];                          // hand-over progress counters (XINV_PIPE_FLAGS)
 
@@ -667,23 +667,28 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
     pwi = wave;
 #endif
     int wt = T;
-    bool active = wt < a.nstrip * a.nrb;
+    bool active = wt < a.nstrip * a.nrb + (SEAM ? a.nsplit * a.nrb : 0);
     if (a.tile_list) {
         wt = a.tile_list[m * a.ntl + T];
         active = wt >= 0;
         wt = active ? wt : 0;
     }
-    const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
+    int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
     const int64_t xc = a.xc, yc = a.yc;
-    const int64_t xu0 = (int64_t)strip * UW;
     int yu0, yu1;
-    if (a.RY > 0) {
+    if constexpr (SEAM) {                                // (edge strips' row blocks cut in two: xinv_tile_rows)
+        const TileRows tr = xinv_tile_rows(active ? wt : 0, a.nstrip, a.nrb, a.nsplit, yc, a.RY);
+        strip = tr.strip; yu0 = (int)tr.y0; yu1 = (int)tr.y1;
+        active = active && (yu0 < yu1);
+        rb = 0;
+    } else if (a.RY > 0) {
         yu0 = rb * a.RY;
         yu1 = (yu0 + a.RY < (int)yc) ? yu0 + a.RY : (int)yc;
     } else {
         yu0 = (int)((((int64_t)rb * yc) / a.nrb) & ~(int64_t)1);
         yu1 = (rb + 1 == a.nrb) ? (int)yc : (int)((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
     }
+    const int64_t xu0 = (int64_t)strip * UW;
     LaneCols lc[NP];
     int64_t st0[NP];
 #pragma unroll
