@@ -100,7 +100,13 @@ typedef struct xinv_options {
        what apps.__mask_FS, the builders' `F * cos(lat)` + re-mask and the output de-mask do with
        numpy in the reference (apps.py:2112-2159, 1409-1411, 1389-1392).                              */
     int32_t prep_flags;         /* XINV_PREP_* bits                                                  */
-    int32_t pad0_;
+    int32_t f32_mask;           /* host-pointer entries: bit 0 = S, bit q+1 = coefficient array q (A = bit 1) is FLOAT32 on
+                                   the host: the pointer (declared double*) points to floats, its batch stride counts
+                                   floats.  The array travels as float32 -- half the bytes over PCIe -- and is promoted
+                                   on the device (exact: the same float64 values a host-side promotion gives); S with
+                                   bit 0 is also written back as float32 (the float64 result rounded to nearest, as
+                                   an assignment into a float32 array does).  The reference's own datasets are float32
+                                   (tests/test_Poisson.py:14-24).  Ignored by the *_dev entries.                    */
     double  prep_undef;         /* XINV_PREP_MASK_VALUE: the caller's undefined value                 */
     double  demask_value;       /* XINV_PREP_DEMASK: written to S where the forcing is masked         */
     const double *prep_rowscale;/* XINV_PREP_ROWSCALE: [yc] host doubles, defined forcing values of

@@ -36,7 +36,21 @@ def main():
         st = S.iParams['stats']
         print('invert_Poisson %dx%d, %d sweeps, mask/scale/de-mask on the %s: %.1f ms end to end (library call %.1f ms: h2d %.1f, sweeps %.1f, d2h %.1f), masked tiles %d%%'
               % (nx, ny, iP['mxLoop'] + 1, 'device' if prep else 'host (numpy)', best * 1e3, st['wall_ms'], st['h2d_ms'], st['sweep_ms'], st['d2h_ms'], st['masked_tile_pct']))
+    # the same forcing as float32 (the dtype of every dataset the reference ships): it travels as float32 and is promoted
+    # on the device (xinv_options.f32_mask); with float32_out the solution comes back as float32 too
     iP['device_prep'] = True
+    F32 = xa.Field(vor.astype(np.float32), ('lat', 'lon'), {'lat': lat, 'lon': lon})
+    for tag, extra in (('float32 forcing', {}), ('float32 forcing, float32 solution', {'float32_out': True})):
+        q = dict(iP); q.update(extra)
+        xa.invert_Poisson(F32, ['lat', 'lon'], iParams=q)
+        best = 1e9
+        for _ in range(5):
+            t = time.perf_counter()
+            S = xa.invert_Poisson(F32, ['lat', 'lon'], iParams=q)
+            best = min(best, time.perf_counter() - t)
+        st = S.iParams['stats']
+        print('invert_Poisson %dx%d, %d sweeps, %s: %.1f ms end to end (library call %.1f ms: h2d %.1f, sweeps %.1f, d2h %.1f)'
+              % (nx, ny, iP['mxLoop'] + 1, tag, best * 1e3, st['wall_ms'], st['h2d_ms'], st['sweep_ms'], st['d2h_ms']))
     pr = cProfile.Profile()
     pr.enable()
     xa.invert_Poisson(F, ['lat', 'lon'], iParams=iP)

@@ -28,7 +28,7 @@ class XinvOptions(ctypes.Structure):
                 ('flags', ctypes.c_int32), ('rowconst_mask', ctypes.c_int32),
                 ('host_chunk', ctypes.c_int32), ('ndev', ctypes.c_int32),
                 ('device_ids', ctypes.c_int32 * MAX_DEVICES),
-                ('prep_flags', ctypes.c_int32), ('pad0_', ctypes.c_int32),
+                ('prep_flags', ctypes.c_int32), ('f32_mask', ctypes.c_int32),
                 ('prep_undef', ctypes.c_double), ('demask_value', ctypes.c_double),
                 ('prep_rowscale', ctypes.POINTER(ctypes.c_double))]
 
@@ -154,7 +154,7 @@ def check(rc):
 
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
             timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0,
-            host_chunk=0, devices=None, prep=None, pin_host=0, no_pipe=0, fma=0):
+            host_chunk=0, devices=None, prep=None, pin_host=0, no_pipe=0, fma=0, f32_mask=0):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
@@ -164,6 +164,7 @@ def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_
               (8 if pin_host else 0) | (16 if no_pipe else 0) | (32 if fma else 0)     # ... | XINV_FLAG_PIN_HOST | XINV_FLAG_NO_PIPE | XINV_FLAG_FMA
     o.rowconst_mask = int(rowconst_mask)
     o.host_chunk = int(host_chunk)
+    o.f32_mask = int(f32_mask)
     # prep: front-end passes on the device -- dict(mask='nan' | value, rowscale=vec | None,
     # s_zero=bool, demask=value | None); the row-scale array is kept alive on the options object
     if prep:
@@ -216,12 +217,13 @@ def bc(b):
 
 
 def hptr(a):
-    """Host pointer of a C-contiguous float64 ndarray (None -> NULL)."""
+    """Host pointer of a C-contiguous float64 ndarray (None -> NULL); a float32 one goes with its bit in
+    xinv_options.f32_mask (the C-ABI declares double* and reads floats there)."""
     if a is None:
         return None
-    if a.dtype != np.float64 or not a.flags.c_contiguous:
-        raise XinvError('need C-contiguous float64 arrays at the C-ABI')
-    return a.ctypes.data_as(_dp)
+    if a.dtype not in (np.float64, np.float32) or not a.flags.c_contiguous:
+        raise XinvError('need C-contiguous float64 (or, with f32_mask, float32) arrays at the C-ABI')
+    return ctypes.cast(a.ctypes.data, _dp)
 
 
 def strides_arg(vals):

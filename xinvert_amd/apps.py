@@ -490,7 +490,7 @@ def _mask_FS(F, dims, iParams, icbc, lazy=False):
     device.  An infinity in the forcing then starts from S = 0 instead of the reference's
     `maskF - maskF` = NaN; both runs overflow at once."""
     if lazy and icbc is None and iParams.get('_lazy', False) and iParams.get('device_prep', True) \
-            and np.asarray(F.values).dtype == np.float64:
+            and np.asarray(F.values).dtype in (np.float64, np.float32):      # (float32 travels as float32: core._solve)
         return LazyForcing(F.values, F.dims, F.coords, iParams['undef'], _undeftmp, name=F.name), None, None
     vals = np.asarray(F.values, dtype=np.float64)
     undef = iParams['undef']

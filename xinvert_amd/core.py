@@ -259,13 +259,23 @@ def _solve(kind, coefs, F, S, dims, iParams):
         Fsrc = F.raw
         Sv = np.empty((nbatch,) + core_shape)
     else:
+        s_created = S is None
         if S is None:
             S = F.like(np.zeros(F.shape))
         Fsrc = F.values
         Sv = np.ascontiguousarray(np.transpose(np.asarray(S.values, dtype=np.float64), perm)
                                   ).reshape((nbatch,) + core_shape)
-    Fv = np.ascontiguousarray(np.transpose(np.asarray(Fsrc, dtype=np.float64), perm)
+    # A float32 forcing (every dataset the reference ships is float32, tests/test_Poisson.py:14-24) travels as float32 --
+    # half the bytes over PCIe -- and is promoted on the device: the same float64 values a host-side promotion gives
+    # (xinv_options.f32_mask).  iParams['float32_out']: the solution also comes back as float32, the dtype the
+    # reference returns for float32 input (its initS is zeros_like(F)).
+    f32_in = np.asarray(Fsrc).dtype == np.float32 and not iParams.get('no_float32_upload')
+    # (float32 out: only where no float64 first guess would be rounded -- S created here, or handed in as float32)
+    f32_out = bool(iParams.get('float32_out')) and (prep is not None or s_created or np.asarray(S.values).dtype == np.float32)
+    Fv = np.ascontiguousarray(np.transpose(np.asarray(Fsrc, dtype=np.float32 if f32_in else np.float64), perm)
                               ).reshape((nbatch,) + core_shape)
+    if f32_out:
+        Sv = np.empty((nbatch,) + core_shape, dtype=np.float32) if prep is not None else Sv.astype(np.float32)
     arrs, strides = [Sv], [n]
     rowconst = 0
     for k, c in enumerate(coefs):
@@ -286,6 +296,7 @@ def _solve(kind, coefs, F, S, dims, iParams):
                        host_chunk=int(iParams.get('host_chunk', 0)),
                        devices=_device_list(iParams, nbatch, sum(a.nbytes for a, st_ in zip(arrs, strides) if a is not None and st_)),
                        prep=prep,
+                       f32_mask=(1 if f32_out else 0) | ((2 << len(coefs)) if f32_in else 0),    # bit 0: S; last array: the forcing
                        fma=1 if iParams.get('contracted') else 0)      # opt-in XINV_FLAG_FMA (include/xinv.h): NOT the reference's arithmetic
     st = _lib.strides_arg(strides)
     ptrs = [_lib.hptr(a) for a in arrs]
@@ -339,7 +350,7 @@ def _solve(kind, coefs, F, S, dims, iParams):
     if prep is not None:                    # the solution was born on the device: no copy into an initS
         S = F.like(out if out.flags.c_contiguous else np.ascontiguousarray(out))
         iParams['_demasked'] = True
-    elif S.values.dtype == np.float64 and S.values.flags.writeable:
+    elif S.values.dtype == out.dtype and S.values.flags.writeable:
         S.values[...] = out
     else:
         S.values = np.ascontiguousarray(out)

@@ -604,6 +604,17 @@ __global__ __launch_bounds__(256) void k_expand_rows(const double *in, double *o
     for (int64_t i = threadIdx.x & 63; i < xc; i += 64) o[i] = v;
 }
 
+// float32 host arrays (xinv_options.f32_mask): promoted on the device after the upload (exact), S demoted before the
+// download (round to nearest even: what assigning a float64 into a float32 array does)
+__global__ __launch_bounds__(256) void k_promote_f32(const float *in, double *out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (double)in[i];
+}
+__global__ __launch_bounds__(256) void k_demote_f64(const double *in, float *out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)in[i];
+}
+
 // ---- front-end passes on the device (xinv_options.prep_flags) --------------------------------
 // The forcing as the caller holds it -> the forcing the kernels read: masked points (NaN, or equal
 // to the caller's undefined value) become `undef_tmp`, defined ones are multiplied by a per-row

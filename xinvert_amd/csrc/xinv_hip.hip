@@ -1113,20 +1113,45 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // ---- device buffers now; what travels is queued for the uploader ----------------------------
     std::vector<std::function<int()>> shared_ops;     // before the first chunk
     std::vector<std::vector<std::function<int()>>> chunk_ops((size_t)nchunk);
-    // host range -> device, `members` pieces of `len` elements (host stride hstride, device stride len)
-    auto h2d = [&](double *dev, const double *host, int64_t members, int64_t hstride, int64_t len) -> int {
-        auto one = [&](double *d, const double *h, size_t bytes) -> int {
+    // host range -> device, `members` pieces of `len` elements of `esz` bytes (host stride hstride, device stride len)
+    auto h2d_raw = [&](void *dev, const void *host, int64_t members, int64_t hstride, int64_t len, int esz) -> int {
+        auto one = [&](char *d, const char *h, size_t bytes) -> int {
             if (pin.covers(h, bytes)) {                // registered in place: the DMA reads the caller's memory
                 HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, sup));
                 return XINV_OK;
             }
-            return stage_h2d(ws->ring_up, sup, d, h, bytes);
+            return stage_h2d(ws->ring_up, sup, (double *)d, (const double *)h, bytes);
         };
-        if (members == 1 || hstride == len) return one(dev, host, (size_t)members * len * sizeof(double));
+        char *dv = (char *)dev; const char *hs = (const char *)host;
+        if (members == 1 || hstride == len) return one(dv, hs, (size_t)members * len * esz);
         for (int64_t m = 0; m < members; m++) {
-            int r = one(dev + m * len, host + m * hstride, (size_t)len * sizeof(double));
+            int r = one(dv + (size_t)m * len * esz, hs + (size_t)m * hstride * esz, (size_t)len * esz);
             if (r) return r;
         }
+        return XINV_OK;
+    };
+    // float64 host array, or (tmp != nullptr) a float32 one: uploaded as it is -- half the bytes over PCIe -- into
+    // `tmp` and promoted on the device (exact), in stream order
+    auto h2d = [&](double *dev, const double *host, int64_t members, int64_t hstride, int64_t len, float *tmp = nullptr) -> int {
+        if (!tmp) return h2d_raw(dev, host, members, hstride, len, 8);
+        int r = h2d_raw(tmp, host, members, hstride, len, 4);
+        if (r) return r;
+        const int64_t cnt = members * len;
+        hipLaunchKernelGGL(k_promote_f32, dim3((unsigned)std::min<int64_t>(4096, (cnt + 255) / 256)), dim3(256), 0, sup,
+                           (const float *)tmp, dev, cnt);
+        return XINV_OK;
+    };
+    auto is_f32 = [&](int arr) { return ((p.f32 >> arr) & 1u) != 0; };       // arr: 0 = S, q + 1 = coefficient q
+    auto esz_of = [&](int arr) { return is_f32(arr) ? (size_t)4 : (size_t)8; };
+    // (scratch for the float32 uploads: one buffer per array, as large as its largest piece; pieces follow each other
+    //  in stream order on `sup`, so the buffer is free again when the next one lands)
+    auto f32_tmp = [&](int arr, int64_t elems, float **out) -> int {
+        *out = nullptr;
+        if (!is_f32(arr)) return XINV_OK;
+        double *t;
+        int r = pool_alloc(pool, (size_t)elems * sizeof(float), &t);
+        if (r) return r;
+        *out = (float *)t;
         return XINV_OK;
     };
     Problem d = p;
@@ -1134,10 +1159,16 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     d.sS = n;
     rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &d.S);
     if (rc) return rc;
-    pin.try_pin(p.S, (size_t)((p.nbatch - 1) * hsS + n) * sizeof(double));
+    pin.try_pin(p.S, (size_t)((p.nbatch - 1) * hsS + n) * esz_of(0));
+    const int64_t mmax_chunk = *std::max_element(chunks.begin(), chunks.end());
+    float *tmpS_up = nullptr, *tmpS_dn = nullptr;
+    if (!(opt.prep_flags & XINV_PREP_S_ZERO)) { rc = f32_tmp(0, mmax_chunk * n, &tmpS_up); if (rc) return rc; }
+    rc = f32_tmp(0, p.nbatch * n, &tmpS_dn);             // (downloads trail the solves: every chunk its own piece)
+    if (rc) return rc;
     bool per_member[10];
+    float *tmpC[10];
     for (int q = 0; q < p.ncoef; q++) {
-        per_member[q] = false;
+        per_member[q] = false; tmpC[q] = nullptr;
         if (!p.c[q]) { d.c[q] = nullptr; d.sc[q] = 0; continue; }
         const int64_t hst = p.nbatch > 1 ? p.sc[q] : 0;
         const double *hq = p.c[q];
@@ -1150,9 +1181,12 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             if (rc) return rc;
             rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &dc);
             if (rc) return rc;
+            rc = f32_tmp(q + 1, members * rows, &tmpC[q]);
+            if (rc) return rc;
+            float *tq = tmpC[q];
             const int64_t xc = p.xc;
             shared_ops.push_back([=, &h2d]() -> int {
-                int r = h2d(drow, hq, members, hst, rows);
+                int r = h2d(drow, hq, members, hst, rows, tq);
                 if (r) return r;
                 hipLaunchKernelGGL(k_expand_rows, dim3(cdiv(rows * members, 4)), dim3(256), 0, sup,
                                    (const double *)drow, dc, rows, xc, members);
@@ -1162,13 +1196,18 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         } else if (hst == 0) {
             rc = pool_alloc(pool, (size_t)n * sizeof(double), &dc);
             if (rc) return rc;
-            pin.try_pin(hq, (size_t)n * sizeof(double));
-            shared_ops.push_back([=, &h2d]() -> int { return h2d(dc, hq, 1, 0, n); });
+            pin.try_pin(hq, (size_t)n * esz_of(q + 1));
+            rc = f32_tmp(q + 1, n, &tmpC[q]);
+            if (rc) return rc;
+            float *tq = tmpC[q];
+            shared_ops.push_back([=, &h2d]() -> int { return h2d(dc, hq, 1, 0, n, tq); });
             d.sc[q] = 0;
         } else {                                      // per member: travels with its chunk
             rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &dc);
             if (rc) return rc;
-            pin.try_pin(hq, (size_t)((p.nbatch - 1) * hst + n) * sizeof(double));
+            pin.try_pin(hq, (size_t)((p.nbatch - 1) * hst + n) * esz_of(q + 1));
+            rc = f32_tmp(q + 1, mmax_chunk * n, &tmpC[q]);
+            if (rc) return rc;
             d.sc[q] = n;
             per_member[q] = true;
         }
@@ -1208,15 +1247,18 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         if (opt.prep_flags & XINV_PREP_S_ZERO)
             ops.push_back([=]() -> int { HIPCHK(hipMemsetAsync(dS + m0 * n, 0, (size_t)nm * n * sizeof(double), sup)); return XINV_OK; });
         else
-            ops.push_back([=, &h2d]() -> int { return h2d(dS + m0 * n, hS + m0 * hsS, nm, hsS, n); });
+            ops.push_back([=, &h2d]() -> int {
+                return h2d(dS + m0 * n, (const double *)((const char *)hS + (size_t)m0 * hsS * (tmpS_up ? 4 : 8)), nm, hsS, n, tmpS_up);
+            });
         for (int q = 0; q < p.ncoef; q++)
             if (per_member[q]) {
                 double *dq_ = const_cast<double *>(d.c[q]);
                 const double *hq = p.c[q];
                 const int64_t hst = p.sc[q];
                 const bool prep_here = do_prep && q == fq;
+                float *tq = tmpC[q];
                 ops.push_back([=, &h2d]() -> int {
-                    int r = h2d(dq_ + m0 * n, hq + m0 * hst, nm, hst, n);
+                    int r = h2d(dq_ + m0 * n, (const double *)((const char *)hq + (size_t)m0 * hst * (tq ? 4 : 8)), nm, hst, n, tq);
                     if (r) return r;
                     if (prep_here) prep_forcing(dq_ + m0 * n, nm * n);
                     return XINV_OK;
@@ -1321,18 +1363,25 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             }
             HIPCHK(hipStreamSynchronize(scp));
         }
+        if (tmpS_dn) {                                   // float32 S: rounded on the device, half the bytes back
+            hipLaunchKernelGGL(k_demote_f64, dim3((unsigned)std::min<int64_t>(4096, (nm * n + 255) / 256)), dim3(256), 0, scp,
+                               (const double *)(d.S + m0 * n), tmpS_dn + m0 * n, nm * n);
+            HIPCHK(hipStreamSynchronize(scp));
+        }
         {
-            double *hS = p.S; const double *dS = d.S;
+            char *hS = (char *)p.S;
+            const char *dS = tmpS_dn ? (const char *)tmpS_dn : (const char *)d.S;
+            const size_t es = tmpS_dn ? 4 : 8;
             const Pinned *pinp = &pin;
             std::lock_guard<std::mutex> lk(act.mu);
             act.dq.push_back([=]() -> int {
-                auto one = [&](double *h, const double *dv, size_t bytes) -> int {
+                auto one = [&](char *h, const char *dv, size_t bytes) -> int {
                     if (pinp->covers(h, bytes)) { HIPCHK(hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, sdn)); return XINV_OK; }
-                    return stage_d2h(ws->ring_down, sdn, h, dv, bytes);
+                    return stage_d2h(ws->ring_down, sdn, (double *)h, (const double *)dv, bytes);
                 };
-                if (hsS == n || nm == 1) return one(hS + m0 * hsS, dS + m0 * n, (size_t)nm * n * sizeof(double));
+                if (hsS == n || nm == 1) return one(hS + (size_t)m0 * hsS * es, dS + (size_t)m0 * n * es, (size_t)nm * n * es);
                 for (int64_t m = m0; m < m0 + nm; m++) {
-                    int r = one(hS + m * hsS, dS + m * n, (size_t)n * sizeof(double));
+                    int r = one(hS + (size_t)m * hsS * es, dS + (size_t)m * n * es, (size_t)n * es);
                     if (r) return r;
                 }
                 return XINV_OK;
@@ -1365,6 +1414,7 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
     xinv_options opt;
     fill_options(opt, opt_in);
     p.rowconst = (unsigned)opt.rowconst_mask & ((1u << p.ncoef) - 1u);
+    p.f32 = (unsigned)opt.f32_mask & ((2u << p.ncoef) - 1u);
     int rc = validate(p, flags);
     if (rc) return rc;
     int nvis = 0;
@@ -1397,11 +1447,12 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
     Pinned pin;                                        // (opt-in: the per-device calls stage through their own rings otherwise)
     pin.enabled = Pinned::env_allowed() || (opt.flags & XINV_FLAG_PIN_HOST);
     pin.flags = hipHostRegisterPortable;
-    pin.try_pin(p.S, (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double));
+    auto esz = [&](int arr) { return ((p.f32 >> arr) & 1u) ? (size_t)4 : (size_t)8; };
+    pin.try_pin(p.S, (size_t)((p.nbatch - 1) * p.sS + n) * esz(0));
     for (int q = 0; q < p.ncoef; q++) {
         if (!p.c[q]) continue;
         const int64_t len = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
-        pin.try_pin(p.c[q], (size_t)((p.sc[q] == 0 ? 0 : (p.nbatch - 1) * p.sc[q]) + len) * sizeof(double));
+        pin.try_pin(p.c[q], (size_t)((p.sc[q] == 0 ? 0 : (p.nbatch - 1) * p.sc[q]) + len) * esz(q + 1));
     }
     struct Result { int rc = 0; std::string err; xinv_stats st; };
     std::vector<Result> res((size_t)nd);
@@ -1412,9 +1463,9 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
         th.emplace_back([&, i, lo, hi]() {
             Problem sub = p;
             sub.nbatch = hi - lo;
-            sub.S = p.S + lo * p.sS;
+            sub.S = (double *)((char *)p.S + (size_t)lo * p.sS * esz(0));          // (strides count elements of the array's type)
             for (int q = 0; q < p.ncoef; q++)
-                if (p.c[q]) sub.c[q] = p.c[q] + lo * p.sc[q];
+                if (p.c[q]) sub.c[q] = (const double *)((const char *)p.c[q] + (size_t)lo * p.sc[q] * esz(q + 1));
             xinv_options o1 = opt;
             o1.device = devs[(size_t)i]; o1.ndev = 0;
             int r;

@@ -263,6 +263,7 @@ struct Problem {
     int64_t sS, sc[10];
     int ncoef;
     unsigned rowconst;           // host entries: arrays given as one value per row (see xinv.h)
+    unsigned f32;                // host entries: bit 0 = S, bit q+1 = coefficient q is FLOAT32 on the host (xinv_options.f32_mask)
     int BCz, BCy, BCx;
     XinvScal sc_;
     XinvStop stop;
