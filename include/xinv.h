@@ -21,7 +21,7 @@
  * Sweep ordering.  The reference sweeps lexicographically (serial Gauss-Seidel).  The engine
  * sweeps red-black on (j+i)&1 when the cross coefficient B is identically zero and 4-colour on
  * (j&1, i&1) otherwise (3-D: (k+j+i)&1; biharmonic: 9 colours (j%3, i%3)); with periodic x and odd xc
- * the last column is its own pair of colours.  Point arithmetic, masking predicate, 'extend' pre-pass, norm (mean |S| over
+ * the last column is its own pair of colours, each run right after the base colour it belongs to.  Point arithmetic, masking predicate, 'extend' pre-pass, norm (mean |S| over
  * S != undef) and the stopping rule are the reference's.
  */
 #ifndef XINV_H
@@ -140,7 +140,8 @@ typedef struct xinv_stats {
     int32_t masked_tile_ppm;    /* masked_tile_pct at full resolution: skipped wave-tiles per million (bench.py prices
                                    its roofline on the tiles that ran)                           */
     int32_t recovered_members;  /* members whose in-kernel norm reduction timed out (watchdog) and that were finished
-                                   sweep by sweep with the separate norm kernels; 0 in every run seen so far      */
+                                   sweep by sweep with the separate norm kernels; 0 in every run seen so far outside the
+                                   test-hooks build of the library                                   */
     int32_t pad1_;
 } xinv_stats;
 
