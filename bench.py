@@ -387,7 +387,7 @@ def config_lines(local):
         line.update({'name': name, 'workload': wl, 'value': n_all * sweeps * steps / dt, 'unit': 'point-sweeps/s',
                     'members': rp.nb, 'sweeps_per_step': sweeps, 'steps': steps, 'ran_all_sweeps': ok,
                     'kernel': kernel_name(kind, s), 'sweeps_per_launch': s['sweeps_per_launch'],
-                    'rows_per_tile': s['rows_per_tile'], 'bound': r['bound'], 'frac': r['frac'], 'achieved': r['achieved'],
+                    'rows_per_tile': s['rows_per_tile'], 'lanes': s.get('lanes', 1), 'bound': r['bound'], 'frac': r['frac'], 'achieved': r['achieved'],
                     'peak': r['peak'], 'unit_roofline': r['unit'], 'valu_frac': r['valu_frac'],
                     'streamed_frac_of_hbm_peak': r['streamed_frac_of_hbm_peak'],
                     'streamed_bytes_per_point_sweep': r['streamed_bytes_per_point_sweep'],
@@ -566,7 +566,7 @@ def main():
             'flags_sha256': __import__('hashlib').sha256(np.ascontiguousarray(allf, dtype=np.float64).tobytes()).hexdigest(),
             'config': {'workload': wl_name, 'sweeps_per_step': sweeps,
                        'members_total': total_members, 'members_this_gpu': nb,
-                       'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'],
+                       'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'], 'lanes': s.get('lanes', 1),
                        'xuniform_mask': s['xuniform_mask'], 'masked_tile_pct': s['masked_tile_pct'],
                        'masked_tile_share': 1.0 - active,
                        'path': {1: 'colour', 2: 'fused'}.get(s['path'], '?'),

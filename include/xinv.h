@@ -126,7 +126,7 @@ typedef struct xinv_stats {
     int32_t rows_per_tile;
     int32_t xuniform_mask;      /* fused path: coefficient streams read as one scalar per row    */
     int32_t masked_tile_pct;    /* fused 2-D path: share of tiles skipped because fully masked   */
-    int64_t sweep_launches;     /* sweep-kernel launches issued (incl. no-op tail launches)     */
+    int64_t sweep_launches;     /* sweep passes issued (incl. no-op tail launches); one kernel launch per lane each */
     int64_t sweeps_max;         /* max over members of sweeps executed                          */
     double  sweep_ms;           /* HIP-event time over all launch chunks (timing=1), ms         */
     double  h2d_ms, d2h_ms;     /* host-pointer entry points only: span of the upload / download
@@ -142,7 +142,9 @@ typedef struct xinv_stats {
     int32_t recovered_members;  /* members whose in-kernel norm reduction timed out (watchdog) and that were finished
                                    sweep by sweep with the separate norm kernels; 0 in every run seen so far outside the
                                    test-hooks build of the library                                   */
-    int32_t pad1_;
+    int32_t lanes;              /* device entries: independent launch chains the batch was cut into (1 or 2; each
+                                   `sweep_launches` pass is then one kernel launch per lane, on its own stream, and
+                                   kernel durations in a trace overlap)                                              */
 } xinv_stats;
 
 void        xinv_default_options(xinv_options *opt);
@@ -186,8 +188,9 @@ int xinv_standard_3d_f64(double *S, const double *A, const double *B, const doub
  * opt:       may be NULL (defaults).
  * *_batched  take HOST pointers (staged through pinned buffers, coefficients with stride 0
  *            uploaded once); *_dev take DEVICE pointers already resident in HBM on opt->device
- *            and run on `stream` (a hipStream_t, NULL = default stream); flags stays a HOST
- *            pointer.  Both return after the solve has completed. */
+ *            and run on `stream` (a hipStream_t, NULL = default stream; a batch may be split over
+ *            `stream` and an engine-owned stream forked from / joined back into it: xinv_stats.lanes);
+ *            flags stays a HOST pointer.  Both return after the solve has completed. */
 int xinv_standard_2d_f64_batched(double *S, const double *A, const double *B, const double *C,
                                  const double *F, int64_t nbatch, const int64_t *strides,
                                  int64_t yc, int64_t xc, double dely, double delx, int BCy,

@@ -1,0 +1,22 @@
+"""The sweep loop in lanes (run_sweeps): the batch cut into independent launch chains on separate
+streams must give every member bitwise the single-chain result -- the oracle's -- whatever the number of lanes, with
+members stopping at different sweeps.  XINV_LANES is read once per process: one child per setting."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize('lanes', ['auto', '1', '2', '3', '4'])
+def test_lanes_give_the_oracles_result(lanes):
+    env = dict(os.environ)
+    env.pop('XINV_LANES', None)
+    if lanes != 'auto':
+        env['XINV_LANES'] = lanes
+    out = subprocess.run([sys.executable, os.path.join(HERE, 'lanes_case.py'), '0' if lanes == 'auto' else lanes],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0 and 'lanes ok' in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])

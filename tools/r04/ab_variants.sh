@@ -21,6 +21,9 @@ for l in sys.stdin:
   ( cd /tmp; rm -rf /tmp/q_f /tmp/q_w
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/q_f -o r -- python $R/tools/bench_configs.py "${args[@]}" --reps 1 > /dev/null 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/q_w -o r -- python $R/tools/bench_configs.py "${args[@]}" --reps 1 > /dev/null 2>&1
-    python $R/tools/prof_summary.py counters $(db /tmp/q_f) | sort -k4 -n -r | head -1 | cut -c1-64,82-100
-    python $R/tools/prof_summary.py counters $(db /tmp/q_w) | sort -k4 -n -r | head -1 | cut -c1-64,82-100 )
+    for d in /tmp/q_f /tmp/q_w; do python $R/tools/prof_summary.py counters $(db $d) | python -c "
+import sys
+L = [l for l in sys.stdin if '_SIZE' in l]
+l = max(L, key=lambda l: float(l[92:108]))
+print(l[:40].strip(), l[65:83].strip(), 'n', l[84:91].strip(), 'mean KiB', l[92:108].strip())"; done )
 done

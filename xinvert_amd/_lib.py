@@ -42,7 +42,7 @@ class XinvStats(ctypes.Structure):
                 ('d2h_ms', ctypes.c_double), ('wall_ms', ctypes.c_double),
                 ('host_chunks', ctypes.c_int32), ('devices', ctypes.c_int32),
                 ('pipelined', ctypes.c_int32), ('masked_tile_ppm', ctypes.c_int32),
-                ('recovered_members', ctypes.c_int32), ('pad1_', ctypes.c_int32)]
+                ('recovered_members', ctypes.c_int32), ('lanes', ctypes.c_int32)]
 
 
 class XinvError(RuntimeError):

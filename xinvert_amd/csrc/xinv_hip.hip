@@ -516,6 +516,7 @@ struct SweepRun {
     const XinvCtl *hc = nullptr;                         // the slot holding the final control blocks
     std::vector<int> rec_where;                          // watchdog recovery: buffer index of a recovered member's final state (-1: not recovered)
     int Kf = 1;
+    int lanes = 1;                                       // independent launch chains the batch was cut into
     // the replayed chunk of small problems: lives until finalise() has drained the stream (replays
     // queued after the last poll may still be executing when run_sweeps returns)
     hipGraphExec_t graph_exec = nullptr;
@@ -534,6 +535,22 @@ static int launch_planned(const Problem &p, const Plan &pl, Workspace *ws, hipSt
          : (p.kind == KIND_STD3D)   ? launch_fused3d(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl)
          : pl.nine                  ? launch_fused9(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl, lag_tag, lag_out, lag_prev)
                                     : launch_fused(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl, lag_tag, lag_out, lag_prev);
+}
+
+// sweep loop in lanes (run_sweeps): how many independent launch chains the batch is cut into.
+// Measured with 1 and 2 lanes on one box (profiles/r04_lanes.txt; XINV_LANES=n forces n, 0 or 1 = off):
+//   3600x1800 x 2/3/4/6/8/12/16/32 members  +6 +7 +6 +8 +10 +5 +8 +1.5 %      (5 members: 0)
+//   1440x720 general form x 4/8/12/16/24/32/64/128   0 +9 +6 +7 +8.5 +7 +5.5 +2 %
+//   360x180 x 100/200/365/1000               +13 +8 +5 +3.5 %
+//   720x360x50 x 4/15/16/30 volumes          +17 +1 -2 -2 %   (one workgroup per CU: the gain is the tail of a launch of
+//                                             two rounds; with eight rounds there is none to win)
+// Three or four lanes were no better than two; lanes on streams of the lowest priority were erratic (-30 % on small
+// batches).  A pass of a few microseconds is bound by the host's launch rate, which lanes double.
+static int lane_rule(const Problem &p, double est_pass_us)
+{
+    if (p.nbatch < 2 || est_pass_us < 30.0) return 1;
+    if (is3d(p.kind)) return p.nbatch <= 8 ? 2 : 1;
+    return 2;
 }
 
 // workspace, then chunks of launches with pipelined polling of the device-side stop flags
@@ -606,6 +623,8 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     const int64_t max_sweeps = p.stop.mxLoop + 1;       // numbas.py:410: loop >= mxLoop stops
     const int Kf = R.Kf = (pl.path == XINV_PATH_FUSED) ? pl.K : 1;
     int check_every = opt.check_every;
+    const double sweep_rate = (pl.path != XINV_PATH_FUSED) ? 4.0e4 : (pl.pipe ? 6.0e5 : (is3d(p.kind) ? 2.5e5 : 3.0e5));   // points per us
+    const double est_pass_us = (double)p.nbatch * (double)n * Kf / sweep_rate;
     if (check_every <= 0) {
         // poll the device stop flags about every 2 ms of sweeping (fused kernels run at roughly
         // 2e5 points per microsecond, the colour path at a quarter of that); launches issued after
@@ -613,8 +632,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         // (round 3: the pipelined 2-D pass runs at 6-7e5 points per microsecond; with the round-1 constant a 500-sweep
         //  solve at 3600x1800 was polled 18 times -- each poll ends a chunk: one-workgroup norm reduction of the lagged
         //  launch + control-block copy, ~10 us of idle GPU -- 4 % of the solve)
-        const double rate = (pl.path != XINV_PATH_FUSED) ? 4.0e4 : (pl.pipe ? 6.0e5 : (is3d(p.kind) ? 2.5e5 : 3.0e5));
-        const double est_us = std::max(4.0, (double)p.nbatch * (double)n * Kf / rate);
+        const double est_us = std::max(4.0, est_pass_us);
         check_every = (int)std::min(256.0, std::max(4.0, 2000.0 / est_us));
     }
     R.buf[0] = p.S; R.buf[1] = S2; R.buf[2] = nullptr;
@@ -671,6 +689,33 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         if (pl.skip) HIPCHK(hipMemcpyAsync(ws->S3, p.S, need, hipMemcpyDeviceToDevice, st));
         R.buf[2] = ws->S3; R.nbuf = 3;
     }
+    // Two lanes.  A launch of many rounds of workgroups ends in a tail: the last round fills a fraction of the CUs (C5, 15
+    // volumes: 2070 workgroups of k_pipe3d, one per CU, 8.09 rounds) and the next launch of the SAME members cannot start
+    // before it has drained.  The batch is cut in two halves whose launches form two independent chains on two streams
+    // (the engine's own one at the lowest priority, so that the chains do not march in step): the tail of one half's
+    // launch is filled by the other half's workgroups.  Control blocks are copied on a third stream behind both chains.
+    static const int lanes_env = [] { const char *e = getenv("XINV_LANES"); return e ? atoi(e) : -1; }();
+    int nlane = 1;
+    if (!lag && !use_graph && !exp_noctl && pl.path == XINV_PATH_FUSED)
+        nlane = (int)std::min<int64_t>(p.nbatch, lanes_env >= 0 ? std::max(1, std::min(lanes_env, XINV_MAX_LANES)) : lane_rule(p, est_pass_us));
+    const bool two = nlane > 1;
+    R.lanes = nlane;
+    auto lane_first = [&](int l) { return p.nbatch * l / nlane; };   // members [lane_first(l), lane_first(l+1))
+    struct LaneGuard {                                   // no return path leaves the side streams running
+        Workspace *w; int n;
+        ~LaneGuard() { if (n > 1) { for (int l = 1; l < n; l++) (void)hipStreamSynchronize(w->s_lane[l]); (void)hipStreamSynchronize(w->s_poll); } }
+    } lane_guard{ws, nlane};
+    if (two) {
+        if (!ws->s_poll) {
+            for (int l = 1; l < XINV_MAX_LANES; l++) HIPCHK(hipStreamCreateWithFlags(&ws->s_lane[l], hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&ws->s_poll, hipStreamNonBlocking));
+            for (int l = 0; l < XINV_MAX_LANES; l++)
+                for (int q = 0; q < 2; q++) HIPCHK(hipEventCreateWithFlags(&ws->ev_lane[l][q], hipEventDisableTiming));
+            HIPCHK(hipEventCreate(&ws->ev_s));
+        }
+        HIPCHK(hipEventRecord(ws->ev_s, st));            // fork: everything queued so far (workspace set-up) precedes every chain
+        for (int l = 1; l < nlane; l++) HIPCHK(hipStreamWaitEvent(ws->s_lane[l], ws->ev_s, 0));
+    }
     // launch number i of the solve (fused path): k sweeps from buf[i % nbuf] into buf[(i+1) % nbuf]
     int64_t wd_at = -1, wd_member = 0;
 #if XINV_TEST_HOOKS
@@ -699,12 +744,24 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
 #endif
     auto launch_idx = [&](int64_t i, int k) -> int {
 #if XINV_TEST_HOOKS
-        if (i == wd_at) hipLaunchKernelGGL(k_ctl_fake_timeout, dim3(1), dim3(1), 0, st, ws->ctl + wd_member);
+        if (i == wd_at) {                                // (on the stream of the member's lane: ordered before ITS launch i)
+            int l = 0;
+            while (l + 1 < nlane && lane_first(l + 1) <= wd_member) l++;
+            hipLaunchKernelGGL(k_ctl_fake_timeout, dim3(1), dim3(1), 0, l ? ws->s_lane[l] : st, ws->ctl + wd_member);
+        }
 #endif
         const double *src = buf[i % R.nbuf];
         double *dst = buf[(i + 1) % R.nbuf];
         if (exp_noctl == 2)                              // (timing experiment: publish only, nobody reduces)
             return launch_fused(p, pl, k, src, dst, ws, st, 0, p.nbatch, 1, 0, (unsigned)(i + 1), nullptr);
+        if (two) {
+            for (int l = 0; l < nlane; l++) {
+                const int r = launch_planned(p, pl, ws, l ? ws->s_lane[l] : st, k, src, dst, lane_first(l),
+                                             lane_first(l + 1) - lane_first(l), 0, 0);
+                if (r) return r;
+            }
+            return XINV_OK;
+        }
         if (!lag) return launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, exp_noctl, exp_noctl);
         NormLagArgs la;
         int r = launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, 0, 0, (unsigned)(i + 1), &la, &lag_pending);
@@ -724,8 +781,9 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         lag_pending.tag = 0;
         return XINV_OK;
     };
+    int last_slot = 0;
     auto issue_chunk = [&](int slot) -> int {
-        if (opt.timing) HIPCHK(hipEventRecord(ws->ev0[slot], st));
+        if (opt.timing && !two) HIPCHK(hipEventRecord(ws->ev0[slot], st));
         if (use_graph && max_sweeps - launched >= (int64_t)check_every * Kf &&
             (pl.path != XINV_PATH_FUSED || (bound.size() & 1) == 0)) {
             HIPCHK(hipGraphLaunch(R.graph_exec, st));
@@ -751,6 +809,18 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             nlaunch++;
         }
         { int r = flush_lag(); if (r) return r; }
+        if (two) {                                       // neither chain waits for the other: the copy does, on its own stream
+            for (int l = 0; l < nlane; l++) {
+                HIPCHK(hipEventRecord(ws->ev_lane[l][slot], l ? ws->s_lane[l] : st));
+                HIPCHK(hipStreamWaitEvent(ws->s_poll, ws->ev_lane[l][slot], 0));
+            }
+            if (opt.timing) HIPCHK(hipEventRecord(ws->ev1[slot], ws->s_poll));
+            HIPCHK(hipMemcpyAsync(ws->hctl + (size_t)slot * p.nbatch, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl),
+                                  hipMemcpyDeviceToHost, ws->s_poll));
+            HIPCHK(hipEventRecord(ws->evc[slot], ws->s_poll));
+            last_slot = slot;
+            return XINV_OK;
+        }
         if (opt.timing) HIPCHK(hipEventRecord(ws->ev1[slot], st));
         HIPCHK(hipMemcpyAsync(ws->hctl + (size_t)slot * p.nbatch, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl),
                               hipMemcpyDeviceToHost, st));
@@ -768,13 +838,23 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         HIPCHK(hipEventSynchronize(ws->evc[slot]));
         if (opt.timing) {
             float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ws->ev0[slot], ws->ev1[slot]));
-            ms_total += ms;
+            HIPCHK(hipEventElapsedTime(&ms, two ? ws->ev_s : ws->ev0[slot], ws->ev1[slot]));
+            if (two) ms_total = ms; else ms_total += ms; // (two lanes: chunks overlap -- from the fork to the end of this chunk)
         }
         hc = ws->hctl + (size_t)slot * p.nbatch;
         all_done = true;
         for (int64_t m = 0; m < p.nbatch; m++) all_done = all_done && hc[m].done;
         if (all_done || !more) break;
+    }
+    if (two) {
+        // join: everything below runs on the caller's stream.  The copies above were taken while later launches ran; a
+        // stopped member's block no longer changes, but the final blocks are read again behind both chains.
+        HIPCHK(hipStreamWaitEvent(st, ws->evc[last_slot], 0));   // (recorded behind every lane's last chunk)
+        HIPCHK(hipMemcpyAsync(ws->hctl, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        hc = ws->hctl;
+        all_done = true;
+        for (int64_t m = 0; m < p.nbatch; m++) all_done = all_done && hc[m].done;
     }
     if (pl.path != XINV_PATH_FUSED)                      // drain the queued no-op tail (the fused path syncs below)
         HIPCHK(hipStreamSynchronize(st));
@@ -902,6 +982,7 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
     t_stats.masked_tile_pct = (pl.path == XINV_PATH_FUSED && pl.skip) ? pl.skip_pct : 0;
     t_stats.masked_tile_ppm = (pl.path == XINV_PATH_FUSED && pl.skip) ? pl.skip_ppm : 0;
     t_stats.pipelined = (pl.path == XINV_PATH_FUSED && pl.pipe) ? pl.npair : 0;
+    t_stats.lanes = R.lanes;
     t_stats.sweep_launches = R.nlaunch;
     t_stats.sweeps_max = sweeps_max;
     t_stats.sweep_ms = R.ms_total;

@@ -201,6 +201,7 @@ static int stage_d2h(StageRing &r, hipStream_t s, double *host, const double *de
 
 // ------------------------------------------------------------------ per-device workspace
 // Grown on demand, reused across solves (no hipMalloc in steady state).
+#define XINV_MAX_LANES 4
 struct Workspace {
     int device = -1;
     std::recursive_mutex busy;                          // one solve at a time per device
@@ -216,6 +217,8 @@ struct Workspace {
     int *hflag = nullptr;
     hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
     hipStream_t gstream = nullptr;                      // capture stream for the small-problem hipGraph
+    hipStream_t s_lane[XINV_MAX_LANES] = {}, s_poll = nullptr;   // sweep loop in lanes: lanes 1.. of the batch; the control-block copies
+    hipEvent_t ev_lane[XINV_MAX_LANES][2] = {}, ev_s = nullptr;  // [0]: the caller's stream
     hipStream_t s_up = nullptr, s_down = nullptr, s_compute = nullptr;   // host-pointer entries: copy / sweep overlap
     // masked-tile skipping
     unsigned char *d_act = nullptr; size_t d_act_cap = 0;

@@ -151,6 +151,16 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     //  offset below 64 KiB -- with the slot outermost the last quarter lay beyond the 16-bit offset and cost a second
     //  base register, which the 128-register budget did not have: spills)
     __shared__ double2 ring[G][RR][2][1 + XINV_P3_FRING][64];
+    // (the first and the last row of the cross-section are updated with a j neighbour missing: whatever they become is
+    //  never read by a row that is kept -- their forcing is not loaded: 2 of 24 rows, 4 % of the bytes read)
+    //  (all ones ORed into the lane offset: out of the resource's range, the request returns zero and fetches nothing;
+    //   a branch around the load cost 31 spilled registers)
+#ifndef XINV_P3_FDROP
+#define XINV_P3_FDROP 1
+#endif
+    unsigned f_drop[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; rr++) f_drop[rr] = (XINV_P3_FRING && XINV_P3_FDROP && ((gw == 0 && rr == 0) || (gw == G - 1 && rr == RR - 1))) ? ~0u : 0u;
 
     double nsx = 0.0, nsy = 0.0;                         // norm share per lane and column (un-owned lanes discarded below)
     int nnx = 0, nny = 0;
@@ -192,15 +202,15 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const unsigned lo0 = (unsigned)lc.l0 * 8u, lo1 = (unsigned)lc.l1 * 8u;
     const unsigned so0 = lc.use_x ? (unsigned)st0 * 8u : 0xffffffffu, so1 = lc.use_y ? (unsigned)(st0 + 1) * 8u : 0xffffffffu;
     constexpr int NTAUX = XINV_P3_NT ? 2 : 0;            // cache-policy operand: bit 1 = nt on this target
-    auto ldrow = [&](__amdgpu_buffer_rsrc_t rs, int soff, auto auxtag) {
+    auto ldrow = [&](__amdgpu_buffer_rsrc_t rs, int soff, auto auxtag, unsigned drop = 0u) {
         constexpr int AUX = decltype(auxtag)::value;
         double2 v;
         if (AL) {
-            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo0, soff, AUX);
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lo0 | drop), soff, AUX);
             v.x = __hiloint2double((int)t[1], (int)t[0]); v.y = __hiloint2double((int)t[3], (int)t[2]);
         } else {
-            const auto t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lo0, soff, AUX);
-            const auto t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lo1, soff, AUX);
+            const auto t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(lo0 | drop), soff, AUX);
+            const auto t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(lo1 | drop), soff, AUX);
             v.x = __hiloint2double((int)t0[1], (int)t0[0]); v.y = __hiloint2double((int)t1[1], (int)t1[0]);
         }
         return v;
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 #ifndef XINV_P3_NTF
 #define XINV_P3_NTF 0             /* forcing loads non-temporal (ring variant: the forcing is read once per pass, like S) */
 #endif
-    auto ldF = [&](int soff) { return ldrow(rsF, soff, std::integral_constant<int, XINV_P3_NTF ? 2 : 0>{}); };
+    auto ldF = [&](int soff, unsigned drop = 0u) { return ldrow(rsF, soff, std::integral_constant<int, XINV_P3_NTF ? 2 : 0>{}, drop); };
     const int rowbytes = (int)(xc * 8);
     auto plane_off = [&](int p, int rr) {                // byte offset of the lane's row in plane p (clamped), a scalar
         const int pr = p > zc - 1 ? zc - 1 : (p < 0 ? 0 : p);
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             if (GRP == 0) ring[gw][rr][U & 1][1][lane] = fwr[rr];
             fwb[rr] = XROW(rr) ? fwr[rr].y : fwr[rr].x;
             fwr[rr] = pfF[rr];
-            if (GRP == 0) pfF[rr] = ldF(plane_off(r, rr));
+            if (GRP == 0) pfF[rr] = ldF(plane_off(r, rr), f_drop[rr]);
             else pfF[rr] = ring[gw][rr][U & 1][1][lane];
 #else
             fw[rr][S1 & 1] = pfF[rr];
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             for (int rr = 0; rr < RR; rr++) pfS[rr] = ldS(plane_off(rstart, rr));
         }
 #pragma unroll
-        for (int rr = 0; rr < RR; rr++) pfF[rr] = ldF(plane_off(rstart - 1 - 3 * GRP, rr));
+        for (int rr = 0; rr < RR; rr++) pfF[rr] = ldF(plane_off(rstart - 1 - 3 * GRP, rr), f_drop[rr]);
         for (int gb = 0; gb <= gend; gb += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int Ug = decltype(utag)::value;                // global step mod D
