@@ -26,7 +26,7 @@ def case(kind, shape, nb, mx, tol, want):
     if want == 0:                                             # the engine's own rule (lane_rule, xinv_hip.hip)
         rate = 6.0e5 if st['pipelined'] else (2.5e5 if kind == 'std3d' else 3.0e5)
         est_us = nb * float(np.prod(shape)) * st['sweeps_per_launch'] / rate
-        want = 2 if (nb >= 2 and est_us >= 30.0 and st['path'] == 2) else 1
+        want = 2 if (nb >= 2 and est_us >= 20.0 and st['path'] == 2) else 1
     want = min(want, nb)
     assert st['lanes'] == want, (kind, shape, nb, st['lanes'], want)
     LANES.append(st['lanes'])

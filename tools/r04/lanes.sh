@@ -4,8 +4,8 @@ import json,sys
 for l in sys.stdin:
     d=json.loads(l); print('$TAG', d['config'], d['shape'], '%.4g  launch %.1f us' % (d['point_sweeps_per_s'], d['avg_launch_ms']*1e3))"; }
 {
-for cfg in "c2 --members 2" "c2 --members 3" "c2 --members 4" "c4 --members 4" "c4 --members 8" "c4 --members 12" "c1 --members 100" "c1 --members 200" "c3m" "c5 --members 4"; do
+for cfg in "c1 --members 4" "c1 --members 8" "c1 --members 16" "c1 --members 32" "c1 --members 64" "c4 --members 2" "c4 --members 3" "c5 --members 2" "c5 --members 3" "c5 --members 6" "c5 --members 8"; do
 for n in 1 2; do TAG=lanes$n XINV_LANES=$n run $cfg; done
 done
-} > gpurun_out/lanes/out4.txt 2>&1
-cat gpurun_out/lanes/out4.txt
+} > gpurun_out/lanes/out5.txt 2>&1
+cat gpurun_out/lanes/out5.txt

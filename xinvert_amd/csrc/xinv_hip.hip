@@ -541,14 +541,15 @@ static int launch_planned(const Problem &p, const Plan &pl, Workspace *ws, hipSt
 // Measured with 1 and 2 lanes on one box (profiles/r04_lanes.txt; XINV_LANES=n forces n, 0 or 1 = off):
 //   3600x1800 x 2/3/4/6/8/12/16/32 members  +6 +7 +6 +8 +10 +5 +8 +1.5 %      (5 members: 0)
 //   1440x720 general form x 4/8/12/16/24/32/64/128   0 +9 +6 +7 +8.5 +7 +5.5 +2 %
-//   360x180 x 100/200/365/1000               +13 +8 +5 +3.5 %
-//   720x360x50 x 4/15/16/30 volumes          +17 +1 -2 -2 %   (one workgroup per CU: the gain is the tail of a launch of
-//                                             two rounds; with eight rounds there is none to win)
+//   360x180 x 8/16/32/64/100/200/365/1000    -1 -6 +1 +11 +13 +8 +5..12 +3.5 %      73x144 x 365/3650  +5 +5 %
+//   720x360x50 x 2/3/4/6/8/15/16/30 volumes  +33 -3 +17 +6 +4 +1 -2 -2 %   (one workgroup per CU: the gain is the tail of a
+//                                             launch of one or two rounds; with eight rounds there is none to win)
 // Three or four lanes were no better than two; lanes on streams of the lowest priority were erratic (-30 % on small
-// batches).  A pass of a few microseconds is bound by the host's launch rate, which lanes double.
+// batches).  A pass of a few microseconds is bound by the host's launch rate, which lanes double: the rule wants an
+// estimated 20 us (64 slices of 360x180, 365 of 144x73).
 static int lane_rule(const Problem &p, double est_pass_us)
 {
-    if (p.nbatch < 2 || est_pass_us < 30.0) return 1;
+    if (p.nbatch < 2 || est_pass_us < 20.0) return 1;
     if (is3d(p.kind)) return p.nbatch <= 8 ? 2 : 1;
     return 2;
 }
