@@ -42,9 +42,10 @@ def case(kind, shape, nb, mx, tol, want):
 def main():
     want = int(sys.argv[1])
     out = []
-    # (many members of few workgroups each: the lagged norm, which excludes lanes, needs 32 workgroups per member)
+    # (many members of few workgroups each: in-kernel reducer; the lagged norm needs 32 workgroups per member)
     out.append(case('std2d', (150, 400), 120, 60, 1e-4, want))
     out.append(case('gen2d', (140, 380), 90, 40, 1e-4, want))
+    out.append(case('std2d', (700, 1500), 3, 40, 1e-4, want))   # few members of many workgroups: lanes WITH the lagged norm
     out.append(case('std3d', (16, 150, 500), 8, 24, 1e-3, want))
     out.append(case('std3d', (12, 120, 380), 3, 12, 1e-3, want))
     out.append(case('std2d', (384, 1100), 1, 24, 0.0, 1 if want else 0))      # one member: one lane whatever was asked

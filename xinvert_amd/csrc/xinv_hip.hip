@@ -544,6 +544,8 @@ static int launch_planned(const Problem &p, const Plan &pl, Workspace *ws, hipSt
 //   360x180 x 8/16/32/64/100/200/365/1000    -1 -6 +1 +11 +13 +8 +5..12 +3.5 %      73x144 x 365/3650  +5 +5 %
 //   720x360x50 x 2/3/4/6/8/15/16/30 volumes  +33 -3 +17 +6 +4 +1 -2 -2 %   (one workgroup per CU: the gain is the tail of a
 //                                             launch of one or two rounds; with eight rounds there is none to win)
+// With the lagged norm (a launch of at most one round; every lane keeps its own pending evaluation):
+//   1440x720 general form x 2/3/4  -5 +9 +4 %
 // Three or four lanes were no better than two; lanes on streams of the lowest priority were erratic (-30 % on small
 // batches).  A pass of a few microseconds is bound by the host's launch rate, which lanes double: the rule wants an
 // estimated 20 us (64 slices of 360x180, 365 of 144x73).
@@ -681,8 +683,8 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         }
     }
     const bool lag = R.lag = lag_cand && !use_graph && !exp_noctl;
-    NormLagArgs lag_pending;
-    memset(&lag_pending, 0, sizeof lag_pending);
+    NormLagArgs lag_pending[XINV_MAX_LANES];               // per lane (one lane: [0])
+    memset(lag_pending, 0, sizeof lag_pending);
     if (lag) {
         const size_t need = (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double);
         rc = ensure_dev(&ws->S3, &ws->S3_cap, need);
@@ -697,7 +699,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // launch is filled by the other half's workgroups.  Control blocks are copied on a third stream behind both chains.
     static const int lanes_env = [] { const char *e = getenv("XINV_LANES"); return e ? atoi(e) : -1; }();
     int nlane = 1;
-    if (!lag && !use_graph && !exp_noctl && pl.path == XINV_PATH_FUSED)
+    if (!use_graph && !exp_noctl && pl.path == XINV_PATH_FUSED)
         nlane = (int)std::min<int64_t>(p.nbatch, lanes_env >= 0 ? std::max(1, std::min(lanes_env, XINV_MAX_LANES)) : lane_rule(p, est_pass_us));
     const bool two = nlane > 1;
     R.lanes = nlane;
@@ -755,31 +757,36 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         double *dst = buf[(i + 1) % R.nbuf];
         if (exp_noctl == 2)                              // (timing experiment: publish only, nobody reduces)
             return launch_fused(p, pl, k, src, dst, ws, st, 0, p.nbatch, 1, 0, (unsigned)(i + 1), nullptr);
-        if (two) {
-            for (int l = 0; l < nlane; l++) {
-                const int r = launch_planned(p, pl, ws, l ? ws->s_lane[l] : st, k, src, dst, lane_first(l),
-                                             lane_first(l + 1) - lane_first(l), 0, 0);
+        if (!lag && !two) return launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, exp_noctl, exp_noctl);
+        for (int l = 0; l < nlane; l++) {                // (one lane: the whole batch on the caller's stream)
+            hipStream_t sl = l ? ws->s_lane[l] : st;
+            const int64_t m0 = lane_first(l), nm = lane_first(l + 1) - m0;
+            if (!lag) {
+                const int r = launch_planned(p, pl, ws, sl, k, src, dst, m0, nm, 0, 0);
                 if (r) return r;
+                continue;
             }
-            return XINV_OK;
+            NormLagArgs la;
+            const int r = launch_planned(p, pl, ws, sl, k, src, dst, m0, nm, 0, 0, (unsigned)(i + 1), &la, &lag_pending[l]);
+            if (r) return r;
+            lag_pending[l] = la;                         // evaluated by the lane's next launch, or by flush_lag()
         }
-        if (!lag) return launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, exp_noctl, exp_noctl);
-        NormLagArgs la;
-        int r = launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, 0, 0, (unsigned)(i + 1), &la, &lag_pending);
-        if (r) return r;
-        lag_pending = la;                                // evaluated by the next launch, or by flush_lag()
         return XINV_OK;
     };
     // the last launch of a chunk has no successor yet: its norm is evaluated by a one-workgroup kernel
     // before the control blocks are copied for the host
     auto flush_lag = [&]() -> int {
-        if (!lag || !lag_pending.tag) return XINV_OK;
-        for (int64_t m0 = 0; m0 < p.nbatch; m0 += (int64_t)1 << 30) {
-            lag_pending.member0 = m0;
-            hipLaunchKernelGGL(k_norm_reduce_lag, dim3((unsigned)std::min<int64_t>((int64_t)1 << 30, p.nbatch - m0)),
-                               dim3(256), 0, st, lag_pending);
+        if (!lag) return XINV_OK;
+        for (int l = 0; l < nlane; l++) {
+            if (!lag_pending[l].tag) continue;
+            const int64_t mend = lane_first(l + 1);
+            for (int64_t m0 = lane_first(l); m0 < mend; m0 += (int64_t)1 << 30) {
+                lag_pending[l].member0 = m0;
+                hipLaunchKernelGGL(k_norm_reduce_lag, dim3((unsigned)std::min<int64_t>((int64_t)1 << 30, mend - m0)),
+                                   dim3(256), 0, l ? ws->s_lane[l] : st, lag_pending[l]);
+            }
+            lag_pending[l].tag = 0;
         }
-        lag_pending.tag = 0;
         return XINV_OK;
     };
     int last_slot = 0;
