@@ -102,7 +102,12 @@ def families():
     F['colour_gen2d_nine'] = (lambda s: util.rand2d('gen2d', 60, 251, 'extend', 'periodic', bnz=True, seed=s),
                               {}, dict(path=1), orc.COLOUR_AUTO)
     F['colour_std3d_ext'] = (lambda s: util.rand3d(9, 30, 121, 'extend', 'periodic', seed=s),
-                             {}, dict(path=1), orc.COLOUR_AUTO)
+                             dict(path=1), dict(path=1), orc.COLOUR_AUTO)
+    # the seam inside k_fused3d (both components of a row exchanged through LDS)
+    F['fused3d_seam'] = (lambda s: util.rand3d(9, 30, 121, 'extend', 'periodic', msk=True, seed=s),
+                         {}, dict(path=2, xuniform_mask=0), orc.COLOUR_2)
+    F['fused3d_seam_uni'] = (lambda s: xuni(util.rand3d(12, 40, 257, 'fixed', 'periodic', seed=s), (0, 1, 2)),
+                             {}, dict(path=2, xuniform_mask=7, sweeps_per_launch=1), orc.COLOUR_2)
     return F
 
 

@@ -10,7 +10,7 @@ import zlib
 import numpy as np
 import pytest
 
-from util import rand2d, rand2dt, run_oracle, run_hip_batched
+from util import rand2d, rand2dt, rand3d, run_oracle, run_hip_batched
 
 pytestmark = pytest.mark.gpu
 COLOUR_2, PATH_COLOUR, PATH_FUSED = 2, 1, 2
@@ -104,6 +104,42 @@ def test_seam_edge_strips_in_half_height_tiles(kind, shape):
         assert st['path'] == PATH_FUSED, st
         for m in range(2):
             _same(S[m], fl[m], ref[m][0], ref[m][1], '%s %r member %d %r' % (kind, shape, m, kw))
+
+
+# 3-D standard form (k_fused3d's SEAM variants: 122 owned columns, both components of a row exchanged between the
+# wavefronts).  Widths: one strip wrapping on both sides, a full strip next to the seam (245 = 2 x 122 + 1, 123, 367),
+# many strips; heights around the 8 / 4 owned rows of the 12- / 8-wavefront cross-sections; k chunks (tall volumes).
+SHAPES_3D = [(7, 20, 65), (9, 23, 101), (6, 17, 127), (12, 30, 129), (8, 19, 245), (8, 14, 123), (5, 9, 367), (40, 11, 131),
+             (6, 12, 641)]
+
+
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', SHAPES_3D)
+def test_seam_fused_3d(BCy, msk, shape):
+    zc, yc, xc = shape
+    p = rand3d(zc, yc, xc, BCy, 'periodic', msk, seed=_seed((BCy, msk, shape)))
+    So, flo = run_oracle(p, 11, 1e-9, COLOUR_2)
+    Sc, fc, sc = run_hip_batched([p], 11, 1e-9, path=PATH_COLOUR)
+    assert sc['path'] == PATH_COLOUR and sc['colours'] == 4
+    _same(Sc[0], fc[0], So, flo, 'colour launches')
+    for rows in (0, 8, 12):                             # full coefficient arrays
+        S, fl, st = run_hip_batched([p], 11, 1e-9, path=PATH_FUSED, rows_per_tile=rows)
+        assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == 1 and st['xuniform_mask'] == 0, st
+        _same(S[0], fl[0], So, flo, '3-D rows=%d %r' % (rows, shape))
+    # x-uniform coefficients (every lat-lon omega problem), three members, the engine's own choice, a tolerance stop
+    qs = []
+    for m in range(3):
+        q = rand3d(zc, yc, xc, BCy, 'periodic', (msk + m) & 1, seed=_seed((BCy, msk, shape, m)))
+        q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :, :1], c.shape)) if k < 3 else c
+                      for k, c in enumerate(q['coefs'])]
+        qs.append(q)
+    ref = [run_oracle(q, 60, 1e-3, COLOUR_2) for q in qs]
+    for kw in (dict(), dict(rows_per_tile=8), dict(sweeps_per_launch=2)):
+        S, fl, st = run_hip_batched(qs, 60, 1e-3, **kw)
+        assert st['path'] == PATH_FUSED and st['xuniform_mask'] == 7 and st['sweeps_per_launch'] == 1, st
+        for m in range(3):
+            _same(S[m], fl[m], ref[m][0], ref[m][1], '3-D x-uniform %r member %d %r' % (shape, m, kw))
 
 
 def test_short_odd_rows_keep_the_colour_launches():

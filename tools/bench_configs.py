@@ -50,6 +50,8 @@ def main():
             p = synthetic.gill_matsuno(720, 1440, a.members or 8); sw = a.sweeps or 200
         elif name == 'c5':
             p = synthetic.omega_latlon(50, 360, 720, a.members or 2); sw = a.sweeps or 50
+        elif name == 'c5odd':                              # odd width, periodic x: the seam inside k_fused3d
+            p = synthetic.omega_latlon(50, 360, 721, a.members or 2); sw = a.sweeps or 50
         elif name == 'c5g':
             p = synthetic.ocean3d_latlon(50, 360, 720, a.members or 2); sw = a.sweeps or 50
         elif name == 'ofes':

@@ -41,6 +41,7 @@ UNITS = [
     ('xinv_tu_fused9', 'xinv_tu_fused9.hip', []),
     ('xinv_tu_fused3d', 'xinv_tu_fused3d.hip', []),
     ('xinv_tu_fused3d_fma', 'xinv_tu_fused3d_fma.hip', []),
+    ('xinv_tu_fused3d_seam', 'xinv_tu_fused3d_seam.hip', []),
     # k_pipe3d: sixteen wavefronts x 128 VGPRs; the default scheduler's interleaving spills, minimum-register scheduling
     # fits the ring variant in 123 (C5, 15 volumes: 2.98 -> 3.26e11, profiles/r04_pipe3d_variants.txt)
     ('xinv_tu_pipe3d', 'xinv_tu_pipe3d.hip', ['-mllvm', '-amdgpu-sched-strategy=iterative-minreg']),

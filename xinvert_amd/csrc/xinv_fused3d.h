@@ -76,11 +76,18 @@ template <> struct Coef3Pack<false> { double2 A, B, B1, C; };
 template <> struct Coef3Pack<true>  { double A, B, B1, C; };
 
 // FMA: the opt-in contracted arithmetic of XINV_FLAG_FMA (x-uniform coefficients only; oracle: XO_FMA, bit for bit).
-template <int NW, bool AL, bool UNI, bool EXT, bool FMA = false>
+// SEAM: periodic x with ODD xc (unaligned strips only) -- the scheme of k_fused2d's SEAM variants (xinv_fused.h) carried to
+// the k march: column xc-1 is updated inside the half-sweep of its own colour right after column 0 (oracle: seq_colour;
+// 3-D colours (k+j+i)&1, seam colours (k+j)&1 on column xc-1), a half-sweep of a tile that wraps around the seam runs as
+// up to three lane-masked passes (east-wrapped lanes' OTHER component, unwrapped lanes, west-wrapped lanes' other
+// component), and -- because a wrapped lane needs the other component of its j neighbours -- the wavefronts exchange
+// BOTH components of their row through LDS.  The strip owns one column pair less (the dependency cone across the seam).
+template <int NW, bool AL, bool UNI, bool EXT, bool FMA = false, bool SEAM = false>
 __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
 {
     static_assert(!FMA || UNI, "contracted arithmetic: x-uniform coefficients only");
-    constexpr int H = 2, UW = 128 - 2 * H, D = 4, RJ = NW - 4;
+    static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
+    constexpr int H = 2, UW = 128 - 2 * H - (SEAM ? 2 : 0), D = 4, RJ = NW - 4;
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -106,6 +113,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
     const double u = a.sc_.undef;
     const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
     const int64_t st0 = xu0 - H + 2 * lane;
+    SeamLanes sl;
+    if constexpr (SEAM) sl = make_seamlanes(st0, lc, xc);
 
     const int64_t j = (int64_t)jb * RJ - 2 + wave;             // this wave's row (may be outside)
     const int64_t jr = j < 0 ? 0 : (j > yc - 1 ? yc - 1 : j);
@@ -120,7 +129,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
     const double *pA = a.c[0] + m * a.sc[0], *pB = a.c[1] + m * a.sc[1];
     const double *pC = a.c[2] + m * a.sc[2], *pF = a.c[3] + m * a.sc[3];
 
-    __shared__ double xch[2][2][NW][64];       // [step parity][as-loaded | red-updated][wave][lane]
+    using XchT = std::conditional_t<SEAM, double2, double>;    // SEAM: both components of the row
+    __shared__ XchT xch[2][2][NW][64];         // [step parity][as-loaded | red-updated][wave][lane]
 
     struct Pack { double2 s, f, sfix; Coef3Pack<UNI> c; };
     auto load = [&](int64_t r) {
@@ -171,7 +181,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         else { if (X == 0) return cw[slot].C.y; else return xinv_lane_down(cw[slot].C.x); } };
 
     // one point update of component X on the plane held in slot `sk` (k+1 in `skp`, k-1 in `skm`)
-    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt) {
+    // (SEAM: `lw` = all-ones word where the lane takes part in this pass)
+    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, unsigned lw = ~0u) {
         constexpr int X = decltype(xt)::value;
         const bool okc = X ? lc.ok_y : lc.ok_x;
         const bool inr = okc && row_upd && (kk >= 1) && (kk <= zc - 2);
@@ -208,9 +219,19 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         } else {
             v = xinv_upd_std3d_sel(sC, sKP, sKM, jP, jM, e, w, aP, a0, bP, b0, cE, c0, f, inr, a.sc_);
         }
+        if constexpr (SEAM) v = xinv_bitsel(lw, v, sC);
         setc<X>(sw[sk], v);
         return v;
     };
+    // SEAM: one half-sweep as lane-masked passes; jP2 / jM2 = both components of the j neighbours' rows
+    auto seam_half = [&](int sk, int skp, int skm, int64_t kk, const double2 &jP2, const double2 &jM2, auto xt) {
+        constexpr int X = decltype(xt)::value;
+        using XB = std::integral_constant<int, 1 - X>;
+        if (sl.has_e) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, sl.fe[1 - X]);
+        update(sk, skp, skm, kk, comp<X>(jP2), comp<X>(jM2), xt, sl.reg[X]);
+        if (sl.has_w) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, sl.fw[1 - X]);
+    };
+    (void)seam_half;
 
     // one pipeline step: plane r (= rbase + U) enters slot U; JP = parity of this wave's row
     auto step = [&](int64_t r, const Pack &p, auto utag, auto jtag) {
@@ -233,17 +254,24 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
                                      (c + c));
             rok[S1] = (aP != u) && (a0 != u) && (bP != u) && (b0 != u) && (c != u);
         }
-        xch[bw][0][wave][lane] = comp<X>(sw[U]);               // as loaded: neighbours' next red
+        if constexpr (SEAM) xch[bw][0][wave][lane] = sw[U];
+        else xch[bw][0][wave][lane] = comp<X>(sw[U]);          // as loaded: neighbours' next red
 
         {   // red half-sweep on plane r-1
-            const double jM = xch[br][0][wm][lane], jP = xch[br][0][wp][lane];
-            const double v = update(S1, U, S2, r - 1, jP, jM, XT{});
-            xch[bw][1][wave][lane] = v;                        // red-updated: neighbours' next black
+            const XchT jM = xch[br][0][wm][lane], jP = xch[br][0][wp][lane];
+            if constexpr (SEAM) {
+                seam_half(S1, U, S2, r - 1, jP, jM, XT{});
+                xch[bw][1][wave][lane] = sw[S1];
+            } else {
+                const double v = update(S1, U, S2, r - 1, jP, jM, XT{});
+                xch[bw][1][wave][lane] = v;                    // red-updated: neighbours' next black
+            }
         }
         {   // black half-sweep on plane r-2
             const int64_t kk = r - 2;
-            const double jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
-            update(S2, S1, S3, kk, jP, jM, XT{});
+            const XchT jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
+            if constexpr (SEAM) seam_half(S2, S1, S3, kk, jP, jM, XT{});
+            else update(S2, S1, S3, kk, jP, jM, XT{});
             const bool pin = row_use && (kk >= k0) && (kk < k1);
             const double2 t = sw[S2];
             if (pin) {                                         // wave-uniform: an owned row of an owned plane

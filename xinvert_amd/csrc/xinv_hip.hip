@@ -211,7 +211,7 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         pl.K = 1;
         pl.RY = (opt.rows_per_tile == 8 || opt.rows_per_tile == 12 || opt.rows_per_tile == 16)
                     ? opt.rows_per_tile : 0;     // 0: decided below, once the variant is known
-        pl.nsg = (int)cdiv(p.xc, 124);                      // x strips
+        pl.nsg = (int)cdiv(p.xc, pl.seam ? 122 : 124);      // x strips (the seam variants own one column pair less)
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
         // only S and the forcing are read as vectors when the coefficients are per-row scalars
         pl.aligned = pl.aligned && ptr_al16(p.c[p.ncoef - 1]) && !(p.sc[p.ncoef - 1] & 1);
@@ -226,8 +226,9 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
             // 16 waves x 64 lanes leaves 128 VGPRs per lane: enough only for the x-uniform variant (the others
             // spilled and are not instantiated: a request for sixteen gets twelve)
             const bool nw16_ok = (pl.um == 7u && p.BCy != XINV_BC_EXTEND);
-            if (pl.RY == 0) pl.RY = nw16_ok ? 16 : 12;
-            if (pl.RY == 16 && !nw16_ok) pl.RY = 12;
+            const bool nw16 = nw16_ok && !pl.seam;            // (seam variants: 8 or 12 wavefronts)
+            if (pl.RY == 0) pl.RY = nw16 ? 16 : 12;
+            if (pl.RY == 16 && !nw16) pl.RY = 12;
         } else {
             pl.um = pl.umask;                               // 0x7f: A..G are per-row scalars
             if (pl.RY == 0 || pl.RY == 16) pl.RY = 12;      // seven coefficient windows: 12 waves x 170 VGPRs
@@ -256,7 +257,7 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         // -- 1.45e11 -- and is gone.)
         pl.K2 = false;
         static const int k2_auto = [] { const char *e = getenv("XINV_3D_K2"); return e ? atoi(e) : 1; }();
-        if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND &&
+        if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND && !pl.seam &&
             (opt.sweeps_per_launch == 2 || (opt.sweeps_per_launch == 0 && k2_auto)) &&
             opt.rows_per_tile == 0 && p.stop.mxLoop >= 1 &&
             p.zc * p.yc * 64 < ((int64_t)1 << 31) &&                      // (32-bit offsets into the record table)
@@ -465,7 +466,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     // ---- path ------------------------------------------------------------------------------
     // (the odd-xc periodic seam runs inside the 2-D 5-point streaming kernels -- xinv_fused.h: SEAM -- when a strip
     //  spans at most three wraps of the row: xc >= 64; the 3-D, 9-point and biharmonic forms keep the colour launches)
-    const bool seam5_ok = !pl.seam || (!is3d(p.kind) && p.xc >= 64);
+    const bool seam5_ok = !pl.seam || (p.kind != KIND_GEN3D && p.xc >= 64);     // (3-D standard form: k_fused3d's SEAM variants)
     const bool fused5_ok = pl.base == 2 && seam5_ok && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
     const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
                            (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
@@ -492,7 +493,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     pl.nine = false;
     if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("no fused kernel for this form (odd-xc periodic seam in 3-D, with B != 0 or with xc < 64; 9-point test form; biharmonic or general 3-D with coefficients that vary along x)");
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam in the general 3-D form, with B != 0 or with xc < 64; 9-point test form; biharmonic or general 3-D with coefficients that vary along x)");
     if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 

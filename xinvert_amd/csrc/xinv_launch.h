@@ -262,8 +262,9 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)NB, (unsigned)nm, 1);
-        if (pl.fma ? xinv_launch_fused3d_fma(pl.RY, pl.aligned, ext, grid, st, a)
-                   : xinv_launch_fused3d(pl.RY, pl.aligned, uni, ext, grid, st, a))
+        if (pl.seam ? xinv_launch_fused3d_seam(pl.RY, uni, ext, grid, st, a)
+            : pl.fma ? xinv_launch_fused3d_fma(pl.RY, pl.aligned, ext, grid, st, a)
+                     : xinv_launch_fused3d(pl.RY, pl.aligned, uni, ext, grid, st, a))
             return fail_arg("internal: no 3-D kernel variant for this cross-section");
     }
     HIPCHK(hipGetLastError());
