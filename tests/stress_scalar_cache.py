@@ -106,6 +106,8 @@ def families():
     # the seam inside k_fused3d (both components of a row exchanged through LDS)
     F['fused3d_seam'] = (lambda s: util.rand3d(9, 30, 121, 'extend', 'periodic', msk=True, seed=s),
                          {}, dict(path=2, xuniform_mask=0), orc.COLOUR_2)
+    F['fused3dg_seam'] = (lambda s: xuni(util.rand3dg(12, 40, 257, 'extend', 'periodic', seed=s), range(7)),
+                          {}, dict(path=2, xuniform_mask=127), orc.COLOUR_2)
     F['fused3d_seam_uni'] = (lambda s: xuni(util.rand3d(12, 40, 257, 'fixed', 'periodic', seed=s), (0, 1, 2)),
                              {}, dict(path=2, xuniform_mask=7, sweeps_per_launch=1), orc.COLOUR_2)
     return F

@@ -10,7 +10,7 @@ import zlib
 import numpy as np
 import pytest
 
-from util import rand2d, rand2dt, rand3d, run_oracle, run_hip_batched
+from util import rand2d, rand2dt, rand3d, rand3dg, run_oracle, run_hip_batched
 
 pytestmark = pytest.mark.gpu
 COLOUR_2, PATH_COLOUR, PATH_FUSED = 2, 1, 2
@@ -140,6 +140,30 @@ def test_seam_fused_3d(BCy, msk, shape):
         assert st['path'] == PATH_FUSED and st['xuniform_mask'] == 7 and st['sweeps_per_launch'] == 1, st
         for m in range(3):
             _same(S[m], fl[m], ref[m][0], ref[m][1], '3-D x-uniform %r member %d %r' % (shape, m, kw))
+
+
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', SHAPES_3D)
+def test_seam_fused_3d_general_form(BCy, msk, shape):
+    """invert_general_3D with every coefficient constant along x (invert_3DOcean): k_fused3dg's SEAM variants, incl. the
+    reference's i == 0 branch that never tests the forcing (numbas.py:849-852) on the wrapped copies of column 0."""
+    zc, yc, xc = shape
+    qs = []
+    for m in range(2):
+        q = rand3dg(zc, yc, xc, BCy, 'periodic', (msk + m) & 1, seed=_seed(('g', BCy, msk, shape, m)))
+        q['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :, :1], c.shape)) if k < 7 else c
+                      for k, c in enumerate(q['coefs'])]
+        qs.append(q)
+    ref = [run_oracle(q, 14, 1e-9, COLOUR_2) for q in qs]
+    Sc, fc, sc = run_hip_batched(qs, 14, 1e-9, path=PATH_COLOUR)
+    assert sc['path'] == PATH_COLOUR and sc['colours'] == 4
+    for kw in (dict(), dict(rows_per_tile=8)):
+        S, fl, st = run_hip_batched(qs, 14, 1e-9, **kw)
+        assert st['path'] == PATH_FUSED and st['xuniform_mask'] == 127, st
+        for m in range(2):
+            _same(Sc[m], fc[m], ref[m][0], ref[m][1], 'colour launches')
+            _same(S[m], fl[m], ref[m][0], ref[m][1], 'general 3-D %r member %d %r' % (shape, m, kw))
 
 
 def test_short_odd_rows_keep_the_colour_launches():

@@ -64,6 +64,7 @@ XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 gr
 XINV_HIDDEN int xinv_launch_pipe3d(bool al, dim3 grid, hipStream_t st, const Fused3Args &a);
 // odd-xc periodic seam inside the kernel (xinv_tu_fused3d_seam.hip): unaligned strips, NW = 8 or 12
 XINV_HIDDEN int xinv_launch_fused3d_seam(int NW, bool uni, bool ext, dim3 grid, hipStream_t st, const Fused3Args &a);
+XINV_HIDDEN int xinv_launch_fused3dg_seam(int NW, bool ext, dim3 grid, hipStream_t st, const Fused3GArgs &a);
 // contracted arithmetic (XINV_FLAG_FMA): x-uniform coefficients only (xinv_tu_fused3d_fma.hip)
 XINV_HIDDEN int xinv_launch_fused3d_fma(int NW, bool al, bool ext, dim3 grid, hipStream_t st, const Fused3Args &a);
 XINV_HIDDEN int xinv_launch_pipe3d_fma(bool al, dim3 grid, hipStream_t st, const Fused3Args &a);

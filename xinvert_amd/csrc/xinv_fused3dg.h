@@ -31,10 +31,12 @@ struct Fused3GArgs {
     unsigned long long *psum;  // [nbatch][NB]
 };
 
-template <int NW, bool AL, bool EXT>
+// SEAM: the odd-xc periodic seam inside the kernel, exactly as in k_fused3d (xinv_fused3d.h).
+template <int NW, bool AL, bool EXT, bool SEAM = false>
 __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
 {
-    constexpr int H = 2, UW = 128 - 2 * H, D = 4, RJ = NW - 4;
+    static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
+    constexpr int H = 2, UW = 128 - 2 * H - (SEAM ? 2 : 0), D = 4, RJ = NW - 4;
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -58,6 +60,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
     const bool tall = yc > xc;             // the general kernel's pre-pass loops over range(1, yc-1)
     const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
     const int64_t st0 = xu0 - H + 2 * lane;
+    SeamLanes sl;
+    if constexpr (SEAM) sl = make_seamlanes(st0, lc, xc);
     // the reference's i == 0 periodic branch does not test H (numbas.py:849-852)
     const bool noH_x = (a.per != 0) && (lc.l0 == 0), noH_y = (a.per != 0) && (lc.l1 == 0);
 
@@ -75,7 +79,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
     for (int q = 0; q < 7; q++) pc[q] = a.c[q] + m * a.sc[q];
     const double *pH = a.c[7] + m * a.sc[7];
 
-    __shared__ double xch[2][2][NW][64];
+    using XchT = std::conditional_t<SEAM, double2, double>;    // SEAM: both components of the row
+    __shared__ XchT xch[2][2][NW][64];
 
     struct Pack { double2 s, h, sfix; double c[7]; };
     auto load = [&](int64_t r) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
     }
 
     // one point update of component X on the plane held in slot `sk` (k+1 in `skp`, k-1 in `skm`)
-    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt) {
+    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, unsigned lw = ~0u) {
         constexpr int X = decltype(xt)::value;
         const bool okc = X ? lc.ok_y : lc.ok_x;
         const bool inr = okc && row_upd && (kk >= 1) && (kk <= zc - 2);
@@ -142,10 +147,19 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
             cG * sC - h) * a.sc_.delxSqr
         );
         temp *= rq[sk];
-        const double v = cond ? sC + temp : sC;
+        double v = cond ? sC + temp : sC;
+        if constexpr (SEAM) v = xinv_bitsel(lw, v, sC);
         setc<X>(sw[sk], v);
         return v;
     };
+    auto seam_half = [&](int sk, int skp, int skm, int64_t kk, const double2 &jP2, const double2 &jM2, auto xt) {
+        constexpr int X = decltype(xt)::value;
+        using XB = std::integral_constant<int, 1 - X>;
+        if (sl.has_e) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, sl.fe[1 - X]);
+        update(sk, skp, skm, kk, comp<X>(jP2), comp<X>(jM2), xt, sl.reg[X]);
+        if (sl.has_w) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, sl.fw[1 - X]);
+    };
+    (void)seam_half;
 
     auto step = [&](int64_t r, const Pack &p, auto utag, auto jtag) {
         constexpr int U = decltype(utag)::value;
@@ -170,17 +184,24 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
             rok[U] = (cG != u) && (cA != u) && (cB != u) && (cC != u) && (p.c[3] != u) &&
                      (p.c[4] != u) && (p.c[5] != u);
         }
-        xch[bw][0][wave][lane] = comp<X>(sw[U]);
+        if constexpr (SEAM) xch[bw][0][wave][lane] = sw[U];
+        else xch[bw][0][wave][lane] = comp<X>(sw[U]);
 
         {   // red half-sweep on plane r-1
-            const double jM = xch[br][0][wm][lane], jP = xch[br][0][wp][lane];
-            const double v = update(S1, U, S2, r - 1, jP, jM, XT{});
-            xch[bw][1][wave][lane] = v;
+            const XchT jM = xch[br][0][wm][lane], jP = xch[br][0][wp][lane];
+            if constexpr (SEAM) {
+                seam_half(S1, U, S2, r - 1, jP, jM, XT{});
+                xch[bw][1][wave][lane] = sw[S1];
+            } else {
+                const double v = update(S1, U, S2, r - 1, jP, jM, XT{});
+                xch[bw][1][wave][lane] = v;
+            }
         }
         {   // black half-sweep on plane r-2
             const int64_t kk = r - 2;
-            const double jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
-            update(S2, S1, S3, kk, jP, jM, XT{});
+            const XchT jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
+            if constexpr (SEAM) seam_half(S2, S1, S3, kk, jP, jM, XT{});
+            else update(S2, S1, S3, kk, jP, jM, XT{});
             const bool pin = row_use && (kk >= k0) && (kk < k1);
             const double2 t = sw[S2];
             if (pin) {                                         // wave-uniform: an owned row of an owned plane

@@ -466,7 +466,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     // ---- path ------------------------------------------------------------------------------
     // (the odd-xc periodic seam runs inside the 2-D 5-point streaming kernels -- xinv_fused.h: SEAM -- when a strip
     //  spans at most three wraps of the row: xc >= 64; the 3-D, 9-point and biharmonic forms keep the colour launches)
-    const bool seam5_ok = !pl.seam || (p.kind != KIND_GEN3D && p.xc >= 64);     // (3-D standard form: k_fused3d's SEAM variants)
+    const bool seam5_ok = !pl.seam || p.xc >= 64;        // (3-D forms: the SEAM variants of k_fused3d / k_fused3dg)
     const bool fused5_ok = pl.base == 2 && seam5_ok && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
     const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
                            (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
@@ -483,7 +483,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     }
     // general 3-D: the fused kernel exists for x-uniform coefficients only (every 3DOcean array)
     bool fused3g_ok = false;
-    if (p.kind == KIND_GEN3D && !pl.seam && opt.path != XINV_PATH_COLOUR && !(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
+    if (p.kind == KIND_GEN3D && seam5_ok && opt.path != XINV_PATH_COLOUR && !(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
         rc = detect_xuniform(ws, st, p.c, p.sc, 7, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
         if (rc) return rc;
         fused3g_ok = (pl.umask == 0x7fu);
@@ -493,7 +493,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     pl.nine = false;
     if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("no fused kernel for this form (odd-xc periodic seam in the general 3-D form, with B != 0 or with xc < 64; 9-point test form; biharmonic or general 3-D with coefficients that vary along x)");
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam with B != 0 or with xc < 64; 9-point test form; biharmonic or general 3-D with coefficients that vary along x)");
     if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 

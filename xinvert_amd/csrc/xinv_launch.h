@@ -343,7 +343,7 @@ static int launch_fused3dg(const Problem &p, const Plan &pl, const double *src, 
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)NB, (unsigned)nm, 1);
-        if (xinv_launch_fused3dg(pl.RY, pl.aligned, ext, grid, st, a))
+        if (pl.seam ? xinv_launch_fused3dg_seam(pl.RY, ext, grid, st, a) : xinv_launch_fused3dg(pl.RY, pl.aligned, ext, grid, st, a))
             return fail_arg("internal: no general 3-D kernel variant for this cross-section");
     }
     HIPCHK(hipGetLastError());
