@@ -100,7 +100,9 @@ def families():
     F['fused2d_seam_um3'] = (lambda s: xuni(util.rand2d('std2d', 96, 385, 'fixed', 'periodic', seed=s), (0, 2)),
                              {}, dict(path=2, xuniform_mask=3), orc.COLOUR_2)
     F['colour_gen2d_nine'] = (lambda s: util.rand2d('gen2d', 60, 251, 'extend', 'periodic', bnz=True, seed=s),
-                              {}, dict(path=1), orc.COLOUR_AUTO)
+                              dict(path=1), dict(path=1), orc.COLOUR_AUTO)
+    F['fused9_seam'] = (lambda s: util.rand2d('std2d', 60, 251, 'extend', 'periodic', bnz=True, msk=True, seed=s),
+                        {}, dict(path=2, colours=6), orc.COLOUR_AUTO)
     F['colour_std3d_ext'] = (lambda s: util.rand3d(9, 30, 121, 'extend', 'periodic', seed=s),
                              dict(path=1), dict(path=1), orc.COLOUR_AUTO)
     # the seam inside k_fused3d (both components of a row exchanged through LDS)

@@ -27,7 +27,7 @@ def _seed(t):
 
 def _same(S, fl, So, flo, what):
     assert np.array_equal(S, So), '%s: %d points differ' % (what, (S != So).sum())
-    assert fl[2] == flo[2] and fl[0] == flo[0] and abs(fl[1] - flo[1]) <= 1e-12, (what, fl, flo)
+    assert fl[2] == flo[2] and fl[0] == flo[0] and abs(fl[1] - flo[1]) <= 1e-12 * max(1.0, abs(flo[1])), (what, fl, flo)
 
 
 def _uniform(p, which):
@@ -104,6 +104,30 @@ def test_seam_edge_strips_in_half_height_tiles(kind, shape):
         assert st['path'] == PATH_FUSED, st
         for m in range(2):
             _same(S[m], fl[m], ref[m][0], ref[m][1], '%s %r member %d %r' % (kind, shape, m, kw))
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('msk', [0, 1])
+@pytest.mark.parametrize('shape', SHAPES + [(24, 111), (24, 221), (24, 331), (24, 95), (24, 189), (24, 283), (151, 251)])
+def test_seam_fused_nine_point(kind, BCy, msk, shape):
+    """B != 0: the 4-colour kernel with the seam colours c0' / c2' (k_fused9's SEAM variants: lanes classed by the wrapped
+    column of each slot, up to six masked passes per row stage, 128 - 8K - 2 owned columns: 118, 110, 102 -- the widths
+    111, 221, 331 / 95, 189, 283 put a full strip next to the seam); the standard form's i == 0 branch (numbas.py:327-328)
+    on a column 0 that sits in a lane's .y slot."""
+    yc, xc = shape
+    ps = [rand2d(kind, yc, xc, BCy, 'periodic', 1, (msk + m) & 1, seed=_seed(('nine', kind, BCy, msk, shape, m))) for m in range(2)]
+    ref = [run_oracle(p, 13, 1e-9, 4) for p in ps]
+    Sc, fc, sc = run_hip_batched(ps, 13, 1e-9, path=PATH_COLOUR)
+    assert sc['path'] == PATH_COLOUR and sc['colours'] == 6
+    for m in range(2):
+        _same(Sc[m], fc[m], ref[m][0], ref[m][1], 'colour launches')
+    for K in (1, 2, 3) if kind == 'std2d' else (1, 2):
+        for rows in (16, 0):
+            S, fl, st = run_hip_batched(ps, 13, 1e-9, path=PATH_FUSED, sweeps_per_launch=K, rows_per_tile=rows)
+            assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == K and st['colours'] == 6, st
+            for m in range(2):
+                _same(S[m], fl[m], ref[m][0], ref[m][1], 'nine-point K=%d rows=%d %s %r member %d' % (K, rows, kind, shape, m))
 
 
 # 3-D standard form (k_fused3d's SEAM variants: 122 owned columns, both components of a row exchanged between the

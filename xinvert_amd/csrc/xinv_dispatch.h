@@ -57,7 +57,7 @@ static inline int xinv_launch_pipe2d(bool gen, unsigned um, int np, bool fr, boo
                : xinv_launch_pipe2d_std(um, np, fr, al, ext, grid, st, a, occ, lds_pad);
 }
 XINV_HIDDEN int xinv_launch_fused9(bool gen, int K, bool al, bool ext, dim3 grid, hipStream_t st,
-                                   const FusedArgs &a, int *occ);
+                                   const FusedArgs &a, int *occ, bool seam = false);
 XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 grid, hipStream_t st,
                                     const Fused3Args &a);
 // two sweeps per pass pipelined across two groups of eight wavefronts (xinv_pipe3d.h): x-uniform coefficients, no 'extend'

@@ -130,19 +130,51 @@ struct Fused9Std {                  // numbas.invert_standard_2D, B != 0
             if (west) { bP_use = cw[1][sjp].y; sM_q = n.m; }
         } else {
             bW = cw[1][sj].x; bE = xinv_lane_down(cw[1][sj].x); cE = xinv_lane_down(cw[2][sj].x);
+            // (odd xc: wrapped column 0 can sit in .y; column 1 is then the next lane's .x -- fetched by every lane: a
+            //  cross-lane move under a divergent branch would read lanes that are switched off)
+            const double bP1 = xinv_lane_down(cw[1][sjp].x);
+            if (west) { bP_use = bP1; sM_q = n.m; }
         }
         return xinv_upd_std2d_9_sel(n.c, n.p, n.m, n.w, n.e, n.pe, n.pw, n.me, n.mw, sM_q,
                                     aP, a0, bE, bW, bP_chk, bP_use, bM, cE, c0, f, inr, sc);
     }
 };
 
-template <class M, int K, bool AL, bool EXT>
+// SEAM (periodic x, ODD xc; unaligned strips only).  Columns 0 and xc-1 are both even: the coloured ordering runs the
+// seam colours right after the colour they split from -- c0, c0' (column xc-1 on even rows), c1, c2, c2' (column xc-1 on
+// odd rows), c3 (oracle: seq_colour) -- and a lane's slots hold columns of the wrong parity beyond a wrap.  The lanes
+// are classed by the WRAPPED column of each slot (even and not xc-1 / xc-1 / odd) and a row stage runs up to six
+// lane-masked passes -- the even columns in .x and in .y, the copies of column xc-1, the odd columns in .x and in .y --
+// of which a tile that does not wrap runs the usual two.  As in the 5-point kernels the dependency cone crosses the
+// seam one column further (xc-2 <- xc-1 <- 0 inside one colour pair): the strip owns one column pair less.
+struct Seam9 {
+    unsigned ev[2], sm[2], od[2];      // per slot: all-ones where the wrapped column is even (not xc-1) / xc-1 / odd
+    bool any_ev_y, any_sm_x, any_sm_y, any_od_x;   // wave-uniform
+};
+__device__ __forceinline__ Seam9 make_seam9(const LaneCols &lc, int64_t xc)
+{
+    Seam9 s;
+    const int64_t l[2] = {lc.l0, lc.l1};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const bool sm = l[q] == xc - 1, od = (l[q] & 1) != 0;
+        s.ev[q] = (!sm && !od) ? ~0u : 0u; s.sm[q] = sm ? ~0u : 0u; s.od[q] = od ? ~0u : 0u;
+    }
+    s.any_ev_y = __builtin_amdgcn_ballot_w64(s.ev[1] != 0u) != 0ull;
+    s.any_sm_x = __builtin_amdgcn_ballot_w64(s.sm[0] != 0u) != 0ull;
+    s.any_sm_y = __builtin_amdgcn_ballot_w64(s.sm[1] != 0u) != 0ull;
+    s.any_od_x = __builtin_amdgcn_ballot_w64(s.od[0] != 0u) != 0ull;
+    return s;
+}
+
+template <class M, int K, bool AL, bool EXT, bool SEAM = false>
 __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
 {
+    static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
     constexpr int NC = M::NC;
     constexpr int HX = 4 * K;           // halo columns: one per colour per sweep
     constexpr int HY = 2 * K;           // halo rows
-    constexpr int UW = 128 - 2 * HX;
+    constexpr int UW = 128 - 2 * HX - (SEAM ? 2 : 0);
     constexpr int D = 2 * K + 2;
 
     const int64_t m = a.member0 + blockIdx.y;
@@ -180,6 +212,10 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     const LaneCols lc = make_lanecols<AL>(xu0, HX, UW, lane, xc, a.per != 0);
     const int64_t st0 = xu0 - HX + 2 * lane;
     const bool west = (a.per != 0) && (lc.l0 == 0);          // .x sits on wrapped column 0
+    const bool west_y = SEAM && (lc.l1 == 0);                // (odd xc: so can .y)
+    Seam9 s9;
+    if constexpr (SEAM) s9 = make_seam9(lc, xc);
+    (void)west_y;
 
     const double *srcS = a.src + m * a.sS;
     double *dstS = a.dst + m * a.sS;
@@ -229,6 +265,30 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
             }
         };
 
+        // the two colours of a row (even row: c0 then c1; odd row: c2 then c3); SEAM: the lane-masked passes
+        auto row_stage = [&](int sj, int sjp, int sjm, bool rowok) {
+            if constexpr (!SEAM) {
+                double v = M::template upd<0, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_x, west, a.sc_);
+                sw[sj].x = v;
+                v = M::template upd<1, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_y, false, a.sc_);
+                sw[sj].y = v;
+            } else {
+                auto px = [&](unsigned lw) {
+                    const double v = M::template upd<0, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_x, west, a.sc_);
+                    sw[sj].x = xinv_bitsel(lw, v, sw[sj].x);
+                };
+                auto py = [&](unsigned lw) {
+                    const double v = M::template upd<1, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_y, west_y, a.sc_);
+                    sw[sj].y = xinv_bitsel(lw, v, sw[sj].y);
+                };
+                px(s9.ev[0]); if (s9.any_ev_y) py(s9.ev[1]);               // c0 / c2
+                if (s9.any_sm_x) px(s9.sm[0]);                             // c0' / c2': column xc-1 and its copies
+                if (s9.any_sm_y) py(s9.sm[1]);
+                if (s9.any_od_x) px(s9.od[0]);                             // c1 / c3
+                py(s9.od[1]);
+            }
+        };
+
         // one double step: even row r-1 sits in slot U, odd row r in slot U+1 (U even)
         auto step2 = [&](int64_t r, auto utag) {
             constexpr int U1 = decltype(utag)::value + 1;            // slot of row r
@@ -244,20 +304,14 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
                         if (je == yc - 2) fused_extend_fix(sw[sjp], sw[sj], lc, a.tall, u);
                     }
                     const bool rowok = (je >= 1) && (je <= yc - 2);
-                    double v = M::template upd<0, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_x, west, a.sc_);
-                    sw[sj].x = v;
-                    v = M::template upd<1, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_y, false, a.sc_);
-                    sw[sj].y = v;
+                    row_stage(sj, sjp, sjm, rowok);
                     tally(s - 1, je, sw[sj]);
                 }
                 {   // O_s: odd row jo = r-2s, colours c2 (.x) then c3 (.y)
                     const int64_t jo = r - 2 * s;
                     const int sj = SLOT(2 * s), sjp = SLOT(2 * s - 1), sjm = SLOT(2 * s + 1);
                     const bool rowok = (jo >= 1) && (jo <= yc - 2);
-                    double v = M::template upd<0, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_x, west, a.sc_);
-                    sw[sj].x = v;
-                    v = M::template upd<1, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_y, false, a.sc_);
-                    sw[sj].y = v;
+                    row_stage(sj, sjp, sjm, rowok);
                     tally(s - 1, jo, sw[sj]);
                 }
             }

@@ -180,22 +180,22 @@ static int plan_fused9(const Problem &p, const xinv_options &opt, Workspace *ws,
             } else {
                 int occ = 1;
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-                fused9_dispatch(p.kind, pl.K, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ);
+                fused9_dispatch(p.kind, pl.K, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ, pl.seam != 0);
                 // the 9-point kernels stream every coefficient array and sit at the fabric's bandwidth
                 // (6+ TB/s): halo re-reads cost more than occupancy gives, so one workgroup per CU
                 // (tall tiles) is the target -- measured +25 % (standard, K=1) / +21 % (general) at 2000x2000
                 pl.lone = 1.0;
-                pl.nrb = (int)choose_row_blocks(p.yc, cdiv(p.xc, 128 - 8 * pl.K), p.nbatch, pl.K, occ, pl.lone);
+                pl.nrb = (int)choose_row_blocks(p.yc, cdiv(p.xc, strip9_uw(pl, pl.K)), p.nbatch, pl.K, occ, pl.lone);
             }
             pl.even_split = true;
             pl.RY = (int)cdiv(p.yc, pl.nrb);
         }
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - 8 * XINV_KMAX) * pl.nrb, 4) + 1;
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, strip9_uw(pl, XINV_KMAX)) * pl.nrb, 4) + 1;
         if (pl.even_split && !(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
             int occ9 = 1;
             FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
-            fused9_dispatch(p.kind, pl.K, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ9);
-            rc = plan_tile_skip(p, pl, ws, st, opt, 0, 128 - 8 * pl.K, occ9);
+            fused9_dispatch(p.kind, pl.K, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ9, pl.seam != 0);
+            rc = plan_tile_skip(p, pl, ws, st, opt, 0, strip9_uw(pl, pl.K), occ9);
             if (rc) return rc;
         }
     return XINV_OK;
@@ -468,7 +468,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     //  spans at most three wraps of the row: xc >= 64; the 3-D, 9-point and biharmonic forms keep the colour launches)
     const bool seam5_ok = !pl.seam || p.xc >= 64;        // (3-D forms: the SEAM variants of k_fused3d / k_fused3dg)
     const bool fused5_ok = pl.base == 2 && seam5_ok && p.kind != KIND_BIH2D && p.kind != KIND_GEN3D;
-    const bool fused9_ok = pl.base == 4 && !pl.seam && p.c[1] &&
+    const bool fused9_ok = pl.base == 4 && seam5_ok && p.c[1] &&      // (seam: k_fused9's SEAM variants)
                            (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);
     // biharmonic: the one-pass kernel needs A..I as per-row scalars (and xc % 3 == 0 when periodic)
     bool fusedbih_ok = false;
@@ -493,7 +493,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     pl.nine = false;
     if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("no fused kernel for this form (odd-xc periodic seam with B != 0 or with xc < 64; 9-point test form; biharmonic or general 3-D with coefficients that vary along x)");
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam with xc < 64; 9-point test form; biharmonic or general 3-D with coefficients that vary along x)");
     if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 
@@ -594,7 +594,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
                            : (pl.path == XINV_PATH_FUSED && pl.pipe) ? strip_uw(pl, pl.K, true)
-                                                    : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K) - ((pl.seam && !pl.nine) ? 2 : 0);
+                                                    : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K) - (pl.seam ? 2 : 0);
     const int tpw = (pl.path == XINV_PATH_FUSED && pl.pipe) ? 1 : 4;
     const int64_t wg_member = pl.skip ? pl.ntl / tpw : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, tpw);
     // ... and only where a launch is one or two rounds of workgroups: with many rounds (64 Gill-Matsuno

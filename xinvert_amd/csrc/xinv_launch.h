@@ -175,10 +175,12 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
 }
 
 static int fused9_dispatch(int kind, int K, bool al, bool ext, dim3 grid, hipStream_t st,
-                           const FusedArgs &a, int *occ)
+                           const FusedArgs &a, int *occ, bool seam = false)
 {
-    return xinv_launch_fused9(kind == KIND_GEN2D, K, al, ext, grid, st, a, occ);
+    return xinv_launch_fused9(kind == KIND_GEN2D, K, al, ext, grid, st, a, occ, seam);
 }
+// columns a wavefront of the 9-point kernel owns (one halo column per colour and sweep; the seam variants one pair less)
+static inline int strip9_uw(const Plan &pl, int K) { return 128 - 8 * K - (pl.seam ? 2 : 0); }
 
 static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
                          Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
@@ -195,7 +197,7 @@ static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *
     a.ext = (p.BCy == XINV_BC_EXTEND);
     a.tall = (p.yc > p.xc);
     a.RY = pl.even_split ? 0 : pl.RY;
-    a.nstrip = (int)cdiv(p.xc, 128 - 8 * K);
+    a.nstrip = (int)cdiv(p.xc, strip9_uw(pl, K));
     a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
     a.nwg = (int)cdiv((int64_t)a.nstrip * a.nrb, 4);
     a.force = force; a.no_ctl = no_ctl;
@@ -216,7 +218,7 @@ static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *
         const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
         a.member0 = member0 + m0;
         dim3 grid((unsigned)a.nwg + (lag_tag ? 1u : 0u), (unsigned)nm, 1);
-        if (fused9_dispatch(p.kind, K, pl.aligned, a.ext != 0, grid, st, a, nullptr))
+        if (fused9_dispatch(p.kind, K, pl.aligned, a.ext != 0, grid, st, a, nullptr, pl.seam != 0))
             return fail_arg("unsupported sweeps_per_launch for the 9-point kernel");
     }
     HIPCHK(hipGetLastError());
