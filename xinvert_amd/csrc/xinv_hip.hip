@@ -693,11 +693,11 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         if (pl.skip) HIPCHK(hipMemcpyAsync(ws->S3, p.S, need, hipMemcpyDeviceToDevice, st));
         R.buf[2] = ws->S3; R.nbuf = 3;
     }
-    // Two lanes.  A launch of many rounds of workgroups ends in a tail: the last round fills a fraction of the CUs (C5, 15
-    // volumes: 2070 workgroups of k_pipe3d, one per CU, 8.09 rounds) and the next launch of the SAME members cannot start
-    // before it has drained.  The batch is cut in two halves whose launches form two independent chains on two streams
-    // (the engine's own one at the lowest priority, so that the chains do not march in step): the tail of one half's
-    // launch is filled by the other half's workgroups.  Control blocks are copied on a third stream behind both chains.
+    // Lanes.  Every launch boundary synchronises the chip: the last round of workgroups drains, the reducers
+    // wait for their last tile, and the next launch of the SAME members starts with every workgroup in the same phase.  The
+    // members are independent, so the batch is cut into halves whose launches form independent chains -- the caller's
+    // stream and the engine's own --; one chain's boundary is covered by the other's launch.  The control blocks are copied
+    // for the host on a third stream behind both chains; everything is joined back into the caller's stream below.
     static const int lanes_env = [] { const char *e = getenv("XINV_LANES"); return e ? atoi(e) : -1; }();
     int nlane = 1;
     if (!use_graph && !exp_noctl && pl.path == XINV_PATH_FUSED)
