@@ -865,7 +865,18 @@ def test_seeded_fuzz_medium_grids(chunk):
     """Larger seeded cases (hundreds of rows, several strips and row blocks, batches of two with a
     shared coefficient stack): automatic tiling, masked-tile skipping, k chunks and the x-uniform
     variants all engage on their own here."""
-    rng = np.random.default_rng(7000 + chunk)
+    _medium_fuzz(chunk, 7000, 0)
+
+
+@pytest.mark.parametrize('chunk', range(12))
+def test_seeded_fuzz_medium_grids_odd_widths(chunk):
+    """The same generator with ODD widths (the biharmonic form keeps multiples of three): with periodic x the seam
+    variants of every streaming kernel -- 5-point, 9-point, both 3-D forms -- chosen by the engine itself."""
+    _medium_fuzz(chunk, 9000, 1)
+
+
+def _medium_fuzz(chunk, seed0, odd):
+    rng = np.random.default_rng(seed0 + chunk)
     for case in range(4):
         kind = ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'][int(rng.integers(6))]
         BCy = ['fixed', 'extend'][int(rng.integers(2))]
@@ -873,7 +884,7 @@ def test_seeded_fuzz_medium_grids(chunk):
         seed = int(rng.integers(1 << 30))
         uni = int(rng.integers(2))
         if kind in ('std3d', 'gen3d'):
-            zc, yc, xc = int(rng.integers(20, 60)), int(rng.integers(30, 80)), 2 * int(rng.integers(60, 200))
+            zc, yc, xc = int(rng.integers(20, 60)), int(rng.integers(30, 80)), 2 * int(rng.integers(60, 200)) + odd
             mk = (lambda s: rand3d(zc, yc, xc, BCy, BCx, 1, seed=s)) if kind == 'std3d' else \
                  (lambda s: rand3dg(zc, yc, xc, BCy, BCx, 1, seed=s))
             un = (lambda q: _uniform3d(q, None)) if kind == 'std3d' else _uniform3dg
@@ -882,7 +893,7 @@ def test_seeded_fuzz_medium_grids(chunk):
             mk = lambda s: randbih(yc, xc, BCy, BCx, int(rng.integers(2)), 1, seed=s)
             un = _uniform_bih
         else:
-            yc, xc = int(rng.integers(100, 400)), 2 * int(rng.integers(100, 700))
+            yc, xc = int(rng.integers(100, 400)), 2 * int(rng.integers(100, 700)) + odd
             bnz = int(rng.integers(2))                 # 1: cross terms -> 4-colour kernels
             mk = (lambda s: rand2dt(yc, xc, BCy, BCx, bnz, 1, seed=s)) if kind == 'std2dt' else \
                  (lambda s: rand2d(kind, yc, xc, BCy, BCx, bnz, 1, seed=s))
