@@ -860,6 +860,25 @@ def test_seeded_fuzz_against_the_oracle(chunk):
             assert_same(S[0], fl[0], So, flo, what)
 
 
+@pytest.mark.parametrize('BCx', ['fixed', 'periodic'])
+@pytest.mark.parametrize('shape', [(123, 813), (242, 219), (60, 399)])
+def test_bih_extend_tolerance_stop_with_the_lagged_norm(shape, BCx):
+    """The one-pass biharmonic kernel's 'extend' pre-pass works in place on its launch's source buffer; with the lagged
+    norm the launch AFTER the one the stop rule fires in has already run and must not leave its pre-pass in the final
+    state (rows 0, 1, yc-2, yc-1; found by the extended medium fuzz, chunks 114 ... 248, at the end of round 4)."""
+    yc, xc = shape
+    ps = [_uniform_bih(randbih(yc, xc, 'extend', BCx, 0, 1, seed=_seed(('bihlag', shape, BCx, m)))) for m in range(2)]
+    stopped = []
+    for tol in (3e-3, 1e-2, 3e-2):
+        S, fl, st = run_hip_batched(ps, 60, tol)
+        assert st['path'] == PATH_FUSED, st
+        for m, q in enumerate(ps):
+            So, flo = run_oracle(q, 60, tol, COLOUR_AUTO)
+            assert_same(S[m], fl[m], So, flo, 'bih extend tol=%g %r member %d' % (tol, shape, m))
+            stopped.append(int(flo[2]))
+    assert min(stopped) < 60, stopped                    # (some case really stopped on the tolerance)
+
+
 @pytest.mark.parametrize('chunk', range(16))
 def test_seeded_fuzz_medium_grids(chunk):
     """Larger seeded cases (hundreds of rows, several strips and row blocks, batches of two with a

@@ -277,10 +277,12 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
 static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, double *dst,
                            Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
                            int no_ctl, unsigned lag_tag = 0, NormLagArgs *lag_out = nullptr,
-                           const NormLagArgs *lag_prev = nullptr)
+                           const NormLagArgs *lag_prev = nullptr, bool prepass = true)
 {
     const bool per = (p.BCx == XINV_BC_PERIODIC);
-    if (p.BCy == XINV_BC_EXTEND) {                   // the kernel's own pre-pass, on the source buffer
+    // (prepass = false: finalise() redoing a pass whose source already carries that pass's pre-pass -- the periodic
+    //  pre-pass, r0 <- r1 then r1 <- r2, is not idempotent)
+    if (p.BCy == XINV_BC_EXTEND && prepass) {        // the kernel's own pre-pass, on the source buffer
         ExtendArgs e;
         e.S = const_cast<double *>(src); e.sS = p.sS; e.yc = p.yc; e.xc = p.xc; e.kfirst = 0; e.nk = 1;
         e.per = per; e.tall = (p.yc > p.xc); e.force = force;
