@@ -894,7 +894,7 @@ def test_seeded_fuzz_medium_grids_odd_widths(chunk):
     _medium_fuzz(chunk, 9000, 1)
 
 
-def _medium_fuzz(chunk, seed0, odd):
+def _medium_fuzz(chunk, seed0, odd, every_case_stops=False):
     rng = np.random.default_rng(seed0 + chunk)
     for case in range(4):
         kind = ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'][int(rng.integers(6))]
@@ -933,7 +933,7 @@ def _medium_fuzz(chunk, seed0, odd):
         shared = tuple(range(len(ps[0]['coefs']) - 1))
         nsw = int(rng.integers(2, 8))
         tol = 0.0
-        if case == 3:                                 # one case per chunk stops on the tolerance (odd sweep
+        if case == 3 or every_case_stops:             # one case per chunk stops on the tolerance (odd sweep
             nsw, tol = 60, 3e-3                       # counts inside 2-sweep launches: the redo path)
         opt = {'force_tile_skip': 1} if kind in ('std2d', 'gen2d', 'std2dt', 'bih2d') and int(rng.integers(2)) else {}
         S, fl, st = run_hip_batched(ps, nsw, tol, shared=shared, **opt)
