@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Seeded fuzz of the sweep loop in lanes on a GPU box: batches of 2..24 members of every form, sizes
+that put the batch in lanes with and without the lagged norm, members that stop on the tolerance at different sweeps --
+every member against the oracle, bit for bit.   python tests/fuzz_lanes.py [first_seed] [count]   (XINV_LANES=n forces n)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import util                                                   # noqa: E402
+from oracle import COLOUR_AUTO                                # noqa: E402
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    kind = ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'][int(rng.integers(6))]
+    BCy = ['fixed', 'extend'][int(rng.integers(2))]
+    BCx = ['fixed', 'periodic'][int(rng.integers(2))]
+    nb = int(rng.integers(2, 25))
+    uni = int(rng.integers(2))
+    if kind in ('std3d', 'gen3d'):
+        zc, yc, xc = int(rng.integers(6, 20)), int(rng.integers(12, 60)), int(rng.integers(64, 400))
+        mk = (lambda s: util.rand3d(zc, yc, xc, BCy, BCx, 1, seed=s)) if kind == 'std3d' else \
+             (lambda s: util.rand3dg(zc, yc, xc, BCy, BCx, 1, seed=s))
+        ncu = 3 if kind == 'std3d' else 7
+        sh = (zc, yc, xc)
+    elif kind == 'bih2d':
+        yc, xc = int(rng.integers(30, 200)), 3 * int(rng.integers(30, 300))
+        mk = lambda s: util.randbih(yc, xc, BCy, BCx, int(seed & 1), 1, seed=s)
+        ncu = 9
+        sh = (yc, xc)
+    else:
+        yc, xc = int(rng.integers(40, 500)), int(rng.integers(64, 1500))
+        bnz = int(rng.integers(3) == 0)
+        mk = (lambda s: util.rand2dt(yc, xc, BCy, BCx, bnz, 1, seed=s)) if kind == 'std2dt' else \
+             (lambda s: util.rand2d(kind, yc, xc, BCy, BCx, bnz, 1, seed=s))
+        ncu = 0 if bnz else {'std2d': 3, 'gen2d': 6, 'std2dt': 5}[kind]   # coefficient arrays (the forcing is the last one)
+        sh = (yc, xc)
+    ps = [mk(seed * 100 + m) for m in range(nb)]
+    if uni and ncu:                                           # coefficients constant along x, one stack for the batch
+        c0 = [np.ascontiguousarray(np.broadcast_to(c[..., :1], c.shape)) for c in ps[0]['coefs'][:ncu]]
+        for q in ps:
+            q['coefs'][:ncu] = c0
+    for m, q in enumerate(ps):                                # forcings of different size: the members stop apart
+        F = q['coefs'][-1]
+        q['coefs'][-1] = np.where(F == q['undef'], q['undef'], F * 10.0 ** (-(m % 5)))
+    shared = tuple(range(ncu)) if (uni and ncu) else ()
+    mx, tol = int(rng.integers(8, 40)), float(10.0 ** rng.uniform(-4, -1.5))
+    S, fl, st = util.run_hip_batched(ps, mx, tol, shared=shared)
+    loops = []
+    for m, q in enumerate(ps):
+        So, flo = util.run_oracle(q, mx, tol, COLOUR_AUTO)
+        what = 'seed %d %s %r %s %s nb=%d uni=%d member %d lanes=%d path=%d' % (seed, kind, sh, BCy, BCx, nb, uni, m, st['lanes'], st['path'])
+        if np.isnan(So).any():
+            assert np.array_equal(S[m], So, equal_nan=True), what
+        else:
+            assert np.array_equal(S[m], So), what + ': %d points differ' % int((S[m] != So).sum())
+            assert fl[m][2] == flo[2] and fl[m][0] == flo[0], (what, fl[m], flo)
+        loops.append(int(flo[2]))
+    return st['lanes'], len(set(loops)) > 1
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    bad, laned, apart = 0, 0, 0
+    for seed in range(first, first + count):
+        try:
+            l, a = one(seed)
+            laned += l > 1; apart += a
+        except Exception as e:
+            bad += 1
+            print('FAIL', str(e)[:400])
+    print('lanes fuzz: seeds %d..%d, XINV_LANES=%s: %d in lanes, %d with members stopping apart, failures: %d'
+          % (first, first + count - 1, os.environ.get('XINV_LANES', 'auto'), laned, apart, bad))
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

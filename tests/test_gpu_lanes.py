@@ -20,3 +20,16 @@ def test_lanes_give_the_oracles_result(lanes):
     out = subprocess.run([sys.executable, os.path.join(HERE, 'lanes_case.py'), '0' if lanes == 'auto' else lanes],
                          capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0 and 'lanes ok' in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize('lanes', ['auto', '2', '3'])
+def test_lanes_fuzz(lanes):
+    """tests/fuzz_lanes.py: 40 seeded batches of 2..24 members of every form, members stopping on the tolerance at
+    different sweeps, every member against the oracle."""
+    env = dict(os.environ)
+    env.pop('XINV_LANES', None)
+    if lanes != 'auto':
+        env['XINV_LANES'] = lanes
+    out = subprocess.run([sys.executable, os.path.join(HERE, 'fuzz_lanes.py'), '1000', '40'],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0 and 'failures: 0' in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
