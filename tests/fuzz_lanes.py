@@ -48,33 +48,36 @@ def one(seed):
         q['coefs'][-1] = np.where(F == q['undef'], q['undef'], F * 10.0 ** (-(m % 5)))
     shared = tuple(range(ncu)) if (uni and ncu) else ()
     mx, tol = int(rng.integers(8, 40)), float(10.0 ** rng.uniform(-4, -1.5))
-    S, fl, st = util.run_hip_batched(ps, mx, tol, shared=shared)
+    # opt-in contracted arithmetic where a variant exists (per-row coefficients, 5-point / 7-point, no odd-width seam)
+    fma = int(bool(shared) and kind in ('std2d', 'gen2d', 'std3d') and not (BCx == 'periodic' and sh[-1] % 2) and rng.integers(2))
+    order = (2 | 0x100) if fma else COLOUR_AUTO
+    S, fl, st = util.run_hip_batched(ps, mx, tol, shared=shared, **(dict(fma=1) if fma else {}))
     loops = []
     for m, q in enumerate(ps):
-        So, flo = util.run_oracle(q, mx, tol, COLOUR_AUTO)
-        what = 'seed %d %s %r %s %s nb=%d uni=%d member %d lanes=%d path=%d' % (seed, kind, sh, BCy, BCx, nb, uni, m, st['lanes'], st['path'])
+        So, flo = util.run_oracle(q, mx, tol, order)
+        what = 'seed %d %s %r %s %s nb=%d uni=%d fma=%d member %d lanes=%d path=%d' % (seed, kind, sh, BCy, BCx, nb, uni, fma, m, st['lanes'], st['path'])
         if np.isnan(So).any():
             assert np.array_equal(S[m], So, equal_nan=True), what
         else:
             assert np.array_equal(S[m], So), what + ': %d points differ' % int((S[m] != So).sum())
             assert fl[m][2] == flo[2] and fl[m][0] == flo[0], (what, fl[m], flo)
         loops.append(int(flo[2]))
-    return st['lanes'], len(set(loops)) > 1
+    return st['lanes'], len(set(loops)) > 1, fma
 
 
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    bad, laned, apart = 0, 0, 0
+    bad, laned, apart, nfma = 0, 0, 0, 0
     for seed in range(first, first + count):
         try:
-            l, a = one(seed)
-            laned += l > 1; apart += a
+            l, a, f = one(seed)
+            laned += l > 1; apart += a; nfma += f
         except Exception as e:
             bad += 1
             print('FAIL', str(e)[:400])
-    print('lanes fuzz: seeds %d..%d, XINV_LANES=%s: %d in lanes, %d with members stopping apart, failures: %d'
-          % (first, first + count - 1, os.environ.get('XINV_LANES', 'auto'), laned, apart, bad))
+    print('lanes fuzz: seeds %d..%d, XINV_LANES=%s: %d in lanes, %d with members stopping apart, %d contracted, failures: %d'
+          % (first, first + count - 1, os.environ.get('XINV_LANES', 'auto'), laned, apart, nfma, bad))
     return 1 if bad else 0
 
 
