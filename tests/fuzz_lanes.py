@@ -51,7 +51,11 @@ def one(seed):
     # opt-in contracted arithmetic where a variant exists (per-row coefficients, 5-point / 7-point, no odd-width seam)
     fma = int(bool(shared) and kind in ('std2d', 'gen2d', 'std3d') and not (BCx == 'periodic' and sh[-1] % 2) and rng.integers(2))
     order = (2 | 0x100) if fma else COLOUR_AUTO
-    S, fl, st = util.run_hip_batched(ps, mx, tol, shared=shared, **(dict(fma=1) if fma else {}))
+    opt = dict(fma=1) if fma else {}
+    hc = int(rng.integers(4))                                 # host-pointer entry: upload / solve / download over member chunks
+    if hc:
+        opt['host_chunk'] = [0, 1, 3, 7][hc]
+    S, fl, st = util.run_hip_batched(ps, mx, tol, shared=shared, **opt)
     loops = []
     for m, q in enumerate(ps):
         So, flo = util.run_oracle(q, mx, tol, order)
