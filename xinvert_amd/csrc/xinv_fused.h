@@ -1271,6 +1271,19 @@ __global__ __launch_bounds__(256) void k_xuniform(XUniArgs a)
         const unsigned long long first = p[0];
         // (four loads in flight per lane: one wavefront walks a row, and the loop was a chain of memory round trips --
         //  53 us per solve for the two 52 MB coefficient arrays of a 3600x1800 lat-lon Poisson problem)
+        //  round 4: 47 us still -- a row of 3600 was fourteen dependent rounds of four 8-byte loads; 16-byte loads where
+        //  the row allows, eight in flight)
+        if (((a.xc & 1) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+            const ulonglong2 *p2 = reinterpret_cast<const ulonglong2 *>(p);
+            const int64_t n2 = a.xc >> 1;
+            for (int64_t i = lane; i < n2; i += 512) {
+                ulonglong2 v[8];
+#pragma unroll
+                for (int h = 0; h < 8; h++) v[h] = (i + 64 * h < n2) ? p2[i + 64 * h] : make_ulonglong2(first, first);
+#pragma unroll
+                for (int h = 0; h < 8; h++) bad |= (v[h].x != first) | (v[h].y != first);
+            }
+        } else
         for (int64_t i = lane; i < a.xc; i += 256) {
             unsigned long long v[4];
 #pragma unroll
