@@ -1232,6 +1232,29 @@ __global__ __launch_bounds__(64) void k_skip_norm_tile(SkipNormArgs a)
     if (lane == 0) { a.tsum[m * a.nskip_max + blockIdx.x] = acc; a.tcnt[m * a.nskip_max + blockIdx.x] = cnt; }
 }
 
+// The skipped tiles are never written by the sweep launches: every buffer S rotates through must hold the caller's S
+// there.  Copies the owned region of each skipped tile into one or two buffers (instead of two whole-array copies per
+// solve: 35 us of a 4.6 ms headline solve for a quarter of the tiles).
+__global__ __launch_bounds__(256) void k_copy_skipped(SkipNormArgs a, double *D1, double *D2)
+{
+    const int64_t m = blockIdx.y;
+    const int wt = a.skip_list[m * a.nskip_max + blockIdx.x];
+    if (wt < 0) return;
+    const TileRows tr = xinv_tile_rows(wt, a.nstrip, a.nrb, a.nsplit, a.yc, a.RB);
+    const int64_t c0 = (int64_t)tr.strip * a.UW;
+    const int64_t c1 = (c0 + a.UW < a.xc) ? c0 + a.UW : a.xc;
+    const double *S = a.S + m * a.sS;
+    D1 += m * a.sS;
+    if (D2) D2 += m * a.sS;
+    const int64_t w = c1 - c0;
+    for (int64_t t = threadIdx.x; t < (tr.y1 - tr.y0) * w; t += 256) {
+        const int64_t j = tr.y0 + t / w, i = c0 + t % w;
+        const double v = S[j * a.xc + i];
+        D1[j * a.xc + i] = v;
+        if (D2) D2[j * a.xc + i] = v;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_skip_norm_sum(SkipNormArgs a)
 {
     const int lane = threadIdx.x;

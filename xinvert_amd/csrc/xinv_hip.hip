@@ -618,8 +618,9 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         rc = ensure_dev(&ws->S2, &ws->S2_cap, need);
         if (rc) return rc;
         S2 = ws->S2;
-        if (pl.skip)            // skipped tiles are never written: both buffers start from the caller's S
-            HIPCHK(hipMemcpyAsync(S2, p.S, need, hipMemcpyDeviceToDevice, st));
+        if (pl.skip)            // skipped tiles are never written: every buffer starts from the caller's S there
+            hipLaunchKernelGGL(k_copy_skipped, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(256), 0, st,
+                               pl.skipna, S2, (double *)nullptr);
     }
 
     hipLaunchKernelGGL(k_ctl_init, dim3(cdiv(p.nbatch, 256)), dim3(256), 0, st, ws->ctl, p.nbatch);
@@ -691,7 +692,9 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         const size_t need = (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double);
         rc = ensure_dev(&ws->S3, &ws->S3_cap, need);
         if (rc) return rc;
-        if (pl.skip) HIPCHK(hipMemcpyAsync(ws->S3, p.S, need, hipMemcpyDeviceToDevice, st));
+        if (pl.skip)
+            hipLaunchKernelGGL(k_copy_skipped, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(256), 0, st,
+                               pl.skipna, ws->S3, (double *)nullptr);
         R.buf[2] = ws->S3; R.nbuf = 3;
     }
     // Lanes.  Every launch boundary synchronises the chip: the last round of workgroups drains, the reducers

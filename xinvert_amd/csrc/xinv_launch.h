@@ -24,6 +24,7 @@ struct Plan {
     bool even_split;         // rows split evenly over nrb row blocks (RY = average height)
     bool nine;               // 9-point form on the fused 4-colour kernel
     bool skip;               // masked-tile skipping: launches of K == Plan::K run the listed tiles only
+    SkipNormArgs skipna;     // (the skipped tiles' geometry and list: k_copy_skipped in run_sweeps)
     int ntl, nskip;          // list entries per member (active, multiple of 4 / skipped)
     int skip_pct;            // share of wave-tiles skipped, percent
     int skip_ppm;            // ... per million
@@ -704,6 +705,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     na.tcnt = (long long *)(base + nt * sizeof(double));
     na.xsum = (double *)(base + nt * (sizeof(double) + sizeof(long long)));
     na.xcnt = (long long *)(base + nt * (sizeof(double) + sizeof(long long)) + (size_t)nb * sizeof(double));
+    pl.skipna = na;
     hipLaunchKernelGGL(k_skip_norm_tile, dim3((unsigned)nskip, (unsigned)nb, 1), dim3(64), 0, st, na);
     hipLaunchKernelGGL(k_skip_norm_sum, dim3((unsigned)nb, 1, 1), dim3(64), 0, st, na);
     HIPCHK(hipGetLastError());

@@ -16,10 +16,14 @@ template <class M, int K, bool AL, unsigned UM, bool EXT>
 static int fused_one(dim3 grid, dim3 block, hipStream_t st, const FusedArgs &a, int *occ)
 {
     if (occ) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused2d<M, K, AL, UM, EXT, 0, SEAM>, 256, 0) != hipSuccess)
-            n = 1;
-        *occ = n < 1 ? 1 : n;
+        static int cached = 0;                           // (asked by the planner in every solve: a few microseconds per query)
+        int n = cached;
+        if (!n) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused2d<M, K, AL, UM, EXT, 0, SEAM>, 256, 0) != hipSuccess)
+                n = 1;
+            cached = n = n < 1 ? 1 : n;
+        }
+        *occ = n;
         return 0;
     }
     hipLaunchKernelGGL((k_fused2d<M, K, AL, UM, EXT, 0, SEAM>), grid, block, 0, st, a);

@@ -12,10 +12,14 @@ template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT>
 static int pipe_one(dim3 grid, hipStream_t st, const FusedArgs &a, int *occ, int lds_pad)
 {
     if (occ) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_pipe2d<M, UM, FR, NP, AL, EXT, SEAM>, 64 * XINV_PIPE_P, 0) != hipSuccess)
-            n = 1;
-        *occ = n < 1 ? 1 : n;
+        static int cached = 0;                           // (asked by the planner in every solve: a few microseconds per query)
+        int n = cached;
+        if (!n) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_pipe2d<M, UM, FR, NP, AL, EXT, SEAM>, 64 * XINV_PIPE_P, 0) != hipSuccess)
+                n = 1;
+            cached = n = n < 1 ? 1 : n;
+        }
+        *occ = n;
         return 0;
     }
     hipLaunchKernelGGL((k_pipe2d<M, UM, FR, NP, AL, EXT, SEAM>), grid, dim3(64 * XINV_PIPE_P, 1, 1), (size_t)lds_pad, st, a);
