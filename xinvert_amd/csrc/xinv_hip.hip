@@ -312,7 +312,19 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                 arr[q] = p.c[sidx]; strd[q] = p.sc[sidx];
             }
             pl.umask = 0;
+            ws->act_ready = false;
             if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
+                // (the activity map plan_tile_skip will ask for, with the pipelined pass's strips -- what a lat-lon problem
+                //  of this size gets --, rides the same host round trip as the detection's flags)
+                if (p.kind != KIND_STD2DT && opt.rows_per_tile == 0 && opt.sweeps_per_launch == 0 &&
+                    !(opt.flags & (XINV_FLAG_NO_TILE_SKIP | XINV_FLAG_NO_PIPE)) && p.nbatch <= 64 &&
+                    p.nbatch * p.yc * p.xc >= (int64_t)2000000) {
+                    const int uw_pipe = XINV_PIPE_UW(1) - (pl.seam ? 2 : 0);      // (one column pair per lane: what ships)
+                    if (p.xc >= uw_pipe && p.nbatch * cdiv(p.xc, uw_pipe) * (p.yc + 1) <= (int64_t)50000000) {
+                        rc = issue_strip_active(p, ws, st, uw_pipe, p.kind == KIND_STD2D ? 3 : 6);
+                        if (rc) return rc;
+                    }
+                }
                 rc = detect_xuniform(ws, st, arr, strd, ns, p.nbatch, p.yc, p.xc, &pl.umask);
                 if (rc) return rc;
             }
@@ -460,6 +472,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
 // which path, then the tiling of its kernel family
 static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, hipStream_t st, Plan &pl)
 {
+    ws->act_ready = false;                               // (an activity map issued ahead belongs to ONE plan: issue_strip_active)
     const int64_t n = p.zc * p.yc * p.xc;
     int rc = XINV_OK;
     (void)n; (void)rc;

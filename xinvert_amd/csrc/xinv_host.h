@@ -225,6 +225,7 @@ struct Workspace {
     unsigned char *h_act = nullptr; size_t h_act_cap = 0;      // pinned
     int *d_list = nullptr; size_t d_list_cap = 0;               // [nbatch][ntl] then [nbatch][nskip]
     int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
+    bool act_ready = false; int act_uw = 0; const double *act_f = nullptr;   // activity map issued ahead (issue_strip_active)
     std::vector<int> h_pre;                                     // plan_tile_skip: prefix counts (kept: no allocation per solve)
     double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
     void *d_rowf = nullptr; size_t d_rowf_cap = 0;              // k_pipe2d: per-row records [nbatch][yc][PIPE_RW]

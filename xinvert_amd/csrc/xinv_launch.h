@@ -548,6 +548,30 @@ static double tile_cost(int64_t wgs, int64_t rows, int K, int occ, double lone =
 // is computed once.  Decided per solve from one pass over the forcing.
 // `fixedRB` > 0 (biharmonic one-pass kernel): tiles are row blocks of exactly fixedRB rows x `UW_` owned
 // columns and the split is kept; 0: the 5-point kernels' even split, re-planned for the active tiles.
+// The activity map of the forcing for strips of UW owned columns: kernel + copy to the host, NOT synchronised.  The planner
+// of the lat-lon forms issues it ahead of the x-uniform detection with the strip width those forms end up with, so that
+// ONE host round trip brings both answers (25 us of a 4.6 ms headline solve); plan_tile_skip issues it itself otherwise.
+static int issue_strip_active(const Problem &p, Workspace *ws, hipStream_t st, int UW, int fi)
+{
+    const int64_t yc = p.yc, nb = p.nbatch;
+    const int nstrip = (int)cdiv(p.xc, UW);
+    const int64_t cells = yc * nstrip;
+    int rc = ensure_dev(&ws->d_act, &ws->d_act_cap, (size_t)(nb * cells));
+    if (rc) return rc;
+    if (ws->h_act_cap < (size_t)(nb * cells)) {
+        if (ws->h_act) HIPCHK(hipHostFree(ws->h_act));
+        HIPCHK(hipHostMalloc((void **)&ws->h_act, (size_t)(nb * cells), hipHostMallocDefault));
+        ws->h_act_cap = (size_t)(nb * cells);
+    }
+    StripActArgs sa;
+    sa.f = p.c[fi]; sa.sf = p.sc[fi]; sa.yc = yc; sa.xc = p.xc; sa.nstrip = nstrip; sa.UW = UW;
+    sa.undef = p.sc_.undef; sa.act = ws->d_act;
+    hipLaunchKernelGGL(k_strip_active, dim3(cdiv(cells, 4), (unsigned)nb, 1), dim3(256), 0, st, sa);
+    HIPCHK(hipMemcpyAsync(ws->h_act, ws->d_act, (size_t)(nb * cells), hipMemcpyDeviceToHost, st));
+    ws->act_ready = true; ws->act_uw = UW; ws->act_f = p.c[fi];
+    return XINV_OK;
+}
+
 static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t st,
                           const xinv_options &opt, int fixedRB = 0, int UW_ = 0, int occ_ = 0)
 {
@@ -565,19 +589,13 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     if (nb * nstrip * (yc + 1) > (int64_t)50000000) return XINV_OK;   // host-side prefix table would exceed 200 MB
     const int fi = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_GEN2D ? 6 : (p.kind == KIND_BIH2D ? 9 : 5));   // the forcing
 
-    int rc = ensure_dev(&ws->d_act, &ws->d_act_cap, (size_t)(nb * cells));
-    if (rc) return rc;
-    if (ws->h_act_cap < (size_t)(nb * cells)) {
-        if (ws->h_act) HIPCHK(hipHostFree(ws->h_act));
-        HIPCHK(hipHostMalloc((void **)&ws->h_act, (size_t)(nb * cells), hipHostMallocDefault));
-        ws->h_act_cap = (size_t)(nb * cells);
+    int rc = XINV_OK;
+    if (!(ws->act_ready && ws->act_uw == UW && ws->act_f == p.c[fi])) {     // (not already there: issue_strip_active below)
+        rc = issue_strip_active(p, ws, st, UW, fi);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(st));
     }
-    StripActArgs sa;
-    sa.f = p.c[fi]; sa.sf = p.sc[fi]; sa.yc = yc; sa.xc = p.xc; sa.nstrip = nstrip; sa.UW = UW;
-    sa.undef = p.sc_.undef; sa.act = ws->d_act;
-    hipLaunchKernelGGL(k_strip_active, dim3(cdiv(cells, 4), (unsigned)nb, 1), dim3(256), 0, st, sa);
-    HIPCHK(hipMemcpyAsync(ws->h_act, ws->d_act, (size_t)(nb * cells), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    ws->act_ready = false;
 
     // prefix counts of active rows per (member, strip), laid out [member][row][strip]: building them and looking up the
     // two rows of a row block for every strip both run along contiguous memory (this planning is host time inside every
