@@ -631,9 +631,6 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         rc = ensure_dev(&ws->S2, &ws->S2_cap, need);
         if (rc) return rc;
         S2 = ws->S2;
-        if (pl.skip)            // skipped tiles are never written: every buffer starts from the caller's S there
-            hipLaunchKernelGGL(k_copy_skipped, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(256), 0, st,
-                               pl.skipna, S2, (double *)nullptr);
     }
 
     hipLaunchKernelGGL(k_ctl_init, dim3(cdiv(p.nbatch, 256)), dim3(256), 0, st, ws->ctl, p.nbatch);
@@ -705,11 +702,37 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         const size_t need = (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double);
         rc = ensure_dev(&ws->S3, &ws->S3_cap, need);
         if (rc) return rc;
-        if (pl.skip)
-            hipLaunchKernelGGL(k_copy_skipped, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(256), 0, st,
-                               pl.skipna, ws->S3, (double *)nullptr);
         R.buf[2] = ws->S3; R.nbuf = 3;
     }
+    // Masked-tile skipping: the skipped tiles' constant share of the norm, and their copy into every buffer S rotates
+    // through (they are never written by the sweep launches).  Nobody needs either before the SECOND launch when the norm
+    // is lagged -- launch 0 reads the caller's S and writes the active tiles of S2, its norm is evaluated in launch 1 --
+    // so for one slice (one chain) the four small kernels (~40 us) run on a side stream beside launch 0.
+    bool side_pending = false;
+    struct SideGuard { Workspace *w; bool *pending; ~SideGuard() { if (*pending) (void)hipStreamSynchronize(w->s_side); } } side_guard{ws, &side_pending};
+    if (pl.path == XINV_PATH_FUSED && pl.skip) {
+        hipStream_t sk = st;
+        if (lag && p.nbatch == 1) {
+            if (!ws->s_side) {
+                HIPCHK(hipStreamCreateWithFlags(&ws->s_side, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ws->ev_side0, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ws->ev_side1, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(ws->ev_side0, st));    // (behind the planner's uploads and the workspace set-up)
+            HIPCHK(hipStreamWaitEvent(ws->s_side, ws->ev_side0, 0));
+            sk = ws->s_side;
+        }
+        hipLaunchKernelGGL(k_skip_norm_tile, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(64), 0, sk, pl.skipna);
+        hipLaunchKernelGGL(k_skip_norm_sum, dim3((unsigned)p.nbatch, 1, 1), dim3(64), 0, sk, pl.skipna);
+        hipLaunchKernelGGL(k_copy_skipped, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(256), 0, sk,
+                           pl.skipna, S2, lag ? ws->S3 : (double *)nullptr);
+        HIPCHK(hipGetLastError());
+        if (sk != st) { HIPCHK(hipEventRecord(ws->ev_side1, sk)); side_pending = true; }
+    }
+    auto side_join = [&]() -> int {                      // before the first reader: launch 1, or a chunk's closing reduction
+        if (side_pending) { HIPCHK(hipStreamWaitEvent(st, ws->ev_side1, 0)); side_pending = false; }
+        return XINV_OK;
+    };
     // Lanes.  Every launch boundary synchronises the chip: the last round of workgroups drains, the reducers
     // wait for their last tile, and the next launch of the SAME members starts with every workgroup in the same phase.  The
     // members are independent, so the batch is cut into halves whose launches form independent chains -- the caller's
@@ -773,6 +796,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
 #endif
         const double *src = buf[i % R.nbuf];
         double *dst = buf[(i + 1) % R.nbuf];
+        if (i >= 1) { const int r = side_join(); if (r) return r; }
         if (exp_noctl == 2)                              // (timing experiment: publish only, nobody reduces)
             return launch_fused(p, pl, k, src, dst, ws, st, 0, p.nbatch, 1, 0, (unsigned)(i + 1), nullptr);
         if (!lag && !two) return launch_planned(p, pl, ws, st, k, src, dst, 0, p.nbatch, exp_noctl, exp_noctl);
@@ -795,6 +819,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // before the control blocks are copied for the host
     auto flush_lag = [&]() -> int {
         if (!lag) return XINV_OK;
+        { const int r = side_join(); if (r) return r; }
         for (int l = 0; l < nlane; l++) {
             if (!lag_pending[l].tag) continue;
             const int64_t mend = lane_first(l + 1);

@@ -217,6 +217,7 @@ struct Workspace {
     int *hflag = nullptr;
     hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
     hipStream_t gstream = nullptr;                      // capture stream for the small-problem hipGraph
+    hipStream_t s_side = nullptr; hipEvent_t ev_side0 = nullptr, ev_side1 = nullptr;   // skipped tiles' work beside the first sweep launch
     hipStream_t s_lane[XINV_MAX_LANES] = {}, s_poll = nullptr;   // sweep loop in lanes: lanes 1.. of the batch; the control-block copies
     hipEvent_t ev_lane[XINV_MAX_LANES][2] = {}, ev_s = nullptr;  // [0]: the caller's stream
     hipStream_t s_up = nullptr, s_down = nullptr, s_compute = nullptr;   // host-pointer entries: copy / sweep overlap

@@ -723,10 +723,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     na.tcnt = (long long *)(base + nt * sizeof(double));
     na.xsum = (double *)(base + nt * (sizeof(double) + sizeof(long long)));
     na.xcnt = (long long *)(base + nt * (sizeof(double) + sizeof(long long)) + (size_t)nb * sizeof(double));
-    pl.skipna = na;
-    hipLaunchKernelGGL(k_skip_norm_tile, dim3((unsigned)nskip, (unsigned)nb, 1), dim3(64), 0, st, na);
-    hipLaunchKernelGGL(k_skip_norm_sum, dim3((unsigned)nb, 1, 1), dim3(64), 0, st, na);
-    HIPCHK(hipGetLastError());
+    pl.skipna = na;                                      // (the skipped tiles' norm share and their copies: run_sweeps)
 
     pl.skip = true; pl.ntl = ntl; pl.nskip = nskip;
     pl.skip_pct = (int)((100 * nskipped) / (ntiles * nb));
