@@ -74,7 +74,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=8)        # (untimed; 3 left the first box-fresh steps in the timed region: 6.6 / 6.9 / 7.0 against 7.0 / 6.9 / 7.1e11 with 20)
     ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c5'])
     ap.add_argument('--sweeps', type=int, default=0, help='SOR sweeps per step (0: SURVEY.md 8(d): 500 for c2/c4, 200 for c5)')
     ap.add_argument('--spl', type=int, default=0, help='sweeps fused per launch (0 = engine default)')
