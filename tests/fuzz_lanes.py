@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Seeded fuzz of the sweep loop in lanes on a GPU box: batches of 2..24 members of every form, sizes
 that put the batch in lanes with and without the lagged norm, members that stop on the tolerance at different sweeps --
-every member against the oracle, bit for bit.   python tests/fuzz_lanes.py [first_seed] [count]   (XINV_LANES=n forces n)"""
+every member against the oracle, bit for bit.   python tests/fuzz_lanes.py [first_seed] [count] [--single]   (XINV_LANES=n forces n)"""
 import os
 import sys
 
@@ -13,12 +13,16 @@ import util                                                   # noqa: E402
 from oracle import COLOUR_AUTO                                # noqa: E402
 
 
+SINGLE = '--single' in sys.argv      # one member, 2-D forms, masked-tile lists forced, grids large enough for the lagged norm:
+                                     # the single-chain paths (skipped tiles' work on the side stream, three buffers)
+
+
 def one(seed):
     rng = np.random.default_rng(seed)
-    kind = ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'][int(rng.integers(6))]
+    kind = ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'][int(rng.integers(4 if SINGLE else 6))]
     BCy = ['fixed', 'extend'][int(rng.integers(2))]
     BCx = ['fixed', 'periodic'][int(rng.integers(2))]
-    nb = int(rng.integers(2, 25))
+    nb = 1 if SINGLE else int(rng.integers(1, 25))            # (one member: the single-chain paths, side stream included)
     uni = int(rng.integers(2))
     if kind in ('std3d', 'gen3d'):
         zc, yc, xc = int(rng.integers(6, 20)), int(rng.integers(12, 60)), int(rng.integers(64, 400))
@@ -33,6 +37,8 @@ def one(seed):
         sh = (yc, xc)
     else:
         yc, xc = int(rng.integers(40, 500)), int(rng.integers(64, 1500))
+        if SINGLE:
+            yc, xc = int(rng.integers(300, 900)), int(rng.integers(900, 2400))
         bnz = int(rng.integers(3) == 0)
         mk = (lambda s: util.rand2dt(yc, xc, BCy, BCx, bnz, 1, seed=s)) if kind == 'std2dt' else \
              (lambda s: util.rand2d(kind, yc, xc, BCy, BCx, bnz, 1, seed=s))
@@ -43,6 +49,11 @@ def one(seed):
         c0 = [np.ascontiguousarray(np.broadcast_to(c[..., :1], c.shape)) for c in ps[0]['coefs'][:ncu]]
         for q in ps:
             q['coefs'][:ncu] = c0
+    if SINGLE:                                                # blank blocks of the forcing: whole tiles to skip
+        F = ps[0]['coefs'][-1]
+        for _ in range(4):
+            j0, i0 = int(rng.integers(0, sh[0] // 2)), int(rng.integers(0, sh[1] // 2))
+            F[j0:j0 + sh[0] // 3, i0:i0 + sh[1] // 3] = ps[0]['undef']
     for m, q in enumerate(ps):                                # forcings of different size: the members stop apart
         F = q['coefs'][-1]
         q['coefs'][-1] = np.where(F == q['undef'], q['undef'], F * 10.0 ** (-(m % 5)))
@@ -55,6 +66,8 @@ def one(seed):
     hc = int(rng.integers(4))                                 # host-pointer entry: upload / solve / download over member chunks
     if hc:
         opt['host_chunk'] = [0, 1, 3, 7][hc]
+    if kind in ('std2d', 'gen2d', 'std2dt', 'bih2d') and (SINGLE or int(rng.integers(2))):
+        opt['force_tile_skip'] = 1                            # masked-tile lists whatever the size
     S, fl, st = util.run_hip_batched(ps, mx, tol, shared=shared, **opt)
     loops = []
     for m, q in enumerate(ps):
@@ -66,22 +79,23 @@ def one(seed):
             assert np.array_equal(S[m], So), what + ': %d points differ' % int((S[m] != So).sum())
             assert fl[m][2] == flo[2] and fl[m][0] == flo[0], (what, fl[m], flo)
         loops.append(int(flo[2]))
-    return st['lanes'], len(set(loops)) > 1, fma
+    return st['lanes'], len(set(loops)) > 1, fma, st['masked_tile_pct'] > 0
 
 
 def main():
-    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    bad, laned, apart, nfma = 0, 0, 0, 0
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    first = int(args[0]) if len(args) > 0 else 0
+    count = int(args[1]) if len(args) > 1 else 100
+    bad, laned, apart, nfma, nskip = 0, 0, 0, 0, 0
     for seed in range(first, first + count):
         try:
-            l, a, f = one(seed)
-            laned += l > 1; apart += a; nfma += f
+            l, a, f, sk = one(seed)
+            laned += l > 1; apart += a; nfma += f; nskip += sk
         except Exception as e:
             bad += 1
             print('FAIL', str(e)[:400])
-    print('lanes fuzz: seeds %d..%d, XINV_LANES=%s: %d in lanes, %d with members stopping apart, %d contracted, failures: %d'
-          % (first, first + count - 1, os.environ.get('XINV_LANES', 'auto'), laned, apart, nfma, bad))
+    print('lanes fuzz: seeds %d..%d%s, XINV_LANES=%s: %d in lanes, %d with members stopping apart, %d contracted, %d with skipped tiles, failures: %d'
+          % (first, first + count - 1, ' (single member)' if SINGLE else '', os.environ.get('XINV_LANES', 'auto'), laned, apart, nfma, nskip, bad))
     return 1 if bad else 0
 
 

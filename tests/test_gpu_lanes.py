@@ -33,3 +33,15 @@ def test_lanes_fuzz(lanes):
     out = subprocess.run([sys.executable, os.path.join(HERE, 'fuzz_lanes.py'), '1000', '40'],
                          capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0 and 'failures: 0' in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
+
+
+def test_single_member_fuzz_with_skipped_tiles():
+    """tests/fuzz_lanes.py --single: one member, blocks of the forcing blanked (masked-tile lists), grids large enough for
+    the lagged norm -- three buffers, the skipped tiles' norm share and copies on the side stream beside the first launch,
+    tolerance stops -- against the oracle."""
+    env = dict(os.environ)
+    env.pop('XINV_LANES', None)
+    out = subprocess.run([sys.executable, os.path.join(HERE, 'fuzz_lanes.py'), '60000', '40', '--single'],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0 and 'failures: 0' in out.stdout and ' 0 with skipped tiles' not in out.stdout, \
+        (out.stdout[-3000:], out.stderr[-3000:])
