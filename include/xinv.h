@@ -111,6 +111,15 @@ typedef struct xinv_options {
     double  demask_value;       /* XINV_PREP_DEMASK: written to S where the forcing is masked         */
     const double *prep_rowscale;/* XINV_PREP_ROWSCALE: [yc] host doubles, defined forcing values of
                                    row j (of every plane / member) are multiplied by prep_rowscale[j] */
+    /* Expert overrides of the planner's own choices (0 = the planner decides).  The library reads NO environment
+       variable: what used to be XINV_LANES / XINV_LAG / XINV_PIPE_FR / XINV_GRAPH in rounds 2-4 are these fields.  */
+    int32_t lanes;              /* device entries: independent launch chains the batch is cut into (n > 0: exactly
+                                   min(n, nbatch, 4) chains; 1 = one chain)                                          */
+    int32_t norm_lag;           /* 2-D streaming kernels: -1 = the launch's own last workgroup reduces the norm
+                                   (no third S buffer); 1 / 0 = evaluated one pass behind where the planner sees a gain  */
+    int32_t pipe_fr;            /* wave-pipelined pass: the forcing rides the LDS ring (1) or is read by every
+                                   wavefront (-1); 0 = by the size of the launch's streams                           */
+    int32_t graph;              /* colour path: replay chunks of launches from a hipGraph (1) or launch one by one (-1) */
 } xinv_options;
 
 #define XINV_PREP_MASK_NAN   1  /* the forcing (last coefficient array) marks masked points with NaN   */
@@ -145,6 +154,13 @@ typedef struct xinv_stats {
     int32_t lanes;              /* device entries: independent launch chains the batch was cut into (1 or 2; each
                                    `sweep_launches` pass is then one kernel launch per lane, on its own stream, and
                                    kernel durations in a trace overlap)                                              */
+    int32_t planned;            /* 1: the solve ran on a resident plan (xinv_plan_*): no detection / planning pass      */
+    int32_t pad_;
+    double  plan_ms;            /* wall clock of the planning part of the call (detection passes, host round trips,
+                                   tile lists, per-row records); ~0 for a solve on a resident plan                    */
+    double  launch_us_min, launch_us_avg, launch_us_max;   /* timing = 2: every sweep launch bracketed by its own pair
+                                   of HIP events on the stream it runs on (one lane only): per-launch durations without
+                                   a profiler's per-dispatch overhead                                                  */
 } xinv_stats;
 
 void        xinv_default_options(xinv_options *opt);
@@ -239,7 +255,8 @@ int xinv_standard_3d_f64_dev(double *S, const double *A, const double *B, const 
 
 /* ---- general 3-D form (3DOcean), SURVEY 8(f) rank 4 -----------------------------------------
  * xinv_general_3d_f64 replaces numbas.invert_general_3D called at core.py:345-356.
- * strides[]: S,A,B,C,D,E,F,G,H.  7-point stencil, red-black on (k+j+i)&1; colour-pass kernels.
+ * strides[]: S,A,B,C,D,E,F,G,H.  7-point stencil, red-black on (k+j+i)&1; streaming kernel k_fused3dg when A..G are
+ * constant along x (every 3DOcean coefficient), colour-pass kernels otherwise.
  * The reference's west-periodic branch never tests the forcing H against undef
  * (numbas.py:849-852) -- kept.  BCz is accepted and never read. */
 int xinv_general_3d_f64(double *S, const double *A, const double *B, const double *C,
@@ -271,7 +288,8 @@ int xinv_general_3d_f64_dev(double *S, const double *A, const double *B, const d
 /* ---- biharmonic 2-D form (Munk / Stommel-Munk), SURVEY 8(f) rank 1 ----------------------------
  * xinv_general_bih_2d_f64 replaces numbas.invert_general_bih_2D called at core.py:503-516.
  * strides[]: S,A,B,C,D,E,F,G,H,I,J.  Radius-2 stencil, 9 colours (j%3, i%3) (+3 per trailing
- * column when x is periodic and xc % 3 != 0); colour-pass kernels; yc >= 5, xc >= 7.  The
+ * column when x is periodic and xc % 3 != 0); one-pass streaming kernel k_fusedbih when A..I are constant along x,
+ * one launch per row class otherwise (colour launches for periodic x with xc % 3 != 0); yc >= 5, xc >= 7.  The
  * reference's east-periodic branches index the B term with a stale loop variable
  * (numbas.py:1495-1497, 1540-1542); that behaviour is reproduced. */
 int xinv_general_bih_2d_f64(double *S, const double *A, const double *B, const double *C,
@@ -327,6 +345,79 @@ int xinv_standard_2d_test_f64_dev(double *S, const double *A, const double *B, c
                                   double ratioQtr, double ratioSqr, double optArg, double undef,
                                   double *flags, int64_t mxLoop, double tolerance,
                                   const xinv_options *opt, void *stream);
+
+/* ---- resident plans: what a solve derives from the coefficient stack, built once -------------------------------
+ * The reference calls its kernel again and again on ONE coefficient stack: apps.animate_iteration (apps.py:1031-1044:
+ * `invt_func(*coeffs, maskF, initS, dims, iParams)` once per frame, tests/test_AnimateConverge.py:13-31: 40 frames of
+ * 2 sweeps on 73x144), the restart of an un-converged solve, another first guess.  Every call of the *_dev entries above
+ * re-derives what depends on that stack alone -- is B zero, which arrays are constant along x, the per-row records
+ * (coefficients, relaxation factor, row predicate), the forcing's activity map, the row split and the lists of tiles
+ * that hold a defined point: passes over the arrays, host round trips and host planning, ~0.26 ms of a 4.8 ms solve at
+ * 3600x1800 and most of a two-sweep frame.  A plan holds all of it in HBM, next to the coefficient stack it describes.
+ *
+ * xinv_plan_create_<form>_f64_dev: the arguments of xinv_<form>_f64_dev without S, flags, mxLoop and tolerance (DEVICE
+ *   pointers; strides[0] = batch stride of the S arrays the plan will be solved on); `opt` as for the *_dev entries
+ *   (device, path, sweeps_per_launch, rows_per_tile, flags, timing, lanes, ...), and additionally opt->rowconst_mask:
+ *   bit q set = coefficient array q holds ONE value per row ([rows] per member, rows = yc or zc*yc, batch stride 0 or
+ *   exactly rows) -- lat-lon coefficients are functions of latitude (apps.py:1406-1408, 1630-1635) --, which the plan
+ *   expands into HBM copies of its own (the caller's row vectors are not referenced after the call returns) and never
+ *   has to test for uniformity.  Synchronous: returns with the plan complete.
+ * xinv_plan_solve_f64_dev: one call of the hot path on the plan -- S (device pointer, read and written in place, 16-byte
+ *   aligned), flags (host, [nbatch*3], caller-initialised), mxLoop, tolerance, on `stream` --, bit for bit what
+ *   xinv_<form>_f64_dev returns for the same arrays.  Returns after the solve has completed; xinv_last_stats() has
+ *   planned = 1.  Solves on one device are serialised (per-device lock), whatever thread or plan they come from.
+ * CONTRACT while a plan lives: the coefficient arrays it was created on stay allocated and UNCHANGED -- values of the
+ *   forcing may change as long as its set of undefined points does not (the plan's tile lists leave out tiles whose
+ *   forcing is undefined throughout).  After any other change call xinv_plan_refresh (re-derives everything in place,
+ *   synchronous) or create a new plan.  S is not part of the plan: any S of the planned shape and stride may be solved.
+ * xinv_plan_destroy frees the plan's device memory (NULL is accepted). */
+typedef struct xinv_plan xinv_plan;
+
+int xinv_plan_create_standard_2d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                         const double *F, int64_t nbatch, const int64_t *strides, int64_t yc,
+                                         int64_t xc, double dely, double delx, int BCy, int BCx, double delxSqr,
+                                         double ratioQtr, double ratioSqr, double optArg, double undef,
+                                         const xinv_options *opt, void *stream);
+
+int xinv_plan_create_general_2d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                        const double *D, const double *E, const double *F, const double *G,
+                                        int64_t nbatch, const int64_t *strides, int64_t yc, int64_t xc, double dely,
+                                        double delx, int BCy, int BCx, double delxSqr, double ratio, double ratioQtr,
+                                        double ratioSqr, double optArg, double undef, const xinv_options *opt,
+                                        void *stream);
+
+int xinv_plan_create_standard_3d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                         const double *F, int64_t nbatch, const int64_t *strides, int64_t zc,
+                                         int64_t yc, int64_t xc, double delz, double dely, double delx, int BCz,
+                                         int BCy, int BCx, double delxSqr, double ratio2Sqr, double ratio1Sqr,
+                                         double optArg, double undef, const xinv_options *opt, void *stream);
+
+int xinv_plan_create_general_3d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                        const double *D, const double *E, const double *F, const double *G,
+                                        const double *H, int64_t nbatch, const int64_t *strides, int64_t zc,
+                                        int64_t yc, int64_t xc, double delz, double dely, double delx, int BCz,
+                                        int BCy, int BCx, double delxSqr, double ratio2, double ratio1,
+                                        double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                                        const xinv_options *opt, void *stream);
+
+int xinv_plan_create_general_bih_2d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                            const double *D, const double *E, const double *F, const double *G,
+                                            const double *H, const double *I, const double *J, int64_t nbatch,
+                                            const int64_t *strides, int64_t yc, int64_t xc, double dely, double delx,
+                                            int BCy, int BCx, double delxSSr, double delxTr, double delxSqr,
+                                            double ratio, double ratioSSr, double ratioQtr, double ratioSqr,
+                                            double optArg, double undef, const xinv_options *opt, void *stream);
+
+int xinv_plan_create_standard_2d_test_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                              const double *D, const double *E, const double *F, int64_t nbatch,
+                                              const int64_t *strides, int64_t yc, int64_t xc, double dely,
+                                              double delx, int BCy, int BCx, double delxSqr, double ratioQtr,
+                                              double ratioSqr, double optArg, double undef, const xinv_options *opt,
+                                              void *stream);
+
+int xinv_plan_solve_f64_dev(xinv_plan *plan, double *S, double *flags, int64_t mxLoop, double tolerance, void *stream);
+int xinv_plan_refresh(xinv_plan *plan, void *stream);
+int xinv_plan_destroy(xinv_plan *plan);
 
 /* ---- Gill-Matsuno winds from the inverted mass field, SURVEY 8(f) rank 3 -----------------------
  * replaces apps.cal_flow(vtype='GillMatsuno') (apps.py:1277-1317) for device-resident fields, so

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Seeded fuzz of the sweep loop in lanes on a GPU box: batches of 2..24 members of every form, sizes
 that put the batch in lanes with and without the lagged norm, members that stop on the tolerance at different sweeps --
-every member against the oracle, bit for bit.   python tests/fuzz_lanes.py [first_seed] [count] [--single]   (XINV_LANES=n forces n)"""
+every member against the oracle, bit for bit.   python tests/fuzz_lanes.py [first_seed] [count] [--single] [--lanes=n]   (xinv_options.lanes = n forces n chains)"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ import util                                                   # noqa: E402
 from oracle import COLOUR_AUTO                                # noqa: E402
 
 
+LANES = ([int(a.split('=')[1]) for a in sys.argv if a.startswith('--lanes=')] or [0])[0]
 SINGLE = '--single' in sys.argv      # one member, 2-D forms, masked-tile lists forced, grids large enough for the lagged norm:
                                      # the single-chain paths (skipped tiles' work on the side stream, three buffers)
 
@@ -63,6 +64,8 @@ def one(seed):
     fma = int(bool(shared) and kind in ('std2d', 'gen2d', 'std3d') and not (BCx == 'periodic' and sh[-1] % 2) and rng.integers(2))
     order = (2 | 0x100) if fma else COLOUR_AUTO
     opt = dict(fma=1) if fma else {}
+    if LANES:
+        opt['lanes'] = LANES
     hc = int(rng.integers(4))                                 # host-pointer entry: upload / solve / download over member chunks
     if hc:
         opt['host_chunk'] = [0, 1, 3, 7][hc]
@@ -94,8 +97,8 @@ def main():
         except Exception as e:
             bad += 1
             print('FAIL', str(e)[:400])
-    print('lanes fuzz: seeds %d..%d%s, XINV_LANES=%s: %d in lanes, %d with members stopping apart, %d contracted, %d with skipped tiles, failures: %d'
-          % (first, first + count - 1, ' (single member)' if SINGLE else '', os.environ.get('XINV_LANES', 'auto'), laned, apart, nfma, nskip, bad))
+    print('lanes fuzz: seeds %d..%d%s, lanes=%s: %d in lanes, %d with members stopping apart, %d contracted, %d with skipped tiles, failures: %d'
+          % (first, first + count - 1, ' (single member)' if SINGLE else '', LANES or 'auto', laned, apart, nfma, nskip, bad))
     return 1 if bad else 0
 
 

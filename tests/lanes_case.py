@@ -1,5 +1,5 @@
-"""Child process of tests/test_gpu_lanes.py (XINV_LANES is read once per process): solves batches whose members stop at
-different sweeps, with the sweep loop cut in XINV_LANES launch chains, and compares every member with the oracle.
+"""Child process of tests/test_gpu_lanes.py: solves batches whose members stop at different sweeps, with the sweep loop
+cut in <lanes> launch chains (xinv_options.lanes; 0 = the engine's rule), and compares every member with the oracle.
   python tests/lanes_case.py <expected lanes>     prints 'lanes ok: ...' or raises"""
 import os
 import sys
@@ -22,7 +22,7 @@ def case(kind, shape, nb, mx, tol, want):
         ps = [util.rand2d(kind, *shape, 'fixed', 'periodic', msk=(m % 2 == 0), seed=10 + m) for m in range(nb)]
     for m, q in enumerate(ps):                                # forcings of very different size: the members stop apart
         q['coefs'][-1] = np.where(q['coefs'][-1] == q['undef'], q['undef'], q['coefs'][-1] * 10.0 ** (-(m % 4)))
-    S, fl, st = util.run_hip_dev(ps, mx, tol)
+    S, fl, st = util.run_hip_dev(ps, mx, tol, lanes=want)
     if want == 0:                                             # the engine's own rule (lane_rule, xinv_hip.hip)
         rate = 6.0e5 if st['pipelined'] else (2.5e5 if kind == 'std3d' else 3.0e5)
         est_us = nb * float(np.prod(shape)) * st['sweeps_per_launch'] / rate

@@ -50,11 +50,11 @@ def families():
                        {}, dict(path=2, pipelined=1), orc.COLOUR_2)
     F['pipe2d_skip'] = (lambda s: masked_blocks(xuni(util.rand2d('std2d', 384, 768, 'fixed', 'periodic', seed=s), (0, 2)), s),
                         dict(force_tile_skip=1), dict(path=2, pipelined=1, masked_min=1), orc.COLOUR_2)
-    # the same with the forcing riding the LDS ring (the variant large batches take; forced here: XINV_PIPE_FR=1)
+    # the same with the forcing riding the LDS ring (the variant large batches take; forced here: xinv_options.pipe_fr = 1)
     F['pipe2d_fr'] = (lambda s: xuni(util.rand2d('std2d', 96, 384, 'extend', 'periodic', msk=True, seed=s), (0, 2)),
-                      dict(_env={'XINV_PIPE_FR': '1'}), dict(path=2, pipelined=1), orc.COLOUR_2)
+                      dict(pipe_fr=1), dict(path=2, pipelined=1), orc.COLOUR_2)
     F['pipe2d_gen_fr'] = (lambda s: xuni(util.rand2d('gen2d', 96, 384, 'fixed', 'periodic', msk=True, seed=s), (0, 2, 3, 4, 5)),
-                          dict(_env={'XINV_PIPE_FR': '1'}), dict(path=2, pipelined=1, xuniform_mask=31), orc.COLOUR_2)
+                          dict(pipe_fr=1), dict(path=2, pipelined=1, xuniform_mask=31), orc.COLOUR_2)
     F['fused2d_std_um3'] = (lambda s: xuni(util.rand2d('std2d', 96, 384, 'fixed', 'periodic', seed=s), (0, 2)),
                             dict(no_pipe=1), dict(path=2, pipelined=0, sweeps_per_launch=4, xuniform_mask=3), orc.COLOUR_2)
     F['fused2d_std_um3_skip'] = (lambda s: masked_blocks(xuni(util.rand2d('std2d', 384, 768, 'extend', 'fixed', seed=s), (0, 2)), s),
@@ -131,7 +131,6 @@ def main():
     nalt = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     make, opt, want, order = families()[fam]
     opt = dict(opt)
-    os.environ.update(opt.pop('_env', {}))               # (the library reads these switches per solve)
     _lib.require_gpu()
     A, B = pair(make)
     # (mxLoop, tolerance): whole passes + a tail; one sweep; a stop the rule decides inside a pass

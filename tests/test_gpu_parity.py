@@ -269,7 +269,7 @@ def _uniform2d_all(p):
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
 def test_pipelined_pass_equals_single_wavefront_pass(BCy, BCx, shape, kind):
     """k_pipe2d (four sweeps pipelined across the wavefronts of a workgroup; standard form with per-row A, C --
-    one or two column pairs per lane -- and general form with per-row A, C, D, E, F) against k_fused2d
+    and general form with per-row A, C, D, E, F) against k_fused2d
     (XINV_FLAG_NO_PIPE) and the oracle: bit for bit, masked tiles skipped or not, several members with
     their own coefficients, stats.pipelined reporting which kernel ran."""
     import os
@@ -282,18 +282,15 @@ def test_pipelined_pass_equals_single_wavefront_pass(BCy, BCx, shape, kind):
     S0, f0, st0 = run_hip_batched(ps, 26, 1e-9, path=PATH_FUSED, sweeps_per_launch=4, no_pipe=1)
     assert st0['pipelined'] == 0 and st0['xuniform_mask'] == um, st0
     # one / two column pairs per lane; the forcing re-read from memory by every wavefront / riding the LDS ring
-    for np_, fr in ((('1', '0'), ('1', '1'), ('2', '0')) if kind == 'std2d' else (('1', '0'), ('1', '1'))):
-        os.environ['XINV_PIPE_NP'] = np_                  # (both read per solve by the library)
-        os.environ['XINV_PIPE_FR'] = fr
+    # the forcing re-read from memory by every wavefront / riding the LDS ring (xinv_options.pipe_fr = -1 / 1)
+    for fr in (-1, 1):
         for kw in (dict(), dict(rows_per_tile=16), dict(force_tile_skip=1), dict(rows_per_tile=-3), dict(sweeps_per_launch=4)):
-            o = dict(path=PATH_FUSED); o.update(kw)
+            o = dict(path=PATH_FUSED, pipe_fr=fr); o.update(kw)
             S, fl, st = run_hip_batched(ps, 26, 1e-9, **o)
-            assert st['pipelined'] == (1 if seam else int(np_)) and st['sweeps_per_launch'] == 4, st
+            assert st['pipelined'] == 1 and st['sweeps_per_launch'] == 4, st
             for m in range(3):
-                assert_same(S[m], fl[m], ref[m][0], ref[m][1], 'pipelined %s %r member %d %r np %s fr %s' % (kind, shape, m, kw, np_, fr))
+                assert_same(S[m], fl[m], ref[m][0], ref[m][1], 'pipelined %s %r member %d %r fr %d' % (kind, shape, m, kw, fr))
             assert np.array_equal(S, S0)
-    os.environ.pop('XINV_PIPE_NP', None)
-    os.environ.pop('XINV_PIPE_FR', None)
 
 
 @pytest.mark.parametrize('tol', [3e-3, 1e-3, 2e-4, 5e-5])
@@ -490,9 +487,8 @@ def test_graph_replay_equals_plain_launches(kind, per, bnz, monkeypatch):
          (lambda s: rand2d(kind, 73, xc, 'fixed', per, bnz, 1, seed=s))
     ps = [mk(s) for s in (1, 2, 3)]
     out = {}
-    for g in ('0', '1'):
-        monkeypatch.setenv('XINV_GRAPH', g)
-        out[g] = run_hip_batched(ps, 3000, 1e-7, check_every=16)
+    for g in ('0', '1'):                                   # xinv_options.graph: -1 = plain launches, 1 = replay
+        out[g] = run_hip_batched(ps, 3000, 1e-7, check_every=16, graph=1 if g == '1' else -1)
     S0, f0, _ = out['0']; S1, f1, _ = out['1']
     assert np.array_equal(S0, S1, equal_nan=True) and np.array_equal(f0, f1, equal_nan=True)
     So, flo = run_oracle(ps[1], 3000, 1e-7, COLOUR_AUTO)

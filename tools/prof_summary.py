@@ -6,8 +6,9 @@
   python tools/prof_summary.py config   <fetch.db> <write.db> <kernel-substring> <config name> <bench.py kernel prefix>
                                         <members> <point-sweeps per launch> <traffic.json> [source text]
         the same per point-sweep, stored under traffic.json['configs'][name] (bench.py's per-configuration lines)
-  python tools/prof_summary.py traffic  <fetch.db> <write.db> <kernel-substring> <key> [traffic.json]
-        HBM-side bytes per launch of one kernel = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes).
+  python tools/prof_summary.py traffic  <fetch.db> <write.db> <kernel-substring> <key> [traffic.json [members lanes]]
+        HBM-side bytes per launch of one kernel = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes); with members / lanes the
+        entry also records bytes per PASS (a pass over `members` in `lanes` launch chains = lanes kernel launches).
         The factor 2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM section):
         this rocprofv3 tallies 128-B read requests at 64 B.  It is re-checked in every profile by
         k_strip_active / k_any_nonzero, which stream exactly one array (known byte count).
@@ -76,7 +77,11 @@ def main():
             d = json.load(open(path)) if os.path.exists(path) else {}
             d[key] = traffic
             d[key + '_detail'] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'fetch_correction': 2.0,
-                                  'calibration_kernel': calname, 'calibration_FETCH_KiB': cal}
+                                  'calibration_kernel': calname, 'calibration_FETCH_KiB': cal,
+                                  'bytes_per_launch': traffic, 'launches_profiled': nf}
+            if len(sys.argv) > 8:                          # members of the whole pass, lanes it ran in (a launch covers members / lanes)
+                d[key + '_detail'].update({'members': int(sys.argv[7]), 'lanes': int(sys.argv[8]),
+                                           'bytes_per_pass': traffic * int(sys.argv[8])})
             json.dump(d, open(path, 'w'), indent=1, sort_keys=True)
     elif cmd == 'config':
         fdb, wdb, ksub, name, prefix, members, psl, path = sys.argv[2:10]

@@ -30,7 +30,9 @@ class XinvOptions(ctypes.Structure):
                 ('device_ids', ctypes.c_int32 * MAX_DEVICES),
                 ('prep_flags', ctypes.c_int32), ('f32_mask', ctypes.c_int32),
                 ('prep_undef', ctypes.c_double), ('demask_value', ctypes.c_double),
-                ('prep_rowscale', ctypes.POINTER(ctypes.c_double))]
+                ('prep_rowscale', ctypes.POINTER(ctypes.c_double)),
+                ('lanes', ctypes.c_int32), ('norm_lag', ctypes.c_int32),
+                ('pipe_fr', ctypes.c_int32), ('graph', ctypes.c_int32)]
 
 
 class XinvStats(ctypes.Structure):
@@ -42,7 +44,10 @@ class XinvStats(ctypes.Structure):
                 ('d2h_ms', ctypes.c_double), ('wall_ms', ctypes.c_double),
                 ('host_chunks', ctypes.c_int32), ('devices', ctypes.c_int32),
                 ('pipelined', ctypes.c_int32), ('masked_tile_ppm', ctypes.c_int32),
-                ('recovered_members', ctypes.c_int32), ('lanes', ctypes.c_int32)]
+                ('recovered_members', ctypes.c_int32), ('lanes', ctypes.c_int32),
+                ('planned', ctypes.c_int32), ('pad_', ctypes.c_int32), ('plan_ms', ctypes.c_double),
+                ('launch_us_min', ctypes.c_double), ('launch_us_avg', ctypes.c_double),
+                ('launch_us_max', ctypes.c_double)]
 
 
 class XinvError(RuntimeError):
@@ -62,6 +67,10 @@ EXPORTS = [
     'xinv_general_3d_f64', 'xinv_general_3d_f64_batched', 'xinv_general_3d_f64_dev',
     'xinv_gm_flow_f64_dev',
     'xinv_abs_norm_f64_dev',
+    'xinv_plan_create_standard_2d_f64_dev', 'xinv_plan_create_general_2d_f64_dev',
+    'xinv_plan_create_standard_3d_f64_dev', 'xinv_plan_create_general_3d_f64_dev',
+    'xinv_plan_create_general_bih_2d_f64_dev', 'xinv_plan_create_standard_2d_test_f64_dev',
+    'xinv_plan_solve_f64_dev', 'xinv_plan_refresh', 'xinv_plan_destroy',
 ]
 
 _lib = None
@@ -116,6 +125,18 @@ def load():
     L.xinv_general_3d_f64_dev.argtypes = [_vp] * 9 + [_i64, _ip] + gen3d_scal + [_opt, _vp]
     L.xinv_gm_flow_f64_dev.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _vp, _f64, _int, _vp]
     L.xinv_abs_norm_f64_dev.argtypes = [_vp, _i64, _f64, _dp, _vp]
+    # resident plans: the *_dev argument lists without S / flags / mxLoop / tolerance, behind the handle's address
+    _pp = ctypes.POINTER(_vp)
+    no_tail = lambda scal: scal[:-3]                     # (drop flags, mxLoop, tolerance)
+    L.xinv_plan_create_standard_2d_f64_dev.argtypes = [_pp] + [_vp] * 4 + [_i64, _ip] + no_tail(std2d_scal) + [_opt, _vp]
+    L.xinv_plan_create_general_2d_f64_dev.argtypes = [_pp] + [_vp] * 7 + [_i64, _ip] + no_tail(gen2d_scal) + [_opt, _vp]
+    L.xinv_plan_create_standard_3d_f64_dev.argtypes = [_pp] + [_vp] * 4 + [_i64, _ip] + no_tail(std3d_scal) + [_opt, _vp]
+    L.xinv_plan_create_general_3d_f64_dev.argtypes = [_pp] + [_vp] * 8 + [_i64, _ip] + no_tail(gen3d_scal) + [_opt, _vp]
+    L.xinv_plan_create_general_bih_2d_f64_dev.argtypes = [_pp] + [_vp] * 10 + [_i64, _ip] + no_tail(bih_scal) + [_opt, _vp]
+    L.xinv_plan_create_standard_2d_test_f64_dev.argtypes = [_pp] + [_vp] * 6 + [_i64, _ip] + no_tail(std2d_scal) + [_opt, _vp]
+    L.xinv_plan_solve_f64_dev.argtypes = [_vp, _vp, _dp, _i64, _f64, _vp]
+    L.xinv_plan_refresh.argtypes = [_vp, _vp]
+    L.xinv_plan_destroy.argtypes = [_vp]
     for name in EXPORTS:
         getattr(L, name).restype = _int
     L.xinv_last_error.restype = ctypes.c_char_p
@@ -154,7 +175,8 @@ def check(rc):
 
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
             timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0,
-            host_chunk=0, devices=None, prep=None, pin_host=0, no_pipe=0, fma=0, f32_mask=0):
+            host_chunk=0, devices=None, prep=None, pin_host=0, no_pipe=0, fma=0, f32_mask=0,
+            lanes=0, norm_lag=0, pipe_fr=0, graph=0):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
@@ -165,6 +187,8 @@ def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_
     o.rowconst_mask = int(rowconst_mask)
     o.host_chunk = int(host_chunk)
     o.f32_mask = int(f32_mask)
+    # expert overrides of the planner (0 = its own choice); the library reads no environment variable
+    o.lanes, o.norm_lag, o.pipe_fr, o.graph = int(lanes), int(norm_lag), int(pipe_fr), int(graph)
     # prep: front-end passes on the device -- dict(mask='nan' | value, rowscale=vec | None,
     # s_zero=bool, demask=value | None); the row-scale array is kept alive on the options object
     if prep:
@@ -216,13 +240,16 @@ def bc(b):
     return int(b)
 
 
-def hptr(a):
-    """Host pointer of a C-contiguous float64 ndarray (None -> NULL); a float32 one goes with its bit in
-    xinv_options.f32_mask (the C-ABI declares double* and reads floats there)."""
+def hptr(a, f32=False):
+    """Host pointer of a C-contiguous float64 ndarray (None -> NULL).  `f32=True`: the array is float32 and the caller
+    has set its bit in xinv_options.f32_mask (the C-ABI declares double* and reads floats there); any other dtype /
+    flag combination raises -- a float32 array read as doubles is garbage and a read past its end."""
     if a is None:
         return None
-    if a.dtype not in (np.float64, np.float32) or not a.flags.c_contiguous:
-        raise XinvError('need C-contiguous float64 (or, with f32_mask, float32) arrays at the C-ABI')
+    want = np.float32 if f32 else np.float64
+    if a.dtype != want or not a.flags.c_contiguous:
+        raise XinvError('need a C-contiguous %s array at the C-ABI here, got %s%s'
+                        % (np.dtype(want).name, a.dtype.name, '' if a.flags.c_contiguous else ' (not contiguous)'))
     return ctypes.cast(a.ctypes.data, _dp)
 
 

@@ -23,7 +23,7 @@ import copy
 import numpy as np
 
 from . import core
-from .field import Field, LazyForcing, aligned, along, from_any, full, to_like
+from .field import Field, LazyForcing, aligned, along, from_any, full, to_like, undef_as
 
 # default undefined value (reference apps.py:18, core.py:15)
 _undeftmp = -9.99e8
@@ -493,7 +493,9 @@ def _mask_FS(F, dims, iParams, icbc, lazy=False):
             and np.asarray(F.values).dtype in (np.float64, np.float32):      # (float32 travels as float32: core._solve)
         return LazyForcing(F.values, F.dims, F.coords, iParams['undef'], _undeftmp, name=F.name), None, None
     vals = np.asarray(F.values, dtype=np.float64)
-    undef = iParams['undef']
+    # (a float32 forcing holds float32(undef): compare with the value its own dtype stores, as the reference's
+    #  `F.where(F != undef)` does -- apps.py:2124-2128)
+    undef = undef_as(np.asarray(F.values).dtype, iParams['undef'])
     if np.isnan(undef):
         mvals = np.where(np.isnan(vals), _undeftmp, vals)
     else:

@@ -100,7 +100,7 @@ def _paths(tag):
 
 def stale(tag=TAG, extra=EXTRA, variant_units=VARIANT_UNITS):
     so, obj = _paths(tag)
-    if not os.path.exists(so):
+    if not os.path.exists(so) or not os.path.exists(so + '.linkstamp'):
         return True
     if tag and os.path.getmtime(so) < os.path.getmtime(_paths('')[0]):
         return True                                     # (a variant links the shipped build's other objects)
@@ -152,7 +152,37 @@ def build(force=False, verbose=False, jobs=None, tag=TAG, extra=EXTRA, variant_u
     if verbose:
         print(' '.join(link), flush=True)
     subprocess.check_call(link)
+    with open(so + '.linkstamp', 'w') as fh:             # what was linked: fresh() compares it with the objects' stamps
+        fh.write(_link_stamp(obj, variant_units))
     return so
+
+
+def _link_stamp(obj, variant_units):
+    """Hash of the stamps of every object a library is linked from (its own and, for a variant, the shipped build's)."""
+    h = hashlib.sha256()
+    for u in _units():
+        d = obj if (not variant_units or u[0] in variant_units) else MAIN_OBJ
+        st = os.path.join(d, u[0] + '.stamp')
+        h.update(open(st).read().encode() if os.path.exists(st) else b'missing')
+    return h.hexdigest()
+
+
+def fresh(tag=TAG, extra=EXTRA, variant_units=VARIANT_UNITS):
+    """True when the library `tag` was linked from objects compiled from the CURRENT sources (content hashes only: no
+    file times, so the answer survives a copy of the tree to another box).  tests/test_gpu_watchdog.py asserts it for the
+    test-hooks variant: a stale hooks library would exercise old kernels and old host code."""
+    so, obj = _paths(tag)
+    variant_units = list(variant_units) if tag else []
+    if not os.path.exists(so) or not os.path.exists(so + '.linkstamp'):
+        return False
+    for name, src, uflags in _units():
+        mine = not variant_units or name in variant_units
+        d = obj if mine else MAIN_OBJ
+        st = os.path.join(d, name + '.stamp')
+        flags = BASE_FLAGS + (list(extra) if mine else []) + uflags
+        if not os.path.exists(st) or open(st).read() != _stamp(os.path.join(CSRC, src), flags):
+            return False
+    return open(so + '.linkstamp').read() == _link_stamp(obj, variant_units)
 
 
 # The test-hooks variant (tests/hooks_suite, run by tests/test_gpu_watchdog.py in a subprocess with XINV_SO set): the

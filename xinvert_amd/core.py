@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .field import Field, LazyForcing, aligned
+from .field import Field, LazyForcing, aligned, undef_as
 
 # default undefined value (reference core.py:15)
 _undeftmp = -9.99e8
@@ -95,6 +95,8 @@ def _prep_coef(c, F, perm, core_shape, nbatch, allow_null=False):
         # labelled coefficient (Field / DataArray): line it up with F by dim NAME, as the
         # reference's xarray arithmetic does -- never by shape coincidence (square cores)
         v = np.broadcast_to(aligned(c, F), F.shape)
+        if v.dtype not in (np.float64, np.float32):       # (float32 travels as float32, xinv_options.f32_mask; anything else is promoted here)
+            v = v.astype(np.float64)
     else:
         v = np.asarray(_vals(c), dtype=np.float64)
     n = int(np.prod(core_shape))
@@ -135,7 +137,9 @@ class Resident:
     uploaded ONCE, every `solve()` continues from the current S (the kernels are in place and
     restartable) and only the flags -- and, on `values()`, S -- cross PCIe.  For callers that solve
     the same operator repeatedly, as `apps.animate_iteration` does frame after frame (reference
-    apps.py:1031-1044: one `invt_func(*coeffs, maskF, initS, dims, iParams)` per frame)."""
+    apps.py:1031-1044: one `invt_func(*coeffs, maskF, initS, dims, iParams)` per frame).  The solves run on a resident
+    plan (include/xinv.h, xinv_plan_*): detection passes, per-row records and tile lists are built on the first solve
+    and reused by every later one; the coefficient stack must not change while the object lives."""
 
     def __init__(self, inv_name, coefs, F, S, dims, iParams):
         from .resident import ResidentProblem
@@ -154,9 +158,9 @@ class Resident:
             a, st, rc = _prep_coef(c, F, self.perm, core_shape, nbatch, allow_null=(k == 1 and kind in ('std2d', 'gen2d')))
             if a is None:
                 a = np.zeros(core_shape)                              # ResidentProblem passes it as NULL again
-            elif rc:                                                   # one value per row: the *_dev entries take full arrays
-                a = np.ascontiguousarray(np.broadcast_to(a[..., None], a.shape + (core_shape[-1],))
-                                         ).reshape(((nbatch,) if st else ()) + core_shape)
+            elif rc:                                                   # one value per row STAYS one value per row: a stride-0 view
+                a = a.reshape(((nbatch,) if st else ()) + core_shape[:-1])    # along x, which ResidentProblem uploads as rows
+                a = np.broadcast_to(a[..., None], a.shape + (core_shape[-1],))   # (the plan expands them in HBM: rowconst_mask)
             if st == 0:
                 shared.append(k)
             cs.append(a)
@@ -254,8 +258,10 @@ def _solve(kind, coefs, F, S, dims, iParams):
     prep = None
     if isinstance(F, LazyForcing) and S is None and \
             (F.scale is None or (F.scale_dim in dims and list(dims).index(F.scale_dim) == len(dims) - 2)):
-        prep = dict(mask='nan' if np.isnan(F.undef_in) else float(F.undef_in), rowscale=F.scale, s_zero=True,
-                    demask=iParams['undef'])
+        # (the mask value as the raw array's own dtype stores it: a float32 forcing carries float32(undef), which the
+        #  device pass compares after promotion -- ADVICE r4; the reference compares in float32, apps.py:2124-2128)
+        prep = dict(mask='nan' if np.isnan(F.undef_in) else undef_as(np.asarray(F.raw).dtype, F.undef_in),
+                    rowscale=F.scale, s_zero=True, demask=iParams['undef'])
         Fsrc = F.raw
         Sv = np.empty((nbatch,) + core_shape)
     else:
@@ -289,6 +295,10 @@ def _solve(kind, coefs, F, S, dims, iParams):
 
     flags = np.tile(np.array([0.0, 1.0, 0.0]), (nbatch, 1))
     BCs = [_lib.bc(b) for b in iParams['BCs']]
+    # float32 arrays travel as float32 with their bit in xinv_options.f32_mask: derived from the dtypes of the arrays
+    # actually handed over, and checked against what the code above meant to send (S, the forcing)
+    f32_mask = sum(1 << k for k, a_ in enumerate(arrs) if a_ is not None and a_.dtype == np.float32)
+    assert bool(f32_mask & 1) == bool(f32_out) and bool(f32_mask >> (len(coefs) + 1)) == bool(f32_in), f32_mask
     opt = _lib.options(device=int(iParams.get('device', -1)),
                        path=int(iParams.get('engine_path', 0)),
                        sweeps_per_launch=int(iParams.get('sweeps_per_launch', 0)),
@@ -296,10 +306,10 @@ def _solve(kind, coefs, F, S, dims, iParams):
                        host_chunk=int(iParams.get('host_chunk', 0)),
                        devices=_device_list(iParams, nbatch, sum(a.nbytes for a, st_ in zip(arrs, strides) if a is not None and st_)),
                        prep=prep,
-                       f32_mask=(1 if f32_out else 0) | ((2 << len(coefs)) if f32_in else 0),    # bit 0: S; last array: the forcing
+                       f32_mask=f32_mask,                                        # bit 0: S; bit q + 1: coefficient q (the forcing last)
                        fma=1 if iParams.get('contracted') else 0)      # opt-in XINV_FLAG_FMA (include/xinv.h): NOT the reference's arithmetic
     st = _lib.strides_arg(strides)
-    ptrs = [_lib.hptr(a) for a in arrs]
+    ptrs = [_lib.hptr(a, f32=bool((f32_mask >> k) & 1)) for k, a in enumerate(arrs)]
     mx, tol = int(iParams['mxLoop']), float(iParams['tolerance'])
     if kind == 'std2d':
         rc = L.xinv_standard_2d_f64_batched(

@@ -37,8 +37,17 @@
 #define XINV_AUX_KERNELS            /* the detection / skip-norm helper kernels live in this unit */
 #include "xinv_dispatch.h"          /* argument structs + launchers of the sweep kernels (xinv_tu_*.hip) */
 
-#define XINV_VERSION 400
+#define XINV_VERSION 500
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
+
+// The shipped library reads NO environment variable: the planner's choices are overridden through xinv_options
+// (lanes, norm_lag, pipe_fr, graph, sweeps_per_launch, flags).  The test-hooks build (build/libxinv_hooks.so) and A/B
+// variant builds (-DXINV_EXPERIMENTS=1) additionally honour the XINV_* switches of rounds 2-4 where the option is 0.
+#if XINV_TEST_HOOKS || XINV_EXPERIMENTS
+#define XINV_ENV_INT(name, dflt) ([] { const char *e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define XINV_ENV_INT(name, dflt) (dflt)
+#endif
 
 #include "xinv_host.h"
 #include "xinv_launch.h"
@@ -219,7 +228,8 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
             for (int q = 0; q < 3; q++) pl.aligned = pl.aligned && ptr_al16(p.c[q]) && !(p.sc[q] & 1);
             pl.umask = 0;
             if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-                rc = detect_xuniform(ws, st, p.c, p.sc, 3, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
+                const int idx3[3] = {0, 1, 2};
+                rc = detect_xuniform_of(p, ws, st, idx3, 3, p.zc * p.yc, &pl.umask);
                 if (rc) return rc;
             }
             pl.um = (pl.umask == 7u) ? 7u : 0u;
@@ -256,7 +266,7 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         // kernel.  (Round 2's k_fused3d2, both sweeps inside every wavefront, was bound by its own latency chain
         // -- 1.45e11 -- and is gone.)
         pl.K2 = false;
-        static const int k2_auto = [] { const char *e = getenv("XINV_3D_K2"); return e ? atoi(e) : 1; }();
+        const int k2_auto = XINV_ENV_INT("XINV_3D_K2", 1);
         if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND && !pl.seam &&
             (opt.sweeps_per_launch == 2 || (opt.sweeps_per_launch == 0 && k2_auto)) &&
             opt.rows_per_tile == 0 && p.stop.mxLoop >= 1 &&
@@ -304,13 +314,10 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
     (void)n; (void)rc;
         // which coefficient streams are constant along x (lat-lon grids: functions of latitude)
         {
+            // (the forcing -- the last stream of every model -- is not looked at: no variant reads it per row)
             const int cmapS[3] = {0, 2, 3}, cmapG[6] = {0, 2, 3, 4, 5, 6}, cmapT[4] = {0, 3, 4, 5};
-            const int ns = (p.kind == KIND_STD2D) ? 3 : (p.kind == KIND_STD2DT ? 4 : 6);
-            const double *arr[6]; int64_t strd[6];
-            for (int q = 0; q < ns; q++) {
-                const int sidx = (p.kind == KIND_STD2D) ? cmapS[q] : (p.kind == KIND_STD2DT ? cmapT[q] : cmapG[q]);
-                arr[q] = p.c[sidx]; strd[q] = p.sc[sidx];
-            }
+            const int ns = (p.kind == KIND_STD2D) ? 2 : (p.kind == KIND_STD2DT ? 3 : 5);
+            const int *cmap = (p.kind == KIND_STD2D) ? cmapS : (p.kind == KIND_STD2DT ? cmapT : cmapG);
             pl.umask = 0;
             ws->act_ready = false;
             if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
@@ -325,7 +332,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                         if (rc) return rc;
                     }
                 }
-                rc = detect_xuniform(ws, st, arr, strd, ns, p.nbatch, p.yc, p.xc, &pl.umask);
+                rc = detect_xuniform_of(p, ws, st, cmap, ns, p.yc, &pl.umask);
                 if (rc) return rc;
             }
             pl.um = pick_um(p.kind, pl.umask);
@@ -354,7 +361,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // the tiles, four times as tall, half the recomputed halo -- for the forms whose coefficients are per-row
         // records: the standard form with per-row A and C (lat-lon Poisson) and the general form with per-row
         // A, C, D, E, F (lat-lon Gill-Matsuno).
-        static const int pipe_mode = [] { const char *e = getenv("XINV_PIPE"); return e ? atoi(e) : 1; }();
+        const int pipe_mode = XINV_ENV_INT("XINV_PIPE", 1);
         // (Only the variants whose relaxation factor is a per-row record.  With coefficient arrays that vary along
         // x every wavefront of the pipeline streams them and divides per point: built, bit-exact, and slower than
         // k_fused2d at three sweeps per pass -- C3 Stommel 2.09 against 2.56e11, C2 with every array streamed 2.95
@@ -391,14 +398,13 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         }
         pl.pipe = pipe_want && pl.K == XINV_PIPE_P;
         pl.tpw = pl.pipe ? 1 : 4;
-        // two column pairs per lane (strips of 240 owned columns) where the grid is wide enough to keep the
-        // workgroup count up; XINV_PIPE_NP=1|2 forces the choice
-        const int np_env = [] { const char *e = getenv("XINV_PIPE_NP"); return e ? atoi(e) : 0; }();   // (read per solve: tests switch it)
-        pl.npair = ((np_env == 1 || np_env == 2) && p.kind == KIND_STD2D && !pl.seam && !pl.fma) ? np_env : 1;   // (two pairs per lane measured slower: 45.2 against 40.0 us at 3600x1800)
+        // one column pair per lane (two -- strips of 240 owned columns -- were measured slower, 45.2 against 40.0 us at
+        // 3600x1800, and are no longer instantiated: round 5)
+        pl.npair = 1;
         // the forcing through the LDS ring where the launch's streams (S read + write + forcing, every member) no
         // longer fit the caches and the later wavefronts' forcing requests would go back to HBM; XINV_PIPE_FR=0|1 forces
         {
-            const int fr_env = [] { const char *e = getenv("XINV_PIPE_FR"); return e ? atoi(e) : -1; }();   // (read per solve: tests switch it)
+            const int fr_env = opt.pipe_fr ? (opt.pipe_fr > 0 ? 1 : 0) : XINV_ENV_INT("XINV_PIPE_FR", -1);
             const bool fr_form = (p.kind == KIND_STD2D && pl.um == 3u) || (p.kind == KIND_GEN2D && pl.um == 0x1fu);
             const bool fr_size = (double)p.nbatch * (double)p.yc * (double)p.xc * 24.0 > 2.0e8;
             pl.pipe_fr = pl.pipe && fr_form && pl.npair == 1 && (fr_env < 0 ? fr_size : fr_env != 0);
@@ -488,7 +494,8 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     if (p.kind == KIND_BIH2D) {
         pl.umask = 0;
         if (!(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-            rc = detect_xuniform(ws, st, p.c, p.sc, 10, p.nbatch, p.yc, p.xc, &pl.umask);
+            const int idx10[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+            rc = detect_xuniform_of(p, ws, st, idx10, 10, p.yc, &pl.umask);
             if (rc) return rc;
         }
         pl.um = pl.umask;
@@ -497,7 +504,8 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     // general 3-D: the fused kernel exists for x-uniform coefficients only (every 3DOcean array)
     bool fused3g_ok = false;
     if (p.kind == KIND_GEN3D && seam5_ok && opt.path != XINV_PATH_COLOUR && !(opt.flags & XINV_FLAG_NO_XUNIFORM)) {
-        rc = detect_xuniform(ws, st, p.c, p.sc, 7, p.nbatch, p.zc * p.yc, p.xc, &pl.umask);
+        const int idx7[7] = {0, 1, 2, 3, 4, 5, 6};
+        rc = detect_xuniform_of(p, ws, st, idx7, 7, p.zc * p.yc, &pl.umask);
         if (rc) return rc;
         fused3g_ok = (pl.umask == 0x7fu);
     }
@@ -535,8 +543,16 @@ struct SweepRun {
     // queued after the last poll may still be executing when run_sweeps returns)
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t stream = nullptr;
-    ~SweepRun() { if (graph_exec) { (void)hipStreamSynchronize(stream); (void)hipGraphExecDestroy(graph_exec); } }
+    // xinv_options.timing == 2 (one lane, plain launches): an event before the first sweep launch and one behind each
+    // of them, on the launches' own stream -- per-launch durations (launch_us_min / avg / max) without a profiler
+    std::vector<hipEvent_t> lev;
+    ~SweepRun()
+    {
+        if (graph_exec) { (void)hipStreamSynchronize(stream); (void)hipGraphExecDestroy(graph_exec); }
+        if (!lev.empty()) { (void)hipStreamSynchronize(stream); for (hipEvent_t e : lev) (void)hipEventDestroy(e); }
+    }
 };
+#define XINV_MAX_LAUNCH_EVENTS 8192
 
 // one sweep launch of the planned kernel (fused: k sweeps from src into dst; colour path: one sweep in place)
 static int launch_planned(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t s, int k,
@@ -603,7 +619,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // The decision about pass i arrives while pass i+1 runs, so S rotates through THREE buffers: pass
     // i+2 -- the first that could overwrite the source of pass i -- starts after reducer i has finished,
     // finds the member stopped and does nothing, and finalise() re-sweeps from the intact source.
-    static const bool lag_env = [] { const char *e = getenv("XINV_LAG"); return !e || atoi(e) != 0; }();
+    const bool lag_env = opt.norm_lag ? opt.norm_lag > 0 : XINV_ENV_INT("XINV_LAG", 1) != 0;
     // Only where a member has many workgroups: the reducing workgroup is one more per member and launch,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
@@ -662,7 +678,11 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // GPU never idles on the host's reaction time; once every member has stopped, the launches
     // already queued are no-ops (each kernel returns on ctl.done).
     // one sweep launch (fused: K sweeps from buf[cur] into buf[cur^1]; colour path: one sweep in place)
-    static const int exp_noctl = [] { const char *e = getenv("XINV_EXP_NOCTL"); return e ? atoi(e) : 0; }();   // timing experiment only
+#if XINV_EXPERIMENTS
+    static const int exp_noctl = XINV_ENV_INT("XINV_EXP_NOCTL", 0);   // timing experiment (variant builds only): launches without norm / stop rule
+#else
+    constexpr int exp_noctl = 0;
+#endif
     auto launch_one = [&](hipStream_t s, int cur, int k) -> int {
         return launch_planned(p, pl, ws, s, k, buf[cur], buf[cur ^ 1], 0, p.nbatch, exp_noctl, exp_noctl);
     };
@@ -672,13 +692,13 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // ping-pong parity at its start is always 0.
     bool use_graph = false;
     {
-        const char *e = getenv("XINV_GRAPH");
+        const int graph_env = opt.graph ? (opt.graph > 0 ? 1 : 0) : XINV_ENV_INT("XINV_GRAPH", -1);
         const double est_launch_us = (double)p.nbatch * (double)n * Kf /
                                      ((pl.path == XINV_PATH_FUSED) ? 2.0e5 : 4.0e4);
         // Replay pays on the colour path only (six or more tiny launches per sweep: 25.8 -> 22.2 us per sweep
         // at 151x251); for the fused kernels it gained nothing (round 1; C1: 2.5 ms replayed against 1.9 ms
         // per 500 sweeps with plain launches and the lagged norm, which excludes replay).  XINV_GRAPH=1 forces it.
-        const bool want = e ? (atoi(e) != 0) : (est_launch_us < 12.0 && pl.path != XINV_PATH_FUSED);
+        const bool want = graph_env >= 0 ? (graph_env != 0) : (est_launch_us < 12.0 && pl.path != XINV_PATH_FUSED);
         if (want && max_sweeps >= 2 * (int64_t)check_every * Kf) {
             check_every = (check_every + 1) & ~1;
             if (!ws->gstream) HIPCHK(hipStreamCreateWithFlags(&ws->gstream, hipStreamNonBlocking));
@@ -738,7 +758,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // members are independent, so the batch is cut into halves whose launches form independent chains -- the caller's
     // stream and the engine's own --; one chain's boundary is covered by the other's launch.  The control blocks are copied
     // for the host on a third stream behind both chains; everything is joined back into the caller's stream below.
-    static const int lanes_env = [] { const char *e = getenv("XINV_LANES"); return e ? atoi(e) : -1; }();
+    const int lanes_env = opt.lanes > 0 ? opt.lanes : XINV_ENV_INT("XINV_LANES", -1);
     int nlane = 1;
     if (!use_graph && !exp_noctl && pl.path == XINV_PATH_FUSED)
         nlane = (int)std::min<int64_t>(p.nbatch, lanes_env >= 0 ? std::max(1, std::min(lanes_env, XINV_MAX_LANES)) : lane_rule(p, est_pass_us));
@@ -833,6 +853,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         return XINV_OK;
     };
     int last_slot = 0;
+    const bool per_launch_events = opt.timing == 2 && !two && !use_graph && pl.path == XINV_PATH_FUSED;
     auto issue_chunk = [&](int slot) -> int {
         if (opt.timing && !two) HIPCHK(hipEventRecord(ws->ev0[slot], st));
         if (use_graph && max_sweeps - launched >= (int64_t)check_every * Kf &&
@@ -848,8 +869,17 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             int r;
             if (pl.path == XINV_PATH_FUSED) {
                 const int k = (int)std::min<int64_t>(Kf, max_sweeps - launched);   // the tail: one shorter pass
+                const bool tev = per_launch_events && R.lev.size() < XINV_MAX_LAUNCH_EVENTS;
+                if (tev && R.lev.empty()) {
+                    hipEvent_t e0; HIPCHK(hipEventCreate(&e0)); R.lev.push_back(e0);
+                    HIPCHK(hipEventRecord(e0, st));
+                }
                 r = launch_idx((int64_t)bound.size(), k);
                 if (r) return r;
+                if (tev) {
+                    hipEvent_t e1; HIPCHK(hipEventCreate(&e1)); R.lev.push_back(e1);
+                    HIPCHK(hipEventRecord(e1, st));
+                }
                 bound.push_back(launched);
                 launched += k;
             } else {
@@ -1030,6 +1060,18 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
                                       hipMemcpyDeviceToDevice, st));
         }
         HIPCHK(hipStreamSynchronize(st));
+        if (R.lev.size() > 1) {                          // timing == 2: the launches that did work (not the no-op tail)
+            double mn = 1e300, mx = 0.0, sum = 0.0; int cnt = 0;
+            for (size_t i = 0; i + 1 < R.lev.size() && i + 1 < bound.size(); i++) {
+                bool live = false;                       // (some member still sweeping when launch i started)
+                for (int64_t m = 0; m < p.nbatch && !live; m++) live = hc[m].sweeps > bound[i];
+                if (!live) break;
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, R.lev[i], R.lev[i + 1]));
+                mn = std::min(mn, (double)ms); mx = std::max(mx, (double)ms); sum += ms; cnt++;
+            }
+            if (cnt) { t_stats.launch_us_min = mn * 1e3; t_stats.launch_us_max = mx * 1e3; t_stats.launch_us_avg = sum * 1e3 / cnt; }
+        }
     }
     for (int64_t m = 0; m < p.nbatch; m++) {
         const XinvCtl &c = hc[m];
@@ -1053,19 +1095,8 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
 }
 
 // ------------------------------------------------------------------ the solve (device ptrs)
-static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st)
+static int ws_ready(Workspace *ws)
 {
-    int rc = validate(p, flags);
-    if (rc) return rc;
-    xinv_options opt;
-    fill_options(opt, opt_in);
-
-    DeviceGuard dg;
-    HIPCHK(dg.select(opt.device));
-    int device = 0;
-    HIPCHK(hipGetDevice(&device));
-    Workspace *ws = get_ws(device);
-    std::lock_guard<std::recursive_mutex> solve_lock(ws->busy);
     if (!ws->ev0[0])
         for (int q = 0; q < 2; q++) {
             HIPCHK(hipEventCreate(&ws->ev0[q])); HIPCHK(hipEventCreate(&ws->ev1[q]));
@@ -1075,13 +1106,16 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
         HIPCHK(hipMalloc((void **)&ws->dflag, sizeof(int)));
         HIPCHK(hipHostMalloc((void **)&ws->hflag, sizeof(int), hipHostMallocDefault));
     }
+    return XINV_OK;
+}
 
-    memset(&t_stats, 0, sizeof t_stats);
-    Plan pl;
+// colouring -> path -> tiling, per-row records, tile lists: everything a solve derives from the coefficient stack and the
+// forcing's mask (nothing from S).  Detection passes run on `st` and are synchronous.
+static int make_plan(const Problem &p, const xinv_options &opt, Workspace *ws, hipStream_t st, Plan &pl)
+{
     memset(&pl, 0, sizeof pl);
-    rc = plan_colouring(p, ws, st, pl);
+    int rc = plan_colouring(p, ws, st, pl);
     if (rc) return rc;
-
     if (opt.path == 3)                                  // (the value of round 2-3's XINV_PATH_SMALL)
         return fail_arg("path 3 (the register-resident small-slice solver) was removed in version 400: it never beat the "
                         "streaming kernels; use XINV_PATH_AUTO");
@@ -1100,11 +1134,189 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
                             "variants only (standard 2-D with A, C constant along x; general 2-D with A, C, D, E, F constant "
                             "along x; standard 3-D with A, B, C constant along x; B == 0; no odd-xc periodic seam)");
     }
+    return XINV_OK;
+}
+
+static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st)
+{
+    int rc = validate(p, flags);
+    if (rc) return rc;
+    xinv_options opt;
+    fill_options(opt, opt_in);
+
+    DeviceGuard dg;
+    HIPCHK(dg.select(opt.device));
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    Workspace *ws = get_ws(device);
+    std::lock_guard<std::recursive_mutex> solve_lock(ws->busy);
+    rc = ws_ready(ws);
+    if (rc) return rc;
+
+    memset(&t_stats, 0, sizeof t_stats);
+    const auto t_plan0 = std::chrono::steady_clock::now();
+    Plan pl;
+    rc = make_plan(p, opt, ws, st, pl);
+    if (rc) return rc;
+    const double plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
     SweepRun R;
     R.stream = st;
     rc = run_sweeps(p, pl, opt, ws, st, R);
     if (rc) return rc;
-    return finalise(p, pl, ws, st, flags, R);
+    rc = finalise(p, pl, ws, st, flags, R);
+    t_stats.plan_ms = plan_ms;
+    return rc;
+}
+
+// ------------------------------------------------------------------ resident plans (xinv_plan_*)
+// The reference calls its kernel again and again on one coefficient stack: apps.animate_iteration (apps.py:1031-1044,
+// one `invt_func(*coeffs, maskF, initS, dims, iParams)` per frame), a restart of an un-converged solve, a new first guess
+// -- and every call of the *_dev entries re-derives what only depends on that stack: which arrays are constant along x
+// (a pass over each), the per-row records, the forcing's activity map (a pass + a host round trip), the row split and
+// the tile lists (host time), ~0.26 ms of a 4.8 ms headline solve and ALL of a two-sweep frame.  A plan holds them:
+// built once by xinv_plan_create_*, used by every xinv_plan_solve_f64_dev; its device buffers (per-row records, tile
+// lists, the skipped tiles' norm slots, expanded row-constant coefficients) are its own, swapped into the per-device
+// workspace for the duration of a solve (under the workspace lock).
+struct PlanBufs {
+    void *d_rowf = nullptr; size_t d_rowf_cap = 0;
+    int *d_list = nullptr; size_t d_list_cap = 0;
+    double *d_tsum = nullptr; size_t d_tsum_cap = 0;
+};
+struct BufSwap {                                         // the plan's buffers sit in the workspace while this lives
+    Workspace *ws; PlanBufs *b;
+    static void sw(Workspace *w, PlanBufs *q)
+    {
+        std::swap(w->d_rowf, q->d_rowf); std::swap(w->d_rowf_cap, q->d_rowf_cap);
+        std::swap(w->d_list, q->d_list); std::swap(w->d_list_cap, q->d_list_cap);
+        std::swap(w->d_tsum, q->d_tsum); std::swap(w->d_tsum_cap, q->d_tsum_cap);
+    }
+    BufSwap(Workspace *w, PlanBufs *q) : ws(w), b(q) { sw(ws, b); }
+    ~BufSwap() { sw(ws, b); }
+};
+
+#define XINV_PLAN_MAGIC 0x58504c4eu
+struct xinv_plan {
+    unsigned magic = XINV_PLAN_MAGIC;
+    int device = 0;
+    Problem p;                                           // S = a placeholder; stop = the kind's stop_on_zero_norm only
+    xinv_options opt;
+    Plan pl;
+    PlanBufs bufs;
+    std::vector<void *> owned;                           // row-constant coefficients expanded into HBM copies of the plan
+    int64_t solves = 0;
+};
+
+static double *const kPlanS = (double *)(uintptr_t)4096;  // (never dereferenced: planning reads no S)
+
+static int plan_build(xinv_plan *h, hipStream_t st)
+{
+    DeviceGuard dg;
+    HIPCHK(dg.select(h->device));
+    Workspace *ws = get_ws(h->device);
+    std::lock_guard<std::recursive_mutex> lock(ws->busy);
+    int rc = ws_ready(ws);
+    if (rc) return rc;
+    Problem p = h->p;
+    p.S = kPlanS;
+    p.stop.mxLoop = (long long)1 << 40; p.stop.tolerance = 0.0;
+    BufSwap sw(ws, &h->bufs);
+    rc = make_plan(p, h->opt, ws, st, h->pl);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(st));                    // records and lists are complete: any stream may solve on them
+    return XINV_OK;
+}
+
+static void plan_free(xinv_plan *h)
+{
+    if (!h) return;
+    DeviceGuard dg;
+    (void)dg.select(h->device);
+    if (h->bufs.d_rowf) (void)hipFree(h->bufs.d_rowf);
+    if (h->bufs.d_list) (void)hipFree(h->bufs.d_list);
+    if (h->bufs.d_tsum) (void)hipFree(h->bufs.d_tsum);
+    for (void *q : h->owned) (void)hipFree(q);
+    h->magic = 0;
+    delete h;
+}
+
+static int plan_create(xinv_plan **out, Problem &p, const xinv_options *opt_in, hipStream_t st)
+{
+    if (!out) return fail_arg("null plan pointer");
+    *out = nullptr;
+    xinv_options opt;
+    fill_options(opt, opt_in);
+    p.rowconst = (unsigned)opt.rowconst_mask & ((1u << p.ncoef) - 1u);
+    if ((p.rowconst >> (p.ncoef - 1)) & 1u) return fail_arg("xinv_plan_create: the forcing cannot be row-constant");
+    p.S = kPlanS;
+    p.stop.mxLoop = 0; p.stop.tolerance = 0.0;
+    double dummy_flags[3];
+    int rc = validate(p, dummy_flags);
+    if (rc) return rc;
+    DeviceGuard dg;
+    HIPCHK(dg.select(opt.device));
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    xinv_plan *h = new xinv_plan();
+    h->device = device;
+    h->opt = opt;
+    h->opt.device = device;
+    struct Undo { xinv_plan *h; ~Undo() { if (h) plan_free(h); } } undo{h};
+    // coefficients handed over as one value per row (lat-lon grids: functions of latitude, apps.py:1406-1408,
+    // 1630-1635): the plan expands them into its own HBM copies -- the caller's row vectors are not referenced after
+    // this call -- and knows without a detection pass that they are constant along x
+    const int64_t n = p.zc * p.yc * p.xc, rows = p.zc * p.yc;
+    for (int q = 0; q < p.ncoef; q++) {
+        if (!((p.rowconst >> q) & 1u) || !p.c[q]) continue;
+        if (p.sc[q] != 0 && p.sc[q] != rows)
+            return fail_arg("xinv_plan_create: a row-constant coefficient has batch stride 0 or exactly rows");
+        const int64_t members = (p.sc[q] == 0) ? 1 : p.nbatch;
+        void *full = nullptr;
+        HIPCHK(hipMalloc(&full, (size_t)members * n * sizeof(double)));
+        h->owned.push_back(full);
+        hipLaunchKernelGGL(k_expand_rows, dim3(cdiv(rows * members, 4)), dim3(256), 0, st, p.c[q], (double *)full, rows,
+                           p.xc, members);
+        p.c[q] = (const double *)full;
+        p.sc[q] = (members == 1) ? 0 : n;
+        p.known_um |= 1u << q;
+    }
+    HIPCHK(hipGetLastError());
+    p.rowconst = 0;
+    h->p = p;
+    rc = plan_build(h, st);
+    if (rc) return rc;
+    undo.h = nullptr;
+    *out = h;
+    return XINV_OK;
+}
+
+static int plan_solve(xinv_plan *h, double *S, double *flags, int64_t mxLoop, double tolerance, hipStream_t st)
+{
+    if (!h || h->magic != XINV_PLAN_MAGIC) return fail_arg("xinv_plan_solve: not a live plan");
+    Problem p = h->p;
+    p.S = S;
+    p.stop.mxLoop = mxLoop; p.stop.tolerance = tolerance;
+    int rc = validate(p, flags);
+    if (rc) return rc;
+    if (h->pl.aligned && !ptr_al16(S))
+        return fail_arg("xinv_plan_solve: this plan's kernels use 16-byte accesses: S must be 16-byte aligned");
+    DeviceGuard dg;
+    HIPCHK(dg.select(h->device));
+    Workspace *ws = get_ws(h->device);
+    std::lock_guard<std::recursive_mutex> lock(ws->busy);
+    rc = ws_ready(ws);
+    if (rc) return rc;
+    BufSwap sw(ws, &h->bufs);
+    memset(&t_stats, 0, sizeof t_stats);
+    Plan pl = h->pl;
+    pl.skipna.S = S;                                     // (the skipped tiles' norm share and copies read THIS solve's S)
+    SweepRun R;
+    R.stream = st;
+    rc = run_sweeps(p, pl, h->opt, ws, st, R);
+    if (rc) return rc;
+    rc = finalise(p, pl, ws, st, flags, R);
+    t_stats.planned = 1;
+    h->solves++;
+    return rc;
 }
 
 // ------------------------------------------------------------------ the solve (host ptrs)
@@ -2073,6 +2285,117 @@ int xinv_standard_2d_test_f64_dev(double *S, const double *A, const double *B, c
     Problem p = mk_std2dt(S, co, nbatch, strides, yc, xc, delx, BCy, BCx, delxSqr, ratioQtr,
                           ratioSqr, optArg, undef, mxLoop, tolerance);
     GUARD(solve_dev(p, flags, opt, (hipStream_t)stream))
+}
+
+// ---- resident plans (include/xinv.h: "resident plans") ---------------------------------------------------------
+int xinv_plan_create_standard_2d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                         const double *F, int64_t nbatch, const int64_t *strides, int64_t yc,
+                                         int64_t xc, double dely, double delx, int BCy, int BCx, double delxSqr,
+                                         double ratioQtr, double ratioSqr, double optArg, double undef,
+                                         const xinv_options *opt, void *stream)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_std2d(nullptr, A, B, C, F, nbatch, strides, yc, xc, delx, BCy, BCx, delxSqr, ratioQtr,
+                         ratioSqr, optArg, undef, 0, 0.0);
+    GUARD(plan_create(plan, p, opt, (hipStream_t)stream))
+}
+
+int xinv_plan_create_general_2d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                        const double *D, const double *E, const double *F, const double *G,
+                                        int64_t nbatch, const int64_t *strides, int64_t yc, int64_t xc, double dely,
+                                        double delx, int BCy, int BCx, double delxSqr, double ratio, double ratioQtr,
+                                        double ratioSqr, double optArg, double undef, const xinv_options *opt,
+                                        void *stream)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_gen2d(nullptr, A, B, C, D, E, F, G, nbatch, strides, yc, xc, delx, BCy, BCx, delxSqr, ratio,
+                         ratioQtr, ratioSqr, optArg, undef, 0, 0.0);
+    GUARD(plan_create(plan, p, opt, (hipStream_t)stream))
+}
+
+int xinv_plan_create_standard_3d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                         const double *F, int64_t nbatch, const int64_t *strides, int64_t zc,
+                                         int64_t yc, int64_t xc, double delz, double dely, double delx, int BCz,
+                                         int BCy, int BCx, double delxSqr, double ratio2Sqr, double ratio1Sqr,
+                                         double optArg, double undef, const xinv_options *opt, void *stream)
+{
+    (void)delz; (void)dely; (void)delx;
+    if (!strides) return fail_arg("null strides");
+    Problem p = mk_std3d(nullptr, A, B, C, F, nbatch, strides, zc, yc, xc, BCz, BCy, BCx, delxSqr, ratio2Sqr,
+                         ratio1Sqr, optArg, undef, 0, 0.0);
+    GUARD(plan_create(plan, p, opt, (hipStream_t)stream))
+}
+
+int xinv_plan_create_general_3d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                        const double *D, const double *E, const double *F, const double *G,
+                                        const double *H, int64_t nbatch, const int64_t *strides, int64_t zc,
+                                        int64_t yc, int64_t xc, double delz, double dely, double delx, int BCz,
+                                        int BCy, int BCx, double delxSqr, double ratio2, double ratio1,
+                                        double ratio2Sqr, double ratio1Sqr, double optArg, double undef,
+                                        const xinv_options *opt, void *stream)
+{
+    (void)delz; (void)dely;
+    if (!strides) return fail_arg("null strides");
+    const double *c[8] = { A, B, C, D, E, F, G, H };
+    Problem p = mk_gen3d(nullptr, c, nbatch, strides, zc, yc, xc, delx, BCz, BCy, BCx, delxSqr, ratio2, ratio1,
+                         ratio2Sqr, ratio1Sqr, optArg, undef, 0, 0.0);
+    GUARD(plan_create(plan, p, opt, (hipStream_t)stream))
+}
+
+int xinv_plan_create_general_bih_2d_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                            const double *D, const double *E, const double *F, const double *G,
+                                            const double *H, const double *I, const double *J, int64_t nbatch,
+                                            const int64_t *strides, int64_t yc, int64_t xc, double dely, double delx,
+                                            int BCy, int BCx, double delxSSr, double delxTr, double delxSqr,
+                                            double ratio, double ratioSSr, double ratioQtr, double ratioSqr,
+                                            double optArg, double undef, const xinv_options *opt, void *stream)
+{
+    (void)dely; (void)delx;
+    if (!strides) return fail_arg("null strides");
+    const double *co[10] = { A, B, C, D, E, F, G, H, I, J };
+    Problem p = mk_bih2d(nullptr, co, nbatch, strides, yc, xc, BCy, BCx, delxSSr, delxTr, delxSqr, ratio, ratioSSr,
+                         ratioQtr, ratioSqr, optArg, undef, 0, 0.0);
+    GUARD(plan_create(plan, p, opt, (hipStream_t)stream))
+}
+
+int xinv_plan_create_standard_2d_test_f64_dev(xinv_plan **plan, const double *A, const double *B, const double *C,
+                                              const double *D, const double *E, const double *F, int64_t nbatch,
+                                              const int64_t *strides, int64_t yc, int64_t xc, double dely,
+                                              double delx, int BCy, int BCx, double delxSqr, double ratioQtr,
+                                              double ratioSqr, double optArg, double undef, const xinv_options *opt,
+                                              void *stream)
+{
+    (void)dely;
+    if (!strides) return fail_arg("null strides");
+    const double *co[6] = { A, B, C, D, E, F };
+    Problem p = mk_std2dt(nullptr, co, nbatch, strides, yc, xc, delx, BCy, BCx, delxSqr, ratioQtr, ratioSqr, optArg,
+                          undef, 0, 0.0);
+    GUARD(plan_create(plan, p, opt, (hipStream_t)stream))
+}
+
+int xinv_plan_solve_f64_dev(xinv_plan *plan, double *S, double *flags, int64_t mxLoop, double tolerance, void *stream)
+{
+    GUARD(plan_solve(plan, S, flags, mxLoop, tolerance, (hipStream_t)stream))
+}
+
+int xinv_plan_refresh(xinv_plan *plan, void *stream)
+{
+    if (!plan || plan->magic != XINV_PLAN_MAGIC) return fail_arg("xinv_plan_refresh: not a live plan");
+    GUARD(plan_build(plan, (hipStream_t)stream))
+}
+
+int xinv_plan_destroy(xinv_plan *plan)
+{
+    if (!plan) return XINV_OK;
+    if (plan->magic != XINV_PLAN_MAGIC) return fail_arg("xinv_plan_destroy: not a live plan");
+    {   // (not while a solve on this device is using the plan's buffers)
+        Workspace *ws = get_ws(plan->device);
+        std::lock_guard<std::recursive_mutex> lock(ws->busy);
+        plan_free(plan);
+    }
+    return XINV_OK;
 }
 
 // Gill-Matsuno (u, v) from the mass field; every array argument is a DEVICE pointer.

@@ -63,7 +63,7 @@ struct CopyPool {                                   // process-wide memcpy worke
         std::lock_guard<std::mutex> lk(mu);
         if (nworker) return;
         unsigned hc = std::thread::hardware_concurrency();
-        if (const char *e = getenv("XINV_COPY_THREADS")) hc = 2u * (unsigned)std::max(1, atoi(e));
+        { const int e_ = XINV_ENV_INT("XINV_COPY_THREADS", 0); if (e_ > 0) hc = 2u * (unsigned)e_; }
         nworker = (int)std::max(1u, std::min(8u, hc / 2u));
         for (int i = 0; i < nworker; i++)
             th.emplace_back([this] {
@@ -227,6 +227,7 @@ struct Workspace {
     int *d_list = nullptr; size_t d_list_cap = 0;               // [nbatch][ntl] then [nbatch][nskip]
     int *h_list = nullptr; size_t h_list_cap = 0;               // pinned
     bool act_ready = false; int act_uw = 0; const double *act_f = nullptr;   // activity map issued ahead (issue_strip_active)
+    bool act_synced = false;                                    // ... and its copy to the host is known to have completed
     std::vector<int> h_pre;                                     // plan_tile_skip: prefix counts (kept: no allocation per solve)
     double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
     void *d_rowf = nullptr; size_t d_rowf_cap = 0;              // k_pipe2d: per-row records [nbatch][yc][PIPE_RW]
@@ -270,6 +271,8 @@ struct Problem {
     int ncoef;
     unsigned rowconst;           // host entries: arrays given as one value per row (see xinv.h)
     unsigned f32;                // host entries: bit 0 = S, bit q+1 = coefficient q is FLOAT32 on the host (xinv_options.f32_mask)
+    unsigned known_um;           // bit q: coefficient q is known to be constant along x (a resident plan expanded it from one
+                                 // value per row itself: xinv_plan_create_*, rowconst_mask) -- the detection pass does not read it
     int BCz, BCy, BCx;
     XinvScal sc_;
     XinvStop stop;
@@ -365,8 +368,7 @@ static int pool_alloc(DevPool *pool, size_t bytes, double **out)
 struct Pinned {                                     // host ranges registered for this call (opt-in, see above)
     static bool env_allowed()
     {
-        static const bool env = [] { const char *e = getenv("XINV_PIN"); return e && atoi(e) != 0; }();
-        return env;
+        return XINV_ENV_INT("XINV_PIN", 0) != 0;         // (variant / hooks builds only: the shipped library takes XINV_FLAG_PIN_HOST)
     }
     std::vector<std::pair<char *, size_t>> regs;    // (base, bytes) of every registered range
     const Pinned *outer = nullptr;                  // multi-device call: the parent's portable registrations

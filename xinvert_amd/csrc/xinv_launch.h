@@ -164,7 +164,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
         if (pipe) {
             // (XINV_PIPE_LDSPAD: unused dynamic LDS per workgroup, to cap the workgroups per CU in experiments;
             //  capping at the planned count changed nothing: the dispatcher already spreads them evenly)
-            static const int pad = [] { const char *e = getenv("XINV_PIPE_LDSPAD"); return e ? std::max(0, atoi(e)) : 0; }();
+            const int pad = std::max(0, XINV_ENV_INT("XINV_PIPE_LDSPAD", 0));
             xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad, pl.seam != 0, pl.fma);
             continue;
         }
@@ -523,8 +523,7 @@ static int64_t choose_row_blocks(int64_t yc, int64_t nstrip, int64_t nbatch, int
 // (pipelined kernel: up to XINV_PIPE_OCC workgroups -- one wavefront each per SIMD -- share a CU)
 static int pipe_occ_cap()
 {
-    static const int cap = [] { const char *e = getenv("XINV_PIPE_OCC"); return e ? std::max(1, atoi(e)) : 5; }();
-    return cap;
+    return std::max(1, XINV_ENV_INT("XINV_PIPE_OCC", 5));
 }
 
 static double tile_cost(int64_t wgs, int64_t rows, int K, int occ, double lone = 1.6, bool pipe = false)
@@ -568,7 +567,7 @@ static int issue_strip_active(const Problem &p, Workspace *ws, hipStream_t st, i
     sa.undef = p.sc_.undef; sa.act = ws->d_act;
     hipLaunchKernelGGL(k_strip_active, dim3(cdiv(cells, 4), (unsigned)nb, 1), dim3(256), 0, st, sa);
     HIPCHK(hipMemcpyAsync(ws->h_act, ws->d_act, (size_t)(nb * cells), hipMemcpyDeviceToHost, st));
-    ws->act_ready = true; ws->act_uw = UW; ws->act_f = p.c[fi];
+    ws->act_ready = true; ws->act_uw = UW; ws->act_f = p.c[fi]; ws->act_synced = false;
     return XINV_OK;
 }
 
@@ -594,7 +593,8 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         rc = issue_strip_active(p, ws, st, UW, fi);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(st));
-    }
+    } else if (!ws->act_synced)                           // (issued ahead, and no detection pass synchronised behind it)
+        HIPCHK(hipStreamSynchronize(st));
     ws->act_ready = false;
 
     // prefix counts of active rows per (member, strip), laid out [member][row][strip]: building them and looking up the
@@ -757,8 +757,30 @@ static int detect_xuniform(Workspace *ws, hipStream_t st, const double *const *a
     hipLaunchKernelGGL(k_xuniform, dim3(512, (unsigned)nstream, 1), dim3(256), 0, st, xa);
     HIPCHK(hipMemcpyAsync(ws->hflags16, ws->dflags16, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    ws->act_synced = true;                                // (an activity map issued ahead on this stream has landed too)
     *mask = 0;
     for (int q = 0; q < nstream; q++) if (!ws->hflags16[q]) *mask |= (1u << q);
     return XINV_OK;
 }
 
+// The same over coefficient arrays idx[0..ns) of a problem; bit q of *mask = array idx[q].  Arrays the caller declared
+// row-constant to a resident plan (Problem::known_um: the plan expanded them itself) are not read again.
+static int detect_xuniform_of(const Problem &p, Workspace *ws, hipStream_t st, const int *idx, int ns, int64_t rows,
+                              unsigned *mask)
+{
+    const double *arr[10]; int64_t strd[10]; int pos[10];
+    int nu = 0;
+    unsigned m = 0;
+    for (int q = 0; q < ns; q++) {
+        if ((p.known_um >> idx[q]) & 1u) { m |= 1u << q; continue; }
+        arr[nu] = p.c[idx[q]]; strd[nu] = p.sc[idx[q]]; pos[nu] = q; nu++;
+    }
+    if (nu) {
+        unsigned mm = 0;
+        const int rc = detect_xuniform(ws, st, arr, strd, nu, p.nbatch, rows, p.xc, &mm);
+        if (rc) return rc;
+        for (int k = 0; k < nu; k++) if ((mm >> k) & 1u) m |= 1u << pos[k];
+    }
+    *mask = m;
+    return XINV_OK;
+}

@@ -51,10 +51,9 @@ int xinv_launch_pipe2d_fma(bool gen, unsigned um, bool fr, bool al, bool ext, di
 #elif XINV_TU_MODEL == 0
 int xinv_launch_pipe2d_std(unsigned um, int np, bool fr, bool al, bool ext, dim3 grid, hipStream_t st, const FusedArgs &a, int *occ, int lds_pad)
 {
-    if (um == 3u && fr) return pipe_np<FusedStd2D, 3u, true, 1>(al, ext, grid, st, a, occ, lds_pad);
-    if constexpr (SEAM) { if (um == 3u && np == 1) return pipe_np<FusedStd2D, 3u, false, 1>(al, ext, grid, st, a, occ, lds_pad); }
-    else if (um == 3u) return np == 2 ? pipe_np<FusedStd2D, 3u, false, 2>(al, ext, grid, st, a, occ, lds_pad)
-                                      : pipe_np<FusedStd2D, 3u, false, 1>(al, ext, grid, st, a, occ, lds_pad);
+    // (two column pairs per lane -- NP = 2 -- were measured slower in round 2 and are no longer instantiated)
+    if (um == 3u && np == 1) return fr ? pipe_np<FusedStd2D, 3u, true, 1>(al, ext, grid, st, a, occ, lds_pad)
+                                       : pipe_np<FusedStd2D, 3u, false, 1>(al, ext, grid, st, a, occ, lds_pad);
     return 1;
 }
 #else

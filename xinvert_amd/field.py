@@ -45,6 +45,12 @@ class Field:
         return 'Field(name=%r, dims=%r, shape=%r)' % (self.name, self.dims, self.shape)
 
 
+def undef_as(dtype, undef):
+    """The undefined value as an array of `dtype` stores it, as a Python float (float32 arrays: float(float32(undef)))."""
+    dt = np.dtype(dtype)
+    return float(np.asarray(undef, dtype=dt)) if dt.kind == 'f' else float(undef)
+
+
 class LazyForcing(Field):
     """The forcing the kernels read, described instead of materialised:
 
@@ -73,7 +79,10 @@ class LazyForcing(Field):
     def values(self):
         if self._values is None:
             r = np.asarray(self.raw, dtype=np.float64)
-            masked = (np.isnan(r) if np.isnan(self.undef_in) else (r == self.undef_in)) | (r == self.undef_tmp)
+            # (the caller's undefined value as the raw array's OWN dtype holds it: a float32 forcing filled with 1e20 or
+            #  9.96921e36 carries float32(undef), which differs from the Python float -- the reference's
+            #  `F.where(F != undef)` compares in float32, apps.py:2124-2128)
+            masked = (np.isnan(r) if np.isnan(self.undef_in) else (r == undef_as(self.raw.dtype, self.undef_in))) | (r == self.undef_tmp)
             v = r if self.scale is None else r * along(self.scale, self, self.scale_dim)
             self._values = np.where(masked, self.undef_tmp, v)
         return self._values

@@ -44,17 +44,31 @@ def scalars(p):
             b(p['BCx']), p['delxSqr'], p['ratio2Sqr'], p['ratio1Sqr'], p['optArg'], p['undef']]
 
 
+PLAN_FN = {k: v.replace('xinv_', 'xinv_plan_create_') + '_dev' for k, v in FN.items()}
+
+
 class ResidentProblem:
     """Upload once, solve many times.  `members`: optional (lo, hi) block of the batch axis this
-    process owns (batch-axis sharding, xinvert_amd.dist)."""
+    process owns (batch-axis sharding, xinvert_amd.dist).
 
-    def __init__(self, p, device=0, members=None, null_zero_B=True):
+    plan=True (default): every `solve()` runs on a resident PLAN (include/xinv.h, xinv_plan_*): what the engine derives
+    from the coefficient stack -- is B zero, which arrays are constant along x, per-row records, the forcing's activity
+    map, row split and tile lists -- is built once per set of engine options, on the first solve with them, and kept in
+    HBM next to the stack.  Coefficients that are stride-0 views along x (the lat-lon builders of apps.py) are uploaded
+    as ONE value per row (rowconst_mask): the plan expands them on the device and never has to test them.
+    The coefficient arrays (and the forcing's set of undefined points) must not change while the object lives; after
+    writing into `coefs[k]` call `refresh()`.  plan=False: every solve goes through xinv_<form>_f64_dev and re-derives
+    all of it (what rounds 1-4 did)."""
+
+    def __init__(self, p, device=0, members=None, null_zero_B=True, plan=True):
         import torch
         self.L = _lib.require_gpu()
         self.kind = p['kind']
         self.p = {k: v for k, v in p.items() if k not in ('S0', 'coefs')}
         self.dev = torch.device('cuda', device)
         self.device = device
+        self.use_plan = bool(plan)
+        self._plans = {}
         S0 = np.asarray(p['S0'])
         core_nd = 3 if self.kind in ('std3d', 'gen3d') else 2
         if S0.ndim == core_nd:
@@ -64,38 +78,89 @@ class ResidentProblem:
         self.nb = hi - lo
         self.core = S0.shape[1:]
         self.n = int(np.prod(self.core))
+        self.rows = self.n // self.core[-1]
         shared = tuple(p.get('shared', ()))
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.dev)
         self.S0 = up(S0[lo:hi])
         self.S = self.S0.clone()
         self.coefs, strides = [], [self.n]
+        self.rowconst = 0                                    # bit k: coefs[k] holds one value per row
+        ncoef = len(p['coefs'])
         for k, c in enumerate(p['coefs']):
             c = np.asarray(c)
-            if k in shared or c.ndim == core_nd:
+            is_shared = k in shared or c.ndim == core_nd
+            # a stride-0 view along x (lat-lon coefficients: functions of latitude): only the rows travel
+            rc = self.use_plan and k < ncoef - 1 and c.strides[-1] == 0 and c.shape[-1] > 1
+            if is_shared:
                 # the cross coefficient B of the 2-D standard / general forms travels as NULL when it
                 # is identically zero, exactly as the front end hands it over (core._prep_coef)
                 if null_zero_B and k == 1 and self.kind in ('std2d', 'gen2d') and not c.any():
                     self.coefs.append(None)
+                elif rc:
+                    self.coefs.append(up(c[..., 0])); self.rowconst |= 1 << k
                 else:
                     self.coefs.append(up(c))
                 strides.append(0)
+            elif rc:
+                self.coefs.append(up(c[lo:hi][..., 0])); self.rowconst |= 1 << k
+                strides.append(self.rows)
             else:
                 self.coefs.append(up(c[lo:hi]))
                 strides.append(self.n)
+        self._strides = list(strides)
         self.strides = _lib.strides_arg(strides)
         self.flags = np.tile(np.array([0., 1., 0.]), (self.nb, 1))
         torch.cuda.synchronize(self.dev)
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def close(self):
+        """Destroy the plans (their HBM: per-row records, tile lists, expanded row-constant coefficients)."""
+        plans, self._plans = getattr(self, '_plans', {}), {}
+        for h in plans.values():
+            self.L.xinv_plan_destroy(h)
+
     def reset(self):
         self.S.copy_(self.S0)
+
+    def refresh(self):
+        """The coefficient arrays (or the forcing's mask) were changed in place: re-derive every plan."""
+        import torch
+        st = torch.cuda.current_stream(self.dev)
+        for h in self._plans.values():
+            _lib.check(self.L.xinv_plan_refresh(h, ctypes.c_void_p(st.cuda_stream)))
+
+    def _plan(self, opt, st):
+        key = tuple(sorted(opt.items()))
+        h = self._plans.get(key)
+        if h is None:
+            o = _lib.options(device=self.device, rowconst_mask=self.rowconst, **opt)
+            ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+            h = ctypes.c_void_p()
+            rc = getattr(self.L, PLAN_FN[self.kind])(
+                ctypes.byref(h), *[ptr(c) for c in self.coefs], self.nb, self.strides, *scalars(self.p),
+                ctypes.byref(o), ctypes.c_void_p(st.cuda_stream))
+            _lib.check(rc)
+            self._plans[key] = h
+        return h
 
     def solve(self, mxLoop, tolerance, stream=None, **opt):
         """One call of the hot path on the resident batch: S is updated in place (restartable, as
         the reference's kernels).  Returns (flags [nb, 3], stats)."""
         import torch
-        o = _lib.options(device=self.device, **opt)
         st = stream if stream is not None else torch.cuda.current_stream(self.dev)
         self.flags[:] = np.array([0., 1., 0.])
+        if self.use_plan:
+            h = self._plan(opt, st)
+            rc = self.L.xinv_plan_solve_f64_dev(h, ctypes.c_void_p(self.S.data_ptr()), _lib.hptr(self.flags),
+                                                int(mxLoop), float(tolerance), ctypes.c_void_p(st.cuda_stream))
+            _lib.check(rc)
+            return self.flags, _lib.last_stats()
+        o = _lib.options(device=self.device, **opt)
         ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         rc = getattr(self.L, FN[self.kind] + '_dev')(
             ptr(self.S), *[ptr(c) for c in self.coefs], self.nb, self.strides, *scalars(self.p),
