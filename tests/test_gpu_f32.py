@@ -30,7 +30,7 @@ def _call(ps, mx, tol, f32_mask, shared=(), S_f32=False, **opt):
             arrs.append(np.ascontiguousarray(np.stack([q['coefs'][k] for q in ps]), dtype=dt(k + 1))); strides.append(n)
     fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
     o = _lib.options(f32_mask=f32_mask, **opt)
-    rc = getattr(L, util._FN[p['kind']] + '_batched')(*[_lib.hptr(a) for a in arrs], nb, _lib.strides_arg(strides),
+    rc = getattr(L, util._FN[p['kind']] + '_batched')(*[_lib.hptr(a, f32=bool((f32_mask >> k) & 1)) for k, a in enumerate(arrs)], nb, _lib.strides_arg(strides),
                                                     *util._scal(p, fl, mx, tol), ctypes.byref(o))
     _lib.check(rc)
     return S, fl, _lib.last_stats()
@@ -88,7 +88,7 @@ def test_f32_shared_rowconst_and_strided_members():
     C = np.ascontiguousarray(ps[0]['coefs'][2], dtype=np.float32)
     fl = np.tile(np.array([0., 1., 0.]), (3, 1))
     o = _lib.options(f32_mask=0b11110, rowconst_mask=1)
-    rc = L.xinv_standard_2d_f64_batched(_lib.hptr(S), _lib.hptr(Arow), _lib.hptr(B), _lib.hptr(C), _lib.hptr(Fbuf), 3,
+    rc = L.xinv_standard_2d_f64_batched(_lib.hptr(S), _lib.hptr(Arow, f32=True), _lib.hptr(B, f32=True), _lib.hptr(C, f32=True), _lib.hptr(Fbuf, f32=True), 3,
                                         _lib.strides_arg([n, 0, 0, 0, pad]), *util._scal(ps[0], fl, 30, 0.0), ctypes.byref(o))
     _lib.check(rc)
     assert np.array_equal(S, S64) and np.array_equal(fl, f64)

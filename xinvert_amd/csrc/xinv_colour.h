@@ -642,16 +642,19 @@ __global__ __launch_bounds__(256) void k_demask(double *S, const double *F, int6
         if (F[i] == undef_tmp) S[i] = value;
 }
 
-__global__ void k_ctl_init(XinvCtl *ctl, int64_t nbatch)
+// control blocks at the start of a solve + the norm partials cleared (n16 uint4 words; pbytes is a multiple of 256), grid-stride
+__global__ __launch_bounds__(256) void k_solve_init(XinvCtl *ctl, int64_t nbatch, uint4 *part, int64_t n16)
 {
-    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nbatch) return;
-    XinvCtl c;
-    c.normPrev = DBL_MAX;
-    c.flag1 = 0.0; c.flag2 = 0.0;
-    c.loop = 0; c.sweeps = 0;
-    c.done = 0; c.overflow = 0; c.wrote = 0; c.ticket = 0; c.seq = 1; c.pad_ = 0;
-    ctl[m] = c;
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+    for (int64_t m = t0; m < nbatch; m += nt) {
+        XinvCtl c;
+        c.normPrev = DBL_MAX;
+        c.flag1 = 0.0; c.flag2 = 0.0;
+        c.loop = 0; c.sweeps = 0;
+        c.done = 0; c.overflow = 0; c.wrote = 0; c.ticket = 0; c.seq = 1; c.pad_ = 0;
+        ctl[m] = c;
+    }
+    for (int64_t i = t0; i < n16; i += nt) part[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // Watchdog recovery (run_sweeps): the member goes on from the control state the timed-out reducer left untouched.

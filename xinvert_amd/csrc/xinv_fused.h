@@ -1190,9 +1190,16 @@ struct SkipNormArgs {
     long long *tcnt;
     double *xsum;              // [nbatch]
     long long *xcnt;
+    unsigned *ticket;          // [nbatch], zero between solves: k_skip_tiles' arrival counter (the last block of a member sums)
 };
 
-__global__ __launch_bounds__(64) void k_skip_norm_tile(SkipNormArgs a)
+// One wavefront per skipped tile: its sum |S| and count over its owned points with S != undef; its owned region copied
+// into the buffers S rotates through (the skipped tiles are never written by the sweep launches: every buffer must hold
+// the caller's S there); and the block that arrives last at the member's ticket adds the tiles' shares (fixed order)
+// into xsum / xcnt and leaves the ticket at zero for the next solve.  ONE launch since round 5 (k_skip_norm_tile,
+// k_skip_norm_sum and k_copy_skipped until round 4: three dependent dispatches, ~32 us + the gaps between them, on the
+// path to a solve's second sweep launch; same loads, same order of additions, same bits).
+__global__ __launch_bounds__(64) void k_skip_tiles(SkipNormArgs a, double *D1, double *D2)
 {
     const int lane = threadIdx.x;
     const int64_t m = blockIdx.y;
@@ -1200,13 +1207,11 @@ __global__ __launch_bounds__(64) void k_skip_norm_tile(SkipNormArgs a)
     double acc = 0.0; long long cnt = 0;
     if (wt >= 0) {
         const TileRows tr = xinv_tile_rows(wt, a.nstrip, a.nrb, a.nsplit, a.yc, a.RB);
-        const int strip = tr.strip;
         const int64_t yu0 = tr.y0, yu1 = tr.y1;
-        const int64_t c0 = (int64_t)strip * a.UW;
+        const int64_t c0 = (int64_t)tr.strip * a.UW;
         const int64_t c1 = (c0 + a.UW < a.xc) ? c0 + a.UW : a.xc;
         const double *S = a.S + m * a.sS;
-        // (four rows' loads in flight at a time, added in the same order as one by one: the loop was a chain of ~90
-        //  dependent memory round trips per tile, 35 us per solve at 3600x1800; a tile is at most 256 columns wide)
+        double *d1 = D1 + m * a.sS, *d2 = D2 ? D2 + m * a.sS : nullptr;
         for (int64_t j = yu0; j < yu1; j += 4) {
             double v[4][4];
 #pragma unroll
@@ -1222,48 +1227,34 @@ __global__ __launch_bounds__(64) void k_skip_norm_tile(SkipNormArgs a)
             for (int q = 0; q < 4; q++)
                 if (j + q < yu1) {
 #pragma unroll
-                    for (int h = 0; h < 4; h++)
+                    for (int h = 0; h < 4; h++) {
+                        const int64_t i = c0 + lane + 64 * h;
+                        if (i < c1) { d1[(j + q) * a.xc + i] = v[q][h]; if (d2) d2[(j + q) * a.xc + i] = v[q][h]; }
                         if (v[q][h] != a.undef) { acc += fabs(v[q][h]); cnt++; }
+                    }
                 }
         }
     }
     acc = xinv_wave_sum(acc);
     cnt = xinv_wave_sum_ll(cnt);
-    if (lane == 0) { a.tsum[m * a.nskip_max + blockIdx.x] = acc; a.tcnt[m * a.nskip_max + blockIdx.x] = cnt; }
-}
-
-// The skipped tiles are never written by the sweep launches: every buffer S rotates through must hold the caller's S
-// there.  Copies the owned region of each skipped tile into one or two buffers (instead of two whole-array copies per
-// solve: 35 us of a 4.6 ms headline solve for a quarter of the tiles).
-__global__ __launch_bounds__(256) void k_copy_skipped(SkipNormArgs a, double *D1, double *D2)
-{
-    const int64_t m = blockIdx.y;
-    const int wt = a.skip_list[m * a.nskip_max + blockIdx.x];
-    if (wt < 0) return;
-    const TileRows tr = xinv_tile_rows(wt, a.nstrip, a.nrb, a.nsplit, a.yc, a.RB);
-    const int64_t c0 = (int64_t)tr.strip * a.UW;
-    const int64_t c1 = (c0 + a.UW < a.xc) ? c0 + a.UW : a.xc;
-    const double *S = a.S + m * a.sS;
-    D1 += m * a.sS;
-    if (D2) D2 += m * a.sS;
-    const int64_t w = c1 - c0;
-    for (int64_t t = threadIdx.x; t < (tr.y1 - tr.y0) * w; t += 256) {
-        const int64_t j = tr.y0 + t / w, i = c0 + t % w;
-        const double v = S[j * a.xc + i];
-        D1[j * a.xc + i] = v;
-        if (D2) D2[j * a.xc + i] = v;
+    __shared__ unsigned s_last;
+    if (lane == 0) {
+        a.tsum[m * a.nskip_max + blockIdx.x] = acc; a.tcnt[m * a.nskip_max + blockIdx.x] = cnt;
+        __threadfence();                                   // (the shares are visible before the ticket counts this block)
+        const unsigned t = atomicAdd(a.ticket + m, 1u);
+        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
     }
-}
-
-__global__ __launch_bounds__(64) void k_skip_norm_sum(SkipNormArgs a)
-{
-    const int lane = threadIdx.x;
-    const int64_t m = blockIdx.x;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
     double ps = 0.0; long long pc = 0;
-    for (int t = lane; t < a.nskip_max; t += 64) { ps += a.tsum[m * a.nskip_max + t]; pc += a.tcnt[m * a.nskip_max + t]; }
+    for (int t = lane; t < a.nskip_max; t += 64) {
+        ps += __hip_atomic_load(a.tsum + m * a.nskip_max + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pc += __hip_atomic_load(a.tcnt + m * a.nskip_max + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     ps = xinv_wave_sum(ps);
     pc = xinv_wave_sum_ll(pc);
-    if (lane == 0) { a.xsum[m] = ps; a.xcnt[m] = pc; }
+    if (lane == 0) { a.xsum[m] = ps; a.xcnt[m] = pc; a.ticket[m] = 0u; }
 }
 
 // ---- detection of x-uniform coefficient rows (once per solve) -----------------------------

@@ -5,7 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 //
 // Control flow of one solve (all batch members together, one stream):
-//   k_ctl_init -> [ sweep launches ... ] x check_every -> async read-back of the per-member
+//   k_solve_init -> [ sweep launches ... ] x check_every -> async read-back of the per-member
 //   control blocks -> repeat until every member has stopped.  The stopping rule runs on the
 //   device after every sweep (reducing workgroup / k_norm_final); once a member is done
 //   every later launch is a no-op for it, so S holds exactly the sweep the reference stops at.
@@ -531,6 +531,7 @@ struct SweepRun {
     double *S2 = nullptr;
     double *buf[3] = {nullptr, nullptr, nullptr};
     int nbuf = 2;                                        // 3 with the lagged norm
+    std::vector<signed char> srcb, dstb;                 // launch i swept buf[srcb[i]] into buf[dstb[i]] (see launch_idx)
     bool lag = false;
     std::vector<int64_t> bound;                          // bound[i] = sweeps before launch i (fused path)
     int64_t launched = 0, nlaunch = 0;
@@ -635,8 +636,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     ws->partials_half = pbytes;
     rc = ensure_dev(&ws->partials, &ws->partials_cap, lag_cand ? 2 * pbytes : pbytes);
     if (rc) return rc;
-    if (pl.path == XINV_PATH_FUSED)                              // tagged partials: no stale sequence numbers
-        HIPCHK(hipMemsetAsync(ws->partials, 0, lag_cand ? 2 * pbytes : pbytes, st));
+    const size_t pclear = (pl.path == XINV_PATH_FUSED) ? (lag_cand ? 2 * pbytes : pbytes) : 0;   // tagged partials: no stale sequence numbers
     double *&S2 = R.S2;
     if (pl.path == XINV_PATH_COLOUR && p.kind == KIND_BIH2D) {       // side buffer of the row-class kernel
         rc = ensure_dev(&ws->S2, &ws->S2_cap, (size_t)((p.nbatch - 1) * p.sS + n) * sizeof(double));
@@ -649,7 +649,9 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         S2 = ws->S2;
     }
 
-    hipLaunchKernelGGL(k_ctl_init, dim3(cdiv(p.nbatch, 256)), dim3(256), 0, st, ws->ctl, p.nbatch);
+    // (control blocks and partials in ONE launch: a dispatch less on the way to the first sweep launch)
+    hipLaunchKernelGGL(k_solve_init, dim3((unsigned)std::max<int64_t>(cdiv(p.nbatch, 256), std::min<int64_t>(256, cdiv((int64_t)(pclear / 16), 256)))),
+                       dim3(256), 0, st, ws->ctl, p.nbatch, (uint4 *)ws->partials, (int64_t)(pclear / 16));
 
     // ---- sweep loop ----------------------------------------------------------------------------
     const int64_t max_sweeps = p.stop.mxLoop + 1;       // numbas.py:410: loop >= mxLoop stops
@@ -666,6 +668,10 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         //  launch + control-block copy, ~10 us of idle GPU -- 4 % of the solve)
         const double est_us = std::max(4.0, est_pass_us);
         check_every = (int)std::min(256.0, std::max(4.0, 2000.0 / est_us));
+        // (a non-positive tolerance can never stop a solve -- the reference tests' idiom for a fixed number of sweeps,
+        //  tests/test_GeoAdjustment.py:31 -- only an overflow or, in the standard form, a zero norm can: nothing worth a
+        //  poll every 2 ms, each of which holds the next launch back for ~10 us)
+        if (p.stop.tolerance <= 0.0 && pl.path == XINV_PATH_FUSED) check_every = 256;
     }
     R.buf[0] = p.S; R.buf[1] = S2; R.buf[2] = nullptr;
     double **buf = R.buf;
@@ -742,9 +748,9 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             HIPCHK(hipStreamWaitEvent(ws->s_side, ws->ev_side0, 0));
             sk = ws->s_side;
         }
-        hipLaunchKernelGGL(k_skip_norm_tile, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(64), 0, sk, pl.skipna);
-        hipLaunchKernelGGL(k_skip_norm_sum, dim3((unsigned)p.nbatch, 1, 1), dim3(64), 0, sk, pl.skipna);
-        hipLaunchKernelGGL(k_copy_skipped, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(256), 0, sk,
+        // (one launch: every skipped tile's share of the norm, its copy into the other buffers, and -- by the block that
+        //  arrives last -- the member's sum; k_skip_norm_tile / k_skip_norm_sum / k_copy_skipped until round 4)
+        hipLaunchKernelGGL(k_skip_tiles, dim3((unsigned)pl.nskip, (unsigned)p.nbatch, 1), dim3(64), 0, sk,
                            pl.skipna, S2, lag ? ws->S3 : (double *)nullptr);
         HIPCHK(hipGetLastError());
         if (sk != st) { HIPCHK(hipEventRecord(ws->ev_side1, sk)); side_pending = true; }
@@ -765,11 +771,16 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     const bool two = nlane > 1;
     R.lanes = nlane;
     auto lane_first = [&](int l) { return p.nbatch * l / nlane; };   // members [lane_first(l), lane_first(l+1))
+    // With several chains the host's polls of the control blocks are copies on a stream of their own, behind an event of
+    // every chain.  (ONE chain keeps its polls on its own stream: with the copies on a second stream -- built in round 5 to
+    // spare the ~10 us a copy holds the next launch back -- every sweep launch of the chain took 1 us longer, 35.0 ->
+    // 36.0 us at 3600x1800, profiles/r05_solve_overhead.txt: a second active queue costs more than three polls.)
+    const bool side_poll = two;
     struct LaneGuard {                                   // no return path leaves the side streams running
-        Workspace *w; int n;
-        ~LaneGuard() { if (n > 1) { for (int l = 1; l < n; l++) (void)hipStreamSynchronize(w->s_lane[l]); (void)hipStreamSynchronize(w->s_poll); } }
-    } lane_guard{ws, nlane};
-    if (two) {
+        Workspace *w; int n; bool poll;
+        ~LaneGuard() { for (int l = 1; l < n; l++) (void)hipStreamSynchronize(w->s_lane[l]); if (poll) (void)hipStreamSynchronize(w->s_poll); }
+    } lane_guard{ws, nlane, side_poll};
+    if (side_poll) {
         if (!ws->s_poll) {
             for (int l = 1; l < XINV_MAX_LANES; l++) HIPCHK(hipStreamCreateWithFlags(&ws->s_lane[l], hipStreamNonBlocking));
             HIPCHK(hipStreamCreateWithFlags(&ws->s_poll, hipStreamNonBlocking));
@@ -777,10 +788,23 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
                 for (int q = 0; q < 2; q++) HIPCHK(hipEventCreateWithFlags(&ws->ev_lane[l][q], hipEventDisableTiming));
             HIPCHK(hipEventCreate(&ws->ev_s));
         }
+    }
+    if (two) {
         HIPCHK(hipEventRecord(ws->ev_s, st));            // fork: everything queued so far (workspace set-up) precedes every chain
         for (int l = 1; l < nlane; l++) HIPCHK(hipStreamWaitEvent(ws->s_lane[l], ws->ev_s, 0));
     }
-    // launch number i of the solve (fused path): k sweeps from buf[i % nbuf] into buf[(i+1) % nbuf]
+    // Launch number i of the solve (fused path): k sweeps from buf[srcb[i]] into buf[dstb[i]]; srcb[0] = 0 (the caller's
+    // S), srcb[i] = dstb[i-1].  Two buffers (no lagged norm): ping-pong.  Three (lagged norm): the decision about pass
+    // i-1 arrives while pass i runs, so pass i must leave the source of pass i-1 intact (finalise() redoes a pass the
+    // stop rule fired in from it): dstb[i] is the buffer that is neither srcb[i] nor srcb[i-1] -- a rotation.  Where
+    // the rotation ends decides whether finalise() has to copy the result back into the caller's array (52 MB at
+    // 3600x1800: ~30 us of a 4.3 ms solve).  Evaluating the pending pass BEFORE launch i (flush_lag: one small kernel)
+    // lifts the constraint for that launch -- pass i is then a no-op for a member that stopped in pass i-1 -- and it
+    // may write into srcb[i-1], which REVERSES the rotation: with nl launches to the sweep budget, forward for f and
+    // backward for nl - f ends in buffer (2 f - nl) mod 3, so one reversal at f = nl - 1 (nl mod 3 == 2) or nl - 2
+    // (nl mod 3 == 1) brings an un-converged solve home to buffer 0.  A solve that stops earlier copies, as before.
+    const int64_t nl_budget = (max_sweeps + Kf - 1) / Kf;
+    const int64_t flip_at = (!lag || nl_budget % 3 == 0) ? -1 : (nl_budget % 3 == 2 ? nl_budget - 1 : nl_budget - 2);
     int64_t wd_at = -1, wd_member = 0;
 #if XINV_TEST_HOOKS
     // TEST-HOOKS BUILD ONLY (build/libxinv_hooks.so; the shipped library reads neither switch):
@@ -806,6 +830,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         }
     }
 #endif
+    std::function<int()> flush_lag;                      // (defined below; launch_idx flushes before a rotation reversal)
     auto launch_idx = [&](int64_t i, int k) -> int {
 #if XINV_TEST_HOOKS
         if (i == wd_at) {                                // (on the stream of the member's lane: ordered before ITS launch i)
@@ -814,8 +839,17 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             hipLaunchKernelGGL(k_ctl_fake_timeout, dim3(1), dim3(1), 0, l ? ws->s_lane[l] : st, ws->ctl + wd_member);
         }
 #endif
-        const double *src = buf[i % R.nbuf];
-        double *dst = buf[(i + 1) % R.nbuf];
+        const int sb = (i == 0) ? 0 : R.dstb[(size_t)i - 1];
+        int db;
+        if (R.nbuf == 2) db = sb ^ 1;
+        else if (i == 0) db = 1;
+        else if (i == flip_at) {                         // (the pending pass is evaluated first: its source is free)
+            const int r = flush_lag(); if (r) return r;
+            db = R.srcb[(size_t)i - 1];
+        } else db = 3 - sb - R.srcb[(size_t)i - 1];
+        R.srcb.push_back((signed char)sb); R.dstb.push_back((signed char)db);
+        const double *src = buf[sb];
+        double *dst = buf[db];
         if (i >= 1) { const int r = side_join(); if (r) return r; }
         if (exp_noctl == 2)                              // (timing experiment: publish only, nobody reduces)
             return launch_fused(p, pl, k, src, dst, ws, st, 0, p.nbatch, 1, 0, (unsigned)(i + 1), nullptr);
@@ -837,7 +871,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     };
     // the last launch of a chunk has no successor yet: its norm is evaluated by a one-workgroup kernel
     // before the control blocks are copied for the host
-    auto flush_lag = [&]() -> int {
+    flush_lag = [&]() -> int {
         if (!lag) return XINV_OK;
         { const int r = side_join(); if (r) return r; }
         for (int l = 0; l < nlane; l++) {
@@ -860,7 +894,10 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             (pl.path != XINV_PATH_FUSED || (bound.size() & 1) == 0)) {
             HIPCHK(hipGraphLaunch(R.graph_exec, st));
             for (int i = 0; i < check_every; i++) {
-                if (pl.path == XINV_PATH_FUSED) bound.push_back(launched);
+                if (pl.path == XINV_PATH_FUSED) {       // (the captured chunk ping-pongs from buffer 0: launch_one)
+                    bound.push_back(launched);
+                    R.srcb.push_back((signed char)(i & 1)); R.dstb.push_back((signed char)((i & 1) ^ 1));
+                }
                 launched += Kf;
                 nlaunch++;
             }
@@ -889,13 +926,17 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             }
             nlaunch++;
         }
-        { int r = flush_lag(); if (r) return r; }
-        if (two) {                                       // neither chain waits for the other: the copy does, on its own stream
+        // (the last pass of a chunk has no successor yet to evaluate its norm: a one-workgroup kernel does -- at the end of
+        //  the sweep budget only; the last pass of an earlier chunk is evaluated by the first launch of the next chunk like
+        //  any other, and the host sees its decision one poll later)
+        if (launched >= max_sweeps) { int r = flush_lag(); if (r) return r; }
+        if (side_poll) {                                 // no chain waits for the copy (or for another chain): it has its own stream
+            if (opt.timing && !two) HIPCHK(hipEventRecord(ws->ev1[slot], st));
             for (int l = 0; l < nlane; l++) {
                 HIPCHK(hipEventRecord(ws->ev_lane[l][slot], l ? ws->s_lane[l] : st));
                 HIPCHK(hipStreamWaitEvent(ws->s_poll, ws->ev_lane[l][slot], 0));
             }
-            if (opt.timing) HIPCHK(hipEventRecord(ws->ev1[slot], ws->s_poll));
+            if (opt.timing && two) HIPCHK(hipEventRecord(ws->ev1[slot], ws->s_poll));
             HIPCHK(hipMemcpyAsync(ws->hctl + (size_t)slot * p.nbatch, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl),
                                   hipMemcpyDeviceToHost, ws->s_poll));
             HIPCHK(hipEventRecord(ws->evc[slot], ws->s_poll));
@@ -910,6 +951,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     };
     const XinvCtl *&hc = R.hc;
     hc = ws->hctl;
+    bool more_at_break = false;
     rc = issue_chunk(0);
     if (rc) return rc;
     for (int c = 0;; c++) {
@@ -925,11 +967,13 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         hc = ws->hctl + (size_t)slot * p.nbatch;
         all_done = true;
         for (int64_t m = 0; m < p.nbatch; m++) all_done = all_done && hc[m].done;
-        if (all_done || !more) break;
+        if (all_done || !more) { more_at_break = more; break; }
     }
-    if (two) {
-        // join: everything below runs on the caller's stream.  The copies above were taken while later launches ran; a
-        // stopped member's block no longer changes, but the final blocks are read again behind both chains.
+    if (side_poll && (two || more_at_break)) {
+        // join: everything below runs on the caller's stream.  The copies above were taken while later launches ran (a
+        // block caught in the middle of a reducer's update may be torn); a stopped member's block no longer changes, and
+        // the final blocks are read again behind every chain.  (One chain that ran to its sweep budget: the last copy sits
+        // behind the last launch and its closing reduction -- nothing to read again.)
         HIPCHK(hipStreamWaitEvent(st, ws->evc[last_slot], 0));   // (recorded behind every lane's last chunk)
         HIPCHK(hipMemcpyAsync(ws->hctl, ws->ctl, (size_t)p.nbatch * sizeof(XinvCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -974,7 +1018,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             na.pcnt = (long long *)((char *)ws->wd_part + XINV_NORM_BLOCKS * sizeof(double)) - m * XINV_NORM_BLOCKS;
             na.ctl = ws->ctl; na.stop = p.stop; na.force = 0; na.member0 = m;
             const int nblk = (int)std::min<int64_t>(XINV_NORM_BLOCKS, std::max<int64_t>(1, n / 2048));
-            const int b0 = (int)(i % R.nbuf), b1 = (int)((i + 1) % R.nbuf);
+            const int b0 = R.srcb[i], b1 = R.dstb[i];
             int a = b0, b = b1;
             int64_t s = L;
             bool fin = false;
@@ -1034,6 +1078,7 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
             // launch i covers sweeps (bound[i], bound[i+1]]; find the one holding sweep `sw`
             size_t i = std::upper_bound(bound.begin(), bound.end(), sw - 1) - bound.begin() - 1;
             const int nbuf = R.nbuf;
+            if (i >= R.dstb.size()) { t_err = "internal: final sweep outside the launches issued"; return XINV_ERR_HIP; }
             int where;                                   // buffer index holding the final state
             // The biharmonic kernel's 'extend' pre-pass (k_extend_bih) works IN PLACE on the source buffer of its launch.
             // With the lagged norm the decision about pass i arrives while pass i+1 runs: that pass's pre-pass has then
@@ -1043,15 +1088,16 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
             // but pass i's own pre-pass -- not applied again: the periodic one (r0 <- r1, then r1 <- r2) is not idempotent.
             const bool prepass_hit = R.lag && p.kind == KIND_BIH2D && p.BCy == XINV_BC_EXTEND && i + 2 < bound.size();
             if (bound[i + 1] == sw && !prepass_hit) {
-                where = (int)((i + 1) % nbuf);
+                where = R.dstb[i];
             } else {                                     // stopped inside a K-sweep launch: redo from its source
-                int cur = (int)(i % nbuf);               // (intact: with the lagged norm the passes after i+1 did nothing)
-                int nxt = (int)((i + 1) % nbuf);         // the pass's own output: free to overwrite
-                const int spare = (nbuf == 3) ? (int)((i + 2) % nbuf) : cur;
+                const int src0 = R.srcb[i];
+                int cur = src0;                          // (intact: with the lagged norm the passes after i+1 did nothing)
+                int nxt = R.dstb[i];                     // the pass's own output: free to overwrite
+                const int spare = (nbuf == 3) ? 3 - cur - nxt : cur;
                 for (int64_t s = bound[i]; s < sw; s++) {
                     rc = launch_planned(p, pl, ws, st, 1, buf[cur], buf[nxt], m, 1, 1, 1, 0, nullptr, nullptr, !prepass_hit);
                     if (rc) return rc;
-                    const int t = cur; cur = nxt; nxt = (nbuf == 3 && t == (int)(i % nbuf)) ? spare : t;
+                    const int t = cur; cur = nxt; nxt = (nbuf == 3 && t == src0) ? spare : t;
                 }
                 where = cur;
             }

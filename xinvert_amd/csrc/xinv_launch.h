@@ -24,7 +24,7 @@ struct Plan {
     bool even_split;         // rows split evenly over nrb row blocks (RY = average height)
     bool nine;               // 9-point form on the fused 4-colour kernel
     bool skip;               // masked-tile skipping: launches of K == Plan::K run the listed tiles only
-    SkipNormArgs skipna;     // (the skipped tiles' geometry and list: k_copy_skipped in run_sweeps)
+    SkipNormArgs skipna;     // (the skipped tiles' geometry and list: k_skip_tiles in run_sweeps)
     int ntl, nskip;          // list entries per member (active, multiple of 4 / skipped)
     int skip_pct;            // share of wave-tiles skipped, percent
     int skip_ppm;            // ... per million
@@ -711,9 +711,10 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     }
     HIPCHK(hipMemcpyAsync(ws->d_list, ws->h_list, nints * sizeof(int), hipMemcpyHostToDevice, st));
     const size_t nt = (size_t)nb * nskip;
-    rc = ensure_dev(&ws->d_tsum, &ws->d_tsum_cap,
-                    (nt + (size_t)nb) * (sizeof(double) + sizeof(long long)));
+    const size_t tsum_bytes = (nt + (size_t)nb) * (sizeof(double) + sizeof(long long));
+    rc = ensure_dev(&ws->d_tsum, &ws->d_tsum_cap, tsum_bytes + (size_t)nb * sizeof(unsigned));
     if (rc) return rc;
+    HIPCHK(hipMemsetAsync((char *)ws->d_tsum + tsum_bytes, 0, (size_t)nb * sizeof(unsigned), st));   // k_skip_tiles' tickets
     SkipNormArgs na;
     na.S = p.S; na.sS = p.sS; na.yc = yc; na.xc = p.xc; na.nstrip = nstrip; na.nrb = best; na.UW = UW; na.RB = fixedRB;
     na.nsplit = nsplit;
@@ -723,6 +724,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     na.tcnt = (long long *)(base + nt * sizeof(double));
     na.xsum = (double *)(base + nt * (sizeof(double) + sizeof(long long)));
     na.xcnt = (long long *)(base + nt * (sizeof(double) + sizeof(long long)) + (size_t)nb * sizeof(double));
+    na.ticket = (unsigned *)(base + tsum_bytes);
     pl.skipna = na;                                      // (the skipped tiles' norm share and their copies: run_sweeps)
 
     pl.skip = true; pl.ntl = ntl; pl.nskip = nskip;

@@ -80,7 +80,9 @@ class ResidentProblem:
         self.n = int(np.prod(self.core))
         self.rows = self.n // self.core[-1]
         shared = tuple(p.get('shared', ()))
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.dev)
+        def up(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            return torch.from_numpy(a if a.flags.writeable else a.copy()).to(self.dev)    # (a view of a broadcast array is read-only)
         self.S0 = up(S0[lo:hi])
         self.S = self.S0.clone()
         self.coefs, strides = [], [self.n]
