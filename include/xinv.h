@@ -71,6 +71,11 @@ extern "C" {
                                     one wavefront (k_fused2d) instead of pipelining them across the four
                                     wavefronts of a workgroup (k_pipe2d)                          */
 
+#define XINV_FLAG_NO_POINT_FACTOR 64 /* general 2-D form with coefficients varying along x: divide and test the operands in
+                                    the kernel whenever a row enters a window, as rounds 1-4 did, instead of reading the
+                                    point's relaxation factor / update predicate from a stream evaluated once per
+                                    coefficient stack (same expression, same bits)                                    */
+
 #define XINV_MAX_DEVICES 16
 
 typedef struct xinv_options {

@@ -176,14 +176,15 @@ def check(rc):
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
             timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0,
             host_chunk=0, devices=None, prep=None, pin_host=0, no_pipe=0, fma=0, f32_mask=0,
-            lanes=0, norm_lag=0, pipe_fr=0, graph=0):
+            lanes=0, norm_lag=0, pipe_fr=0, graph=0, no_point_factor=0):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
     o.check_every, o.rows_per_tile, o.timing = check_every, rows_per_tile, timing
     # XINV_FLAG_NO_XUNIFORM | XINV_FLAG_NO_TILE_SKIP | XINV_FLAG_FORCE_TILE_SKIP
     o.flags = (1 if no_xuniform else 0) | (2 if no_tile_skip else 0) | (4 if force_tile_skip else 0) | \
-              (8 if pin_host else 0) | (16 if no_pipe else 0) | (32 if fma else 0)     # ... | XINV_FLAG_PIN_HOST | XINV_FLAG_NO_PIPE | XINV_FLAG_FMA
+              (8 if pin_host else 0) | (16 if no_pipe else 0) | (32 if fma else 0) | \
+              (64 if no_point_factor else 0)      # ... | XINV_FLAG_PIN_HOST | XINV_FLAG_NO_PIPE | XINV_FLAG_FMA | XINV_FLAG_NO_POINT_FACTOR
     o.rowconst_mask = int(rowconst_mask)
     o.host_chunk = int(host_chunk)
     o.f32_mask = int(f32_mask)

@@ -35,6 +35,8 @@ UNITS = [
     # contracted arithmetic (XINV_FLAG_FMA): the per-row-coefficient variants on the F models
     ('xinv_tu_fused2d_stdf', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=3']),
     ('xinv_tu_fused2d_genf', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=4']),
+    # general form with coefficient arrays that vary along x: the point-factor stream (FusedGen2DQ, round 5)
+    ('xinv_tu_fused2d_genq', 'xinv_tu_fused2d.hip', ['-DXINV_TU_MODEL=5']),
     ('xinv_tu_pipe2d_fma', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=2']),
     ('xinv_tu_pipe2d_std_seam', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=0', '-DXINV_TU_SEAM=1']),
     ('xinv_tu_pipe2d_gen_seam', 'xinv_tu_pipe2d.hip', ['-DXINV_TU_MODEL=1', '-DXINV_TU_SEAM=1']),
@@ -190,7 +192,7 @@ def fresh(tag=TAG, extra=EXTRA, variant_units=VARIANT_UNITS):
 # can make one tile withhold its norm partial (a REAL reducer timeout, with a 30 ms watchdog) or leave a member in the
 # state a timed-out reducer leaves behind.  The shipped library has neither hook nor environment switch.
 HOOKS_TAG = 'hooks'
-HOOKS_UNITS = ['xinv_hip', 'xinv_tu_fused2d_std', 'xinv_tu_fused2d_gen', 'xinv_tu_pipe2d_std']
+HOOKS_UNITS = ['xinv_hip', 'xinv_tu_fused2d_std', 'xinv_tu_fused2d_gen', 'xinv_tu_fused2d_genq', 'xinv_tu_pipe2d_std']
 HOOKS_SO = os.path.join(HERE, '..', 'build', 'libxinv_%s.so' % HOOKS_TAG)
 
 

@@ -32,6 +32,9 @@ XINV_HIDDEN int xinv_launch_fused2d_stdf(bool al, bool ext, unsigned um, int K, 
                                          hipStream_t st, const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_fused2d_genf(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                                          hipStream_t st, const FusedArgs &a, int *occ);
+// general form with coefficient arrays that vary along x and the point-factor stream Q (FusedGen2DQ: um = 0x1c or 0)
+XINV_HIDDEN int xinv_launch_fused2d_genq(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
+                                         hipStream_t st, const FusedArgs &a, int *occ);
 XINV_HIDDEN int xinv_launch_pipe2d_fma(bool gen, unsigned um, bool fr, bool al, bool ext, dim3 grid, hipStream_t st,
                                        const FusedArgs &a, int *occ, int lds_pad);
 // wave-pipelined four-sweep pass, one tile per 256-thread workgroup: standard form (um = 3: A and C per row, np = 1

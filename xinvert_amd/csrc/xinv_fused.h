@@ -513,6 +513,70 @@ struct FusedGen2DF : FusedGen2D {
     }
 };
 
+// ---- general form, coefficients that vary along x (round 5; BASELINE configs[2]: Stommel with R(x, y)).  One more
+// stream Q carries everything of a point that does not change during a solve: its relaxation factor
+// optArg / ((A ratioSqr + C) 2 - F delxSqr) -- the expression FusedGen2D divides by when a row enters the window,
+// evaluated ONCE per coefficient stack (k_point_factor: same expression, same bits; kept by a resident plan) -- and, as
+// Q == 0, the verdict of the update predicate (numbas.py:1126-1129: some operand undefined).  A pass then multiplies and
+// compares instead of dividing and testing six operands per point.  Streams: A, C, D, E, F, Q, G (the forcing last).
+// (On the wave-pipelined pass the same model was measured and not kept: bit-exact, 175-181 VGPRs -- four vector
+//  streams x eight row records --, two workgroups per CU, C3 Stommel 2.6e11 against 3.08e11 for k_fused2d with three
+//  sweeps per pass: profiles/r05_point_factor.txt.)
+// AC: A and C are the same numbers everywhere (an isotropic operator on a Cartesian grid: Stommel, apps.py:1733-1735,
+// found by k_point_factor): C is read out of A's registers, one stream and its window less (the variant runs with bit 1
+// of UM set, so that nothing of C is loaded as a vector).
+template <bool AC> struct FusedGen2DQ_ {
+    static constexpr int NC = 7;
+    static constexpr bool PQ = true;
+    static constexpr int QI = 5;                         // stream index of Q
+    template <unsigned UM> static constexpr bool hoist() { return false; }
+    static constexpr int PIPE_PFR = 1;
+    template <unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ void derive(CoefWin<NC, D> &w, int, int s1, bool okx, bool oky, const XinvScal &)
+    {
+        w.mx[s1] = xinv_lane_word(okx && (w.v[QI][s1].x != 0.0));
+        w.my[s1] = xinv_lane_word(oky && (w.v[QI][s1].y != 0.0));
+    }
+    template <int X, unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ double upd(const CoefWin<NC, D> &w, int sj, int sjp, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 const XinvScal &sc)
+    {
+        const double temp = inc<X, UM, D, PRE>(w, sj, sjp, sC, sP, sM, sW, sE, sc);
+        return xinv_bitsel(X ? w.my[sj] : w.mx[sj], sC + temp, sC);
+    }
+    template <int X, unsigned UM, int D, bool PRE = true>
+    static __device__ __forceinline__ double inc(const CoefWin<NC, D> &w, int sj, int, double sC,
+                                                 double sP, double sM, double sW, double sE,
+                                                 const XinvScal &sc)
+    {
+        const double A = cget<X, UM, 0>(w, sj), C = AC ? A : cget<X, UM, 1>(w, sj);
+        const double Dd = cget<X, UM, 2>(w, sj), E = cget<X, UM, 3>(w, sj);
+        const double F = cget<X, UM, 4>(w, sj), G = cget<X, UM, 6>(w, sj);
+        double temp = (
+            A * (
+                (sP - sC) - (sC - sM)
+            ) * sc.ratioSqr +
+            C * (
+                (sE - sC) - (sC - sW)
+            ) + (
+            Dd * (
+                (sP - sM)
+            ) * sc.ratio +
+            E * (
+                (sE - sW)
+            )) * sc.delx / 2.0 + (
+            F * sC - G) * sc.delxSqr
+        );
+        temp *= cget<X, UM, QI>(w, sj);
+        return temp;
+    }
+};
+using FusedGen2DQ = FusedGen2DQ_<false>;
+using FusedGen2DQA = FusedGen2DQ_<true>;
+template <class M, class = void> struct ModelPQ { static constexpr bool value = false; };
+template <class M> struct ModelPQ<M, std::void_t<decltype(M::PQ)>> { static constexpr bool value = M::PQ; };
+
 template <class M, class = void> struct ModelFma { static constexpr bool value = false; };
 template <class M> struct ModelFma<M, std::void_t<decltype(M::FMA)>> { static constexpr bool value = M::FMA; };
 

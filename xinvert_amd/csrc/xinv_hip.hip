@@ -397,6 +397,27 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             }
         }
         pl.pipe = pipe_want && pl.K == XINV_PIPE_P;
+        // Round 5: the general form with A and C varying along x (Stommel with R(x, y), BASELINE configs[2]) reads the
+        // relaxation factor and the update predicate of every point from one more stream (FusedGen2DQ) instead of dividing
+        // and testing six operands whenever a row enters a window.  XINV_FLAG_NO_POINT_FACTOR keeps FusedGen2D.
+        pl.pq = p.kind == KIND_GEN2D && (pl.um == 0x1cu || pl.um == 0u) && !pl.pipe && !pl.seam && !pl.fma &&
+                !(opt.flags & XINV_FLAG_NO_POINT_FACTOR) && p.sc_.optArg != 0.0;
+        if (pl.pq) {                                     // the point-factor stream, once per coefficient stack
+            rc = ensure_dev(&ws->d_pfac, &ws->d_pfac_cap, (size_t)p.nbatch * p.yc * p.xc * sizeof(double));
+            if (rc) return rc;
+            PointFactorArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.c[0] = p.c[0]; fa.sc[0] = p.sc[0];
+            for (int q = 2; q < 7; q++) { fa.c[q - 1] = p.c[q]; fa.sc[q - 1] = p.sc[q]; }
+            fa.yc = p.yc; fa.xc = p.xc; fa.n = p.yc * p.xc; fa.sc_ = p.sc_; fa.q = ws->d_pfac; fa.flag = ws->dflag;
+            HIPCHK(hipMemsetAsync(ws->dflag, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_point_factor, dim3((unsigned)std::min<int64_t>(2048, cdiv(fa.n, 256)), (unsigned)p.nbatch, 1),
+                               dim3(256), 0, st, fa);
+            HIPCHK(hipMemcpyAsync(ws->hflag, ws->dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (*ws->hflag & 1) pl.pq = false;           // (a factor of exactly zero somewhere: Q == 0 could not mean "skip")
+            pl.alias_ac = pl.pq && !(*ws->hflag & 2);    // A and C bitwise equal everywhere: C is read out of A
+        }
         pl.tpw = pl.pipe ? 1 : 4;
         // one column pair per lane (two -- strips of 240 owned columns -- were measured slower, 45.2 against 40.0 us at
         // 3600x1800, and are no longer instantiated: round 5)
@@ -447,8 +468,8 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
             {
                 FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
                 if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, p.BCy == XINV_BC_EXTEND, dim3(1), st, dummy, &occ, 0, pl.seam != 0, pl.fma);
-                else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um, pl.K, dim3(1), dim3(256),
-                                    st, dummy, &occ, pl.seam != 0, pl.fma);
+                else fused_dispatch(p.kind, pl.aligned, p.BCy == XINV_BC_EXTEND, pl.um | (pl.alias_ac ? 2u : 0u), pl.K, dim3(1), dim3(256),
+                                    st, dummy, &occ, pl.seam != 0, pl.fma, pl.pq);
             }
             // (pl.lone, set with K above: with one or two vector streams a second workgroup per CU
             // fills idle issue slots; with four or more a pair runs no faster than one, and tall
@@ -1227,6 +1248,7 @@ struct PlanBufs {
     void *d_rowf = nullptr; size_t d_rowf_cap = 0;
     int *d_list = nullptr; size_t d_list_cap = 0;
     double *d_tsum = nullptr; size_t d_tsum_cap = 0;
+    double *d_pfac = nullptr; size_t d_pfac_cap = 0;
 };
 struct BufSwap {                                         // the plan's buffers sit in the workspace while this lives
     Workspace *ws; PlanBufs *b;
@@ -1235,6 +1257,7 @@ struct BufSwap {                                         // the plan's buffers s
         std::swap(w->d_rowf, q->d_rowf); std::swap(w->d_rowf_cap, q->d_rowf_cap);
         std::swap(w->d_list, q->d_list); std::swap(w->d_list_cap, q->d_list_cap);
         std::swap(w->d_tsum, q->d_tsum); std::swap(w->d_tsum_cap, q->d_tsum_cap);
+        std::swap(w->d_pfac, q->d_pfac); std::swap(w->d_pfac_cap, q->d_pfac_cap);
     }
     BufSwap(Workspace *w, PlanBufs *q) : ws(w), b(q) { sw(ws, b); }
     ~BufSwap() { sw(ws, b); }
@@ -1280,6 +1303,7 @@ static void plan_free(xinv_plan *h)
     if (h->bufs.d_rowf) (void)hipFree(h->bufs.d_rowf);
     if (h->bufs.d_list) (void)hipFree(h->bufs.d_list);
     if (h->bufs.d_tsum) (void)hipFree(h->bufs.d_tsum);
+    if (h->bufs.d_pfac) (void)hipFree(h->bufs.d_pfac);
     for (void *q : h->owned) (void)hipFree(q);
     h->magic = 0;
     delete h;

@@ -231,6 +231,7 @@ struct Workspace {
     std::vector<int> h_pre;                                     // plan_tile_skip: prefix counts (kept: no allocation per solve)
     double *d_tsum = nullptr; size_t d_tsum_cap = 0;            // tsum | tcnt | xsum | xcnt
     void *d_rowf = nullptr; size_t d_rowf_cap = 0;              // k_pipe2d: per-row records [nbatch][yc][PIPE_RW]
+    double *d_pfac = nullptr; size_t d_pfac_cap = 0;            // k_pipe2d<FusedGen2DQ>: the point-factor stream Q [nbatch][yc][xc]
     void *wd_part = nullptr; size_t wd_part_cap = 0;            // watchdog recovery: partials of the separate norm kernels
     StageRing ring_up, ring_down;                               // host-pointer entries: the library's pinned staging
 };

@@ -36,6 +36,10 @@ struct Plan {
     bool split;              // odd-xc periodic seam: the edge strips' row blocks are cut in two (xinv_tile_rows): their
                              // workgroups run up to three passes per half-sweep and would otherwise end a launch alone
     bool fma;                // XINV_FLAG_FMA: the contracted-arithmetic kernel variants (per-row-coefficient forms only)
+    bool alias_ac;           // `pq`: A and C hold the same numbers everywhere -- C is read out of A (FusedGen2DQA, kernel mask um | 2)
+    bool pq;                 // general form with A, C varying along x: the point-factor stream Q (FusedGen2DQ: relaxation
+                             // factor and update predicate of every point, evaluated once per coefficient stack);
+                             // Q lives in ws->d_pfac (a plan's own buffer while it solves)
     bool lag;                // 5-point 2-D kernels: norm + stop rule evaluated by k_norm_reduce_lag on a second stream,
                              // one pass behind the sweeps (three S buffers); see run_sweeps
 };
@@ -60,8 +64,9 @@ static inline int strip_uw(const Plan &pl, int K, bool pipe)
 static inline int seam_nsplit(const Plan &pl, int nstrip) { return !pl.split ? 0 : (nstrip == 1 ? 1 : 2); }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
-                          hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false)
+                          hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false, bool pq = false)
 {
+    if (pq) return (kind != KIND_GEN2D || seam || fma) ? 1 : xinv_launch_fused2d_genq(al, ext, um, K, grid, block, st, a, occ);   // (um | 2: the A == C variant)
     if (fma) {                                           // contracted arithmetic (xinv_fused.h: FusedStd2DF / FusedGen2DF)
         if (seam || kind == KIND_STD2DT) return 1;
         return kind == KIND_GEN2D ? xinv_launch_fused2d_genf(al, ext, um, K, grid, block, st, a, occ)
@@ -121,6 +126,10 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     } else {
         a.c[0] = p.c[0]; a.sc[0] = p.sc[0];      // A
         for (int q = 2; q < 7; q++) { a.c[q - 1] = p.c[q]; a.sc[q - 1] = p.sc[q]; }   // C..G
+        if (pl.pq) {                             // A, C, D, E, F, Q, G (FusedGen2DQ)
+            a.c[6] = a.c[5]; a.sc[6] = a.sc[5];
+            a.c[5] = (const double *)ws->d_pfac; a.sc[5] = p.yc * p.xc;
+        }
     }
     a.yc = p.yc; a.xc = p.xc;
     a.per = (p.BCx == XINV_BC_PERIODIC);
@@ -168,7 +177,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
             xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, a.ext != 0, grid, st, a, nullptr, pad, pl.seam != 0, pl.fma);
             continue;
         }
-        if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um, K, grid, block, st, a, nullptr, pl.seam != 0, pl.fma))
+        if (fused_dispatch(p.kind, pl.aligned, a.ext != 0, pl.um | (pl.alias_ac ? 2u : 0u), K, grid, block, st, a, nullptr, pl.seam != 0, pl.fma, pl.pq))
             return fail_arg("unsupported sweeps_per_launch for this kernel variant");
     }
     HIPCHK(hipGetLastError());
@@ -655,7 +664,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     if (!fixedRB && occ_ <= 0) {
         FusedArgs dummy; memset(&dummy, 0, sizeof dummy);
         if (pl.pipe) xinv_launch_pipe2d(p.kind == KIND_GEN2D, pl.um, pl.npair, pl.pipe_fr, pl.aligned, ext, dim3(1), st, dummy, &occ, 0, pl.seam != 0, pl.fma);
-        else fused_dispatch(p.kind, pl.aligned, ext, pl.um, K, dim3(1), dim3(256), st, dummy, &occ, pl.seam != 0, pl.fma);
+        else fused_dispatch(p.kind, pl.aligned, ext, pl.um | (pl.alias_ac ? 2u : 0u), K, dim3(1), dim3(256), st, dummy, &occ, pl.seam != 0, pl.fma, pl.pq);
     }
     const bool pp = pl.pipe;
     const double cost0 = tile_cost((int64_t)cdiv((int64_t)nstrip * pl.nrb, tpw) * nb, cdiv(yc, pl.nrb), K, occ, pl.lone, pp);

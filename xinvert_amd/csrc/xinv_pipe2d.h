@@ -134,6 +134,44 @@ __global__ __launch_bounds__(256) void k_row_factor(RowFactorArgs a)
 }
 #endif
 
+// ---- the point-factor stream Q of FusedGen2DQ (xinv_fused.h; k_fused2d) ------------------------------------------
+struct PointFactorArgs {
+    const double *c[6];           // A, C, D, E, F, G (FusedArgs order of the general form)
+    int64_t sc[6];
+    int64_t yc, xc, n;            // n = yc * xc
+    XinvScal sc_;
+    double *q;                    // [nbatch][yc][xc]
+    int *flag;                    // bit 0: an updatable point's factor is +-0 (Q == 0 means "skip": the variant is not used);
+                                  // bit 1: A and C differ somewhere (bitwise)
+};
+#ifdef XINV_AUX_KERNELS
+// once per coefficient stack: Q[j,i] = optArg / ((A ratioSqr + C) 2 - F delxSqr) where numbas.py:1126-1129 lets the point
+// be updated (every operand on the point defined, an interior row), 0 elsewhere.  The expression is inc()'s of
+// FusedGen2D, evaluated in this translation unit under the same -ffp-contract=off: the same bits.
+__global__ __launch_bounds__(256) void k_point_factor(PointFactorArgs a)
+{
+    const int64_t m = blockIdx.y;
+    const double u = a.sc_.undef;
+    bool zero = false, differ = false;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < a.n; t += (int64_t)gridDim.x * 256) {
+        const int64_t j = t / a.xc;
+        const double A = a.c[0][m * a.sc[0] + t], C = a.c[1][m * a.sc[1] + t], Dd = a.c[2][m * a.sc[2] + t];
+        const double E = a.c[3][m * a.sc[3] + t], F = a.c[4][m * a.sc[4] + t], G = a.c[5][m * a.sc[5] + t];
+        differ = differ || (__double_as_longlong(A) != __double_as_longlong(C));
+        const bool ok = (j >= 1) && (j <= a.yc - 2) && (G != u) && (A != u) && (C != u) && (Dd != u) && (E != u) && (F != u);
+        double q = 0.0;
+        if (ok) {
+            q = a.sc_.optArg / ((A * a.sc_.ratioSqr + C) * 2.0
+                                - F * a.sc_.delxSqr);
+            zero = zero || (q == 0.0);
+        }
+        a.q[m * a.n + t] = q;
+    }
+    if (__any(zero) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 1);
+    if (__any(differ) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 2);
+}
+#endif
+
 __device__ __forceinline__ void xinv_pipe_barrier()
 {
 #if defined(XINV_PIPE_NOBAR)       /* timing experiments only (results are wrong): what do the barriers cost? */

@@ -63,11 +63,20 @@ static int launch_fused_um(unsigned um, int K, dim3 grid, dim3 block, hipStream_
             if (um == 3u) return launch_fused_k<M, AL, 3u, EXT>(K, grid, block, st, a, occ);
         } else if constexpr (std::is_same<M, FusedStd2DT>::value) {
             if (um == 7u) return launch_fused_k<M, AL, 7u, EXT>(K, grid, block, st, a, occ);
+        } else if constexpr (std::is_same<M, FusedGen2DQA>::value) {   // (C read out of A: bit 1 set, nothing of C loaded)
+            if (um == 0x1eu) return launch_fused_k<M, AL, 0x1eu, EXT>(K, grid, block, st, a, occ);
+            if (um == 0x02u) return launch_fused_k<M, AL, 0x02u, EXT>(K, grid, block, st, a, occ);
+            return 1;
+        } else if constexpr (ModelPQ<M>::value) {        // (A, C varying along x: D, E, F per row, or nothing)
+            if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a, occ);
+            if (um != 0u) return 1;
         } else {
             if (um == 0x1fu) return launch_fused_k<M, AL, 0x1fu, EXT>(K, grid, block, st, a, occ);
             if (um == 0x1cu) return launch_fused_k<M, AL, 0x1cu, EXT>(K, grid, block, st, a, occ);
         }
-        return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a, occ);
+        if constexpr (!std::is_same<M, FusedGen2DQA>::value)      // (every stream a vector)
+            return launch_fused_k<M, AL, 0u, EXT>(K, grid, block, st, a, occ);
+        return 1;
     }
 }
 
@@ -105,8 +114,15 @@ int xinv_launch_fused2d_std2dt(bool al, bool ext, unsigned um, int K, dim3 grid,
 int xinv_launch_fused2d_stdf(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
                              const FusedArgs &a, int *occ)
 { return launch_fused_m<FusedStd2DF>(al, ext, um, K, grid, block, st, a, occ); }
-#else
+#elif XINV_TU_MODEL == 4
 int xinv_launch_fused2d_genf(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
                              const FusedArgs &a, int *occ)
 { return launch_fused_m<FusedGen2DF>(al, ext, um, K, grid, block, st, a, occ); }
+#else
+int xinv_launch_fused2d_genq(bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block, hipStream_t st,
+                             const FusedArgs &a, int *occ)
+{
+    if (um & 2u) return launch_fused_m<FusedGen2DQA>(al, ext, um, K, grid, block, st, a, occ);
+    return launch_fused_m<FusedGen2DQ>(al, ext, um, K, grid, block, st, a, occ);
+}
 #endif
