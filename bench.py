@@ -213,7 +213,8 @@ def kernel_name(kind, s):
         return 'k_pipe2d<%s, NP=%d> (four sweeps per pass, one per wavefront; x-uniform mask=%d)' % (model, s['pipelined'], um)
     if s['colours'] == 4:
         return 'k_fused9<%s, K=%d>' % (model, K)
-    return 'k_fused2d<Fused%s, K=%d, x-uniform mask=%d>' % (model, K, um)
+    pf = {0: '', 1: '; point-factor stream Q', 2: '; point-factor stream Q, C read out of A'}[s.get('point_factor', 0)]
+    return 'k_fused2d<Fused%s, K=%d, x-uniform mask=%d%s>' % (model, K, um, pf)
 
 
 def streamed_bytes_per_point_sweep(kind, s):
@@ -226,6 +227,7 @@ def streamed_bytes_per_point_sweep(kind, s):
         nvec = 3 - bin(um & 7).count('1')                   # A, C, F
     elif kind == 'gen2d':
         nvec = 6 - bin(um & 63).count('1')                  # A, C, D, E, F, G
+        nvec += {0: 0, 1: 1, 2: 0}[s.get('point_factor', 0)]   # (+ Q; - C when it is read out of A)
     elif kind == 'std3d':
         nvec = 4 - bin(um & 7).count('1')                   # A, B, C + forcing
     else:

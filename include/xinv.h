@@ -160,7 +160,9 @@ typedef struct xinv_stats {
                                    `sweep_launches` pass is then one kernel launch per lane, on its own stream, and
                                    kernel durations in a trace overlap)                                              */
     int32_t planned;            /* 1: the solve ran on a resident plan (xinv_plan_*): no detection / planning pass      */
-    int32_t pad_;
+    int32_t point_factor;       /* general 2-D form, coefficients varying along x: 1 = the sweeps read the relaxation factor /
+                                   update predicate of every point from the stream k_point_factor evaluated once per
+                                   coefficient stack; 2 = ... and C out of A (the two hold the same numbers); 0 = in-kernel */
     double  plan_ms;            /* wall clock of the planning part of the call (detection passes, host round trips,
                                    tile lists, per-row records); ~0 for a solve on a resident plan                    */
     double  launch_us_min, launch_us_avg, launch_us_max;   /* timing = 2: every sweep launch bracketed by its own pair

@@ -35,6 +35,7 @@ def test_point_factor_stream_equals_in_kernel_factor_and_oracle(shape, BCy, BCx,
             S, fl, st = util.run_hip_dev(ps, mx, tol, sweeps_per_launch=spl)
             S1, fl1, st1 = util.run_hip_dev(ps, mx, tol, sweeps_per_launch=spl, no_point_factor=1)
             assert st['path'] == 2 and st['xuniform_mask'] == want_um and st['pipelined'] == 0, st
+            assert st['point_factor'] == (2 if alias else 1) and st1['point_factor'] == 0, (st['point_factor'], st1['point_factor'])
             assert np.array_equal(S, S1) and np.array_equal(fl, fl1), (shape, BCy, BCx, rows_def, alias, spl, mx)
             for m, q in enumerate(ps):
                 So, flo = util.run_oracle(q, mx, tol, COLOUR_2)
@@ -72,6 +73,7 @@ def test_zero_relaxation_factor_falls_back_to_the_in_kernel_evaluation():
     q['coefs'][0][20, 50] = np.inf                            # A = inf: optArg / inf = 0 at that point
     S, fl, st = util.run_hip_dev([q], 6, 0.0)
     S1, fl1, st1 = util.run_hip_dev([q], 6, 0.0, no_point_factor=1)
+    assert st['point_factor'] == 0                            # (refused: a zero factor on an updatable point)
     assert np.array_equal(S, S1, equal_nan=True) and np.array_equal(fl, fl1, equal_nan=True)
     # (the infinity poisons S -- the overflow exit -- and how far a NaN has spread when the run stops is the one thing the
     #  B == 0 kernels do not share with the oracle, DESIGN.md 2: the exit sweep and the flags are the same)

@@ -45,7 +45,7 @@ class XinvStats(ctypes.Structure):
                 ('host_chunks', ctypes.c_int32), ('devices', ctypes.c_int32),
                 ('pipelined', ctypes.c_int32), ('masked_tile_ppm', ctypes.c_int32),
                 ('recovered_members', ctypes.c_int32), ('lanes', ctypes.c_int32),
-                ('planned', ctypes.c_int32), ('pad_', ctypes.c_int32), ('plan_ms', ctypes.c_double),
+                ('planned', ctypes.c_int32), ('point_factor', ctypes.c_int32), ('plan_ms', ctypes.c_double),
                 ('launch_us_min', ctypes.c_double), ('launch_us_avg', ctypes.c_double),
                 ('launch_us_max', ctypes.c_double)]
 

@@ -1155,6 +1155,7 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
     t_stats.masked_tile_ppm = (pl.path == XINV_PATH_FUSED && pl.skip) ? pl.skip_ppm : 0;
     t_stats.pipelined = (pl.path == XINV_PATH_FUSED && pl.pipe) ? pl.npair : 0;
     t_stats.lanes = R.lanes;
+    t_stats.point_factor = (pl.path == XINV_PATH_FUSED && pl.pq) ? (pl.alias_ac ? 2 : 1) : 0;
     t_stats.sweep_launches = R.nlaunch;
     t_stats.sweeps_max = sweeps_max;
     t_stats.sweep_ms = R.ms_total;
