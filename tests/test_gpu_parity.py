@@ -890,7 +890,7 @@ def test_seeded_fuzz_medium_grids_odd_widths(chunk):
     _medium_fuzz(chunk, 9000, 1)
 
 
-def _medium_fuzz(chunk, seed0, odd, every_case_stops=False):
+def _medium_fuzz(chunk, seed0, odd, every_case_stops=False, runner=None):
     rng = np.random.default_rng(seed0 + chunk)
     for case in range(4):
         kind = ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'][int(rng.integers(6))]
@@ -932,7 +932,7 @@ def _medium_fuzz(chunk, seed0, odd, every_case_stops=False):
         if case == 3 or every_case_stops:             # one case per chunk stops on the tolerance (odd sweep
             nsw, tol = 60, 3e-3                       # counts inside 2-sweep launches: the redo path)
         opt = {'force_tile_skip': 1} if kind in ('std2d', 'gen2d', 'std2dt', 'bih2d') and int(rng.integers(2)) else {}
-        S, fl, st = run_hip_batched(ps, nsw, tol, shared=shared, **opt)
+        S, fl, st = (runner or run_hip_batched)(ps, nsw, tol, shared=shared, **opt)      # (runner: tests/fuzz_plan.py)
         for m, q in enumerate(ps):
             So, flo = run_oracle(q, nsw, tol, COLOUR_AUTO)
             what = 'medium fuzz %d/%d %s %r %s %s uni=%d member %d %r' % (chunk, case, kind, q['S0'].shape, BCy, BCx, uni, m, st)

@@ -237,3 +237,16 @@ def test_float32_forcing_with_an_undef_float32_cannot_hold_exactly():
         F = xa.Field(z32, ('time', 'lat', 'lon'), {'lat': lat, 'lon': lon})
         host = np.asarray(xa.invert_Poisson(F, dims=['lat', 'lon'], coords='lat-lon', iParams=ip).values, dtype=np.float64)
         assert np.array_equal(host[:, sea], out['f64nan'][:, sea]), undef
+
+
+@pytest.mark.parametrize('mode', ['', '--stops'])
+def test_plan_fuzz(mode):
+    """tests/fuzz_plan.py: the medium seeded generator (every form, masks, 'extend', odd widths, batches of two) with
+    every case solved on a plan, re-solved on the same plan and continued from its result -- against the oracle."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, 'fuzz_plan.py'), '2000', '6'] + ([mode] if mode else []),
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and 'failures: 0' in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
