@@ -27,6 +27,7 @@ python tools/bench_configs.py c2 --members 8 --reps 2 2>/dev/null | grep '^{' >>
 python tools/bench_configs.py c4 --members 64 --reps 2 2>/dev/null | grep '^{' >> $out/r05_configs.txt
 python tools/bench_configs.py c5 --members 15 --reps 2 2>/dev/null | grep '^{' >> $out/r05_configs.txt
 cut -c1-200 $out/r05_configs.txt
+python tools/bench_animate.py 2>/dev/null | grep "^{" > $out/r05_animate.txt; cat $out/r05_animate.txt
 python tools/bench_small_batch.py 2>/dev/null | grep '^{' > $out/r05_small_batches.txt; cut -c1-170 $out/r05_small_batches.txt
 for i in 1 2 3; do python tools/solve_overhead.py 2>/dev/null | grep '^{'; done > $out/r05_solve_overhead_final.txt; python tools/solve_overhead.py --plan 0 2>/dev/null | grep '^{' >> $out/r05_solve_overhead_final.txt; cat $out/r05_solve_overhead_final.txt | cut -c1-260
 [ "$1" = "noprof" ] && exit 0
@@ -60,12 +61,12 @@ with open('$out/r05_launch_events_$name.txt', 'a') as f:
 EOF
   )
 }
-prof C2 "k_pipe2d<FusedStd2D" "k_pipe2d<Std2D" 1 1 25920000 python $R/tools/bench_configs.py c2 --reps 1 --sweeps 500
-prof C3-Stommel "k_fused2d<FusedGen2DQ_<true>, 3" "k_fused2d<FusedGen2D, K=3" 1 1 12000000 python $R/tools/bench_configs.py c3 --reps 1 --sweeps 300
-prof C3-Munk "k_fusedbih" "k_fusedbih" 1 1 4000000 python $R/tools/bench_configs.py c3m --reps 1 --sweeps 100
-prof C4 "k_pipe2d<FusedGen2D" "k_pipe2d<Gen2D" 8 2 16588800 python $R/tools/bench_configs.py c4 --members 8 --reps 1 --sweeps 200
-prof C1 "k_pipe2d<FusedStd2D" "k_pipe2d<Std2D" 1 1 259200 python $R/tools/bench_configs.py c1 --reps 1 --sweeps 500
-prof C5 "k_pipe3d" "k_pipe3d" 15 1 388800000 python $R/tools/bench_configs.py c5 --members 15 --reps 1
+prof C2 "k_pipe2d<FusedStd2D" "k_pipe2d<Std2D" 1 1 25920000 python $R/tools/bench_configs.py c2 --reps 4 --sweeps 500
+prof C3-Stommel "k_fused2d<FusedGen2DQ_<true>, 3" "k_fused2d<FusedGen2D, K=3" 1 1 12000000 python $R/tools/bench_configs.py c3 --reps 4 --sweeps 300
+prof C3-Munk "k_fusedbih" "k_fusedbih" 1 1 4000000 python $R/tools/bench_configs.py c3m --reps 4 --sweeps 100
+prof C4 "k_pipe2d<FusedGen2D" "k_pipe2d<Gen2D" 8 2 16588800 python $R/tools/bench_configs.py c4 --members 8 --reps 4 --sweeps 200
+prof C1 "k_pipe2d<FusedStd2D" "k_pipe2d<Std2D" 1 1 259200 python $R/tools/bench_configs.py c1 --reps 4 --sweeps 500
+prof C5 "k_pipe3d" "k_pipe3d" 15 1 388800000 python $R/tools/bench_configs.py c5 --members 15 --reps 2
 # the headline workload through bench.py itself (kernel trace + traffic of the HBM leg: 8 members in two lanes)
 cmd="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-parity --no-configs"
 ( cd /tmp; rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w

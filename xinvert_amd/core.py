@@ -186,7 +186,8 @@ class Resident:
         if dev < 0:
             import torch
             dev = torch.cuda.current_device()
-        self.rp = ResidentProblem(p, device=dev)
+        # (iParams['resident_plan'] = False: every solve re-derives what a plan keeps -- rounds 1-4, for comparisons)
+        self.rp = ResidentProblem(p, device=dev, plan=bool(iParams.get('resident_plan', True)))
 
     def solve(self, mxLoop, tolerance, **opt):
         """One more call of the hot path on the resident batch -> flags [nbatch, 3].  Engine options the
