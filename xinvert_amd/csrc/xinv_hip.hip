@@ -1182,6 +1182,7 @@ static int ws_ready(Workspace *ws)
 static int make_plan(const Problem &p, const xinv_options &opt, Workspace *ws, hipStream_t st, Plan &pl)
 {
     memset(&pl, 0, sizeof pl);
+    t_detected_um = 0;
     int rc = plan_colouring(p, ws, st, pl);
     if (rc) return rc;
     if (opt.path == 3)                                  // (the value of round 2-3's XINV_PATH_SMALL)
@@ -1205,7 +1206,7 @@ static int make_plan(const Problem &p, const xinv_options &opt, Workspace *ws, h
     return XINV_OK;
 }
 
-static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st)
+static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipStream_t st, int slot = 0)
 {
     int rc = validate(p, flags);
     if (rc) return rc;
@@ -1216,7 +1217,7 @@ static int solve_dev(Problem &p, double *flags, const xinv_options *opt_in, hipS
     HIPCHK(dg.select(opt.device));
     int device = 0;
     HIPCHK(hipGetDevice(&device));
-    Workspace *ws = get_ws(device);
+    Workspace *ws = get_ws(device, slot);
     std::lock_guard<std::recursive_mutex> solve_lock(ws->busy);
     rc = ws_ready(ws);
     if (rc) return rc;
@@ -1415,12 +1416,8 @@ struct HostEvents {                                   // destroyed on every retu
 // Member chunks of the upload / solve / download pipeline: sizes in members, in batch order.
 // Chunking hides PCIe time behind sweeps (chunk c+1 travels and chunk c-1 returns while chunk c sweeps) but
 // costs twice: every chunk repeats the once-per-solve detection / planning passes (~0.5 ms), and a chunk fills
-// the 256 CUs less evenly than the whole batch.  The 3-D kernels tile a volume in fixed cross-sections, one
-// workgroup per CU, so a chunk costs ceil(workgroups / 256) rounds: the split is chosen among those whose
-// rounds add up to (about) the rounds of the whole batch, with the first and last chunk -- whose upload and
-// download are exposed -- as small as that allows (C5, 15 volumes of 180 workgroups: [4, 7, 4] = 3 + 5 + 3
-// rounds = the 11 of one chunk; equal thirds would be 4 + 4 + 4).  The 2-D kernels re-tile every chunk to the
-// CU count, so equal chunks of at least 192 MiB of per-member data do.
+// the 256 CUs less evenly than the whole batch (the 3-D kernels run ceil(workgroups / 256) rounds of one
+// workgroup per CU).
 static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &opt)
 {
     const int64_t nb = p.nbatch;
@@ -1436,33 +1433,18 @@ static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &op
     for (int q = 0; q < p.ncoef; q++) per_member += (p.c[q] && p.sc[q] != 0 && !((p.rowconst >> q) & 1u)) ? 1 : 0;
     const double member_bytes = (double)n * 8.0 * per_member;
     const double total = member_bytes * (double)nb;
-    if (total < 268435456.0 || nb < 3) { out.push_back(nb); return out; }
-    if (is3d(p.kind)) {
-        const int64_t w = (int64_t)cdiv(p.xc, 124) * cdiv(p.yc, 12);          // workgroups per volume (16-row cross-sections)
-        auto rounds = [&](int64_t m) { return (int64_t)cdiv(w * m, 256); };
-        const int64_t r1 = rounds(nb);
-        int64_t best_a = nb, best_b = 0, best_c = 0;
-        double best = 1e300;
-        for (int64_t a = 1; a < nb; a++)
-            for (int64_t c = 0; a + c < nb; c++) {        // [a, nb - a - c, c]; c == 0: two chunks
-                const int64_t mid = nb - a - c;
-                const int64_t r = rounds(a) + rounds(mid) + (c ? rounds(c) : 0);
-                if ((double)r > (double)r1 * 1.04 + 0.01) continue;
-                // exposed transfer: first chunk's upload + last chunk's download (a third of the upload's bytes
-                // when S alone returns); one round of sweeps is taken as worth one member's transfer
-                const double exposed = (double)a + (double)(c ? c : mid) * 0.5 + 0.25 * (double)(r - r1) + 0.05 * (c ? 3 : 2);
-                if (exposed < best) { best = exposed; best_a = a; best_b = mid; best_c = c; }
-            }
-        if (best < (double)nb + 0.5 * (double)nb) {
-            out.push_back(best_a); out.push_back(best_b);
-            if (best_c) out.push_back(best_c);
-            return out;
-        }
-        out.push_back(nb);
+    // Round 5: TWO chunk solves are in flight on the device at a time (solve_host_one), so the holes a small chunk leaves
+    // on the 256 CUs are filled by its neighbour's launches, and what remains to be minimised is the exposed first
+    // upload / last download against the fixed cost of a chunk (~0.5 ms of planning, launches of few workgroups).
+    // Measured (profiles/r05_host_pipeline.txt): C5, 15 volumes -- 1 chunk 212 ms, [4, 7, 4] (round 4's split) 172,
+    // chunks of 2 volumes 161, of 1 volume 200; C4, 8 members -- 1 chunk 15.4 ms, chunks of 2 members 14.1, of 1: 17.2.
+    if (total < 100663296.0 || nb < 4) { out.push_back(nb); return out; }
+    if (is3d(p.kind)) {                                   // up to eight chunks of at least two volumes, the remainder LAST
+        const int64_t nch = std::min<int64_t>(8, (nb + 1) / 2), per = (nb + nch - 1) / nch;
+        for (int64_t m0 = 0; m0 < nb; m0 += per) out.push_back(std::min(per, nb - m0));
         return out;
     }
-    const int64_t want = std::min<int64_t>(4, std::max<int64_t>(1, (int64_t)(total / 201326592.0)));
-    const int64_t nch = std::min<int64_t>(want, nb);
+    const int64_t nch = std::min<int64_t>(std::min<int64_t>(4, nb / 2), std::max<int64_t>(2, (int64_t)((total + 33554431.0) / 33554432.0)));
     for (int64_t c = 0; c < nch; c++) out.push_back(nb / nch + (c < nb % nch ? 1 : 0));
     return out;
 }
@@ -1476,20 +1458,21 @@ static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &op
 // last chunk's download.  Members are independent (reference core.py:129: no cross-slice state), so the
 // chunking cannot change any result.
 struct HostActors {                                   // joins the helper threads and drains the streams on EVERY return path
-    std::thread up, down;
+    std::thread up, down, solver2;                    // (solver2: the odd chunks' solves, beside the calling thread's)
     std::mutex mu;
     std::condition_variable cv;
     std::vector<char> chunk_ready;                    // set by the uploader once chunk c's event is recorded
     std::deque<std::function<int()>> dq;              // download jobs
     bool d_closed = false, abort = false;
-    int u_rc = 0, d_rc = 0;
-    std::string u_err, d_err;
+    int u_rc = 0, d_rc = 0, s2_rc = 0;                // (s2: the helper solver thread's verdict -- kept here: this object
+    std::string u_err, d_err, s2_err;                 //  outlives the thread on every return path)
     std::vector<hipStream_t> streams;
     void close_downloads() { { std::lock_guard<std::mutex> lk(mu); d_closed = true; } cv.notify_all(); }
     ~HostActors()
     {
         { std::lock_guard<std::mutex> lk(mu); abort = true; d_closed = true; }
         cv.notify_all();
+        if (solver2.joinable()) solver2.join();       // (before the downloader: it still queues download jobs)
         if (up.joinable()) up.join();
         if (down.joinable()) down.join();
         for (hipStream_t s : streams) (void)hipStreamSynchronize(s);      // nothing of this call stays in flight
@@ -1620,6 +1603,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
                 return XINV_OK;
             });
             d.sc[q] = (hst == 0) ? 0 : n;
+            d.known_um |= 1u << q;                    // (expanded from one value per row: constant along x by construction)
         } else if (hst == 0) {
             rc = pool_alloc(pool, (size_t)n * sizeof(double), &dc);
             if (rc) return rc;
@@ -1740,60 +1724,83 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     });
 
     // ---- solve chunk by chunk; downloads trail on their own thread ------------------------------
-    // the per-device workspace grows on demand: size it for the LARGEST chunk now, so that a later, larger chunk
-    // does not pay a free + malloc of the ping-pong buffer (or of the pinned control-block mirror) mid-pipeline
+    // Two chunk solves are in flight at a time (round 5): the even chunks on the calling thread (the device's workspace),
+    // the odd ones on a helper thread with a workspace and a compute stream of its own.  A chunk fills the 256 CUs less
+    // evenly than the whole batch -- the 3-D kernels run ceil(workgroups / 256) rounds, every 2-D launch ends with a
+    // tail --; with the next chunk's launches already queued on the device those holes are filled, as the two launch
+    // chains of a device-resident batch fill each other's (the lanes of run_sweeps).
+    Workspace *ws1 = (nchunk > 1) ? get_ws(device, 1) : nullptr;
+    hipStream_t scp1 = nullptr;
+    if (ws1) {
+        if (!ws1->s_compute) HIPCHK(hipStreamCreateWithFlags(&ws1->s_compute, hipStreamNonBlocking));
+        scp1 = ws1->s_compute;
+        act.streams.push_back(scp1);
+    }
+    // the workspaces grow on demand: size them for the LARGEST chunk now, so that a later, larger chunk does not pay a
+    // free + malloc of the ping-pong buffer (or of the pinned control-block mirror) mid-pipeline
     {
         const int64_t mmax = *std::max_element(chunks.begin(), chunks.end());
-        if (nchunk > 1 && p.kind != KIND_BIH2D) {
-            if ((rc = ensure_dev(&ws->S2, &ws->S2_cap, (size_t)mmax * n * sizeof(double)))) return rc;
-            if ((rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)mmax * sizeof(XinvCtl)))) return rc;
-            if (ws->hctl_cap < (size_t)mmax) {
-                if (ws->hctl) HIPCHK(hipHostFree(ws->hctl));
-                ws->hctl = nullptr; ws->hctl_cap = 0;
-                HIPCHK(hipHostMalloc((void **)&ws->hctl, 2 * (size_t)mmax * sizeof(XinvCtl), hipHostMallocDefault));
-                ws->hctl_cap = (size_t)mmax;
+        if (nchunk > 1 && p.kind != KIND_BIH2D)
+            for (Workspace *w : { ws, ws1 }) {
+                if ((rc = ensure_dev(&w->S2, &w->S2_cap, (size_t)mmax * n * sizeof(double)))) return rc;
+                if ((rc = ensure_dev(&w->ctl, &w->ctl_cap, (size_t)mmax * sizeof(XinvCtl)))) return rc;
+                if (w->hctl_cap < (size_t)mmax) {
+                    if (w->hctl) HIPCHK(hipHostFree(w->hctl));
+                    w->hctl = nullptr; w->hctl_cap = 0;
+                    HIPCHK(hipHostMalloc((void **)&w->hctl, 2 * (size_t)mmax * sizeof(XinvCtl), hipHostMallocDefault));
+                    w->hctl_cap = (size_t)mmax;
+                }
             }
-        }
     }
     xinv_stats acc;
     memset(&acc, 0, sizeof acc);
+    bool acc_set = false;
+    unsigned shared_um = 0;
     xinv_options o1 = opt;
     o1.device = device; o1.ndev = 0;
-    for (int64_t c = 0; c < nchunk; c++) {
+    // one chunk: wait for its upload, solve it on `cs` (workspace `slot`), run the output passes, hand it to the downloader
+    auto do_chunk = [&](int64_t c, hipStream_t cs, int slot) -> int {
         const int64_t m0 = first[(size_t)c], nm = chunks[(size_t)c];
         {
             std::unique_lock<std::mutex> lk(act.mu);
-            act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)c] != 0; });
+            act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)c] != 0 || act.abort; });
             if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
+            if (act.abort) { t_err = "host-pointer solve aborted"; return XINV_ERR_HIP; }
         }
-        HIPCHK(hipStreamWaitEvent(scp, e_chunk[(size_t)c], 0));
+        HIPCHK(hipStreamWaitEvent(cs, e_chunk[(size_t)c], 0));
         Problem dc = d;
+        { std::lock_guard<std::mutex> lk(act.mu); dc.known_um |= shared_um; }     // (what an earlier chunk's plan found out)
         dc.nbatch = nm;
         dc.S = d.S + m0 * n;
         for (int q = 0; q < p.ncoef; q++)
             if (d.c[q] && d.sc[q] != 0) dc.c[q] = d.c[q] + m0 * d.sc[q];
-        rc = solve_dev(dc, flags + 3 * m0, &o1, scp);
-        if (rc) return rc;
-        if (c == 0) acc = t_stats;
-        else {
-            acc.sweep_launches += t_stats.sweep_launches;
-            acc.sweeps_max = std::max(acc.sweeps_max, t_stats.sweeps_max);
-            acc.sweep_ms += t_stats.sweep_ms;
-            acc.recovered_members += t_stats.recovered_members;
+        int r = solve_dev(dc, flags + 3 * m0, &o1, cs, slot);
+        if (r) return r;
+        {
+            std::lock_guard<std::mutex> lk(act.mu);
+            for (int q = 0; q < p.ncoef; q++)            // shared arrays found constant along x: the same for every chunk
+                if (d.c[q] && d.sc[q] == 0 && ((t_detected_um >> q) & 1u)) shared_um |= 1u << q;
+            if (!acc_set) { acc = t_stats; acc_set = true; }
+            else {
+                acc.sweep_launches += t_stats.sweep_launches;
+                acc.sweeps_max = std::max(acc.sweeps_max, t_stats.sweeps_max);
+                acc.sweep_ms += t_stats.sweep_ms;
+                acc.recovered_members += t_stats.recovered_members;
+            }
         }
         // solve_dev has returned: the chunk's S is final on the device
         if (opt.prep_flags & XINV_PREP_DEMASK) {
             for (int64_t m = 0; m < nm; m++) {
                 const double *dF = d.c[fq] + (per_member[fq] ? (m0 + m) * n : 0);
-                hipLaunchKernelGGL(k_demask, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, scp,
+                hipLaunchKernelGGL(k_demask, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, cs,
                                    d.S + (m0 + m) * n, dF, n, p.sc_.undef, opt.demask_value);
             }
-            HIPCHK(hipStreamSynchronize(scp));
+            HIPCHK(hipStreamSynchronize(cs));
         }
         if (tmpS_dn) {                                   // float32 S: rounded on the device, half the bytes back
-            hipLaunchKernelGGL(k_demote_f64, dim3((unsigned)std::min<int64_t>(4096, (nm * n + 255) / 256)), dim3(256), 0, scp,
+            hipLaunchKernelGGL(k_demote_f64, dim3((unsigned)std::min<int64_t>(4096, (nm * n + 255) / 256)), dim3(256), 0, cs,
                                (const double *)(d.S + m0 * n), tmpS_dn + m0 * n, nm * n);
-            HIPCHK(hipStreamSynchronize(scp));
+            HIPCHK(hipStreamSynchronize(cs));
         }
         {
             char *hS = (char *)p.S;
@@ -1808,14 +1815,29 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
                 };
                 if (hsS == n || nm == 1) return one(hS + (size_t)m0 * hsS * es, dS + (size_t)m0 * n * es, (size_t)nm * n * es);
                 for (int64_t m = m0; m < m0 + nm; m++) {
-                    int r = one(hS + (size_t)m * hsS * es, dS + (size_t)m * n * es, (size_t)n * es);
-                    if (r) return r;
+                    int rr = one(hS + (size_t)m * hsS * es, dS + (size_t)m * n * es, (size_t)n * es);
+                    if (rr) return rr;
                 }
                 return XINV_OK;
             });
         }
         act.cv.notify_all();
+        return XINV_OK;
+    };
+    if (nchunk > 1)
+        act.solver2 = std::thread([&]() {
+            int r = (hipSetDevice(device) == hipSuccess) ? XINV_OK : XINV_ERR_HIP;
+            for (int64_t c = 1; c < nchunk && !r; c += 2) {
+                try { r = do_chunk(c, scp1, 1); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
+            }
+            act.s2_rc = r; if (r) act.s2_err = t_err;
+        });
+    for (int64_t c = 0; c < nchunk; c += 2) {
+        rc = do_chunk(c, scp, 0);
+        if (rc) return rc;                               // (HostActors' destructor stops and joins the helper)
     }
+    if (act.solver2.joinable()) act.solver2.join();
+    if (act.s2_rc) { t_err = act.s2_err; return act.s2_rc; }
     act.close_downloads();
     act.up.join();
     act.down.join();

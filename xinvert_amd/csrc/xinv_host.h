@@ -204,6 +204,8 @@ static int stage_d2h(StageRing &r, hipStream_t s, double *host, const double *de
 #define XINV_MAX_LANES 4
 struct Workspace {
     int device = -1;
+    int slot = 0;                                       // 0: the device's workspace; 1: a second one, so that two solves of ONE
+                                                        // host-pointer call can be in flight on the device at once (solve_host_one)
     std::recursive_mutex busy;                          // one solve at a time per device
     double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
     XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
@@ -239,12 +241,13 @@ struct Workspace {
 static std::mutex g_ws_mutex;
 static std::vector<Workspace *> g_ws;
 
-static Workspace *get_ws(int device)
+static Workspace *get_ws(int device, int slot = 0)
 {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
-    for (auto *w : g_ws) if (w->device == device) return w;
+    for (auto *w : g_ws) if (w->device == device && w->slot == slot) return w;
     Workspace *w = new Workspace();
     w->device = device;
+    w->slot = slot;
     g_ws.push_back(w);
     return w;
 }

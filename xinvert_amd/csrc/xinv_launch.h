@@ -774,6 +774,9 @@ static int detect_xuniform(Workspace *ws, hipStream_t st, const double *const *a
     return XINV_OK;
 }
 
+static thread_local unsigned t_detected_um = 0;       // coefficient arrays (bit = coefficient index) the calling thread's last
+                                                      // plan found constant along x (or knew to be): solve_host_one hands the
+                                                      // shared ones to the later chunks of the same call
 // The same over coefficient arrays idx[0..ns) of a problem; bit q of *mask = array idx[q].  Arrays the caller declared
 // row-constant to a resident plan (Problem::known_um: the plan expanded them itself) are not read again.
 static int detect_xuniform_of(const Problem &p, Workspace *ws, hipStream_t st, const int *idx, int ns, int64_t rows,
@@ -792,6 +795,7 @@ static int detect_xuniform_of(const Problem &p, Workspace *ws, hipStream_t st, c
         if (rc) return rc;
         for (int k = 0; k < nu; k++) if ((mm >> k) & 1u) m |= 1u << pos[k];
     }
+    for (int q = 0; q < ns; q++) if ((m >> q) & 1u) t_detected_um |= 1u << idx[q];
     *mask = m;
     return XINV_OK;
 }
