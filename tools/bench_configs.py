@@ -44,6 +44,11 @@ def make(name, a):
         return synthetic.omega_latlon(50, 360, 721, a.members or 2), a.sweeps or 50
     if name == 'c5g':
         return synthetic.ocean3d_latlon(50, 360, 720, a.members or 2), a.sweeps or 50
+    if name.startswith('poisson:') or name.startswith('gm:'):       # poisson:1800x3601 / gm:720x1441 -- any slice shape (seam rates)
+        ny, nx = (int(v) for v in name.split(':')[1].split('x'))
+        if name.startswith('gm:'):
+            return synthetic.gill_matsuno(ny, nx, a.members or 1), a.sweeps or 400
+        return synthetic.poisson_latlon(ny, nx, mask=a.mask, members=a.members or 1, BCs=('fixed', a.bcx)), a.sweeps or 400
     if name == 'ofes':
         # the shape of the reference's only published wall-clock figure: invert_omega on a
         # 601 x 300 x 300 ocean grid, 501 sweeps, 730 s per solve on one CPU core
@@ -62,6 +67,8 @@ def main():
     ap.add_argument('--members', type=int, default=0)
     ap.add_argument('--lanes', type=int, default=0)
     ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--bcx', default='periodic', help='poisson:<ny>x<nx>: BCx')
+    ap.add_argument('--mask', action='store_true', help='poisson:<ny>x<nx>: with the synthetic land/sea mask')
     ap.add_argument('--no-xuniform', action='store_true', help='stream every coefficient array in full')
     ap.add_argument('--no-pipe', action='store_true')
     ap.add_argument('--no-plan', action='store_true', help='every solve through xinv_<form>_f64_dev (re-derives everything)')

@@ -254,10 +254,12 @@ def animate_iteration(app_name, F, dims, coords='lat-lon', icbc=None,
         res = core.Resident(inv_name, coeffs, maskF, initS, dims, iParams)
     except ImportError:
         res = None
+    if res is not None:
+        res.keep_frames(max_frames)
     for _ in range(max_frames):
         if res is not None:
             res.solve(loop_per_frame, float(iParams['tolerance']))
-            frames.append(res.values())
+            res.snapshot()                                # (stays in HBM: one download after the last frame)
         else:
             initS = invt_func(*coeffs, maskF, initS, dims, iParams)
             frames.append(np.array(initS.values, copy=True))
@@ -267,7 +269,7 @@ def animate_iteration(app_name, F, dims, coords='lat-lon', icbc=None,
         for k in ('flags', 'stats', 'frame_flags'):      # where the inv_* calls leave them for the caller
             if k in iParams:
                 iParams_in[k] = iParams[k]
-    out = np.stack(frames)
+    out = res.frames() if res is not None else np.stack(frames)
     if icbc is None:
         out = np.where(maskF.values[None] != _undeftmp, out, iParams['undef'])
     coords_out = dict(maskF.coords)

@@ -207,6 +207,23 @@ class Resident:
         out = self.rp.result().reshape(tuple(self.bshape) + self.core_shape)
         return np.ascontiguousarray(np.transpose(out, np.argsort(self.perm)))
 
+    def keep_frames(self, n):
+        """Room in HBM for `n` snapshots of S (apps.animate_iteration: the frames stay on the device -- a copy queued behind
+        each solve -- and cross PCIe once, at the end, instead of one blocking download per frame)."""
+        import torch
+        self._frames = torch.empty((n,) + tuple(self.rp.S.shape), dtype=self.rp.S.dtype, device=self.rp.S.device)
+        self._nframe = 0
+
+    def snapshot(self):
+        self._frames[self._nframe].copy_(self.rp.S)      # (device to device, on the stream the solve ran on)
+        self._nframe += 1
+
+    def frames(self):
+        """The snapshots taken so far, [n, ...] in the forcing's axis order (one download)."""
+        out = self._frames[:self._nframe].cpu().numpy().reshape((self._nframe,) + tuple(self.bshape) + self.core_shape)
+        inv = np.argsort(self.perm)
+        return np.ascontiguousarray(np.transpose(out, (0,) + tuple(1 + a for a in inv)))
+
 
 # in-process multi-GPU is the default only when every device gets a worthwhile share: below this much
 # per-member data per device, the contexts, workspaces and re-uploaded coefficient stacks cost more than

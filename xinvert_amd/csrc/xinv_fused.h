@@ -124,44 +124,15 @@ struct FusedArgs {
     int ntl;                   // entries per member (multiple of 4); nwg = ntl / 4
     const double *xsum;        // [nbatch] sum |S| over the skipped tiles (S != undef)
     const long long *xcnt;     // [nbatch] their sample count
-    int nsplit;                // odd-xc periodic seam: 0, or the number of edge strips (1: one strip spans the row; 2: the
-                               // last and the first) whose row blocks are cut in two (xinv_tile_rows)
+    int nsplit;                // odd-xc periodic seam: 0, or the extra tile groups of the edge strips (1: one strip spans the
+                               // row; 2: the last and the first) whose row blocks are cut in pieces (xinv_tile_rows)
     const void *rowf;          // k_pipe2d: [nbatch][yc] per-row records (M::PIPE_RW doubles each, xinv_pipe2d.h)
     double *dbg;               // debugging builds only (XINV_PIPE_DEBUG): rows as the pipeline stages received them;
                                // test-hooks build (XINV_TEST_HOOKS): three ints {tile, launch tag, member} -- that tile of
                                // that launch withholds its norm partial, so that the reducer REALLY times out
 };
 
-// Tile id -> strip and owned rows [y0, y1).  Ids [0, nstrip nrb): row block rb = id / nstrip of strip id % nstrip (fixed
-// height RY, or RY == 0: the yc rows split evenly, boundaries rounded to even rows).  With the odd-xc periodic seam the
-// tiles of the EDGE strips run up to three passes per half-sweep (SEAM, below) and a launch of one round of workgroups
-// ends with them; their row blocks are therefore cut in two (nsplit = number of edge strips): id (rb, edge strip) is
-// the first half, ids nstrip nrb + e nrb + rb the second half of edge strip e (e = 0: the last strip, 1: strip 0).
-// Halves start on even rows like every tile; a half without rows is an idle tile (y0 >= y1).
-struct TileRows { int strip; int64_t y0, y1; };
-__host__ __device__ inline TileRows xinv_tile_rows(int wt, int nstrip, int nrb, int nsplit, int64_t yc, int RY)
-{
-    TileRows t;
-    int rb, half = -1;
-    if (wt < nstrip * nrb) {
-        rb = wt / nstrip; t.strip = wt - rb * nstrip;
-        if (nsplit > 0 && (t.strip == nstrip - 1 || (nsplit == 2 && t.strip == 0))) half = 0;
-    } else {
-        const int q = wt - nstrip * nrb, e = q / nrb;
-        rb = q - e * nrb; t.strip = (e == 0) ? nstrip - 1 : 0; half = 1;
-    }
-    if (RY > 0) { t.y0 = (int64_t)rb * RY; t.y1 = (t.y0 + RY < yc) ? t.y0 + RY : yc; }
-    else {
-        t.y0 = (((int64_t)rb * yc) / nrb) & ~(int64_t)1;
-        t.y1 = (rb + 1 == nrb) ? yc : ((((int64_t)(rb + 1) * yc) / nrb) & ~(int64_t)1);
-    }
-    if (half >= 0) {
-        const int64_t mid = t.y0 + ((((t.y1 - t.y0) / 2) + 1) & ~(int64_t)1);
-        const int64_t m2 = mid < t.y1 ? mid : t.y1;
-        if (half == 0) t.y1 = m2; else t.y0 = m2;
-    }
-    return t;
-}
+#include "xinv_tiles.h"                              // tile ids, the seam launches' dispatch order
 
 template <class F, int... U>
 __device__ __forceinline__ void xinv_unroll_steps(F &&f, std::integer_sequence<int, U...>)
@@ -969,6 +940,14 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #endif
     int wt = T * 4 + wave;
     bool active = wt < a.nstrip * a.nrb + (SEAM ? a.nsplit * a.nrb : 0);
+    if constexpr (SEAM) {                            // (the edge strips' tiles first, four to a workgroup: xinv_heavy_first)
+        if (!a.tile_list) {
+            const int nh = (a.nstrip == 1 ? 1 : 2) * a.nrb + a.nsplit * a.nrb;
+            wt = xinv_heavy_first((int)blockIdx.x, NB, nh >> 2) * 4 + wave;
+            active = wt < a.nstrip * a.nrb + a.nsplit * a.nrb;
+            wt = xinv_seam_tile(active ? wt : 0, a.nstrip, a.nrb, a.nsplit);
+        }
+    }
     if (a.tile_list) {
         wt = a.tile_list[m * a.ntl + wt];
         active = wt >= 0;
@@ -1020,7 +999,12 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #pragma unroll
     for (int s = 0; s < K; s++) { acc[s] = 0.0; cnt[s] = 0; }
 
-    if (active) {
+    // SEAM: only a tile that wraps around the seam takes the lane-masked passes; every other tile of the launch runs the
+    // plain march (with the passes behind wave-uniform branches inside ONE march every tile lost its instruction
+    // interleaving: 3601 columns took 1.9x the time of 3600 -- profiles/r05_seam_rates.txt)
+    auto march = [&](auto smtag) {
+        constexpr bool SM = decltype(smtag)::value;
+        (void)SM;
 #if XINV_INCR_OFF
         // rows are requested in increasing order: keep the clamped row offset incrementally
         row_t lrow = yu0 - H;
@@ -1120,7 +1104,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                     const row_t da = (yu0 - ja > ja - (yu1 - 1)) ? yu0 - ja : ja - (yu1 - 1);
                     if (da <= 2 * K - (2 * s - 1) && ja >= 1 && ja <= ycr - 2)
 #endif
-                    if constexpr (!SEAM) {
+                    if constexpr (!SM) {
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
                     const double v = M::template upd<X, UM, D>(cw, sj, sjp, comp<X>(sw[sj]),
@@ -1138,7 +1122,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                     const row_t db = (yu0 - jb > jb - (yu1 - 1)) ? yu0 - jb : jb - (yu1 - 1);
                     if (db <= 2 * K - 2 * s && jb >= 1 && jb <= ycr - 2)
 #endif
-                    if constexpr (!SEAM) {
+                    if constexpr (!SM) {
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
                     const double v = M::template upd<X, UM, D>(cw, sj, sjp, comp<X>(sw[sj]),
@@ -1203,6 +1187,11 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #endif
             }, std::make_integer_sequence<int, D>{});
         }
+    };
+    if (active) {
+        bool wraps = false;
+        if constexpr (SEAM) wraps = sl.has_e || sl.has_w;
+        if (wraps) march(std::integral_constant<bool, SEAM>{}); else march(std::false_type{});
     }
 
     if (a.no_ctl) return;

@@ -182,8 +182,9 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
 
     // one point update of component X on the plane held in slot `sk` (k+1 in `skp`, k-1 in `skm`)
     // (SEAM: `lw` = all-ones word where the lane takes part in this pass)
-    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, unsigned lw = ~0u) {
+    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, auto smt, unsigned lw = ~0u) {
         constexpr int X = decltype(xt)::value;
+        constexpr bool SM = decltype(smt)::value;
         const bool okc = X ? lc.ok_y : lc.ok_x;
         const bool inr = okc && row_upd && (kk >= 1) && (kk <= zc - 2);
         double w, e;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         } else {
             v = xinv_upd_std3d_sel(sC, sKP, sKM, jP, jM, e, w, aP, a0, bP, b0, cE, c0, f, inr, a.sc_);
         }
-        if constexpr (SEAM) v = xinv_bitsel(lw, v, sC);
+        if constexpr (SM) v = xinv_bitsel(lw, v, sC);
         setc<X>(sw[sk], v);
         return v;
     };
@@ -227,14 +228,22 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
     auto seam_half = [&](int sk, int skp, int skm, int64_t kk, const double2 &jP2, const double2 &jM2, auto xt) {
         constexpr int X = decltype(xt)::value;
         using XB = std::integral_constant<int, 1 - X>;
-        if (sl.has_e) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, sl.fe[1 - X]);
-        update(sk, skp, skm, kk, comp<X>(jP2), comp<X>(jM2), xt, sl.reg[X]);
-        if (sl.has_w) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, sl.fw[1 - X]);
+        if (sl.has_e) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, std::true_type{}, sl.fe[1 - X]);
+        update(sk, skp, skm, kk, comp<X>(jP2), comp<X>(jM2), xt, std::true_type{}, sl.reg[X]);
+        if (sl.has_w) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, std::true_type{}, sl.fw[1 - X]);
     };
     (void)seam_half;
 
+    // SEAM: only a cross-section that wraps around the seam takes the lane-masked passes and exchanges both components of
+    // its rows; every other workgroup of the launch runs the plain march (SM = false) with the one-component exchange in
+    // the same LDS (profiles/r05_seam_rates.txt: with the passes behind uniform branches in ONE march, and 16 bytes per lane
+    // exchanged everywhere, 721 columns ran 1.4x the time of 720)
+    double (*xd)[2][NW][64] = reinterpret_cast<double (*)[2][NW][64]>(&xch[0][0][0][0]);
+    double2 (*x2)[2][NW][64] = reinterpret_cast<double2 (*)[2][NW][64]>(&xch[0][0][0][0]);   // (SM marches only: SEAM kernels)
     // one pipeline step: plane r (= rbase + U) enters slot U; JP = parity of this wave's row
-    auto step = [&](int64_t r, const Pack &p, auto utag, auto jtag) {
+    auto step = [&](int64_t r, const Pack &p, auto utag, auto jtag, auto smt) {
+        constexpr bool SM = decltype(smt)::value;
+        using XchS = std::conditional_t<SM, double2, double>;
         constexpr int U = decltype(utag)::value;
         constexpr int JP = decltype(jtag)::value;
         constexpr int X = (1 + (U & 1) + JP) & 1;              // component touched in this step
@@ -254,24 +263,30 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
                                      (c + c));
             rok[S1] = (aP != u) && (a0 != u) && (bP != u) && (b0 != u) && (c != u);
         }
-        if constexpr (SEAM) xch[bw][0][wave][lane] = sw[U];
-        else xch[bw][0][wave][lane] = comp<X>(sw[U]);          // as loaded: neighbours' next red
+        if constexpr (SM) x2[bw][0][wave][lane] = sw[U];
+        else xd[bw][0][wave][lane] = comp<X>(sw[U]);           // as loaded: neighbours' next red
 
         {   // red half-sweep on plane r-1
-            const XchT jM = xch[br][0][wm][lane], jP = xch[br][0][wp][lane];
-            if constexpr (SEAM) {
+            XchS jM, jP;
+            if constexpr (SM) {
+                jM = x2[br][0][wm][lane]; jP = x2[br][0][wp][lane];
                 seam_half(S1, U, S2, r - 1, jP, jM, XT{});
-                xch[bw][1][wave][lane] = sw[S1];
+                x2[bw][1][wave][lane] = sw[S1];
             } else {
-                const double v = update(S1, U, S2, r - 1, jP, jM, XT{});
-                xch[bw][1][wave][lane] = v;                    // red-updated: neighbours' next black
+                jM = xd[br][0][wm][lane]; jP = xd[br][0][wp][lane];
+                const double v = update(S1, U, S2, r - 1, jP, jM, XT{}, std::false_type{});
+                xd[bw][1][wave][lane] = v;                     // red-updated: neighbours' next black
             }
         }
         {   // black half-sweep on plane r-2
             const int64_t kk = r - 2;
-            const XchT jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
-            if constexpr (SEAM) seam_half(S2, S1, S3, kk, jP, jM, XT{});
-            else update(S2, S1, S3, kk, jP, jM, XT{});
+            if constexpr (SM) {
+                const double2 jM = x2[br][1][wm][lane], jP = x2[br][1][wp][lane];
+                seam_half(S2, S1, S3, kk, jP, jM, XT{});
+            } else {
+                const double jM = xd[br][1][wm][lane], jP = xd[br][1][wp][lane];
+                update(S2, S1, S3, kk, jP, jM, XT{}, std::false_type{});
+            }
             const bool pin = row_use && (kk >= k0) && (kk < k1);
             const double2 t = sw[S2];
             if (pin) {                                         // wave-uniform: an owned row of an owned plane
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         __syncthreads();
     };
 
-    auto march = [&](auto jtag) {
+    auto march = [&](auto jtag, auto smt) {
         // start a multiple of D planes below k0 - 2 (slot indices are compile-time), run until the
         // black half-sweep of plane k1 - 1 (step k1 + 1)
         const int64_t rstart = (k0 >= D) ? k0 - D : 0;
@@ -303,13 +318,20 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         for (int64_t rb_ = rstart; rb_ <= rlast; rb_ += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
-                step(rb_ + U, pf[U % PF], utag, jtag);
+                step(rb_ + U, pf[U % PF], utag, jtag, smt);
                 pf[U % PF] = load(rb_ + U + PF);
             }, std::make_integer_sequence<int, D>{});
         }
     };
-    if (j & 1) march(std::integral_constant<int, 1>{});
-    else       march(std::integral_constant<int, 0>{});
+    bool wraps = false;
+    if constexpr (SEAM) wraps = sl.has_e || sl.has_w;        // (the same for every wavefront of the workgroup: one strip)
+    if (wraps) {
+        if (j & 1) march(std::integral_constant<int, 1>{}, std::integral_constant<bool, SEAM>{});
+        else       march(std::integral_constant<int, 0>{}, std::integral_constant<bool, SEAM>{});
+    } else {
+        if (j & 1) march(std::integral_constant<int, 1>{}, std::false_type{});
+        else       march(std::integral_constant<int, 0>{}, std::false_type{});
+    }
 
     if (a.no_ctl) return;
 

@@ -44,7 +44,7 @@
 // (lanes, norm_lag, pipe_fr, graph, sweeps_per_launch, flags).  The test-hooks build (build/libxinv_hooks.so) and A/B
 // variant builds (-DXINV_EXPERIMENTS=1) additionally honour the XINV_* switches of rounds 2-4 where the option is 0.
 #if XINV_TEST_HOOKS || XINV_EXPERIMENTS
-#define XINV_ENV_INT(name, dflt) ([] { const char *e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#define XINV_ENV_INT(name, dflt) ([&] { const char *e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
 #else
 #define XINV_ENV_INT(name, dflt) (dflt)
 #endif
@@ -485,10 +485,12 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         // (the shorter tail / redo passes of a pipelined plan run k_fused2d: four 112-column tiles per workgroup)
         // odd-xc periodic seam: the edge strips' tiles run two or three passes per half-sweep; where the row blocks are
         // tall enough their row blocks are cut in two, so that a launch of one round of workgroups does not end with them
-        pl.split = pl.seam && cdiv(p.yc, pl.nrb) >= 16 && cdiv(p.xc, strip_uw(pl, pl.K, pl.pipe)) >= 8;   // (and the edge strips a minority)
+        pl.split = (pl.seam && cdiv(p.yc, pl.nrb) >= 16 && cdiv(p.xc, strip_uw(pl, pl.K, pl.pipe)) >= 8) ? 2 : 0;   // (and the edge strips a minority)
+        if (pl.split && cdiv(p.yc, pl.nrb) >= 48) pl.split = 3;   // (profiles/r05_seam_rates.txt: 2, 3, 4 pieces within 3 % of each other)
+        if (pl.split) pl.split = XINV_ENV_INT("XINV_SEAM_PARTS", pl.split);
         pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, strip_uw(pl, XINV_KMAX, false)) * pl.nrb, 4) + 1;
         if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, strip_uw(pl, pl.K, true)) * pl.nrb + 1);
-        if (pl.split) pl.nsg += 2 * pl.nrb;
+        if (pl.split) pl.nsg += 2 * (pl.split - 1) * pl.nrb;
         if (pl.even_split && !(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
             rc = plan_tile_skip(p, pl, ws, st, opt);
             if (rc) return rc;

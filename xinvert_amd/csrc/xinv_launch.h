@@ -33,7 +33,7 @@ struct Plan {
     int tpw;                 // wave-tiles per workgroup of the planned kernel: 4, or 1 with `pipe`
     int npair;               // `pipe`: column pairs per lane (1 or 2: strips of 112 or 240 owned columns)
     bool pipe_fr;            // `pipe`: the forcing rides the LDS ring (launches whose arrays exceed the caches)
-    bool split;              // odd-xc periodic seam: the edge strips' row blocks are cut in two (xinv_tile_rows): their
+    int split;               // odd-xc periodic seam: the edge strips' row blocks are cut in this many pieces (0: whole; xinv_tile_rows): their
                              // workgroups run up to three passes per half-sweep and would otherwise end a launch alone
     bool fma;                // XINV_FLAG_FMA: the contracted-arithmetic kernel variants (per-row-coefficient forms only)
     bool alias_ac;           // `pq`: A and C hold the same numbers everywhere -- C is read out of A (FusedGen2DQA, kernel mask um | 2)
@@ -61,7 +61,7 @@ static inline int strip_uw(const Plan &pl, int K, bool pipe)
 {
     return (pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K) - (pl.seam ? 2 : 0);
 }
-static inline int seam_nsplit(const Plan &pl, int nstrip) { return !pl.split ? 0 : (nstrip == 1 ? 1 : 2); }
+static inline int seam_nsplit(const Plan &pl, int nstrip) { return pl.split < 2 ? 0 : (nstrip == 1 ? 1 : 2) * (pl.split - 1); }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                           hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false, bool pq = false)
@@ -715,7 +715,21 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     }
     int *hl = ws->h_list, *hs = ws->h_list + (size_t)nb * ntl;
     for (int64_t m = 0; m < nb; m++) {
-        for (int t = 0; t < ntl; t++) hl[m * ntl + t] = t < (int)act[(size_t)m].size() ? act[(size_t)m][t] : -1;
+        std::vector<int> &am = act[(size_t)m];
+        if (pl.seam && !fixedRB) {
+            // odd-xc periodic seam: the edge strips' tiles (two passes per half-sweep) are dispatched first, spread over
+            // the XCDs (xinv_heavy_first; the kernels do the same arithmetic when there is no list)
+            auto heavy = [&](int id) { const int s_ = id % nstrip; return id >= nstrip * best || s_ == 0 || s_ == nstrip - 1; };
+            const int nh = (int)(std::stable_partition(am.begin(), am.end(), heavy) - am.begin());
+            const int nwg = ntl / tpw, q = nwg >> 3, rem = nwg & 7;
+            for (int L = 0; L < nwg; L++) {
+                const int xcd = L & 7, T = xcd * q + std::min(xcd, rem) + (L >> 3);
+                const int sq = xinv_heavy_first(L, nwg, nh / tpw);
+                for (int w = 0; w < tpw; w++)
+                    hl[m * ntl + T * tpw + w] = sq * tpw + w < (int)am.size() ? am[(size_t)(sq * tpw + w)] : -1;
+            }
+        } else
+        for (int t = 0; t < ntl; t++) hl[m * ntl + t] = t < (int)am.size() ? am[(size_t)t] : -1;
         for (int t = 0; t < nskip; t++) hs[m * nskip + t] = t < (int)skp[(size_t)m].size() ? skp[(size_t)m][t] : -1;
     }
     HIPCHK(hipMemcpyAsync(ws->d_list, ws->h_list, nints * sizeof(int), hipMemcpyHostToDevice, st));
@@ -743,7 +757,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
         pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX - (pl.seam ? 2 : 0)) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
         if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, UW) * pl.nrb + 1);
-        if (pl.split) pl.nsg += 2 * pl.nrb;                                   // (the second halves of the edge strips' row blocks)
+        if (pl.split) pl.nsg += 2 * (pl.split - 1) * pl.nrb;                  // (the later pieces of the edge strips' row blocks)
     }
     return XINV_OK;
 }

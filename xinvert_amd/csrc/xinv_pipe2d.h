@@ -706,6 +706,12 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 #endif
     int wt = T;
     bool active = wt < a.nstrip * a.nrb + (SEAM ? a.nsplit * a.nrb : 0);
+    if constexpr (SEAM) {                                // (the edge strips' tiles first: xinv_heavy_first)
+        if (!a.tile_list && NB == a.nstrip * a.nrb + a.nsplit * a.nrb) {
+            const int nh = (a.nstrip == 1 ? 1 : 2) * a.nrb + a.nsplit * a.nrb;
+            wt = xinv_seam_tile(xinv_heavy_first((int)blockIdx.x, NB, nh), a.nstrip, a.nrb, a.nsplit);
+        }
+    }
     if (a.tile_list) {
         wt = a.tile_list[m * a.ntl + T];
         active = wt >= 0;
@@ -751,12 +757,23 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
             gtot = g > gtot ? g : gtot;
         }
         gtot = ((gtot + B - 1) / B) * B;
-        switch (pwi) {
-        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0, SEAM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF, SEAM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF, SEAM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
-        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF, SEAM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break;
+        // SEAM: only the tiles that wrap around the seam (the edge strips') take the three-pass march; every other tile of
+        // the launch runs the plain one.  (One march with the extra passes behind wave-uniform branches cost EVERY tile
+        // its instruction interleaving: 3601 columns ran 1.45x the time of 3600 -- profiles/r05_seam_rates.txt.)
+        bool wraps = false;
+        if constexpr (SEAM) { const SeamLanes sl = make_seamlanes(st0[0], lc[0], xc); wraps = sl.has_e || sl.has_w; }
+#ifdef XINV_EXP_SEAM_NOWRAP
+        wraps = false;                                   // (timing experiment only: wrong results)
+#endif
+#define XINV_PIPE_MARCH(SM) \
+        switch (pwi) { \
+        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break; \
+        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break; \
+        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break; \
+        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break; \
         }
+        if (wraps) { XINV_PIPE_MARCH(SEAM) } else { XINV_PIPE_MARCH(false) }
+#undef XINV_PIPE_MARCH
     }
     }
     // What follows needs a dozen kernel arguments the march does not: read them again from the argument
