@@ -189,6 +189,17 @@ __device__ __forceinline__ double xinv_bitsel(unsigned m, double a, double b)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// select by a wave-uniform 64-bit lane mask (an SGPR pair): lanes of m -> a, the others -> b (two v_cndmask_b32)
+__device__ __forceinline__ double xinv_bitsel64(unsigned long long m, double a, double b)
+{
+    unsigned lo, hi;
+    asm("v_cndmask_b32_e64 %0, %2, %3, %6\n\tv_cndmask_b32_e64 %1, %4, %5, %6"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"((unsigned)__double2loint(b)), "v"((unsigned)__double2loint(a)),
+          "v"((unsigned)__double2hiint(b)), "v"((unsigned)__double2hiint(a)), "s"(m));
+    return __hiloint2double((int)hi, (int)lo);
+}
+
 template <int X, unsigned UM, int Q, int NC, int D>
 __device__ __forceinline__ double cget(const CoefWin<NC, D> &w, int slot)
 {
@@ -596,6 +607,38 @@ __device__ __forceinline__ LaneCols make_lanecols(int64_t xu0, int H, int UW, in
     }
     lc.use_x = (c0 >= xu0 && c0 < xu0 + UW && c0 < xc);
     lc.use_y = (c1 >= xu0 && c1 < xu0 + UW && c1 < xc);
+    return lc;
+}
+
+// RING (periodic x with ODD xc; round 5, k_pipe3d): the row as an EVEN ring of xc + 1 virtual columns -- the xc real ones
+// and a phantom column P between xc-1 and 0.  Strips start on even virtual columns, so a lane's .x slot always holds an
+// even virtual column and its .y slot an odd one: the lane slots keep ONE parity across a wrap (the SeamLanes scheme
+// above flips it and runs a half-sweep of a wrapping tile as two or three lane-masked passes with both components of the
+// j neighbours).  Column xc-1 (even) always sits in an .x slot and P in the .y slot of the same lane ("seam lanes").
+//   * P is never updated (ok_y = false there), never owned; it is loaded from column xc-1's address and refreshed from the
+//     lane's .x after every update of column xc-1: it always MIRRORS column xc-1.  Column 0 reads it as its west neighbour.
+//   * The coloured order of this case (oracle: seq_colour) updates column xc-1 inside the half-sweep of its own colour --
+//     the one that updates the .x slots of its row -- right AFTER column 0: that half-sweep masks the seam lanes out of
+//     its pass and runs ONE more pass for them alone, whose east operand is the next lane's .x (the new column 0)
+//     instead of the lane's own .y.  The other half-sweep of the row is the plain single pass: 1.5 passes on average,
+//     and only in tiles that hold a seam lane.
+//   * Information crosses the seam westwards one virtual column pair faster (0 -> xc-1 inside one half-sweep, P skipped)
+//     and the west halo of a strip loses a slot to P: both halos get one column pair more (HW = H + 2 virtual columns
+//     a side, the strip owns 128 - 2 H - 4).
+struct RingSeam { unsigned long long lanes; bool any; };     // lanes whose .x slot holds column xc-1 (wave-uniform mask)
+__device__ __forceinline__ LaneCols make_lanecols_ring(int64_t xu0, int HW, int UW, int lane, int64_t xc, RingSeam &rs)
+{
+    LaneCols lc;
+    const int64_t c0 = xu0 - HW + 2 * lane, c1 = c0 + 1, xv = xc + 1;
+    int64_t w0 = c0 % xv; if (w0 < 0) w0 += xv;              // (even: never P)
+    int64_t w1 = c1 % xv; if (w1 < 0) w1 += xv;
+    lc.l0 = w0; lc.l1 = (w1 == xc) ? xc - 1 : w1;
+    lc.ok_x = true; lc.ok_y = (w1 != xc);
+    lc.cls_x = lc.cls_y = 1;
+    lc.use_x = (c0 >= xu0 && c0 < xu0 + UW && c0 < xc);
+    lc.use_y = (c1 >= xu0 && c1 < xu0 + UW && c1 < xc);
+    rs.lanes = __builtin_amdgcn_ballot_w64(w0 == xc - 1);
+    rs.any = rs.lanes != 0ull;
     return lc;
 }
 

@@ -192,6 +192,14 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int wt = T * 4 + wave;
     bool active = wt < a.nstrip * a.nrb;
+    if constexpr (SEAM) {                                    // (the edge strips' tiles first: xinv_heavy_first, as k_fused2d)
+        if (!a.tile_list) {
+            const int nh = (a.nstrip == 1 ? 1 : 2) * a.nrb;
+            wt = xinv_heavy_first((int)blockIdx.x, NB, nh >> 2) * 4 + wave;
+            active = wt < a.nstrip * a.nrb;
+            wt = xinv_seam_tile(active ? wt : 0, a.nstrip, a.nrb, 0);
+        }
+    }
     if (a.tile_list) {                                       // masked-tile skipping, as k_fused2d
         wt = a.tile_list[m * a.ntl + wt];
         active = wt >= 0;
@@ -228,7 +236,10 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
 #pragma unroll
     for (int s = 0; s < K; s++) { acc[s] = 0.0; cnt[s] = 0; }
 
-    if (active) {
+    // SEAM: only a tile that wraps around the seam takes the lane-masked passes (as k_fused2d: with them behind uniform
+    // branches inside ONE march every tile of the launch paid for them)
+    auto march = [&](auto smtag) {
+        constexpr bool SM = decltype(smtag)::value;
         struct Pack { double2 s; double2 c[NC]; };
         auto load = [&](int64_t r) {
             Pack p;
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
 
         // the two colours of a row (even row: c0 then c1; odd row: c2 then c3); SEAM: the lane-masked passes
         auto row_stage = [&](int sj, int sjp, int sjm, bool rowok) {
-            if constexpr (!SEAM) {
+            if constexpr (!SM) {
                 double v = M::template upd<0, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_x, west, a.sc_);
                 sw[sj].x = v;
                 v = M::template upd<1, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_y, false, a.sc_);
@@ -335,6 +346,11 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
                 step2(rb_ + U + 1, std::integral_constant<int, U>{});
             }, std::make_integer_sequence<int, D / 2>{});
         }
+    };
+    if (active) {
+        bool wraps = false;
+        if constexpr (SEAM) wraps = s9.any_ev_y || s9.any_sm_x || s9.any_sm_y || s9.any_od_x;
+        if (wraps) march(std::integral_constant<bool, SEAM>{}); else march(std::false_type{});
     }
 
     if (a.no_ctl) return;

@@ -267,14 +267,14 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         // -- 1.45e11 -- and is gone.)
         pl.K2 = false;
         const int k2_auto = XINV_ENV_INT("XINV_3D_K2", 1);
-        if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND && !pl.seam &&
+        if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND && !(pl.seam && (pl.fma || p.xc < 64)) &&
             (opt.sweeps_per_launch == 2 || (opt.sweeps_per_launch == 0 && k2_auto)) &&
             opt.rows_per_tile == 0 && p.stop.mxLoop >= 1 &&
             p.zc * p.yc * 64 < ((int64_t)1 << 31) &&                      // (32-bit offsets into the record table)
             n * 8 < ((int64_t)1 << 31)) {                                 // (k_pipe3d addresses a volume through buffer resources: below 2 GiB)
             pl.K2 = true;
             pl.K = 2;
-            pl.nsg2 = (int)cdiv(p.xc, 120);
+            pl.nsg2 = (int)cdiv(p.xc, pl.seam ? 116 : 120);  // (odd-xc periodic seam: the ring variant's halos, xinv_fused.h RING)
             pl.nrb2 = (int)cdiv(p.yc, XINV_P3_G * XINV_P3_RR - 8);
             {
                 // per-(plane, row) records of the x-uniform coefficients, relaxation factor and predicate: once per solve

@@ -258,7 +258,7 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
             a.member0 = member0 + m0;
             a.rowf = (const double *)ws->d_rowf; a.srowf = pl.srowf2;
             if (pl.fma) xinv_launch_pipe3d_fma(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a);
-            else        xinv_launch_pipe3d(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a);
+            else        xinv_launch_pipe3d(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a, pl.seam != 0);
         }
         HIPCHK(hipGetLastError());
         return XINV_OK;

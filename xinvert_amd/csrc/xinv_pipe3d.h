@@ -73,11 +73,14 @@ __global__ __launch_bounds__(256) void k_row_factor3d(RowFactor3Args a)
 }
 #endif
 
-template <int G, int RR, bool AL, bool FMA = false>
+// SEAM (periodic x, ODD xc): the even ring with a phantom column (xinv_fused.h: RING) -- one more pass, for the seam lanes
+// alone, in the half-sweeps that update the .x slots, and only in the cross-sections that hold a seam lane.
+template <int G, int RR, bool AL, bool FMA = false, bool SEAM = false>
 __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 {
+    static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
     xinv_fresh_scalar_cache();
-    constexpr int K = 2, H = 2 * K, UW = 128 - 2 * H, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
+    constexpr int K = 2, H = 2 * K, HW = H + (SEAM ? 2 : 0), UW = 128 - 2 * HW, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -105,9 +108,13 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const int64_t xc = a.xc;
     const int64_t xu0 = (int64_t)st * UW;
     const double u = a.sc_.undef;
-    const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
-    const int64_t st0 = xu0 - H + 2 * lane;
-    const unsigned long long okx64 = __builtin_amdgcn_ballot_w64(lc.ok_x), oky64 = __builtin_amdgcn_ballot_w64(lc.ok_y);
+    RingSeam rs = {0ull, false};
+    LaneCols lc;
+    if constexpr (SEAM) lc = make_lanecols_ring(xu0, HW, UW, lane, xc, rs);
+    else lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
+    const int64_t st0 = xu0 - HW + 2 * lane;
+    // (SEAM: the seam lanes' .x -- column xc-1 -- is left out of the pass of its half-sweep and updated alone behind it)
+    const unsigned long long okx64 = __builtin_amdgcn_ballot_w64(lc.ok_x) & ~rs.lanes, oky64 = __builtin_amdgcn_ballot_w64(lc.ok_y);
 
     // the RR rows of this wavefront (the same rows in both groups)
     const int j0 = jb * RJ - H + gw * RR;
@@ -199,20 +206,25 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)srcS, 0, vol_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)pF, 0, vol_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)dstS, 0, vol_bytes, 0x00020000);
-    const unsigned lo0 = (unsigned)lc.l0 * 8u, lo1 = (unsigned)lc.l1 * 8u;
-    const unsigned so0 = lc.use_x ? (unsigned)st0 * 8u : 0xffffffffu, so1 = lc.use_y ? (unsigned)(st0 + 1) * 8u : 0xffffffffu;
+    const unsigned lo0 = (unsigned)lc.l0 * 8u;
+    const unsigned so0 = lc.use_x ? (unsigned)st0 * 8u : 0xffffffffu;
+    // (unaligned strips: a lane owns both of its columns or -- the last column of an odd row -- only the first: one 16-byte
+    //  store, one 8-byte)
+    const unsigned so01 = (lc.use_x && lc.use_y) ? (unsigned)st0 * 8u : 0xffffffffu;
+    const unsigned sox = (lc.use_x && !lc.use_y) ? (unsigned)st0 * 8u : 0xffffffffu;
+    (void)so01; (void)sox;
     constexpr int NTAUX = XINV_P3_NT ? 2 : 0;            // cache-policy operand: bit 1 = nt on this target
     auto ldrow = [&](__amdgpu_buffer_rsrc_t rs, int soff, auto auxtag, unsigned drop = 0u) {
         constexpr int AUX = decltype(auxtag)::value;
         double2 v;
-        if (AL) {
-            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lo0 | drop), soff, AUX);
-            v.x = __hiloint2double((int)t[1], (int)t[0]); v.y = __hiloint2double((int)t[3], (int)t[2]);
-        } else {
-            const auto t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(lo0 | drop), soff, AUX);
-            const auto t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(lo1 | drop), soff, AUX);
-            v.x = __hiloint2double((int)t0[1], (int)t0[0]); v.y = __hiloint2double((int)t1[1], (int)t1[0]);
-        }
+        // ONE 16-byte request per lane also where the strips are not 16-byte aligned (odd xc, odd strides: the hardware
+        // takes 8-byte-aligned addresses; round 4 split these into two 8-byte requests: fixed x, 721 columns 2.34 against
+        // 2.74e11 for 720).  A lane's .y is the element behind its .x wherever .y is a column that is ever read: even xc
+        // (periodic or not), odd xc with fixed x (the last real column sits in an .x slot, what follows it is never
+        // read), and the ring layout of the odd-xc periodic seam, whose seam lanes' .y -- column 0 of the next row, or
+        // nothing -- is replaced by the mirror of column xc-1 where the plane enters the window.
+        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lo0 | drop), soff, AUX);
+        v.x = __hiloint2double((int)t[1], (int)t[0]); v.y = __hiloint2double((int)t[3], (int)t[2]);
         return v;
     };
     auto ldS = [&](int soff) { return ldrow(rsS, soff, std::integral_constant<int, NTAUX>{}); };
@@ -238,11 +250,17 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 
     // one point update of component X of row rr on the plane in slot sk (k+1 in skp, k-1 in skm): the expression
     // of k_fused3d<UNI>, the increment added under the predicate as EXEC
-    auto update = [&](auto rtag, auto xt, int sk, int skp, int skm, const Rec &e, double jP, double jM, double f) {
+    // (fixt: the seam lanes' pass -- X == 0, east operand = the next lane's .x, the new column 0; lanes: rs.lanes)
+    auto update = [&](auto rtag, auto xt, int sk, int skp, int skm, const Rec &e, double jP, double jM, double f,
+                      auto fixt) {
         constexpr int rr = decltype(rtag)::value;
         constexpr int X = decltype(xt)::value;
+        constexpr bool FIX = decltype(fixt)::value;
+        static_assert(!FIX || X == 0, "column xc-1 sits in an .x slot");
         double w, ee;
         row_neighbours<X>(sw[rr][sk], w, ee);
+        if constexpr (FIX) ee = xinv_lane_down(sw[rr][sk].x);
+        const unsigned long long lanes64 = FIX ? rs.lanes : (X ? oky64 : okx64);
         const double sC = comp<X>(sw[rr][sk]), sKP = comp<X>(sw[rr][skp]), sKM = comp<X>(sw[rr][skm]);
         if constexpr (FMA) {                             // XINV_FLAG_FMA: the oracle's XO_FMA form, finished by one fma under EXEC
             const double ya = __builtin_fma(e.aP, sKP - sC, -(e.a0 * (sC - sKM)));
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             const double yc_ = __builtin_fma(e.c, ee - sC, -(e.c * (sC - w)));
             double t = __builtin_fma(ya, a.sc_.ratio2Sqr, __builtin_fma(yb, a.sc_.ratio1Sqr, yc_));
             t = __builtin_fma(-f, a.sc_.delxSqr, t);
-            const double v = xinv_fma_where_ne(sC, t, e.rq, f, u, (X ? oky64 : okx64) & e.rok);
+            const double v = xinv_fma_where_ne(sC, t, e.rq, f, u, lanes64 & e.rok);
             setc<X>(sw[rr][sk], v);
             return v;
         }
@@ -267,14 +285,23 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             )
         ) - f * a.sc_.delxSqr;
         temp *= e.rq;
-        const double v = xinv_add_where_ne(sC, temp, f, u, (X ? oky64 : okx64) & e.rok);
+        const double v = xinv_add_where_ne(sC, temp, f, u, lanes64 & e.rok);
         setc<X>(sw[rr][sk], v);
         return v;
     };
+    // SM marches: column xc-1 after its half-sweep's pass, then P mirrors it again
+    auto seam_fix = [&](auto rtag, int sk, int skp, int skm, const Rec &e, double jP, double jM, double f) {
+        constexpr int rr = decltype(rtag)::value;
+        const double v = update(rtag, std::integral_constant<int, 0>{}, sk, skp, skm, e, jP, jM, f, std::true_type{});
+        sw[rr][sk].y = xinv_bitsel64(rs.lanes, v, sw[rr][sk].y);
+        return v;
+    };
 
-    // one pipeline step of group GRP: plane r enters slot U; JP = parity of the wavefront's first row
-    auto step = [&](int r, auto gtag, auto utag, auto jtag) {
+    // one pipeline step of group GRP: plane r enters slot U; JP = parity of the wavefront's first row; SM: this
+    // cross-section holds a seam lane
+    auto step = [&](int r, auto gtag, auto utag, auto jtag, auto smt) {
         constexpr int GRP = decltype(gtag)::value, U = decltype(utag)::value, JP = decltype(jtag)::value;
+        constexpr bool SM = decltype(smt)::value;
         constexpr int S1 = (U + 3) % D, S2 = (U + 2) % D, S3 = (U + 1) % D;
         constexpr int bw = U & 1, br = (U + 1) & 1;
 #define XROW(rr) ((1 + (U & 1) + JP + (rr)) & 1)          /* component row rr touches in this step */
@@ -284,6 +311,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         for (int rr = 0; rr < RR; rr++) {
             if (GRP == 0) {
                 sw[rr][U] = pfS[rr];
+                if constexpr (SM) sw[rr][U].y = xinv_bitsel64(rs.lanes, sw[rr][U].x, sw[rr][U].y);     // P mirrors column xc-1
                 pfS[rr] = ldS(plane_off(r + 1, rr));
             } else {
                 sw[rr][U] = ring[gw][rr][U & 1][0][lane];
@@ -316,10 +344,12 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                 const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S1]) : jMe;
                 const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S1]) : jPe;
 #if XINV_P3_FRING
-                const double v = update(rtag, XT{}, S1, U, S2, e, jP, jM, comp<X>(fwr[rr]));
+                const double fX = comp<X>(fwr[rr]);
 #else
-                const double v = update(rtag, XT{}, S1, U, S2, e, jP, jM, comp<X>(fw[rr][S1 & 1]));
+                const double fX = comp<X>(fw[rr][S1 & 1]);
 #endif
+                double v = update(rtag, XT{}, S1, U, S2, e, jP, jM, fX, std::false_type{});
+                if constexpr (SM && X == 0) v = seam_fix(rtag, S1, U, S2, e, jP, jM, fX);
                 if (rr == 0) xch[bw][1][wave][0][lane] = v;          // red-updated: the neighbours' next black half-sweep
                 if (rr == RR - 1) xch[bw][1][wave][1][lane] = v;
             }, std::make_integer_sequence<int, RR>{});
@@ -337,10 +367,12 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                 const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S2]) : jMe;
                 const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S2]) : jPe;
 #if XINV_P3_FRING
-                update(rtag, XT{}, S2, S1, S3, e, jP, jM, fwb[rr]);
+                const double fX = fwb[rr];
 #else
-                update(rtag, XT{}, S2, S1, S3, e, jP, jM, comp<X>(fw[rr][S2 & 1]));
+                const double fX = comp<X>(fw[rr][S2 & 1]);
 #endif
+                update(rtag, XT{}, S2, S1, S3, e, jP, jM, fX, std::false_type{});
+                if constexpr (SM && X == 0) seam_fix(rtag, S2, S1, S3, e, jP, jM, fX);
             }, std::make_integer_sequence<int, RR>{});
 #pragma unroll
             for (int rr = 0; rr < RR; rr++) {
@@ -359,10 +391,12 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                                                   (unsigned)__double2loint(t.y), (unsigned)__double2hiint(t.y)};
                             __builtin_amdgcn_raw_buffer_store_b128(tv, rsD, (int)so0, doff, NTAUX);
                         } else {
+                            const xinv_v4u_ tv = {(unsigned)__double2loint(t.x), (unsigned)__double2hiint(t.x),
+                                                  (unsigned)__double2loint(t.y), (unsigned)__double2hiint(t.y)};
                             const xinv_v2u_ tx = {(unsigned)__double2loint(t.x), (unsigned)__double2hiint(t.x)};
-                            const xinv_v2u_ ty = {(unsigned)__double2loint(t.y), (unsigned)__double2hiint(t.y)};
-                            __builtin_amdgcn_raw_buffer_store_b64(tx, rsD, (int)so0, doff, NTAUX);
-                            __builtin_amdgcn_raw_buffer_store_b64(ty, rsD, (int)so1, doff, NTAUX);
+                            __builtin_amdgcn_raw_buffer_store_b128(tv, rsD, (int)so01, doff, NTAUX);
+                            // (a last real column in an .x slot: odd xc -- with the seam only in the cross-sections that hold it)
+                            if constexpr (SM || !SEAM) __builtin_amdgcn_raw_buffer_store_b64(tx, rsD, (int)sox, doff, NTAUX);
                         }
                     }
                 }
@@ -377,7 +411,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     // a multiple of D); the last owned plane, k1 - 1, leaves group 1 in step k1 + 4 - rstart.
     const int rstart = (k0 >= D) ? k0 - D : 0;
     const int gend = k1 + 4 - rstart;
-    auto march = [&](auto gtag, auto jtag) {
+    auto march = [&](auto gtag, auto jtag, auto smt) {
         constexpr int GRP = decltype(gtag)::value;
         if (GRP == 0) {
 #pragma unroll
@@ -389,14 +423,21 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             xinv_unroll_steps([&](auto utag) {
                 constexpr int Ug = decltype(utag)::value;                // global step mod D
                 constexpr int U = (Ug + (GRP ? 1 : 0)) % D;              // slot of the entering plane: (g - 3) mod D for group 1
-                step(rstart + gb + Ug - 3 * GRP, gtag, std::integral_constant<int, U>{}, jtag);
+                step(rstart + gb + Ug - 3 * GRP, gtag, std::integral_constant<int, U>{}, jtag, smt);
             }, std::make_integer_sequence<int, D>{});
         }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    if (grp == 0) { if (j0 & 1) march(I0{}, I1{}); else march(I0{}, I0{}); }
-    else          { if (j0 & 1) march(I1{}, I1{}); else march(I1{}, I0{}); }
+    using SMF = std::false_type;
+    using SMT = std::integral_constant<bool, SEAM>;
+    if (SEAM && rs.any) {                                    // (the same for every wavefront of the workgroup: one strip)
+        if (grp == 0) { if (j0 & 1) march(I0{}, I1{}, SMT{}); else march(I0{}, I0{}, SMT{}); }
+        else          { if (j0 & 1) march(I1{}, I1{}, SMT{}); else march(I1{}, I0{}, SMT{}); }
+    } else {
+        if (grp == 0) { if (j0 & 1) march(I0{}, I1{}, SMF{}); else march(I0{}, I0{}, SMF{}); }
+        else          { if (j0 & 1) march(I1{}, I1{}, SMF{}); else march(I1{}, I0{}, SMF{}); }
+    }
 
     if (a.no_ctl) return;
     // wavefronts of group g hold the tile's share of sweep g+1 (only the columns a lane owns count)
