@@ -111,7 +111,12 @@ def families():
     F['fused3dg_seam'] = (lambda s: xuni(util.rand3dg(12, 40, 257, 'extend', 'periodic', seed=s), range(7)),
                           {}, dict(path=2, xuniform_mask=127), orc.COLOUR_2)
     F['fused3d_seam_uni'] = (lambda s: xuni(util.rand3d(12, 40, 257, 'fixed', 'periodic', seed=s), (0, 1, 2)),
-                             {}, dict(path=2, xuniform_mask=7, sweeps_per_launch=1), orc.COLOUR_2)
+                             dict(sweeps_per_launch=1), dict(path=2, xuniform_mask=7, sweeps_per_launch=1), orc.COLOUR_2)
+    # the seam as an even ring with a phantom column (round 5): k_pipe3d's two-sweep pass, k_pipe2d's four-sweep pass
+    F['fused3d_seam_ring'] = (lambda s: xuni(util.rand3d(12, 40, 257, 'fixed', 'periodic', seed=s), (0, 1, 2)),
+                        {}, dict(path=2, xuniform_mask=7, sweeps_per_launch=2), orc.COLOUR_2)
+    F['pipe2d_seam'] = (lambda s: xuni(util.rand2d('std2d', 96, 385, 'extend', 'periodic', msk=True, seed=s), (0, 2)),
+                        {}, dict(path=2, xuniform_mask=3, sweeps_per_launch=4, pipelined=1), orc.COLOUR_2)
     return F
 
 

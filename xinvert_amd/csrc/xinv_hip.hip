@@ -326,7 +326,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                 if (p.kind != KIND_STD2DT && opt.rows_per_tile == 0 && opt.sweeps_per_launch == 0 &&
                     !(opt.flags & (XINV_FLAG_NO_TILE_SKIP | XINV_FLAG_NO_PIPE)) && p.nbatch <= 64 &&
                     p.nbatch * p.yc * p.xc >= (int64_t)2000000) {
-                    const int uw_pipe = XINV_PIPE_UW(1) - (pl.seam ? 2 : 0);      // (one column pair per lane: what ships)
+                    const int uw_pipe = XINV_PIPE_UW(1) - (pl.seam ? 4 : 0);      // (one column pair per lane: what ships)
                     if (p.xc >= uw_pipe && p.nbatch * cdiv(p.xc, uw_pipe) * (p.yc + 1) <= (int64_t)50000000) {
                         rc = issue_strip_active(p, ws, st, uw_pipe, p.kind == KIND_STD2D ? 3 : 6);
                         if (rc) return rc;

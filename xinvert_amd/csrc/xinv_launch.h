@@ -59,7 +59,8 @@ static unsigned pick_um(int kind, unsigned umask)
 // lane; the odd-xc periodic seam variants own one pair less (k_fused2d: SEAM)
 static inline int strip_uw(const Plan &pl, int K, bool pipe)
 {
-    return (pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K) - (pl.seam ? 2 : 0);
+    // (odd-xc periodic seam: k_pipe2d's ring layout gives both halos a column pair, k_fused2d's lane classes the east one)
+    return (pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K) - (pl.seam ? (pipe ? 4 : 2) : 0);
 }
 static inline int seam_nsplit(const Plan &pl, int nstrip) { return pl.split < 2 ? 0 : (nstrip == 1 ? 1 : 2) * (pl.split - 1); }
 
@@ -755,7 +756,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     pl.skip_ppm = (int)((1000000 * nskipped) / (ntiles * nb));
     if (!fixedRB) {
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX - (pl.seam ? 2 : 0)) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX - (pl.seam ? (pl.nine ? 2 : 4) : 0)) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
         if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, UW) * pl.nrb + 1);
         if (pl.split) pl.nsg += 2 * (pl.split - 1) * pl.nrb;                  // (the later pieces of the edge strips' row blocks)
     }

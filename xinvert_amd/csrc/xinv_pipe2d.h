@@ -234,14 +234,16 @@ __device__ __forceinline__ void pipe_extend_fix(double2 &edge, const double2 &in
 // LDS instead of asking the L2 for it again.  For launches whose arrays exceed the caches (a batch of members) the
 // later wavefronts' requests, ~20 rows behind the first, had fallen out of the L2 by then: C4, 64 members: 8.3 B
 // per point-sweep measured against 6 B the variant must move (profiles/r03_pmc_*_c4.txt).
-// SEAM (periodic x, odd xc: xinv_fused.h): a half-sweep of a tile that wraps around the seam is up to three passes
-// under 64-bit lane masks ANDed into the update's EXEC mask -- east-wrapped lanes' other component, unwrapped lanes,
-// west-wrapped lanes' other component.
+// SEAM (periodic x, odd xc): the row as an even ring with a phantom column (xinv_fused.h: RING).  `seam_lanes`: the lanes
+// whose .x slot holds column xc-1; the half-sweeps that update the .x slots leave them out of their pass and run one more
+// pass for them alone (east operand: the next lane's .x, the new column 0), after which the phantom column mirrors
+// column xc-1 again.  Only the tiles that hold a seam lane are marched with SEAM = true (k_pipe2d below).
 template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT, int PW, int PF, bool SEAM = false>
 __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
                                                const LaneCols (&lc)[NP], const int64_t (&st0)[NP], int lane,
                                                double2 (*ring)[XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE], int gtot,
-                                               double &acc, int &cnt, int *prog, XinvCtl *ctl, int dbg_tile = 0)
+                                               double &acc, int &cnt, int *prog, XinvCtl *ctl, int dbg_tile = 0,
+                                               unsigned long long seam_lanes = 0ull)
 {
     constexpr int P = XINV_PIPE_P, H = 2 * P, D = 4, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     constexpr int R = PF + D;                            // row records; also the unroll period
@@ -281,22 +283,12 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     int nnx[NP], nny[NP];
 #pragma unroll
     for (int q = 0; q < NP; q++) {
-        okx64[q] = __builtin_amdgcn_ballot_w64(lc[q].ok_x); oky64[q] = __builtin_amdgcn_ballot_w64(lc[q].ok_y);
+        okx64[q] = __builtin_amdgcn_ballot_w64(lc[q].ok_x) & ~seam_lanes; oky64[q] = __builtin_amdgcn_ballot_w64(lc[q].ok_y);
         nsx[q] = nsy[q] = 0.0; nnx[q] = nny[q] = 0;
     }
 #endif
-
-    // SEAM: lane classes of the two components as 64-bit masks (wave-uniform: SGPR pairs)
-    unsigned long long sfe[2] = {0ull, 0ull}, sfw[2] = {0ull, 0ull};
-    if constexpr (SEAM) {
-        static_assert(!SEAM || (NP == 1 && !AL && PipeRec<M, UM>::HOIST), "seam variants: one column pair per lane, per-row records");
-        const SeamLanes sl = make_seamlanes(st0[0], lc[0], a.xc);
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            sfe[c] = __builtin_amdgcn_ballot_w64(sl.fe[c] != 0u);
-            sfw[c] = __builtin_amdgcn_ballot_w64(sl.fw[c] != 0u);
-        }
-    }
+    static_assert(!SEAM || (NP == 1 && !AL && PipeRec<M, UM>::HOIST && XINV_PIPE_EXECSEL),
+                  "seam variants: one column pair per lane, per-row records, updates under EXEC masks");
 
     const int in_lo = yu0 - H + 2 * PW;                  // first / last row entering this wavefront's window
     const int in_hi = yu1 - 1 + H - 2 * PW;
@@ -384,10 +376,12 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #endif
 
     // one half-sweep of row record sj (sjp / sjm: the rows below / above) on lane components X
-    auto half_pass = [&](auto xtag, auto jtag, auto ptag, auto mtag, unsigned long long lanes) {
+    // (fixt: the seam lanes' pass -- X == 0, the east operand is the next lane's .x)
+    auto half_pass = [&](auto xtag, auto jtag, auto ptag, auto mtag, auto fixt) {
         constexpr int X = decltype(xtag)::value, sj = decltype(jtag)::value, sjp = decltype(ptag)::value,
                       sjm = decltype(mtag)::value;
-        (void)lanes;
+        constexpr bool FIX = decltype(fixt)::value;
+        static_assert(!FIX || (X == 0 && NP == 1), "column xc-1 sits in an .x slot");
         // the one operand that crosses lanes: west of the first column / east of the last
         const double edge = (X == 0) ? xinv_lane_up(sw[NP - 1][sj].y) : xinv_lane_down(sw[0][sj].x);
         double nv[NP];
@@ -396,6 +390,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
             double w, e;
             if (X == 0) { w = (q == 0) ? edge : sw[q > 0 ? q - 1 : 0][sj].y; e = sw[q][sj].y; }
             else        { w = sw[q][sj].x; e = (q == NP - 1) ? edge : sw[q < NP - 1 ? q + 1 : q][sj].x; }
+            if constexpr (FIX) e = xinv_lane_down(sw[q][sj].x);
 #if XINV_PIPE_EXECSEL
             // the increment, added under the update predicate as EXEC (xinv_add_where: no select on the VALU)
             const double t = M::template inc<X, UM, R, false>(cw[q], sj, sjp, comp<X>(sw[q][sj]), comp<X>(sw[q][sjp]),
@@ -404,8 +399,8 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 // the predicate: (column may be updated) & (row may be updated: the record's predicate word is all
                 // ones or zero, k_row_factor) as a 64-bit lane mask on the scalar unit, (forcing defined) by the
                 // compare that writes EXEC
-                unsigned long long rm = (X ? oky64[q] : okx64[q]) & (unsigned long long)__double_as_longlong(rokw[sj]);
-                if constexpr (SEAM) rm &= lanes;
+                const unsigned long long rm = (FIX ? seam_lanes : (X ? oky64[q] : okx64[q])) &
+                                              (unsigned long long)__double_as_longlong(rokw[sj]);
                 if constexpr (ModelFma<M>::value)          // (t is the bracket before the relaxation factor: one fma finishes)
                     nv[q] = xinv_fma_where_ne(comp<X>(sw[q][sj]), t, cw[q].rq[sj], comp<X>(cw[q].v[FQ][sj]), u, rm);
                 else
@@ -424,13 +419,11 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
     };
     auto half_sweep = [&](auto xtag, auto jtag, auto ptag, auto mtag) {
         constexpr int X = decltype(xtag)::value;
-        if constexpr (!SEAM) {
-            half_pass(xtag, jtag, ptag, mtag, ~0ull);
-        } else {
-            using XB = std::integral_constant<int, 1 - X>;
-            if (sfe[1 - X]) half_pass(XB{}, jtag, ptag, mtag, sfe[1 - X]);
-            half_pass(xtag, jtag, ptag, mtag, ~(sfe[X] | sfw[X]));
-            if (sfw[1 - X]) half_pass(XB{}, jtag, ptag, mtag, sfw[1 - X]);
+        half_pass(xtag, jtag, ptag, mtag, std::false_type{});
+        if constexpr (SEAM && X == 0) {                  // column xc-1 behind column 0; the phantom column mirrors it again
+            constexpr int sj = decltype(jtag)::value;
+            half_pass(xtag, jtag, ptag, mtag, std::true_type{});
+            sw[0][sj].y = xinv_bitsel64(seam_lanes, sw[0][sj].x, sw[0][sj].y);
         }
     };
 
@@ -674,7 +667,8 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 #if XINV_PIPE_INV
     xinv_fresh_scalar_cache();
 #endif
-    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, UW = XINV_PIPE_UW(NP) - (SEAM ? 2 : 0), LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;   // (SEAM: k_fused2d's note)
+    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, HW = H + (SEAM ? 2 : 0), UW = XINV_PIPE_UW(NP) - (SEAM ? 4 : 0),
+                  LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;       // (SEAM: the ring layout's halos, xinv_fused.h RING)
     __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE];
     __shared__ int prog[2 * P];                          // hand-over progress counters (XINV_PIPE_FLAGS)
 
@@ -735,10 +729,12 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
     const int64_t xu0 = (int64_t)strip * UW;
     LaneCols lc[NP];
     int64_t st0[NP];
+    RingSeam rs = {0ull, false};
 #pragma unroll
     for (int q = 0; q < NP; q++) {
-        lc[q] = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0, NP, q);
-        st0[q] = xu0 - H + 2 * NP * lane + 2 * q;        // unwrapped store column of the pair's .x
+        if constexpr (SEAM) lc[q] = make_lanecols_ring(xu0, HW, UW, lane, xc, rs);
+        else lc[q] = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0, NP, q);
+        st0[q] = xu0 - HW + 2 * NP * lane + 2 * q;       // unwrapped store column of the pair's .x
     }
 
 #if XINV_PIPE_FLAGS
@@ -757,20 +753,19 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
             gtot = g > gtot ? g : gtot;
         }
         gtot = ((gtot + B - 1) / B) * B;
-        // SEAM: only the tiles that wrap around the seam (the edge strips') take the three-pass march; every other tile of
-        // the launch runs the plain one.  (One march with the extra passes behind wave-uniform branches cost EVERY tile
-        // its instruction interleaving: 3601 columns ran 1.45x the time of 3600 -- profiles/r05_seam_rates.txt.)
-        bool wraps = false;
-        if constexpr (SEAM) { const SeamLanes sl = make_seamlanes(st0[0], lc[0], xc); wraps = sl.has_e || sl.has_w; }
+        // SEAM: only the tiles that hold a seam lane take the march with the extra pass; every other tile of the launch
+        // runs the plain one.  (One march with the extra passes behind wave-uniform branches cost EVERY tile its
+        // instruction interleaving: 3601 columns ran 1.45x the time of 3600 -- profiles/r05_seam_rates.txt.)
+        bool wraps = rs.any;
 #ifdef XINV_EXP_SEAM_NOWRAP
         wraps = false;                                   // (timing experiment only: wrong results)
 #endif
 #define XINV_PIPE_MARCH(SM) \
         switch (pwi) { \
-        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break; \
-        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break; \
-        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break; \
-        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt); break; \
+        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \
+        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \
+        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \
+        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \
         }
         if (wraps) { XINV_PIPE_MARCH(SEAM) } else { XINV_PIPE_MARCH(false) }
 #undef XINV_PIPE_MARCH
