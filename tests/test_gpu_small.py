@@ -95,29 +95,31 @@ def test_small_slices_large_batch_on_device_pointers():
 
 
 # ------------------------------------------------------------------ 3-D: two sweeps per pass
-def xuniform3d(zc, yc, xc, BCx, msk, seed):
+def xuniform3d(zc, yc, xc, BCx, msk, seed, BCy='fixed'):
     from util import rand3d
-    p = rand3d(zc, yc, xc, 'fixed', BCx, msk, seed=seed)
+    p = rand3d(zc, yc, xc, BCy, BCx, msk, seed=seed)
     for q in range(3):
         c = p['coefs'][q]
         c[:] = c[:, :, :1]                             # constant along x (lat-lon omega coefficients)
     return p
 
 
-@pytest.mark.parametrize('shape', [(9, 20, 66), (12, 33, 130), (50, 40, 250), (7, 17, 24), (64, 18, 120), (21, 50, 241)])
+@pytest.mark.parametrize('shape', [(9, 20, 66), (12, 33, 130), (50, 40, 250), (7, 17, 24), (64, 18, 120), (21, 50, 241), (8, 39, 65),
+                                   (6, 21, 121), (6, 22, 121), (6, 23, 121)])
 @pytest.mark.parametrize('BCx', ['fixed', 'periodic'])
-def test_fused3d_two_sweeps_per_pass_vs_oracle(shape, BCx):
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+def test_fused3d_two_sweeps_per_pass_vs_oracle(shape, BCx, BCy):
     """k_pipe3d (x-uniform coefficients; the planner's choice, asked for explicitly here: sweeps_per_launch = 2): passes of two sweeps + a
-    one-sweep tail; must equal the oracle's coloured ordering and the one-sweep-per-pass kernel bit for bit."""
+    one-sweep tail; must equal the oracle's coloured ordering and the one-sweep-per-pass kernel bit for bit.  Round 5: odd
+    widths with periodic x run the two-sweep pass too (the even-ring variant); BCy = 'extend' keeps the one-sweep kernel
+    whatever is asked for (a two-sweep variant was built, bit-exact, and spilled: profiles/r05_seam_rates.txt, section 6)."""
     zc, yc, xc = shape
-    if BCx == 'periodic' and xc % 2:
-        pytest.skip('odd xc periodic: seam colours, colour path')
     for msk in (0, 1):
-        p = xuniform3d(zc, yc, xc, BCx, msk, seed=zc + yc + xc + msk)
+        p = xuniform3d(zc, yc, xc, BCx, msk, seed=zc + yc + xc + msk, BCy=BCy)
         for nsw in (7, 8):                              # odd: 3 passes + tail; even: 4 passes
             So, flo = run_oracle(p, nsw - 1, 0.0, C2)
             S, fl, st = util.run_hip_batched([p], nsw - 1, 0.0, sweeps_per_launch=2)
-            assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == 2 and st['xuniform_mask'] == 7, st
+            assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == (2 if BCy == 'fixed' else 1) and st['xuniform_mask'] == 7, st
             assert np.array_equal(S[0], So), '%d points differ' % (S[0] != So).sum()
             assert fl[0][2] == flo[2] and abs(fl[0][1] - flo[1]) <= 1e-12
         S1, f1, s1 = util.run_hip_batched([p], 7, 0.0, sweeps_per_launch=1)
