@@ -371,8 +371,11 @@ int xinv_standard_2d_test_f64_dev(double *S, const double *A, const double *B, c
  *   has to test for uniformity.  Synchronous: returns with the plan complete.
  * xinv_plan_solve_f64_dev: one call of the hot path on the plan -- S (device pointer, read and written in place, 16-byte
  *   aligned), flags (host, [nbatch*3], caller-initialised), mxLoop, tolerance, on `stream` --, bit for bit what
- *   xinv_<form>_f64_dev returns for the same arrays.  Returns after the solve has completed; xinv_last_stats() has
- *   planned = 1.  Solves on one device are serialised (per-device lock), whatever thread or plan they come from.
+ *   xinv_<form>_f64_dev returns for the same arrays.  Returns when the stop rule has decided every member: flags are
+ *   final on return; S completes IN STREAM ORDER -- the copy of the final state into S may still be queued on `stream`
+ *   (work queued on `stream` afterwards sees the result; a reader on another stream or on the host synchronises with
+ *   `stream` first).  xinv_last_stats() has planned = 1.  Solves on one device are serialised (per-device lock),
+ *   whatever thread or plan they come from.
  * CONTRACT while a plan lives: the coefficient arrays it was created on stay allocated and UNCHANGED -- values of the
  *   forcing may change as long as its set of undefined points does not (the plan's tile lists leave out tiles whose
  *   forcing is undefined throughout).  After any other change call xinv_plan_refresh (re-derives everything in place,

@@ -6,7 +6,7 @@ re-deriving what a plan keeps (rounds 1-4: iParams['resident_plan'] = False).
 import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.environ.get('XINV_TREE', ROOT))          # (XINV_TREE: another checkout of the package, e.g. a round-4 tree)
 import xinvert_amd as xa
 from xinvert_amd import apps
 
@@ -30,5 +30,5 @@ for plan in (True, False, True, False):
     if ref is None:
         ref = v
     print(json.dumps({'resident_plan': plan, 'frames': a.frames, 'loops_per_frame': a.loops, 'shape': [a.ny, a.nx],
-                      'wall_ms': best * 1e3, 'ms_per_frame': best * 1e3 / a.frames, 'planned': ip['stats']['planned'],
+                      'wall_ms': best * 1e3, 'ms_per_frame': best * 1e3 / a.frames, 'planned': ip.get('stats', {}).get('planned', 0), 'tree': os.environ.get('XINV_TREE', 'this'),
                       'same_frames': bool(np.array_equal(v, ref))}), flush=True)

@@ -619,6 +619,10 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     int rc = XINV_OK;
     (void)n; (void)rc;
     // ---- workspace ---------------------------------------------------------------------------
+    if (ws->tail_pending) {                              // (the previous plan solve's copy into its caller's S reads S2 / S3)
+        if (ws->tail_stream != st) HIPCHK(hipStreamSynchronize(ws->tail_stream));
+        ws->tail_pending = false;
+    }
     rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)p.nbatch * sizeof(XinvCtl));
     if (rc) return rc;
     if (ws->hctl_cap < (size_t)p.nbatch) {             // two slots: polling is pipelined
@@ -1078,7 +1082,8 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
 }
 
 // fused path: put each member's final state into S (redo of a pass the stop rule fired inside); flags, stats
-static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st, double *flags, SweepRun &R)
+static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t st, double *flags, SweepRun &R,
+                    bool stream_ordered = false)
 {
     const int64_t n = p.zc * p.yc * p.xc;
     int rc = XINV_OK;
@@ -1128,7 +1133,11 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
                 HIPCHK(hipMemcpyAsync(p.S + m * p.sS, buf[where] + m * p.sS, (size_t)n * sizeof(double),
                                       hipMemcpyDeviceToDevice, st));
         }
-        HIPCHK(hipStreamSynchronize(st));
+        // (run_sweeps has synchronised behind the last launch and its control blocks; what may be queued behind that is
+        //  the copy of the final state into S -- and a redone pass.  A plan solve leaves them in flight: S completes in
+        //  stream order, 15-25 us of host wake-up less per solve; the workspace remembers the stream)
+        if (stream_ordered && R.lev.size() <= 1) { ws->tail_stream = st; ws->tail_pending = true; }
+        else HIPCHK(hipStreamSynchronize(st));
         if (R.lev.size() > 1) {                          // timing == 2: the launches that did work (not the no-op tail)
             double mn = 1e300, mx = 0.0, sum = 0.0; int cnt = 0;
             for (size_t i = 0; i + 1 < R.lev.size() && i + 1 < bound.size(); i++) {
@@ -1387,7 +1396,7 @@ static int plan_solve(xinv_plan *h, double *S, double *flags, int64_t mxLoop, do
     R.stream = st;
     rc = run_sweeps(p, pl, h->opt, ws, st, R);
     if (rc) return rc;
-    rc = finalise(p, pl, ws, st, flags, R);
+    rc = finalise(p, pl, ws, st, flags, R, true);
     t_stats.planned = 1;
     h->solves++;
     return rc;

@@ -208,6 +208,8 @@ struct Workspace {
                                                         // host-pointer call can be in flight on the device at once (solve_host_one)
     std::recursive_mutex busy;                          // one solve at a time per device
     double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
+    hipStream_t tail_stream = nullptr; bool tail_pending = false;   // a plan solve's last copy out of S2 / S3 may still be in
+                                                        // flight on this stream (xinv_plan_solve: S completes in stream order)
     XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
     void *partials = nullptr; size_t partials_cap = 0;  // norm partials
     size_t partials_half = 0;                           // lagged norm: byte offset of the odd launches' buffer
