@@ -81,14 +81,18 @@ __device__ __forceinline__ double xinv_upd_std2d_9_sel(
 // the 3x3 neighbourhood of component X on the row in slot sj
 struct Nbr9 { double c, p, m, w, e, pe, pw, me, mw; };
 
-template <int X>
+// (FIX: the seam lanes' pass of the ring layout -- X == 0, the east column is the NEXT lane's .x, column 0, instead of the
+//  lane's own .y, the phantom column: xinv_fused.h RING)
+template <int X, bool FIX = false>
 __device__ __forceinline__ Nbr9 nbr9(const double2 &Rm, const double2 &R0, const double2 &Rp)
 {
+    static_assert(!FIX || X == 0, "column xc-1 sits in an .x slot");
     Nbr9 n;
     n.c = comp<X>(R0); n.p = comp<X>(Rp); n.m = comp<X>(Rm);
     if (X == 0) {
         n.w = xinv_lane_up(R0.y); n.pw = xinv_lane_up(Rp.y); n.mw = xinv_lane_up(Rm.y);
-        n.e = R0.y; n.pe = Rp.y; n.me = Rm.y;
+        if (FIX) { n.e = xinv_lane_down(R0.x); n.pe = xinv_lane_down(Rp.x); n.me = xinv_lane_down(Rm.x); }
+        else { n.e = R0.y; n.pe = Rp.y; n.me = Rm.y; }
     } else {
         n.w = R0.x; n.pw = Rp.x; n.mw = Rm.x;
         n.e = xinv_lane_down(R0.x); n.pe = xinv_lane_down(Rp.x); n.me = xinv_lane_down(Rm.x);
@@ -98,12 +102,12 @@ __device__ __forceinline__ Nbr9 nbr9(const double2 &Rm, const double2 &R0, const
 
 struct Fused9Gen {                  // numbas.invert_general_2D, B != 0
     static constexpr int NC = 7;    // A, B, C, D, E, F, G
-    template <int X, int D>
+    template <int X, int D, bool FIX = false>
     static __device__ __forceinline__ double upd(const double2 (&cw)[NC][D], const double2 (&sw)[D],
                                                  int sj, int sjp, int sjm, bool inr, bool,
                                                  const XinvScal &sc)
     {
-        const Nbr9 n = nbr9<X>(sw[sjm], sw[sj], sw[sjp]);
+        const Nbr9 n = nbr9<X, FIX>(sw[sjm], sw[sj], sw[sjp]);
         return xinv_upd_gen2d_9_sel(n.c, n.p, n.m, n.w, n.e, n.pe, n.pw, n.me, n.mw,
                                     comp<X>(cw[0][sj]), comp<X>(cw[1][sj]), comp<X>(cw[2][sj]),
                                     comp<X>(cw[3][sj]), comp<X>(cw[4][sj]), comp<X>(cw[5][sj]),
@@ -115,18 +119,19 @@ struct Fused9Std {                  // numbas.invert_standard_2D, B != 0
     static constexpr int NC = 4;    // A, B, C, F
     // `west`: this lane's .x is (wrapped) column 0 of a periodic row -- the reference's i == 0
     // branch multiplies by B[j+1,1] and differences S[j-1,0] - S[j-1,-1] (numbas.py:327-328).
-    template <int X, int D>
+    template <int X, int D, bool FIX = false>
     static __device__ __forceinline__ double upd(const double2 (&cw)[NC][D], const double2 (&sw)[D],
                                                  int sj, int sjp, int sjm, bool inr, bool west,
                                                  const XinvScal &sc)
     {
-        const Nbr9 n = nbr9<X>(sw[sjm], sw[sj], sw[sjp]);
+        const Nbr9 n = nbr9<X, FIX>(sw[sjm], sw[sj], sw[sjp]);
         const double aP = comp<X>(cw[0][sjp]), a0 = comp<X>(cw[0][sj]);
         const double bP_chk = comp<X>(cw[1][sjp]), bM = comp<X>(cw[1][sjm]);
         const double c0 = comp<X>(cw[2][sj]), f = comp<X>(cw[3][sj]);
         double bE, bW, cE, bP_use = bP_chk, sM_q = n.me;
         if (X == 0) {
             bW = xinv_lane_up(cw[1][sj].y); bE = cw[1][sj].y; cE = cw[2][sj].y;
+            if (FIX) { bE = xinv_lane_down(cw[1][sj].x); cE = xinv_lane_down(cw[2][sj].x); }   // (column 0's, not the phantom's)
             if (west) { bP_use = cw[1][sjp].y; sM_q = n.m; }
         } else {
             bW = cw[1][sj].x; bE = xinv_lane_down(cw[1][sj].x); cE = xinv_lane_down(cw[2][sj].x);
@@ -142,31 +147,12 @@ struct Fused9Std {                  // numbas.invert_standard_2D, B != 0
 
 // SEAM (periodic x, ODD xc; unaligned strips only).  Columns 0 and xc-1 are both even: the coloured ordering runs the
 // seam colours right after the colour they split from -- c0, c0' (column xc-1 on even rows), c1, c2, c2' (column xc-1 on
-// odd rows), c3 (oracle: seq_colour) -- and a lane's slots hold columns of the wrong parity beyond a wrap.  The lanes
-// are classed by the WRAPPED column of each slot (even and not xc-1 / xc-1 / odd) and a row stage runs up to six
-// lane-masked passes -- the even columns in .x and in .y, the copies of column xc-1, the odd columns in .x and in .y --
-// of which a tile that does not wrap runs the usual two.  As in the 5-point kernels the dependency cone crosses the
-// seam one column further (xc-2 <- xc-1 <- 0 inside one colour pair): the strip owns one column pair less.
-struct Seam9 {
-    unsigned ev[2], sm[2], od[2];      // per slot: all-ones where the wrapped column is even (not xc-1) / xc-1 / odd
-    bool any_ev_y, any_sm_x, any_sm_y, any_od_x;   // wave-uniform
-};
-__device__ __forceinline__ Seam9 make_seam9(const LaneCols &lc, int64_t xc)
-{
-    Seam9 s;
-    const int64_t l[2] = {lc.l0, lc.l1};
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const bool sm = l[q] == xc - 1, od = (l[q] & 1) != 0;
-        s.ev[q] = (!sm && !od) ? ~0u : 0u; s.sm[q] = sm ? ~0u : 0u; s.od[q] = od ? ~0u : 0u;
-    }
-    s.any_ev_y = __builtin_amdgcn_ballot_w64(s.ev[1] != 0u) != 0ull;
-    s.any_sm_x = __builtin_amdgcn_ballot_w64(s.sm[0] != 0u) != 0ull;
-    s.any_sm_y = __builtin_amdgcn_ballot_w64(s.sm[1] != 0u) != 0ull;
-    s.any_od_x = __builtin_amdgcn_ballot_w64(s.od[0] != 0u) != 0ull;
-    return s;
-}
-
+// odd rows), c3 (oracle: seq_colour).  Round 5: the row is laid out as an even ring with a phantom column (xinv_fused.h:
+// RING) -- .x slots hold even, .y slots odd virtual columns across any wrap; a row stage of a tile that holds the seam is
+// three passes (the .x slots without the seam lanes; the seam lanes alone, their east column taken from the next lane's
+// .x -- rows j-1, j, j+1 and, in the standard form, the coefficients -- after which the phantom column mirrors column
+// xc-1 again; the .y slots), every other tile's the usual two.  (Round 4 classed the lanes by their wrapped columns and
+// ran up to six lane-masked passes: 2000 x 2001 at 0.8 against 1.5e11.)  Both halos hold a column pair more.
 template <class M, int K, bool AL, bool EXT, bool SEAM = false>
 __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
 {
@@ -174,7 +160,8 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     constexpr int NC = M::NC;
     constexpr int HX = 4 * K;           // halo columns: one per colour per sweep
     constexpr int HY = 2 * K;           // halo rows
-    constexpr int UW = 128 - 2 * HX - (SEAM ? 2 : 0);
+    constexpr int HW = HX + (SEAM ? 2 : 0);
+    constexpr int UW = 128 - 2 * HW;
     constexpr int D = 2 * K + 2;
 
     const int64_t m = a.member0 + blockIdx.y;
@@ -217,13 +204,13 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
         yu1 = (rb + 1 == a.nrb) ? yc : ((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
     }
     const double u = a.sc_.undef;
-    const LaneCols lc = make_lanecols<AL>(xu0, HX, UW, lane, xc, a.per != 0);
-    const int64_t st0 = xu0 - HX + 2 * lane;
+    RingSeam rs = {0ull, false};
+    LaneCols lc;
+    if constexpr (SEAM) lc = make_lanecols_ring(xu0, HW, UW, lane, xc, rs);
+    else lc = make_lanecols<AL>(xu0, HX, UW, lane, xc, a.per != 0);
+    const int64_t st0 = xu0 - HW + 2 * lane;
     const bool west = (a.per != 0) && (lc.l0 == 0);          // .x sits on wrapped column 0
-    const bool west_y = SEAM && (lc.l1 == 0);                // (odd xc: so can .y)
-    Seam9 s9;
-    if constexpr (SEAM) s9 = make_seam9(lc, xc);
-    (void)west_y;
+    const bool seam_x = SEAM && (lc.l0 == xc - 1);           // .x sits on column xc-1 (its .y is the phantom column)
 
     const double *srcS = a.src + m * a.sS;
     double *dstS = a.dst + m * a.sS;
@@ -284,19 +271,13 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
                 v = M::template upd<1, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_y, false, a.sc_);
                 sw[sj].y = v;
             } else {
-                auto px = [&](unsigned lw) {
-                    const double v = M::template upd<0, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_x, west, a.sc_);
-                    sw[sj].x = xinv_bitsel(lw, v, sw[sj].x);
-                };
-                auto py = [&](unsigned lw) {
-                    const double v = M::template upd<1, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_y, west_y, a.sc_);
-                    sw[sj].y = xinv_bitsel(lw, v, sw[sj].y);
-                };
-                px(s9.ev[0]); if (s9.any_ev_y) py(s9.ev[1]);               // c0 / c2
-                if (s9.any_sm_x) px(s9.sm[0]);                             // c0' / c2': column xc-1 and its copies
-                if (s9.any_sm_y) py(s9.sm[1]);
-                if (s9.any_od_x) px(s9.od[0]);                             // c1 / c3
-                py(s9.od[1]);
+                double v = M::template upd<0, D>(cw, sw, sj, sjp, sjm, rowok && !seam_x, west, a.sc_);     // c0 / c2
+                sw[sj].x = v;
+                v = M::template upd<0, D, true>(cw, sw, sj, sjp, sjm, rowok && seam_x, false, a.sc_);      // c0' / c2': column xc-1
+                sw[sj].x = v;
+                sw[sj].y = seam_x ? v : sw[sj].y;                                                          // (the phantom column mirrors it)
+                v = M::template upd<1, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_y, false, a.sc_);           // c1 / c3
+                sw[sj].y = v;
             }
         };
 
@@ -349,7 +330,7 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     };
     if (active) {
         bool wraps = false;
-        if constexpr (SEAM) wraps = s9.any_ev_y || s9.any_sm_x || s9.any_sm_y || s9.any_od_x;
+        if constexpr (SEAM) wraps = rs.any;
         if (wraps) march(std::integral_constant<bool, SEAM>{}); else march(std::false_type{});
     }
 

@@ -654,7 +654,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
                            : (pl.path == XINV_PATH_FUSED && pl.pipe) ? strip_uw(pl, pl.K, true)
-                                                    : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K) - (pl.seam ? 2 : 0);
+                                                    : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K) - (pl.seam ? (pl.nine ? 4 : 2) : 0);
     const int tpw = (pl.path == XINV_PATH_FUSED && pl.pipe) ? 1 : 4;
     const int64_t wg_member = pl.skip ? pl.ntl / tpw : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, tpw);
     // ... and only where a launch is one or two rounds of workgroups: with many rounds (64 Gill-Matsuno

@@ -191,7 +191,7 @@ static int fused9_dispatch(int kind, int K, bool al, bool ext, dim3 grid, hipStr
     return xinv_launch_fused9(kind == KIND_GEN2D, K, al, ext, grid, st, a, occ, seam);
 }
 // columns a wavefront of the 9-point kernel owns (one halo column per colour and sweep; the seam variants one pair less)
-static inline int strip9_uw(const Plan &pl, int K) { return 128 - 8 * K - (pl.seam ? 2 : 0); }
+static inline int strip9_uw(const Plan &pl, int K) { return 128 - 8 * K - (pl.seam ? 4 : 0); }       // (seam: the ring layout's halos)
 
 static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
                          Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,
@@ -756,7 +756,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     pl.skip_ppm = (int)((1000000 * nskipped) / (ntiles * nb));
     if (!fixedRB) {
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
-        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX - (pl.seam ? (pl.nine ? 2 : 4) : 0)) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
+        pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX - (pl.seam ? 4 : 0)) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
         if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, UW) * pl.nrb + 1);
         if (pl.split) pl.nsg += 2 * (pl.split - 1) * pl.nrb;                  // (the later pieces of the edge strips' row blocks)
     }
