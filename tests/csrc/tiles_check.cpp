@@ -57,6 +57,23 @@ int main()
             if (sq < 0 || sq >= nwg || seen4[(size_t)sq]++) return fail("workgroup bijection", nstrip, nrb, parts, yc);
         }
     }
+    // the ring layout's strips (odd xc, periodic x): every strip has H halo columns a side, H + 2 on a side whose halo holds
+    // the seam (west: the phantom column takes a slot; east: when column xc-1 sits in it anywhere but in the outermost slot)
+    for (int H : {2, 4, 8, 12, 16})
+        for (long xc = 65; xc < 1500; xc += 2) {
+            const int uw = xinv_ring_uw(xc, H), nstrip = (int)((xc + uw - 1) / uw);
+            if (uw != 128 - 2 * H - 2 && uw != 128 - 2 * H - 4) return fail("ring uw", nstrip, 0, H, xc);
+            for (int s_ = 0; s_ < nstrip; s_++) {
+                const int hw = xinv_ring_hw(xc, H, s_), he = 128 - hw - uw;
+                const long lo = (long)s_ * uw - hw, hi = lo + 127;              // virtual columns of the strip's 128 slots
+                if (hw < H || he < H) return fail("ring halo", nstrip, s_, H, xc);
+                if (lo < 0 && hw < H + 2) return fail("ring west halo with the phantom column", nstrip, s_, H, xc);
+                bool seam_east = false;                                         // column xc-1 (virtual xc-1 + n (xc+1)) in the east halo, not outermost
+                for (long v = (long)s_ * uw + uw; v < hi; v++) seam_east = seam_east || ((v % (xc + 1)) == xc - 1);
+                if (seam_east && he < H + 2) return fail("ring east halo with column xc-1", nstrip, s_, H, xc);
+            }
+            cases++;
+        }
     std::printf("OK %ld geometries\n", cases);
     return 0;
 }

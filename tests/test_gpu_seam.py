@@ -14,7 +14,10 @@ from util import rand2d, rand2dt, rand3d, rand3dg, run_oracle, run_hip_batched
 
 pytestmark = pytest.mark.gpu
 COLOUR_2, PATH_COLOUR, PATH_FUSED = 2, 1, 2
-SHAPES = [(20, 65), (70, 101), (30, 127), (25, 129), (40, 301), (33, 257), (12, 641)]
+# (113 .. 125: either side of the widths from which the ring layout's strips take the asymmetric halos, 126 - H for H = 2 ..
+#  12 halo columns -- xinv_tiles.h; 219, 221, 235: a last strip of one or two columns beside them)
+SHAPES = [(20, 65), (70, 101), (30, 127), (25, 129), (40, 301), (33, 257), (12, 641), (22, 113), (22, 115), (22, 117), (22, 119),
+          (22, 121), (22, 123), (22, 125), (26, 219), (26, 235)]
 # widths that put a FULL strip next to the seam for one of the tilings (seam strips own 128 - 4K - 2 columns: 122, 118,
 # 114, 110): column xc-1 is updated after column 0 inside one half-sweep, so the dependency cone of the columns west of
 # the seam reaches 2K + 1 columns east across it -- one more than the plain halo (found in round 4 with 361 = 3 x 120 + 1)
@@ -134,7 +137,7 @@ def test_seam_fused_nine_point(kind, BCy, msk, shape):
 # wavefronts; k_pipe3d's ring variant: 116 owned columns).  Widths: one strip wrapping on both sides, a full strip next to the seam (245 = 2 x 122 + 1, 123, 367),
 # many strips; heights around the 8 / 4 owned rows of the 12- / 8-wavefront cross-sections; k chunks (tall volumes).
 SHAPES_3D = [(7, 20, 65), (9, 23, 101), (6, 17, 127), (12, 30, 129), (8, 19, 245), (8, 14, 123), (5, 9, 367), (40, 11, 131),
-             (6, 12, 641)]
+             (6, 12, 641), (6, 15, 119), (6, 15, 121), (6, 15, 125), (6, 15, 237)]
 
 
 @pytest.mark.parametrize('BCy', ['fixed', 'extend'])

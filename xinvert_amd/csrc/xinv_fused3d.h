@@ -76,18 +76,18 @@ template <> struct Coef3Pack<false> { double2 A, B, B1, C; };
 template <> struct Coef3Pack<true>  { double A, B, B1, C; };
 
 // FMA: the opt-in contracted arithmetic of XINV_FLAG_FMA (x-uniform coefficients only; oracle: XO_FMA, bit for bit).
-// SEAM: periodic x with ODD xc (unaligned strips only) -- the scheme of k_fused2d's SEAM variants (xinv_fused.h) carried to
-// the k march: column xc-1 is updated inside the half-sweep of its own colour right after column 0 (oracle: seq_colour;
-// 3-D colours (k+j+i)&1, seam colours (k+j)&1 on column xc-1), a half-sweep of a tile that wraps around the seam runs as
-// up to three lane-masked passes (east-wrapped lanes' OTHER component, unwrapped lanes, west-wrapped lanes' other
-// component), and -- because a wrapped lane needs the other component of its j neighbours -- the wavefronts exchange
-// BOTH components of their row through LDS.  The strip owns one column pair less (the dependency cone across the seam).
+// SEAM: periodic x with ODD xc (unaligned strips only): column xc-1 is updated inside the half-sweep of its own colour right
+// after column 0 (oracle: seq_colour; 3-D colours (k+j+i)&1, seam colours (k+j)&1 on column xc-1).  Round 5: the row as an
+// even ring with a phantom column (xinv_fused.h: RING) -- the half-sweeps that update the .x slots leave the seam lanes out
+// of their pass and run one more for them alone (east operand and, with full coefficient arrays, east coefficient from the
+// next lane's .x), then the phantom column mirrors column xc-1 again; only the cross-sections that hold a seam lane march
+// with that code.  (Round 4: lane classes, up to three passes, both components of a row exchanged through LDS.)
 template <int NW, bool AL, bool UNI, bool EXT, bool FMA = false, bool SEAM = false>
 __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
 {
     static_assert(!FMA || UNI, "contracted arithmetic: x-uniform coefficients only");
     static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
-    constexpr int H = 2, UW = 128 - 2 * H - (SEAM ? 2 : 0), D = 4, RJ = NW - 4;
+    constexpr int H = 2, D = 4, RJ = NW - 4;
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -109,12 +109,15 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
     const int64_t k1 = (kc + 1 == a.nkc) ? a.zc : k0 + a.KC;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t xc = a.xc, yc = a.yc, zc = a.zc;
+    const int UW = SEAM ? xinv_ring_uw(xc, H) : 128 - 2 * H, HW = SEAM ? xinv_ring_hw(xc, H, st) : H;   // (SEAM: xinv_tiles.h)
     const int64_t xu0 = (int64_t)st * UW;
     const double u = a.sc_.undef;
-    const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
-    const int64_t st0 = xu0 - H + 2 * lane;
-    SeamLanes sl;
-    if constexpr (SEAM) sl = make_seamlanes(st0, lc, xc);
+    RingSeam rs = {0ull, false};
+    LaneCols lc;
+    if constexpr (SEAM) lc = make_lanecols_ring(xu0, HW, UW, lane, xc, rs);
+    else lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
+    const int64_t st0 = xu0 - HW + 2 * lane;
+    const bool seam_x = SEAM && (lc.l0 == xc - 1);           // .x holds column xc-1 (its .y is the phantom column)
 
     const int64_t j = (int64_t)jb * RJ - 2 + wave;             // this wave's row (may be outside)
     const int64_t jr = j < 0 ? 0 : (j > yc - 1 ? yc - 1 : j);
@@ -129,8 +132,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
     const double *pA = a.c[0] + m * a.sc[0], *pB = a.c[1] + m * a.sc[1];
     const double *pC = a.c[2] + m * a.sc[2], *pF = a.c[3] + m * a.sc[3];
 
-    using XchT = std::conditional_t<SEAM, double2, double>;    // SEAM: both components of the row
-    __shared__ XchT xch[2][2][NW][64];         // [step parity][as-loaded | red-updated][wave][lane]
+    __shared__ double xch[2][2][NW][64];       // [step parity][as-loaded | red-updated][wave][lane]
 
     struct Pack { double2 s, f, sfix; Coef3Pack<UNI> c; };
     auto load = [&](int64_t r) {
@@ -176,22 +178,24 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         if constexpr (UNI) return cw[slot].B1; else return comp<X>(cw[slot].B1); };
     auto gC = [&](int slot, auto xt) { constexpr int X = decltype(xt)::value;
         if constexpr (UNI) return cw[slot].C; else return comp<X>(cw[slot].C); };
-    auto gCE = [&](int slot, auto xt) { constexpr int X = decltype(xt)::value;
+    auto gCE = [&](int slot, auto xt, auto fixt) { constexpr int X = decltype(xt)::value;
         if constexpr (UNI) return cw[slot].C;
-        else { if (X == 0) return cw[slot].C.y; else return xinv_lane_down(cw[slot].C.x); } };
+        else { if (X == 0 && !decltype(fixt)::value) return cw[slot].C.y; else return xinv_lane_down(cw[slot].C.x); } };
 
     // one point update of component X on the plane held in slot `sk` (k+1 in `skp`, k-1 in `skm`)
-    // (SEAM: `lw` = all-ones word where the lane takes part in this pass)
-    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, auto smt, unsigned lw = ~0u) {
+    // (SM marches: the pass of the .x slots leaves the seam lanes out; fixt: the seam lanes' own pass, east = the next lane's .x)
+    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, auto smt, auto fixt) {
         constexpr int X = decltype(xt)::value;
-        constexpr bool SM = decltype(smt)::value;
-        const bool okc = X ? lc.ok_y : lc.ok_x;
+        constexpr bool SM = decltype(smt)::value, FIX = decltype(fixt)::value;
+        static_assert(!FIX || (SM && X == 0), "column xc-1 sits in an .x slot");
+        const bool okc = FIX ? seam_x : ((X ? lc.ok_y : lc.ok_x) && !(SM && X == 0 && seam_x));
         const bool inr = okc && row_upd && (kk >= 1) && (kk <= zc - 2);
         double w, e;
         row_neighbours<X>(sw[sk], w, e);
+        if constexpr (FIX) e = xinv_lane_down(sw[sk].x);
         const double sC = comp<X>(sw[sk]), sKP = comp<X>(sw[skp]), sKM = comp<X>(sw[skm]);
         const double aP = gA(skp, xt), a0 = gA(sk, xt), bP = gB1(sk, xt), b0 = gB(sk, xt);
-        const double cE = gCE(sk, xt), c0 = gC(sk, xt), f = comp<X>(fw[sk]);
+        const double cE = gCE(sk, xt, fixt), c0 = gC(sk, xt), f = comp<X>(fw[sk]);
         double v;
         if constexpr (FMA) {
             const bool cond = inr && rok[sk] && (f != u);
@@ -220,30 +224,26 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         } else {
             v = xinv_upd_std3d_sel(sC, sKP, sKM, jP, jM, e, w, aP, a0, bP, b0, cE, c0, f, inr, a.sc_);
         }
-        if constexpr (SM) v = xinv_bitsel(lw, v, sC);
         setc<X>(sw[sk], v);
         return v;
     };
-    // SEAM: one half-sweep as lane-masked passes; jP2 / jM2 = both components of the j neighbours' rows
-    auto seam_half = [&](int sk, int skp, int skm, int64_t kk, const double2 &jP2, const double2 &jM2, auto xt) {
+    // a half-sweep on the plane in slot sk; SM marches: column xc-1 behind the pass of the .x slots, the phantom column after it
+    auto half = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, auto smt) {
         constexpr int X = decltype(xt)::value;
-        using XB = std::integral_constant<int, 1 - X>;
-        if (sl.has_e) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, std::true_type{}, sl.fe[1 - X]);
-        update(sk, skp, skm, kk, comp<X>(jP2), comp<X>(jM2), xt, std::true_type{}, sl.reg[X]);
-        if (sl.has_w) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, std::true_type{}, sl.fw[1 - X]);
+        constexpr bool SM = decltype(smt)::value;
+        double v = update(sk, skp, skm, kk, jP, jM, xt, smt, std::false_type{});
+        if constexpr (SM && X == 0) {
+            v = update(sk, skp, skm, kk, jP, jM, xt, smt, std::true_type{});
+            sw[sk].y = seam_x ? v : sw[sk].y;
+        }
+        return v;
     };
-    (void)seam_half;
 
-    // SEAM: only a cross-section that wraps around the seam takes the lane-masked passes and exchanges both components of
-    // its rows; every other workgroup of the launch runs the plain march (SM = false) with the one-component exchange in
-    // the same LDS (profiles/r05_seam_rates.txt: with the passes behind uniform branches in ONE march, and 16 bytes per lane
-    // exchanged everywhere, 721 columns ran 1.4x the time of 720)
-    double (*xd)[2][NW][64] = reinterpret_cast<double (*)[2][NW][64]>(&xch[0][0][0][0]);
-    double2 (*x2)[2][NW][64] = reinterpret_cast<double2 (*)[2][NW][64]>(&xch[0][0][0][0]);   // (SM marches only: SEAM kernels)
+    // SEAM: only a cross-section that holds a seam lane marches with the extra pass (SM); every other workgroup of the launch
+    // runs the plain march (profiles/r05_seam_rates.txt: with extra passes behind uniform branches in ONE march every
+    // tile lost its instruction interleaving)
     // one pipeline step: plane r (= rbase + U) enters slot U; JP = parity of this wave's row
     auto step = [&](int64_t r, const Pack &p, auto utag, auto jtag, auto smt) {
-        constexpr bool SM = decltype(smt)::value;
-        using XchS = std::conditional_t<SM, double2, double>;
         constexpr int U = decltype(utag)::value;
         constexpr int JP = decltype(jtag)::value;
         constexpr int X = (1 + (U & 1) + JP) & 1;              // component touched in this step
@@ -263,30 +263,17 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
                                      (c + c));
             rok[S1] = (aP != u) && (a0 != u) && (bP != u) && (b0 != u) && (c != u);
         }
-        if constexpr (SM) x2[bw][0][wave][lane] = sw[U];
-        else xd[bw][0][wave][lane] = comp<X>(sw[U]);           // as loaded: neighbours' next red
+        xch[bw][0][wave][lane] = comp<X>(sw[U]);               // as loaded: neighbours' next red
 
         {   // red half-sweep on plane r-1
-            XchS jM, jP;
-            if constexpr (SM) {
-                jM = x2[br][0][wm][lane]; jP = x2[br][0][wp][lane];
-                seam_half(S1, U, S2, r - 1, jP, jM, XT{});
-                x2[bw][1][wave][lane] = sw[S1];
-            } else {
-                jM = xd[br][0][wm][lane]; jP = xd[br][0][wp][lane];
-                const double v = update(S1, U, S2, r - 1, jP, jM, XT{}, std::false_type{});
-                xd[bw][1][wave][lane] = v;                     // red-updated: neighbours' next black
-            }
+            const double jM = xch[br][0][wm][lane], jP = xch[br][0][wp][lane];
+            const double v = half(S1, U, S2, r - 1, jP, jM, XT{}, smt);
+            xch[bw][1][wave][lane] = v;                        // red-updated: neighbours' next black
         }
         {   // black half-sweep on plane r-2
             const int64_t kk = r - 2;
-            if constexpr (SM) {
-                const double2 jM = x2[br][1][wm][lane], jP = x2[br][1][wp][lane];
-                seam_half(S2, S1, S3, kk, jP, jM, XT{});
-            } else {
-                const double jM = xd[br][1][wm][lane], jP = xd[br][1][wp][lane];
-                update(S2, S1, S3, kk, jP, jM, XT{}, std::false_type{});
-            }
+            const double jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
+            half(S2, S1, S3, kk, jP, jM, XT{}, smt);
             const bool pin = row_use && (kk >= k0) && (kk < k1);
             const double2 t = sw[S2];
             if (pin) {                                         // wave-uniform: an owned row of an owned plane
@@ -324,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3d(Fused3Args a)
         }
     };
     bool wraps = false;
-    if constexpr (SEAM) wraps = sl.has_e || sl.has_w;        // (the same for every wavefront of the workgroup: one strip)
+    if constexpr (SEAM) wraps = rs.any;                      // (the same for every wavefront of the workgroup: one strip)
     if (wraps) {
         if (j & 1) march(std::integral_constant<int, 1>{}, std::integral_constant<bool, SEAM>{});
         else       march(std::integral_constant<int, 0>{}, std::integral_constant<bool, SEAM>{});

@@ -160,8 +160,6 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     constexpr int NC = M::NC;
     constexpr int HX = 4 * K;           // halo columns: one per colour per sweep
     constexpr int HY = 2 * K;           // halo rows
-    constexpr int HW = HX + (SEAM ? 2 : 0);
-    constexpr int UW = 128 - 2 * HW;
     constexpr int D = 2 * K + 2;
 
     const int64_t m = a.member0 + blockIdx.y;
@@ -194,6 +192,7 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
     }
     const int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
     const int64_t xc = a.xc, yc = a.yc;
+    const int UW = SEAM ? xinv_ring_uw(xc, HX) : 128 - 2 * HX, HW = SEAM ? xinv_ring_hw(xc, HX, strip) : HX;   // (SEAM: xinv_tiles.h)
     const int64_t xu0 = (int64_t)strip * UW;
     int64_t yu0, yu1;
     if (a.RY > 0) {

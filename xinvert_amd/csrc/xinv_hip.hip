@@ -93,6 +93,7 @@ static int plan_colouring(const Problem &p, Workspace *ws, hipStream_t st, Plan 
         pl.ncol = 9 + 3 * pl.seam;
     } else {
         pl.seam = (p.BCx == XINV_BC_PERIODIC) && (p.xc & 1);
+        pl.xc = p.xc;
         pl.ncol = pl.base + (pl.seam ? 2 : 0);
     }
 
@@ -220,7 +221,8 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         pl.K = 1;
         pl.RY = (opt.rows_per_tile == 8 || opt.rows_per_tile == 12 || opt.rows_per_tile == 16)
                     ? opt.rows_per_tile : 0;     // 0: decided below, once the variant is known
-        pl.nsg = (int)cdiv(p.xc, pl.seam ? 122 : 124);      // x strips (the seam variants own one column pair less)
+        pl.nsg = (int)cdiv(p.xc, pl.seam ? (p.kind == KIND_STD3D ? xinv_ring_uw(p.xc, 2) : 122) : 124);   // x strips (seam: k_fused3d's ring
+                                                            // layout -- xinv_tiles.h --, k_fused3dg's lane classes: the east halo a pair more)
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
         // only S and the forcing are read as vectors when the coefficients are per-row scalars
         pl.aligned = pl.aligned && ptr_al16(p.c[p.ncoef - 1]) && !(p.sc[p.ncoef - 1] & 1);
@@ -274,7 +276,7 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
             n * 8 < ((int64_t)1 << 31)) {                                 // (k_pipe3d addresses a volume through buffer resources: below 2 GiB)
             pl.K2 = true;
             pl.K = 2;
-            pl.nsg2 = (int)cdiv(p.xc, pl.seam ? 116 : 120);  // (odd-xc periodic seam: the ring variant's halos, xinv_fused.h RING)
+            pl.nsg2 = (int)cdiv(p.xc, pl.seam ? xinv_ring_uw(p.xc, 4) : 120);  // (odd-xc periodic seam: the ring variant's strips, xinv_tiles.h)
             pl.nrb2 = (int)cdiv(p.yc, XINV_P3_G * XINV_P3_RR - 8);
             {
                 // per-(plane, row) records of the x-uniform coefficients, relaxation factor and predicate: once per solve
@@ -326,7 +328,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
                 if (p.kind != KIND_STD2DT && opt.rows_per_tile == 0 && opt.sweeps_per_launch == 0 &&
                     !(opt.flags & (XINV_FLAG_NO_TILE_SKIP | XINV_FLAG_NO_PIPE)) && p.nbatch <= 64 &&
                     p.nbatch * p.yc * p.xc >= (int64_t)2000000) {
-                    const int uw_pipe = XINV_PIPE_UW(1) - (pl.seam ? 4 : 0);      // (one column pair per lane: what ships)
+                    const int uw_pipe = pl.seam ? xinv_ring_uw(p.xc, 2 * XINV_PIPE_P) : XINV_PIPE_UW(1);   // (one column pair per lane: what ships)
                     if (p.xc >= uw_pipe && p.nbatch * cdiv(p.xc, uw_pipe) * (p.yc + 1) <= (int64_t)50000000) {
                         rc = issue_strip_active(p, ws, st, uw_pipe, p.kind == KIND_STD2D ? 3 : 6);
                         if (rc) return rc;
@@ -654,7 +656,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
                            : (pl.path == XINV_PATH_FUSED && pl.pipe) ? strip_uw(pl, pl.K, true)
-                                                    : 128 - (pl.nine ? 8 : 4) * std::max(1, pl.K) - (pl.seam ? (pl.nine ? 4 : 2) : 0);
+                                                    : (pl.nine ? strip9_uw(pl, std::max(1, pl.K)) : 128 - 4 * std::max(1, pl.K) - (pl.seam ? 2 : 0));
     const int tpw = (pl.path == XINV_PATH_FUSED && pl.pipe) ? 1 : 4;
     const int64_t wg_member = pl.skip ? pl.ntl / tpw : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, tpw);
     // ... and only where a launch is one or two rounds of workgroups: with many rounds (64 Gill-Matsuno

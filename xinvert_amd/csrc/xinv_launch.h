@@ -33,6 +33,7 @@ struct Plan {
     int tpw;                 // wave-tiles per workgroup of the planned kernel: 4, or 1 with `pipe`
     int npair;               // `pipe`: column pairs per lane (1 or 2: strips of 112 or 240 owned columns)
     bool pipe_fr;            // `pipe`: the forcing rides the LDS ring (launches whose arrays exceed the caches)
+    int64_t xc;              // the problem's row length (the ring layout's strip width depends on it: xinv_tiles.h)
     int split;               // odd-xc periodic seam: the edge strips' row blocks are cut in this many pieces (0: whole; xinv_tile_rows): their
                              // workgroups run up to three passes per half-sweep and would otherwise end a launch alone
     bool fma;                // XINV_FLAG_FMA: the contracted-arithmetic kernel variants (per-row-coefficient forms only)
@@ -59,8 +60,9 @@ static unsigned pick_um(int kind, unsigned umask)
 // lane; the odd-xc periodic seam variants own one pair less (k_fused2d: SEAM)
 static inline int strip_uw(const Plan &pl, int K, bool pipe)
 {
-    // (odd-xc periodic seam: k_pipe2d's ring layout gives both halos a column pair, k_fused2d's lane classes the east one)
-    return (pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K) - (pl.seam ? (pipe ? 4 : 2) : 0);
+    // (odd-xc periodic seam: k_pipe2d's ring layout -- xinv_tiles.h --, k_fused2d's lane classes: the east halo a pair more)
+    if (pl.seam && pipe) return xinv_ring_uw(pl.xc, 2 * XINV_PIPE_P);
+    return (pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K) - (pl.seam ? 2 : 0);
 }
 static inline int seam_nsplit(const Plan &pl, int nstrip) { return pl.split < 2 ? 0 : (nstrip == 1 ? 1 : 2) * (pl.split - 1); }
 
@@ -191,7 +193,7 @@ static int fused9_dispatch(int kind, int K, bool al, bool ext, dim3 grid, hipStr
     return xinv_launch_fused9(kind == KIND_GEN2D, K, al, ext, grid, st, a, occ, seam);
 }
 // columns a wavefront of the 9-point kernel owns (one halo column per colour and sweep; the seam variants one pair less)
-static inline int strip9_uw(const Plan &pl, int K) { return 128 - 8 * K - (pl.seam ? 4 : 0); }       // (seam: the ring layout's halos)
+static inline int strip9_uw(const Plan &pl, int K) { return pl.seam ? xinv_ring_uw(pl.xc, 4 * K) : 128 - 8 * K; }   // (seam: the ring layout, xinv_tiles.h)
 
 static int launch_fused9(const Problem &p, const Plan &pl, int K, const double *src, double *dst,
                          Workspace *ws, hipStream_t st, int64_t member0, int64_t nmem, int force,

@@ -667,8 +667,7 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 #if XINV_PIPE_INV
     xinv_fresh_scalar_cache();
 #endif
-    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, HW = H + (SEAM ? 2 : 0), UW = XINV_PIPE_UW(NP) - (SEAM ? 4 : 0),
-                  LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;       // (SEAM: the ring layout's halos, xinv_fused.h RING)
+    constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE];
     __shared__ int prog[2 * P];                          // hand-over progress counters (XINV_PIPE_FLAGS)
 
@@ -726,6 +725,8 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         yu0 = (int)((((int64_t)rb * yc) / a.nrb) & ~(int64_t)1);
         yu1 = (rb + 1 == a.nrb) ? (int)yc : (int)((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
     }
+    // (SEAM: the ring layout's strips and halos, xinv_tiles.h)
+    const int UW = SEAM ? xinv_ring_uw(xc, H) : XINV_PIPE_UW(NP), HW = SEAM ? xinv_ring_hw(xc, H, strip) : H;
     const int64_t xu0 = (int64_t)strip * UW;
     LaneCols lc[NP];
     int64_t st0[NP];
@@ -756,10 +757,7 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         // SEAM: only the tiles that hold a seam lane take the march with the extra pass; every other tile of the launch
         // runs the plain one.  (One march with the extra passes behind wave-uniform branches cost EVERY tile its
         // instruction interleaving: 3601 columns ran 1.45x the time of 3600 -- profiles/r05_seam_rates.txt.)
-        bool wraps = rs.any;
-#ifdef XINV_EXP_SEAM_NOWRAP
-        wraps = false;                                   // (timing experiment only: wrong results)
-#endif
+        const bool wraps = rs.any;
 #define XINV_PIPE_MARCH(SM) \
         switch (pwi) { \
         case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 {
     static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
     xinv_fresh_scalar_cache();
-    constexpr int K = 2, H = 2 * K, HW = H + (SEAM ? 2 : 0), UW = 128 - 2 * HW, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
+    constexpr int K = 2, H = 2 * K, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int grp = wave >= G ? 1 : 0, gw = wave - grp * G;
     const int64_t xc = a.xc;
+    const int UW = SEAM ? xinv_ring_uw(xc, H) : 128 - 2 * H, HW = SEAM ? xinv_ring_hw(xc, H, st) : H;   // (SEAM: xinv_tiles.h)
     const int64_t xu0 = (int64_t)st * UW;
     const double u = a.sc_.undef;
     RingSeam rs = {0ull, false};

@@ -72,3 +72,20 @@ __host__ __device__ inline int xinv_seam_tile(int s, int nstrip, int nrb, int ns
     return rb * nstrip + (k - rb * nl) + 1;
 }
 
+
+// Strips of the even-ring layout of the odd-xc periodic seam (xinv_fused.h: RING; H = halo columns a side the kernel needs
+// without a seam).  A halo that holds the seam needs a column pair more: on the west because the phantom column takes a
+// slot, on the east because information crosses the seam one pair faster.
+//   symmetric:  every strip H + 2 | 128 - 2H - 4 owned | H + 2;
+//   asymmetric: strip 0 -- its west halo wraps -- H + 2 | 128 - 2H - 2 | H, every other strip H | 128 - 2H - 2 | H + 2: valid
+//               when no strip's halos hold the seam on both sides, i.e. strip 0's east halo -- H slots -- holds column xc-1
+//               at most as its outermost slot (a column xc-1 further in is updated with the NEW column 0, which such a
+//               halo does not hold: it would go stale two half-sweeps early): xc >= 128 - 2H - 2 + H; there are then at
+//               least two strips.  3601 columns are then 33 strips of the pipelined pass, as 3600 are (34 symmetric).
+// The kernels and the planner both call these with the kernel's H: no argument travels.
+__host__ __device__ inline bool xinv_ring_asym(int64_t xc, int H) { return xc >= (int64_t)(128 - 2 * H - 2) + H; }
+__host__ __device__ inline int xinv_ring_uw(int64_t xc, int H) { return 128 - 2 * H - (xinv_ring_asym(xc, H) ? 2 : 4); }
+__host__ __device__ inline int xinv_ring_hw(int64_t xc, int H, int strip)      // west halo of a strip
+{
+    return xinv_ring_asym(xc, H) ? (strip == 0 ? H + 2 : H) : H + 2;
+}
