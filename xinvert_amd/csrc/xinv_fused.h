@@ -905,45 +905,22 @@ __global__ __launch_bounds__(256) void k_norm_reduce_lag(NormLagArgs a)
 #ifndef XINV_MINWAVES
 #define XINV_MINWAVES 1
 #endif
-// SEAM (periodic x with ODD xc; strips are never aligned then).  Columns 0 and xc-1 are neighbours of the same colour,
-// and a strip that wraps around the seam holds the wrapped columns with the parity of their lane slots flipped (the
-// .x slots hold odd columns there).  The coloured ordering for this case (oracle: seq_colour) updates column xc-1 inside
-// the half-sweep of its own colour, right after column 0; the kernel runs a half-sweep of such a tile as up to three
-// lane-masked passes -- the wrapped lanes east of the seam (their OTHER component carries this colour, column 0 among
-// them), the unwrapped lanes, the wrapped lanes west of the seam (column xc-1's halo copy last) -- each pass the plain
-// update on one component, kept where the lane class matches.  Tiles that do not touch the seam run one pass.
-// The planner admits xc >= 64 (a strip then spans at most three wraps).
-struct SeamLanes {
-    unsigned reg[2], fe[2], fw[2];     // per component: all-ones where the lane's column is unwrapped / wrapped east / west
-    bool has_e, has_w;                 // wave-uniform: any lane of that class
-};
-__device__ __forceinline__ SeamLanes make_seamlanes(int64_t c0, const LaneCols &lc, int64_t xc)
-{
-    SeamLanes s;
-    const int64_t c[2] = {c0, c0 + 1}, l[2] = {lc.l0, lc.l1};
-    bool any_e = false, any_w = false;
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const bool flip = ((c[q] ^ l[q]) & 1) != 0;      // xc odd: one wrap flips the column's parity
-        const bool e = flip && c[q] >= xc, w = flip && c[q] < 0;
-        s.reg[q] = flip ? 0u : ~0u; s.fe[q] = e ? ~0u : 0u; s.fw[q] = w ? ~0u : 0u;
-        any_e = any_e || e; any_w = any_w || w;
-    }
-    s.has_e = __builtin_amdgcn_ballot_w64(any_e) != 0ull;
-    s.has_w = __builtin_amdgcn_ballot_w64(any_w) != 0ull;
-    return s;
-}
-
+// SEAM (periodic x with ODD xc; strips are never aligned then).  Columns 0 and xc-1 are neighbours of the same colour; the
+// coloured ordering for this case (oracle: seq_colour) updates column xc-1 inside the half-sweep of its own colour, right
+// after column 0.  The row is laid out as an even ring with a phantom column (RING above): the half-sweeps that update the
+// .x slots leave the seam lanes out of their pass and run one more for them alone, after which the phantom column mirrors
+// column xc-1 again; tiles that hold no seam lane run the plain march.  With coefficient arrays that vary along x the
+// phantom slot's COEFFICIENTS are read from column 0: the models take a point's east coefficient from the lane's own .y,
+// which is then right for column xc-1 (nothing else reads them: the phantom column is never updated).
+// (Round 4 classed the lanes by wrap -- the slots' parity flipped beyond one -- and ran two or three lane-masked passes.)
+// The planner admits xc >= 64.
 template <class M, int K, bool AL, unsigned UM, bool EXT, int PFD = 0, bool SEAM = false>
 __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 {
     static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
     constexpr int NC = M::NC;
     constexpr int H = 2 * K;            // halo (rows and columns) consumed by K sweeps
-    // columns owned by one wavefront.  SEAM: one column pair less -- column xc-1 is updated AFTER column 0 inside the
-    // half-sweep of their colour, so the dependency cone of a column west of the seam reaches one column further east
-    // across it (xc-2 <- xc-1 <- 0 in ONE half-sweep): the east halo must hold 2K + 1 columns (it gets 2K + 2)
-    constexpr int UW = 128 - 2 * H - (SEAM ? 2 : 0);
+    // (columns owned by one wavefront: 128 - 2 H; SEAM: the ring layout's strips, xinv_tiles.h)
     constexpr int D = 2 * K + 2;        // rows held in the register window
 #ifndef XINV_PF_MODE
 #define XINV_PF_MODE 0
@@ -1024,12 +1001,17 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     yu1 = (row_t)__builtin_amdgcn_readfirstlane((int)yu1);
 #endif
     const double u = a.sc_.undef;
+    const int UW = SEAM ? xinv_ring_uw(xc, H) : 128 - 2 * H, HW = SEAM ? xinv_ring_hw(xc, H, strip) : H;
     const int64_t xu0 = (int64_t)strip * UW;
 
-    const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
-    const int64_t st0 = xu0 - H + 2 * lane;          // unwrapped store column of .x
-    SeamLanes sl;
-    if constexpr (SEAM) sl = make_seamlanes(st0, lc, xc);
+    RingSeam rs = {0ull, false};
+    LaneCols lc;
+    if constexpr (SEAM) lc = make_lanecols_ring(xu0, HW, UW, lane, xc, rs);
+    else lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
+    const int64_t st0 = xu0 - HW + 2 * lane;         // unwrapped store column of .x
+    const bool seam_x = SEAM && (lc.l0 == xc - 1);   // .x holds column xc-1 (its .y is the phantom column)
+    LaneCols lcc = lc;                               // coefficient loads: the phantom slot reads column 0's (see SEAM above)
+    if (seam_x) lcc.l1 = 0;
 
     const double *srcS = a.src + m * a.sS;
     double *dstS = a.dst + m * a.sS;
@@ -1080,7 +1062,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #endif
                     p.cs[q] = t; p.c[q] = make_double2(0.0, 0.0);
                 }
-                else                { p.c[q] = ld2<AL>(cp[q], off, lc); p.cs[q] = 0.0; }
+                else                { p.c[q] = ld2<AL>(cp[q], off, lcc); p.cs[q] = 0.0; }
             }
             return p;
         };
@@ -1116,22 +1098,22 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                 const bool rv = (r - 1 >= 1) && (r - 1 <= ycr - 2);
                 M::template derive<UM, D>(cw, U, SLOT(1), rv && lc.ok_x, rv && lc.ok_y, a.sc_);
             }
-            // SEAM: one half-sweep as lane-masked passes (east-wrapped lanes' other component, unwrapped lanes, west-wrapped)
-            auto seam_pass = [&](auto xt, int sj, int sjp, int sjm, unsigned lw) {
-                constexpr int XX = decltype(xt)::value;
-                double w, e;
-                row_neighbours<XX>(sw[sj], w, e);
-                const double old = comp<XX>(sw[sj]);
-                const double v = M::template upd<XX, UM, D>(cw, sj, sjp, old, comp<XX>(sw[sjp]), comp<XX>(sw[sjm]),
-                                                            w, e, a.sc_);
-                setc<XX>(sw[sj], xinv_bitsel(lw, v, old));
-            };
+            // SM marches: a half-sweep on the .x slots leaves the seam lanes out of its pass and updates them alone behind it
+            // (east operand: the next lane's .x, the new column 0); then the phantom column mirrors column xc-1 again
             auto seam_half = [&](int sj, int sjp, int sjm) {
-                using XA = std::integral_constant<int, X>;
-                using XB = std::integral_constant<int, 1 - X>;
-                if (sl.has_e) seam_pass(XB{}, sj, sjp, sjm, sl.fe[1 - X]);
-                seam_pass(XA{}, sj, sjp, sjm, sl.reg[X]);
-                if (sl.has_w) seam_pass(XB{}, sj, sjp, sjm, sl.fw[1 - X]);
+                double w, e;
+                row_neighbours<X>(sw[sj], w, e);
+                const double old = comp<X>(sw[sj]);
+                double v = M::template upd<X, UM, D>(cw, sj, sjp, old, comp<X>(sw[sjp]), comp<X>(sw[sjm]), w, e, a.sc_);
+                if constexpr (X == 0) {
+                    sw[sj].x = seam_x ? old : v;
+                    e = xinv_lane_down(sw[sj].x);
+                    v = M::template upd<X, UM, D>(cw, sj, sjp, old, comp<X>(sw[sjp]), comp<X>(sw[sjm]), w, e, a.sc_);
+                    sw[sj].x = seam_x ? v : sw[sj].x;
+                    sw[sj].y = seam_x ? v : sw[sj].y;
+                } else {
+                    sw[sj].y = v;
+                }
             };
             (void)seam_half;
 #pragma unroll
@@ -1233,7 +1215,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     };
     if (active) {
         bool wraps = false;
-        if constexpr (SEAM) wraps = sl.has_e || sl.has_w;
+        if constexpr (SEAM) wraps = rs.any;
         if (wraps) march(std::integral_constant<bool, SEAM>{}); else march(std::false_type{});
     }
 

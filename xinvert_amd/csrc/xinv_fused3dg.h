@@ -31,12 +31,13 @@ struct Fused3GArgs {
     unsigned long long *psum;  // [nbatch][NB]
 };
 
-// SEAM: the odd-xc periodic seam inside the kernel, exactly as in k_fused3d (xinv_fused3d.h).
+// SEAM: the odd-xc periodic seam inside the kernel, exactly as in k_fused3d (xinv_fused3d.h): the even ring with a phantom
+// column, one more pass for the seam lanes in the half-sweeps of their colour, only in cross-sections that hold them.
 template <int NW, bool AL, bool EXT, bool SEAM = false>
 __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
 {
     static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
-    constexpr int H = 2, UW = 128 - 2 * H - (SEAM ? 2 : 0), D = 4, RJ = NW - 4;
+    constexpr int H = 2, D = 4, RJ = NW - 4;
 
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -55,13 +56,16 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
     const int64_t k1 = (kc + 1 == a.nkc) ? a.zc : k0 + a.KC;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t xc = a.xc, yc = a.yc, zc = a.zc;
+    const int UW = SEAM ? xinv_ring_uw(xc, H) : 128 - 2 * H, HW = SEAM ? xinv_ring_hw(xc, H, st) : H;   // (SEAM: xinv_tiles.h)
     const int64_t xu0 = (int64_t)st * UW;
     const double u = a.sc_.undef;
     const bool tall = yc > xc;             // the general kernel's pre-pass loops over range(1, yc-1)
-    const LaneCols lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
-    const int64_t st0 = xu0 - H + 2 * lane;
-    SeamLanes sl;
-    if constexpr (SEAM) sl = make_seamlanes(st0, lc, xc);
+    RingSeam rs = {0ull, false};
+    LaneCols lc;
+    if constexpr (SEAM) lc = make_lanecols_ring(xu0, HW, UW, lane, xc, rs);
+    else lc = make_lanecols<AL>(xu0, H, UW, lane, xc, a.per != 0);
+    const int64_t st0 = xu0 - HW + 2 * lane;
+    const bool seam_x = SEAM && (lc.l0 == xc - 1);           // .x holds column xc-1 (its .y is the phantom column)
     // the reference's i == 0 periodic branch does not test H (numbas.py:849-852)
     const bool noH_x = (a.per != 0) && (lc.l0 == 0), noH_y = (a.per != 0) && (lc.l1 == 0);
 
@@ -79,8 +83,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
     for (int q = 0; q < 7; q++) pc[q] = a.c[q] + m * a.sc[q];
     const double *pH = a.c[7] + m * a.sc[7];
 
-    using XchT = std::conditional_t<SEAM, double2, double>;    // SEAM: both components of the row
-    __shared__ XchT xch[2][2][NW][64];
+    __shared__ double xch[2][2][NW][64];
 
     struct Pack { double2 s, h, sfix; double c[7]; };
     auto load = [&](int64_t r) {
@@ -114,12 +117,16 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
     }
 
     // one point update of component X on the plane held in slot `sk` (k+1 in `skp`, k-1 in `skm`)
-    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, unsigned lw = ~0u) {
+    // (SM marches: the pass of the .x slots leaves the seam lanes out; fixt: the seam lanes' own pass, east = the next lane's .x)
+    auto update = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, auto smt, auto fixt) {
         constexpr int X = decltype(xt)::value;
-        const bool okc = X ? lc.ok_y : lc.ok_x;
+        constexpr bool SM = decltype(smt)::value, FIX = decltype(fixt)::value;
+        static_assert(!FIX || (SM && X == 0), "column xc-1 sits in an .x slot");
+        const bool okc = FIX ? seam_x : ((X ? lc.ok_y : lc.ok_x) && !(SM && X == 0 && seam_x));
         const bool inr = okc && row_upd && (kk >= 1) && (kk <= zc - 2);
         double w, e;
         row_neighbours<X>(sw[sk], w, e);
+        if constexpr (FIX) e = xinv_lane_down(sw[sk].x);
         const double sC = comp<X>(sw[sk]), sKP = comp<X>(sw[skp]), sKM = comp<X>(sw[skm]);
         const double cA = cw[sk][0], cB = cw[sk][1], cC = cw[sk][2], cD = cw[sk][3];
         const double cE = cw[sk][4], cF = cw[sk][5], cG = cw[sk][6], h = comp<X>(hw[sk]);
@@ -147,21 +154,22 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
             cG * sC - h) * a.sc_.delxSqr
         );
         temp *= rq[sk];
-        double v = cond ? sC + temp : sC;
-        if constexpr (SEAM) v = xinv_bitsel(lw, v, sC);
+        const double v = cond ? sC + temp : sC;
         setc<X>(sw[sk], v);
         return v;
     };
-    auto seam_half = [&](int sk, int skp, int skm, int64_t kk, const double2 &jP2, const double2 &jM2, auto xt) {
+    auto half = [&](int sk, int skp, int skm, int64_t kk, double jP, double jM, auto xt, auto smt) {
         constexpr int X = decltype(xt)::value;
-        using XB = std::integral_constant<int, 1 - X>;
-        if (sl.has_e) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, sl.fe[1 - X]);
-        update(sk, skp, skm, kk, comp<X>(jP2), comp<X>(jM2), xt, sl.reg[X]);
-        if (sl.has_w) update(sk, skp, skm, kk, comp<1 - X>(jP2), comp<1 - X>(jM2), XB{}, sl.fw[1 - X]);
+        constexpr bool SM = decltype(smt)::value;
+        double v = update(sk, skp, skm, kk, jP, jM, xt, smt, std::false_type{});
+        if constexpr (SM && X == 0) {                        // column xc-1 behind column 0; the phantom column mirrors it again
+            v = update(sk, skp, skm, kk, jP, jM, xt, smt, std::true_type{});
+            sw[sk].y = seam_x ? v : sw[sk].y;
+        }
+        return v;
     };
-    (void)seam_half;
 
-    auto step = [&](int64_t r, const Pack &p, auto utag, auto jtag) {
+    auto step = [&](int64_t r, const Pack &p, auto utag, auto jtag, auto smt) {
         constexpr int U = decltype(utag)::value;
         constexpr int JP = decltype(jtag)::value;
         constexpr int X = (1 + (U & 1) + JP) & 1;
@@ -184,24 +192,17 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
             rok[U] = (cG != u) && (cA != u) && (cB != u) && (cC != u) && (p.c[3] != u) &&
                      (p.c[4] != u) && (p.c[5] != u);
         }
-        if constexpr (SEAM) xch[bw][0][wave][lane] = sw[U];
-        else xch[bw][0][wave][lane] = comp<X>(sw[U]);
+        xch[bw][0][wave][lane] = comp<X>(sw[U]);
 
         {   // red half-sweep on plane r-1
-            const XchT jM = xch[br][0][wm][lane], jP = xch[br][0][wp][lane];
-            if constexpr (SEAM) {
-                seam_half(S1, U, S2, r - 1, jP, jM, XT{});
-                xch[bw][1][wave][lane] = sw[S1];
-            } else {
-                const double v = update(S1, U, S2, r - 1, jP, jM, XT{});
-                xch[bw][1][wave][lane] = v;
-            }
+            const double jM = xch[br][0][wm][lane], jP = xch[br][0][wp][lane];
+            const double v = half(S1, U, S2, r - 1, jP, jM, XT{}, smt);
+            xch[bw][1][wave][lane] = v;
         }
         {   // black half-sweep on plane r-2
             const int64_t kk = r - 2;
-            const XchT jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
-            if constexpr (SEAM) seam_half(S2, S1, S3, kk, jP, jM, XT{});
-            else update(S2, S1, S3, kk, jP, jM, XT{});
+            const double jM = xch[br][1][wm][lane], jP = xch[br][1][wp][lane];
+            half(S2, S1, S3, kk, jP, jM, XT{}, smt);
             const bool pin = row_use && (kk >= k0) && (kk < k1);
             const double2 t = sw[S2];
             if (pin) {                                         // wave-uniform: an owned row of an owned plane
@@ -218,20 +219,26 @@ __global__ __launch_bounds__(NW * 64) void k_fused3dg(Fused3GArgs a)
         __syncthreads();
     };
 
-    auto march = [&](auto jtag) {
+    auto march = [&](auto jtag, auto smt) {
         const int64_t rstart = (k0 >= D) ? k0 - D : 0;
         Pack p0 = load(rstart), p1 = load(rstart + 1);
         const int64_t rlast = k1 - 1 + 2;
         for (int64_t rb_ = rstart; rb_ <= rlast; rb_ += D) {
             xinv_unroll_steps([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
-                if (U & 1) { step(rb_ + U, p1, utag, jtag); p1 = load(rb_ + U + 2); }
-                else       { step(rb_ + U, p0, utag, jtag); p0 = load(rb_ + U + 2); }
+                if (U & 1) { step(rb_ + U, p1, utag, jtag, smt); p1 = load(rb_ + U + 2); }
+                else       { step(rb_ + U, p0, utag, jtag, smt); p0 = load(rb_ + U + 2); }
             }, std::make_integer_sequence<int, D>{});
         }
     };
-    if (j & 1) march(std::integral_constant<int, 1>{});
-    else       march(std::integral_constant<int, 0>{});
+    // (only a cross-section that holds a seam lane marches with the extra pass: the same for every wavefront of the workgroup)
+    if (SEAM && rs.any) {
+        if (j & 1) march(std::integral_constant<int, 1>{}, std::integral_constant<bool, SEAM>{});
+        else       march(std::integral_constant<int, 0>{}, std::integral_constant<bool, SEAM>{});
+    } else {
+        if (j & 1) march(std::integral_constant<int, 1>{}, std::false_type{});
+        else       march(std::integral_constant<int, 0>{}, std::false_type{});
+    }
 
     if (a.no_ctl) return;
 

@@ -221,8 +221,7 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         pl.K = 1;
         pl.RY = (opt.rows_per_tile == 8 || opt.rows_per_tile == 12 || opt.rows_per_tile == 16)
                     ? opt.rows_per_tile : 0;     // 0: decided below, once the variant is known
-        pl.nsg = (int)cdiv(p.xc, pl.seam ? (p.kind == KIND_STD3D ? xinv_ring_uw(p.xc, 2) : 122) : 124);   // x strips (seam: k_fused3d's ring
-                                                            // layout -- xinv_tiles.h --, k_fused3dg's lane classes: the east halo a pair more)
+        pl.nsg = (int)cdiv(p.xc, pl.seam ? xinv_ring_uw(p.xc, 2) : 124);   // x strips (seam: the ring layout's, xinv_tiles.h)
         pl.aligned = !(p.xc & 1) && !(p.sS & 1) && ptr_al16(p.S);
         // only S and the forcing are read as vectors when the coefficients are per-row scalars
         pl.aligned = pl.aligned && ptr_al16(p.c[p.ncoef - 1]) && !(p.sc[p.ncoef - 1] & 1);
@@ -656,7 +655,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     // and with one or two tile workgroups per member (365 slices of 73x144) it would double the launch.
     const int64_t own_cols = (p.kind == KIND_BIH2D) ? XINV_BIH_OWN(p.BCx == XINV_BC_PERIODIC)
                            : (pl.path == XINV_PATH_FUSED && pl.pipe) ? strip_uw(pl, pl.K, true)
-                                                    : (pl.nine ? strip9_uw(pl, std::max(1, pl.K)) : 128 - 4 * std::max(1, pl.K) - (pl.seam ? 2 : 0));
+                                                    : (pl.nine ? strip9_uw(pl, std::max(1, pl.K)) : strip_uw(pl, std::max(1, pl.K), false));
     const int tpw = (pl.path == XINV_PATH_FUSED && pl.pipe) ? 1 : 4;
     const int64_t wg_member = pl.skip ? pl.ntl / tpw : (int64_t)cdiv((int64_t)cdiv(p.xc, own_cols) * pl.nrb, tpw);
     // ... and only where a launch is one or two rounds of workgroups: with many rounds (64 Gill-Matsuno

@@ -60,9 +60,9 @@ static unsigned pick_um(int kind, unsigned umask)
 // lane; the odd-xc periodic seam variants own one pair less (k_fused2d: SEAM)
 static inline int strip_uw(const Plan &pl, int K, bool pipe)
 {
-    // (odd-xc periodic seam: k_pipe2d's ring layout -- xinv_tiles.h --, k_fused2d's lane classes: the east halo a pair more)
-    if (pl.seam && pipe) return xinv_ring_uw(pl.xc, 2 * XINV_PIPE_P);
-    return (pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K) - (pl.seam ? 2 : 0);
+    // (odd-xc periodic seam: the ring layout's strips, xinv_tiles.h)
+    if (pl.seam) return xinv_ring_uw(pl.xc, pipe ? 2 * XINV_PIPE_P : 2 * K);
+    return pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K;
 }
 static inline int seam_nsplit(const Plan &pl, int nstrip) { return pl.split < 2 ? 0 : (nstrip == 1 ? 1 : 2) * (pl.split - 1); }
 
