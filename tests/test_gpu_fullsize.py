@@ -146,6 +146,39 @@ def test_c5_omega_volume_720x360x50_vs_oracle():
     assert st['xuniform_mask'] == 7
 
 
+# ------------------------------------------------------------------ the same grids one column wider: the odd-xc periodic seam
+def test_c2_poisson_3601x1800_seam_vs_oracle():
+    """BASELINE configs[1] with 3601 columns (periodic x, odd xc): the pipelined pass on the even-ring layout (a phantom
+    column mirroring column xc-1, one more pass for the seam lanes: csrc/xinv_fused.h RING), masked tiles skipped, 22 sweeps
+    = 5 passes + a 2-sweep tail on k_fused2d's seam variant; and a tolerance stop inside a pass."""
+    from xinvert_amd import synthetic
+    q = synthetic.member(synthetic.poisson_latlon(1800, 3601, mask=True), 0)
+    st = _bitwise(q, 22, COLOUR_2)
+    assert st['pipelined'] == 1 and st['sweeps_per_launch'] == 4 and st['colours'] == 4 and st['masked_tile_pct'] >= 15, st
+    hist = [run_oracle(q, n, 0.0, COLOUR_2)[1][1] for n in (17, 18)]
+    tol = 0.5 * (hist[0] + hist[1])
+    So, fo = run_oracle(q, 40, tol, COLOUR_2)
+    S, fl, st = util.run_hip_dev([q], 40, tol)
+    assert fo[2] == 18 and fl[0][2] == fo[2] and np.array_equal(S[0], So), (fl, fo)
+
+
+def test_c4_gill_matsuno_member_1441x720_seam_vs_oracle():
+    """BASELINE configs[3] with 1441 columns: the general form on the pipelined pass, ring layout."""
+    from xinvert_amd import synthetic
+    q = synthetic.member(synthetic.gill_matsuno(720, 1441, 2), 1)
+    st = _bitwise(q, 21, COLOUR_2)
+    assert st['xuniform_mask'] == 31 and st['pipelined'] == 1 and st['colours'] == 4, st
+
+
+def test_c5_omega_volume_721x360x50_seam_vs_oracle():
+    """BASELINE configs[4] with 721 columns: the two-sweep 3-D pass on the ring layout (11 sweeps: five passes and a
+    one-sweep tail on k_fused3d's seam variant)."""
+    from xinvert_amd import synthetic
+    q = synthetic.member(synthetic.omega_latlon(50, 360, 721, 1), 0)
+    st = _bitwise(q, 11, COLOUR_2)
+    assert st['xuniform_mask'] == 7 and st['sweeps_per_launch'] == 2 and st['colours'] == 4, st
+
+
 # ------------------------------------------------------------------ converged fields
 def _converged(name, q, valid):
     """HIP converged field against the committed sample of the oracle's converged lexicographic
