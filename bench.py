@@ -360,6 +360,12 @@ def config_lines(local):
         ('C5', 'invert_omega 720x360x50, 15 of the 120 time steps = one GPU\'s share of eight (BASELINE configs[4]; '
                '--config c5 runs all 120)',
          lambda: c5_members(0, 15), 200, 3, orc.COLOUR_2, 10),
+        # not BASELINE configurations: the headline's and the omega grid one column wider -- periodic x with an ODD number of
+        # columns (the even-ring layout of the streaming kernels), beside their even twins above
+        ('C2-odd', 'invert_Poisson 3601x1800 (configs[1] one column wider: the odd-xc periodic seam), one slice',
+         lambda: synthetic.poisson_latlon(1800, 3601, mask=True), 500, 5, orc.COLOUR_2, 22),
+        ('C5-odd', 'invert_omega 721x360x50 (configs[4] one column wider), 15 volumes',
+         lambda: synthetic.omega_latlon(50, 360, 721, steps=15), 200, 3, orc.COLOUR_2, 11),
     ]
     out = []
     traffic = load_traffic().get('configs', {})
