@@ -105,7 +105,7 @@ def families():
                         {}, dict(path=2, colours=6), orc.COLOUR_AUTO)
     F['colour_std3d_ext'] = (lambda s: util.rand3d(9, 30, 121, 'extend', 'periodic', seed=s),
                              dict(path=1), dict(path=1), orc.COLOUR_AUTO)
-    # the seam inside k_fused3d (both components of a row exchanged through LDS)
+    # the seam inside k_fused3d (ring layout, full coefficient arrays: the seam lanes' east coefficient from the next lane)
     F['fused3d_seam'] = (lambda s: util.rand3d(9, 30, 121, 'extend', 'periodic', msk=True, seed=s),
                          {}, dict(path=2, xuniform_mask=0), orc.COLOUR_2)
     F['fused3dg_seam'] = (lambda s: xuni(util.rand3dg(12, 40, 257, 'extend', 'periodic', seed=s), range(7)),

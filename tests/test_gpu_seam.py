@@ -2,7 +2,8 @@
 
 Columns 0 and xc-1 are neighbours of one colour there.  The coloured ordering (oracle: seq_colour) updates column
 xc-1 inside the half-sweep of its own colour, right after column 0 -- red, red', black, black' -- and the fused
-kernels do the same with lane-masked passes in the tiles that wrap around the seam (xinv_fused.h: SEAM).  Bit for bit
+kernels do the same on the even-ring layout: a phantom column mirroring column xc-1, one more pass for the seam lanes in
+the tiles that hold them (xinv_fused.h: RING / SEAM; halos: xinv_tiles.h).  Bit for bit
 against the oracle and the colour launches, single-strip rows (65 ... 127 columns: the strip wraps on both sides),
 multi-strip rows, every sweeps-per-pass, masks, 'extend', x-uniform and full coefficient arrays, batches."""
 import zlib
@@ -89,8 +90,8 @@ def test_seam_fused_test_form(BCy, shape):
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
 @pytest.mark.parametrize('shape', [(300, 257), (180, 361), (402, 113), (96, 1201)])
 def test_seam_edge_strips_in_half_height_tiles(kind, shape):
-    """Tall row blocks: the edge strips' row blocks are cut in two (their workgroups run two or three passes per
-    half-sweep and would otherwise end a one-round launch alone) -- tile ids beyond nstrip x nrb, in the launches, in the
+    """Tall row blocks: k_fused2d's edge strips' row blocks are cut in two or three (their workgroups run an extra pass in
+    every other half-sweep and would otherwise end a one-round launch alone; k_pipe2d keeps them whole) -- tile ids beyond nstrip x nrb, in the launches, in the
     masked-tile lists and in the skipped tiles' norm share; fixed and even row splits, one strip spanning the row (113)
     and many."""
     yc, xc = shape
@@ -133,8 +134,7 @@ def test_seam_fused_nine_point(kind, BCy, msk, shape):
                 _same(S[m], fl[m], ref[m][0], ref[m][1], 'nine-point K=%d rows=%d %s %r member %d' % (K, rows, kind, shape, m))
 
 
-# 3-D standard form (k_fused3d's SEAM variants: 122 owned columns, both components of a row exchanged between the
-# wavefronts; k_pipe3d's ring variant: 116 owned columns).  Widths: one strip wrapping on both sides, a full strip next to the seam (245 = 2 x 122 + 1, 123, 367),
+# 3-D standard form (k_fused3d's and k_pipe3d's SEAM variants on the ring layout: 120 / 122 and 116 / 118 owned columns).  Widths: one strip wrapping on both sides, a full strip next to the seam (245 = 2 x 122 + 1, 123, 367),
 # many strips; heights around the 8 / 4 owned rows of the 12- / 8-wavefront cross-sections; k chunks (tall volumes).
 SHAPES_3D = [(7, 20, 65), (9, 23, 101), (6, 17, 127), (12, 30, 129), (8, 19, 245), (8, 14, 123), (5, 9, 367), (40, 11, 131),
              (6, 12, 641), (6, 15, 119), (6, 15, 121), (6, 15, 125), (6, 15, 237)]

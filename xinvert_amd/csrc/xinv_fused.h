@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
 #pragma unroll
     for (int s = 0; s < K; s++) { acc[s] = 0.0; cnt[s] = 0; }
 
-    // SEAM: only a tile that wraps around the seam takes the lane-masked passes; every other tile of the launch runs the
+    // SEAM: only a tile that holds a seam lane marches with the extra pass; every other tile of the launch runs the
     // plain march (with the passes behind wave-uniform branches inside ONE march every tile lost its instruction
     // interleaving: 3601 columns took 1.9x the time of 3600 -- profiles/r05_seam_rates.txt)
     auto march = [&](auto smtag) {

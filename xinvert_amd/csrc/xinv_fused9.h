@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
 #pragma unroll
     for (int s = 0; s < K; s++) { acc[s] = 0.0; cnt[s] = 0; }
 
-    // SEAM: only a tile that wraps around the seam takes the lane-masked passes (as k_fused2d: with them behind uniform
+    // SEAM: only a tile that holds a seam lane marches with the extra pass (as k_fused2d: with it behind uniform
     // branches inside ONE march every tile of the launch paid for them)
     auto march = [&](auto smtag) {
         constexpr bool SM = decltype(smtag)::value;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
             }
         };
 
-        // the two colours of a row (even row: c0 then c1; odd row: c2 then c3); SEAM: the lane-masked passes
+        // the two colours of a row (even row: c0 then c1; odd row: c2 then c3); SEAM: one more pass for the seam lanes
         auto row_stage = [&](int sj, int sjp, int sjm, bool rowok) {
             if constexpr (!SM) {
                 double v = M::template upd<0, D>(cw, sw, sj, sjp, sjm, rowok && lc.ok_x, west, a.sc_);

@@ -484,7 +484,7 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         }
         // workgroups per member with the narrowest strips any K uses: sizes the partials
         // (the shorter tail / redo passes of a pipelined plan run k_fused2d: four 112-column tiles per workgroup)
-        // odd-xc periodic seam: the edge strips' tiles run two or three passes per half-sweep; where the row blocks are
+        // odd-xc periodic seam: the edge strips' tiles run an extra pass in every other half-sweep; where the row blocks are
         // tall enough their row blocks are cut in two, so that a launch of one round of workgroups does not end with them
         // (k_fused2d's lane-class seam only: with the ring layout of k_pipe2d -- 1.5 passes in the tiles that hold the seam,
         //  dispatched first -- whole row blocks are fastest: 47.7 us against 49.0-49.6 cut in 2-4, profiles/r05_seam_rates.txt)

@@ -35,7 +35,7 @@ struct Plan {
     bool pipe_fr;            // `pipe`: the forcing rides the LDS ring (launches whose arrays exceed the caches)
     int64_t xc;              // the problem's row length (the ring layout's strip width depends on it: xinv_tiles.h)
     int split;               // odd-xc periodic seam: the edge strips' row blocks are cut in this many pieces (0: whole; xinv_tile_rows): their
-                             // workgroups run up to three passes per half-sweep and would otherwise end a launch alone
+                             // workgroups run an extra pass in every other half-sweep and would otherwise end a launch alone
     bool fma;                // XINV_FLAG_FMA: the contracted-arithmetic kernel variants (per-row-coefficient forms only)
     bool alias_ac;           // `pq`: A and C hold the same numbers everywhere -- C is read out of A (FusedGen2DQA, kernel mask um | 2)
     bool pq;                 // general form with A, C varying along x: the point-factor stream Q (FusedGen2DQ: relaxation

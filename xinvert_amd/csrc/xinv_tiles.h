@@ -14,7 +14,7 @@
 
 // Tile id -> strip and owned rows [y0, y1).  Ids [0, nstrip nrb): row block rb = id / nstrip of strip id % nstrip (fixed
 // height RY, or RY == 0: the yc rows split evenly, boundaries rounded to even rows).  With the odd-xc periodic seam the
-// tiles of the EDGE strips run up to three passes per half-sweep (SEAM, below) and a launch of one round of workgroups
+// tiles of the EDGE strips run an extra pass in every other half-sweep (the seam lanes') and a launch of one round of workgroups
 // ends with them; their row blocks are therefore cut in `parts` pieces (nsplit = edge strips x (parts - 1) = the extra
 // tile groups; the edge strips are the last one and, with more than one strip, strip 0): id (rb, edge strip) is the
 // first piece, ids nstrip nrb + (e (parts - 1) + piece - 1) nrb + rb the later pieces of edge strip e (e = 0: the last

@@ -1,5 +1,5 @@
 // xinv_tu_fused3d_seam.hip -- k_fused3d / k_fused3dg with the odd-xc periodic seam inside the kernel (SEAM variants: unaligned strips,
-// both components of a row exchanged between the wavefronts; xinv_fused3d.h).
+// the even-ring layout; xinv_fused3d.h).
 #include "xinv_dispatch.h"
 
 template <int NW>
