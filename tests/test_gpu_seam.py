@@ -90,9 +90,9 @@ def test_seam_fused_test_form(BCy, shape):
 @pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
 @pytest.mark.parametrize('shape', [(300, 257), (180, 361), (402, 113), (96, 1201)])
 def test_seam_edge_strips_in_half_height_tiles(kind, shape):
-    """Tall row blocks: k_fused2d's edge strips' row blocks are cut in two or three (their workgroups run an extra pass in
-    every other half-sweep and would otherwise end a one-round launch alone; k_pipe2d keeps them whole) -- tile ids beyond nstrip x nrb, in the launches, in the
-    masked-tile lists and in the skipped tiles' norm share; fixed and even row splits, one strip spanning the row (113)
+    """Tall row blocks, the edge strips' tiles dispatched first (round 4 cut their row blocks in pieces; the ring layout's
+    launches keep them whole: profiles/r05_seam_rates.txt) -- the dispatch order in the launches and in the masked-tile
+    lists, the skipped tiles' norm share; fixed and even row splits, one strip spanning the row (113)
     and many."""
     yc, xc = shape
     which = (0, 2) if kind == 'std2d' else (0, 2, 3, 4, 5)
