@@ -124,8 +124,6 @@ struct FusedArgs {
     int ntl;                   // entries per member (multiple of 4); nwg = ntl / 4
     const double *xsum;        // [nbatch] sum |S| over the skipped tiles (S != undef)
     const long long *xcnt;     // [nbatch] their sample count
-    int nsplit;                // odd-xc periodic seam: 0, or the extra tile groups of the edge strips (1: one strip spans the
-                               // row; 2: the last and the first) whose row blocks are cut in pieces (xinv_tile_rows)
     const void *rowf;          // k_pipe2d: [nbatch][yc] per-row records (M::PIPE_RW doubles each, xinv_pipe2d.h)
     double *dbg;               // debugging builds only (XINV_PIPE_DEBUG): rows as the pipeline stages received them;
                                // test-hooks build (XINV_TEST_HOOKS): three ints {tile, launch tag, member} -- that tile of
@@ -959,13 +957,13 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #endif
     int wt = T * 4 + wave;
-    bool active = wt < a.nstrip * a.nrb + (SEAM ? a.nsplit * a.nrb : 0);
+    bool active = wt < a.nstrip * a.nrb;
     if constexpr (SEAM) {                            // (the edge strips' tiles first, four to a workgroup: xinv_heavy_first)
         if (!a.tile_list) {
-            const int nh = (a.nstrip == 1 ? 1 : 2) * a.nrb + a.nsplit * a.nrb;
+            const int nh = (a.nstrip == 1 ? 1 : 2) * a.nrb;
             wt = xinv_heavy_first((int)blockIdx.x, NB, nh >> 2) * 4 + wave;
-            active = wt < a.nstrip * a.nrb + a.nsplit * a.nrb;
-            wt = xinv_seam_tile(active ? wt : 0, a.nstrip, a.nrb, a.nsplit);
+            active = wt < a.nstrip * a.nrb;
+            wt = xinv_seam_tile(active ? wt : 0, a.nstrip, a.nrb);
         }
     }
     if (a.tile_list) {
@@ -982,12 +980,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     // rows owned by this tile: fixed height RY, or (RY == 0) the yc rows split evenly over the
     // nrb row blocks, boundaries rounded to even rows
     row_t yu0, yu1;
-    if constexpr (SEAM) {                            // (edge strips' row blocks cut in two: xinv_tile_rows)
-        const TileRows tr = xinv_tile_rows(active ? wt : 0, a.nstrip, a.nrb, a.nsplit, yc, a.RY);
-        strip = tr.strip; yu0 = (row_t)tr.y0; yu1 = (row_t)tr.y1;
-        active = active && (yu0 < yu1);
-        rb = 0;
-    } else if (a.RY > 0) {
+    if (a.RY > 0) {
         yu0 = (row_t)rb * a.RY;
         yu1 = (yu0 + a.RY < ycr) ? yu0 + a.RY : ycr;
     } else {
@@ -1259,7 +1252,6 @@ struct SkipNormArgs {
     const double *S;
     int64_t sS, yc, xc;
     int nstrip, nrb, UW;
-    int nsplit;                // odd-xc periodic seam: edge strips whose row blocks are cut in two (xinv_tile_rows)
     int RB;                    // > 0: row blocks of exactly RB rows (biharmonic kernel); 0: even split
     double undef;
     const int *skip_list;      // [nbatch][nskip_max] wave-tile ids, -1 = none
@@ -1284,7 +1276,7 @@ __global__ __launch_bounds__(64) void k_skip_tiles(SkipNormArgs a, double *D1, d
     const int wt = a.skip_list[m * a.nskip_max + blockIdx.x];
     double acc = 0.0; long long cnt = 0;
     if (wt >= 0) {
-        const TileRows tr = xinv_tile_rows(wt, a.nstrip, a.nrb, a.nsplit, a.yc, a.RB);
+        const TileRows tr = xinv_tile_rows(wt, a.nstrip, a.nrb, a.yc, a.RB);
         const int64_t yu0 = tr.y0, yu1 = tr.y1;
         const int64_t c0 = (int64_t)tr.strip * a.UW;
         const int64_t c1 = (c0 + a.UW < a.xc) ? c0 + a.UW : a.xc;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_fused9(FusedArgs a)
             const int nh = (a.nstrip == 1 ? 1 : 2) * a.nrb;
             wt = xinv_heavy_first((int)blockIdx.x, NB, nh >> 2) * 4 + wave;
             active = wt < a.nstrip * a.nrb;
-            wt = xinv_seam_tile(active ? wt : 0, a.nstrip, a.nrb, 0);
+            wt = xinv_seam_tile(active ? wt : 0, a.nstrip, a.nrb);
         }
     }
     if (a.tile_list) {                                       // masked-tile skipping, as k_fused2d

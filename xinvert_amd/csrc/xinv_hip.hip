@@ -484,16 +484,8 @@ static int plan_fused5(const Problem &p, const xinv_options &opt, Workspace *ws,
         }
         // workgroups per member with the narrowest strips any K uses: sizes the partials
         // (the shorter tail / redo passes of a pipelined plan run k_fused2d: four 112-column tiles per workgroup)
-        // odd-xc periodic seam: the edge strips' tiles run an extra pass in every other half-sweep
-        // (round 4 cut their row blocks in two, so that a launch of one round of workgroups did not end with them; with the ring layout -- 1.5 passes in the tiles that hold the seam, dispatched first --
-        //  whole row blocks are fastest in both kernels: k_pipe2d 47.7 us against 49.0-49.6 cut in 2-4, k_fused2d 43.0 against
-        //  52-55, profiles/r05_seam_rates.txt.  The pieces stay available to the experiments build: XINV_SEAM_PARTS)
-        pl.split = 0;
-        if (pl.seam && cdiv(p.yc, pl.nrb) >= 16 && cdiv(p.xc, strip_uw(pl, pl.K, pl.pipe)) >= 8)
-            pl.split = XINV_ENV_INT("XINV_SEAM_PARTS", 0);
         pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, strip_uw(pl, XINV_KMAX, false)) * pl.nrb, 4) + 1;
         if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, strip_uw(pl, pl.K, true)) * pl.nrb + 1);
-        if (pl.split) pl.nsg += 2 * (pl.split - 1) * pl.nrb;
         if (pl.even_split && !(opt.flags & XINV_FLAG_NO_TILE_SKIP)) {
             rc = plan_tile_skip(p, pl, ws, st, opt);
             if (rc) return rc;

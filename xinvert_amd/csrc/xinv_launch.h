@@ -34,8 +34,6 @@ struct Plan {
     int npair;               // `pipe`: column pairs per lane (1 or 2: strips of 112 or 240 owned columns)
     bool pipe_fr;            // `pipe`: the forcing rides the LDS ring (launches whose arrays exceed the caches)
     int64_t xc;              // the problem's row length (the ring layout's strip width depends on it: xinv_tiles.h)
-    int split;               // odd-xc periodic seam: the edge strips' row blocks are cut in this many pieces (0: whole; xinv_tile_rows): their
-                             // workgroups run an extra pass in every other half-sweep and would otherwise end a launch alone
     bool fma;                // XINV_FLAG_FMA: the contracted-arithmetic kernel variants (per-row-coefficient forms only)
     bool alias_ac;           // `pq`: A and C hold the same numbers everywhere -- C is read out of A (FusedGen2DQA, kernel mask um | 2)
     bool pq;                 // general form with A, C varying along x: the point-factor stream Q (FusedGen2DQ: relaxation
@@ -64,7 +62,6 @@ static inline int strip_uw(const Plan &pl, int K, bool pipe)
     if (pl.seam) return xinv_ring_uw(pl.xc, pipe ? 2 * XINV_PIPE_P : 2 * K);
     return pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K;
 }
-static inline int seam_nsplit(const Plan &pl, int nstrip) { return pl.split < 2 ? 0 : (nstrip == 1 ? 1 : 2) * (pl.split - 1); }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                           hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false, bool pq = false)
@@ -143,8 +140,7 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     const int UW = strip_uw(pl, K, pipe);
     a.nstrip = (int)cdiv(p.xc, UW);
     a.nrb = pl.even_split ? pl.nrb : (int)cdiv(p.yc, pl.RY);
-    a.nsplit = seam_nsplit(pl, a.nstrip);
-    const int64_t ntiles = (int64_t)a.nstrip * a.nrb + (int64_t)a.nsplit * a.nrb;
+    const int64_t ntiles = (int64_t)a.nstrip * a.nrb;
     a.nwg = (int)cdiv(ntiles, 4);
     a.force = force; a.no_ctl = no_ctl;
     a.member0 = member0;
@@ -631,33 +627,28 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
 
     const bool ext = (p.BCy == XINV_BC_EXTEND);
     // (tile ids and their rows: xinv_tile_rows -- with the odd-xc periodic seam the edge strips' row blocks are two tiles)
-    const int nsplit = fixedRB ? 0 : seam_nsplit(pl, nstrip);
-    auto ntile_ids = [&](int nrb) { return nstrip * nrb + nsplit * nrb; };
-    auto id_rb = [&](int nrb, int id) { return id < nstrip * nrb ? id / nstrip : (id - nstrip * nrb) % nrb; };
+    auto ntile_ids = [&](int nrb) { return nstrip * nrb; };
+    auto id_rb = [&](int, int id) { return id / nstrip; };
     auto tile_active = [&](int64_t m, int nrb, int id) {
         const int rb = id_rb(nrb, id);
-        const TileRows t = xinv_tile_rows(id, nstrip, nrb, nsplit, yc, fixedRB);
-        if (t.y0 >= t.y1) return false;                                        // (an empty half)
+        const TileRows t = xinv_tile_rows(id, nstrip, nrb, yc, fixedRB);
+        if (t.y0 >= t.y1) return false;
         if (ext && (rb == 0 || rb >= nrb - (fixedRB ? 2 : 1))) return true;    // the boundary rows get their copy
                                                                // (a last block of one row: yc-2 sits in the one before)
         return rows_active(m, t.strip, t.y0, t.y1);
     };
     auto active_wgs = [&](int nrb, int64_t *maxact) {
         int64_t wgs = 0, mx = 0;
-        const int nid = ntile_ids(nrb);
         for (int64_t m = 0; m < nb; m++) {
             int64_t c = 0;
-            if (nsplit == 0) {                           // (no half-height tiles: the rows of a block once, then its strips)
-                const int *q = &pre[(size_t)(m * (yc + 1) * nstrip)];
-                for (int rb = 0; rb < nrb; rb++) {
-                    const TileRows t = xinv_tile_rows(rb * nstrip, nstrip, nrb, 0, yc, fixedRB);
-                    if (t.y0 >= t.y1) continue;
-                    if (ext && (rb == 0 || rb >= nrb - (fixedRB ? 2 : 1))) { c += nstrip; continue; }
-                    const int *q0 = q + t.y0 * nstrip, *q1 = q + t.y1 * nstrip;
-                    for (int st_ = 0; st_ < nstrip; st_++) c += (q1[st_] - q0[st_]) > 0;
-                }
-            } else
-            for (int id = 0; id < nid; id++) c += tile_active(m, nrb, id) ? 1 : 0;
+            const int *q = &pre[(size_t)(m * (yc + 1) * nstrip)];                // (the rows of a block once, then its strips)
+            for (int rb = 0; rb < nrb; rb++) {
+                const TileRows t = xinv_tile_rows(rb * nstrip, nstrip, nrb, yc, fixedRB);
+                if (t.y0 >= t.y1) continue;
+                if (ext && (rb == 0 || rb >= nrb - (fixedRB ? 2 : 1))) { c += nstrip; continue; }
+                const int *q0 = q + t.y0 * nstrip, *q1 = q + t.y1 * nstrip;
+                for (int st_ = 0; st_ < nstrip; st_++) c += (q1[st_] - q0[st_]) > 0;
+            }
             wgs += cdiv(c, tpw); mx = std::max(mx, c);
         }
         if (maxact) *maxact = mx;
@@ -699,8 +690,8 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     std::vector<std::vector<int>> act((size_t)nb), skp((size_t)nb);
     for (int64_t m = 0; m < nb; m++) {
         for (int id = 0; id < (int)ntiles; id++) {
-            const TileRows t = xinv_tile_rows(id, nstrip, best, nsplit, yc, fixedRB);
-            if (t.y0 >= t.y1) continue;                                        // (an empty half: neither run nor summed)
+            const TileRows t = xinv_tile_rows(id, nstrip, best, yc, fixedRB);
+            if (t.y0 >= t.y1) continue;
             (tile_active(m, best, id) ? act[(size_t)m] : skp[(size_t)m]).push_back(id);
         }
         maxskip = std::max<int64_t>(maxskip, (int64_t)skp[(size_t)m].size());
@@ -722,7 +713,7 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         if (pl.seam && !fixedRB) {
             // odd-xc periodic seam: the edge strips' tiles (two passes per half-sweep) are dispatched first, spread over
             // the XCDs (xinv_heavy_first; the kernels do the same arithmetic when there is no list)
-            auto heavy = [&](int id) { const int s_ = id % nstrip; return id >= nstrip * best || s_ == 0 || s_ == nstrip - 1; };
+            auto heavy = [&](int id) { const int s_ = id % nstrip; return s_ == 0 || s_ == nstrip - 1; };
             const int nh = (int)(std::stable_partition(am.begin(), am.end(), heavy) - am.begin());
             const int nwg = ntl / tpw, q = nwg >> 3, rem = nwg & 7;
             for (int L = 0; L < nwg; L++) {
@@ -743,7 +734,6 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
     HIPCHK(hipMemsetAsync((char *)ws->d_tsum + tsum_bytes, 0, (size_t)nb * sizeof(unsigned), st));   // k_skip_tiles' tickets
     SkipNormArgs na;
     na.S = p.S; na.sS = p.sS; na.yc = yc; na.xc = p.xc; na.nstrip = nstrip; na.nrb = best; na.UW = UW; na.RB = fixedRB;
-    na.nsplit = nsplit;
     na.undef = p.sc_.undef; na.skip_list = ws->d_list + (size_t)nb * ntl; na.nskip_max = nskip;
     char *base = (char *)ws->d_tsum;
     na.tsum = (double *)base;
@@ -760,7 +750,6 @@ static int plan_tile_skip(const Problem &p, Plan &pl, Workspace *ws, hipStream_t
         pl.nrb = best; pl.even_split = true; pl.RY = (int)cdiv(yc, best);
         pl.nsg = (int)cdiv((int64_t)cdiv(p.xc, 128 - (pl.nine ? 8 : 4) * XINV_KMAX - (pl.seam ? 4 : 0)) * pl.nrb, pl.pipe ? 4 : tpw) + 1;
         if (pl.pipe) pl.nsg = std::max(pl.nsg, (int)cdiv(p.xc, UW) * pl.nrb + 1);
-        if (pl.split) pl.nsg += 2 * (pl.split - 1) * pl.nrb;                  // (the later pieces of the edge strips' row blocks)
     }
     return XINV_OK;
 }

@@ -698,12 +698,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
     pwi = wave;
 #endif
     int wt = T;
-    bool active = wt < a.nstrip * a.nrb + (SEAM ? a.nsplit * a.nrb : 0);
+    bool active = wt < a.nstrip * a.nrb;
     if constexpr (SEAM) {                                // (the edge strips' tiles first: xinv_heavy_first)
-        if (!a.tile_list && NB == a.nstrip * a.nrb + a.nsplit * a.nrb) {
-            const int nh = (a.nstrip == 1 ? 1 : 2) * a.nrb + a.nsplit * a.nrb;
-            wt = xinv_seam_tile(xinv_heavy_first((int)blockIdx.x, NB, nh), a.nstrip, a.nrb, a.nsplit);
-        }
+        if (!a.tile_list && NB == a.nstrip * a.nrb)
+            wt = xinv_seam_tile(xinv_heavy_first((int)blockIdx.x, NB, (a.nstrip == 1 ? 1 : 2) * a.nrb), a.nstrip, a.nrb);
     }
     if (a.tile_list) {
         wt = a.tile_list[m * a.ntl + T];
@@ -713,12 +711,7 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
     int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
     const int64_t xc = a.xc, yc = a.yc;
     int yu0, yu1;
-    if constexpr (SEAM) {                                // (edge strips' row blocks cut in two: xinv_tile_rows)
-        const TileRows tr = xinv_tile_rows(active ? wt : 0, a.nstrip, a.nrb, a.nsplit, yc, a.RY);
-        strip = tr.strip; yu0 = (int)tr.y0; yu1 = (int)tr.y1;
-        active = active && (yu0 < yu1);
-        rb = 0;
-    } else if (a.RY > 0) {
+    if (a.RY > 0) {
         yu0 = rb * a.RY;
         yu1 = (yu0 + a.RY < (int)yc) ? yu0 + a.RY : (int)yc;
     } else {

@@ -12,43 +12,26 @@
 #endif
 #endif
 
-// Tile id -> strip and owned rows [y0, y1).  Ids [0, nstrip nrb): row block rb = id / nstrip of strip id % nstrip (fixed
-// height RY, or RY == 0: the yc rows split evenly, boundaries rounded to even rows).  With the odd-xc periodic seam the
-// tiles of the EDGE strips run an extra pass in every other half-sweep (the seam lanes') and a launch of one round of workgroups
-// ends with them; their row blocks are therefore cut in `parts` pieces (nsplit = edge strips x (parts - 1) = the extra
-// tile groups; the edge strips are the last one and, with more than one strip, strip 0): id (rb, edge strip) is the
-// first piece, ids nstrip nrb + (e (parts - 1) + piece - 1) nrb + rb the later pieces of edge strip e (e = 0: the last
-// strip, 1: strip 0).  Pieces start on even rows like every tile; a piece without rows is an idle tile (y0 >= y1).
+// Tile id -> strip and owned rows [y0, y1): row block rb = id / nstrip of strip id % nstrip (fixed height RY, or RY == 0:
+// the yc rows split evenly, boundaries rounded to even rows).
 struct TileRows { int strip; int64_t y0, y1; };
-__host__ __device__ inline TileRows xinv_tile_rows(int wt, int nstrip, int nrb, int nsplit, int64_t yc, int RY)
+__host__ __device__ inline TileRows xinv_tile_rows(int wt, int nstrip, int nrb, int64_t yc, int RY)
 {
     TileRows t;
-    int rb, part = -1;
-    const int edges = nstrip == 1 ? 1 : 2, parts = nsplit > 0 ? nsplit / edges + 1 : 1;
-    if (wt < nstrip * nrb) {
-        rb = wt / nstrip; t.strip = wt - rb * nstrip;
-        if (nsplit > 0 && (t.strip == nstrip - 1 || t.strip == 0)) part = 0;
-    } else {
-        const int q = wt - nstrip * nrb, g = q / nrb, e = g / (parts - 1);
-        rb = q - g * nrb; t.strip = (e == 0) ? nstrip - 1 : 0; part = 1 + g - e * (parts - 1);
-    }
+    const int rb = wt / nstrip;
+    t.strip = wt - rb * nstrip;
     if (RY > 0) { t.y0 = (int64_t)rb * RY; t.y1 = (t.y0 + RY < yc) ? t.y0 + RY : yc; }
     else {
         t.y0 = (((int64_t)rb * yc) / nrb) & ~(int64_t)1;
         t.y1 = (rb + 1 == nrb) ? yc : ((((int64_t)(rb + 1) * yc) / nrb) & ~(int64_t)1);
     }
-    if (part >= 0) {
-        const int64_t y0 = t.y0, y1 = t.y1, len = y1 - y0;
-        if (part > 0) { const int64_t c = y0 + ((((len * part) / parts) + 1) & ~(int64_t)1); t.y0 = c < y1 ? c : y1; }
-        if (part < parts - 1) { const int64_t c = y0 + ((((len * (part + 1)) / parts) + 1) & ~(int64_t)1); t.y1 = c < y1 ? c : y1; }
-    }
     return t;
 }
 
-// Dispatch order of a seam launch.  The edge strips' tiles are the slow ones (two passes per half-sweep) and the launch
-// ends with the last of them: they go FIRST, spread over the XCDs -- with the later pieces' ids at the end of the id
-// space (above) the chunk mapping handed all of them to ONE XCD, the one dispatched last (measured: cutting the blocks
-// made a launch slower, profiles/r05_seam_rates.txt).
+// Dispatch order of a seam launch (periodic x, odd xc).  The edge strips' tiles -- the ones that hold the seam: an extra pass
+// in every other half-sweep -- are the slow ones and the launch ends with the last of them: they go FIRST, spread over the
+// XCDs (round 4 cut their row blocks in pieces instead, whose ids at the end of the id space the chunk mapping handed to
+// the one XCD dispatched last: profiles/r05_seam_rates.txt; whole row blocks, dispatched first, are faster).
 // xinv_heavy_first: dispatch position L of `n` (blockIdx.x: XCD L & 7, round L >> 3) -> index in a sequence whose first
 // `nh` entries are the heavy ones: rounds below nh / 8 take them eight at a time, the rest keeps the contiguous range per
 // XCD of the plain mapping.  A bijection of [0, n).
@@ -59,19 +42,18 @@ __host__ __device__ inline int xinv_heavy_first(int L, int n, int nh)
     const int nr = n - 8 * hq, q = nr >> 3, rem = nr & 7;
     return 8 * hq + xcd * q + (xcd < rem ? xcd : rem) + (idx - hq);
 }
-// xinv_seam_tile: index in the heavy-first sequence -> tile id of xinv_tile_rows (heavy: the pieces of the edge strips'
-// row blocks, row block fastest; light: the other strips' tiles in id order).
-__host__ __device__ inline int xinv_seam_tile(int s, int nstrip, int nrb, int nsplit)
+// xinv_seam_tile: index in the heavy-first sequence -> tile id (heavy: the tiles of the last strip, then of strip 0, row
+// block fastest; light: the other strips' tiles in id order).
+__host__ __device__ inline int xinv_seam_tile(int s, int nstrip, int nrb)
 {
-    const int edges = nstrip == 1 ? 1 : 2, parts = nsplit / edges + 1, nh = edges * parts * nrb;
+    const int edges = nstrip == 1 ? 1 : 2, nh = edges * nrb;
     if (s < nh) {
-        const int g = s / nrb, rb = s - g * nrb, e = g / parts, part = g - e * parts;
-        return part == 0 ? rb * nstrip + (e == 0 ? nstrip - 1 : 0) : nstrip * nrb + (e * (parts - 1) + part - 1) * nrb + rb;
+        const int e = s / nrb, rb = s - e * nrb;
+        return rb * nstrip + (e == 0 ? nstrip - 1 : 0);
     }
     const int k = s - nh, nl = nstrip > edges ? nstrip - edges : 1, rb = k / nl;
     return rb * nstrip + (k - rb * nl) + 1;
 }
-
 
 // Strips of the even-ring layout of the odd-xc periodic seam (xinv_fused.h: RING; H = halo columns a side the kernel needs
 // without a seam).  A halo that holds the seam needs a column pair more: on the west because the phantom column takes a
