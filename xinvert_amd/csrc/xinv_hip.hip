@@ -743,7 +743,9 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
             (void)hipGetLastError();                       // a failed capture falls back to plain launches
         }
     }
-    const bool lag = R.lag = lag_cand && !use_graph && !exp_noctl;
+    // (a solve of ONE launch -- the frames of apps.animate_iteration -- has nothing to overlap the reduction with: its own
+    //  last workgroup reduces, one kernel launch less per frame)
+    const bool lag = R.lag = lag_cand && !use_graph && !exp_noctl && max_sweeps > (int64_t)Kf;
     NormLagArgs lag_pending[XINV_MAX_LANES];               // per lane (one lane: [0])
     memset(lag_pending, 0, sizeof lag_pending);
     if (lag) {
