@@ -1,5 +1,13 @@
-import cProfile, pstats, sys, io
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""cProfile of apps.animate_iteration as the reference's tests call it (73 x 144, 40 frames of 2 sweeps): where the Python side of a
+call goes (profiles/r05_animate.txt)."""
+import cProfile
+import io
+import os
+import pstats
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import xinvert_amd as xa
 from xinvert_amd import apps
