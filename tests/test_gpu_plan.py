@@ -152,6 +152,34 @@ def test_plan_refresh_after_the_coefficients_changed():
     rp.close()
 
 
+def test_plan_solves_complete_in_stream_order_on_any_stream():
+    """xinv_plan_solve_f64_dev returns with the flags final and S complete IN STREAM ORDER (include/xinv.h): two problems
+    solved alternately on two non-default streams -- every solve leaves a copy of its final state queued behind it, the next
+    solve, on the other stream, reuses the workspace's ping-pong buffers -- and read back on the stream they were solved on:
+    bit for bit the oracle, short solves (one launch) and tolerance stops inside a pass."""
+    import torch
+    from xinvert_amd.resident import ResidentProblem
+    ps = [_uniform(_mk('std2d', 0, 51 + k)) for k in range(2)]
+    rps = [ResidentProblem(_as_problem([q], (0, 1, 2))) for q in ps]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for mx, tol in ((2, 0.0), (13, 0.0), (40, 3e-3), (1, 0.0)):
+        refs = [util.run_oracle(q, mx, tol, COLOUR_2) for q in ps]
+        for rep in range(6):
+            outs = []
+            for k in (0, 1):
+                with torch.cuda.stream(streams[k]):
+                    rps[k].reset()
+                    fl, st = rps[k].solve(mx, tol)
+                    outs.append((rps[k].S.clone(), np.array(fl, copy=True), st))       # (the clone is queued on the same stream)
+            for k in (0, 1):
+                streams[k].synchronize()
+                S, fl, st = outs[k]
+                assert st['planned'] == 1 and fl[0][2] == refs[k][1][2], (fl, refs[k][1])
+                assert np.array_equal(S.cpu().numpy()[0], refs[k][0]), 'problem %d mxLoop %d rep %d' % (k, mx, rep)
+    for rp in rps:
+        rp.close()
+
+
 def test_plan_argument_errors():
     import torch
     from xinvert_amd import _lib
