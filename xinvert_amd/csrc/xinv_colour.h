@@ -657,6 +657,17 @@ __global__ __launch_bounds__(256) void k_solve_init(XinvCtl *ctl, int64_t nbatch
     for (int64_t i = t0; i < n16; i += nt) part[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// The control blocks of a SHORT solve handed to the host without a copy engine and without a stream synchronisation
+// (run_sweeps): written into the pinned host mirror by the device, then a sequence word with system-scope release order --
+// the host spins on that word (a frame of apps.animate_iteration: 42 -> see profiles/r05_animate.txt).
+__global__ __launch_bounds__(64) void k_ctl_mail(const XinvCtl *ctl, int64_t nbatch, XinvCtl *host, unsigned *seq, unsigned val)
+{
+    for (int64_t m = threadIdx.x; m < nbatch; m += 64) host[m] = ctl[m];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(seq, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Watchdog recovery (run_sweeps): the member goes on from the control state the timed-out reducer left untouched.
 __global__ void k_ctl_resume(XinvCtl *c) { c->overflow = 0; c->done = 0; }
 #if XINV_TEST_HOOKS

@@ -218,6 +218,7 @@ struct Workspace {
     int *d_hook = nullptr;                              // test-hooks build: {tile, launch tag, member} (FusedArgs::dbg)
     int *dflags16 = nullptr, *hflags16 = nullptr;      // x-uniform detection flags
     XinvCtl *hctl = nullptr; size_t hctl_cap = 0;       // pinned mirror of ctl
+    unsigned *hmail = nullptr; unsigned mail_seq = 0;   // pinned sequence word of k_ctl_mail (short solves: the host spins on it)
     int *hflag = nullptr;
     hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr}, evc[2] = {nullptr, nullptr};
     hipStream_t gstream = nullptr;                      // capture stream for the small-problem hipGraph
