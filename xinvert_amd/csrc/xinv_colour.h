@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void k_solve_init(XinvCtl *ctl, int64_t nbatch
 
 // The control blocks of a SHORT solve handed to the host without a copy engine and without a stream synchronisation
 // (run_sweeps): written into the pinned host mirror by the device, then a sequence word with system-scope release order --
-// the host spins on that word (a frame of apps.animate_iteration: 42 -> see profiles/r05_animate.txt).
+// the host spins on that word (a frame of apps.animate_iteration: 42 -> 36-38 us, profiles/r05_animate.txt).
 __global__ __launch_bounds__(64) void k_ctl_mail(const XinvCtl *ctl, int64_t nbatch, XinvCtl *host, unsigned *seq, unsigned val)
 {
     for (int64_t m = threadIdx.x; m < nbatch; m += 64) host[m] = ctl[m];
