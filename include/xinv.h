@@ -125,6 +125,12 @@ typedef struct xinv_options {
     int32_t pipe_fr;            /* wave-pipelined pass: the forcing rides the LDS ring (1) or is read by every
                                    wavefront (-1); 0 = by the size of the launch's streams                           */
     int32_t graph;              /* colour path: replay chunks of launches from a hipGraph (1) or launch one by one (-1) */
+    int32_t cu_count;           /* compute units the planner fills (0 = the device's own count).  The two-sweep 3-D pass
+                                   runs one workgroup per CU: the tiles of a launch's last, partly filled round are cut
+                                   into k chunks so that they do not march alone (xinv_pipe3d.h).  A smaller count makes
+                                   small test problems take that path; it never changes a result.  -1: the device's count,
+                                   without that cut (A/B comparisons); -n: n units, without it.                        */
+    int32_t reserved_;          /* (keeps the struct a multiple of 8 bytes)                                            */
 } xinv_options;
 
 #define XINV_PREP_MASK_NAN   1  /* the forcing (last coefficient array) marks masked points with NaN   */
@@ -165,6 +171,9 @@ typedef struct xinv_stats {
                                    coefficient stack; 2 = ... and C out of A (the two hold the same numbers); 0 = in-kernel */
     double  plan_ms;            /* wall clock of the planning part of the call (detection passes, host round trips,
                                    tile lists, per-row records); ~0 for a solve on a resident plan                    */
+    int32_t k_chunks;           /* two-sweep 3-D pass: chunks the plan cuts a tile's column into where it cuts (1: never)    */
+    int32_t cut_tiles;          /* ... tiles of the solve's first sweep launch that were cut (the remainder of its last round
+                                   of one workgroup per CU, or every tile of a small batch); the others march whole         */
     double  launch_us_min, launch_us_avg, launch_us_max;   /* timing = 2: every sweep launch bracketed by its own pair
                                    of HIP events on the stream it runs on (one lane only): per-launch durations without
                                    a profiler's per-dispatch overhead                                                  */

@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--path', type=int, default=0)
     ap.add_argument('--members', type=int, default=0)
     ap.add_argument('--lanes', type=int, default=0)
+    ap.add_argument('--cus', type=int, default=0, help='xinv_options.cu_count (0 = the device; a huge count = no remainder cut in k_pipe3d)')
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--bcx', default='periodic', help='poisson:<ny>x<nx>: BCx')
     ap.add_argument('--mask', action='store_true', help='poisson:<ny>x<nx>: with the synthetic land/sea mask')
@@ -83,7 +84,7 @@ def main():
         rp = ResidentProblem(p, plan=not a.no_plan)
         nb, n = rp.nb, rp.n
         opt = dict(sweeps_per_launch=a.spl, rows_per_tile=a.rows, path=a.path, no_xuniform=1 if a.no_xuniform else 0,
-                   no_pipe=1 if a.no_pipe else 0, lanes=a.lanes)
+                   no_pipe=1 if a.no_pipe else 0, lanes=a.lanes, cu_count=a.cus)
         best = None
         for rep in range(a.reps + 1):
             rp.reset(); torch.cuda.synchronize()
@@ -98,7 +99,7 @@ def main():
         out = {'config': name, 'kind': p['kind'], 'shape': [nb] + list(rp.core), 'sweeps': sw,
                'point_sweeps_per_s': nb * n * sw / dt, 'solve_ms': dt * 1e3, 'planned': st['planned'],
                'path': st['path'], 'colours': st['colours'], 'xuniform_mask': st['xuniform_mask'], 'sweeps_per_launch': k,
-               'rows_per_tile': st['rows_per_tile'], 'masked_tile_pct': st['masked_tile_pct'], 'lanes': st['lanes'],
+               'rows_per_tile': st['rows_per_tile'], 'k_chunks': st.get('k_chunks'), 'cut_tiles': st.get('cut_tiles'), 'masked_tile_pct': st['masked_tile_pct'], 'lanes': st['lanes'],
                'pipelined': st['pipelined'], 'launches': st['sweep_launches'], 'avg_launch_ms': avg_ms,
                'launches_x_avg_ms': avg_ms * st['sweep_launches'],
                'alg_GBps': ALG[p['kind']] * nb * n * k / (avg_ms * 1e-3) / 1e9 if st['path'] == 2

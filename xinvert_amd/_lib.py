@@ -32,7 +32,8 @@ class XinvOptions(ctypes.Structure):
                 ('prep_undef', ctypes.c_double), ('demask_value', ctypes.c_double),
                 ('prep_rowscale', ctypes.POINTER(ctypes.c_double)),
                 ('lanes', ctypes.c_int32), ('norm_lag', ctypes.c_int32),
-                ('pipe_fr', ctypes.c_int32), ('graph', ctypes.c_int32)]
+                ('pipe_fr', ctypes.c_int32), ('graph', ctypes.c_int32),
+                ('cu_count', ctypes.c_int32), ('reserved_', ctypes.c_int32)]
 
 
 class XinvStats(ctypes.Structure):
@@ -46,6 +47,7 @@ class XinvStats(ctypes.Structure):
                 ('pipelined', ctypes.c_int32), ('masked_tile_ppm', ctypes.c_int32),
                 ('recovered_members', ctypes.c_int32), ('lanes', ctypes.c_int32),
                 ('planned', ctypes.c_int32), ('point_factor', ctypes.c_int32), ('plan_ms', ctypes.c_double),
+                ('k_chunks', ctypes.c_int32), ('cut_tiles', ctypes.c_int32),
                 ('launch_us_min', ctypes.c_double), ('launch_us_avg', ctypes.c_double),
                 ('launch_us_max', ctypes.c_double)]
 
@@ -176,7 +178,7 @@ def check(rc):
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
             timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0,
             host_chunk=0, devices=None, prep=None, pin_host=0, no_pipe=0, fma=0, f32_mask=0,
-            lanes=0, norm_lag=0, pipe_fr=0, graph=0, no_point_factor=0):
+            lanes=0, norm_lag=0, pipe_fr=0, graph=0, no_point_factor=0, cu_count=0):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
@@ -190,6 +192,7 @@ def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_
     o.f32_mask = int(f32_mask)
     # expert overrides of the planner (0 = its own choice); the library reads no environment variable
     o.lanes, o.norm_lag, o.pipe_fr, o.graph = int(lanes), int(norm_lag), int(pipe_fr), int(graph)
+    o.cu_count = int(cu_count)
     # prep: front-end passes on the device -- dict(mask='nan' | value, rowscale=vec | None,
     # s_zero=bool, demask=value | None); the row-scale array is kept alive on the options object
     if prep:

@@ -207,20 +207,49 @@ class Resident:
         out = self.rp.result().reshape(tuple(self.bshape) + self.core_shape)
         return np.ascontiguousarray(np.transpose(out, np.argsort(self.perm)))
 
-    def keep_frames(self, n):
-        """Room in HBM for `n` snapshots of S (apps.animate_iteration: the frames stay on the device -- a copy queued behind
-        each solve -- and cross PCIe once, at the end, instead of one blocking download per frame)."""
+    def keep_frames(self, n, max_bytes=None):
+        """Room in HBM for up to `n` snapshots of S (apps.animate_iteration: the frames stay on the device -- a copy queued
+        behind each solve -- and cross PCIe in blocks instead of one blocking download per frame).  The block is capped at
+        `max_bytes` (default: a quarter of the HBM that is free right now, so that the solver's rotation twins of S still
+        fit) and at what the allocator grants; a full block is flushed to the host and reused."""
         import torch
-        self._frames = torch.empty((n,) + tuple(self.rp.S.shape), dtype=self.rp.S.dtype, device=self.rp.S.device)
+        per = int(self.rp.S.numel()) * self.rp.S.element_size()
+        if max_bytes is None:
+            try:
+                max_bytes = torch.cuda.mem_get_info(self.rp.S.device)[0] // 4
+            except Exception:
+                max_bytes = 1 << 30
+        cap = int(max(1, min(int(n), max_bytes // max(per, 1))))
+        self._frames = None
+        while self._frames is None:
+            try:
+                self._frames = torch.empty((cap,) + tuple(self.rp.S.shape), dtype=self.rp.S.dtype, device=self.rp.S.device)
+            except RuntimeError:                             # (out of memory: a smaller block, down to one frame at a time)
+                if cap == 1:
+                    raise
+                cap = max(1, cap // 2)
         self._nframe = 0
+        self._flushed = []
+
+    def _flush_frames(self):
+        if self._nframe:
+            self._flushed.append(self._frames[:self._nframe].cpu().numpy())
+            self._nframe = 0
 
     def snapshot(self):
+        self.rp._join()                                      # (a solve on a non-current stream: the copy waits for it)
+        if self._nframe == self._frames.shape[0]:
+            self._flush_frames()
         self._frames[self._nframe].copy_(self.rp.S)      # (device to device, on the stream the solve ran on)
         self._nframe += 1
 
     def frames(self):
-        """The snapshots taken so far, [n, ...] in the forcing's axis order (one download)."""
-        out = self._frames[:self._nframe].cpu().numpy().reshape((self._nframe,) + tuple(self.bshape) + self.core_shape)
+        """The snapshots taken so far, [n, ...] in the forcing's axis order."""
+        self._flush_frames()
+        blocks, self._flushed = self._flushed, []
+        out = np.concatenate(blocks) if blocks else np.empty((0,) + tuple(self.rp.S.shape))
+        self._flushed = [out] if len(out) else []
+        out = out.reshape((out.shape[0],) + tuple(self.bshape) + self.core_shape)
         inv = np.argsort(self.perm)
         return np.ascontiguousarray(np.transpose(out, (0,) + tuple(1 + a for a in inv)))
 

@@ -42,6 +42,11 @@ struct Fused3Args {
     unsigned long long *psum;  // [nbatch][NB]
     const double *rowf;        // k_pipe3d: per-(plane, row) records [nb][zc][yc][8] (xinv_pipe3d.h)
     int64_t srowf;             // member stride of the table in doubles (0: one table for the batch)
+    // k_pipe3d: a FLAT grid over the launch's members.  With g the tile's index in the launch (member-major; a member has
+    // nstrip * njb tiles), workgroups L < nfull march tile g = L through the whole column; the tiles behind them are cut
+    // into the nkc chunks: workgroup nfull + q marches chunk q % nkc of tile nfull + q / nkc (xinv_pipe3d.h: the tail of
+    // a launch whose tile count is not a multiple of the compute units).  nfull == 0: every tile is cut.
+    int64_t nfull;
 };
 
 // 7-point update with the mask folded into a select (numbas.py:146-169).

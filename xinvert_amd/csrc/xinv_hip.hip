@@ -49,6 +49,19 @@
 #define XINV_ENV_INT(name, dflt) (dflt)
 #endif
 
+// The control-block mirror and the mailbox word the host SPINS on (k_ctl_mail) must be fine-grained, coherent host
+// memory whatever HIP_HOST_COHERENT says: the device's stores of the blocks have to be visible before its store of the
+// sequence word.
+#define XINV_HOST_COHERENT (hipHostMallocCoherent | hipHostMallocMapped)
+static inline void xinv_cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
 #include "xinv_host.h"
 #include "xinv_launch.h"
 
@@ -292,13 +305,15 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
                 hipLaunchKernelGGL(k_row_factor3d, dim3((unsigned)cdiv(p.zc * p.yc, 256), (unsigned)(shared ? 1 : p.nbatch), 1),
                                    dim3(256), 0, st, ra);
             }
+            // the cut of the column into k chunks (p3_whole_tiles: which tiles of a launch are cut is decided per launch):
+            // the count that makes the launch of the whole batch cheapest
             const int64_t wg1 = (int64_t)pl.nsg2 * pl.nrb2 * p.nbatch;
             int best = 1; double best_cost = 1e300;
             for (int nk = 1; nk <= 16; nk++) {
                 const int64_t KC = (int64_t)cdiv(cdiv(p.zc, nk), 4) * 4;
                 if (nk > 1 && (KC < 16 || (int64_t)(nk - 1) * KC >= p.zc)) break;
-                const int64_t rounds = cdiv(wg1 * nk, 256);
-                const double cost = (double)rounds * (double)(KC + (nk > 1 ? 14 : 4));
+                double cost;
+                p3_whole_tiles(wg1, nk, KC, p.zc, pl.cus, &cost);
                 if (cost < best_cost * 0.97) { best_cost = cost; best = nk; }
             }
             pl.nkc2 = best;
@@ -587,6 +602,19 @@ static int launch_planned(const Problem &p, const Plan &pl, Workspace *ws, hipSt
                                     : launch_fused(p, pl, k, src, dst, ws, s, member0, nmem, force, no_ctl, lag_tag, lag_out, lag_prev);
 }
 
+// A stream-ordered plan solve returns with its redo pass and the copy of the final state out of S2 / S3 still queued
+// (finalise); the workspace's own event sits behind them.  Whoever writes those buffers or a plan's records next -- the
+// next solve, a plan build / refresh -- makes ITS stream wait for the event (no host wait, no handle of the earlier
+// caller's stream: that stream may be gone by now); plan_free waits on the host before it frees.
+static int tail_wait(Workspace *ws, hipStream_t st, bool host = false)
+{
+    if (!ws->tail_pending) return XINV_OK;
+    if (host) HIPCHK(hipEventSynchronize(ws->ev_tail));
+    else HIPCHK(hipStreamWaitEvent(st, ws->ev_tail, 0));
+    if (host) ws->tail_pending = false;                  // (a stream wait orders only `st`: another stream must wait again;
+    return XINV_OK;                                      //  waiting on an event that has completed costs nothing)
+}
+
 // sweep loop in lanes (run_sweeps): how many independent launch chains the batch is cut into.
 // Measured with 1 and 2 lanes on one box (profiles/r04_lanes.txt; XINV_LANES=n forces n, 0 or 1 = off):
 //   3600x1800 x 2/3/4/6/8/12/16/32 members  +6 +7 +6 +8 +10 +5 +8 +1.5 %      (5 members: 0)
@@ -614,15 +642,13 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
     int rc = XINV_OK;
     (void)n; (void)rc;
     // ---- workspace ---------------------------------------------------------------------------
-    if (ws->tail_pending) {                              // (the previous plan solve's copy into its caller's S reads S2 / S3)
-        if (ws->tail_stream != st) HIPCHK(hipStreamSynchronize(ws->tail_stream));
-        ws->tail_pending = false;
-    }
+    rc = tail_wait(ws, st);                              // (the previous plan solve's copy into its caller's S reads S2 / S3)
+    if (rc) return rc;
     rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)p.nbatch * sizeof(XinvCtl));
     if (rc) return rc;
     if (ws->hctl_cap < (size_t)p.nbatch) {             // two slots: polling is pipelined
         if (ws->hctl) HIPCHK(hipHostFree(ws->hctl));
-        HIPCHK(hipHostMalloc((void **)&ws->hctl, 2 * (size_t)p.nbatch * sizeof(XinvCtl), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&ws->hctl, 2 * (size_t)p.nbatch * sizeof(XinvCtl), XINV_HOST_COHERENT));
         ws->hctl_cap = (size_t)p.nbatch;
     }
     size_t pbytes;
@@ -918,7 +944,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
                          (int64_t)p.nbatch * n <= ((int64_t)1 << 21);
     unsigned mail_val[2] = {0u, 0u};
     if (mail_ok && !ws->hmail) {
-        HIPCHK(hipHostMalloc((void **)&ws->hmail, 64, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&ws->hmail, 64, XINV_HOST_COHERENT));
         *ws->hmail = 0u;
     }
     auto issue_chunk = [&](int slot) -> int {
@@ -1003,7 +1029,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         if (mail_val[slot]) {
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned spin = 0; __atomic_load_n(ws->hmail, __ATOMIC_ACQUIRE) != mail_val[slot]; spin++) {
-                __builtin_ia32_pause();
+                xinv_cpu_relax();
                 if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
                     HIPCHK(hipStreamSynchronize(st));    // (not short after all: wait the ordinary way; the mail has landed then)
                     break;
@@ -1162,8 +1188,11 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
         // (run_sweeps has synchronised behind the last launch and its control blocks; what may be queued behind that is
         //  the copy of the final state into S -- and a redone pass.  A plan solve leaves them in flight: S completes in
         //  stream order, 15-25 us of host wake-up less per solve; the workspace remembers the stream)
-        if (stream_ordered && R.lev.size() <= 1) { ws->tail_stream = st; ws->tail_pending = true; }
-        else HIPCHK(hipStreamSynchronize(st));
+        if (stream_ordered && R.lev.size() <= 1) {
+            if (!ws->ev_tail) HIPCHK(hipEventCreateWithFlags(&ws->ev_tail, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ws->ev_tail, st));
+            ws->tail_pending = true;
+        } else HIPCHK(hipStreamSynchronize(st));
         if (R.lev.size() > 1) {                          // timing == 2: the launches that did work (not the no-op tail)
             double mn = 1e300, mx = 0.0, sum = 0.0; int cnt = 0;
             for (size_t i = 0; i + 1 < R.lev.size() && i + 1 < bound.size(); i++) {
@@ -1193,6 +1222,12 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
     t_stats.pipelined = (pl.path == XINV_PATH_FUSED && pl.pipe) ? pl.npair : 0;
     t_stats.lanes = R.lanes;
     t_stats.point_factor = (pl.path == XINV_PATH_FUSED && pl.pq) ? (pl.alias_ac ? 2 : 1) : 0;
+    if (pl.path == XINV_PATH_FUSED && p.kind == KIND_STD3D && pl.K2) {
+        const int64_t nm = (p.nbatch * 1 / R.lanes) - (p.nbatch * 0 / R.lanes);      // (members of the first lane's launches)
+        const int64_t tiles = (int64_t)pl.nsg2 * pl.nrb2 * nm;
+        t_stats.k_chunks = std::max(1, pl.nkc2);
+        t_stats.cut_tiles = (int32_t)(tiles - p3_whole_tiles(tiles, std::max(1, pl.nkc2), pl.KC2, p.zc, pl.cus));
+    }
     t_stats.sweep_launches = R.nlaunch;
     t_stats.sweeps_max = sweeps_max;
     t_stats.sweep_ms = R.ms_total;
@@ -1220,6 +1255,13 @@ static int make_plan(const Problem &p, const xinv_options &opt, Workspace *ws, h
 {
     memset(&pl, 0, sizeof pl);
     t_detected_um = 0;
+    if (ws->cus <= 0) {
+        int dev = 0, cus = 0;
+        HIPCHK(hipGetDevice(&dev));
+        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        ws->cus = cus > 0 ? cus : 256;
+    }
+    pl.cus = opt.cu_count > 0 ? opt.cu_count : (opt.cu_count < 0 ? (opt.cu_count == -1 ? -ws->cus : opt.cu_count) : ws->cus);
     int rc = plan_colouring(p, ws, st, pl);
     if (rc) return rc;
     if (opt.path == 3)                                  // (the value of round 2-3's XINV_PATH_SMALL)
@@ -1327,6 +1369,8 @@ static int plan_build(xinv_plan *h, hipStream_t st)
     Problem p = h->p;
     p.S = kPlanS;
     p.stop.mxLoop = (long long)1 << 40; p.stop.tolerance = 0.0;
+    rc = tail_wait(ws, st);                              // (a queued redo pass may still read this plan's records and lists)
+    if (rc) return rc;
     BufSwap sw(ws, &h->bufs);
     rc = make_plan(p, h->opt, ws, st, h->pl);
     if (rc) return rc;
@@ -1339,6 +1383,11 @@ static void plan_free(xinv_plan *h)
     if (!h) return;
     DeviceGuard dg;
     (void)dg.select(h->device);
+    {                                                    // (a stream-ordered solve's redo pass may still read the buffers)
+        Workspace *ws = get_ws(h->device);
+        std::lock_guard<std::recursive_mutex> lock(ws->busy);
+        (void)tail_wait(ws, nullptr, true);
+    }
     if (h->bufs.d_rowf) (void)hipFree(h->bufs.d_rowf);
     if (h->bufs.d_list) (void)hipFree(h->bufs.d_list);
     if (h->bufs.d_tsum) (void)hipFree(h->bufs.d_tsum);
@@ -1784,7 +1833,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
                 if (w->hctl_cap < (size_t)mmax) {
                     if (w->hctl) HIPCHK(hipHostFree(w->hctl));
                     w->hctl = nullptr; w->hctl_cap = 0;
-                    HIPCHK(hipHostMalloc((void **)&w->hctl, 2 * (size_t)mmax * sizeof(XinvCtl), hipHostMallocDefault));
+                    HIPCHK(hipHostMalloc((void **)&w->hctl, 2 * (size_t)mmax * sizeof(XinvCtl), XINV_HOST_COHERENT));
                     w->hctl_cap = (size_t)mmax;
                 }
             }

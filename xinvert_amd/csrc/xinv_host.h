@@ -204,12 +204,15 @@ static int stage_d2h(StageRing &r, hipStream_t s, double *host, const double *de
 #define XINV_MAX_LANES 4
 struct Workspace {
     int device = -1;
+    int cus = 0;                                        // the device's compute units (make_plan)
     int slot = 0;                                       // 0: the device's workspace; 1: a second one, so that two solves of ONE
                                                         // host-pointer call can be in flight on the device at once (solve_host_one)
     std::recursive_mutex busy;                          // one solve at a time per device
     double *S2 = nullptr; size_t S2_cap = 0;            // ping-pong twin of S (fused path)
-    hipStream_t tail_stream = nullptr; bool tail_pending = false;   // a plan solve's last copy out of S2 / S3 may still be in
-                                                        // flight on this stream (xinv_plan_solve: S completes in stream order)
+    hipEvent_t ev_tail = nullptr; bool tail_pending = false;   // a plan solve's redo pass and last copy out of S2 / S3 may still
+                                                        // be in flight (xinv_plan_solve: S completes in stream order): an event
+                                                        // the WORKSPACE owns sits behind them -- the caller may destroy its stream
+                                                        // (tail_wait: whoever touches S2 / S3 or a plan's buffers next waits on it)
     XinvCtl *ctl = nullptr; size_t ctl_cap = 0;
     void *partials = nullptr; size_t partials_cap = 0;  // norm partials
     size_t partials_half = 0;                           // lagged norm: byte offset of the odd launches' buffer

@@ -16,6 +16,7 @@ struct Plan {
     int nkc, KC;             // 3-D: k chunks and planes per chunk
     bool K2;                 // 3-D standard form: passes of two sweeps (k_pipe3d) with the tiling below
     int nsg2, nrb2, nkc2, KC2;
+    int cus;                 // compute units the planner fills (xinv_options.cu_count, or the device's)
     int64_t srowf2;          // k_pipe3d: member stride of the record table (0: shared by the batch)
     bool bih_zbe;            // biharmonic one-pass kernel: B and E identically zero (terms left out)
     bool aligned;
@@ -61,6 +62,34 @@ static inline int strip_uw(const Plan &pl, int K, bool pipe)
     // (odd-xc periodic seam: the ring layout's strips, xinv_tiles.h)
     if (pl.seam) return xinv_ring_uw(pl.xc, pipe ? 2 * XINV_PIPE_P : 2 * K);
     return pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K;
+}
+
+// k_pipe3d runs ONE workgroup per compute unit.  A launch of `tiles` tiles (every member of the launch) therefore takes
+// ceil(tiles / cus) rounds of a whole march -- and when the last round holds only a few tiles (15 volumes of
+// 50 x 360 x 720 on 256 CUs: 2070 tiles, 8.09 rounds) they march alone while the other CUs idle.  The plan fixes a cut of
+// the column into nk chunks of KC planes (a member's partial slots are laid out for it); per launch this decides which
+// tiles are cut: none, all (small batches: more workgroups than tiles), or the remainder of the last round -- pieces that
+// start together when the whole-column rounds end and finish in a fraction of a march.  Costs in pipeline steps, as the
+// planner's: a whole march zc + 4, a chunk KC + 14 (four halo planes a side and the pipeline's fill).
+// Returns the number of tiles marched whole (they come first in the launch).
+static int64_t p3_whole_tiles(int64_t tiles, int nk, int64_t KC, int64_t zc, int cus_, double *cost_out = nullptr)
+{
+    const bool no_rem = cus_ < 0;                        // (xinv_options.cu_count = -n: n compute units, never the remainder cut)
+    const int cus = cus_ < 0 ? -cus_ : cus_;
+    const double cf = (double)(zc + 4), cs = (double)(KC + 14);
+    double best = (double)cdiv(tiles, cus) * cf;
+    int64_t nfull = tiles;
+    if (nk > 1) {
+        const double call = (double)cdiv(tiles * nk, cus) * cs;
+        if (call < best * 0.97) { best = call; nfull = 0; }
+        const int64_t r = tiles % cus, R = tiles / cus;
+        if (r && R && !no_rem) {
+            const double crem = (double)R * cf + (double)cdiv(r * nk, cus) * cs;
+            if (crem < best * 0.985) { best = crem; nfull = tiles - r; }
+        }
+    }
+    if (cost_out) *cost_out = best;
+    return nfull;
 }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
@@ -251,13 +280,18 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
         a.force = force; a.no_ctl = no_ctl;
         a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
         a.psum = (unsigned long long *)ws->partials;
-        const size_t NB2 = (size_t)a.nstrip * a.njb * a.nkc;
-        for (int64_t m0 = 0; m0 < nmem; m0 += XINV_MEMBER_CHUNK) {
-            const int64_t nm = std::min<int64_t>(XINV_MEMBER_CHUNK, nmem - m0);
+        const int64_t NT2 = (int64_t)a.nstrip * a.njb;
+        // a flat grid over the members of the launch (k_pipe3d); at most 2^30 workgroups per launch
+        const int64_t mstep = std::max<int64_t>(1, std::min<int64_t>(XINV_MEMBER_CHUNK, ((int64_t)1 << 30) / (NT2 * a.nkc)));
+        for (int64_t m0 = 0; m0 < nmem; m0 += mstep) {
+            const int64_t nm = std::min<int64_t>(mstep, nmem - m0);
             a.member0 = member0 + m0;
             a.rowf = (const double *)ws->d_rowf; a.srowf = pl.srowf2;
-            if (pl.fma) xinv_launch_pipe3d_fma(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a);
-            else        xinv_launch_pipe3d(pl.aligned, dim3((unsigned)NB2, (unsigned)nm, 1), st, a, pl.seam != 0);
+            // which tiles march the whole column, which are cut into the plan's k chunks (p3_whole_tiles)
+            a.nfull = p3_whole_tiles(NT2 * nm, a.nkc, a.KC, p.zc, pl.cus);
+            const int64_t nwg = a.nfull + (NT2 * nm - a.nfull) * a.nkc;
+            if (pl.fma) xinv_launch_pipe3d_fma(pl.aligned, dim3((unsigned)nwg, 1, 1), st, a);
+            else        xinv_launch_pipe3d(pl.aligned, dim3((unsigned)nwg, 1, 1), st, a, pl.seam != 0);
         }
         HIPCHK(hipGetLastError());
         return XINV_OK;

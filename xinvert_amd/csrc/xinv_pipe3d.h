@@ -82,26 +82,50 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     xinv_fresh_scalar_cache();
     constexpr int K = 2, H = 2 * K, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
 
-    const int64_t m = a.member0 + blockIdx.y;
+    // ---- which tile, which planes.  The grid is FLAT over the launch's members (Fused3Args::nfull): the workgroups below
+    // nfull march one tile each through the whole column; the tiles behind them -- the remainder of a launch whose tile
+    // count is not a multiple of the compute units: at one workgroup per CU they would march alone in a last round while
+    // the other CUs idle (15 volumes of 50 x 360 x 720: 2070 tiles = 8.09 rounds) -- are cut into the nkc chunks of KC
+    // planes, pieces of a third to a half of a march that finish together.  A member's partials are laid out for the cut
+    // (nkc slots per tile); a workgroup that marches the whole column publishes its share in the first and zeros in the rest.
+    const int NT = a.nstrip * a.njb;                     // tiles of a member
+    const int NB = NT * a.nkc;                           // partial slots of a member
+    const int L = (int)blockIdx.x, nfull = (int)a.nfull; // (a launch has fewer than 2^31 workgroups)
+    const bool whole = L < nfull;
+    int g;                                               // tile index in the launch, member-major
+    int kc = 0;
+    if (whole) g = L;
+    else { const int q = L - nfull; g = nfull + q / a.nkc; kc = q - (g - nfull) * a.nkc; }
+    const int ml = g / NT;                               // member of the launch
+    const int64_t m = a.member0 + ml;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && xinv_ctl_done(ctl)) return;
     const unsigned tag = xinv_ctl_seq(ctl);
-
-    const int NB = a.nstrip * a.njb * a.nkc;
-    int T;
+    // the member's workgroup dispatched last reduces its norm (every other one is resident or finished by then)
+    bool reducer;
     {
-        const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
-        T = xcd * q + (xcd < rem ? xcd : rem) + idx;
+        const int gl = (ml + 1) * NT - 1;                // the member's last tile
+        reducer = (gl < nfull) ? (L == gl) : (L == nfull + (gl - nfull) * a.nkc + a.nkc - 1);
     }
-    // (MEASURED AND NOT KEPT, round 4, profiles/r04_pipe3d_variants.txt: the launch's tiles as one list with the row block
-    //  fastest, cut in eight contiguous ranges, so that the workgroups resident on an XCD are j-neighbours of one strip and
-    //  their halo rows could meet in that XCD's L2 -- 15 volumes: 7.37 against 7.72 GB per launch: the L2 does not absorb the
-    //  halo, the workgroups of a round do not march in step)
-    const int kc = T / (a.nstrip * a.njb), Tj = T - kc * (a.nstrip * a.njb);
+    int Tj;                                              // tile of the member
+    if (whole) {
+        // XCD-aware order: dispatch slot L lands on XCD L & 7; the member's workgroups of one XCD take a contiguous band of
+        // its tiles (rank of (L & 7, L) among the member's slots [L0, L0 + n): with L0 a multiple of 8 this is
+        // xcd * (n / 8) + min(xcd, n % 8) + (L - L0) / 8, the mapping of the 2-D grid this kernel used to have)
+        const int L0 = ml * NT;
+        const int n = (L0 + NT <= nfull) ? NT : (nfull - L0);                 // (the member's whole-column workgroups)
+        const int xcd = L & 7;
+        auto below = [](int e, int x) { return (e >> 3) * x + ((e & 7) < x ? (e & 7) : x); };       // v in [0, e): (v & 7) < x
+        auto same = [](int e, int x) { return e <= x ? 0 : ((e - x + 7) >> 3); };                   // v in [0, e): (v & 7) == x
+        Tj = (below(L0 + n, xcd) - below(L0, xcd)) + (same(L, xcd) - same(L0, xcd));
+    } else {
+        Tj = g - ml * NT;
+    }
+    const int T = kc * NT + Tj;                          // the partial slot
     const int jb = Tj / a.nstrip, st = Tj - jb * a.nstrip;
     const int zc = (int)a.zc, yc = (int)a.yc;
-    const int k0 = kc * a.KC;
-    const int k1 = (kc + 1 == a.nkc) ? zc : k0 + a.KC;
+    const int k0 = whole ? 0 : kc * a.KC;
+    const int k1 = (whole || kc + 1 == a.nkc) ? zc : k0 + a.KC;
     // (the wavefront index as a scalar: rows, record addresses and row predicates are then wave-uniform values)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int grp = wave >= G ? 1 : 0, gw = wave - grp * G;
@@ -453,7 +477,21 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         cnt[0] = grp == 0 ? n : 0;   cnt[1] = grp == 1 ? n : 0;
     }
     __syncthreads();                                     // (every wavefront is done with xch: the norm tail's scratch)
-    xinv_norm_finalize<K, NW, true>(acc, cnt, wave, lane, NB, T, tag,
-                                    a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW, ctl, a.stop, 0.0, 0,
-                                    reinterpret_cast<char *>(&xch[0][0][0][0][0]));
+    unsigned long long *pw = a.psum + (size_t)m * XINV_KMAX * NB * XINV_PW;
+    char *scr = reinterpret_cast<char *>(&xch[0][0][0][0][0]);
+    xinv_norm_publish<K, NW, true>(acc, cnt, wave, lane, NB, T, tag, pw, scr);
+    if (whole && a.nkc > 1) {                            // the slots of the chunks this march covered: nothing to add
+        const unsigned long long hi = (unsigned long long)tag << 32;
+        const int i = (int)threadIdx.x - 64;             // (K * (nkc - 1) <= 30 words: the second wavefront's lanes)
+        if (i >= 0 && i < K * (a.nkc - 1)) {
+            const int s = i / (a.nkc - 1), c = 1 + i - s * (a.nkc - 1);
+            unsigned long long *q = pw + ((size_t)s * NB + (size_t)c * NT + Tj) * XINV_PW;
+            __hip_atomic_store(q + 0, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 2, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!reducer) return;
+    __syncthreads();                                     // (the publish step's LDS scratch is reused by the reducer)
+    xinv_norm_reduce<K, NW, true>(wave, lane, NB, tag, pw, ctl, a.stop, 0.0, 0, scr);
 }

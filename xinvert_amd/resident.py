@@ -110,6 +110,7 @@ class ResidentProblem:
                 self.coefs.append(up(c[lo:hi]))
                 strides.append(self.n)
         self._strides = list(strides)
+        self._last_stream = None                             # a non-current stream a solve left S completing on (_join)
         self.strides = _lib.strides_arg(strides)
         self.flags = np.tile(np.array([0., 1., 0.]), (self.nb, 1))
         torch.cuda.synchronize(self.dev)
@@ -126,12 +127,25 @@ class ResidentProblem:
         for h in plans.values():
             self.L.xinv_plan_destroy(h)
 
+    def _join(self):
+        """A plan solve returns with S completing in stream order on ITS stream.  Everything that reads or overwrites S
+        afterwards runs on torch's current stream: when the solve was given another stream, make the current one wait
+        for it first (no host synchronisation)."""
+        import torch
+        last, self._last_stream = self._last_stream, None
+        if last is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            if cur.cuda_stream != last.cuda_stream:
+                cur.wait_stream(last)
+
     def reset(self):
+        self._join()
         self.S.copy_(self.S0)
 
     def refresh(self):
         """The coefficient arrays (or the forcing's mask) were changed in place: re-derive every plan."""
         import torch
+        self._join()
         st = torch.cuda.current_stream(self.dev)
         for h in self._plans.values():
             _lib.check(self.L.xinv_plan_refresh(h, ctypes.c_void_p(st.cuda_stream)))
@@ -154,7 +168,14 @@ class ResidentProblem:
         """One call of the hot path on the resident batch: S is updated in place (restartable, as
         the reference's kernels).  Returns (flags [nb, 3], stats)."""
         import torch
-        st = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        st = stream if stream is not None else cur
+        if st.cuda_stream != cur.cuda_stream:                # (what the current stream queued on S -- a reset -- comes first)
+            self._join()
+            st.wait_stream(cur)
+            self._last_stream = st
+        else:
+            self._join()
         self.flags[:] = np.array([0., 1., 0.])
         if self.use_plan:
             h = self._plan(opt, st)
@@ -172,4 +193,5 @@ class ResidentProblem:
         return self.flags, _lib.last_stats()
 
     def result(self):
+        self._join()
         return self.S.cpu().numpy()
