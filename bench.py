@@ -94,6 +94,8 @@ def parse():
     ap.add_argument('--no-hbm', action='store_true', help='skip the HBM-bound variant')
     ap.add_argument('--no-configs', action='store_true', help='skip the per-configuration lines')
     ap.add_argument('--inproc', action='store_true', help='also time the in-process multi-device mode (host pointers, ndev = N)')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end (host arrays in, host arrays out) leg')
+    ap.add_argument('--sustained-seconds', type=float, default=5.0)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--parity-sweeps', type=int, default=0, help='sweeps of the parity check (0 = the timed count)')
     return ap.parse_args()
@@ -332,6 +334,33 @@ def load_traffic():
         return {}
 
 
+_SRC_SHA = None
+
+
+def src_sha():
+    """hash of the library's sources in THIS tree (xinvert_amd/build.py: source_hash)"""
+    global _SRC_SHA
+    if _SRC_SHA is None:
+        from xinvert_amd import build as xbuild
+        _SRC_SHA = xbuild.source_hash()
+    return _SRC_SHA
+
+
+def traffic_entry(d, key):
+    """A counter figure of profiles/traffic.json -- ONLY when the entry was profiled on the sources of this very tree (every
+    entry carries the hash of xinvert_amd/csrc + include/xinv.h it was measured on): a kernel change that forgot to
+    re-profile carries no stale bytes into the line.  -> (entry dict or None, why not)."""
+    e = d.get(key)
+    if e is None:
+        return None, 'no entry'
+    if not isinstance(e, dict):                              # (a bare number: its details sit beside it)
+        det = d.get(key + '_detail') or {}
+        e = dict(det, bytes_per_launch=det.get('bytes_per_launch', e))
+    if e.get('src_sha') != src_sha():
+        return None, 'stale: profiled on sources %s, this tree is %s' % (e.get('src_sha'), src_sha())
+    return e, None
+
+
 def alg_figures(kind, pts_per_launch, avg_ms):
     """SURVEY 8(d)'s comparable number: the reference kernel's operand set (48 / 72 B per point-sweep) over the
     launch time.  Labelled, because it is a fraction of the HBM roof only for a variant that streams all of it."""
@@ -374,10 +403,13 @@ def config_lines(local):
         p = make()
         kind = p['kind']
         rp = ResidentProblem(p, device=local)
-        # (the better of two timed runs of `steps` steps: one stalled run -- seen once in the round, a third of the usual rate on
-        #  one line -- should not stand for a kernel; `timed_runs` says so in the line)
-        runs = [time_resident(rp, sweeps, steps, 1 if r_ == 0 else 0, timing=1) for r_ in range(2)]
-        dt, ms, nl, s, fl = min(runs, key=lambda t: t[0])
+        # Three timed runs of `steps` steps; ALL are in the line (`values`, `run_launch_us`) and the MEDIAN stands.  (Round 5
+        # kept the better of two because of one stalled run seen once -- a third of the usual rate on one line, never seen
+        # again in this round's runs: profiles/r06_bench_runs.txt; an outlier now shows in `values` instead of being dropped.)
+        runs = [time_resident(rp, sweeps, steps, 1 if r_ == 0 else 0, timing=1) for r_ in range(3)]
+        run_values = [float(rp.nb) * rp.n * sweeps * steps / t[0] for t in runs]
+        run_launch_us = [t[1] / max(t[2], 1) * 1e3 for t in runs]
+        dt, ms, nl, s, fl = sorted(runs, key=lambda t: t[0])[1]
         ok = bool((fl[:, 2] == sweeps - 1).all() and not fl[:, 0].any())
         n_all = float(rp.nb) * rp.n
         avg_ms = ms / max(nl, 1)
@@ -390,7 +422,7 @@ def config_lines(local):
         par = [oracle_parity(synthetic.member(p, m), res[m], flp[m], psw, order) for m in m_chk]
         line = alg_figures(kind, n_all * spl_mean, avg_ms)
         # HBM-side bytes of this kernel on this workload (PMC passes, profiles/traffic.json: per point-sweep, static)
-        tr = traffic.get(name)
+        tr, why = traffic_entry(traffic, name)
         if tr and tr.get('kernel_prefix') and kernel_name(kind, s).startswith(tr['kernel_prefix']) and tr.get('members') == rp.nb:
             tb = tr['bytes_per_point_sweep'] * n_all * spl_mean
             line.update({'traffic': tb, 'traffic_bytes_per_point_sweep': tr['bytes_per_point_sweep'],
@@ -399,11 +431,15 @@ def config_lines(local):
                          'traffic_source': 'static: ' + tr.get('source', 'profiles/traffic.json')})
         else:
             line['traffic'] = None
+            line['traffic_why_null'] = why or 'profiled kernel / member count differs from this run'
         out.append(line)
         line.update({'name': name, 'workload': wl, 'value': n_all * sweeps * steps / dt, 'unit': 'point-sweeps/s',
-                    'members': rp.nb, 'sweeps_per_step': sweeps, 'steps': steps, 'timed_runs': 2, 'ran_all_sweeps': ok,
+                    'values': run_values, 'value_is': 'median of the three timed runs in `values`',
+                    'run_launch_us': run_launch_us, 'run_spread': max(run_values) / min(run_values),
+                    'members': rp.nb, 'sweeps_per_step': sweeps, 'steps': steps, 'timed_runs': 3, 'ran_all_sweeps': ok,
                     'kernel': kernel_name(kind, s), 'sweeps_per_launch': s['sweeps_per_launch'],
-                    'rows_per_tile': s['rows_per_tile'], 'lanes': s.get('lanes', 1), 'bound': r['bound'], 'frac': r['frac'], 'achieved': r['achieved'],
+                    'rows_per_tile': s['rows_per_tile'], 'lanes': s.get('lanes', 1),
+                    'k_chunks': s.get('k_chunks', 0), 'cut_tiles': s.get('cut_tiles', 0), 'bound': r['bound'], 'frac': r['frac'], 'achieved': r['achieved'],
                     'peak': r['peak'], 'unit_roofline': r['unit'], 'valu_frac': r['valu_frac'],
                     'streamed_frac_of_hbm_peak': r['streamed_frac_of_hbm_peak'],
                     'streamed_bytes_per_point_sweep': r['streamed_bytes_per_point_sweep'],
@@ -412,6 +448,116 @@ def config_lines(local):
                     'parity_sweeps': psw, 'parity_members': m_chk,
                     'seconds': time.perf_counter() - t_all})
         del rp
+    return out
+
+
+def sustained_leg(rp, sweeps, opts, n_all, seconds=5.0):
+    """The headline solve back to back for >= `seconds` of wall clock: point-sweeps/s of every whole second and the mean
+    launch duration in the first and the last of them -- what the fp64 clocks do under sustained load (the timed region
+    of the contract line is twenty solves, under 0.1 s)."""
+    import torch
+    rp.reset(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks = []                                               # (end time, sweep ms, launches) of every solve
+    while True:
+        fl, st = rp.solve(sweeps - 1, 0.0, **opts)
+        torch.cuda.synchronize()
+        marks.append((time.perf_counter() - t0, st['sweep_ms'], st['sweep_launches']))
+        if marks[-1][0] >= seconds:
+            break
+    total = marks[-1][0]
+    nsec = int(total)
+    rates, launch = [], []
+    for k in range(nsec):
+        w = [m for m in marks if k <= m[0] < k + 1]
+        rates.append(len(w) * n_all * sweeps / 1.0)
+        launch.append(sum(m[1] for m in w) / max(1, sum(m[2] for m in w)))
+    rs = sorted(rates)
+    return {'seconds': total, 'solves': len(marks), 'value': len(marks) * n_all * sweeps / total, 'unit': 'point-sweeps/s',
+            'per_second': rates, 'per_second_min': rs[0], 'per_second_median': rs[len(rs) // 2], 'per_second_max': rs[-1],
+            'avg_launch_ms_first_second': launch[0], 'avg_launch_ms_last_second': launch[-1],
+            'launch_drift': launch[-1] / launch[0] - 1.0,
+            'note': 'every solve is followed by a host synchronisation (the per-second counts need its end time): '
+                    'back-to-back solves, not one queue of launches'}
+
+
+def host_pointer_solve(p, sweeps, reps=3, **opt):
+    """One C-ABI call on HOST arrays (the `_batched` entry): upload, sweeps, download -- what a caller of the reference's
+    API pays.  -> (best wall seconds, stats of that call, S, flags)"""
+    import ctypes
+    from xinvert_amd import _lib
+    from xinvert_amd.resident import FN, scalars
+    L = _lib.require_gpu()
+    nb = p['S0'].shape[0]
+    n = int(np.prod(p['S0'].shape[1:]))
+    arrs, strides = [np.ascontiguousarray(p['S0'], dtype=np.float64)], [n]
+    for k, c in enumerate(p['coefs']):
+        if k == 1 and p['kind'] in ('std2d', 'gen2d') and not np.asarray(c).any():
+            arrs.append(None); strides.append(0)
+        else:
+            arrs.append(np.ascontiguousarray(c, dtype=np.float64)); strides.append(0 if k in p['shared'] else n)
+    q = {k: v for k, v in p.items() if k not in ('S0', 'coefs')}
+    best = None
+    for _ in range(reps):
+        S = arrs[0].copy()
+        fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
+        o = _lib.options(**opt)
+        t = time.perf_counter()
+        rc = getattr(L, FN[p['kind']] + '_batched')(_lib.hptr(S), *[_lib.hptr(x) for x in arrs[1:]], nb,
+                                                    _lib.strides_arg(strides), *scalars(q), _lib.hptr(fl),
+                                                    sweeps - 1, 0.0, ctypes.byref(o))
+        dt = time.perf_counter() - t
+        _lib.check(rc)
+        if best is None or dt < best[0]:
+            best = (dt, _lib.last_stats(), S, fl)
+    return best
+
+
+def end_to_end_leg(local, p_c2, S_resident):
+    """Host arrays in, host arrays out -- what a caller of the reference's API sees (core.py:129-139, apps.py:1324-1394):
+    `apps.invert_Poisson` on the headline slice, and the C-ABI host-pointer entry on one GPU's share of C5 and C4.
+    Each with the wall clock, the upload / sweep / download spans, and the device-resident time of the same solve."""
+    import xinvert_amd as xa
+    from xinvert_amd import synthetic
+    from xinvert_amd.resident import ResidentProblem
+    out = {'note': 'PCIe-inclusive: never the headline `value` (inputs resident).  h2d_ms / d2h_ms are the spans of the copy '
+                   'streams (they overlap the sweeps when the batch is cut into chunks)'}
+    # ---- the front end on the headline slice
+    ny, nx = p_c2['yc'], p_c2['xc']
+    F = xa.Field(p_c2['zeta'][0], ('lat', 'lon'), {'lat': p_c2['lat'], 'lon': p_c2['lon']})
+    iP = {'BCs': [p_c2['BCy'], p_c2['BCx']], 'mxLoop': 499, 'tolerance': 0.0, 'printInfo': False, 'device_prep': True,
+          'device': local}
+    xa.invert_Poisson(F, ['lat', 'lon'], iParams=iP)          # (library load, pools, pinned rings)
+    best, S = None, None
+    for _ in range(5):
+        t = time.perf_counter()
+        S = xa.invert_Poisson(F, ['lat', 'lon'], iParams=iP)
+        dt = time.perf_counter() - t
+        if best is None or dt < best[0]:
+            best = (dt, S.iParams['stats'])
+    dt, st = best
+    sea = ~np.isnan(p_c2['zeta'][0])
+    out['C2_invert_Poisson'] = {
+        'workload': 'apps.invert_Poisson(zeta [%d, %d] float64 with NaN land, BCs fixed / periodic, 500 sweeps): mask, '
+                    'cos(lat) scaling and de-mask on the device, result as a host array' % (ny, nx),
+        'wall_ms': dt * 1e3, 'library_call_ms': st['wall_ms'], 'h2d_ms': st['h2d_ms'], 'd2h_ms': st['d2h_ms'],
+        'python_ms': dt * 1e3 - st['wall_ms'], 'value_pcie_inclusive': float(ny) * nx * 500 / dt,
+        'bitwise_equal_to_resident': bool(S_resident is not None and np.array_equal(S.values[sea], S_resident[sea]))}
+    # ---- one GPU's share of the batched configurations through host pointers
+    for name, make, sweeps in (('C5x15', lambda: c5_members(0, 15), 200),
+                               ('C4x8', lambda: synthetic.gill_matsuno(720, 1440, 8), 500)):
+        p = make()
+        rp = ResidentProblem(p, device=local)
+        tr = min(time_resident(rp, sweeps, 1, 1 if r_ == 0 else 0)[0] for r_ in range(3))
+        rp.reset(); rp.solve(sweeps - 1, 0.0)
+        res = rp.result()
+        del rp
+        dt, st, S, fl = host_pointer_solve(p, sweeps, device=local)
+        n_all = float(np.prod(p['S0'].shape))
+        out[name] = {'wall_ms': dt * 1e3, 'h2d_ms': st['h2d_ms'], 'd2h_ms': st['d2h_ms'], 'sweep_ms_resident': tr * 1e3,
+                     'host_chunks': st['host_chunks'], 'vs_resident': dt / tr,
+                     'value_pcie_inclusive': n_all * sweeps / dt, 'unit': 'point-sweeps/s',
+                     'bitwise_equal_to_resident': bool(np.array_equal(S, res))}
     return out
 
 
@@ -577,6 +723,8 @@ def main():
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'rank_values': rank_values, 'n1_value': n1,
+            'rank_spread': None if not rank_values else max(r['value'] for r in rank_values) / min(r['value'] for r in rank_values),
+            'linear_scaling_value': None if n1 is None else (n1 * ranks_done if scaling == 'weak' else n1 * ranks_done),
             'n1_value_note': None if n1 is None else 'rank 0 alone on its own block (%d member(s)), the other ranks idle: the '
                              'N = 1 rate for the same per-GPU work; linear scaling = n1_value x n_gpus' % nb,
             'flags_sha256': __import__('hashlib').sha256(np.ascontiguousarray(allf, dtype=np.float64).tobytes()).hexdigest(),
@@ -601,6 +749,7 @@ def main():
                          'contraction is off by the bit-exactness contract; datasheet FMA peak %.1f); hbm: 8 TB/s spec'
                          % FP64_FMA_SPEC_TFLOPS,
             'frac_of_measured_valu_peak': rr['valu_TFLOPs'] / FP64_VALU_MEASURED_TFLOPS,
+            'frac_of_fma_datasheet_peak': rr['valu_TFLOPs'] / FP64_FMA_SPEC_TFLOPS,
             'useful_flops_per_point_update': UPD_FLOPS[kind],
             'kernel': kernel_name(kind, s),
             'launches': int(launches),
@@ -614,33 +763,31 @@ def main():
         em = tile_model(s) if kind in ('std2d', 'gen2d') else None
         if em:
             roof['executed_over_useful'] = em
-        traffic = None
+        traffic, traffic_why = None, 'no profile of this configuration'
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile) and a.config == 'c2' and (a.ny, a.nx) == (1800, 3600) and nb == 1 and a.mask == 'continents':
-            try:
-                traffic = json.load(open(tfile)).get(('std2d_pipe_um%d' % s['xuniform_mask']) if s.get('pipelined')
-                                                     else 'std2d_spl%d_um%d' % (spl, s['xuniform_mask']))
-            except Exception:
-                traffic = None
-        elif os.path.exists(tfile) and a.config == 'c4' and nb == 64 and s.get('pipelined') and s['xuniform_mask'] == 31:
-            try:                                                 # (the 64-member launch profiled by tools/profile_headline.sh)
-                traffic = json.load(open(tfile)).get('gen2d_pipe_um31_fr_c4x64')
-            except Exception:
-                traffic = None
-        if traffic is None and os.path.exists(tfile) and a.config == 'c5' and spl == 2:
-            try:                                                 # per point-sweep, from the 15-volume launch profiled by
-                det = json.load(open(tfile)).get('std3d_pipe3d_c5x15_detail')      # a 15-volume launch, scaled to this one
-                traffic = det['bytes_per_point_sweep'] * pts_per_launch if det else None
-            except Exception:
-                traffic = None
+        tj = load_traffic()
+        if a.config == 'c2' and (a.ny, a.nx) == (1800, 3600) and nb == 1 and a.mask == 'continents':
+            e, traffic_why = traffic_entry(tj, ('std2d_pipe_um%d' % s['xuniform_mask']) if s.get('pipelined')
+                                           else 'std2d_spl%d_um%d' % (spl, s['xuniform_mask']))
+            traffic = e['bytes_per_launch'] if e else None
+        elif a.config == 'c4' and nb == 64 and s.get('pipelined') and s['xuniform_mask'] == 31:
+            e, traffic_why = traffic_entry(tj, 'gen2d_pipe_um31_fr_c4x64')     # (the 64-member launch profiled by tools/profile_headline.sh)
+            traffic = e['bytes_per_launch'] if e else None
+        elif a.config == 'c5' and spl == 2:
+            e, traffic_why = traffic_entry(tj.get('configs', {}), 'C5')        # per point-sweep, from the 15-volume launch
+            traffic = e['bytes_per_point_sweep'] * pts_per_launch if e else None
         roof['traffic'] = traffic
-        roof['traffic_source'] = 'static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel variant (profiles/traffic.json), not read in this run'
+        roof['traffic_source'] = 'static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel variant (profiles/traffic.json), not read in this run; used only while the entry\'s source hash matches this tree (src_sha)'
+        roof['src_sha'] = src_sha()
+        if not traffic:
+            roof['traffic_why_null'] = traffic_why
         if traffic:
             roof['traffic_GBps'] = traffic / (avg_ms * 1e-3) / 1e9
             roof['traffic_frac_of_hbm_peak'] = roof['traffic_GBps'] / HBM_PEAK_GBS
         out['roofline'] = roof
 
         single = (world == 1)
+        S_res500 = None
         if a.config == 'c2' and single and not a.no_hbm:
             # ---- the HBM-bound variant on a working set far beyond the Infinity Cache -----------------
             hm = 8
@@ -673,21 +820,18 @@ def main():
                 'sweeps_per_launch': sh['sweeps_per_launch'], 'xuniform_mask': sh['xuniform_mask'],
                 'masked_tile_pct': sh['masked_tile_pct'], 'parity_bitwise_10_sweeps': hpar['bitwise'] and hpar['loop_equal'],
                 'traffic': None}
-            try:
-                # PMC bytes of this very variant, static, PER PASS over the 8 members: the profiled kernel launch covers
-                # members / lanes of them (two launch chains: `lanes`), so bytes per pass = bytes per launch x lanes
-                hd = json.load(open(tfile)).get('std2d_spl1_um0_all_detail') or {}
-                bpl = hd.get('bytes_per_launch') or json.load(open(tfile)).get('std2d_spl1_um0_all')
-                lanes_prof = int(hd.get('lanes') or max(1, round(hm * n * 44.0 / max(bpl, 1.0))))     # (a profile without the field: ~44 B per point measured)
-                if bpl and (a.ny, a.nx) == (1800, 3600) and int(hd.get('members', hm)) == hm:
-                    ht = float(bpl) * lanes_prof
-                    out['roofline_hbm'].update({'traffic': ht, 'traffic_GBps': ht / (h_avg * 1e-3) / 1e9,
-                                                'traffic_frac_of_hbm_peak': ht / (h_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                'traffic_bytes_per_point_sweep': ht / pts,
-                                                'traffic_lanes_profiled': lanes_prof,
-                                                'traffic_source': roof['traffic_source']})
-            except Exception:
-                pass
+            # PMC bytes of this very variant, static, PER PASS over the 8 members: the profiled kernel launch covers
+            # members / lanes of them (two launch chains: `lanes`), so bytes per pass = bytes per launch x lanes
+            hd, hwhy = traffic_entry(load_traffic(), 'std2d_spl1_um0_all')
+            if hd and hd.get('lanes') and (a.ny, a.nx) == (1800, 3600) and int(hd.get('members', hm)) == hm:
+                ht = float(hd['bytes_per_launch']) * int(hd['lanes'])
+                out['roofline_hbm'].update({'traffic': ht, 'traffic_GBps': ht / (h_avg * 1e-3) / 1e9,
+                                            'traffic_frac_of_hbm_peak': ht / (h_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            'traffic_bytes_per_point_sweep': ht / pts,
+                                            'traffic_lanes_profiled': int(hd['lanes']),
+                                            'traffic_source': roof['traffic_source']})
+            else:
+                out['roofline_hbm']['traffic_why_null'] = hwhy or 'profile of another launch shape'
             # the one figure of this line that IS a fraction of the HBM roof, next to the headline kernel's own bound
             out['roofline']['hbm_variant'] = {k: out['roofline_hbm'][k] for k in
                                               ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_of_achievable_6300',
@@ -704,10 +848,14 @@ def main():
             fl_p, sp_ = rp.solve(psw - 1, 0.0, **opts)
             same_cfg = all(sp_[k] == s[k] for k in ('path', 'sweeps_per_launch', 'rows_per_tile',
                                                     'xuniform_mask', 'masked_tile_pct', 'pipelined'))
-            par = oracle_parity(synthetic.member(p, 0), rp.result()[0], fl_p[0], psw)
+            S_res = rp.result()[0]
+            S_res500 = S_res if psw == 500 else None
+            par = oracle_parity(synthetic.member(p, 0), S_res, fl_p[0], psw)
             par['same_kernel_config_as_timed'] = bool(same_cfg)
             out['parity'] = par
             out['roofline']['parity_bitwise'] = bool(par['bitwise'] and par['loop_equal'] and same_cfg)
+        if a.config == 'c2' and single and not a.no_configs:
+            out['sustained'] = sustained_leg(rp, sweeps, opts, float(nb) * n, a.sustained_seconds)
         if a.config == 'c2' and single and a.mask == 'continents' and not a.no_configs:
             # mask sensitivity of the headline: the same solve with a coastline-scale mask
             # (few whole tiles to skip) and with tile skipping off
@@ -744,6 +892,8 @@ def main():
                                                                   'frac', 'valu_frac', 'streamed_frac_of_hbm_peak', 'alg_frac',
                                                                   'traffic_bytes_per_point_sweep', 'traffic_frac_of_hbm_peak',
                                                                   'parity_bitwise')} for c in out['configs']]
+        if a.config == 'c2' and single and not a.no_e2e and (a.ny, a.nx) == (1800, 3600) and a.mask == 'continents':
+            out['end_to_end'] = end_to_end_leg(local, p, S_res500)
         if a.inproc and single:
             out['inproc'] = inproc_leg(a, a.gpus)
         if a.config == 'c2' and single and not a.no_cpu:

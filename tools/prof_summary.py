@@ -49,6 +49,15 @@ def mean_counter(db, name, kernel_sub):
     return r[0], r[1]
 
 
+def src_sha():
+    """hash of the library's sources as they are in this tree (xinvert_amd/build.py: source_hash) -- every entry written
+    into traffic.json carries it, and bench.py reports the entry only while it matches the tree it runs from"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from xinvert_amd import build as xbuild
+    return xbuild.source_hash()
+
+
 def main():
     cmd = sys.argv[1]
     if cmd in ('kernels', 'counters'):
@@ -78,7 +87,7 @@ def main():
             d[key] = traffic
             d[key + '_detail'] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'fetch_correction': 2.0,
                                   'calibration_kernel': calname, 'calibration_FETCH_KiB': cal,
-                                  'bytes_per_launch': traffic, 'launches_profiled': nf}
+                                  'bytes_per_launch': traffic, 'launches_profiled': nf, 'src_sha': src_sha()}
             if len(sys.argv) > 8:                          # members of the whole pass, lanes it ran in (a launch covers members / lanes)
                 d[key + '_detail'].update({'members': int(sys.argv[7]), 'lanes': int(sys.argv[8]),
                                            'bytes_per_pass': traffic * int(sys.argv[8])})
@@ -92,7 +101,8 @@ def main():
         d = json.load(open(path)) if os.path.exists(path) else {}
         d.setdefault('configs', {})[name] = {'kernel_prefix': prefix, 'members': int(members),
                                              'bytes_per_point_sweep': traffic / float(psl), 'bytes_per_launch': traffic,
-                                             'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'launches_profiled': nf, 'source': src}
+                                             'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'launches_profiled': nf, 'source': src,
+                                             'src_sha': src_sha()}
         json.dump(d, open(path, 'w'), indent=1, sort_keys=True)
         print('%s: %s  %.4e B per launch = %.2f B per point-sweep (n=%d)' % (name, ksub, traffic, traffic / float(psl), nf))
     else:

@@ -90,6 +90,20 @@ def _stamp(src, flags):
     return h.hexdigest()
 
 
+def source_hash():
+    """Content hash (16 hex digits) of everything the library is built from: every file of csrc/ and include/xinv.h.
+    profiles/traffic.json entries carry the hash of the tree they were profiled on; bench.py reports a counter figure
+    only while it still matches (a kernel change that forgets to re-profile must not carry stale bytes forward)."""
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.h', '.hip'))]
+    files.append(os.path.join(HERE, '..', 'include', 'xinv.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _units():
     return [u for u in UNITS if os.path.exists(os.path.join(CSRC, u[1]))]
 

@@ -65,7 +65,8 @@ def poisson_latlon(ny, nx, mask=True, seed=SEED, BCs=('fixed', 'periodic'), memb
     return dict(kind='std2d', yc=ny, xc=nx, BCy=BCs[0], BCx=BCs[1], dely=ps['del2'], delx=ps['del1'],
                 delxSqr=ps['del1Sqr'], ratio=ps['ratio'], ratioQtr=ps['ratioQtr'],
                 ratioSqr=ps['ratioSqr'], optArg=ps['optArg'], undef=apps._undeftmp,
-                S0=initS.values, coefs=[A, B, C, Fm.values], shared=(0, 1, 2), lat=lat, lon=lon)
+                S0=initS.values, coefs=[A, B, C, Fm.values], shared=(0, 1, 2), lat=lat, lon=lon,
+                zeta=zeta)          # (the raw forcing, NaN on land: what a caller of apps.invert_Poisson holds)
 
 
 def stommel_cartesian(ny, nx, seed=SEED, varying_R=True):
