@@ -205,6 +205,10 @@ def kernel_name(kind, s):
     if s['path'] == 1:
         return 'colour-pass kernels (%d colours)' % s['colours']
     if kind == 'bih2d':
+        vm = s.get('point_factor', 0)
+        if vm:
+            return 'k_fusedbih (one pass per sweep; %s as vector streams + the point-factor stream Q)' % \
+                   ('A, C, D, F' if vm == 1 else 'A..I')
         return 'k_fusedbih (one pass per sweep, A..I and the relaxation factor as per-row records)'
     if kind == 'std3d':
         if K == 2:
@@ -232,8 +236,8 @@ def streamed_bytes_per_point_sweep(kind, s):
         nvec += {0: 0, 1: 1, 2: 0}[s.get('point_factor', 0)]   # (+ Q; - C when it is read out of A)
     elif kind == 'std3d':
         nvec = 4 - bin(um & 7).count('1')                   # A, B, C + forcing
-    else:
-        nvec = 1                                            # biharmonic one-pass kernel: forcing J only
+    else:                                                   # biharmonic one-pass kernel: the forcing J (+ the vector streams + Q)
+        nvec = 1 + {0: 0, 1: 5, 2: 10}[s.get('point_factor', 0)]
     return 8.0 * (2 + nvec) / K
 
 
@@ -383,6 +387,9 @@ def config_lines(local):
          lambda: synthetic.stommel_cartesian(2000, 2000), 500, 5, orc.COLOUR_2, 12),
         ('C3-Munk', 'invert_StommelMunk 2000x2000 Cartesian, biharmonic form (BASELINE configs[2])',
          lambda: synthetic.munk_cartesian(2000, 2000), 500, 3, orc.COLOUR_AUTO, 10),
+        ('C3-Munk-xy', 'invert_StommelMunk 2000x2000 Cartesian, biharmonic form with A4(x,y) and R(x,y) varying along both axes '
+                       '(BASELINE configs[2]: "spatially-varying" coefficients)',
+         lambda: synthetic.munk_cartesian(2000, 2000, varying=True), 500, 3, orc.COLOUR_AUTO, 10),
         ('C4', 'invert_GillMatsuno 1440x720, 8 of the 64 forcing members = one GPU\'s share of eight (BASELINE configs[3]; '
                '--config c4 runs all 64)',
          lambda: synthetic.gill_matsuno(720, 1440, 8), 500, 5, orc.COLOUR_2, 12),
@@ -491,9 +498,14 @@ def host_pointer_solve(p, sweeps, reps=3, **opt):
     nb = p['S0'].shape[0]
     n = int(np.prod(p['S0'].shape[1:]))
     arrs, strides = [np.ascontiguousarray(p['S0'], dtype=np.float64)], [n]
+    rowconst = 0
     for k, c in enumerate(p['coefs']):
-        if k == 1 and p['kind'] in ('std2d', 'gen2d') and not np.asarray(c).any():
+        c = np.asarray(c)
+        if k == 1 and p['kind'] in ('std2d', 'gen2d') and not c.any():
             arrs.append(None); strides.append(0)
+        elif k in p['shared'] and k < len(p['coefs']) - 1 and c.strides[-1] == 0 and c.shape[-1] > 1:
+            # a function of latitude handed over as the front end hands it over (core._prep_coef): one value per row
+            arrs.append(np.ascontiguousarray(c[..., 0], dtype=np.float64)); strides.append(0); rowconst |= 1 << k
         else:
             arrs.append(np.ascontiguousarray(c, dtype=np.float64)); strides.append(0 if k in p['shared'] else n)
     q = {k: v for k, v in p.items() if k not in ('S0', 'coefs')}
@@ -501,7 +513,7 @@ def host_pointer_solve(p, sweeps, reps=3, **opt):
     for _ in range(reps):
         S = arrs[0].copy()
         fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
-        o = _lib.options(**opt)
+        o = _lib.options(rowconst_mask=rowconst, **opt)
         t = time.perf_counter()
         rc = getattr(L, FN[p['kind']] + '_batched')(_lib.hptr(S), *[_lib.hptr(x) for x in arrs[1:]], nb,
                                                     _lib.strides_arg(strides), *scalars(q), _lib.hptr(fl),
@@ -674,6 +686,12 @@ def main():
     dt = time.perf_counter() - t0
     ranks_done, backend = 1, None
     rank_values, n1 = None, None
+    # a checksum of checksums over the FINAL state of every member: the wrap-around int64 sum of the bit patterns of its
+    # S (order-independent, exact, one pass on the device), gathered over the ranks like the flags -- equal digests = the
+    # same fields bit for bit however the batch was split.  (flags[:, 1], the relative change of mean|S|, is a sum whose
+    # grouping follows the launch's tiling -- 1e-12 between two splits of a batch, DESIGN 5.3 -- and is not hashed.)
+    ck = rp.S.view(torch.int64).reshape(nb, -1).sum(dim=1).cpu().numpy().reshape(nb, 1)
+    all_ck = xdist.gather_blocks(ck, total_members) if joined else ck
     if joined:
         backend = torch.distributed.get_backend()
         tdev = dev if backend == 'nccl' else torch.device('cpu')
@@ -727,7 +745,11 @@ def main():
             'linear_scaling_value': None if n1 is None else (n1 * ranks_done if scaling == 'weak' else n1 * ranks_done),
             'n1_value_note': None if n1 is None else 'rank 0 alone on its own block (%d member(s)), the other ranks idle: the '
                              'N = 1 rate for the same per-GPU work; linear scaling = n1_value x n_gpus' % nb,
-            'flags_sha256': __import__('hashlib').sha256(np.ascontiguousarray(allf, dtype=np.float64).tobytes()).hexdigest(),
+            'flags_sha256': __import__('hashlib').sha256(np.ascontiguousarray(allf[:, [0, 2]], dtype=np.float64).tobytes()).hexdigest(),
+            'flags_sha256_of': 'overflow flag and loop index of every slice, gathered over the ranks',
+            'S_checksum_sha256': __import__('hashlib').sha256(np.ascontiguousarray(all_ck, dtype=np.int64).tobytes()).hexdigest(),
+            'S_checksum_of': 'per slice: wrap-around int64 sum of the bit patterns of its final S; gathered over the ranks',
+            'S_checksums_first': [int(v) for v in np.asarray(all_ck).reshape(-1)[:16]],
             'config': {'workload': wl_name, 'sweeps_per_step': sweeps,
                        'members_total': total_members, 'members_this_gpu': nb,
                        'sweeps_per_launch': spl, 'rows_per_tile': s['rows_per_tile'], 'lanes': s.get('lanes', 1),

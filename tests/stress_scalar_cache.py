@@ -88,7 +88,17 @@ def families():
     F['fusedbih_ext_per'] = (lambda s: xuni(util.randbih(96, 384, 'extend', 'periodic', seed=s), range(9)),
                              {}, dict(path=2), orc.COLOUR_AUTO)
     F['bih_rowclass_uni'] = (lambda s: xuni(util.randbih(96, 384, 'fixed', 'fixed', bnz=True, seed=s), (0, 2, 3)),
-                             {}, dict(path=1), orc.COLOUR_AUTO)
+                             dict(path=1), dict(path=1), orc.COLOUR_AUTO)
+    # the one-pass kernel's vector-stream variants (round 6): vm = 1 reads G, H, I out of the per-row records (scalar unit)
+    # beside the A, C, D, F streams; vm = 2 reads every coefficient as a vector
+    def munk_like(p):
+        p = xuni(p, (6, 7, 8))
+        p['coefs'] = [np.zeros_like(c) if k in (1, 4) else c for k, c in enumerate(p['coefs'])]
+        return p
+    F['fusedbih_vm1'] = (lambda s: munk_like(util.randbih(96, 384, 'fixed', 'fixed', bnz=True, seed=s)),
+                         {}, dict(path=2, point_factor=1), orc.COLOUR_AUTO)
+    F['fusedbih_vm2'] = (lambda s: util.randbih(96, 384, 'extend', 'periodic', bnz=True, seed=s),
+                         {}, dict(path=2, point_factor=2), orc.COLOUR_AUTO)
     F['bih_colour_uni'] = (lambda s: xuni(util.randbih(60, 250, 'extend', 'periodic', bnz=True, seed=s), (0, 2, 3)),
                            {}, dict(path=1), orc.COLOUR_AUTO)
     # colour-pass kernels (odd-xc periodic seam; 'extend' runs k_extend, whose corner reads are block-uniform)

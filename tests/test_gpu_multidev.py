@@ -179,7 +179,9 @@ def test_bench_self_launches_two_ranks():
 
 def test_bench_c5_two_ranks_equal_one_rank():
     """The C5 strong-scaling split (`--config c5 --members 4 --gpus 2`, two ranks sharing this GPU over gloo): the
-    flags gathered from the two blocks are, bit for bit, those of a single rank solving all four volumes; the line
+    loop indices / overflow flags and the per-volume checksums of the final S gathered from the two blocks are, bit for bit,
+    those of a single rank solving all four volumes (the grouping of the norm's partial sums follows the launch's tiling --
+    which tiles are cut into k chunks depends on the tile count: flags[:, 1] agrees to 1e-12, not hashed); the line
     carries every rank's own rate and rank 0's stand-alone rate (what the driver's N = 1 run is compared with)."""
     import json
     import os
@@ -199,7 +201,8 @@ def test_bench_c5_two_ranks_equal_one_rank():
     two, one = got[2], got[1]
     assert two['n_gpus'] == 2 and two['scaling'] == 'strong' and two['config']['members_total'] == 4
     assert two['config']['members_this_gpu'] == 2 and one['config']['members_this_gpu'] == 4
-    assert two['flags_sha256'] == one['flags_sha256']
+    assert two['flags_sha256'] == one['flags_sha256']                    # overflow flags and loop indices
+    assert two['S_checksum_sha256'] == one['S_checksum_sha256']          # every volume's final S, bit for bit
     assert [r['members'] for r in two['rank_values']] == [2, 2] and all(r['value'] > 0 for r in two['rank_values'])
     assert two['n1_value'] > 0 and one['n1_value'] is None and one['rank_values'] is None
 

@@ -565,12 +565,16 @@ def test_biharmonic_colour_path(BCy, BCx, bnz, msk, shape):
     x is periodic), including the reference's stale-index east branches."""
     p = randbih(shape[0], shape[1], BCy, BCx, bnz, msk, seed=_seed((BCy, BCx, bnz, msk, shape)))
     So, flo = run_oracle(p, 15, 1e-9, COLOUR_AUTO)
-    S, fl, st = run_hip_batched([p], 15, 1e-9)
+    S, fl, st = run_hip_batched([p], 15, 1e-9, path=PATH_COLOUR)
     assert st['path'] == PATH_COLOUR
     assert st['colours'] == 9 + (3 * (shape[1] % 3) if BCx == 'periodic' else 0)
     assert_same(S[0], fl[0], So, flo, 'bih')
+    # the default path: the one-pass kernel's vector-stream variants (round 6) wherever x is not periodic with xc % 3 != 0
     S1, f1 = run_hip_single(p, 15, 1e-9)
     assert np.array_equal(S1, S[0])
+    Sd, fld, std = run_hip_batched([p], 15, 1e-9)
+    assert std['path'] == (PATH_COLOUR if (BCx == 'periodic' and shape[1] % 3) else PATH_FUSED)
+    assert np.array_equal(Sd, S) and fld[0][2] == fl[0][2]
 
 
 @pytest.mark.parametrize('BCy', ['fixed', 'extend'])
@@ -585,7 +589,7 @@ def test_biharmonic_rowclass_strips(BCy, xc, xuni):
         p['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k in (0, 2, 3, 5, 8) else c
                       for k, c in enumerate(p['coefs'])]
     So, flo = run_oracle(p, 9, 1e-9, COLOUR_AUTO)
-    S, fl, st = run_hip_batched([p, p], 9, 1e-9)
+    S, fl, st = run_hip_batched([p, p], 9, 1e-9, path=PATH_COLOUR)
     assert st['path'] == PATH_COLOUR and st['colours'] == 9
     if xuni:
         assert st['xuniform_mask'] & 0x12d == 0x12d
@@ -606,7 +610,7 @@ def test_biharmonic_rowclass_periodic(BCy, xc, xuni):
         p['coefs'] = [np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k in (0, 2, 3, 5, 8) else c
                       for k, c in enumerate(p['coefs'])]
     So, flo = run_oracle(p, 9, 1e-9, COLOUR_AUTO)
-    S, fl, st = run_hip_batched([p, p], 9, 1e-9)
+    S, fl, st = run_hip_batched([p, p], 9, 1e-9, path=PATH_COLOUR)
     assert st['path'] == PATH_COLOUR and st['colours'] == 9
     assert_same(S[0], fl[0], So, flo, 'bih rowclass periodic')
     assert np.array_equal(S[0], S[1])
@@ -639,6 +643,40 @@ def test_biharmonic_one_pass_kernel(BCy, BCx, rows, shape, bnz):
     for m, q in enumerate(ps):
         So, flo = run_oracle(q, 25, 1e-4, COLOUR_AUTO)
         assert_same(S[m], fl[m], So, flo, 'bih one-pass %r member %d' % (shape, m))
+    Sc, flc, stc = run_hip_batched(ps, 25, 1e-4, path=PATH_COLOUR)
+    assert stc['path'] == PATH_COLOUR and np.array_equal(S, Sc) and np.array_equal(fl[:, 2], flc[:, 2])
+
+
+def _munk_like_bih(p):
+    """A, C, D, F vary along x (A4(x, y), R(x, y): apps.py:1793-1836 puts A4 into A and C, R / D into D and F); no mixed
+    derivatives (B == E == 0); G, H, I functions of the row at most."""
+    q = dict(p)
+    q['coefs'] = [np.zeros_like(c) if k in (1, 4) else
+                  (np.ascontiguousarray(np.broadcast_to(c[:, :1], c.shape)) if k in (6, 7, 8) else c)
+                  for k, c in enumerate(p['coefs'])]
+    return q
+
+
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('BCx', ['fixed', 'periodic', 'extend'])
+@pytest.mark.parametrize('rows', [0, 3, 9])
+@pytest.mark.parametrize('shape', [(5, 9), (7, 12), (13, 183), (31, 366), (64, 543), (20, 72), (9, 180)])
+@pytest.mark.parametrize('vm', [1, 2])
+def test_biharmonic_one_pass_vector_streams(BCy, BCx, rows, shape, vm):
+    """k_fusedbih with coefficient arrays that vary along x (round 6): vm = 1 -- A, C, D, F as vector streams beside per-row
+    G, H, I (Munk with A4(x, y), R(x, y)); vm = 2 -- all nine, mixed derivatives included -- and the point-factor stream Q
+    (relaxation factor, 0 = the reference's predicate on A..I forbids the update).  Bit for bit the oracle's 9-colour
+    order and the colour launches: masks in coefficients and forcing, tile seams, periodic wrap with the stale-index east
+    columns, a batch with an early stop."""
+    if BCx == 'periodic' and shape[1] % 3:
+        pytest.skip('periodic x with xc % 3 != 0 runs the colour launches')
+    mk = _munk_like_bih if vm == 1 else (lambda q: q)
+    ps = [mk(randbih(shape[0], shape[1], BCy, BCx, 1, 1, seed=_seed(('bvs', BCy, BCx, shape, m, vm)))) for m in range(2)]
+    S, fl, st = run_hip_batched(ps, 25, 1e-4, rows_per_tile=rows)
+    assert st['path'] == PATH_FUSED and st['colours'] == 9 and st['point_factor'] == vm, st
+    for m, q in enumerate(ps):
+        So, flo = run_oracle(q, 25, 1e-4, COLOUR_AUTO)
+        assert_same(S[m], fl[m], So, flo, 'bih vector streams vm %d %r member %d' % (vm, shape, m))
     Sc, flc, stc = run_hip_batched(ps, 25, 1e-4, path=PATH_COLOUR)
     assert stc['path'] == PATH_COLOUR and np.array_equal(S, Sc) and np.array_equal(fl[:, 2], flc[:, 2])
 

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FAMILIES = ['pipe2d', 'pipe2d_ext', 'pipe2d_skip', 'pipe2d_fr', 'pipe2d_gen', 'pipe2d_gen_fr', 'fused2d_std_um3', 'fused2d_std_um3_skip', 'fused2d_std_full',
             'fused2d_gen_um31', 'fused2d_gen_um28', 'fused2d_gen_full', 'fused2d_std2dt_um7', 'fused9_std',
             'fused9_gen', 'fused3d_uni', 'fused3d_full', 'fused3d_two_sweeps', 'fused3dg', 'fusedbih',
-            'fusedbih_ext_per', 'bih_rowclass_uni', 'bih_colour_uni', 'colour_std2d_ext', 'colour_gen2d_nine',
+            'fusedbih_ext_per', 'fusedbih_vm1', 'fusedbih_vm2', 'bih_rowclass_uni', 'bih_colour_uni', 'colour_std2d_ext', 'colour_gen2d_nine',
             'colour_std3d_ext', 'fused2d_seam', 'fused2d_seam_um3', 'fused3d_seam', 'fused3d_seam_uni', 'fused3dg_seam', 'fused9_seam', 'fused3d_seam_ring', 'pipe2d_seam']
 
 

@@ -34,6 +34,8 @@ def make(name, a):
         return synthetic.stommel_cartesian(2000, 2000), a.sweeps or 200
     if name == 'c3m':
         return synthetic.munk_cartesian(2000, 2000), a.sweeps or 100
+    if name == 'c3mxy':                                  # Munk with A4(x, y), R(x, y): the vector-stream variant of k_fusedbih
+        return synthetic.munk_cartesian(2000, 2000, varying=True), a.sweeps or 100
     if name == 'c4':
         return synthetic.gill_matsuno(720, 1440, a.members or 8), a.sweeps or 200
     if name == 'gm73':                                  # the reference's own regime: tests/test_GillMatsuno.py:14-57

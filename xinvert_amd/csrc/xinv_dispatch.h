@@ -73,5 +73,6 @@ XINV_HIDDEN int xinv_launch_fused3d_fma(int NW, bool al, bool ext, dim3 grid, hi
 XINV_HIDDEN int xinv_launch_pipe3d_fma(bool al, dim3 grid, hipStream_t st, const Fused3Args &a);
 XINV_HIDDEN int xinv_launch_fused3dg(int NW, bool al, bool ext, dim3 grid, hipStream_t st,
                                      const Fused3GArgs &a);
-XINV_HIDDEN int xinv_launch_fusedbih(bool per, bool zbe, dim3 grid, hipStream_t st,
+// vm: where the coefficients come from (xinv_fusedbih.h: 0 per-row records, 1 A C D F as vector streams, 2 all nine)
+XINV_HIDDEN int xinv_launch_fusedbih(bool per, bool zbe, int vm, dim3 grid, hipStream_t st,
                                      const FusedBihArgs &a, int *occ);

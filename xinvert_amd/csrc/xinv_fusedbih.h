@@ -21,10 +21,19 @@
 // of 3, so every tile starts on a class-0 row and needs no recomputation above it: two source rows
 // suffice); below the tile rows y1, y1+1, y1+3 are recomputed from source rows up to y1+5.  Tiles
 // do not communicate: S ping-pongs between two buffers; the 'extend' pre-pass (k_extend_bih) runs
-// on the source buffer before the sweep.  Requires the coefficient arrays A..I to be constant
-// along x (per-row scalars: Munk / Stommel-Munk on Cartesian and lat-lon grids); otherwise the
-// row-class kernel runs.  Periodic x needs xc % 3 == 0 (see k_bih_rowclass).  Same ordering as
-// nine colour launches: bitwise equal results.
+// on the source buffer before the sweep.  Periodic x needs xc % 3 == 0 (see k_bih_rowclass).  Same
+// ordering as nine colour launches: bitwise equal results.
+//
+// Where the coefficients come from (template VM):
+//   VM = 0  A..I constant along x (Munk / Stommel-Munk with constant A4, R on Cartesian and lat-lon grids): per-row
+//           records through the scalar unit (k_row_factor_bih);
+//   VM = 1  A, C, D, F vary along x (A4(x, y), R(x, y): apps.py:1793-1836 puts A4 into A and C, R / D into D and F),
+//           B == E == 0, G, H, I per row: four vector streams + the point-factor stream Q (round 6);
+//   VM = 2  anything: all nine as vector streams + Q.
+// Q (k_point_factor_bih, once per coefficient stack): the point's relaxation factor -optArg / denominator
+// (numbas.py:1474-1477, same expression, same bits), 0 where the reference's predicate on A..I (or the row) forbids the
+// update.  Every coefficient is sampled at the updated point only, so a row's coefficient values are requested a group
+// ahead of its update, like its forcing, and used once.
 #pragma once
 #include "xinv_fused.h"
 #include "xinv_pipe2d.h"      /* xinv_cdouble_ptr: loads through the scalar unit */
@@ -83,7 +92,7 @@ __device__ __forceinline__ double xinv_upd_bih2d_rq(
 struct FusedBihArgs {
     const double *src;
     double *dst;
-    const double *c[10];       // A..I (x-uniform), J
+    const double *c[10];       // A..I, J
     int64_t sS, sc[10];
     int64_t yc, xc;
     int per;
@@ -108,6 +117,7 @@ struct FusedBihArgs {
     int lagp_NB, lagp_K;
     unsigned lagp_tag;
     const double *rowf;        // per-row records [nbatch][yc][XINV_BIH_RW] (k_row_factor_bih), read through the scalar unit
+    const double *q;           // VM > 0: the point-factor stream [nbatch][yc][xc] (k_point_factor_bih)
 };
 
 // Per-row record of the one-pass kernel (round 3): A..I of the row, the row's relaxation factor
@@ -117,9 +127,6 @@ struct FusedBihArgs {
 // update began with nine dependent vector loads of the coefficients and an IEEE divide, and the VALU sat idle 60 %
 // of the time (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.40 at one wavefront per SIMD).
 #define XINV_BIH_RW 12
-#ifndef XINV_BIH_REC
-#define XINV_BIH_REC 1
-#endif
 
 struct RowFactorBihArgs {
     const double *c[9];
@@ -127,6 +134,15 @@ struct RowFactorBihArgs {
     int64_t yc, xc;
     XinvScal sc_;
     double *rowf;
+};
+
+struct PointFactorBihArgs {
+    const double *c[9];           // A..I
+    int64_t sc[9];
+    int64_t yc, xc, n;            // n = yc * xc
+    XinvScal sc_;
+    double *q;                    // [nbatch][yc][xc]
+    int *flag;                    // bit 0: an updatable point's factor is +-0 (Q == 0 means "skip": the variants are not used)
 };
 
 #ifdef XINV_AUX_KERNELS
@@ -150,18 +166,42 @@ __global__ __launch_bounds__(256) void k_row_factor_bih(RowFactorBihArgs a)
     f[10] = rowok ? __longlong_as_double(-1LL) : 0.0;
     f[11] = 0.0;
 }
+
+// once per coefficient stack: Q[j,i] = -optArg / denominator (numbas.py:1474-1477: the expression of the reference, of
+// k_row_factor_bih and of the colour kernels, evaluated under the same -ffp-contract=off: the same bits) where the
+// reference's predicate on A..I lets the point be updated (numbas.py:1437-1442 without J; rows 2 .. yc-3), 0 elsewhere
+__global__ __launch_bounds__(256) void k_point_factor_bih(PointFactorBihArgs a)
+{
+    const int64_t m = blockIdx.y;
+    const double u = a.sc_.undef;
+    bool zero = false;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < a.n; t += (int64_t)gridDim.x * 256) {
+        const int64_t j = t / a.xc;
+        double cs[9];
+        bool ok = (j >= 2) && (j <= a.yc - 3);
+#pragma unroll
+        for (int q = 0; q < 9; q++) { cs[q] = a.c[q][m * a.sc[q] + t]; ok = ok && (cs[q] != u); }
+        double qv = 0.0;
+        if (ok) {
+            qv = -a.sc_.optArg / ((cs[0]*a.sc_.ratioSSr + cs[2]) * 6.0 +
+                                    cs[1]*a.sc_.ratioSqr / 4.0 +
+                                  -(cs[3]*a.sc_.ratioSqr + cs[5]) * 2.0 * a.sc_.delxSqr +
+                                    cs[8]*a.sc_.delxSSr);
+            zero = zero || (qv == 0.0);
+        }
+        a.q[m * a.n + t] = qv;
+    }
+    if (__any(zero) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 1);
+}
 #endif
 
-#ifndef XINV_BIH_MINWAVES
-#define XINV_BIH_MINWAVES 2
-#endif
-template <bool PER, bool ZBE>
-__global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArgs a)
+template <bool PER, bool ZBE, int VM = 0>
+__global__ __launch_bounds__(256, VM == 2 ? 1 : 2) void k_fusedbih(FusedBihArgs a)
 {
+    static_assert(VM != 1 || ZBE, "VM = 1: B and E are identically zero");
     constexpr int D = 9;
-#if XINV_BIH_REC
+    constexpr int NV = VM == 0 ? 0 : (VM == 1 ? 4 : 9);  // coefficient streams read as vectors
     xinv_fresh_scalar_cache();                         // (the per-row records come through the scalar unit: DESIGN.md 4.8)
-#endif
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && xinv_ctl_done(ctl)) return;
@@ -181,12 +221,10 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
         wt = a.tile_list[m * a.ntl + wt];
         active = wt >= 0;
     }
-#if XINV_BIH_REC
     // the tile is the wavefront's: its index in an SGPR makes every row quantity below scalar (row bases as SGPR
     // pairs, the march's compares on the scalar unit, the record loads s_loads)
     wt = __builtin_amdgcn_readfirstlane(active ? wt : 0);
     active = __builtin_amdgcn_readfirstlane((int)active) != 0;
-#endif
     const int rb = active ? wt / a.nstrip : 0, strip = active ? wt - rb * a.nstrip : 0;
     const int64_t xc = a.xc, yc = a.yc;
     const int64_t y0 = (int64_t)rb * a.RB;
@@ -220,12 +258,8 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
                 own[k] = (cc >= 0) && (cc < xc) && (lane >= LH) && (lane < 58);
             }
         }
-        const double *cp[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++) cp[q] = a.c[q] + m * a.sc[q];
         const double *pJ = a.c[9] + m * a.sc[9];
 
-#if XINV_BIH_REC
         // rows as 32-bit scalars (clamps on the scalar unit: 64-bit compares are VALU instructions on this target, and
         // each one a round trip VALU -> scalar unit), the lane's columns as 32-bit byte offsets: every access is
         // `uniform row base (SGPR pair) + 32-bit lane offset`, no 64-bit address arithmetic per load
@@ -250,32 +284,16 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
             }
             return t;
         };
-#else
-        typedef int64_t row_t;
-        auto load_row = [&](const double *base, int64_t r) {
-            const int64_t rr = r < 0 ? 0 : (r > yc - 1 ? yc - 1 : r);
-            const double *row = base + rr * xc;
-            Tri t;
-#pragma unroll
-            for (int k = 0; k < 3; k++) t.v[k] = row[lcol[k]];
-            return t;
-        };
-#endif
 
-#ifndef XINV_BIH_VSCAL
-#define XINV_BIH_VSCAL XINV_BIH_REC
-#endif
         // The solve's scalars in VECTOR registers (every lane the same value): with them, the records, the lane masks and
         // the row pointers in SGPRs the compiler ran out (106) and re-read kernel arguments from memory, waiting for
         // each, a dozen times per group of three rows.
         XinvScal scl = a.sc_;
-#if XINV_BIH_VSCAL
         asm("" : "+v"(scl.ratioSSr), "+v"(scl.ratioSqr), "+v"(scl.delxSqr), "+v"(scl.delxTr), "+v"(scl.ratio),
                  "+v"(scl.delxSSr), "+v"(scl.ratioQtr));
         double uv = u;
         asm("" : "+v"(uv));
 #define u uv
-#endif
         Tri W[D];
 #pragma unroll
         for (int t = 0; t < D; t++) { W[t].v[0] = 0.0; W[t].v[1] = 0.0; W[t].v[2] = 0.0; }
@@ -283,44 +301,64 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
 #pragma unroll
         for (int t = 0; t < 3; t++) Jst[t] = W[0];
 
-#if XINV_BIH_REC
         struct Rec { double cs[9]; double rq; double rok; };
         const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(a.rowf + m * yc * XINV_BIH_RW);
         // the record of row j (clamped: rows outside 2 .. yc-3 carry a zero predicate and are left alone)
+        // (VM = 2 reads nothing from it: the loads fall away)
         auto ldrec = [&](int j) {
-            const int jj = min(max(j, 0), (int)yc - 1);
-            const xinv_cdouble_ptr pr = rowf + (int64_t)jj * XINV_BIH_RW;
             Rec R;
+            if constexpr (VM == 2) {
 #pragma unroll
-            for (int q = 0; q < 9; q++) R.cs[q] = pr[q];
-            R.rq = pr[9]; R.rok = pr[10];
+                for (int q = 0; q < 9; q++) R.cs[q] = 0.0;
+                R.rq = 0.0; R.rok = 0.0;
+            } else {
+                const int jj = min(max(j, 0), (int)yc - 1);
+                const xinv_cdouble_ptr pr = rowf + (int64_t)jj * XINV_BIH_RW;
+#pragma unroll
+                for (int q = 0; q < 9; q++) R.cs[q] = pr[q];
+                R.rq = pr[9]; R.rok = pr[10];
+            }
             return R;
         };
-#endif
+        // VM > 0: the row's coefficient values at the lane's columns and its point factors, requested a group ahead of
+        // the row's update like its forcing (one request per stream and row; every value is used exactly once)
+        constexpr int NVA = NV > 0 ? NV : 1;
+        struct CoefV { Tri a[NVA]; Tri q; };
+        const double *cpv[NVA];
+        const double *pQ = nullptr;
+        if constexpr (VM > 0) {
+            constexpr int idx1[4] = {0, 2, 3, 5};            // A, C, D, F
+#pragma unroll
+            for (int t = 0; t < NV; t++) {
+                const int q = (VM == 1) ? idx1[t < 4 ? t : 0] : t;
+                cpv[t] = a.c[q] + m * a.sc[q];
+            }
+            pQ = a.q + m * yc * xc;
+        } else {
+            cpv[0] = nullptr;
+        }
+        auto ldcoef = [&](int j) {
+            CoefV v;
+            if constexpr (VM > 0) {
+#pragma unroll
+                for (int t = 0; t < NV; t++) v.a[t] = load_row(cpv[t], j);
+                v.q = load_row(pQ, j);
+            } else {
+                v.a[0] = W[0]; v.q = W[0];
+            }
+            return v;
+        };
+        // two sets live: `cvc` -- the row about to be updated -- and `cvn`, requested one update earlier for the update
+        // after it (a set per class, requested a whole group ahead like the forcing, is 90 VGPRs: A, C, D, F, Q x three
+        // columns x three classes -- the variant spilled at 256)
+        CoefV cvc, cvn;
+
         // the three column colours of row j (window slot SJ), forcing row Jt
-#if XINV_BIH_REC
-        auto upd_row = [&](auto sjtag, int, const Tri &Jt, const Rec &R) {
+        auto upd_row = [&](auto sjtag, int, const Tri &Jt, const Rec &R, const CoefV &V) {
             constexpr int SJ = decltype(sjtag)::value;
             constexpr int SM2 = (SJ + 7) % D, SM1 = (SJ + 8) % D, SP1 = (SJ + 1) % D, SP2 = (SJ + 2) % D;
             const double (&cs)[9] = R.cs;
-            const double rq = R.rq;
             const bool rowok = __double_as_longlong(R.rok) != 0;
-#else
-        auto upd_row = [&](auto sjtag, int64_t j, const Tri &Jt) {
-            constexpr int SJ = decltype(sjtag)::value;
-            constexpr int SM2 = (SJ + 7) % D, SM1 = (SJ + 8) % D, SP1 = (SJ + 1) % D, SP2 = (SJ + 2) % D;
-            if (j < 2 || j > yc - 3) return;                       // rows 0, 1, yc-2, yc-1 are never updated
-            double cs[9];
-#pragma unroll
-            for (int q = 0; q < 9; q++) cs[q] = cp[q][j * xc];     // one value per row
-            bool rowok = true;
-#pragma unroll
-            for (int q = 0; q < 9; q++) rowok = rowok && (cs[q] != u);
-            const double rq = -a.sc_.optArg / ((cs[0]*a.sc_.ratioSSr + cs[2]) * 6.0 +
-                                                 cs[1]*a.sc_.ratioSqr / 4.0 +
-                                               -(cs[3]*a.sc_.ratioSqr + cs[5]) * 2.0 * a.sc_.delxSqr +
-                                                 cs[8]*a.sc_.delxSSr);
-#endif
             double em2[7], em1[7], ep1[7], ep2[7];
             bih_ext(W[SM2], em2); bih_ext(W[SM1], em1); bih_ext(W[SP1], ep1); bih_ext(W[SP2], ep2);
             double fm2[2] = {0.0, 0.0}, fp2[2] = {0.0, 0.0};
@@ -336,15 +374,29 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
                     bih_far(W[SJ], f0[0], f0[1]);
                     if (east[k]) { p2_b = fp2[k - 1]; r0_b = f0[k - 1]; m2_b = fm2[k - 1]; }
                 }
+                // the coefficients of the point: per-row values out of the record, or the lane's own out of the streams
+                double cA, cB, cC, cD, cE, cF, cG, cH, cI, rq;
+                bool cok;
+                if constexpr (VM == 0) {
+                    cA = cs[0]; cB = cs[1]; cC = cs[2]; cD = cs[3]; cE = cs[4]; cF = cs[5]; cG = cs[6]; cH = cs[7]; cI = cs[8];
+                    rq = R.rq; cok = rowok;
+                } else if constexpr (VM == 1) {
+                    cA = V.a[0].v[k]; cC = V.a[1].v[k]; cD = V.a[2].v[k]; cF = V.a[3].v[k];
+                    cB = 0.0; cE = 0.0; cG = cs[6]; cH = cs[7]; cI = cs[8];
+                    rq = V.q.v[k]; cok = (rq != 0.0);
+                } else {
+                    cA = V.a[0].v[k]; cB = V.a[1].v[k]; cC = V.a[2].v[k]; cD = V.a[3].v[k]; cE = V.a[4].v[k];
+                    cF = V.a[5].v[k]; cG = V.a[6].v[k]; cH = V.a[7].v[k]; cI = V.a[8].v[k];
+                    rq = V.q.v[k]; cok = (rq != 0.0);
+                }
                 W[SJ].v[k] = xinv_upd_bih2d_rq<ZBE>(
                     ep2[o], ep2[o + 2], p2_b, ep1[o], ep1[o + 1], ep1[o - 1],
                     e0[o], e0[o + 1], e0[o - 1], e0[o + 2], e0[o - 2], r0_b,
                     em1[o], em1[o + 1], em1[o - 1], em2[o], em2[o + 2], m2_b,
-                    cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[7], cs[8],
-                    Jt.v[k], rq, upd[k] && rowok && (Jt.v[k] != u), edge[k], scl);
+                    cA, cB, cC, cD, cE, cF, cG, cH, cI,
+                    Jt.v[k], rq, upd[k] && cok && (Jt.v[k] != u), edge[k], scl);
             }
         };
-#if XINV_BIH_REC
         unsigned sof[3];                                     // store offsets: a column the lane does not own lies beyond the
 #pragma unroll                                               // row's range and the store is dropped (no branch)
         for (int k = 0; k < 3; k++) sof[k] = own[k] ? boff[k] : 0xffffffffu;
@@ -364,48 +416,21 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
                 cnt[0] += c ? 1 : 0;
             }
         };
-#else
-        auto retire = [&](auto stag, row_t j) {
-            constexpr int SL = decltype(stag)::value;
-            if (j < (row_t)y0 || j >= (row_t)y1) return;
-            double *row = dstS + j * xc;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double v = W[SL].v[k];
-                if (own[k]) {
-                    row[lcol[k]] = v;
-                    if (v != u) { acc[0] += fabs(v); cnt[0] += 1; }
-                }
-            }
-        };
-#endif
 
-        // Rows y0-3 .. y1+7 stream through the window three at a time.  The window is shifted by
-        // three rows per group (18 register moves against ~900 instructions of updates), so the
-        // newest row always sits in slot 8 and every slot index below is a constant: with
-        // r = base + 2 = 2 (mod 3), rows r-2 / r-4 / r-6 are slots 6 / 4 / 2 and rows r-8..r-6
-        // (slots 0..2) retire.  The next group's three rows and forcing rows are requested before
-        // the updates of this one.
-        const row_t rstart = (row_t)y0 - 3, rlast = (row_t)y1 + 7;   // row j retires by step j + 8
-#ifndef XINV_BIH_PREFETCH
-#define XINV_BIH_PREFETCH XINV_BIH_REC
-#endif
-#if XINV_BIH_PREFETCH
-        Tri N0 = load_row(srcS, rstart), N1 = load_row(srcS, rstart + 1), N2 = load_row(srcS, rstart + 2);
-#endif
-        Jst[0] = load_row(pJ, rstart + 2 - 2); Jst[1] = load_row(pJ, rstart + 2 - 4); Jst[2] = load_row(pJ, rstart + 2 - 6);
-#if XINV_BIH_REC
-        Rec R0 = ldrec(rstart + 2 - 2);
-#endif
-#ifndef XINV_BIH_ROT
-#define XINV_BIH_ROT XINV_BIH_REC
-#endif
-#if XINV_BIH_ROT
+        // Rows y0-3 .. y1+7 stream through the window three at a time; with r = base + 2 = 2 (mod 3), rows r-2 / r-4 / r-6
+        // are logical slots 6 / 4 / 2 and rows r-8..r-6 (slots 0..2) retire.  The next group's three rows are requested
+        // before the updates of this one, the forcing row (and, VM > 0, the coefficient rows) of each class right after
+        // their use.
         // The window ROTATES instead of being shifted: group g keeps logical slot s in register slot (s + 3 g) mod 9,
         // the march is unrolled three groups so that every slot is a compile-time register name, and what moves per
         // group is only the three prefetched rows into their slots (they are the slots of the rows retiring in the
-        // group before, which the class-2 update still reads).  The forcing row of each class is re-requested right
-        // after its use.  55 -> 9 register moves per group of ~600 vector instructions.
+        // group before, which the class-2 update still reads): 55 -> 9 register moves per group of ~600 vector
+        // instructions.
+        const row_t rstart = (row_t)y0 - 3, rlast = (row_t)y1 + 7;   // row j retires by step j + 8
+        Tri N0 = load_row(srcS, rstart), N1 = load_row(srcS, rstart + 1), N2 = load_row(srcS, rstart + 2);
+        Jst[0] = load_row(pJ, rstart + 2 - 2); Jst[1] = load_row(pJ, rstart + 2 - 4); Jst[2] = load_row(pJ, rstart + 2 - 6);
+        cvc = ldcoef(rstart + 2 - 2); cvn = ldcoef(rstart + 2 - 4);
+        Rec R0 = ldrec(rstart + 2 - 2);
         auto group = [&](auto phtag, row_t base) {
             constexpr int PH = decltype(phtag)::value;
 #define XINV_BIH_P(sl) std::integral_constant<int, ((sl) + 3 * PH) % D>{}
@@ -413,14 +438,17 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
             W[((6) + 3 * PH) % D] = N0; W[((7) + 3 * PH) % D] = N1; W[((8) + 3 * PH) % D] = N2;
             N0 = load_row(srcS, base + 3); N1 = load_row(srcS, base + 4); N2 = load_row(srcS, base + 5);
             const Rec R1 = ldrec(r - 4);
-            upd_row(XINV_BIH_P(6), r - 2, Jst[0], R0);          // class 0
+            upd_row(XINV_BIH_P(6), r - 2, Jst[0], R0, cvc);     // class 0
             Jst[0] = load_row(pJ, r + 3 - 2);
+            if constexpr (VM > 0) { cvc = cvn; cvn = ldcoef(r - 6); }
             const Rec R2 = ldrec(r - 6);
-            upd_row(XINV_BIH_P(4), r - 4, Jst[1], R1);          // class 1
+            upd_row(XINV_BIH_P(4), r - 4, Jst[1], R1, cvc);     // class 1
             Jst[1] = load_row(pJ, r + 3 - 4);
+            if constexpr (VM > 0) { cvc = cvn; cvn = ldcoef(r + 3 - 2); }
             R0 = ldrec(r + 3 - 2);
-            upd_row(XINV_BIH_P(2), r - 6, Jst[2], R2);          // class 2
+            upd_row(XINV_BIH_P(2), r - 6, Jst[2], R2, cvc);     // class 2
             Jst[2] = load_row(pJ, r + 3 - 6);
+            if constexpr (VM > 0) { cvc = cvn; cvn = ldcoef(r + 3 - 4); }
             retire(XINV_BIH_P(0), r - 8);
             retire(XINV_BIH_P(1), r - 7);
             retire(XINV_BIH_P(2), r - 6);
@@ -433,38 +461,6 @@ __global__ __launch_bounds__(256, XINV_BIH_MINWAVES) void k_fusedbih(FusedBihArg
             if (base + 6 > rlast) break;
             group(std::integral_constant<int, 2>{}, base + 6);
         }
-#else
-        for (row_t base = rstart; base <= rlast; base += 3) {
-            const row_t r = base + 2;
-#pragma unroll
-            for (int t = 0; t < 6; t++) W[t] = W[t + 3];
-#if XINV_BIH_PREFETCH
-            W[6] = N0; W[7] = N1; W[8] = N2;
-            const Tri J0 = Jst[0], J1 = Jst[1], J2 = Jst[2];
-            N0 = load_row(srcS, base + 3); N1 = load_row(srcS, base + 4); N2 = load_row(srcS, base + 5);
-#else
-            W[6] = load_row(srcS, base); W[7] = load_row(srcS, base + 1); W[8] = load_row(srcS, base + 2);
-            const Tri J0 = Jst[0], J1 = Jst[1], J2 = Jst[2];
-#endif
-            Jst[0] = load_row(pJ, r + 3 - 2); Jst[1] = load_row(pJ, r + 3 - 4); Jst[2] = load_row(pJ, r + 3 - 6);
-#if XINV_BIH_REC
-            // each row's record is asked for one row update (~1000 cycles of arithmetic) before it is used
-            const Rec R1 = ldrec(r - 4);
-            upd_row(std::integral_constant<int, 6>{}, r - 2, J0, R0);   // class 0
-            const Rec R2 = ldrec(r - 6);
-            upd_row(std::integral_constant<int, 4>{}, r - 4, J1, R1);   // class 1
-            R0 = ldrec(r + 3 - 2);
-            upd_row(std::integral_constant<int, 2>{}, r - 6, J2, R2);   // class 2
-#else
-            upd_row(std::integral_constant<int, 6>{}, r - 2, J0);   // class 0
-            upd_row(std::integral_constant<int, 4>{}, r - 4, J1);   // class 1
-            upd_row(std::integral_constant<int, 2>{}, r - 6, J2);   // class 2
-#endif
-            retire(std::integral_constant<int, 0>{}, r - 8);
-            retire(std::integral_constant<int, 1>{}, r - 7);
-            retire(std::integral_constant<int, 2>{}, r - 6);
-        }
-#endif
     }
 
 #undef u

@@ -135,9 +135,33 @@ static int plan_fusedbih(const Problem &p, const xinv_options &opt, Workspace *w
             HIPCHK(hipStreamSynchronize(st));
             pl.bih_zbe = (*ws->hflag == 0) && (p.sc_.undef != 0.0);
         }
+        // Where the coefficients come from (xinv_fusedbih.h): per-row records when A..I are constant along x; else the
+        // vector-stream variants (round 6): A, C, D, F as streams when only they vary (A4(x, y), R(x, y) of
+        // apps.py:1793-1836) and there are no mixed derivatives, all nine otherwise -- with the point-factor stream Q
+        // (relaxation factor, 0 = the reference's predicate forbids the update), evaluated here, once per coefficient stack.
+        pl.bih_vm = ((pl.umask & 0x1ffu) == 0x1ffu) ? 0 : ((pl.bih_zbe && (pl.umask & 0x1d2u) == 0x1d2u) ? 1 : 2);
+        if (pl.bih_vm) {
+            rc = ensure_dev(&ws->d_pfac, &ws->d_pfac_cap, (size_t)p.nbatch * p.yc * p.xc * sizeof(double));
+            if (rc) return rc;
+            PointFactorBihArgs fa;
+            memset(&fa, 0, sizeof fa);
+            for (int q = 0; q < 9; q++) { fa.c[q] = p.c[q]; fa.sc[q] = p.sc[q]; }
+            fa.yc = p.yc; fa.xc = p.xc; fa.n = p.yc * p.xc; fa.sc_ = p.sc_; fa.q = ws->d_pfac; fa.flag = ws->dflag;
+            HIPCHK(hipMemsetAsync(ws->dflag, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_point_factor_bih, dim3((unsigned)std::min<int64_t>(2048, cdiv(fa.n, 256)), (unsigned)p.nbatch, 1),
+                               dim3(256), 0, st, fa);
+            HIPCHK(hipMemcpyAsync(ws->hflag, ws->dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (*ws->hflag & 1) {                        // (a factor of exactly zero somewhere: Q == 0 could not mean "skip")
+                if (opt.path == XINV_PATH_FUSED)
+                    return fail_arg("biharmonic form: a relaxation factor of exactly zero on an updatable point -- the colour launches handle it");
+                pl.path = XINV_PATH_COLOUR;
+                return XINV_OK;
+            }
+        }
         {
             FusedBihArgs dummy; memset(&dummy, 0, sizeof dummy);
-            xinv_launch_fusedbih(false, false, dim3(1), st, dummy, &occ);
+            xinv_launch_fusedbih(false, pl.bih_zbe, pl.bih_vm, dim3(1), st, dummy, &occ);
         }
         {   // per-row records (A..I, relaxation factor, row predicate), once per solve: xinv_fusedbih.h
             rc = ensure_dev(&ws->d_rowf, &ws->d_rowf_cap, (size_t)p.nbatch * p.yc * XINV_BIH_RW * sizeof(double));
@@ -151,6 +175,11 @@ static int plan_fusedbih(const Problem &p, const xinv_options &opt, Workspace *w
         // Time of a launch ~ (steps per tile) x f(workgroups per CU).  f measured on the round-3 kernel at 2000 x 2000
         // (profiles/r03_bih_rework.txt: rows 9 .. 33): one workgroup per CU 1.0; the second costs little (the
         // wavefronts fill each other's dependency stalls): 1.2 just above one per CU, 1.35 at two; a third 1.6 .. 1.75.
+        // (the vector-stream variants, round 6, move 64 / 104 bytes per point and sweep and sit at what the fabric delivers
+        //  -- 6.4 TB/s at 2000 x 2000 whatever the tile height: a second workgroup on a CU takes as long again, so the launch
+        //  is planned in whole rounds of ONE workgroup per CU and what counts are the ten halo rows per tile: 15-row tiles
+        //  67.5 us, 24-row tiles -- 273 workgroups -- 80 us, 27-row tiles 55 us, profiles/r06_bih_vector_streams.txt)
+        const bool streams = pl.bih_vm != 0;
         auto wg_cost = [](double x) {
             if (x <= 1.0) return 1.0;
             if (x <= 2.0) return 1.15 + 0.10 * x;
@@ -161,7 +190,7 @@ static int plan_fusedbih(const Problem &p, const xinv_options &opt, Workspace *w
             if (opt.rows_per_tile > 0 && RB != std::max(3, (opt.rows_per_tile / 3) * 3)) continue;
             const int64_t nrb = cdiv(p.yc, RB);
             const int64_t wgs = (int64_t)cdiv((int64_t)nstrip * nrb, 4) * p.nbatch;
-            const int n = std::min(occ, 3);
+            const int n = streams ? 1 : std::min(occ, 3);
             const int64_t cap = 256 * (int64_t)n;
             const int64_t rounds = cdiv(wgs, cap);
             const int64_t w_last = wgs - (rounds - 1) * cap;
@@ -532,7 +561,9 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
             if (rc) return rc;
         }
         pl.um = pl.umask;
-        fusedbih_ok = ((pl.umask & 0x1ffu) == 0x1ffu) && (p.BCx != XINV_BC_PERIODIC || p.xc % 3 == 0);
+        // (coefficients that vary along x: the vector-stream variants of the one-pass kernel, xinv_fusedbih.h)
+        fusedbih_ok = (p.BCx != XINV_BC_PERIODIC || p.xc % 3 == 0) && !(opt.flags & XINV_FLAG_NO_XUNIFORM) &&
+                      p.sc_.optArg != 0.0;
     }
     // general 3-D: the fused kernel exists for x-uniform coefficients only (every 3DOcean array)
     bool fused3g_ok = false;
@@ -547,7 +578,7 @@ static int plan_path(const Problem &p, const xinv_options &opt, Workspace *ws, h
     pl.nine = false;
     if (fused_ok && opt.path != XINV_PATH_COLOUR) { pl.path = XINV_PATH_FUSED; pl.nine = fused9_ok && !fused5_ok; }
     if (opt.path == XINV_PATH_FUSED && !fused_ok)
-        return fail_arg("no fused kernel for this form (odd-xc periodic seam with xc < 64; 9-point test form; biharmonic or general 3-D with coefficients that vary along x)");
+        return fail_arg("no fused kernel for this form (odd-xc periodic seam with xc < 64; 9-point test form; biharmonic with periodic x and xc % 3 != 0; general 3-D with coefficients that vary along x)");
     if (pl.path == XINV_PATH_COLOUR && !is3d(p.kind) && !p.c[1] && pl.base == 4)
         return fail_arg("internal: 9-point form without B");
 
@@ -1222,6 +1253,7 @@ static int finalise(const Problem &p, const Plan &pl, Workspace *ws, hipStream_t
     t_stats.pipelined = (pl.path == XINV_PATH_FUSED && pl.pipe) ? pl.npair : 0;
     t_stats.lanes = R.lanes;
     t_stats.point_factor = (pl.path == XINV_PATH_FUSED && pl.pq) ? (pl.alias_ac ? 2 : 1) : 0;
+    if (pl.path == XINV_PATH_FUSED && p.kind == KIND_BIH2D) t_stats.point_factor = pl.bih_vm;
     if (pl.path == XINV_PATH_FUSED && p.kind == KIND_STD3D && pl.K2) {
         const int64_t nm = (p.nbatch * 1 / R.lanes) - (p.nbatch * 0 / R.lanes);      // (members of the first lane's launches)
         const int64_t tiles = (int64_t)pl.nsg2 * pl.nrb2 * nm;
@@ -1656,6 +1688,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &d.S);
     if (rc) return rc;
     pin.try_pin(p.S, (size_t)((p.nbatch - 1) * hsS + n) * esz_of(0));
+    pin.note_pinned(p.S, (size_t)((p.nbatch - 1) * hsS + n) * esz_of(0));
     const int64_t mmax_chunk = *std::max_element(chunks.begin(), chunks.end());
     float *tmpS_up = nullptr, *tmpS_dn = nullptr;
     if (!(opt.prep_flags & XINV_PREP_S_ZERO)) { rc = f32_tmp(0, mmax_chunk * n, &tmpS_up); if (rc) return rc; }
@@ -1694,6 +1727,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             rc = pool_alloc(pool, (size_t)n * sizeof(double), &dc);
             if (rc) return rc;
             pin.try_pin(hq, (size_t)n * esz_of(q + 1));
+            pin.note_pinned(hq, (size_t)n * esz_of(q + 1));
             rc = f32_tmp(q + 1, n, &tmpC[q]);
             if (rc) return rc;
             float *tq = tmpC[q];
@@ -1703,6 +1737,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &dc);
             if (rc) return rc;
             pin.try_pin(hq, (size_t)((p.nbatch - 1) * hst + n) * esz_of(q + 1));
+            pin.note_pinned(hq, (size_t)((p.nbatch - 1) * hst + n) * esz_of(q + 1));
             rc = f32_tmp(q + 1, mmax_chunk * n, &tmpC[q]);
             if (rc) return rc;
             d.sc[q] = n;
@@ -1984,10 +2019,12 @@ static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
     pin.flags = hipHostRegisterPortable;
     auto esz = [&](int arr) { return ((p.f32 >> arr) & 1u) ? (size_t)4 : (size_t)8; };
     pin.try_pin(p.S, (size_t)((p.nbatch - 1) * p.sS + n) * esz(0));
+    pin.note_pinned(p.S, (size_t)((p.nbatch - 1) * p.sS + n) * esz(0));
     for (int q = 0; q < p.ncoef; q++) {
         if (!p.c[q]) continue;
         const int64_t len = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
         pin.try_pin(p.c[q], (size_t)((p.sc[q] == 0 ? 0 : (p.nbatch - 1) * p.sc[q]) + len) * esz(q + 1));
+        pin.note_pinned(p.c[q], (size_t)((p.sc[q] == 0 ? 0 : (p.nbatch - 1) * p.sc[q]) + len) * esz(q + 1));
     }
     struct Result { int rc = 0; std::string err; xinv_stats st; };
     std::vector<Result> res((size_t)nd);

@@ -119,13 +119,15 @@ struct CopyPool {                                   // process-wide memcpy worke
 static CopyPool g_copy_pool;
 
 struct StageRing {                                  // pinned slots of one direction on one device
+    // (round 6, measured and not kept: eight slots of 8 MiB -- less of the first / last slot's memcpy exposed: 3600 x 1800 host
+    //  to host 8.4 -> 8.2 ms, but C5 x 15 through host pointers 160 -> 209 ms: four times the DMAs and event waits)
     static constexpr int NSLOT = 4;
     static constexpr size_t SLOT = (size_t)32 << 20;
-    char *buf[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    bool inflight[NSLOT] = {false, false, false, false};
-    char *dst[NSLOT] = {nullptr, nullptr, nullptr, nullptr};      // downloads: where the slot's bytes go on the host
-    size_t len[NSLOT] = {0, 0, 0, 0};
+    char *buf[NSLOT] = {};
+    hipEvent_t ev[NSLOT] = {};
+    bool inflight[NSLOT] = {};
+    char *dst[NSLOT] = {};                                        // downloads: where the slot's bytes go on the host
+    size_t len[NSLOT] = {};
     int next = 0;
     // Forget every slot in flight (after the stream they were queued on has been drained): an error return from a
     // staged copy must not leave `dst` / `len` pointing into that call's host array for the next call to retire.
@@ -395,12 +397,31 @@ struct Pinned {                                     // host ranges registered fo
         regs.push_back({(char *)h, bytes});
         return true;
     }
-    // [h, h + bytes) lies inside a range registered by this call (or by the parent of a per-device call): every chunk
-    // and member of a registered array copies straight out of / into the caller's memory, not only its first bytes
+    // Host arrays the CALLER allocated as pinned memory (hipHostMalloc / a framework's pinned allocator: the front end's
+    // result array comes out of torch's pinned pool, xinvert_amd/core.py): the DMA engines reach them directly, no staging
+    // copy through the library's ring.  Asked once per array (note_pinned); nothing is registered or unregistered.
+    std::vector<std::pair<char *, size_t>> native;
+    void note_pinned(const void *h, size_t bytes)
+    {
+        if (!h || bytes < (1u << 20)) return;
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        if (hipPointerGetAttributes(&at, h) != hipSuccess) { (void)hipGetLastError(); return; }   // (pageable memory: an error, cleared)
+        if (at.type != hipMemoryTypeHost) return;
+        // the allocation must cover the whole range (the last byte belongs to a pinned allocation too)
+        hipPointerAttribute_t a2;
+        memset(&a2, 0, sizeof a2);
+        if (hipPointerGetAttributes(&a2, (const char *)h + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (a2.type != hipMemoryTypeHost) return;
+        native.push_back({(char *)h, bytes});
+    }
+    // [h, h + bytes) lies inside a range registered by this call (or by the parent of a per-device call) or inside an
+    // array the caller pinned itself: every chunk and member of it copies straight out of / into the caller's memory
     bool covers(const void *h, size_t bytes) const
     {
         const char *c = (const char *)h;
         for (const auto &r : regs) if (c >= r.first && c + bytes <= r.first + r.second) return true;
+        for (const auto &r : native) if (c >= r.first && c + bytes <= r.first + r.second) return true;
         return outer ? outer->covers(h, bytes) : false;
     }
     // Every return path -- error paths included -- drains the copy streams before the ranges are

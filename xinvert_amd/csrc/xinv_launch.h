@@ -19,6 +19,8 @@ struct Plan {
     int cus;                 // compute units the planner fills (xinv_options.cu_count, or the device's)
     int64_t srowf2;          // k_pipe3d: member stride of the record table (0: shared by the batch)
     bool bih_zbe;            // biharmonic one-pass kernel: B and E identically zero (terms left out)
+    int bih_vm;              // ... where its coefficients come from: 0 per-row records (A..I constant along x), 1 A C D F
+                             // as vector streams + the point-factor stream, 2 all nine (xinv_fusedbih.h); Q in ws->d_pfac
     bool aligned;
     unsigned umask;          // fused streams whose rows are constant along x (bit = stream index)
     unsigned um;             // the kernel variant's mask (subset of umask)
@@ -346,6 +348,7 @@ static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, 
     a.force = force; a.no_ctl = no_ctl;
     a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;
     a.rowf = (const double *)ws->d_rowf;
+    a.q = pl.bih_vm ? (const double *)ws->d_pfac : nullptr;
     const size_t NBmax = (size_t)pl.nsg;
     a.psum = (unsigned long long *)ws->partials;
     if (pl.skip) {                                   // fully masked tiles are left out (plan_tile_skip)
@@ -363,7 +366,7 @@ static int launch_fusedbih(const Problem &p, const Plan &pl, const double *src, 
         a.member0 = member0 + m0;
         dim3 grid((unsigned)a.nwg + (lag_tag ? 1u : 0u), (unsigned)nm, 1), block(256, 1, 1);
         (void)block;
-        xinv_launch_fusedbih(per, pl.bih_zbe, grid, st, a, nullptr);
+        xinv_launch_fusedbih(per, pl.bih_zbe, pl.bih_vm, grid, st, a, nullptr);
     }
     HIPCHK(hipGetLastError());
     return XINV_OK;

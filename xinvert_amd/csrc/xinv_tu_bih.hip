@@ -1,21 +1,30 @@
 // xinv_tu_bih.hip -- instantiations of k_fusedbih (one-pass biharmonic kernel).
 #include "xinv_dispatch.h"
 
-int xinv_launch_fusedbih(bool per, bool zbe, dim3 grid, hipStream_t st, const FusedBihArgs &a, int *occ)
+// vm: 0 = A..I per row (records); 1 = A, C, D, F vector streams (B == E == 0: zbe); 2 = all nine vector streams
+template <int VM>
+static int launch_vm(bool per, bool zbe, dim3 grid, hipStream_t st, const FusedBihArgs &a, int *occ)
 {
     if (occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fusedbih<false, false>, 256, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fusedbih<false, VM == 1, VM>, 256, 0) != hipSuccess || n < 1) n = 1;
         *occ = n;
         return 0;
     }
     dim3 block(256, 1, 1);
-    if (zbe) {
-        if (per) hipLaunchKernelGGL((k_fusedbih<true, true>), grid, block, 0, st, a);
-        else     hipLaunchKernelGGL((k_fusedbih<false, true>), grid, block, 0, st, a);
-    } else {
-        if (per) hipLaunchKernelGGL((k_fusedbih<true, false>), grid, block, 0, st, a);
-        else     hipLaunchKernelGGL((k_fusedbih<false, false>), grid, block, 0, st, a);
+    if (zbe || VM == 1) {
+        if (per) hipLaunchKernelGGL((k_fusedbih<true, true, VM>), grid, block, 0, st, a);
+        else     hipLaunchKernelGGL((k_fusedbih<false, true, VM>), grid, block, 0, st, a);
+    } else if constexpr (VM != 1) {
+        if (per) hipLaunchKernelGGL((k_fusedbih<true, false, VM>), grid, block, 0, st, a);
+        else     hipLaunchKernelGGL((k_fusedbih<false, false, VM>), grid, block, 0, st, a);
     }
     return 0;
+}
+
+int xinv_launch_fusedbih(bool per, bool zbe, int vm, dim3 grid, hipStream_t st, const FusedBihArgs &a, int *occ)
+{
+    if (vm == 1) return launch_vm<1>(per, true, grid, st, a, occ);
+    if (vm == 2) return launch_vm<2>(per, zbe, grid, st, a, occ);
+    return launch_vm<0>(per, zbe, grid, st, a, occ);
 }

@@ -22,7 +22,13 @@ def _modes(rng, lat, lon, nmodes, kmax, lmax):
         ph, ps = rng.uniform(0, 2 * np.pi, 2)
         Y[m] = a * np.sin(np.pi * l * y + ps)
         X[m] = np.cos(k * x + ph)
-    return Y.T @ X
+    # (an explicit loop over the modes, not `Y.T @ X`: a BLAS matmul adds in an order that depends on its thread count --
+    #  torchrun sets OMP_NUM_THREADS=1 for its ranks -- and a member must hold the same bits in every process of a job:
+    #  bench.py's S_checksum_sha256 compares the fields of differently split batches)
+    out = np.zeros((lat.size, lon.size))
+    for m in range(nmodes):
+        out += Y[m][:, None] * X[m][None, :]
+    return out
 
 
 def poisson_latlon(ny, nx, mask=True, seed=SEED, BCs=('fixed', 'periodic'), members=1):
@@ -92,8 +98,10 @@ def stommel_cartesian(ny, nx, seed=SEED, varying_R=True):
                 S0=initS.values[None], coefs=list(cs) + [G.values[None]], shared=(0, 1, 2, 3, 4, 5))
 
 
-def munk_cartesian(ny, nx, seed=SEED):
-    """Config 3 (Munk branch): Stommel-Munk gyre, biharmonic form, Cartesian box."""
+def munk_cartesian(ny, nx, seed=SEED, varying=False):
+    """Config 3 (Munk branch): Stommel-Munk gyre, biharmonic form, Cartesian box.  varying=True: the lateral viscosity
+    A4(x, y) and the bottom friction R(x, y) are smooth 2-D fields (BASELINE configs[2]: "spatially-varying" coefficients:
+    A, C, D, F of the biharmonic form then vary along x)."""
     rng = np.random.default_rng(seed)
     Lx, Ly = 1e7, 2 * np.pi * 1e6
     x = np.linspace(0, Lx, nx); y = np.linspace(0, Ly, ny)
@@ -101,7 +109,12 @@ def munk_cartesian(ny, nx, seed=SEED):
     curl = -0.3 * np.sin(np.pi * yg / Ly) * np.pi / Ly * (1.0 + 0.1 * rng.standard_normal((ny, nx)))
     F = Field(curl, ('ydef', 'xdef'), {'ydef': y, 'xdef': x})
     iP = apps._update(apps.default_iParams, {'BCs': ['fixed', 'fixed']})
-    mP = dict(apps.default_mParams); mP.update({'A4': 5e2 * (151.0 / ny) ** 0, 'beta': 1.8e-11, 'R': 1e-4, 'D': 200})
+    A4, R = 5e2 * (151.0 / ny) ** 0, 1e-4
+    if varying:                                              # (drawn behind the forcing's noise: the constant case keeps its numbers)
+        sa, sr = _modes(rng, y, x, 8, 3, 3), _modes(rng, y, x, 8, 3, 3)
+        A4 = A4 * (1.0 + 0.4 * sa / np.abs(sa).max())
+        R = R * (1.0 + 0.5 * sr / np.abs(sr).max())
+    mP = dict(apps.default_mParams); mP.update({'A4': A4, 'beta': 1.8e-11, 'R': R, 'D': 200})
     J, initS, cs = apps._coeffs_StommelMunk(F, ['ydef', 'xdef'], 'cartesian', mP, iP, None)
     ps = apps._cal_params2D(y, x, 'cartesian')
     return dict(kind='bih2d', yc=ny, xc=nx, BCy='fixed', BCx='fixed', dely=ps['del2'], delx=ps['del1'],
