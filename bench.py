@@ -87,6 +87,8 @@ def parse():
     ap.add_argument('--members', type=int, default=0, help='c2: batch members per GPU (default 1); c4/c5: total batch (default 64 / 120)')
     ap.add_argument('--ny', type=int, default=1800)
     ap.add_argument('--nx', type=int, default=3600)
+    ap.add_argument('--grid', default='', help='c4: "ny,nx", c5: "nz,ny,nx" -- a reduced grid for the batched configurations '
+                                               '(tests: the REAL 8-way shard shapes, 64 -> 8 members and 120 -> 15 volumes, at a size eight ranks on one GPU can hold)')
     ap.add_argument('--mask', default='continents', choices=['continents', 'coastline', 'none'],
                     help='c2 land mask: continent-size blobs (default, SURVEY 8(d)), coastline-scale, or none')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
@@ -287,23 +289,26 @@ def build_problem(a, rank, world):
         return p, nb * world, 'weak', 'invert_Poisson %dx%d lat-lon, land/sea mask (%s), periodic-x, fixed-y (BASELINE configs[1])' % (a.nx, a.ny, a.mask)
     total = a.members or (64 if a.config == 'c4' else 120)
     lo, hi = xdist.shard_range(total, rank, world)
+    grid = [int(v) for v in a.grid.split(',')] if a.grid else None
     if a.config == 'c4':
         # every rank draws the same member list (same seed) and keeps its block
-        p = synthetic.gill_matsuno(720, 1440, total)
+        ny, nx = grid if grid else (720, 1440)
+        p = synthetic.gill_matsuno(ny, nx, total)
         p['S0'] = p['S0'][lo:hi]
         p['coefs'] = [c if k in p['shared'] else c[lo:hi] for k, c in enumerate(p['coefs'])]
-        return p, total, 'strong', 'invert_GillMatsuno 1440x720, %d forcing members (BASELINE configs[3])' % total
-    return c5_members(lo, hi), total, 'strong', 'invert_omega 720x360x50, %d time steps (BASELINE configs[4])' % total
+        return p, total, 'strong', 'invert_GillMatsuno %dx%d, %d forcing members (BASELINE configs[3])' % (nx, ny, total)
+    nz, ny, nx = grid if grid else (50, 360, 720)
+    return c5_members(lo, hi, (nz, ny, nx)), total, 'strong', 'invert_omega %dx%dx%d, %d time steps (BASELINE configs[4])' % (nx, ny, nz, total)
 
 
-def c5_members(lo, hi):
+def c5_members(lo, hi, shape=(50, 360, 720)):
     """Volumes lo..hi-1 of the 120-step omega batch.  Generated in FIXED blocks of eight steps (a 120-step forcing is
     12 GB per array on the host), block b always from seed + 8 b with eight steps, so that volume m holds the same
     numbers however the batch is split over ranks (the two-rank / one-rank flag comparison of the tests)."""
     from xinvert_amd import synthetic
     parts = []
     for b in range(lo // 8, (hi + 7) // 8):
-        q = synthetic.omega_latlon(50, 360, 720, steps=8, seed=synthetic.SEED + 8 * b)
+        q = synthetic.omega_latlon(shape[0], shape[1], shape[2], steps=8, seed=synthetic.SEED + 8 * b)
         a, e = max(lo, 8 * b) - 8 * b, min(hi, 8 * b + 8) - 8 * b
         q['S0'] = q['S0'][a:e]
         q['coefs'] = [c if k in q['shared'] else c[a:e] for k, c in enumerate(q['coefs'])]

@@ -734,3 +734,22 @@ def test_device_side_mask_scale_demask_equals_host_front_end(undef):
     Wd = xa.invert_omega(W, ['lev', 'lat', 'lon'], mParams=mP, iParams=iP)
     Wh = xa.invert_omega(W, ['lev', 'lat', 'lon'], mParams=mP, iParams=dict(iP, device_prep=False))
     assert _same(Wd.values, Wh.values) and np.abs(Wd.values[np.isfinite(Wd.values)]).max() > 0
+
+
+def test_invert_poisson_dataarray_in_dataarray_out():
+    """The front end with a DataArray-shaped forcing (a stand-in `xarray` module: the image has none): the result comes back
+    as `xarray.DataArray` named 'inverted' with the forcing's dims and coordinates (reference apps.py:1389-1392), and holds
+    the numbers the Field call gives."""
+    import xinvert_amd as xa
+    lat = np.linspace(-87.5, 87.5, 36); lon = np.arange(0., 360., 5.)
+    rng = np.random.default_rng(7)
+    vor = 1e-5 * rng.standard_normal((36, 72))
+    vor[5:9, 10:20] = np.nan
+    iP = {'BCs': ['fixed', 'periodic'], 'mxLoop': 60, 'tolerance': 1e-9, 'printInfo': False}
+    ref = xa.invert_Poisson(xa.Field(vor, ('lat', 'lon'), {'lat': lat, 'lon': lon}), ['lat', 'lon'], iParams=iP)
+    with util.xarray_standin() as xr:
+        da = xr.DataArray(vor, dims=('lat', 'lon'), coords={'lat': lat, 'lon': lon}, name='vor')
+        out = xa.invert_Poisson(da, ['lat', 'lon'], iParams=iP)
+        assert isinstance(out, xr.DataArray) and out.name == 'inverted' and out.dims == ('lat', 'lon')
+        assert np.array_equal(out.coords['lon'].values, lon)
+        assert np.array_equal(out.values, ref.values, equal_nan=True)

@@ -207,6 +207,35 @@ def test_bench_c5_two_ranks_equal_one_rank():
     assert two['n1_value'] > 0 and one['n1_value'] is None and one['rank_values'] is None
 
 
+@pytest.mark.parametrize('cfg,members,grid', [('c4', 64, '144,288'), ('c5', 120, '50,72,144')])
+def test_bench_eight_way_shard_shapes(cfg, members, grid):
+    """The REAL 8-way splits of the batched BASELINE configurations -- C4: 64 members -> 8 per rank, C5: 120 volumes -> 15
+    per rank (8.09 rounds of k_pipe3d's workgroups: the cut tail) -- as eight ranks sharing this GPU over gloo, on a reduced
+    grid: every slice's loop index / overflow flag and the checksum of its final field are, bit for bit, those of one rank
+    solving the whole batch (reference core.py:129: no cross-slice state)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    full = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        full.pop(k, None)
+    full.update(XINV_FORCE_DEVICE='0', XINV_DIST_BACKEND='gloo')
+    got = {}
+    for ng in (8, 1):
+        out = subprocess.run([sys.executable, 'bench.py', '--config', cfg, '--members', str(members), '--grid', grid, '--gpus', str(ng),
+                              '--steps', '1', '--warmup', '0', '--sweeps', '21'], capture_output=True, text=True, timeout=1500,
+                             env=full, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+        got[ng] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    eight, one = got[8], got[1]
+    assert eight['n_gpus'] == 8 and eight['scaling'] == 'strong' and eight['config']['members_total'] == members
+    assert [r['members'] for r in eight['rank_values']] == [members // 8] * 8
+    assert eight['flags_sha256'] == one['flags_sha256']
+    assert eight['S_checksum_sha256'] == one['S_checksum_sha256']
+    assert eight['rank_spread'] >= 1.0 and eight['n1_value'] > 0
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     import os
     import subprocess

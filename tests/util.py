@@ -281,3 +281,42 @@ def rel_l2(a, b, mask=None):
     if mask is not None:
         a, b = a[mask], b[mask]
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+# ------------------------------------------------------------------ a minimal `xarray` for the front end's edge
+class _StandinCoord:
+    def __init__(self, v):
+        self.values = np.asarray(v)
+
+
+class StandinDataArray:
+    """What xinvert_amd.field reads of an xarray.DataArray (from_any) and how it builds one (to_like): `values`, `dims`,
+    `coords[d].values`, `name`, and the constructor `DataArray(values, dims=..., coords=..., name=...)`."""
+
+    def __init__(self, values, dims=None, coords=None, name=None):
+        self.values = np.asarray(values)
+        self.dims = tuple(dims)
+        self.coords = {d: (c if hasattr(c, 'values') else _StandinCoord(c)) for d, c in (coords or {}).items()}
+        self.name = name
+
+
+class xarray_standin:
+    """Context manager: `import xarray` finds a module whose DataArray is StandinDataArray (xarray is not installed in the
+    build image; the real-xarray return branch of field.to_like would otherwise never execute anywhere)."""
+
+    def __enter__(self):
+        import sys
+        import types
+        self.prev = sys.modules.get('xarray')
+        m = types.ModuleType('xarray')
+        m.DataArray = StandinDataArray
+        sys.modules['xarray'] = m
+        return m
+
+    def __exit__(self, *exc):
+        import sys
+        if self.prev is None:
+            sys.modules.pop('xarray', None)
+        else:
+            sys.modules['xarray'] = self.prev
+        return False

@@ -26,12 +26,6 @@ __device__ __forceinline__ void xinv_fresh_scalar_cache()
 {
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
-#ifndef XINV_DPP_ZERO_EDGE
-#define XINV_DPP_ZERO_EDGE 1
-#endif
-#ifndef XINV_INCR_OFF
-#define XINV_INCR_OFF 1
-#endif
 
 // One control block per batch member, resident in HBM for the whole solve.  Written only by
 // the reducing workgroup of a sweep launch (fused path) or by k_norm_final (colour path);
@@ -98,9 +92,6 @@ __device__ __forceinline__ void xinv_ctl_update(XinvCtl *c, double sum, long lon
 // instructions per double instead of six dependent ds_bpermute round trips (__shfl_xor): the norm
 // partials of K fused sweeps are reduced at the very end of every wavefront, on the critical path.
 // The order of the additions is fixed (run-to-run reproducible), though not the butterfly's.
-#ifndef XINV_DPP_REDUCE
-#define XINV_DPP_REDUCE 1
-#endif
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double xinv_dpp_add(double v)
 {
@@ -112,7 +103,6 @@ __device__ __forceinline__ double xinv_dpp_add(double v)
 
 __device__ __forceinline__ double xinv_wave_sum(double v)
 {
-#if XINV_DPP_REDUCE
     v = xinv_dpp_add<0x111, 0xf>(v);       // row_shr:1
     v = xinv_dpp_add<0x112, 0xf>(v);       // row_shr:2
     v = xinv_dpp_add<0x114, 0xf>(v);       // row_shr:4
@@ -122,11 +112,6 @@ __device__ __forceinline__ double xinv_wave_sum(double v)
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
-#else
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, XINV_WAVE);
-    return v;
-#endif
 }
 
 template <int CTRL, int ROW_MASK>
@@ -139,7 +124,6 @@ __device__ __forceinline__ long long xinv_dpp_add_ll(long long v)
 
 __device__ __forceinline__ long long xinv_wave_sum_ll(long long v)
 {
-#if XINV_DPP_REDUCE
     v = xinv_dpp_add_ll<0x111, 0xf>(v);
     v = xinv_dpp_add_ll<0x112, 0xf>(v);
     v = xinv_dpp_add_ll<0x114, 0xf>(v);
@@ -149,11 +133,6 @@ __device__ __forceinline__ long long xinv_wave_sum_ll(long long v)
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)v, 63);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), 63);
     return (long long)(((unsigned long long)hi << 32) | lo);
-#else
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, XINV_WAVE);
-    return v;
-#endif
 }
 
 // Neighbour-lane moves on the VALU (DPP wave shifts, gfx9 family): no LDS round trip, unlike
@@ -162,28 +141,18 @@ __device__ __forceinline__ long long xinv_wave_sum_ll(long long v)
 __device__ __forceinline__ double xinv_lane_up(double v)       // lane i <- lane i-1
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-#if XINV_DPP_ZERO_EDGE
     // bound_ctrl: the edge lane reads 0 instead of keeping its own value, so the destination
     // needs no prior copy of the source (one v_mov_b32 less per half).  Edge lanes are halo.
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);     // wave_shr:1
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
-#else
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-#endif
     return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double xinv_lane_down(double v)     // lane i <- lane i+1
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-#if XINV_DPP_ZERO_EDGE
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);     // wave_shl:1
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
-#else
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-#endif
     return __hiloint2double(hi, lo);
 }
 

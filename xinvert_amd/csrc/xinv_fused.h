@@ -63,23 +63,7 @@ __device__ __forceinline__ bool xinv_hook_withhold(const void *hook, int T, unsi
     return false;
 #endif
 }
-#ifndef XINV_VGPR_MASK
-#define XINV_VGPR_MASK 0
-#endif
-#ifndef XINV_NORM_BRANCH
-#define XINV_NORM_BRANCH 1
-#endif
-#ifndef XINV_ROW32
-#define XINV_ROW32 0
-#endif
-#if XINV_ROW32
-typedef int row_t;                 // row counters (the grid has fewer than 2^31 rows; offsets stay 64-bit)
-#else
 typedef int64_t row_t;
-#endif
-#ifndef XINV_LOAD_EARLY
-#define XINV_LOAD_EARLY 0
-#endif
 // Stage skipping: half-sweep h of a halo row d rows outside the owned block can only reach an owned
 // row's final value if h + d <= 2K; the other half-sweep stages of the pipeline (a triangle at each
 // end of the tile, and the stages that run on empty window slots while the pipeline fills) are
@@ -88,9 +72,6 @@ typedef int64_t row_t;
 // 24 % fewer stage executions at 3600x1800, K = 4 -- and 46.3 -> 61.5 us per launch: the branches
 // cut each pipeline step into eight basic blocks, the scheduler can no longer interleave
 // independent stages, and every block boundary waits on its operands.
-#ifndef XINV_STAGE_SKIP
-#define XINV_STAGE_SKIP 0
-#endif
 
 struct FusedArgs {
     const double *src;
@@ -125,7 +106,7 @@ struct FusedArgs {
     const double *xsum;        // [nbatch] sum |S| over the skipped tiles (S != undef)
     const long long *xcnt;     // [nbatch] their sample count
     const void *rowf;          // k_pipe2d: [nbatch][yc] per-row records (M::PIPE_RW doubles each, xinv_pipe2d.h)
-    double *dbg;               // debugging builds only (XINV_PIPE_DEBUG): rows as the pipeline stages received them;
+    double *dbg;               // test-hooks build only: the hook record {tile, launch tag, member} (xinv_hook_withhold);
                                // test-hooks build (XINV_TEST_HOOKS): three ints {tile, launch tag, member} -- that tile of
                                // that launch withholds its norm partial, so that the reducer REALLY times out
 };
@@ -171,9 +152,6 @@ template <int NC, int D> struct CoefWin {
 __device__ __forceinline__ unsigned xinv_lane_word(bool b)
 {
     unsigned m = b ? ~0u : 0u;
-#if XINV_VGPR_MASK
-    asm("" : "+v"(m));
-#endif
     return m;
 }
 
@@ -344,12 +322,6 @@ struct FusedStd2DT {                // numbas.invert_standard_2D_test, B == 0 an
     }
 };
 
-#ifndef XINV_GEN_RQ_WINDOW
-#define XINV_GEN_RQ_WINDOW 1        /* general form with coefficients that vary along x: the relaxation factor of a point is
-                                       divided once, when its row enters the window, and kept there (four registers per
-                                       row) -- each of the 2K half-sweeps that touch the row then multiplies.  The variants
-                                       run one wavefront per SIMD anyway (290-360 VGPRs), so the registers cost nothing. */
-#endif
 struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
     static constexpr int NC = 6;    // A, C, D, E, F, G
     template <unsigned UM> static constexpr bool hoist() { return (UM & 0x13u) == 0x13u; }  // A, C, F uniform
@@ -378,13 +350,11 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
                  (cget<0, UM, 2>(w, s1) != u) && (cget<0, UM, 3>(w, s1) != u) && (cget<0, UM, 4>(w, s1) != u);
             by = by && (cget<1, UM, 0>(w, s1) != u) && (cget<1, UM, 1>(w, s1) != u) &&
                  (cget<1, UM, 2>(w, s1) != u) && (cget<1, UM, 3>(w, s1) != u) && (cget<1, UM, 4>(w, s1) != u);
-#if XINV_GEN_RQ_WINDOW
             // (same expression as inc()'s: same bits; every operand sits on the point itself)
             w.rqv[s1].x = sc.optArg / ((cget<0, UM, 0>(w, s1) * sc.ratioSqr + cget<0, UM, 1>(w, s1)) * 2.0
                                        - cget<0, UM, 4>(w, s1) * sc.delxSqr);
             w.rqv[s1].y = sc.optArg / ((cget<1, UM, 0>(w, s1) * sc.ratioSqr + cget<1, UM, 1>(w, s1)) * 2.0
                                        - cget<1, UM, 4>(w, s1) * sc.delxSqr);
-#endif
         }
         w.mx[s1] = xinv_lane_word(bx);
         w.my[s1] = xinv_lane_word(by);
@@ -414,9 +384,7 @@ struct FusedGen2D {                 // numbas.invert_general_2D, B == 0
             F * sC - G) * sc.delxSqr
         );
         if (hoist<UM>()) temp *= w.rq[sj];
-#if XINV_GEN_RQ_WINDOW
         else if (PRE)    temp *= comp<X>(w.rqv[sj]);     // (k_fused2d: divided once per row entry; k_pipe2d: PRE = false)
-#endif
         else             temp *= sc.optArg / ((A * sc.ratioSqr + C) * 2.0
                                               - F * sc.delxSqr);
         return temp;
@@ -920,17 +888,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     constexpr int H = 2 * K;            // halo (rows and columns) consumed by K sweeps
     // (columns owned by one wavefront: 128 - 2 H; SEAM: the ring layout's strips, xinv_tiles.h)
     constexpr int D = 2 * K + 2;        // rows held in the register window
-#ifndef XINV_PF_MODE
-#define XINV_PF_MODE 0
-#endif
-#ifndef XINV_FORCE_VGPR
-#define XINV_FORCE_VGPR 0
-#endif
-#ifdef XINV_PF_FIXED
-    constexpr int PF = (D % XINV_PF_FIXED == 0) ? XINV_PF_FIXED : 2;
-#else
-    constexpr int PF = PFD > 0 ? PFD : (XINV_PF_MODE == 0 ? 2 : ((UM != 0u) ? D : (K == 1 ? 4 : 3)));
-#endif
+    constexpr int PF = PFD > 0 ? PFD : 2;        // rows in flight
     static_assert(D % PF == 0, "prefetch depth must divide the window depth");
 
     const int64_t m = a.member0 + blockIdx.y;
@@ -948,14 +906,7 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
         const int L = blockIdx.x, q = NB >> 3, rem = NB & 7, xcd = L & 7, idx = L >> 3;
         T = xcd * q + (xcd < rem ? xcd : rem) + idx;
     }
-#ifndef XINV_WAVE_UNIFORM
-#define XINV_WAVE_UNIFORM 0
-#endif
-#if XINV_WAVE_UNIFORM
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-#else
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#endif
     int wt = T * 4 + wave;
     bool active = wt < a.nstrip * a.nrb;
     if constexpr (SEAM) {                            // (the edge strips' tiles first, four to a workgroup: xinv_heavy_first)
@@ -971,9 +922,6 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
         active = wt >= 0;
         wt = active ? wt : 0;
     }
-#if XINV_WAVE_UNIFORM
-    wt = __builtin_amdgcn_readfirstlane(wt);       // row bookkeeping on the scalar unit
-#endif
     int rb = wt / a.nstrip, strip = wt - rb * a.nstrip;
     const int64_t xc = a.xc, yc = a.yc;
     const row_t ycr = (row_t)yc;
@@ -987,12 +935,6 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
         yu0 = (row_t)((((int64_t)rb * yc) / a.nrb) & ~(int64_t)1);
         yu1 = (rb + 1 == a.nrb) ? ycr : (row_t)((((int64_t)(rb + 1) * yc) / a.nrb) & ~(int64_t)1);
     }
-#if XINV_STAGE_SKIP
-    // the tile's row range is the same for the whole wavefront: keep it (and everything derived
-    // from it -- the march counter, the stage predicates below) on the scalar unit
-    yu0 = (row_t)__builtin_amdgcn_readfirstlane((int)yu0);
-    yu1 = (row_t)__builtin_amdgcn_readfirstlane((int)yu1);
-#endif
     const double u = a.sc_.undef;
     const int UW = SEAM ? xinv_ring_uw(xc, H) : 128 - 2 * H, HW = SEAM ? xinv_ring_hw(xc, H, strip) : H;
     const int64_t xu0 = (int64_t)strip * UW;
@@ -1023,36 +965,20 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
     auto march = [&](auto smtag) {
         constexpr bool SM = decltype(smtag)::value;
         (void)SM;
-#if XINV_INCR_OFF
         // rows are requested in increasing order: keep the clamped row offset incrementally
         row_t lrow = yu0 - H;
         int64_t loff = (int64_t)(lrow < 0 ? 0 : (lrow > ycr - 1 ? ycr - 1 : lrow)) * xc;
-#endif
         auto load = [&](row_t r) {
             RowPack<NC> p;
-#if XINV_INCR_OFF
             const int64_t off = loff;
             loff += (lrow >= 0 && lrow < ycr - 1) ? xc : 0;
             lrow += 1;
             (void)r;
-#else
-            const row_t rr = r < 0 ? 0 : (r > ycr - 1 ? ycr - 1 : r);
-            const int64_t off = (int64_t)rr * xc;
-#endif
             p.s = ld2<AL>(srcS, off, lc);
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 if ((UM >> q) & 1u) {
-#if XINV_WAVE_UNIFORM == 2
-                    const double *rp = cp[q] + off;      // keep the row value a (broadcast) vector load:
-                    asm("" : "+v"(rp));                  // in order with the others on vmcnt
-                    double t = *rp;
-#else
                     double t = cp[q][off];               // scalar load: one value per row
-#endif
-#if XINV_FORCE_VGPR
-                    asm volatile("" : "+v"(t));          // held in a VGPR pair: SGPRs are scarcer here
-#endif
                     p.cs[q] = t; p.c[q] = make_double2(0.0, 0.0);
                 }
                 else                { p.c[q] = ld2<AL>(cp[q], off, lcc); p.cs[q] = 0.0; }
@@ -1118,10 +1044,6 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                         if (ja == 1) fused_extend_fix(sw[sjm], sw[sj], lc, a.tall, u);
                         if (ja == ycr - 2) fused_extend_fix(sw[sjp], sw[sj], lc, a.tall, u);
                     }
-#if XINV_STAGE_SKIP
-                    const row_t da = (yu0 - ja > ja - (yu1 - 1)) ? yu0 - ja : ja - (yu1 - 1);
-                    if (da <= 2 * K - (2 * s - 1) && ja >= 1 && ja <= ycr - 2)
-#endif
                     if constexpr (!SM) {
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
@@ -1136,10 +1058,6 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                 {   // black half-sweep of sweep s on row jb = r-2s
                     const row_t jb = r - 2 * s;
                     const int sj = SLOT(2 * s), sjp = SLOT(2 * s - 1), sjm = SLOT(2 * s + 1);
-#if XINV_STAGE_SKIP
-                    const row_t db = (yu0 - jb > jb - (yu1 - 1)) ? yu0 - jb : jb - (yu1 - 1);
-                    if (db <= 2 * K - 2 * s && jb >= 1 && jb <= ycr - 2)
-#endif
                     if constexpr (!SM) {
                     double w, e;
                     row_neighbours<X>(sw[sj], w, e);
@@ -1151,7 +1069,6 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                         seam_half(sj, sjp, sjm);
                     }
                     // row jb now holds sweep s: its share of mean|S| (branch-free)
-#if XINV_NORM_BRANCH
                     if ((jb >= yu0) && (jb < yu1)) {           // wave-uniform: an owned row
                         const double2 t = sw[sj];
                         const bool cx = lc.use_x & (t.x != u);
@@ -1160,15 +1077,6 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
                         acc[s - 1] += (cy ? fabs(t.y) : 0.0);
                         cnt[s - 1] += (cx ? 1 : 0) + (cy ? 1 : 0);
                     }
-#else
-                    const bool rowin = (jb >= yu0) && (jb < yu1);
-                    const double2 t = sw[sj];
-                    const bool cx = rowin && lc.use_x && (t.x != u);
-                    const bool cy = rowin && lc.use_y && (t.y != u);
-                    acc[s - 1] += (cx ? fabs(t.x) : 0.0);
-                    acc[s - 1] += (cy ? fabs(t.y) : 0.0);
-                    cnt[s - 1] += (cx ? 1 : 0) + (cy ? 1 : 0);
-#endif
                 }
             }
             const row_t jo = r - 2 * K;                  // row leaving the pipeline
@@ -1196,13 +1104,8 @@ __global__ __launch_bounds__(256, XINV_MINWAVES) void k_fused2d(FusedArgs a)
             xinv_unroll_steps([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
                 enter(pf[U % PF], utag);
-#if XINV_LOAD_EARLY
-                pf[U % PF] = load(rb_ + U + PF);
-                step(rb_ + U, utag);
-#else
                 step(rb_ + U, utag);
                 pf[U % PF] = load(rb_ + U + PF);
-#endif
             }, std::make_integer_sequence<int, D>{});
         }
     };

@@ -201,6 +201,55 @@ static int stage_d2h(StageRing &r, hipStream_t s, double *host, const double *de
     return XINV_OK;
 }
 
+// ------------------------------------------------------------------ NUMA placement of a device's host threads
+// In-process multi-GPU (xinv_options.ndev > 1): the host thread that drives a GPU -- and the uploader / downloader threads
+// it starts, which inherit its affinity, and the pinned staging rings they allocate (first touch) -- is bound to the CPUs of
+// the NUMA node the GPU hangs off (sysfs: /sys/bus/pci/devices/<bus id>/numa_node -> /sys/devices/system/node/nodeN/cpulist),
+// so that eight GPUs' staging copies do not all run out of one socket's memory.  Best effort: no sysfs entry, node -1 or a
+// cpulist that does not parse leave the thread where it is.  Returns the node, or -1.
+#include <sched.h>
+static int bind_thread_to_device_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    if (node < 0) return -1;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return -1;
+    char list[4096] = {0};
+    const bool got = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!got) return -1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int count = 0;
+    char *save = nullptr;                                 // (several device threads parse at once: strtok_r)
+    for (char *tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {     // "0-63,128-191"
+        int a = -1, b = -1;
+        if (sscanf(tok, "%d-%d", &a, &b) == 2) { for (int c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0) { CPU_SET(c, &set); count++; } }
+        else if (sscanf(tok, "%d", &a) == 1 && a >= 0 && a < CPU_SETSIZE) { CPU_SET(a, &set); count++; }
+    }
+    if (count == 0) return -1;
+    // (only CPUs the process may run on: a cgroup / taskset restriction of the caller stays in force)
+    cpu_set_t cur;
+    CPU_ZERO(&cur);
+    if (sched_getaffinity(0, sizeof cur, &cur) == 0) {
+        cpu_set_t both;
+        CPU_AND(&both, &set, &cur);
+        if (CPU_COUNT(&both) == 0) return -1;
+        set = both;
+    }
+    return sched_setaffinity(0, sizeof set, &set) == 0 ? node : -1;
+}
+
 // ------------------------------------------------------------------ per-device workspace
 // Grown on demand, reused across solves (no hipMalloc in steady state).
 #define XINV_MAX_LANES 4

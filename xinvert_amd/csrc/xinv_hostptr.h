@@ -1,0 +1,564 @@
+// xinv_hostptr.h -- the host-pointer entries of libxinv_hip.so: upload -> solve -> download pipelined over member
+// chunks (uploader / downloader threads through the library's pinned staging rings, two chunk solves in flight),
+// and the in-call split of the batch axis over several GPUs (one host thread per device, bound to the GPU's NUMA
+// node).  Included by xinv_hip.hip only, after xinv_sweep.h.
+#pragma once
+
+// ------------------------------------------------------------------ the solve (host ptrs)
+// One device: upload -> solve -> download, pipelined over chunks of members on three streams.
+// Every upload is queued at once on the `up` stream (shared coefficient arrays first, then S and
+// the per-member arrays chunk by chunk, an event after each chunk); the solve of chunk c waits only
+// for ITS event, so chunk c+1 travels while chunk c sweeps, and the download of chunk c (queued on
+// the `down` stream when its solve returns) overlaps the sweeps of chunk c+1.  Both DMA directions
+// and the CUs are busy at once; what stays exposed is the first chunk's upload and the last
+// chunk's download.  Members are independent (reference core.py:129: no cross-slice state), so the
+// chunking cannot change any result.
+struct HostEvents {                                   // destroyed on every return path
+    std::vector<hipEvent_t> e;
+    ~HostEvents() { for (auto x : e) if (x) (void)hipEventDestroy(x); }
+    int make(hipEvent_t *out, bool timing)
+    {
+        hipEvent_t x = nullptr;
+        HIPCHK(timing ? hipEventCreate(&x) : hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        e.push_back(x);
+        *out = x;
+        return XINV_OK;
+    }
+};
+
+// Member chunks of the upload / solve / download pipeline: sizes in members, in batch order.
+// Chunking hides PCIe time behind sweeps (chunk c+1 travels and chunk c-1 returns while chunk c sweeps) but
+// costs twice: every chunk repeats the once-per-solve detection / planning passes (~0.5 ms), and a chunk fills
+// the 256 CUs less evenly than the whole batch (the 3-D kernels run ceil(workgroups / 256) rounds of one
+// workgroup per CU).
+static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &opt)
+{
+    const int64_t nb = p.nbatch;
+    std::vector<int64_t> out;
+    if (nb <= 1) { out.push_back(nb); return out; }
+    if (opt.host_chunk > 0) {
+        const int64_t mc = std::min<int64_t>(opt.host_chunk, nb);
+        for (int64_t m0 = 0; m0 < nb; m0 += mc) out.push_back(std::min(mc, nb - m0));
+        return out;
+    }
+    const int64_t n = p.zc * p.yc * p.xc;
+    int per_member = 1;                                   // S
+    for (int q = 0; q < p.ncoef; q++) per_member += (p.c[q] && p.sc[q] != 0 && !((p.rowconst >> q) & 1u)) ? 1 : 0;
+    const double member_bytes = (double)n * 8.0 * per_member;
+    const double total = member_bytes * (double)nb;
+    // Round 5: TWO chunk solves are in flight on the device at a time (solve_host_one), so the holes a small chunk leaves
+    // on the 256 CUs are filled by its neighbour's launches, and what remains to be minimised is the exposed first
+    // upload / last download against the fixed cost of a chunk (~0.5 ms of planning, launches of few workgroups).
+    // Measured (profiles/r05_host_pipeline.txt): C5, 15 volumes -- 1 chunk 212 ms, [4, 7, 4] (round 4's split) 172,
+    // chunks of 2 volumes 161, of 1 volume 200; C4, 8 members -- 1 chunk 15.4 ms, chunks of 2 members 14.1, of 1: 17.2.
+    if (total < 100663296.0 || nb < 4) { out.push_back(nb); return out; }
+    if (is3d(p.kind)) {                                   // up to eight chunks of at least two volumes, the remainder LAST
+        const int64_t nch = std::min<int64_t>(8, (nb + 1) / 2), per = (nb + nch - 1) / nch;
+        for (int64_t m0 = 0; m0 < nb; m0 += per) out.push_back(std::min(per, nb - m0));
+        return out;
+    }
+    const int64_t nch = std::min<int64_t>(std::min<int64_t>(4, nb / 2), std::max<int64_t>(2, (int64_t)((total + 33554431.0) / 33554432.0)));
+    for (int64_t c = 0; c < nch; c++) out.push_back(nb / nch + (c < nb % nch ? 1 : 0));
+    return out;
+}
+
+// One device: upload -> solve -> download, pipelined over member chunks by three actors:
+//   the UPLOADER thread stages every upload through the library's pinned ring (xinv_host.h) in batch order --
+//     shared coefficient arrays first, then S and the per-member arrays chunk by chunk, an event after each chunk;
+//   the CALLING thread solves chunk c as soon as its event is recorded (the compute stream waits for it);
+//   the DOWNLOADER thread brings each solved chunk's S back through its own ring.
+// Both DMA directions and the CUs are busy at once; what stays exposed is the first chunk's upload and the
+// last chunk's download.  Members are independent (reference core.py:129: no cross-slice state), so the
+// chunking cannot change any result.
+struct HostActors {                                   // joins the helper threads and drains the streams on EVERY return path
+    std::thread up, down, solver2;                    // (solver2: the odd chunks' solves, beside the calling thread's)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> chunk_ready;                    // set by the uploader once chunk c's event is recorded
+    std::deque<std::function<int()>> dq;              // download jobs
+    bool d_closed = false, abort = false;
+    int u_rc = 0, d_rc = 0, s2_rc = 0;                // (s2: the helper solver thread's verdict -- kept here: this object
+    std::string u_err, d_err, s2_err;                 //  outlives the thread on every return path)
+    std::vector<hipStream_t> streams;
+    void close_downloads() { { std::lock_guard<std::mutex> lk(mu); d_closed = true; } cv.notify_all(); }
+    ~HostActors()
+    {
+        { std::lock_guard<std::mutex> lk(mu); abort = true; d_closed = true; }
+        cv.notify_all();
+        if (solver2.joinable()) solver2.join();       // (before the downloader: it still queues download jobs)
+        if (up.joinable()) up.join();
+        if (down.joinable()) down.join();
+        for (hipStream_t s : streams) (void)hipStreamSynchronize(s);      // nothing of this call stays in flight
+    }
+};
+
+static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, const Pinned *outer)
+{
+    const bool may_register = (outer == nullptr);     // a per-device call of a multi-device solve uses the parent's registrations
+    const auto wall0 = std::chrono::steady_clock::now();
+    DeviceGuard dg;
+    HIPCHK(dg.select(opt.device));
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    const int64_t n = p.zc * p.yc * p.xc;
+    // the staging rings, the device pool and the solver workspace are per device: hold the device for the whole
+    // upload -> solve -> download sequence
+    Workspace *ws = get_ws(device);
+    std::lock_guard<std::recursive_mutex> host_lock(ws->busy);
+    for (hipStream_t *sp : { &ws->s_up, &ws->s_down, &ws->s_compute })
+        if (!*sp) HIPCHK(hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+    hipStream_t sup = ws->s_up, sdn = ws->s_down, scp = ws->s_compute;
+    DevPool *pool = get_pool(device);
+    pool->reset();
+    g_copy_pool.start();
+    Pinned pin;                                       // opt-in registration of the caller's arrays (off by default)
+    pin.enabled = may_register && (Pinned::env_allowed() || (opt.flags & XINV_FLAG_PIN_HOST));
+    pin.outer = outer;
+    pin.streams = { sup, sdn, scp };
+    // a previous call that returned on an error may have left slots of the staging rings marked in flight, with
+    // `dst` pointing into ITS host array: drain the (normally idle) copy streams and forget them
+    HIPCHK(hipStreamSynchronize(sup));
+    HIPCHK(hipStreamSynchronize(sdn));
+    ws->ring_up.reset();
+    ws->ring_down.reset();
+    HostEvents ev;
+    hipEvent_t e_up0, e_up1, e_dn0, e_dn1;
+    int rc;
+    if ((rc = ev.make(&e_up0, true)) || (rc = ev.make(&e_up1, true)) || (rc = ev.make(&e_dn0, true)) ||
+        (rc = ev.make(&e_dn1, true))) return rc;
+
+    const int64_t hsS = p.nbatch > 1 ? p.sS : n;
+    const std::vector<int64_t> chunks = host_chunks(p, opt);
+    const int64_t nchunk = (int64_t)chunks.size();
+    std::vector<int64_t> first((size_t)nchunk + 1, 0);
+    for (int64_t c = 0; c < nchunk; c++) first[(size_t)c + 1] = first[(size_t)c] + chunks[(size_t)c];
+
+    // ---- device buffers now; what travels is queued for the uploader ----------------------------
+    std::vector<std::function<int()>> shared_ops;     // before the first chunk
+    std::vector<std::vector<std::function<int()>>> chunk_ops((size_t)nchunk);
+    // host range -> device, `members` pieces of `len` elements of `esz` bytes (host stride hstride, device stride len)
+    auto h2d_raw = [&](void *dev, const void *host, int64_t members, int64_t hstride, int64_t len, int esz) -> int {
+        auto one = [&](char *d, const char *h, size_t bytes) -> int {
+            if (pin.covers(h, bytes)) {                // registered in place: the DMA reads the caller's memory
+                HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, sup));
+                return XINV_OK;
+            }
+            return stage_h2d(ws->ring_up, sup, (double *)d, (const double *)h, bytes);
+        };
+        char *dv = (char *)dev; const char *hs = (const char *)host;
+        if (members == 1 || hstride == len) return one(dv, hs, (size_t)members * len * esz);
+        for (int64_t m = 0; m < members; m++) {
+            int r = one(dv + (size_t)m * len * esz, hs + (size_t)m * hstride * esz, (size_t)len * esz);
+            if (r) return r;
+        }
+        return XINV_OK;
+    };
+    // float64 host array, or (tmp != nullptr) a float32 one: uploaded as it is -- half the bytes over PCIe -- into
+    // `tmp` and promoted on the device (exact), in stream order
+    auto h2d = [&](double *dev, const double *host, int64_t members, int64_t hstride, int64_t len, float *tmp = nullptr) -> int {
+        if (!tmp) return h2d_raw(dev, host, members, hstride, len, 8);
+        int r = h2d_raw(tmp, host, members, hstride, len, 4);
+        if (r) return r;
+        const int64_t cnt = members * len;
+        hipLaunchKernelGGL(k_promote_f32, dim3((unsigned)std::min<int64_t>(4096, (cnt + 255) / 256)), dim3(256), 0, sup,
+                           (const float *)tmp, dev, cnt);
+        return XINV_OK;
+    };
+    auto is_f32 = [&](int arr) { return ((p.f32 >> arr) & 1u) != 0; };       // arr: 0 = S, q + 1 = coefficient q
+    auto esz_of = [&](int arr) { return is_f32(arr) ? (size_t)4 : (size_t)8; };
+    // (scratch for the float32 uploads: one buffer per array, as large as its largest piece; pieces follow each other
+    //  in stream order on `sup`, so the buffer is free again when the next one lands)
+    auto f32_tmp = [&](int arr, int64_t elems, float **out) -> int {
+        *out = nullptr;
+        if (!is_f32(arr)) return XINV_OK;
+        double *t;
+        int r = pool_alloc(pool, (size_t)elems * sizeof(float), &t);
+        if (r) return r;
+        *out = (float *)t;
+        return XINV_OK;
+    };
+    Problem d = p;
+    d.rowconst = 0;
+    d.sS = n;
+    rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &d.S);
+    if (rc) return rc;
+    pin.try_pin(p.S, (size_t)((p.nbatch - 1) * hsS + n) * esz_of(0));
+    pin.note_pinned(p.S, (size_t)((p.nbatch - 1) * hsS + n) * esz_of(0));
+    const int64_t mmax_chunk = *std::max_element(chunks.begin(), chunks.end());
+    float *tmpS_up = nullptr, *tmpS_dn = nullptr;
+    if (!(opt.prep_flags & XINV_PREP_S_ZERO)) { rc = f32_tmp(0, mmax_chunk * n, &tmpS_up); if (rc) return rc; }
+    rc = f32_tmp(0, p.nbatch * n, &tmpS_dn);             // (downloads trail the solves: every chunk its own piece)
+    if (rc) return rc;
+    bool per_member[10];
+    float *tmpC[10];
+    for (int q = 0; q < p.ncoef; q++) {
+        per_member[q] = false; tmpC[q] = nullptr;
+        if (!p.c[q]) { d.c[q] = nullptr; d.sc[q] = 0; continue; }
+        const int64_t hst = p.nbatch > 1 ? p.sc[q] : 0;
+        const double *hq = p.c[q];
+        double *dc;
+        if ((p.rowconst >> q) & 1u) {                 // one value per row: upload rows, expand on the device
+            const int64_t rows = p.zc * p.yc;
+            const int64_t members = (hst == 0) ? 1 : p.nbatch;
+            double *drow;
+            rc = pool_alloc(pool, (size_t)members * rows * sizeof(double), &drow);
+            if (rc) return rc;
+            rc = pool_alloc(pool, (size_t)members * n * sizeof(double), &dc);
+            if (rc) return rc;
+            rc = f32_tmp(q + 1, members * rows, &tmpC[q]);
+            if (rc) return rc;
+            float *tq = tmpC[q];
+            const int64_t xc = p.xc;
+            shared_ops.push_back([=, &h2d]() -> int {
+                int r = h2d(drow, hq, members, hst, rows, tq);
+                if (r) return r;
+                hipLaunchKernelGGL(k_expand_rows, dim3(cdiv(rows * members, 4)), dim3(256), 0, sup,
+                                   (const double *)drow, dc, rows, xc, members);
+                return XINV_OK;
+            });
+            d.sc[q] = (hst == 0) ? 0 : n;
+            d.known_um |= 1u << q;                    // (expanded from one value per row: constant along x by construction)
+        } else if (hst == 0) {
+            rc = pool_alloc(pool, (size_t)n * sizeof(double), &dc);
+            if (rc) return rc;
+            pin.try_pin(hq, (size_t)n * esz_of(q + 1));
+            pin.note_pinned(hq, (size_t)n * esz_of(q + 1));
+            rc = f32_tmp(q + 1, n, &tmpC[q]);
+            if (rc) return rc;
+            float *tq = tmpC[q];
+            shared_ops.push_back([=, &h2d]() -> int { return h2d(dc, hq, 1, 0, n, tq); });
+            d.sc[q] = 0;
+        } else {                                      // per member: travels with its chunk
+            rc = pool_alloc(pool, (size_t)p.nbatch * n * sizeof(double), &dc);
+            if (rc) return rc;
+            pin.try_pin(hq, (size_t)((p.nbatch - 1) * hst + n) * esz_of(q + 1));
+            pin.note_pinned(hq, (size_t)((p.nbatch - 1) * hst + n) * esz_of(q + 1));
+            rc = f32_tmp(q + 1, mmax_chunk * n, &tmpC[q]);
+            if (rc) return rc;
+            d.sc[q] = n;
+            per_member[q] = true;
+        }
+        d.c[q] = dc;
+    }
+    // front-end passes on the device (xinv_options.prep_flags): the forcing is the last array
+    const int fq = p.ncoef - 1;
+    const bool do_prep = (opt.prep_flags & (XINV_PREP_MASK_NAN | XINV_PREP_MASK_VALUE)) != 0;
+    double *d_rowscale = nullptr;
+    if (do_prep && (opt.prep_flags & XINV_PREP_ROWSCALE)) {
+        if (!opt.prep_rowscale) return fail_arg("XINV_PREP_ROWSCALE without prep_rowscale");
+        rc = pool_alloc(pool, (size_t)p.yc * sizeof(double), &d_rowscale);
+        if (rc) return rc;
+        const double *hrs = opt.prep_rowscale;
+        const int64_t yc = p.yc;
+        shared_ops.push_back([=, &h2d]() -> int { return h2d(d_rowscale, hrs, 1, 0, yc); });
+    }
+    const int prep_nan = (opt.prep_flags & XINV_PREP_MASK_NAN) ? 1 : 0;
+    const double prep_undef = opt.prep_undef, undef_tmp = p.sc_.undef;
+    const int64_t pyc = p.yc, pxc = p.xc;
+    auto prep_forcing = [=](double *dF, int64_t nelem) {
+        const unsigned nblk = (unsigned)std::min<int64_t>(4096, (nelem + 255) / 256);
+        hipLaunchKernelGGL(k_prep_forcing, dim3(nblk), dim3(256), 0, sup, dF, nelem, pyc, pxc, (const double *)d_rowscale,
+                           prep_nan, prep_undef, undef_tmp);
+    };
+    if (do_prep && !per_member[fq]) {
+        double *dF = const_cast<double *>(d.c[fq]);
+        shared_ops.push_back([=]() -> int { prep_forcing(dF, n); return XINV_OK; });      // one shared forcing
+    }
+    std::vector<hipEvent_t> e_chunk((size_t)nchunk);
+    for (int64_t c = 0; c < nchunk; c++) {
+        const int64_t m0 = first[(size_t)c], nm = chunks[(size_t)c];
+        if ((rc = ev.make(&e_chunk[(size_t)c], false))) return rc;
+        auto &ops = chunk_ops[(size_t)c];
+        double *dS = d.S;
+        const double *hS = p.S;
+        if (opt.prep_flags & XINV_PREP_S_ZERO)
+            ops.push_back([=]() -> int { HIPCHK(hipMemsetAsync(dS + m0 * n, 0, (size_t)nm * n * sizeof(double), sup)); return XINV_OK; });
+        else
+            ops.push_back([=, &h2d]() -> int {
+                return h2d(dS + m0 * n, (const double *)((const char *)hS + (size_t)m0 * hsS * (tmpS_up ? 4 : 8)), nm, hsS, n, tmpS_up);
+            });
+        for (int q = 0; q < p.ncoef; q++)
+            if (per_member[q]) {
+                double *dq_ = const_cast<double *>(d.c[q]);
+                const double *hq = p.c[q];
+                const int64_t hst = p.sc[q];
+                const bool prep_here = do_prep && q == fq;
+                float *tq = tmpC[q];
+                ops.push_back([=, &h2d]() -> int {
+                    int r = h2d(dq_ + m0 * n, (const double *)((const char *)hq + (size_t)m0 * hst * (tq ? 4 : 8)), nm, hst, n, tq);
+                    if (r) return r;
+                    if (prep_here) prep_forcing(dq_ + m0 * n, nm * n);
+                    return XINV_OK;
+                });
+            }
+    }
+
+    // ---- the actors -----------------------------------------------------------------------------
+    HostActors act;
+    act.streams = { sup, sdn, scp };
+    act.chunk_ready.assign((size_t)nchunk, 0);
+    act.up = std::thread([&]() {
+        int r = (hipSetDevice(device) == hipSuccess) ? XINV_OK : XINV_ERR_HIP;
+        auto run = [&](std::vector<std::function<int()>> &ops) {
+            for (auto &f : ops) {
+                { std::lock_guard<std::mutex> lk(act.mu); if (act.abort) r = r ? r : XINV_ERR_HIP; }
+                if (r) return;
+                try { r = f(); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
+            }
+        };
+        if (!r && hipEventRecord(e_up0, sup) != hipSuccess) r = XINV_ERR_HIP;
+        if (!r) run(shared_ops);
+        for (int64_t c = 0; c < nchunk; c++) {
+            if (!r) run(chunk_ops[(size_t)c]);
+            if (!r && hipEventRecord(e_chunk[(size_t)c], sup) != hipSuccess) r = XINV_ERR_HIP;
+            if (!r && c == nchunk - 1 && hipEventRecord(e_up1, sup) != hipSuccess) r = XINV_ERR_HIP;
+            { std::lock_guard<std::mutex> lk(act.mu); act.chunk_ready[(size_t)c] = 1; if (r) { act.u_rc = r; act.u_err = t_err; } }
+            act.cv.notify_all();
+        }
+    });
+    act.down = std::thread([&]() {
+        int r = (hipSetDevice(device) == hipSuccess) ? XINV_OK : XINV_ERR_HIP;
+        bool first_job = true;
+        for (;;) {
+            std::function<int()> job;
+            {
+                std::unique_lock<std::mutex> lk(act.mu);
+                act.cv.wait(lk, [&] { return act.d_closed || !act.dq.empty(); });
+                if (act.dq.empty()) break;
+                job = std::move(act.dq.front()); act.dq.pop_front();
+                if (act.abort) continue;
+            }
+            if (r) continue;
+            if (first_job) { if (hipEventRecord(e_dn0, sdn) != hipSuccess) r = XINV_ERR_HIP; first_job = false; }
+            if (!r) { try { r = job(); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; } }
+        }
+        if (!r && first_job && hipEventRecord(e_dn0, sdn) != hipSuccess) r = XINV_ERR_HIP;
+        if (!r && hipEventRecord(e_dn1, sdn) != hipSuccess) r = XINV_ERR_HIP;
+        if (!r && hipStreamSynchronize(sdn) != hipSuccess) r = XINV_ERR_HIP;
+        std::lock_guard<std::mutex> lk(act.mu);
+        act.d_rc = r; if (r) act.d_err = t_err;
+    });
+
+    // ---- solve chunk by chunk; downloads trail on their own thread ------------------------------
+    // Two chunk solves are in flight at a time (round 5): the even chunks on the calling thread (the device's workspace),
+    // the odd ones on a helper thread with a workspace and a compute stream of its own.  A chunk fills the 256 CUs less
+    // evenly than the whole batch -- the 3-D kernels run ceil(workgroups / 256) rounds, every 2-D launch ends with a
+    // tail --; with the next chunk's launches already queued on the device those holes are filled, as the two launch
+    // chains of a device-resident batch fill each other's (the lanes of run_sweeps).
+    Workspace *ws1 = (nchunk > 1) ? get_ws(device, 1) : nullptr;
+    hipStream_t scp1 = nullptr;
+    if (ws1) {
+        if (!ws1->s_compute) HIPCHK(hipStreamCreateWithFlags(&ws1->s_compute, hipStreamNonBlocking));
+        scp1 = ws1->s_compute;
+        act.streams.push_back(scp1);
+    }
+    // the workspaces grow on demand: size them for the LARGEST chunk now, so that a later, larger chunk does not pay a
+    // free + malloc of the ping-pong buffer (or of the pinned control-block mirror) mid-pipeline
+    {
+        const int64_t mmax = *std::max_element(chunks.begin(), chunks.end());
+        if (nchunk > 1 && p.kind != KIND_BIH2D)
+            for (Workspace *w : { ws, ws1 }) {
+                if ((rc = ensure_dev(&w->S2, &w->S2_cap, (size_t)mmax * n * sizeof(double)))) return rc;
+                if ((rc = ensure_dev(&w->ctl, &w->ctl_cap, (size_t)mmax * sizeof(XinvCtl)))) return rc;
+                if (w->hctl_cap < (size_t)mmax) {
+                    if (w->hctl) HIPCHK(hipHostFree(w->hctl));
+                    w->hctl = nullptr; w->hctl_cap = 0;
+                    HIPCHK(hipHostMalloc((void **)&w->hctl, 2 * (size_t)mmax * sizeof(XinvCtl), XINV_HOST_COHERENT));
+                    w->hctl_cap = (size_t)mmax;
+                }
+            }
+    }
+    xinv_stats acc;
+    memset(&acc, 0, sizeof acc);
+    bool acc_set = false;
+    unsigned shared_um = 0;
+    xinv_options o1 = opt;
+    o1.device = device; o1.ndev = 0;
+    // one chunk: wait for its upload, solve it on `cs` (workspace `slot`), run the output passes, hand it to the downloader
+    auto do_chunk = [&](int64_t c, hipStream_t cs, int slot) -> int {
+        const int64_t m0 = first[(size_t)c], nm = chunks[(size_t)c];
+        {
+            std::unique_lock<std::mutex> lk(act.mu);
+            act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)c] != 0 || act.abort; });
+            if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
+            if (act.abort) { t_err = "host-pointer solve aborted"; return XINV_ERR_HIP; }
+        }
+        HIPCHK(hipStreamWaitEvent(cs, e_chunk[(size_t)c], 0));
+        Problem dc = d;
+        { std::lock_guard<std::mutex> lk(act.mu); dc.known_um |= shared_um; }     // (what an earlier chunk's plan found out)
+        dc.nbatch = nm;
+        dc.S = d.S + m0 * n;
+        for (int q = 0; q < p.ncoef; q++)
+            if (d.c[q] && d.sc[q] != 0) dc.c[q] = d.c[q] + m0 * d.sc[q];
+        int r = solve_dev(dc, flags + 3 * m0, &o1, cs, slot);
+        if (r) return r;
+        {
+            std::lock_guard<std::mutex> lk(act.mu);
+            for (int q = 0; q < p.ncoef; q++)            // shared arrays found constant along x: the same for every chunk
+                if (d.c[q] && d.sc[q] == 0 && ((t_detected_um >> q) & 1u)) shared_um |= 1u << q;
+            if (!acc_set) { acc = t_stats; acc_set = true; }
+            else {
+                acc.sweep_launches += t_stats.sweep_launches;
+                acc.sweeps_max = std::max(acc.sweeps_max, t_stats.sweeps_max);
+                acc.sweep_ms += t_stats.sweep_ms;
+                acc.recovered_members += t_stats.recovered_members;
+            }
+        }
+        // solve_dev has returned: the chunk's S is final on the device
+        if (opt.prep_flags & XINV_PREP_DEMASK) {
+            for (int64_t m = 0; m < nm; m++) {
+                const double *dF = d.c[fq] + (per_member[fq] ? (m0 + m) * n : 0);
+                hipLaunchKernelGGL(k_demask, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, cs,
+                                   d.S + (m0 + m) * n, dF, n, p.sc_.undef, opt.demask_value);
+            }
+            HIPCHK(hipStreamSynchronize(cs));
+        }
+        if (tmpS_dn) {                                   // float32 S: rounded on the device, half the bytes back
+            hipLaunchKernelGGL(k_demote_f64, dim3((unsigned)std::min<int64_t>(4096, (nm * n + 255) / 256)), dim3(256), 0, cs,
+                               (const double *)(d.S + m0 * n), tmpS_dn + m0 * n, nm * n);
+            HIPCHK(hipStreamSynchronize(cs));
+        }
+        {
+            char *hS = (char *)p.S;
+            const char *dS = tmpS_dn ? (const char *)tmpS_dn : (const char *)d.S;
+            const size_t es = tmpS_dn ? 4 : 8;
+            const Pinned *pinp = &pin;
+            std::lock_guard<std::mutex> lk(act.mu);
+            act.dq.push_back([=]() -> int {
+                auto one = [&](char *h, const char *dv, size_t bytes) -> int {
+                    if (pinp->covers(h, bytes)) { HIPCHK(hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, sdn)); return XINV_OK; }
+                    return stage_d2h(ws->ring_down, sdn, (double *)h, (const double *)dv, bytes);
+                };
+                if (hsS == n || nm == 1) return one(hS + (size_t)m0 * hsS * es, dS + (size_t)m0 * n * es, (size_t)nm * n * es);
+                for (int64_t m = m0; m < m0 + nm; m++) {
+                    int rr = one(hS + (size_t)m * hsS * es, dS + (size_t)m * n * es, (size_t)n * es);
+                    if (rr) return rr;
+                }
+                return XINV_OK;
+            });
+        }
+        act.cv.notify_all();
+        return XINV_OK;
+    };
+    if (nchunk > 1)
+        act.solver2 = std::thread([&]() {
+            int r = (hipSetDevice(device) == hipSuccess) ? XINV_OK : XINV_ERR_HIP;
+            for (int64_t c = 1; c < nchunk && !r; c += 2) {
+                try { r = do_chunk(c, scp1, 1); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
+            }
+            act.s2_rc = r; if (r) act.s2_err = t_err;
+        });
+    for (int64_t c = 0; c < nchunk; c += 2) {
+        rc = do_chunk(c, scp, 0);
+        if (rc) return rc;                               // (HostActors' destructor stops and joins the helper)
+    }
+    if (act.solver2.joinable()) act.solver2.join();
+    if (act.s2_rc) { t_err = act.s2_err; return act.s2_rc; }
+    act.close_downloads();
+    act.up.join();
+    act.down.join();
+    if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
+    if (act.d_rc) { t_err = act.d_err; return act.d_rc; }
+    HIPCHK(hipStreamSynchronize(sup));
+    float a = 0.f, b = 0.f;
+    HIPCHK(hipEventElapsedTime(&a, e_up0, e_up1));
+    HIPCHK(hipEventElapsedTime(&b, e_dn0, e_dn1));
+    t_stats = acc;
+    t_stats.h2d_ms = a; t_stats.d2h_ms = b;
+    t_stats.host_chunks = (int32_t)nchunk;
+    t_stats.devices = 1;
+    t_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return XINV_OK;
+}
+
+// Host-pointer entry: one device, or the batch axis split in contiguous blocks over a device list
+// (the reference loops slices in ONE process, core.py:129-139; so does this --
+// one host thread per GPU, no collective, S and flags land in the caller's arrays).
+static int solve_host(Problem &p, double *flags, const xinv_options *opt_in)
+{
+    xinv_options opt;
+    fill_options(opt, opt_in);
+    p.rowconst = (unsigned)opt.rowconst_mask & ((1u << p.ncoef) - 1u);
+    p.f32 = (unsigned)opt.f32_mask & ((2u << p.ncoef) - 1u);
+    int rc = validate(p, flags);
+    if (rc) return rc;
+    int nvis = 0;
+    if (hipGetDeviceCount(&nvis) != hipSuccess || nvis < 1) {
+        (void)hipGetLastError();
+        t_err = "no HIP device available";
+        return XINV_ERR_NODEV;
+    }
+    std::vector<int> devs;
+    if (opt.ndev < 0) {                                // every visible GPU
+        for (int i = 0; i < nvis; i++) devs.push_back(i);
+    } else if (opt.ndev > 0) {
+        if (opt.ndev > XINV_MAX_DEVICES) return fail_arg("ndev exceeds XINV_MAX_DEVICES");
+        for (int i = 0; i < opt.ndev; i++) {
+            if (opt.device_ids[i] < 0 || opt.device_ids[i] >= nvis) return fail_arg("device_ids: no such device");
+            devs.push_back(opt.device_ids[i]);
+        }
+    }
+    if ((int64_t)devs.size() > p.nbatch) devs.resize((size_t)p.nbatch);
+    if (devs.size() <= 1) {
+        if (devs.size() == 1) opt.device = devs[0];
+        return solve_host_one(p, flags, opt, nullptr);
+    }
+
+    const auto wall0 = std::chrono::steady_clock::now();
+    const int nd = (int)devs.size();
+    const int64_t n = p.zc * p.yc * p.xc;
+    // host ranges pinned ONCE for every device (portable registration); the per-device threads
+    // then copy straight out of / into the caller's arrays
+    Pinned pin;                                        // (opt-in: the per-device calls stage through their own rings otherwise)
+    pin.enabled = Pinned::env_allowed() || (opt.flags & XINV_FLAG_PIN_HOST);
+    pin.flags = hipHostRegisterPortable;
+    auto esz = [&](int arr) { return ((p.f32 >> arr) & 1u) ? (size_t)4 : (size_t)8; };
+    pin.try_pin(p.S, (size_t)((p.nbatch - 1) * p.sS + n) * esz(0));
+    pin.note_pinned(p.S, (size_t)((p.nbatch - 1) * p.sS + n) * esz(0));
+    for (int q = 0; q < p.ncoef; q++) {
+        if (!p.c[q]) continue;
+        const int64_t len = ((p.rowconst >> q) & 1u) ? p.zc * p.yc : n;
+        pin.try_pin(p.c[q], (size_t)((p.sc[q] == 0 ? 0 : (p.nbatch - 1) * p.sc[q]) + len) * esz(q + 1));
+        pin.note_pinned(p.c[q], (size_t)((p.sc[q] == 0 ? 0 : (p.nbatch - 1) * p.sc[q]) + len) * esz(q + 1));
+    }
+    struct Result { int rc = 0; std::string err; xinv_stats st; };
+    std::vector<Result> res((size_t)nd);
+    std::vector<std::thread> th;
+    const int64_t q0 = p.nbatch / nd, r0 = p.nbatch % nd;
+    for (int i = 0; i < nd; i++) {
+        const int64_t lo = i * q0 + std::min<int64_t>(i, r0), hi = lo + q0 + (i < r0 ? 1 : 0);
+        th.emplace_back([&, i, lo, hi]() {
+            Problem sub = p;
+            sub.nbatch = hi - lo;
+            sub.S = (double *)((char *)p.S + (size_t)lo * p.sS * esz(0));          // (strides count elements of the array's type)
+            for (int q = 0; q < p.ncoef; q++)
+                if (p.c[q]) sub.c[q] = (const double *)((const char *)p.c[q] + (size_t)lo * p.sc[q] * esz(q + 1));
+            xinv_options o1 = opt;
+            o1.device = devs[(size_t)i]; o1.ndev = 0;
+            (void)bind_thread_to_device_node(o1.device);         // (this thread only lives for the call: nothing to undo)
+            int r;
+            try { r = solve_host_one(sub, flags + 3 * lo, o1, &pin); }
+            catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
+            catch (...) { t_err = "unknown C++ exception"; r = XINV_ERR_HIP; }
+            res[(size_t)i].rc = r; res[(size_t)i].err = t_err; res[(size_t)i].st = t_stats;
+        });
+    }
+    for (auto &t : th) t.join();
+    t_stats = res[0].st;
+    for (int i = 0; i < nd; i++) {
+        if (res[(size_t)i].rc) { t_err = res[(size_t)i].err; return res[(size_t)i].rc; }
+        if (i == 0) continue;
+        const xinv_stats &s = res[(size_t)i].st;
+        t_stats.sweep_launches += s.sweep_launches;
+        t_stats.sweeps_max = std::max(t_stats.sweeps_max, s.sweeps_max);
+        t_stats.sweep_ms = std::max(t_stats.sweep_ms, s.sweep_ms);
+        t_stats.h2d_ms = std::max(t_stats.h2d_ms, s.h2d_ms);
+        t_stats.d2h_ms = std::max(t_stats.d2h_ms, s.d2h_ms);
+        t_stats.host_chunks += s.host_chunks;
+        t_stats.recovered_members += s.recovered_members;
+    }
+    t_stats.devices = nd;
+    t_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return XINV_OK;
+}
+

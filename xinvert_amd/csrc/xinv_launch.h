@@ -180,9 +180,6 @@ static int launch_fused(const Problem &p, const Plan &pl, int K, const double *s
     a.stop = p.stop;
     a.psum = (unsigned long long *)ws->partials;
     if (pipe) { a.nwg = (int)ntiles; a.rowf = ws->d_rowf; }
-#ifdef XINV_PIPE_DEBUG
-    if (pipe) { const char *e = getenv("XINV_DBG_PTR"); a.dbg = e ? (double *)(uintptr_t)strtoull(e, nullptr, 0) : nullptr; }
-#endif
 #if XINV_TEST_HOOKS
     a.dbg = (double *)t_hook_record;                 // (run_sweeps: XINV_HOOK_SKIP_PUBLISH; nullptr otherwise)
 #endif

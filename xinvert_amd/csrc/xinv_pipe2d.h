@@ -31,34 +31,11 @@
 #include "xinv_fused.h"
 
 #define XINV_PIPE_P 4             /* wavefronts per workgroup = sweeps per pass */
-#ifndef XINV_PIPE_EXECSEL
-#define XINV_PIPE_EXECSEL 1       /* the update and the norm share add under a lane mask in EXEC instead of selecting
-                                     (xinv_add_where): 5-6 of ~29 VALU instructions per point update less */
-#endif
-#ifndef XINV_PIPE_FLAGS
-#define XINV_PIPE_FLAGS 0         /* 0: one workgroup barrier every XINV_PIPE_B steps (kept);
-                                     1: hand-over by progress counters in LDS, no barrier in the march, the successor
-                                        five steps behind instead of seven.  MEASURED AND NOT KEPT: bit-exact, but
-                                        47.4 us per launch at 3600x1800 against 39.7 -- the polls and the two
-                                        counter stores per step cost more than the barriers they replace (taking
-                                        the barriers out altogether, results wrong, only gains 10 %) */
-#endif
 #ifndef XINV_PIPE_B
 #define XINV_PIPE_B 2             /* steps per workgroup barrier (1 or 2; the four-row LDS ring allows no more) */
 #endif
-#if XINV_PIPE_FLAGS
-#define XINV_PIPE_LAG 5           /* steps wavefront p+1 runs behind wavefront p at the least */
-#else
 #define XINV_PIPE_LAG (XINV_PIPE_B + 5)   /* steps wavefront p+1 runs behind wavefront p */
-#endif
-#ifndef XINV_PIPE_ROT
-#define XINV_PIPE_ROT 1
-#endif
-#if XINV_PIPE_FLAGS
-#define XINV_PIPE_NS 8            /* ring rows per hand-over: the producer may run that far ahead */
-#elif !defined(XINV_PIPE_NS)
 #define XINV_PIPE_NS 4            /* ring rows per hand-over */
-#endif
 #define XINV_PIPE_UW(np) (128 * (np) - 4 * XINV_PIPE_P)   /* columns a tile owns with np column pairs per lane */
 #ifndef XINV_PIPE_PF0
 #define XINV_PIPE_PF0 4           /* rows in flight from HBM, wavefront 0 (S and F) */
@@ -174,17 +151,7 @@ __global__ __launch_bounds__(256) void k_point_factor(PointFactorArgs a)
 
 __device__ __forceinline__ void xinv_pipe_barrier()
 {
-#if defined(XINV_PIPE_NOBAR)       /* timing experiments only (results are wrong): what do the barriers cost? */
-#if XINV_PIPE_NOBAR == 2
-    asm volatile("" ::: "memory");
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#elif defined(XINV_PIPE_SYNCTHREADS)
-    __syncthreads();
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 // per-row factors through the scalar unit: the constant address space makes a uniform load an s_load
@@ -242,7 +209,7 @@ template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT, int PW, int 
 __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, int yu0, int yu1,
                                                const LaneCols (&lc)[NP], const int64_t (&st0)[NP], int lane,
                                                double2 (*ring)[XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE], int gtot,
-                                               double &acc, int &cnt, int *prog, XinvCtl *ctl, int dbg_tile = 0,
+                                               double &acc, int &cnt,
                                                unsigned long long seam_lanes = 0ull)
 {
     constexpr int P = XINV_PIPE_P, H = 2 * P, D = 4, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
@@ -277,7 +244,6 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         so1[q] = lc[q].use_y ? (unsigned)(st0[q] + 1) * 8u : 0xffffffffu;  //  resource's range -- the store is dropped)
     }
 
-#if XINV_PIPE_EXECSEL
     unsigned long long okx64[NP], oky64[NP];             // "column may be updated" as 64-bit lane masks (SGPR pairs)
     double nsx[NP], nsy[NP];                             // norm share per lane and column
     int nnx[NP], nny[NP];
@@ -286,8 +252,7 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         okx64[q] = __builtin_amdgcn_ballot_w64(lc[q].ok_x) & ~seam_lanes; oky64[q] = __builtin_amdgcn_ballot_w64(lc[q].ok_y);
         nsx[q] = nsy[q] = 0.0; nnx[q] = nny[q] = 0;
     }
-#endif
-    static_assert(!SEAM || (NP == 1 && !AL && PipeRec<M, UM>::HOIST && XINV_PIPE_EXECSEL),
+    static_assert(!SEAM || (NP == 1 && !AL && PipeRec<M, UM>::HOIST),
                   "seam variants: one column pair per lane, per-row records, updates under EXEC masks");
 
     const int in_lo = yu0 - H + 2 * PW;                  // first / last row entering this wavefront's window
@@ -368,12 +333,6 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                       std::make_integer_sequence<int, PF>{});
     xinv_unroll_steps([&](auto ttag) { request_rf(in_lo + decltype(ttag)::value, ttag); },
                       std::make_integer_sequence<int, PFR>{});
-#ifndef XINV_PIPE_DRAIN
-#define XINV_PIPE_DRAIN 0
-#endif
-#if XINV_PIPE_DRAIN & 1
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
 
     // one half-sweep of row record sj (sjp / sjm: the rows below / above) on lane components X
     // (fixt: the seam lanes' pass -- X == 0, the east operand is the next lane's .x)
@@ -391,7 +350,6 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
             if (X == 0) { w = (q == 0) ? edge : sw[q > 0 ? q - 1 : 0][sj].y; e = sw[q][sj].y; }
             else        { w = sw[q][sj].x; e = (q == NP - 1) ? edge : sw[q < NP - 1 ? q + 1 : q][sj].x; }
             if constexpr (FIX) e = xinv_lane_down(sw[q][sj].x);
-#if XINV_PIPE_EXECSEL
             // the increment, added under the update predicate as EXEC (xinv_add_where: no select on the VALU)
             const double t = M::template inc<X, UM, R, false>(cw[q], sj, sjp, comp<X>(sw[q][sj]), comp<X>(sw[q][sjp]),
                                               comp<X>(sw[q][sjm]), w, e, a.sc_);
@@ -409,10 +367,6 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 const unsigned long long pm = __builtin_amdgcn_ballot_w64((X ? cw[q].my[sj] : cw[q].mx[sj]) != 0u);
                 nv[q] = xinv_add_where(comp<X>(sw[q][sj]), t, pm);
             }
-#else
-            nv[q] = M::template upd<X, UM, R, false>(cw[q], sj, sjp, comp<X>(sw[q][sj]), comp<X>(sw[q][sjp]),
-                                              comp<X>(sw[q][sjm]), w, e, a.sc_);
-#endif
         }
 #pragma unroll
         for (int q = 0; q < NP; q++) setc<X>(sw[q][sj], nv[q]);
@@ -427,43 +381,6 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         }
     };
 
-#if XINV_PIPE_FLAGS
-    // Hand-over by progress counters (LDS words, one writer each): prog[2p] = rows wavefront p has written
-    // into its ring, prog[2p+1] = rows it has taken out of its predecessor's.  A wavefront's LDS operations
-    // execute in order, so a consumer that reads the new count finds the row.  The producer's k-th row
-    // (k = its local step) is the consumer's row k-4; the ring holds NS rows.  Counts are cached in SGPRs
-    // and re-read only when the cached value does not yet allow the next step; a wavefront that waits
-    // sleeps (s_sleep) instead of taking issue slots.  A wait that does not end within ~1 s stops the
-    // member with overflow = 2 (reported as an internal error), as in xinv_norm_reduce.
-    constexpr int NS = XINV_PIPE_NS;
-    const int n_self = ((in_hi - in_lo + 1 + R - 1) / R) * R;                 // steps of this wavefront
-    const int n_prod = (((in_hi + 2) - (in_lo - 2) + 1 + R - 1) / R) * R;     // ... of its predecessor (same PF -> same R)
-    const int n_cons = (((in_hi - 2) - (in_lo + 2) + 1 + R - 1) / R) * R;     // ... of its successor
-    int seen_prod = 0, seen_cons = 0;
-    bool timed_out = false;
-    // (relaxed workgroup-scope atomics: plain ds_read / ds_write -- a `volatile` access makes the compiler
-    //  drain every outstanding load, vmcnt(0), around it: 39.8 -> 54 us per launch)
-    auto wait_ge = [&](int *ctr, int &seen, int need) {
-        if (seen >= need || timed_out) return;
-        for (unsigned spin = 0;; spin++) {
-            seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (seen >= need) break;
-            if (spin > (1u << 21)) { timed_out = true; break; }
-            if (spin >= 4) __builtin_amdgcn_s_sleep(2);
-        }
-        asm volatile("" ::: "memory");
-    };
-    if (PW > 0) {
-#ifndef XINV_PIPE_SLACK
-#define XINV_PIPE_SLACK 2         /* rows the successor lets its predecessor get ahead before it starts: with equal
-                                     rates it then finds its row already there and polls once every few steps */
-#endif
-        wait_ge(prog + 2 * (PW - 1), seen_prod, min(5 + XINV_PIPE_SLACK, n_prod));   // row in_lo is the predecessor's 5th
-#pragma unroll
-        for (int q = 0; q < NP; q++) sw[q][0] = ring[PW - 1][(2 * PW) % NS][q * RS][lane];
-    }
-    (void)gtot;
-#else
     // global step g of the workgroup = local step + LAG * PW; a barrier closes every B-th global step.
     // Row in_lo is taken out of the ring in global step LAG * PW - 1 -- the step before this wavefront's first,
     // like every later row (one step before it enters) -- and BEFORE the barrier that may close that step: the
@@ -485,12 +402,6 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
         }
         if ((g + 1) % B == 0) xinv_pipe_barrier();
     }
-#endif
-#ifdef XINV_PIPE_DEBUG
-    // [member][tile][stage][k = 0..3][lane][2]: the first four rows stage PW took out of its predecessor's ring
-    double *dbgp = a.dbg ? a.dbg + ((((size_t)m * a.nwg + dbg_tile) * 4 + PW) * 4) * 128 : nullptr;
-    if (PW > 0 && dbgp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbgp[lane * 2] = sw[0][0].x; dbgp[lane * 2 + 1] = sw[0][0].y; }
-#endif
 
     for (int rb_ = in_lo; rb_ <= in_hi; rb_ += R) {
         xinv_unroll_steps([&](auto utag) {
@@ -500,47 +411,16 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #define RSLOT(w) ((2 * PW + U - (w) + 64 * XINV_PIPE_NS) % XINV_PIPE_NS)  /* LDS ring slot of row r - w */
 #define ITAG(v) std::integral_constant<int, (v)>{}
             const int r = rb_ + U;
-#if XINV_PIPE_DRAIN & 2
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-#if defined(XINV_PIPE_PAD_SALU)       /* timing experiments only: what does an extra scalar / vector instruction per step cost? */
-            { int t_ = r;
-#pragma unroll
-              for (int k_ = 0; k_ < XINV_PIPE_PAD_SALU; k_++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(t_) :: "scc"); }
-#endif
-#if defined(XINV_PIPE_PAD_VALU)
-            { int t_ = lane;
-#pragma unroll
-              for (int k_ = 0; k_ < XINV_PIPE_PAD_VALU; k_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(t_)); }
-#endif
             request(r + PF, ITAG((U + PF) % R));
             request_rf(r + PFR, ITAG((U + PFR) % R));
-#if !XINV_PIPE_FLAGS
             if (PW > 0) {
 #pragma unroll
                 for (int q = 0; q < NP; q++) {
                     sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q * RS][lane];   // row r+1: written B+1 steps ago
                     if (FR) cw[q].v[FQ][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q * RS + 1][lane];
                 }
-#ifdef XINV_PIPE_DEBUG
-                if (dbgp && r - in_lo < 3) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    double *d = dbgp + (r - in_lo + 1) * 128;
-                    d[lane * 2] = sw[0][(U + 1) % R].x; d[lane * 2 + 1] = sw[0][(U + 1) % R].y;
-                }
-#endif
             }
-#endif
-            if constexpr (HOIST && !XINV_PIPE_EXECSEL) {   // row r-1: update predicate, once for both half-sweeps
-                constexpr int s1 = SLOT(1);
-                const bool rok = rokw[s1] != 0.0;
-#pragma unroll
-                for (int q = 0; q < NP; q++) {
-                    const double fx = cw[q].v[FQ][s1].x, fy = cw[q].v[FQ][s1].y;
-                    cw[q].mx[s1] = xinv_lane_word(lc[q].ok_x && rok && (fx != u));
-                    cw[q].my[s1] = xinv_lane_word(lc[q].ok_y && rok && (fy != u));
-                }
-            } else if constexpr (!HOIST) {   // coefficient arrays that vary along x: the model's own predicate
+            if constexpr (!HOIST) {          // coefficient arrays that vary along x: the model's own predicate
                 const bool rv = (r - 1 >= 1) && (r - 1 <= ycr - 2);
 #pragma unroll
                 for (int q = 0; q < NP; q++)
@@ -562,14 +442,6 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                 }
                 half_sweep(ITAG(X), ITAG(sj), ITAG(sjp), ITAG(sjm));
             }
-#if XINV_PIPE_FLAGS
-            if (PW > 0) {   // row r+1 for the next step: the predecessor's row (local step + 6), once it is there
-                const int j = r - in_lo;
-                wait_ge(prog + 2 * (PW - 1), seen_prod, min(j + 6, n_prod));
-#pragma unroll
-                for (int q = 0; q < NP; q++) sw[q][(U + 1) % R] = ring[PW - 1][RSLOT(-1)][q * RS][lane];
-            }
-#endif
             {   // black half-sweep on row r-2
                 const int jb = r - 2;
                 constexpr int sj = SLOT(2), sjp = SLOT(1), sjm = SLOT(3);
@@ -578,35 +450,18 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
 #pragma unroll
                     for (int q = 0; q < NP; q++) {
                         const double2 t = sw[q][sj];
-#if XINV_PIPE_EXECSEL
                         // magnitudes and samples per lane and column under `S != undef` as EXEC; the lanes that
                         // do not own their column are discarded after the march
                         xinv_norm_row(nsx[q], nsy[q], nnx[q], nny[q], t.x, t.y, u);
-#else
-                        const bool cx = lc[q].use_x & (t.x != u);
-                        const bool cy = lc[q].use_y & (t.y != u);
-                        acc += (cx ? fabs(t.x) : 0.0);
-                        acc += (cy ? fabs(t.y) : 0.0);
-                        cnt += (cx ? 1 : 0) + (cy ? 1 : 0);
-#endif
                     }
                 }
                 // ---- row r-2 leaves
                 if (PW < P - 1) {
-#if XINV_PIPE_FLAGS
-                    const int j = r - in_lo;                 // this row replaces the one written NS steps ago: the
-                    if (j >= NS + 4)                         // successor's row j - NS - 4 must have been taken out
-                        wait_ge(prog + 2 * (PW + 1) + 1, seen_cons, min(j - NS - 3, n_cons));
-#endif
 #pragma unroll
                     for (int q = 0; q < NP; q++) {
                         ring[PW][RSLOT(2)][q * RS][lane] = sw[q][sj];
                         if (FR) ring[PW][RSLOT(2)][q * RS + 1][lane] = cw[q].v[FQ][sj];
                     }
-#if XINV_PIPE_FLAGS
-                    asm volatile("" ::: "memory");
-                    __hip_atomic_store(prog + 2 * PW, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
                 } else if ((unsigned)(jb - yu0) < (unsigned)(yu1 - yu0)) {
                     const int doff = jb * (int)rowbytes;
                     xinv_unroll_steps([&](auto qtag) {
@@ -627,49 +482,28 @@ __device__ __forceinline__ void xinv_pipe_wave(const FusedArgs &a, int64_t m, in
                     }, std::make_integer_sequence<int, NP>{});
                 }
             }
-#if XINV_PIPE_FLAGS
-            if (PW > 0)                                      // row r has been taken out of the predecessor's ring
-                __hip_atomic_store(prog + 2 * PW + 1, r - in_lo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
-#else
             if ((LAG * PW + U + 1) % B == 0) xinv_pipe_barrier();
-#endif
 #undef SLOT
 #undef RSLOT
 #undef ITAG
         }, std::make_integer_sequence<int, R>{});
-#if !XINV_PIPE_FLAGS
         g += R;
-#endif
     }
-#if XINV_PIPE_FLAGS
-    (void)n_self;
-    if (timed_out && lane == 0) { ctl->overflow = 2; ctl->done = 1; ctl->sweeps = ctl->loop + 1; }
-#else
     for (; g < gtot; g++) if ((g + 1) % B == 0) xinv_pipe_barrier();
-#endif
-#if XINV_PIPE_EXECSEL
 #pragma unroll
     for (int q = 0; q < NP; q++) {                       // only the columns this lane owns count
         acc += (lc[q].use_x ? nsx[q] : 0.0);
         acc += (lc[q].use_y ? nsy[q] : 0.0);
         cnt += (lc[q].use_x ? nnx[q] : 0) + (lc[q].use_y ? nny[q] : 0);
     }
-#endif
 }
 
 template <class M, unsigned UM, bool FR, int NP, bool AL, bool EXT, bool SEAM = false>
 __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
 {
-#ifndef XINV_PIPE_INV
-#define XINV_PIPE_INV 1
-#endif
-#if XINV_PIPE_INV
     xinv_fresh_scalar_cache();
-#endif
     constexpr int P = XINV_PIPE_P, K = P, H = 2 * K, LAG = XINV_PIPE_LAG, B = XINV_PIPE_B;
     __shared__ double2 ring[P - 1][XINV_PIPE_NS][NP * (FR ? 2 : 1)][XINV_WAVE];
-    __shared__ int prog[2 * P];                          // hand-over progress counters (XINV_PIPE_FLAGS)
 
     unsigned tag;
     int T;
@@ -692,11 +526,7 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
     }
     // which sweep this wavefront applies: rotated from workgroup to workgroup, so that the workgroups sharing
     // a CU do not all start (and drain) their pipelines on the same SIMD
-#if XINV_PIPE_ROT
     pwi = (wave + (int)(blockIdx.x >> 8)) & (P - 1);       // (dispatch order: 8 XCDs x 32 CUs, then the next round)
-#else
-    pwi = wave;
-#endif
     int wt = T;
     bool active = wt < a.nstrip * a.nrb;
     if constexpr (SEAM) {                                // (the edge strips' tiles first: xinv_heavy_first)
@@ -731,10 +561,6 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         st0[q] = xu0 - HW + 2 * NP * lane + 2 * q;       // unwrapped store column of the pair's .x
     }
 
-#if XINV_PIPE_FLAGS
-    if (threadIdx.x < 2 * P) prog[threadIdx.x] = 0;
-    __syncthreads();
-#endif
     if (active) {
         // global steps every wavefront goes through: the longest of the four schedules, whole barrier periods
         const int ry = yu1 - yu0;
@@ -753,10 +579,10 @@ __global__ __launch_bounds__(64 * XINV_PIPE_P) void k_pipe2d(FusedArgs a_)
         const bool wraps = rs.any;
 #define XINV_PIPE_MARCH(SM) \
         switch (pwi) { \
-        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \
-        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \
-        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \
-        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, prog, ctl, wt, rs.lanes); break; \
+        case 0: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 0, XINV_PIPE_PF0, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, rs.lanes); break; \
+        case 1: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 1, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, rs.lanes); break; \
+        case 2: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 2, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, rs.lanes); break; \
+        default: xinv_pipe_wave<M, UM, FR, NP, AL, EXT, 3, XINV_PIPE_PF, SM>(a, m, yu0, yu1, lc, st0, lane, ring, gtot, acc, cnt, rs.lanes); break; \
         }
         if (wraps) { XINV_PIPE_MARCH(SEAM) } else { XINV_PIPE_MARCH(false) }
 #undef XINV_PIPE_MARCH

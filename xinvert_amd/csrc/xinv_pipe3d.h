@@ -160,44 +160,22 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const xinv_cdouble_ptr rowf = (xinv_cdouble_ptr)(uintptr_t)(a.rowf + m * a.srowf);
 
     __shared__ double xch[2][2][NW][2][64];              // [step parity][as loaded | red-updated][wave][top | bottom row][lane]
-#ifndef XINV_P3_FRING
-#define XINV_P3_FRING 1           /* The forcing rides the ring with S, as in k_pipe2d's FR variant: group 1 runs three planes behind
-                                     group 0 and its own forcing requests had mostly left the L2 by then (19.8 B of HBM-side
-                                     traffic per point-sweep against 12 + halo).  Round 3: bit-exact, reads -24 %, xch + ring =
-                                     160 KiB to the byte (the norm tail borrows xch) -- and 15 % slower: 128 VGPRs, and group 1's
-                                     march spilled 48-104 bytes per lane.  Round 4 (profiles/r04_pipe3d_variants.txt): the
-                                     forcing window trimmed (the plane in its black stage keeps ONE component) and this unit
-                                     compiled with -amdgpu-sched-strategy=iterative-minreg: 123 VGPRs, no spill; C5, 15 volumes:
-                                     7.69 -> 6.13 GB per launch (15.7 B per point-sweep), 2.98 -> 3.26e11.  Now only group 0 has
-                                     loads in flight, one plane ahead (48 KB per CU): 5.3 TB/s, a step is one memory latency.
-                                     Measured and not kept on top of it: two planes of S in flight for one or two of a
-                                     wavefront's three rows (7-12 registers spilled, 3.24 / 3.16e11), forcing loads
-                                     non-temporal (6.70 GB, 3.02e11), S loads cached (5.57 GB = 14.3 B per point-sweep, but
-                                     3.0e11: latency), 12 or 8 wavefronts with two planes in flight (2.3-2.4e11), 8-byte loads
-                                     (2.9e11), one 4-byte load per line of the plane after next to pull it into the L2
-                                     ahead of the real request (one register: 11 spilled, 2.7e11).
-                                     0: both groups read the forcing from HBM (round 3's kernel). */
-#endif
     // [wave of the group][row][slot][S (| forcing)][lane]: planes with sweep 1 complete.
     // (laid out [wave][row][slot][S | forcing][lane]: every access of a wavefront is ONE base register + an immediate
     //  offset below 64 KiB -- with the slot outermost the last quarter lay beyond the 16-bit offset and cost a second
     //  base register, which the 128-register budget did not have: spills)
-    __shared__ double2 ring[G][RR][2][1 + XINV_P3_FRING][64];
+    __shared__ double2 ring[G][RR][2][2][64];
     // (the first and the last row of the cross-section are updated with a j neighbour missing: whatever they become is
     //  never read by a row that is kept -- their forcing is not loaded: 2 of 24 rows, 4 % of the bytes read)
     //  (all ones ORed into the lane offset: out of the resource's range, the request returns zero and fetches nothing;
     //   a branch around the load cost 31 spilled registers)
-#ifndef XINV_P3_FDROP
-#define XINV_P3_FDROP 1
-#endif
     unsigned f_drop[RR];
 #pragma unroll
-    for (int rr = 0; rr < RR; rr++) f_drop[rr] = (XINV_P3_FRING && XINV_P3_FDROP && ((gw == 0 && rr == 0) || (gw == G - 1 && rr == RR - 1))) ? ~0u : 0u;
+    for (int rr = 0; rr < RR; rr++) f_drop[rr] = ((gw == 0 && rr == 0) || (gw == G - 1 && rr == RR - 1)) ? ~0u : 0u;
 
     double nsx = 0.0, nsy = 0.0;                         // norm share per lane and column (un-owned lanes discarded below)
     int nnx = 0, nny = 0;
 
-#if XINV_P3_FRING
     // (ring variant: the forcing of the plane in its red stage as both components, of the plane in its black stage as
     //  the one component that stage still reads: six registers less than two full planes)
     double2 sw[RR][D], fwr[RR], pfS[RR], pfF[RR];
@@ -209,19 +187,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         fwr[rr] = pfS[rr] = pfF[rr] = make_double2(0.0, 0.0);
         fwb[rr] = 0.0;
     }
-#else
-    double2 sw[RR][D], fw[RR][2], pfS[RR], pfF[RR];
-#pragma unroll
-    for (int rr = 0; rr < RR; rr++) {
-#pragma unroll
-        for (int t = 0; t < D; t++) sw[rr][t] = make_double2(0.0, 0.0);
-        fw[rr][0] = fw[rr][1] = pfS[rr] = pfF[rr] = make_double2(0.0, 0.0);
-    }
-#endif
 
-#ifndef XINV_P3_NT
-#define XINV_P3_NT 1
-#endif
     // Every array of the member is addressed through a raw buffer resource (base, bytes of the volume) with the row as
     // the instruction's scalar offset and the lane's columns as its 32-bit vector offset -- no 64-bit vector address per
     // load in flight (twelve VGPRs of the 128 this kernel has), stores of columns a lane does not own dropped by range
@@ -238,7 +204,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const unsigned so01 = (lc.use_x && lc.use_y) ? (unsigned)st0 * 8u : 0xffffffffu;
     const unsigned sox = (lc.use_x && !lc.use_y) ? (unsigned)st0 * 8u : 0xffffffffu;
     (void)so01; (void)sox;
-    constexpr int NTAUX = XINV_P3_NT ? 2 : 0;            // cache-policy operand: bit 1 = nt on this target
+    constexpr int NTAUX = 2;                             // cache-policy operand of S loads / stores: bit 1 = nt on this target
     auto ldrow = [&](__amdgpu_buffer_rsrc_t rs, int soff, auto auxtag, unsigned drop = 0u) {
         constexpr int AUX = decltype(auxtag)::value;
         double2 v;
@@ -253,10 +219,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
         return v;
     };
     auto ldS = [&](int soff) { return ldrow(rsS, soff, std::integral_constant<int, NTAUX>{}); };
-#ifndef XINV_P3_NTF
-#define XINV_P3_NTF 0             /* forcing loads non-temporal (ring variant: the forcing is read once per pass, like S) */
-#endif
-    auto ldF = [&](int soff, unsigned drop = 0u) { return ldrow(rsF, soff, std::integral_constant<int, XINV_P3_NTF ? 2 : 0>{}, drop); };
+    auto ldF = [&](int soff, unsigned drop = 0u) { return ldrow(rsF, soff, std::integral_constant<int, 0>{}, drop); };
     const int rowbytes = (int)(xc * 8);
     auto plane_off = [&](int p, int rr) {                // byte offset of the lane's row in plane p (clamped), a scalar
         const int pr = p > zc - 1 ? zc - 1 : (p < 0 ? 0 : p);
@@ -341,7 +304,6 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             } else {
                 sw[rr][U] = ring[gw][rr][U & 1][0][lane];
             }
-#if XINV_P3_FRING
             // plane r-2 goes from its red to its black stage: its forcing travels on to group 1 (slot U & 1 was read by
             // group 1 in the previous step and is rewritten with S at the end of this one) and keeps one component
             if (GRP == 0) ring[gw][rr][U & 1][1][lane] = fwr[rr];
@@ -349,10 +311,6 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             fwr[rr] = pfF[rr];
             if (GRP == 0) pfF[rr] = ldF(plane_off(r, rr), f_drop[rr]);
             else pfF[rr] = ring[gw][rr][U & 1][1][lane];
-#else
-            fw[rr][S1 & 1] = pfF[rr];
-            pfF[rr] = ldF(plane_off(r, rr));
-#endif
         }
         // as loaded: what the neighbouring wavefronts' next red half-sweep reads of the first / last row
         xch[bw][0][wave][0][lane] = XROW(0) ? sw[0][U].y : sw[0][U].x;
@@ -368,11 +326,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                 const Rec e = record(r - 1, rr);
                 const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S1]) : jMe;
                 const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S1]) : jPe;
-#if XINV_P3_FRING
                 const double fX = comp<X>(fwr[rr]);
-#else
-                const double fX = comp<X>(fw[rr][S1 & 1]);
-#endif
                 double v = update(rtag, XT{}, S1, U, S2, e, jP, jM, fX, std::false_type{});
                 if constexpr (SM && X == 0) v = seam_fix(rtag, S1, U, S2, e, jP, jM, fX);
                 if (rr == 0) xch[bw][1][wave][0][lane] = v;          // red-updated: the neighbours' next black half-sweep
@@ -391,11 +345,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
                 const Rec e = record(kk, rr);
                 const double jM = (rr > 0) ? comp<X>(sw[rr > 0 ? rr - 1 : 0][S2]) : jMe;
                 const double jP = (rr < RR - 1) ? comp<X>(sw[rr < RR - 1 ? rr + 1 : rr][S2]) : jPe;
-#if XINV_P3_FRING
                 const double fX = fwb[rr];
-#else
-                const double fX = comp<X>(fw[rr][S2 & 1]);
-#endif
                 update(rtag, XT{}, S2, S1, S3, e, jP, jM, fX, std::false_type{});
                 if constexpr (SM && X == 0) seam_fix(rtag, S2, S1, S3, e, jP, jM, fX);
             }, std::make_integer_sequence<int, RR>{});
