@@ -980,18 +980,21 @@ def _medium_fuzz(chunk, seed0, odd, every_case_stops=False, runner=None):
                 assert_same(S[m], fl[m], So, flo, what)
 
 
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
 @pytest.mark.parametrize('BCx', ['fixed', 'periodic'])
 @pytest.mark.parametrize('nmem,cus', [(3, 8), (7, 8), (2, 5), (4, 256)])
-@pytest.mark.parametrize('shape', [(50, 40, 130), (37, 20, 250)])
-def test_pipe3d_tail_cut(BCx, nmem, cus, shape):
+@pytest.mark.parametrize('shape', [(50, 40, 130), (37, 20, 250), (50, 41, 130), (50, 42, 130)])
+def test_pipe3d_tail_cut(BCy, BCx, nmem, cus, shape):
     """k_pipe3d runs one workgroup per CU; the tiles of a launch's last, partly filled round are cut into k chunks while the
     others march the whole column (xinv_pipe3d.h, p3_whole_tiles).  With `cu_count` a small batch takes the mixed launch:
     whole-column and cut tiles of one member, members of both kinds -- bit for bit the oracle, stop rule included."""
-    ps = [_uniform3d(rand3d(shape[0], shape[1], shape[2], 'fixed', BCx, 1, seed=_seed(('tail', BCx, nmem, cus, shape, m))), None)
+    # (BCy = 'extend': yc = 40 / 42 put rows yc-2, yc-1 into one wavefront; 41 splits them: the one-sweep kernel)
+    ps = [_uniform3d(rand3d(shape[0], shape[1], shape[2], BCy, BCx, 1, seed=_seed(('tail', BCy, BCx, nmem, cus, shape, m))), None)
           for m in range(nmem)]
     S, fl, st = run_hip_batched(ps, 40, 1e-4, path=PATH_FUSED, cu_count=cus, lanes=1)
-    assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == 2, st
-    if cus < 256:
+    two = BCy == 'fixed' or util.p3_extend_ok(shape[1])
+    assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == (2 if two else 1), st
+    if cus < 256 and two:
         assert st['k_chunks'] > 1 and 0 < st['cut_tiles'] < cus, st
     for m, q in enumerate(ps):
         So, flo = run_oracle(q, 40, 1e-4, COLOUR_2)

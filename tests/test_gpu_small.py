@@ -111,25 +111,29 @@ def xuniform3d(zc, yc, xc, BCx, msk, seed, BCy='fixed'):
 def test_fused3d_two_sweeps_per_pass_vs_oracle(shape, BCx, BCy):
     """k_pipe3d (x-uniform coefficients; the planner's choice, asked for explicitly here: sweeps_per_launch = 2): passes of two sweeps + a
     one-sweep tail; must equal the oracle's coloured ordering and the one-sweep-per-pass kernel bit for bit.  Round 5: odd
-    widths with periodic x run the two-sweep pass too (the even-ring variant); BCy = 'extend' keeps the one-sweep kernel
-    whatever is asked for (a two-sweep variant was built, bit-exact, and spilled: profiles/r05_seam_rates.txt, section 6)."""
+    widths with periodic x run the two-sweep pass too (the even-ring variant).  Round 6: BCy = 'extend' runs it as well (the
+    first sweep's pre-pass by k_extend on the source, the second's inside the kernel: xinv_pipe3d.h EXT) where rows yc-2 / yc-1
+    share a wavefront (util.p3_extend_ok: two row counts in three) -- not with the odd-xc periodic seam; the rest keep the
+    one-sweep kernel."""
     zc, yc, xc = shape
     for msk in (0, 1):
         p = xuniform3d(zc, yc, xc, BCx, msk, seed=zc + yc + xc + msk, BCy=BCy)
         for nsw in (7, 8):                              # odd: 3 passes + tail; even: 4 passes
             So, flo = run_oracle(p, nsw - 1, 0.0, C2)
             S, fl, st = util.run_hip_batched([p], nsw - 1, 0.0, sweeps_per_launch=2)
-            assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == (2 if BCy == 'fixed' else 1) and st['xuniform_mask'] == 7, st
+            one = BCy == 'extend' and ((BCx == 'periodic' and xc % 2 == 1) or not util.p3_extend_ok(yc))
+            assert st['path'] == PATH_FUSED and st['sweeps_per_launch'] == (1 if one else 2) and st['xuniform_mask'] == 7, st
             assert np.array_equal(S[0], So), '%d points differ' % (S[0] != So).sum()
             assert fl[0][2] == flo[2] and abs(fl[0][1] - flo[1]) <= 1e-12
         S1, f1, s1 = util.run_hip_batched([p], 7, 0.0, sweeps_per_launch=1)
         assert s1['sweeps_per_launch'] == 1 and np.array_equal(S1, S)
 
 
-def test_fused3d_two_sweeps_tolerance_stop_inside_a_pass():
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+def test_fused3d_two_sweeps_tolerance_stop_inside_a_pass(BCy):
     """Members stop at different sweeps, some on the first sweep of a two-sweep pass (redo from the
-    pass's source buffer)."""
-    ps = [xuniform3d(10, 24, 64, 'periodic', 1, seed=40 + s) for s in range(6)]
+    pass's source buffer -- with 'extend' that source carries the first sweep's pre-pass already: idempotent)."""
+    ps = [xuniform3d(10, 24, 64, 'periodic', 1, seed=40 + s, BCy=BCy) for s in range(6 if BCy == 'fixed' else 14)]
     S, fl, st = util.run_hip_batched(ps, 300, 2e-3, sweeps_per_launch=2)
     assert st['sweeps_per_launch'] == 2
     par = set()
@@ -140,9 +144,10 @@ def test_fused3d_two_sweeps_tolerance_stop_inside_a_pass():
     assert par == {0, 1}
 
 
-def test_fused3d_two_sweeps_k_chunks_tall_volume():
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+def test_fused3d_two_sweeps_k_chunks_tall_volume(BCy):
     """A tall, narrow volume is split into k chunks (four recomputed halo planes a side)."""
-    p = xuniform3d(200, 20, 100, 'fixed', 1, seed=3)
+    p = xuniform3d(200, 20, 100, 'fixed', 1, seed=3, BCy=BCy)
     So, flo = run_oracle(p, 5, 0.0, C2)
     S, fl, st = util.run_hip_batched([p], 5, 0.0, sweeps_per_launch=2)
     assert st['sweeps_per_launch'] == 2 and np.array_equal(S[0], So) and fl[0][2] == flo[2]

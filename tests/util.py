@@ -320,3 +320,16 @@ class xarray_standin:
         else:
             sys.modules['xarray'] = self.prev
         return False
+
+
+def p3_extend_ok(yc):
+    """Mirror of the planner's rule (xinv_launch.h: p3_extend_ok): the two-sweep 3-D pass takes BCy = 'extend' where rows
+    yc-2 / yc-1 sit in one wavefront of every cross-section that needs row yc-1 right; other row counts keep the one-sweep kernel."""
+    RJ, H, RR = 16, 4, 3
+    jbo = (yc - 1) // RJ
+    tog = lambda jb: ((yc - 2) - (jb * RJ - H)) % RR != RR - 1
+    if not tog(jbo):
+        return False
+    if jbo > 0 and (yc - 1) - jbo * RJ <= 1 and not tog(jbo - 1):
+        return False
+    return True

@@ -68,6 +68,7 @@ def main():
     ap.add_argument('--path', type=int, default=0)
     ap.add_argument('--members', type=int, default=0)
     ap.add_argument('--lanes', type=int, default=0)
+    ap.add_argument('--bcy', default='', help='override BCy of the configuration (c5 --bcy extend)')
     ap.add_argument('--cus', type=int, default=0, help='xinv_options.cu_count (0 = the device; a huge count = no remainder cut in k_pipe3d)')
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--bcx', default='periodic', help='poisson:<ny>x<nx>: BCx')
@@ -83,6 +84,8 @@ def main():
     _lib.require_gpu()
     for name in a.configs:
         p, sw = make(name, a)
+        if a.bcy:
+            p['BCy'] = a.bcy
         rp = ResidentProblem(p, plan=not a.no_plan)
         nb, n = rp.nb, rp.n
         opt = dict(sweeps_per_launch=a.spl, rows_per_tile=a.rows, path=a.path, no_xuniform=1 if a.no_xuniform else 0,

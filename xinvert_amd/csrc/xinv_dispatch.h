@@ -64,7 +64,7 @@ XINV_HIDDEN int xinv_launch_fused9(bool gen, int K, bool al, bool ext, dim3 grid
 XINV_HIDDEN int xinv_launch_fused3d(int NW, bool al, bool uni, bool ext, dim3 grid, hipStream_t st,
                                     const Fused3Args &a);
 // two sweeps per pass pipelined across two groups of eight wavefronts (xinv_pipe3d.h): x-uniform coefficients, no 'extend'
-XINV_HIDDEN int xinv_launch_pipe3d(bool al, dim3 grid, hipStream_t st, const Fused3Args &a, bool seam = false);
+XINV_HIDDEN int xinv_launch_pipe3d(bool al, dim3 grid, hipStream_t st, const Fused3Args &a, bool seam = false, bool ext = false);
 // odd-xc periodic seam inside the kernel (xinv_tu_fused3d_seam.hip): unaligned strips, NW = 8 or 12
 XINV_HIDDEN int xinv_launch_fused3d_seam(int NW, bool uni, bool ext, dim3 grid, hipStream_t st, const Fused3Args &a);
 XINV_HIDDEN int xinv_launch_fused3dg_seam(int NW, bool ext, dim3 grid, hipStream_t st, const Fused3GArgs &a);

@@ -94,6 +94,21 @@ static int64_t p3_whole_tiles(int64_t tiles, int nk, int64_t KC, int64_t zc, int
     return nfull;
 }
 
+// k_pipe3d with BCy = 'extend' (xinv_pipe3d.h: EXT) applies the second sweep's pre-pass out of a wavefront's own registers:
+// rows yc-2 and yc-1 have to sit in ONE wavefront (RR adjacent rows each, the cross-section of row block jb starting at row
+// jb * RJ - H) in the block that owns row yc-1 -- and in the block before it when that one owns row yc-2 or yc-3, whose
+// second sweep reads row yc-1 through row yc-2.  (Rows 0 / 1 always do: H mod RR = 1.)
+static bool p3_extend_ok(int64_t yc)
+{
+    const int RJ = XINV_P3_G * XINV_P3_RR - 8, H = 4, RR = XINV_P3_RR;
+    static_assert(XINV_P3_RR == 3 && XINV_P3_G * XINV_P3_RR - 8 > 0, "p3_extend_ok: three rows per wavefront");
+    const int64_t jbo = (yc - 1) / RJ;                           // the block that owns row yc-1
+    auto together = [&](int64_t jb) { return ((yc - 2) - (jb * RJ - H)) % RR != RR - 1; };   // row yc-2 is not a wavefront's last row
+    if (!together(jbo)) return false;
+    if (jbo > 0 && (yc - 1) - jbo * RJ <= 1 && !together(jbo - 1)) return false;
+    return true;
+}
+
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                           hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false, bool pq = false)
 {
@@ -282,15 +297,31 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
         const int64_t NT2 = (int64_t)a.nstrip * a.njb;
         // a flat grid over the members of the launch (k_pipe3d); at most 2^30 workgroups per launch
         const int64_t mstep = std::max<int64_t>(1, std::min<int64_t>(XINV_MEMBER_CHUNK, ((int64_t)1 << 30) / (NT2 * a.nkc)));
+        const bool ext2 = (p.BCy == XINV_BC_EXTEND);
         for (int64_t m0 = 0; m0 < nmem; m0 += mstep) {
             const int64_t nm = std::min<int64_t>(mstep, nmem - m0);
             a.member0 = member0 + m0;
             a.rowf = (const double *)ws->d_rowf; a.srowf = pl.srowf2;
+            if (ext2) {
+                // 'extend': the pre-pass of the pass's first sweep, in place on the source (numbas.py:87-115; idempotent: a
+                // pass redone from this source by the one-sweep kernel applies it again to the same effect); the second
+                // sweep's is applied inside the kernel (xinv_pipe3d.h: EXT).  A no-op for a member that has stopped.
+                ExtendArgs e;
+                e.S = const_cast<double *>(src); e.sS = p.sS; e.yc = p.yc; e.xc = p.xc;
+                e.kfirst = 1; e.nk = p.zc - 2;
+                e.per = a.per; e.tall = 0; e.force = force;
+                e.undef = p.sc_.undef; e.ctl = ws->ctl; e.member0 = a.member0;
+                for (int64_t q0 = 0; q0 < nm; q0 += 32768) {     // (grid.z is limited to 65535)
+                    const int64_t nq = std::min<int64_t>(32768, nm - q0);
+                    e.member0 = a.member0 + q0;
+                    hipLaunchKernelGGL(k_extend, dim3(cdiv(p.xc, 256), (unsigned)e.nk, (unsigned)nq), dim3(256, 1, 1), 0, st, e);
+                }
+            }
             // which tiles march the whole column, which are cut into the plan's k chunks (p3_whole_tiles)
             a.nfull = p3_whole_tiles(NT2 * nm, a.nkc, a.KC, p.zc, pl.cus);
             const int64_t nwg = a.nfull + (NT2 * nm - a.nfull) * a.nkc;
             if (pl.fma) xinv_launch_pipe3d_fma(pl.aligned, dim3((unsigned)nwg, 1, 1), st, a);
-            else        xinv_launch_pipe3d(pl.aligned, dim3((unsigned)nwg, 1, 1), st, a, pl.seam != 0);
+            else        xinv_launch_pipe3d(pl.aligned, dim3((unsigned)nwg, 1, 1), st, a, pl.seam != 0, ext2);
         }
         HIPCHK(hipGetLastError());
         return XINV_OK;

@@ -75,10 +75,20 @@ __global__ __launch_bounds__(256) void k_row_factor3d(RowFactor3Args a)
 
 // SEAM (periodic x, ODD xc): the even ring with a phantom column (xinv_fused.h: RING) -- one more pass, for the seam lanes
 // alone, in the half-sweeps that update the .x slots, and only in the cross-sections that hold a seam lane.
-template <int G, int RR, bool AL, bool FMA = false, bool SEAM = false>
+// EXT (BCy = 'extend', numbas.py:87-115: at the start of every sweep rows 0 / yc-1 of planes 1 .. zc-2 take the values of rows
+// 1 / yc-2 where those are defined): the pre-pass of the pass's FIRST sweep is applied to the source buffer by k_extend
+// before this launch (idempotent; launch_fused3d) -- group 0 finds it in what it loads; the pre-pass of the SECOND sweep is
+// applied by group 1 to the plane it takes out of the ring, before anything reads it, out of the wavefront's own registers:
+// rows 0 / 1 always sit in one wavefront; the planner takes this variant only where rows yc-2 / yc-1 do too in every
+// cross-section that needs row yc-1 right (p3_extend_ok, xinv_launch.h: two row counts in three; the others keep the
+// one-sweep kernel).  (Round 5 loaded the partner rows from HBM; round 6 first read row yc-2 out of the neighbouring
+// wavefront's ring slot where the pair is split: both bit-exact, both spilled 26-34 registers and ran at a third of the
+// rate -- the kernel has 128 registers and uses 123-126.)
+template <int G, int RR, bool AL, bool FMA = false, bool SEAM = false, bool EXT = false>
 __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
 {
     static_assert(!SEAM || !AL, "odd xc: strips are never aligned");
+    static_assert(!EXT || !SEAM, "'extend' with the odd-xc periodic seam keeps the one-sweep kernel");
     xinv_fresh_scalar_cache();
     constexpr int K = 2, H = 2 * K, NW = 2 * G, NR = G * RR, RJ = NR - 2 * H, D = 4;
 
@@ -311,6 +321,43 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             fwr[rr] = pfF[rr];
             if (GRP == 0) pfF[rr] = ldF(plane_off(r, rr), f_drop[rr]);
             else pfF[rr] = ring[gw][rr][U & 1][1][lane];
+        }
+        if constexpr (EXT && GRP == 1) {
+            // the 'extend' pre-pass of sweep 2 on the entering plane (planes 1 .. zc-2): row 0 <- row 1, row yc-1 <- row yc-2
+            // where the source is defined; with fixed x the corners take the diagonal neighbours (numbas.py:109-115) --
+            // fused_extend_fix's rules, with the column classes worked out here from the lane's load offset instead of
+            // living in two registers through the march (the whole kernel has 128)
+            auto ext_fix = [&](double2 &edge, const double2 inner) {
+                double sx = inner.x, sy = inner.y;
+                bool doy = true;
+                if (!a.per) {
+                    const int cx = (int)(lo0 >> 3), xl = (int)xc - 1;
+                    const double iw = xinv_lane_up(inner.y);                 // column cx - 1
+                    sx = (cx == 0) ? inner.y : ((cx == xl) ? iw : inner.x);  // (0, 0) <- (1, 1); (0, xc-1) <- (1, xc-2)
+                    sy = (cx + 1 == xl) ? inner.x : inner.y;
+                    doy = cx + 1 <= xl;
+                }
+                if (sx != u) edge.x = sx;
+                if (doy && sy != u) edge.y = sy;
+            };
+            if (r >= 1 && r <= zc - 2 && j0 <= 0 && j0 + RR > 0) {            // (wave-uniform: this wavefront holds row 0)
+                xinv_unroll_steps([&](auto rtag) {
+                    constexpr int rr = decltype(rtag)::value;
+                    if (j0 + rr == 0) {                          // (rows 0 and 1 share a wavefront: H mod RR = 1)
+                        const double2 inner = sw[rr + 1 < RR ? rr + 1 : rr][U];
+                        ext_fix(sw[rr][U], inner);
+                    }
+                }, std::make_integer_sequence<int, RR>{});
+            }
+            if (r >= 1 && r <= zc - 2 && j0 <= yc - 1 && j0 + RR > yc - 1) {  // (... row yc-1)
+                xinv_unroll_steps([&](auto rtag) {
+                    constexpr int rr = decltype(rtag)::value;
+                    if (j0 + rr == yc - 1) {                     // (rr > 0 wherever this row matters: p3_extend_ok)
+                        const double2 inner = sw[rr > 0 ? rr - 1 : 0][U];
+                        ext_fix(sw[rr][U], inner);
+                    }
+                }, std::make_integer_sequence<int, RR>{});
+            }
         }
         // as loaded: what the neighbouring wavefronts' next red half-sweep reads of the first / last row
         xch[bw][0][wave][0][lane] = XROW(0) ? sw[0][U].y : sw[0][U].x;

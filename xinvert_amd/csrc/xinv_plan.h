@@ -248,7 +248,8 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         // -- 1.45e11 -- and is gone.)
         pl.K2 = false;
         const int k2_auto = XINV_ENV_INT("XINV_3D_K2", 1);
-        if (p.kind == KIND_STD3D && pl.um == 7u && p.BCy != XINV_BC_EXTEND && !(pl.seam && (pl.fma || p.xc < 64)) &&
+        const bool ext3 = (p.BCy == XINV_BC_EXTEND);      // ('extend': the EXT variant -- not with the seam or the contracted arithmetic)
+        if (p.kind == KIND_STD3D && pl.um == 7u && !(ext3 && (pl.seam || pl.fma || !p3_extend_ok(p.yc))) && !(pl.seam && (pl.fma || p.xc < 64)) &&
             (opt.sweeps_per_launch == 2 || (opt.sweeps_per_launch == 0 && k2_auto)) &&
             opt.rows_per_tile == 0 && p.stop.mxLoop >= 1 &&
             p.zc * p.yc * 64 < ((int64_t)1 << 31) &&                      // (32-bit offsets into the record table)
