@@ -210,7 +210,7 @@ def kernel_name(kind, s):
         vm = s.get('point_factor', 0)
         if vm:
             return 'k_fusedbih (one pass per sweep; %s as vector streams + the point-factor stream Q)' % \
-                   ('A, C, D, F' if vm == 1 else 'A..I')
+                   ({1: 'A, C, D, F', 3: 'A (= C), D (= F)'}.get(vm, 'A..I'))
         return 'k_fusedbih (one pass per sweep, A..I and the relaxation factor as per-row records)'
     if kind == 'std3d':
         if K == 2:
@@ -239,7 +239,7 @@ def streamed_bytes_per_point_sweep(kind, s):
     elif kind == 'std3d':
         nvec = 4 - bin(um & 7).count('1')                   # A, B, C + forcing
     else:                                                   # biharmonic one-pass kernel: the forcing J (+ the vector streams + Q)
-        nvec = 1 + {0: 0, 1: 5, 2: 10}[s.get('point_factor', 0)]
+        nvec = 1 + {0: 0, 1: 5, 2: 10, 3: 3}[s.get('point_factor', 0)]
     return 8.0 * (2 + nvec) / K
 
 

@@ -170,7 +170,8 @@ typedef struct xinv_stats {
                                    update predicate of every point from the stream k_point_factor evaluated once per
                                    coefficient stack; 2 = ... and C out of A (the two hold the same numbers); 0 = in-kernel.
                                    Biharmonic one-pass kernel: 0 = A..I per row (records); 1 = A, C, D, F as vector streams
-                                   + the point-factor stream; 2 = all nine coefficient arrays as vector streams + it       */
+                                   + the point-factor stream; 3 = ... with C read out of A and F out of D (the pairs hold the same
+                                   numbers: Cartesian Munk); 2 = all nine coefficient arrays as vector streams + it        */
     double  plan_ms;            /* wall clock of the planning part of the call (detection passes, host round trips,
                                    tile lists, per-row records); ~0 for a solve on a resident plan                    */
     int32_t k_chunks;           /* two-sweep 3-D pass: chunks the plan cuts a tile's column into where it cuts (1: never)    */

@@ -661,16 +661,21 @@ def _munk_like_bih(p):
 @pytest.mark.parametrize('BCx', ['fixed', 'periodic', 'extend'])
 @pytest.mark.parametrize('rows', [0, 3, 9])
 @pytest.mark.parametrize('shape', [(5, 9), (7, 12), (13, 183), (31, 366), (64, 543), (20, 72), (9, 180)])
-@pytest.mark.parametrize('vm', [1, 2])
+@pytest.mark.parametrize('vm', [1, 2, 3])
 def test_biharmonic_one_pass_vector_streams(BCy, BCx, rows, shape, vm):
     """k_fusedbih with coefficient arrays that vary along x (round 6): vm = 1 -- A, C, D, F as vector streams beside per-row
     G, H, I (Munk with A4(x, y), R(x, y)); vm = 2 -- all nine, mixed derivatives included -- and the point-factor stream Q
-    (relaxation factor, 0 = the reference's predicate on A..I forbids the update).  Bit for bit the oracle's 9-colour
+    (relaxation factor, 0 = the reference's predicate on A..I forbids the update); vm = 3 -- vm = 1 with C read out of A and F
+    out of D where the pairs hold the same numbers.  Bit for bit the oracle's 9-colour
     order and the colour launches: masks in coefficients and forcing, tile seams, periodic wrap with the stale-index east
     columns, a batch with an early stop."""
     if BCx == 'periodic' and shape[1] % 3:
         pytest.skip('periodic x with xc % 3 != 0 runs the colour launches')
-    mk = _munk_like_bih if vm == 1 else (lambda q: q)
+    def alias(q):                                        # vm = 3: C holds A's numbers, F holds D's (Cartesian Munk)
+        q = _munk_like_bih(q)
+        q['coefs'][2] = q['coefs'][0].copy(); q['coefs'][5] = q['coefs'][3].copy()
+        return q
+    mk = {1: _munk_like_bih, 2: (lambda q: q), 3: alias}[vm]
     ps = [mk(randbih(shape[0], shape[1], BCy, BCx, 1, 1, seed=_seed(('bvs', BCy, BCx, shape, m, vm)))) for m in range(2)]
     S, fl, st = run_hip_batched(ps, 25, 1e-4, rows_per_tile=rows)
     assert st['path'] == PATH_FUSED and st['colours'] == 9 and st['point_factor'] == vm, st

@@ -67,7 +67,7 @@ EOF
 prof C2 "k_pipe2d<FusedStd2D" "k_pipe2d<Std2D" 1 1 25920000 python $R/tools/bench_configs.py c2 --reps 4 --sweeps 500
 prof C3-Stommel "k_fused2d<FusedGen2DQ_<true>, 3" "k_fused2d<FusedGen2D, K=3" 1 1 12000000 python $R/tools/bench_configs.py c3 --reps 4 --sweeps 300
 prof C3-Munk "k_fusedbih<false, true, 0>" "k_fusedbih (one pass per sweep, A..I" 1 1 4000000 python $R/tools/bench_configs.py c3m --reps 4 --sweeps 100
-prof C3-Munk-xy "k_fusedbih<false, true, 1>" "k_fusedbih (one pass per sweep; A, C, D, F" 1 1 4000000 python $R/tools/bench_configs.py c3mxy --reps 4 --sweeps 100
+prof C3-Munk-xy "k_fusedbih<false, true, 3>" "k_fusedbih (one pass per sweep; A (= C), D (= F)" 1 1 4000000 python $R/tools/bench_configs.py c3mxy --reps 4 --sweeps 100
 prof C4 "k_pipe2d<FusedGen2D" "k_pipe2d<Gen2D" 8 2 16588800 python $R/tools/bench_configs.py c4 --members 8 --reps 4 --sweeps 200
 prof C1 "k_pipe2d<FusedStd2D" "k_pipe2d<Std2D" 1 1 259200 python $R/tools/bench_configs.py c1 --reps 4 --sweeps 500
 prof C5 "k_pipe3d" "k_pipe3d" 15 1 388800000 python $R/tools/bench_configs.py c5 --members 15 --reps 2

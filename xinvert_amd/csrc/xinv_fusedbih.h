@@ -29,6 +29,8 @@
 //           records through the scalar unit (k_row_factor_bih);
 //   VM = 1  A, C, D, F vary along x (A4(x, y), R(x, y): apps.py:1793-1836 puts A4 into A and C, R / D into D and F),
 //           B == E == 0, G, H, I per row: four vector streams + the point-factor stream Q (round 6);
+//   VM = 3  VM = 1 where A and C hold the same numbers everywhere, and D and F do (Cartesian Munk: apps.py:1823-1829 puts A4
+//           into both A and C, -R / D into both D and F): C is read out of A's registers, F out of D's -- two streams less;
 //   VM = 2  anything: all nine as vector streams + Q.
 // Q (k_point_factor_bih, once per coefficient stack): the point's relaxation factor -optArg / denominator
 // (numbas.py:1474-1477, same expression, same bits), 0 where the reference's predicate on A..I (or the row) forbids the
@@ -142,7 +144,8 @@ struct PointFactorBihArgs {
     int64_t yc, xc, n;            // n = yc * xc
     XinvScal sc_;
     double *q;                    // [nbatch][yc][xc]
-    int *flag;                    // bit 0: an updatable point's factor is +-0 (Q == 0 means "skip": the variants are not used)
+    int *flag;                    // bit 0: an updatable point's factor is +-0 (Q == 0 means "skip": the variants are not used);
+                                  // bit 1: A and C differ somewhere (bitwise); bit 2: D and F do
 };
 
 #ifdef XINV_AUX_KERNELS
@@ -174,13 +177,15 @@ __global__ __launch_bounds__(256) void k_point_factor_bih(PointFactorBihArgs a)
 {
     const int64_t m = blockIdx.y;
     const double u = a.sc_.undef;
-    bool zero = false;
+    bool zero = false, dac = false, ddf = false;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < a.n; t += (int64_t)gridDim.x * 256) {
         const int64_t j = t / a.xc;
         double cs[9];
         bool ok = (j >= 2) && (j <= a.yc - 3);
 #pragma unroll
         for (int q = 0; q < 9; q++) { cs[q] = a.c[q][m * a.sc[q] + t]; ok = ok && (cs[q] != u); }
+        dac = dac || (__double_as_longlong(cs[0]) != __double_as_longlong(cs[2]));
+        ddf = ddf || (__double_as_longlong(cs[3]) != __double_as_longlong(cs[5]));
         double qv = 0.0;
         if (ok) {
             qv = -a.sc_.optArg / ((cs[0]*a.sc_.ratioSSr + cs[2]) * 6.0 +
@@ -192,15 +197,17 @@ __global__ __launch_bounds__(256) void k_point_factor_bih(PointFactorBihArgs a)
         a.q[m * a.n + t] = qv;
     }
     if (__any(zero) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 1);
+    if (__any(dac) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 2);
+    if (__any(ddf) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 4);
 }
 #endif
 
 template <bool PER, bool ZBE, int VM = 0>
 __global__ __launch_bounds__(256, VM == 2 ? 1 : 2) void k_fusedbih(FusedBihArgs a)
 {
-    static_assert(VM != 1 || ZBE, "VM = 1: B and E are identically zero");
+    static_assert((VM != 1 && VM != 3) || ZBE, "VM = 1, 3: B and E are identically zero");
     constexpr int D = 9;
-    constexpr int NV = VM == 0 ? 0 : (VM == 1 ? 4 : 9);  // coefficient streams read as vectors
+    constexpr int NV = VM == 0 ? 0 : (VM == 1 ? 4 : (VM == 3 ? 2 : 9));  // coefficient streams read as vectors
     xinv_fresh_scalar_cache();                         // (the per-row records come through the scalar unit: DESIGN.md 4.8)
     const int64_t m = a.member0 + blockIdx.y;
     XinvCtl *ctl = a.ctl + m;
@@ -328,9 +335,10 @@ __global__ __launch_bounds__(256, VM == 2 ? 1 : 2) void k_fusedbih(FusedBihArgs 
         const double *pQ = nullptr;
         if constexpr (VM > 0) {
             constexpr int idx1[4] = {0, 2, 3, 5};            // A, C, D, F
+            constexpr int idx3[2] = {0, 3};                  // A (= C), D (= F)
 #pragma unroll
             for (int t = 0; t < NV; t++) {
-                const int q = (VM == 1) ? idx1[t < 4 ? t : 0] : t;
+                const int q = (VM == 1) ? idx1[t < 4 ? t : 0] : (VM == 3 ? idx3[t < 2 ? t : 0] : t);
                 cpv[t] = a.c[q] + m * a.sc[q];
             }
             pQ = a.q + m * yc * xc;
@@ -382,6 +390,10 @@ __global__ __launch_bounds__(256, VM == 2 ? 1 : 2) void k_fusedbih(FusedBihArgs 
                     rq = R.rq; cok = rowok;
                 } else if constexpr (VM == 1) {
                     cA = V.a[0].v[k]; cC = V.a[1].v[k]; cD = V.a[2].v[k]; cF = V.a[3].v[k];
+                    cB = 0.0; cE = 0.0; cG = cs[6]; cH = cs[7]; cI = cs[8];
+                    rq = V.q.v[k]; cok = (rq != 0.0);
+                } else if constexpr (VM == 3) {
+                    cA = V.a[0].v[k]; cC = cA; cD = V.a[1].v[k]; cF = cD;
                     cB = 0.0; cE = 0.0; cG = cs[6]; cH = cs[7]; cI = cs[8];
                     rq = V.q.v[k]; cok = (rq != 0.0);
                 } else {

@@ -90,6 +90,7 @@ static int plan_fusedbih(const Problem &p, const xinv_options &opt, Workspace *w
                                dim3(256), 0, st, fa);
             HIPCHK(hipMemcpyAsync(ws->hflag, ws->dflag, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (pl.bih_vm == 1 && !(*ws->hflag & 6)) pl.bih_vm = 3;      // A == C and D == F everywhere (bitwise): two streams less
             if (*ws->hflag & 1) {                        // (a factor of exactly zero somewhere: Q == 0 could not mean "skip")
                 if (opt.path == XINV_PATH_FUSED)
                     return fail_arg("biharmonic form: a relaxation factor of exactly zero on an updatable point -- the colour launches handle it");
