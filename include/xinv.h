@@ -130,7 +130,12 @@ typedef struct xinv_options {
                                    into k chunks so that they do not march alone (xinv_pipe3d.h).  A smaller count makes
                                    small test problems take that path; it never changes a result.  -1: the device's count,
                                    without that cut (A/B comparisons); -n: n units, without it.                        */
-    int32_t reserved_;          /* (keeps the struct a multiple of 8 bytes)                                            */
+    int32_t host_inflight;      /* host-pointer entries: chunk solves in flight on a device at a time (1 .. 6; 0 = the
+                                   library's choice): every one is a chain of dependent launches on a stream and a
+                                   workspace of its own; their launches fill each other's tails.  The standard 3-D form with
+                                   shared coefficient arrays runs a ROLLING batch instead where it is left at 0 (and
+                                   host_chunk is): one chain of launches over the members that have arrived and are
+                                   not done yet (xinv_hostptr.h); -1 takes the rolling batch for any batch of two or more */
 } xinv_options;
 
 #define XINV_PREP_MASK_NAN   1  /* the forcing (last coefficient array) marks masked points with NaN   */

@@ -127,3 +127,40 @@ def test_members_beyond_2G_elements(kind, BCy, BCx, opt):
     assert np.array_equal(fl[0::2, [0, 2]], np.tile(fl[0, [0, 2]], (NB // 2, 1)))
     assert np.allclose(fl[0::2, 1], fl[0, 1], rtol=0, atol=1e-12)
     assert bool(torch.isfinite(S[NB - 1][S[NB - 1] != util.U]).all())
+
+
+@pytest.mark.parametrize('BCy', ['fixed', 'extend'])
+@pytest.mark.parametrize('sweeps,tol', [(24, 0.0), (25, 0.0), (400, 3e-3)])
+@pytest.mark.parametrize('uni', [0, 1])
+def test_rolling_batch_3d_host_pointers(BCy, sweeps, tol, uni):
+    """The host-pointer entry of the standard 3-D form with shared coefficient arrays runs a ROLLING batch (xinv_hostptr.h:
+    roll_3d): one chain of launches over the volumes that have arrived and still have sweeps to do -- a volume joins at an
+    even launch, retires after its budget (an odd budget: a last one-sweep launch for the retiring group beside the
+    others' two-sweep launch), a volume the tolerance stops earlier idles, one that stops INSIDE a pass is redone from that
+    pass's source.  Bit for bit the oracle per volume, flags included; `host_inflight = -1` takes the path at this size."""
+    from util import rand3d
+    nb = 7
+    base = rand3d(12, 40, 136, BCy, 'periodic', 1, seed=900)
+    if uni:
+        for q in range(3):
+            base['coefs'][q][:] = base['coefs'][q][:, :, :1]
+    ps = []
+    for m in range(nb):
+        q = dict(base)
+        r = rand3d(12, 40, 136, BCy, 'periodic', 1, seed=901 + m)
+        q['coefs'] = list(base['coefs'][:3]) + [r['coefs'][3]]
+        q['S0'] = r['S0']
+        ps.append(q)
+    S, fl, st = util.run_hip_batched(ps, sweeps - 1, tol, shared=(0, 1, 2), host_inflight=-1)
+    assert st['path'] == 2 and st['host_chunks'] == nb, st
+    loops = set()
+    for m, q in enumerate(ps):
+        So, flo = util.run_oracle(q, sweeps - 1, tol, 2)
+        assert np.array_equal(S[m], So), 'member %d: %d points differ' % (m, (S[m] != So).sum())
+        assert fl[m][0] == flo[0] and fl[m][2] == flo[2] and abs(fl[m][1] - flo[1]) <= 1e-12 * max(1.0, abs(flo[1])), (m, fl[m], flo)
+        loops.add(int(flo[2]))
+    if tol > 0:
+        assert len(loops) > 1 and {l % 2 for l in loops} == {0, 1}, loops      # (stops at both parities: inside and at the end of a pass)
+    # the chunked pipeline gives the same fields
+    S2, fl2, st2 = util.run_hip_batched(ps, sweeps - 1, tol, shared=(0, 1, 2), host_chunk=2)
+    assert np.array_equal(S, S2) and np.array_equal(fl[:, [0, 2]], fl2[:, [0, 2]])

@@ -13,6 +13,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument('config', nargs='?', default='c5')
 ap.add_argument('--members', type=int, default=15)
 ap.add_argument('--sweeps', type=int, default=200)
+ap.add_argument('--chunks', default='', help='comma list of host_chunk values to time (default: a sweep over several)')
+ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--lanes', type=int, default=0)
+ap.add_argument('--inflight', default='0', help='comma list of xinv_options.host_inflight values')
 a = ap.parse_args()
 p = synthetic.omega_latlon(50, 360, 720, a.members) if a.config == 'c5' else synthetic.gill_matsuno(720, 1440, a.members)
 L = _lib.require_gpu()
@@ -32,12 +36,13 @@ for k, c in enumerate(p['coefs']):
     c = np.ascontiguousarray(c, dtype=np.float64)
     null = (k == 1 and p['kind'] in ('std2d', 'gen2d') and not c.any())
     arrs.append(None if null else c); strides.append(0 if k in shared else n)
-for chunk in (nb, 0, 1, 2, 3, 5):
+for chunk, infl in [(c_, i_) for c_ in ([int(v) for v in a.chunks.split(',')] if a.chunks else (nb, 0, 1, 2, 3, 5))
+                    for i_ in [int(v) for v in a.inflight.split(',')]]:
     best = 1e9
-    for rep in range(3):
+    for rep in range(a.reps):
         S = arrs[0].copy()
         fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
-        o = _lib.options(host_chunk=chunk)
+        o = _lib.options(host_chunk=chunk, host_inflight=infl, lanes=a.lanes)
         t = time.perf_counter()
         rc = getattr(L, FN[p['kind']] + '_batched')(_lib.hptr(S), *[_lib.hptr(x) for x in arrs[1:]], nb, _lib.strides_arg(strides),
                                                     *scalars(p), _lib.hptr(fl), a.sweeps - 1, 0.0, ctypes.byref(o))
@@ -45,6 +50,6 @@ for chunk in (nb, 0, 1, 2, 3, 5):
         _lib.check(rc)
         if dt < best:
             best, st = dt, _lib.last_stats()
-    print(json.dumps({'entry': 'host pointers', 'host_chunk': chunk, 'chunks': st['host_chunks'], 'wall_ms': best * 1e3,
+    print(json.dumps({'entry': 'host pointers', 'host_chunk': chunk, 'inflight': infl, 'chunks': st['host_chunks'], 'wall_ms': best * 1e3,
                       'h2d_ms': st['h2d_ms'], 'd2h_ms': st['d2h_ms'], 'vs_dev': best / dev_s,
                       'point_sweeps_per_s': nb * n * a.sweeps / best}), flush=True)

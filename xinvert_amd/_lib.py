@@ -33,7 +33,7 @@ class XinvOptions(ctypes.Structure):
                 ('prep_rowscale', ctypes.POINTER(ctypes.c_double)),
                 ('lanes', ctypes.c_int32), ('norm_lag', ctypes.c_int32),
                 ('pipe_fr', ctypes.c_int32), ('graph', ctypes.c_int32),
-                ('cu_count', ctypes.c_int32), ('reserved_', ctypes.c_int32)]
+                ('cu_count', ctypes.c_int32), ('host_inflight', ctypes.c_int32)]
 
 
 class XinvStats(ctypes.Structure):
@@ -178,7 +178,7 @@ def check(rc):
 def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_per_tile=0,
             timing=0, no_xuniform=0, no_tile_skip=0, force_tile_skip=0, rowconst_mask=0,
             host_chunk=0, devices=None, prep=None, pin_host=0, no_pipe=0, fma=0, f32_mask=0,
-            lanes=0, norm_lag=0, pipe_fr=0, graph=0, no_point_factor=0, cu_count=0):
+            lanes=0, norm_lag=0, pipe_fr=0, graph=0, no_point_factor=0, cu_count=0, host_inflight=0):
     o = XinvOptions()
     load().xinv_default_options(ctypes.byref(o))
     o.device, o.path, o.sweeps_per_launch = device, path, sweeps_per_launch
@@ -193,6 +193,7 @@ def options(device=-1, path=PATH_AUTO, sweeps_per_launch=0, check_every=0, rows_
     # expert overrides of the planner (0 = its own choice); the library reads no environment variable
     o.lanes, o.norm_lag, o.pipe_fr, o.graph = int(lanes), int(norm_lag), int(pipe_fr), int(graph)
     o.cu_count = int(cu_count)
+    o.host_inflight = int(host_inflight)
     # prep: front-end passes on the device -- dict(mask='nan' | value, rowscale=vec | None,
     # s_zero=bool, demask=value | None); the row-scale array is kept alive on the options object
     if prep:

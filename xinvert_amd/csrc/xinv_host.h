@@ -253,6 +253,8 @@ static int bind_thread_to_device_node(int device)
 // ------------------------------------------------------------------ per-device workspace
 // Grown on demand, reused across solves (no hipMalloc in steady state).
 #define XINV_MAX_LANES 4
+#define XINV_MAX_INFLIGHT 6          /* host-pointer entries: chunk solves in flight on one device (workspace slots 0 .. 5) */
+#define XINV_DEFAULT_INFLIGHT 2
 struct Workspace {
     int device = -1;
     int cus = 0;                                        // the device's compute units (make_plan)

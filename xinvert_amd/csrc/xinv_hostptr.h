@@ -41,6 +41,12 @@ static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &op
         for (int64_t m0 = 0; m0 < nb; m0 += mc) out.push_back(std::min(mc, nb - m0));
         return out;
     }
+    if (opt.host_chunk < 0) {                              // -k: a ramp 1, 2, 4, .. up to k members, then chunks of k
+        const int64_t kmax = -(int64_t)opt.host_chunk;
+        int64_t left = nb, c = 1;
+        while (left > 0) { const int64_t t = std::min(std::min(c, kmax), left); out.push_back(t); left -= t; c *= 2; }
+        return out;
+    }
     const int64_t n = p.zc * p.yc * p.xc;
     int per_member = 1;                                   // S
     for (int q = 0; q < p.ncoef; q++) per_member += (p.c[q] && p.sc[q] != 0 && !((p.rowconst >> q) & 1u)) ? 1 : 0;
@@ -52,8 +58,11 @@ static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &op
     // Measured (profiles/r05_host_pipeline.txt): C5, 15 volumes -- 1 chunk 212 ms, [4, 7, 4] (round 4's split) 172,
     // chunks of 2 volumes 161, of 1 volume 200; C4, 8 members -- 1 chunk 15.4 ms, chunks of 2 members 14.1, of 1: 17.2.
     if (total < 100663296.0 || nb < 4) { out.push_back(nb); return out; }
-    if (is3d(p.kind)) {                                   // up to eight chunks of at least two volumes, the remainder LAST
-        const int64_t nch = std::min<int64_t>(8, (nb + 1) / 2), per = (nb + nch - 1) / nch;
+    if (is3d(p.kind)) {
+        // Round 6 (profiles/r06_host_pipeline.txt; C5 x 15, ms): chunks of three volumes, THREE chunk solves in flight, each
+        // one launch chain (no lanes inside a chunk): 148; chunks of two, two in flight -- round 5 -- 160-167; three
+        // in flight 155; chunks of four 154-168; ramps 1, 2, 4, .. 163-173.  The remainder LAST.
+        const int64_t per = nb >= 6 ? 3 : 2;
         for (int64_t m0 = 0; m0 < nb; m0 += per) out.push_back(std::min(per, nb - m0));
         return out;
     }
@@ -71,21 +80,22 @@ static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &op
 // last chunk's download.  Members are independent (reference core.py:129: no cross-slice state), so the
 // chunking cannot change any result.
 struct HostActors {                                   // joins the helper threads and drains the streams on EVERY return path
-    std::thread up, down, solver2;                    // (solver2: the odd chunks' solves, beside the calling thread's)
+    std::thread up, down;
+    std::vector<std::thread> solvers;                 // helper threads: chunk solves in flight beside the calling thread's
     std::mutex mu;
     std::condition_variable cv;
     std::vector<char> chunk_ready;                    // set by the uploader once chunk c's event is recorded
     std::deque<std::function<int()>> dq;              // download jobs
     bool d_closed = false, abort = false;
-    int u_rc = 0, d_rc = 0, s2_rc = 0;                // (s2: the helper solver thread's verdict -- kept here: this object
-    std::string u_err, d_err, s2_err;                 //  outlives the thread on every return path)
+    int u_rc = 0, d_rc = 0, s2_rc = 0;                // (s2: the first failing helper solver thread's verdict -- kept here: this
+    std::string u_err, d_err, s2_err;                 //  object outlives the threads on every return path)
     std::vector<hipStream_t> streams;
     void close_downloads() { { std::lock_guard<std::mutex> lk(mu); d_closed = true; } cv.notify_all(); }
     ~HostActors()
     {
         { std::lock_guard<std::mutex> lk(mu); abort = true; d_closed = true; }
         cv.notify_all();
-        if (solver2.joinable()) solver2.join();       // (before the downloader: it still queues download jobs)
+        for (auto &t : solvers) if (t.joinable()) t.join();      // (before the downloader: they still queue download jobs)
         if (up.joinable()) up.join();
         if (down.joinable()) down.join();
         for (hipStream_t s : streams) (void)hipStreamSynchronize(s);      // nothing of this call stays in flight
@@ -128,7 +138,15 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         (rc = ev.make(&e_dn1, true))) return rc;
 
     const int64_t hsS = p.nbatch > 1 ? p.sS : n;
-    const std::vector<int64_t> chunks = host_chunks(p, opt);
+    // The rolling batch (round 6; roll_3d below): ONE chain of launches over the members that have arrived and are not done
+    // yet, instead of one solve per chunk.  For the standard 3-D form with shared coefficient arrays (its plan reads nothing
+    // of a member's own), on the streaming path, where the planner is left to itself.
+    // (xinv_options.host_inflight = -1 takes it for any batch of two or more: the tests' small volumes)
+    bool rolling = p.kind == KIND_STD3D && opt.host_chunk == 0 && opt.host_inflight <= 0 &&
+                   opt.path != XINV_PATH_COLOUR && !(p.BCx == XINV_BC_PERIODIC && (p.xc & 1) && p.xc < 64) &&
+                   ((p.nbatch >= 4 && (double)n * 16.0 * (double)p.nbatch >= 100663296.0) || (opt.host_inflight < 0 && p.nbatch >= 2));
+    for (int q = 0; q + 1 < p.ncoef; q++) rolling = rolling && p.c[q] && (p.nbatch == 1 || p.sc[q] == 0);
+    const std::vector<int64_t> chunks = rolling ? std::vector<int64_t>((size_t)p.nbatch, 1) : host_chunks(p, opt);
     const int64_t nchunk = (int64_t)chunks.size();
     std::vector<int64_t> first((size_t)nchunk + 1, 0);
     for (int64_t c = 0; c < nchunk; c++) first[(size_t)c + 1] = first[(size_t)c] + chunks[(size_t)c];
@@ -345,19 +363,27 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // evenly than the whole batch -- the 3-D kernels run ceil(workgroups / 256) rounds, every 2-D launch ends with a
     // tail --; with the next chunk's launches already queued on the device those holes are filled, as the two launch
     // chains of a device-resident batch fill each other's (the lanes of run_sweeps).
-    Workspace *ws1 = (nchunk > 1) ? get_ws(device, 1) : nullptr;
-    hipStream_t scp1 = nullptr;
-    if (ws1) {
-        if (!ws1->s_compute) HIPCHK(hipStreamCreateWithFlags(&ws1->s_compute, hipStreamNonBlocking));
-        scp1 = ws1->s_compute;
-        act.streams.push_back(scp1);
+    // How many chunk solves are in flight: every one is a chain of dependent launches, and a launch of a two-volume chunk
+    // (276 tiles on 256 CUs) ends in a tail during which only the OTHER chains' launches keep the CUs busy.  Two chains
+    // (round 5) left the chip 1.68 launches deep on average -- C5 x 15: 160 ms of which the GPU is busy 160, at 107 us per
+    // volume and launch against 77 for the resident batch (profiles/r06_host_pipeline.txt) --; three / four fill the tails.
+    const int ninfl = (int)std::min<int64_t>(nchunk, std::max(1, opt.host_inflight > 0 ? std::min(opt.host_inflight, XINV_MAX_INFLIGHT)
+                                                                                         : (is3d(p.kind) ? 3 : XINV_DEFAULT_INFLIGHT)));
+    std::vector<Workspace *> wss((size_t)ninfl, nullptr);
+    std::vector<hipStream_t> scps((size_t)ninfl, nullptr);
+    wss[0] = ws; scps[0] = scp;
+    for (int k = 1; k < ninfl; k++) {
+        wss[(size_t)k] = get_ws(device, k);
+        if (!wss[(size_t)k]->s_compute) HIPCHK(hipStreamCreateWithFlags(&wss[(size_t)k]->s_compute, hipStreamNonBlocking));
+        scps[(size_t)k] = wss[(size_t)k]->s_compute;
+        act.streams.push_back(scps[(size_t)k]);
     }
     // the workspaces grow on demand: size them for the LARGEST chunk now, so that a later, larger chunk does not pay a
     // free + malloc of the ping-pong buffer (or of the pinned control-block mirror) mid-pipeline
     {
         const int64_t mmax = *std::max_element(chunks.begin(), chunks.end());
         if (nchunk > 1 && p.kind != KIND_BIH2D)
-            for (Workspace *w : { ws, ws1 }) {
+            for (Workspace *w : wss) {
                 if ((rc = ensure_dev(&w->S2, &w->S2_cap, (size_t)mmax * n * sizeof(double)))) return rc;
                 if ((rc = ensure_dev(&w->ctl, &w->ctl_cap, (size_t)mmax * sizeof(XinvCtl)))) return rc;
                 if (w->hctl_cap < (size_t)mmax) {
@@ -374,6 +400,46 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     unsigned shared_um = 0;
     xinv_options o1 = opt;
     o1.device = device; o1.ndev = 0;
+    if (is3d(p.kind) && nchunk > 1 && o1.lanes == 0) o1.lanes = 1;      // (several chunk solves in flight already: one chain each)
+    // members [m0, m0 + nm): S is final on the device in stream order of `cs` -- the output passes (de-mask, float32), then
+    // the hand-over to the downloader.  `after`: an event to record behind them for the downloader to wait on (the rolling
+    // batch: no host synchronisation of the compute stream); nullptr: synchronise `cs` here.
+    auto finish_members = [&](int64_t m0, int64_t nm, hipStream_t cs, hipEvent_t after) -> int {
+        if (opt.prep_flags & XINV_PREP_DEMASK) {
+            for (int64_t m = 0; m < nm; m++) {
+                const double *dF = d.c[fq] + (per_member[fq] ? (m0 + m) * n : 0);
+                hipLaunchKernelGGL(k_demask, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, cs,
+                                   d.S + (m0 + m) * n, dF, n, p.sc_.undef, opt.demask_value);
+            }
+        }
+        if (tmpS_dn)                                     // float32 S: rounded on the device, half the bytes back
+            hipLaunchKernelGGL(k_demote_f64, dim3((unsigned)std::min<int64_t>(4096, (nm * n + 255) / 256)), dim3(256), 0, cs,
+                               (const double *)(d.S + m0 * n), tmpS_dn + m0 * n, nm * n);
+        if (after) HIPCHK(hipEventRecord(after, cs));
+        else if ((opt.prep_flags & XINV_PREP_DEMASK) || tmpS_dn) HIPCHK(hipStreamSynchronize(cs));
+        {
+            char *hS = (char *)p.S;
+            const char *dS = tmpS_dn ? (const char *)tmpS_dn : (const char *)d.S;
+            const size_t es = tmpS_dn ? 4 : 8;
+            const Pinned *pinp = &pin;
+            std::lock_guard<std::mutex> lk(act.mu);
+            act.dq.push_back([=]() -> int {
+                if (after) HIPCHK(hipStreamWaitEvent(sdn, after, 0));
+                auto one = [&](char *h, const char *dv, size_t bytes) -> int {
+                    if (pinp->covers(h, bytes)) { HIPCHK(hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, sdn)); return XINV_OK; }
+                    return stage_d2h(ws->ring_down, sdn, (double *)h, (const double *)dv, bytes);
+                };
+                if (hsS == n || nm == 1) return one(hS + (size_t)m0 * hsS * es, dS + (size_t)m0 * n * es, (size_t)nm * n * es);
+                for (int64_t m = m0; m < m0 + nm; m++) {
+                    int rr = one(hS + (size_t)m * hsS * es, dS + (size_t)m * n * es, (size_t)n * es);
+                    if (rr) return rr;
+                }
+                return XINV_OK;
+            });
+        }
+        act.cv.notify_all();
+        return XINV_OK;
+    };
     // one chunk: wait for its upload, solve it on `cs` (workspace `slot`), run the output passes, hand it to the downloader
     auto do_chunk = [&](int64_t c, hipStream_t cs, int slot) -> int {
         const int64_t m0 = first[(size_t)c], nm = chunks[(size_t)c];
@@ -405,55 +471,179 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             }
         }
         // solve_dev has returned: the chunk's S is final on the device
-        if (opt.prep_flags & XINV_PREP_DEMASK) {
-            for (int64_t m = 0; m < nm; m++) {
-                const double *dF = d.c[fq] + (per_member[fq] ? (m0 + m) * n : 0);
-                hipLaunchKernelGGL(k_demask, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, cs,
-                                   d.S + (m0 + m) * n, dF, n, p.sc_.undef, opt.demask_value);
-            }
-            HIPCHK(hipStreamSynchronize(cs));
+        return finish_members(m0, nm, cs, nullptr);
+    };
+    // ---- the rolling batch (standard 3-D form, shared coefficients) ---------------------------------------------------
+    // Every chunk solve above is a chain of small launches -- a two-volume launch of k_pipe3d is 276 tiles on 256 CUs -- and
+    // with two or three chains in flight the chip still ran at 107 us per volume and launch against 77 for the resident
+    // batch (profiles/r06_host_pipeline.txt).  Here ONE chain of launches sweeps the members [lo, hi) that have arrived and
+    // still have sweeps to do: a volume joins at the next even launch after its upload event (its S sits in buffer 0, the
+    // launches ping-pong), runs its L = ceil(sweeps / K) launches -- the device-side stop rule counts its sweeps, whatever
+    // the launch index -- and retires (FIFO: every member runs the same budget; a member the tolerance stopped earlier
+    // idles through its remaining launches as a no-op).  Members are independent (reference core.py:129), so what a
+    // launch covers cannot change any result.  The host stays two launches ahead of the GPU, so that a join is decided
+    // when the launch is about to run; a retired member's control block travels behind its last launch, its final state
+    // is put into S as finalise() does (the redo of a pass the stop rule fired in: from that pass's source, intact since),
+    // and the downloader takes it from there behind an event.
+    auto roll_3d = [&]() -> int {
+        const int64_t nb = p.nbatch;
+        {   // the plan needs the shared coefficient arrays: they travel ahead of member 0
+            std::unique_lock<std::mutex> lk(act.mu);
+            act.cv.wait(lk, [&] { return act.chunk_ready[0] != 0 || act.abort; });
+            if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
+            if (act.abort) { t_err = "host-pointer solve aborted"; return XINV_ERR_HIP; }
         }
-        if (tmpS_dn) {                                   // float32 S: rounded on the device, half the bytes back
-            hipLaunchKernelGGL(k_demote_f64, dim3((unsigned)std::min<int64_t>(4096, (nm * n + 255) / 256)), dim3(256), 0, cs,
-                               (const double *)(d.S + m0 * n), tmpS_dn + m0 * n, nm * n);
-            HIPCHK(hipStreamSynchronize(cs));
+        HIPCHK(hipStreamWaitEvent(scp, e_chunk[0], 0));
+        int r = ws_ready(ws);
+        if (r) return r;
+        memset(&t_stats, 0, sizeof t_stats);
+        const auto t_plan0 = std::chrono::steady_clock::now();
+        Plan pl;
+        r = make_plan(d, o1, ws, scp, pl);
+        if (r) return r;
+        if (pl.path != XINV_PATH_FUSED) { t_err = "internal: rolling batch without a streaming kernel"; return XINV_ERR_HIP; }
+        const double plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
+        // workspace (run_sweeps' own, without the lagged norm: never in 3-D)
+        r = tail_wait(ws, scp);
+        if (r) return r;
+        if ((r = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)nb * sizeof(XinvCtl)))) return r;
+        if (ws->hctl_cap < (size_t)nb) {
+            if (ws->hctl) HIPCHK(hipHostFree(ws->hctl));
+            ws->hctl = nullptr; ws->hctl_cap = 0;
+            HIPCHK(hipHostMalloc((void **)&ws->hctl, 2 * (size_t)nb * sizeof(XinvCtl), XINV_HOST_COHERENT));
+            ws->hctl_cap = (size_t)nb;
         }
-        {
-            char *hS = (char *)p.S;
-            const char *dS = tmpS_dn ? (const char *)tmpS_dn : (const char *)d.S;
-            const size_t es = tmpS_dn ? 4 : 8;
-            const Pinned *pinp = &pin;
-            std::lock_guard<std::mutex> lk(act.mu);
-            act.dq.push_back([=]() -> int {
-                auto one = [&](char *h, const char *dv, size_t bytes) -> int {
-                    if (pinp->covers(h, bytes)) { HIPCHK(hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, sdn)); return XINV_OK; }
-                    return stage_d2h(ws->ring_down, sdn, (double *)h, (const double *)dv, bytes);
-                };
-                if (hsS == n || nm == 1) return one(hS + (size_t)m0 * hsS * es, dS + (size_t)m0 * n * es, (size_t)nm * n * es);
-                for (int64_t m = m0; m < m0 + nm; m++) {
-                    int rr = one(hS + (size_t)m * hsS * es, dS + (size_t)m * n * es, (size_t)n * es);
-                    if (rr) return rr;
+        const size_t pbytes = (partial_bytes(d, pl) + 255) & ~(size_t)255;
+        ws->partials_half = pbytes;
+        if ((r = ensure_dev(&ws->partials, &ws->partials_cap, pbytes))) return r;
+        if ((r = ensure_dev(&ws->S2, &ws->S2_cap, (size_t)nb * n * sizeof(double)))) return r;
+        hipLaunchKernelGGL(k_solve_init, dim3((unsigned)std::max<int64_t>(cdiv(nb, 256), std::min<int64_t>(256, cdiv((int64_t)(pbytes / 16), 256)))),
+                           dim3(256), 0, scp, ws->ctl, nb, (uint4 *)ws->partials, (int64_t)(pbytes / 16));
+        double *buf[2] = { d.S, ws->S2 };
+        const int64_t max_sweeps = d.stop.mxLoop + 1;
+        const int Kf = pl.K;
+        const int64_t L = (max_sweeps + Kf - 1) / Kf;               // launches of a member
+        const int klast = (int)(max_sweeps - (L - 1) * Kf);           // sweeps of its last one
+        std::vector<int64_t> join((size_t)nb, -1);
+        struct Retired { int64_t a, b; hipEvent_t ctl_done; };
+        std::deque<Retired> fin;
+        constexpr int NQ = 4;
+        hipEvent_t ev_l[NQ];
+        for (int q = 0; q < NQ; q++) if ((r = ev.make(&ev_l[q], false))) return r;
+        hipEvent_t ev_t0, ev_t1;
+        if ((r = ev.make(&ev_t0, true)) || (r = ev.make(&ev_t1, true))) return r;
+        HIPCHK(hipEventRecord(ev_t0, scp));
+        XinvCtl *hc = ws->hctl;
+        int64_t nlaunch = 0, sweeps_max = 0;
+        // a retired group whose control blocks have arrived: final state into S, flags, output passes, download
+        auto finish = [&](const Retired &g) -> int {
+            for (int64_t m = g.a; m < g.b; m++) {
+                const XinvCtl &c = hc[m];
+                if (!c.done) { t_err = "internal: rolling batch: a member retired before its stop rule fired"; return XINV_ERR_HIP; }
+                if (c.overflow == 2) { t_err = "internal: norm partials of a sweep launch never arrived (watchdog) in the rolling batch"; return XINV_ERR_HIP; }
+                const int64_t sw = c.sweeps;
+                const int64_t rl = (sw - 1) / Kf;                   // the member's launch that holds sweep sw (0-based)
+                const int64_t lend = std::min<int64_t>((rl + 1) * Kf, max_sweeps);
+                int where;
+                if (sw == lend) where = (int)((join[(size_t)m] + rl + 1) & 1);
+                else {                                              // stopped inside a pass: redo from its source, sweep by sweep
+                    int cur = (int)((join[(size_t)m] + rl) & 1);
+                    for (int64_t q = rl * Kf; q < sw; q++) {
+                        int rr = launch_planned(d, pl, ws, scp, 1, buf[cur], buf[cur ^ 1], m, 1, 1, 1);
+                        if (rr) return rr;
+                        cur ^= 1;
+                    }
+                    where = cur;
                 }
-                return XINV_OK;
-            });
+                if (where != 0)
+                    HIPCHK(hipMemcpyAsync(d.S + m * n, ws->S2 + m * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, scp));
+                if (c.overflow) flags[3 * m + 0] = 1.0;
+                if (c.wrote) { flags[3 * m + 1] = c.flag1; flags[3 * m + 2] = c.flag2; }
+                sweeps_max = std::max<int64_t>(sweeps_max, sw);
+            }
+            hipEvent_t after;
+            int rr = ev.make(&after, false);
+            if (rr) return rr;
+            return finish_members(g.a, g.b - g.a, scp, after);
+        };
+        int64_t lo = 0, hi = 0;
+        for (int64_t i = 0; lo < nb; i++) {
+            if (!(i & 1)) {                                          // a join point: buffer 0 is the source of this launch
+                int64_t nh = hi;
+                {
+                    std::unique_lock<std::mutex> lk(act.mu);
+                    if (hi == lo && hi < nb)                         // nobody active: wait for the next arrival
+                        act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)hi] != 0 || act.abort; });
+                    if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
+                    if (act.abort) { t_err = "host-pointer solve aborted"; return XINV_ERR_HIP; }
+                    while (nh < nb && act.chunk_ready[(size_t)nh]) nh++;
+                }
+                for (int64_t m = hi; m < nh; m++) { HIPCHK(hipStreamWaitEvent(scp, e_chunk[(size_t)m], 0)); join[(size_t)m] = i; }
+                hi = nh;
+            }
+            if (hi > lo) {
+                int64_t f = lo;                                      // [lo, f): their last launch (klast sweeps)
+                while (f < hi && i - join[(size_t)f] == L - 1) f++;
+                const double *src = buf[i & 1];
+                double *dst = buf[(i + 1) & 1];
+                if (klast == Kf) {                                   // (a budget that is whole passes: one launch for everybody)
+                    r = launch_planned(d, pl, ws, scp, Kf, src, dst, lo, hi - lo, 0, 0); if (r) return r; nlaunch++;
+                } else {
+                    if (f > lo) { r = launch_planned(d, pl, ws, scp, klast, src, dst, lo, f - lo, 0, 0); if (r) return r; nlaunch++; }
+                    if (hi > f) { r = launch_planned(d, pl, ws, scp, Kf, src, dst, f, hi - f, 0, 0); if (r) return r; nlaunch++; }
+                }
+                if (f > lo) {
+                    HIPCHK(hipMemcpyAsync(hc + lo, ws->ctl + lo, (size_t)(f - lo) * sizeof(XinvCtl), hipMemcpyDeviceToHost, scp));
+                    Retired g{lo, f, nullptr};
+                    if ((r = ev.make(&g.ctl_done, false))) return r;
+                    HIPCHK(hipEventRecord(g.ctl_done, scp));
+                    fin.push_back(g);
+                    lo = f;
+                }
+            }
+            HIPCHK(hipEventRecord(ev_l[i % NQ], scp));
+            if (i >= 2) HIPCHK(hipEventSynchronize(ev_l[(i - 2) % NQ]));     // two launches ahead of the GPU, no more
+            while (!fin.empty() && hipEventQuery(fin.front().ctl_done) == hipSuccess) {
+                r = finish(fin.front()); if (r) return r;
+                fin.pop_front();
+            }
+            (void)hipGetLastError();                                 // (hipEventQuery: hipErrorNotReady is not an error)
         }
-        act.cv.notify_all();
+        while (!fin.empty()) {
+            HIPCHK(hipEventSynchronize(fin.front().ctl_done));
+            r = finish(fin.front()); if (r) return r;
+            fin.pop_front();
+        }
+        HIPCHK(hipEventRecord(ev_t1, scp));
+        HIPCHK(hipStreamSynchronize(scp));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev_t0, ev_t1));
+        t_stats.path = pl.path; t_stats.colours = pl.ncol; t_stats.sweeps_per_launch = Kf; t_stats.rows_per_tile = pl.RY;
+        t_stats.xuniform_mask = (int32_t)pl.um; t_stats.lanes = 1; t_stats.sweep_launches = nlaunch;
+        t_stats.sweeps_max = sweeps_max; t_stats.sweep_ms = ms; t_stats.plan_ms = plan_ms;
+        t_stats.k_chunks = pl.K2 ? std::max(1, pl.nkc2) : 0;
+        acc = t_stats; acc_set = true;
         return XINV_OK;
     };
-    if (nchunk > 1)
-        act.solver2 = std::thread([&]() {
+    if (rolling) {
+        rc = roll_3d();
+        if (rc) return rc;
+    } else {
+    for (int k = 1; k < ninfl; k++)
+        act.solvers.emplace_back([&, k]() {
             int r = (hipSetDevice(device) == hipSuccess) ? XINV_OK : XINV_ERR_HIP;
-            for (int64_t c = 1; c < nchunk && !r; c += 2) {
-                try { r = do_chunk(c, scp1, 1); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
+            for (int64_t c = k; c < nchunk && !r; c += ninfl) {
+                try { r = do_chunk(c, scps[(size_t)k], k); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; }
             }
-            act.s2_rc = r; if (r) act.s2_err = t_err;
+            if (r) { std::lock_guard<std::mutex> lk(act.mu); if (!act.s2_rc) { act.s2_rc = r; act.s2_err = t_err; } }
         });
-    for (int64_t c = 0; c < nchunk; c += 2) {
+    for (int64_t c = 0; c < nchunk; c += ninfl) {
         rc = do_chunk(c, scp, 0);
-        if (rc) return rc;                               // (HostActors' destructor stops and joins the helper)
+        if (rc) return rc;                               // (HostActors' destructor stops and joins the helpers)
     }
-    if (act.solver2.joinable()) act.solver2.join();
+    for (auto &t : act.solvers) if (t.joinable()) t.join();
     if (act.s2_rc) { t_err = act.s2_err; return act.s2_rc; }
+    }
     act.close_downloads();
     act.up.join();
     act.down.join();

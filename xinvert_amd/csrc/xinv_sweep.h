@@ -81,6 +81,18 @@ static int lane_rule(const Problem &p, double est_pass_us)
 }
 
 // workspace, then chunks of launches with pipelined polling of the device-side stop flags
+// bytes of the norm partials of one solve (every member, every tiling its launches may use)
+static size_t partial_bytes(const Problem &p, const Plan &pl)
+{
+    if (pl.path == XINV_PATH_FUSED)
+        return (size_t)p.nbatch * XINV_KMAX *
+               (is3d(p.kind) ? std::max((size_t)pl.nsg * pl.nrb * std::max(1, pl.nkc),
+                                        pl.K2 ? (size_t)pl.nsg2 * pl.nrb2 * std::max(1, pl.nkc2) : (size_t)0)
+                             : (size_t)pl.nsg) *
+               (3 * sizeof(unsigned long long));        // three tagged words per partial
+    return (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
+}
+
 static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt, Workspace *ws, hipStream_t st,
                       SweepRun &R)
 {
@@ -97,15 +109,7 @@ static int run_sweeps(const Problem &p, const Plan &pl, const xinv_options &opt,
         HIPCHK(hipHostMalloc((void **)&ws->hctl, 2 * (size_t)p.nbatch * sizeof(XinvCtl), XINV_HOST_COHERENT));
         ws->hctl_cap = (size_t)p.nbatch;
     }
-    size_t pbytes;
-    if (pl.path == XINV_PATH_FUSED)
-        pbytes = (size_t)p.nbatch * XINV_KMAX *
-                 (is3d(p.kind) ? std::max((size_t)pl.nsg * pl.nrb * std::max(1, pl.nkc),
-                                          pl.K2 ? (size_t)pl.nsg2 * pl.nrb2 * std::max(1, pl.nkc2) : (size_t)0)
-                               : (size_t)pl.nsg) *
-                 (3 * sizeof(unsigned long long));      // three tagged words per partial
-    else
-        pbytes = (size_t)p.nbatch * XINV_NORM_BLOCKS * (sizeof(double) + sizeof(long long));
+    size_t pbytes = partial_bytes(p, pl);
     // Lagged norm (5-point 2-D kernels): the sweep kernel only publishes its partials; an extra workgroup
     // of the NEXT launch adds them and applies the stop rule while that pass's tiles run.  Measured at
     // 3600x1800, K = 4 (profiles/r02_norm_lag_experiment.txt): 47.6 us per launch with the in-kernel
