@@ -72,7 +72,7 @@ prof C4 "k_pipe2d<FusedGen2D" "k_pipe2d<Gen2D" 8 2 16588800 python $R/tools/benc
 prof C1 "k_pipe2d<FusedStd2D" "k_pipe2d<Std2D" 1 1 259200 python $R/tools/bench_configs.py c1 --reps 4 --sweeps 500
 prof C5 "k_pipe3d" "k_pipe3d" 15 1 388800000 python $R/tools/bench_configs.py c5 --members 15 --reps 2
 # the headline workload through bench.py itself (kernel trace + traffic of the HBM leg: 8 members in two lanes)
-cmd="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-parity --no-configs"
+cmd="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-parity --no-configs --no-e2e"
 ( cd /tmp; rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w
   rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o r -- $cmd > /dev/null 2>&1
   python $R/tools/prof_summary.py kernels $(db /tmp/p_kt) $out/${RN}_kernel_trace_bench.txt | head -4 | cut -c1-150
