@@ -443,6 +443,15 @@ int xinv_plan_create_standard_2d_test_f64_dev(xinv_plan **plan, const double *A,
                                               void *stream);
 
 int xinv_plan_solve_f64_dev(xinv_plan *plan, double *S, double *flags, int64_t mxLoop, double tolerance, void *stream);
+/* nframes restarts of the plan's solve queued behind each other (apps.animate_iteration, reference apps.py:1031-1044: one
+ * kernel call per frame, every frame continuing from the previous frame's S): frame f runs mxLoop + 1 sweeps at most from the
+ * state frame f-1 left, its S is copied into frames + f * frame_stride (device pointer, frame_stride >= the elements S
+ * spans) and its flags land in flags + 3 * nbatch * f (host, [nframes][nbatch][3]).  No host round trip between the frames
+ * while every frame runs its whole budget; a frame the tolerance stops earlier sends the remaining frames down the road of
+ * xinv_plan_solve_f64_dev, one call each.  Results are those of nframes calls of xinv_plan_solve_f64_dev, bit for bit.
+ * Returns with S, the frames and the flags complete. */
+int xinv_plan_solve_frames_f64_dev(xinv_plan *plan, double *S, double *frames, int64_t nframes, int64_t frame_stride,
+                                   double *flags, int64_t mxLoop, double tolerance, void *stream);
 int xinv_plan_refresh(xinv_plan *plan, void *stream);
 int xinv_plan_destroy(xinv_plan *plan);
 

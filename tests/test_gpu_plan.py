@@ -278,3 +278,36 @@ def test_plan_fuzz(mode):
     out = subprocess.run([sys.executable, os.path.join(here, 'fuzz_plan.py'), '2000', '6'] + ([mode] if mode else []),
                          capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and 'failures: 0' in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d', 'std2dt', 'bih2d', 'std3d', 'gen3d'])
+@pytest.mark.parametrize('mxLoop,tol,nf', [(1, 0.0, 9), (4, 0.0, 5), (2, 3e-3, 40)])
+def test_plan_solve_frames_equals_repeated_solves(kind, mxLoop, tol, nf):
+    """xinv_plan_solve_frames_f64_dev: nf restarts queued behind each other (apps.animate_iteration's frames) are, bit for bit,
+    nf calls of xinv_plan_solve_f64_dev -- the snapshot of every frame, the flags of every frame, the final S.  Budgets of
+    one launch and of several (with a shorter tail launch), a masked forcing (skipped tiles), and a tolerance that stops some
+    frame early INSIDE the sequence: the fast road's result up to there, the ordinary road from there on."""
+    import torch
+    from xinvert_amd.resident import ResidentProblem
+    ps = [_mk(kind, 1, 70 + 3 * m) for m in range(2)]
+    p = _as_problem(ps)
+    ref = ResidentProblem(p, null_zero_B=True)
+    ref_frames, ref_flags = [], []
+    for f in range(nf):
+        fl, st = ref.solve(mxLoop, tol)
+        ref_frames.append(ref.S.clone()); ref_flags.append(np.array(fl, copy=True))
+    rp = ResidentProblem(p, null_zero_B=True)
+    frames = torch.empty((nf,) + tuple(rp.S.shape), dtype=rp.S.dtype, device=rp.S.device)
+    fl, st = rp.solve_frames(frames, mxLoop, tol)
+    assert fl.shape == (nf, rp.nb, 3)
+    for f in range(nf):
+        assert torch.equal(frames[f], ref_frames[f]), 'frame %d differs' % f
+        assert np.array_equal(fl[f][:, [0, 2]], ref_flags[f][:, [0, 2]]), (f, fl[f], ref_flags[f])
+        assert np.allclose(fl[f][:, 1], ref_flags[f][:, 1], rtol=1e-12, atol=0, equal_nan=True)
+    assert torch.equal(rp.S, ref.S)
+    if tol > 0:                                          # (the sequence must really have hit an early stop)
+        assert any((ref_flags[f][:, 2] < mxLoop).any() for f in range(nf)), [r[:, 2] for r in ref_flags]
+    # and a second call continues from there
+    fl2, _ = rp.solve_frames(frames[:2], mxLoop, tol)
+    r1, _ = ref.solve(mxLoop, tol)
+    assert torch.equal(frames[0], ref.S) and np.array_equal(fl2[0][:, [0, 2]], r1[:, [0, 2]])

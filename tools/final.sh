@@ -84,4 +84,4 @@ cmd="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-parity --no-configs -
   python $R/tools/prof_summary.py traffic $(db /tmp/p_f) $(db /tmp/p_w) "k_fused2d<FusedStd2D, 1" std2d_spl1_um0_all $out/traffic.json 8 2 )
 python -c "
 import json; d=json.load(open('$out/traffic.json')); print({k: (v if not isinstance(v, dict) else '...') for k, v in d.items() if not k.endswith('_detail') and k != 'configs'}); print({k: round(v['bytes_per_point_sweep'], 2) for k, v in d['configs'].items()}); print(d.get('std2d_spl1_um0_all_detail'))"
-( python tools/bench_host_pipeline.py c5 --members 15 --sweeps 200; python tools/bench_host_pipeline.py c4 --members 8 --sweeps 500 ) 2>/dev/null | grep '^{' > $out/${RN}_host_pipeline.txt; cut -c1-230 $out/${RN}_host_pipeline.txt
+( python tools/bench_host_pipeline.py c5 --members 15 --sweeps 200; python tools/bench_host_pipeline.py c4 --members 8 --sweeps 500 ) 2>/dev/null | grep '^{' > $out/${RN}_host_pipeline_final.txt; cut -c1-230 $out/${RN}_host_pipeline_final.txt

@@ -72,7 +72,7 @@ EXPORTS = [
     'xinv_plan_create_standard_2d_f64_dev', 'xinv_plan_create_general_2d_f64_dev',
     'xinv_plan_create_standard_3d_f64_dev', 'xinv_plan_create_general_3d_f64_dev',
     'xinv_plan_create_general_bih_2d_f64_dev', 'xinv_plan_create_standard_2d_test_f64_dev',
-    'xinv_plan_solve_f64_dev', 'xinv_plan_refresh', 'xinv_plan_destroy',
+    'xinv_plan_solve_f64_dev', 'xinv_plan_solve_frames_f64_dev', 'xinv_plan_refresh', 'xinv_plan_destroy',
 ]
 
 _lib = None
@@ -137,6 +137,7 @@ def load():
     L.xinv_plan_create_general_bih_2d_f64_dev.argtypes = [_pp] + [_vp] * 10 + [_i64, _ip] + no_tail(bih_scal) + [_opt, _vp]
     L.xinv_plan_create_standard_2d_test_f64_dev.argtypes = [_pp] + [_vp] * 6 + [_i64, _ip] + no_tail(std2d_scal) + [_opt, _vp]
     L.xinv_plan_solve_f64_dev.argtypes = [_vp, _vp, _dp, _i64, _f64, _vp]
+    L.xinv_plan_solve_frames_f64_dev.argtypes = [_vp, _vp, _vp, _i64, _i64, _dp, _i64, _f64, _vp]
     L.xinv_plan_refresh.argtypes = [_vp, _vp]
     L.xinv_plan_destroy.argtypes = [_vp]
     for name in EXPORTS:

@@ -255,15 +255,16 @@ def animate_iteration(app_name, F, dims, coords='lat-lon', icbc=None,
     except ImportError:
         res = None
     if res is not None:
+        # every frame queued behind the last on the device (xinv_plan_solve_frames_f64_dev: no host round trip between the
+        # frames while every frame runs its whole budget); the snapshots stay in HBM and cross PCIe in blocks
         res.keep_frames(max_frames)
-    for _ in range(max_frames):
-        if res is not None:
-            res.solve(loop_per_frame, float(iParams['tolerance']))
-            res.snapshot()                                # (stays in HBM: one download after the last frame)
-        else:
+        fl = res.solve_frames(max_frames, loop_per_frame, float(iParams['tolerance']))
+        frame_flags = [np.array(f if res.rp.nb > 1 else f[0], copy=True) for f in fl]
+    else:
+        for _ in range(max_frames):
             initS = invt_func(*coeffs, maskF, initS, dims, iParams)
             frames.append(np.array(initS.values, copy=True))
-        frame_flags.append(np.array(iParams['flags'], copy=True))
+            frame_flags.append(np.array(iParams['flags'], copy=True))
     iParams['frame_flags'] = np.stack(frame_flags)       # flags of every frame (iParams['flags'] holds the last)
     if isinstance(iParams_in, dict) and iParams_in is not default_iParams:
         for k in ('flags', 'stats', 'frame_flags'):      # where the inv_* calls leave them for the caller

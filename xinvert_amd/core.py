@@ -202,6 +202,29 @@ class Resident:
         self.iParams['stats'] = self.stats
         return fl
 
+    def solve_frames(self, n, mxLoop, tolerance, **opt):
+        """`n` restarts of the solve, every one continuing from the last, their S snapshots kept in HBM (keep_frames first):
+        queued behind each other without a host round trip (ResidentProblem.solve_frames).  -> flags [n, nbatch, 3]; the
+        snapshots join those of snapshot() in frames()."""
+        o = dict(path=int(self.iParams.get('engine_path', 0)),
+                 sweeps_per_launch=int(self.iParams.get('sweeps_per_launch', 0)),
+                 check_every=int(self.iParams.get('check_every', 0)))
+        o.update(opt)
+        out = []
+        left = int(n)
+        while left > 0:
+            if self._nframe == self._frames.shape[0]:
+                self._flush_frames()
+            k = min(left, int(self._frames.shape[0]) - self._nframe)
+            fl, self.stats = self.rp.solve_frames(self._frames[self._nframe:self._nframe + k], mxLoop, tolerance, **o)
+            self._nframe += k
+            left -= k
+            out.append(fl)
+        fl = np.concatenate(out)
+        self.iParams['flags'] = np.array(fl[-1] if self.rp.nb > 1 else fl[-1][0], copy=True)
+        self.iParams['stats'] = self.stats
+        return fl
+
     def values(self):
         """S in the forcing's axis order (a fresh host array)."""
         out = self.rp.result().reshape(tuple(self.bshape) + self.core_shape)

@@ -600,6 +600,12 @@ int xinv_plan_solve_f64_dev(xinv_plan *plan, double *S, double *flags, int64_t m
     GUARD(plan_solve(plan, S, flags, mxLoop, tolerance, (hipStream_t)stream))
 }
 
+int xinv_plan_solve_frames_f64_dev(xinv_plan *plan, double *S, double *frames, int64_t nframes, int64_t frame_stride,
+                                   double *flags, int64_t mxLoop, double tolerance, void *stream)
+{
+    GUARD(plan_solve_frames(plan, S, frames, nframes, frame_stride, flags, mxLoop, tolerance, (hipStream_t)stream))
+}
+
 int xinv_plan_refresh(xinv_plan *plan, void *stream)
 {
     if (!plan || plan->magic != XINV_PLAN_MAGIC) return fail_arg("xinv_plan_refresh: not a live plan");

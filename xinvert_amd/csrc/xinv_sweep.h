@@ -928,3 +928,124 @@ static int plan_solve(xinv_plan *h, double *S, double *flags, int64_t mxLoop, do
     return rc;
 }
 
+
+// ------------------------------------------------------------------ several restarts of a plan without a host round trip
+// apps.animate_iteration (reference apps.py:1031-1044; tests/test_AnimateConverge.py:13-31: 40 frames of 2 sweeps on 73 x
+// 144) calls its kernel once per frame, continuing from the previous frame's S.  Through xinv_plan_solve_f64_dev a frame is
+// one C-ABI call: control blocks reset, one or two launches, the control blocks back to the host (k_ctl_mail), 36-38 us of
+// which 18 are the launch.  Here nframes restarts are QUEUED behind each other: every frame has its own control blocks,
+// the state ping-pongs between S and its twin ACROSS the frames (no copy back per frame), a snapshot of the state goes into
+// the caller's frame buffer behind each frame, and the host reads all the control blocks once, at the end.  What the host
+// cannot do without looking -- redo a pass the stop rule fired INSIDE of (finalise) -- does not happen while every frame runs
+// its whole budget; if some frame stopped early (the field has converged) the state before the first such frame is
+// restored from the frame buffer and the remaining frames take the ordinary road, one xinv_plan_solve each.
+// One launch chain, the launch's own last workgroup reduces the norm (no lagged evaluation: its three-buffer rotation is
+// what the per-frame bookkeeping was for).  Bit for bit nframes calls of xinv_plan_solve_f64_dev.
+static int plan_solve_frames(xinv_plan *h, double *S, double *frames, int64_t nframes, int64_t frame_stride, double *flags,
+                             int64_t mxLoop, double tolerance, hipStream_t st)
+{
+    if (!h || h->magic != XINV_PLAN_MAGIC) return fail_arg("xinv_plan_solve_frames: not a live plan");
+    if (nframes < 1 || !frames || !flags) return fail_arg("xinv_plan_solve_frames: no frames");
+    Problem p = h->p;
+    p.S = S;
+    p.stop.mxLoop = mxLoop; p.stop.tolerance = tolerance;
+    int rc = validate(p, flags);
+    if (rc) return rc;
+    const int64_t n = p.zc * p.yc * p.xc, nb = p.nbatch;
+    const int64_t span = (nb - 1) * p.sS + n;            // elements of S
+    if (frame_stride < span) return fail_arg("xinv_plan_solve_frames: frame stride smaller than S");
+    const int64_t max_sweeps = mxLoop + 1;
+    auto slow_from = [&](int64_t f0) -> int {             // frames f0 .. nframes-1 the ordinary way (S holds the state before f0)
+        for (int64_t f = f0; f < nframes; f++) {
+            double *fl = flags + 3 * nb * f;
+            for (int64_t m = 0; m < nb; m++) { fl[3 * m] = 0.0; fl[3 * m + 1] = 1.0; fl[3 * m + 2] = 0.0; }
+            int r = plan_solve(h, S, fl, mxLoop, tolerance, st);
+            if (r) return r;
+            HIPCHK(hipMemcpyAsync(frames + f * frame_stride, S, (size_t)span * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        return XINV_OK;
+    };
+    // the queued road: the streaming path, a batch small enough for one chain; anything else frame by frame
+    if (h->pl.path != XINV_PATH_FUSED || nb > 64 || nframes * nb > 65536 || (h->pl.aligned && !ptr_al16(S)))
+        return slow_from(0);
+    DeviceGuard dg;
+    HIPCHK(dg.select(h->device));
+    Workspace *ws = get_ws(h->device);
+    std::unique_lock<std::recursive_mutex> lock(ws->busy);
+    rc = ws_ready(ws);
+    if (rc) return rc;
+    memset(&t_stats, 0, sizeof t_stats);
+    const Plan &pl0 = h->pl;
+    const int Kf = pl0.K;
+    const int64_t L = (max_sweeps + Kf - 1) / Kf;
+    XinvCtl *ctl_all = nullptr;
+    std::vector<XinvCtl> hc((size_t)(nframes * nb));
+    int64_t bad = -1;
+    {
+        BufSwap sw(ws, &h->bufs);
+        Plan pl = pl0;
+        pl.skipna.S = S;
+        rc = tail_wait(ws, st);
+        if (rc) return rc;
+        // control blocks of EVERY frame (the workspace's block is theirs for the duration), partials, the twin of S
+        if ((rc = ensure_dev(&ws->ctl, &ws->ctl_cap, (size_t)(nframes * nb) * sizeof(XinvCtl)))) return rc;
+        ctl_all = ws->ctl;
+        const size_t pbytes = (partial_bytes(p, pl) + 255) & ~(size_t)255;
+        ws->partials_half = pbytes;
+        if ((rc = ensure_dev(&ws->partials, &ws->partials_cap, pbytes))) return rc;
+        if ((rc = ensure_dev(&ws->S2, &ws->S2_cap, (size_t)span * sizeof(double)))) return rc;
+        if ((rc = ensure_dev(&ws->S3, &ws->S3_cap, (size_t)span * sizeof(double)))) return rc;
+        HIPCHK(hipMemcpyAsync(ws->S3, S, (size_t)span * sizeof(double), hipMemcpyDeviceToDevice, st));   // (the state before frame 0)
+        struct CtlRestore { Workspace *w; XinvCtl *base; ~CtlRestore() { w->ctl = base; } } restore{ws, ctl_all};
+        if (pl.skip) {                                   // the skipped tiles' share of the norm and their copy into the twin: once
+            hipLaunchKernelGGL(k_skip_tiles, dim3((unsigned)pl.nskip, (unsigned)nb, 1), dim3(64), 0, st, pl.skipna, ws->S2,
+                               (double *)nullptr);
+            HIPCHK(hipGetLastError());
+        }
+        double *buf[2] = { S, ws->S2 };
+        int cur = 0;
+        int64_t nlaunch = 0;
+        for (int64_t f = 0; f < nframes; f++) {
+            ws->ctl = ctl_all + f * nb;                  // (the launchers take the control blocks from the workspace)
+            hipLaunchKernelGGL(k_solve_init, dim3((unsigned)std::max<int64_t>(cdiv(nb, 256), std::min<int64_t>(256, cdiv((int64_t)(pbytes / 16), 256)))),
+                               dim3(256), 0, st, ws->ctl, nb, (uint4 *)ws->partials, (int64_t)(pbytes / 16));
+            for (int64_t i = 0; i < L; i++) {
+                const int k = (int)std::min<int64_t>(Kf, max_sweeps - i * Kf);
+                rc = launch_planned(p, pl, ws, st, k, buf[cur], buf[cur ^ 1], 0, nb, 0, 0);
+                if (rc) return rc;
+                cur ^= 1; nlaunch++;
+            }
+            HIPCHK(hipMemcpyAsync(frames + f * frame_stride, buf[cur], (size_t)span * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        ws->ctl = ctl_all;
+        HIPCHK(hipMemcpyAsync(hc.data(), ctl_all, (size_t)(nframes * nb) * sizeof(XinvCtl), hipMemcpyDeviceToHost, st));
+        if (cur != 0) HIPCHK(hipMemcpyAsync(S, ws->S2, (size_t)span * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        // every frame must have run its whole budget (or have stopped exactly at the end of its last pass)
+        for (int64_t f = 0; f < nframes && bad < 0; f++)
+            for (int64_t m = 0; m < nb; m++) {
+                const XinvCtl &c = hc[(size_t)(f * nb + m)];
+                if (!c.done || c.overflow == 2 || c.sweeps != max_sweeps) { bad = f; break; }
+            }
+        const int64_t good = bad < 0 ? nframes : bad;
+        for (int64_t f = 0; f < good; f++)
+            for (int64_t m = 0; m < nb; m++) {
+                const XinvCtl &c = hc[(size_t)(f * nb + m)];
+                double *fl = flags + 3 * (nb * f + m);
+                fl[0] = c.overflow ? 1.0 : 0.0; fl[1] = 1.0; fl[2] = 0.0;
+                if (c.wrote) { fl[1] = c.flag1; fl[2] = c.flag2; }
+            }
+        t_stats.path = pl.path; t_stats.colours = pl.ncol; t_stats.sweeps_per_launch = Kf; t_stats.rows_per_tile = pl.RY;
+        t_stats.xuniform_mask = (int32_t)pl.um; t_stats.lanes = 1; t_stats.sweep_launches = nlaunch; t_stats.planned = 1;
+        t_stats.sweeps_max = max_sweeps; t_stats.pipelined = pl.pipe ? pl.npair : 0;
+        t_stats.masked_tile_pct = pl.skip ? pl.skip_pct : 0; t_stats.masked_tile_ppm = pl.skip ? pl.skip_ppm : 0;
+        h->solves += good;
+        if (bad >= 0)                                    // the state before the first frame that stopped early, back into S
+            HIPCHK(hipMemcpyAsync(S, bad > 0 ? frames + (bad - 1) * frame_stride : ws->S3, (size_t)span * sizeof(double),
+                                  hipMemcpyDeviceToDevice, st));
+    }
+    if (bad < 0) return XINV_OK;
+    lock.unlock();
+    return slow_from(bad);
+}

@@ -192,6 +192,28 @@ class ResidentProblem:
         _lib.check(rc)
         return self.flags, _lib.last_stats()
 
+    def solve_frames(self, frames, mxLoop, tolerance, stream=None, **opt):
+        """`frames.shape[0]` restarts of the solve queued behind each other (include/xinv.h: xinv_plan_solve_frames_f64_dev):
+        frame f continues from frame f-1's S, which is copied into `frames[f]` (a torch tensor [nframes, *S.shape] on this
+        device).  -> flags [nframes, nb, 3].  No host round trip between the frames while every frame runs its whole budget."""
+        import torch
+        assert self.use_plan, 'solve_frames runs on a resident plan'
+        assert frames.is_cuda and frames.dtype == self.S.dtype and tuple(frames.shape[1:]) == tuple(self.S.shape) and frames.is_contiguous()
+        cur = torch.cuda.current_stream(self.dev)
+        st = stream if stream is not None else cur
+        self._join()
+        if st.cuda_stream != cur.cuda_stream:
+            st.wait_stream(cur)
+        nf = int(frames.shape[0])
+        fl = np.tile(np.array([0., 1., 0.]), (nf, self.nb, 1))
+        h = self._plan(opt, st)
+        rc = self.L.xinv_plan_solve_frames_f64_dev(h, ctypes.c_void_p(self.S.data_ptr()), ctypes.c_void_p(frames.data_ptr()), nf,
+                                                   int(self.S.numel()), _lib.hptr(fl), int(mxLoop), float(tolerance),
+                                                   ctypes.c_void_p(st.cuda_stream))
+        _lib.check(rc)
+        self.flags[:] = fl[-1]
+        return fl, _lib.last_stats()
+
     def result(self):
         self._join()
         return self.S.cpu().numpy()
