@@ -210,6 +210,12 @@ class Resident:
                  sweeps_per_launch=int(self.iParams.get('sweeps_per_launch', 0)),
                  check_every=int(self.iParams.get('check_every', 0)))
         o.update(opt)
+        if not self.rp.use_plan:                             # (iParams['resident_plan'] = False: frame by frame, as rounds 1-4)
+            out = []
+            for _ in range(int(n)):
+                out.append(np.array(self.solve(mxLoop, tolerance, **opt), copy=True))
+                self.snapshot()
+            return np.stack(out)
         out = []
         left = int(n)
         while left > 0:
