@@ -46,6 +46,16 @@ def one(seed):
         ncu = 0 if bnz else {'std2d': 3, 'gen2d': 6, 'std2dt': 5}[kind]   # coefficient arrays (the forcing is the last one)
         sh = (yc, xc)
     ps = [mk(seed * 100 + m) for m in range(nb)]
+    munk = 0
+    if kind == 'bih2d' and not uni:                           # (round 6) the one-pass kernel's vector-stream variants: 0 = all nine
+        munk = int(rng.integers(3))                           # arrays vary (VM = 2); 1 = A C D F vary, G H I per row, B = E = 0
+        if munk:                                              # (VM = 1); 2 = ... and C holds A's numbers, F holds D's (VM = 3)
+            for q in ps:
+                q['coefs'] = [np.zeros_like(c) if k in (1, 4) else
+                              (np.ascontiguousarray(np.broadcast_to(ps[0]['coefs'][k][:, :1], c.shape)) if k in (6, 7, 8) else c)
+                              for k, c in enumerate(q['coefs'])]
+                if munk == 2:
+                    q['coefs'][2] = q['coefs'][0].copy(); q['coefs'][5] = q['coefs'][3].copy()
     if uni and ncu:                                           # coefficients constant along x, one stack for the batch
         c0 = [np.ascontiguousarray(np.broadcast_to(c[..., :1], c.shape)) for c in ps[0]['coefs'][:ncu]]
         for q in ps:
@@ -69,6 +79,13 @@ def one(seed):
     hc = int(rng.integers(4))                                 # host-pointer entry: upload / solve / download over member chunks
     if hc:
         opt['host_chunk'] = [0, 1, 3, 7][hc]
+    # (round 6) chunk solves in flight / the rolling batch of the standard 3-D form with shared coefficients (-1); the
+    # compute-unit count the planner fills (the cut of a launch's last round of k_pipe3d workgroups)
+    hi = int(rng.integers(4))
+    if hi:
+        opt['host_inflight'] = [0, -1, 3, 1][hi]
+    if kind == 'std3d' and int(rng.integers(2)):
+        opt['cu_count'] = [3, 8, 17, 40][int(rng.integers(4))]
     if kind in ('std2d', 'gen2d', 'std2dt', 'bih2d') and (SINGLE or int(rng.integers(2))):
         opt['force_tile_skip'] = 1                            # masked-tile lists whatever the size
     S, fl, st = util.run_hip_batched(ps, mx, tol, shared=shared, **opt)

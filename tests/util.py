@@ -323,13 +323,6 @@ class xarray_standin:
 
 
 def p3_extend_ok(yc):
-    """Mirror of the planner's rule (xinv_launch.h: p3_extend_ok): the two-sweep 3-D pass takes BCy = 'extend' where rows
-    yc-2 / yc-1 sit in one wavefront of every cross-section that needs row yc-1 right; other row counts keep the one-sweep kernel."""
-    RJ, H, RR = 16, 4, 3
-    jbo = (yc - 1) // RJ
-    tog = lambda jb: ((yc - 2) - (jb * RJ - H)) % RR != RR - 1
-    if not tog(jbo):
-        return False
-    if jbo > 0 and (yc - 1) - jbo * RJ <= 1 and not tog(jbo - 1):
-        return False
+    """The two-sweep 3-D pass takes BCy = 'extend' at every row count since the row blocks may be shifted up by two rows
+    (xinv_launch.h: p3_extend_joff); kept for the tests that asked which counts it took before."""
     return True

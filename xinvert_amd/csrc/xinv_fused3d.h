@@ -47,6 +47,8 @@ struct Fused3Args {
     // into the nkc chunks: workgroup nfull + q marches chunk q % nkc of tile nfull + q / nkc (xinv_pipe3d.h: the tail of
     // a launch whose tile count is not a multiple of the compute units).  nfull == 0: every tile is cut.
     int64_t nfull;
+    int joff;                  // k_pipe3d: rows the row blocks are shifted up by (0, or 2 with BCy = 'extend' where that puts rows
+                               // yc-2 / yc-1 into one wavefront: xinv_launch.h, p3_extend_joff); block jb owns rows [jb RJ - joff, ..)
 };
 
 // 7-point update with the mask folded into a select (numbas.py:146-169).

@@ -16,6 +16,7 @@ struct Plan {
     int nkc, KC;             // 3-D: k chunks and planes per chunk
     bool K2;                 // 3-D standard form: passes of two sweeps (k_pipe3d) with the tiling below
     int nsg2, nrb2, nkc2, KC2;
+    int joff2;               // k_pipe3d: rows its row blocks are shifted up by ('extend': p3_extend_joff; 0 elsewhere)
     int cus;                 // compute units the planner fills (xinv_options.cu_count, or the device's)
     int64_t srowf2;          // k_pipe3d: member stride of the record table (0: shared by the batch)
     bool bih_zbe;            // biharmonic one-pass kernel: B and E identically zero (terms left out)
@@ -95,19 +96,22 @@ static int64_t p3_whole_tiles(int64_t tiles, int nk, int64_t KC, int64_t zc, int
 }
 
 // k_pipe3d with BCy = 'extend' (xinv_pipe3d.h: EXT) applies the second sweep's pre-pass out of a wavefront's own registers:
-// rows yc-2 and yc-1 have to sit in ONE wavefront (RR adjacent rows each, the cross-section of row block jb starting at row
-// jb * RJ - H) in the block that owns row yc-1 -- and in the block before it when that one owns row yc-2 or yc-3, whose
-// second sweep reads row yc-1 through row yc-2.  (Rows 0 / 1 always do: H mod RR = 1.)
-static bool p3_extend_ok(int64_t yc)
+// rows 0 / 1 and rows yc-2 / yc-1 each have to sit in ONE wavefront (RR adjacent rows each; the cross-section of row block
+// jb starts at row jb * RJ - H - joff) -- the first pair in block 0, the second in the block that owns row yc-1 and in the
+// block before it when that one owns row yc-2 or yc-3, whose second sweep reads row yc-1 through row yc-2.  Returns the
+// shift of the row blocks that achieves it: 0 for five row counts in eight, 2 for the others (-1: none -- not reached).
+static bool p3_extend_ok(int64_t yc, int joff)
 {
     const int RJ = XINV_P3_G * XINV_P3_RR - 8, H = 4, RR = XINV_P3_RR;
     static_assert(XINV_P3_RR == 3 && XINV_P3_G * XINV_P3_RR - 8 > 0, "p3_extend_ok: three rows per wavefront");
-    const int64_t jbo = (yc - 1) / RJ;                           // the block that owns row yc-1
-    auto together = [&](int64_t jb) { return ((yc - 2) - (jb * RJ - H)) % RR != RR - 1; };   // row yc-2 is not a wavefront's last row
+    if ((H + joff) % RR == RR - 1) return false;                   // row 0 would be a wavefront's last row
+    const int64_t jbo = (yc - 1 + joff) / RJ;                      // the block that owns row yc-1
+    auto together = [&](int64_t jb) { return ((yc - 2) - (jb * RJ - H - joff)) % RR != RR - 1; };   // row yc-2 is not a wavefront's last row
     if (!together(jbo)) return false;
-    if (jbo > 0 && (yc - 1) - jbo * RJ <= 1 && !together(jbo - 1)) return false;
+    if (jbo > 0 && (yc - 1 + joff) - jbo * RJ <= 1 && !together(jbo - 1)) return false;
     return true;
 }
+static int p3_extend_joff(int64_t yc) { return p3_extend_ok(yc, 0) ? 0 : (p3_extend_ok(yc, 2) ? 2 : -1); }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                           hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false, bool pq = false)
@@ -289,7 +293,7 @@ static int launch_fused3d(const Problem &p, const Plan &pl, int K, const double 
     a.per = (p.BCx == XINV_BC_PERIODIC);
     if (K == 2) {                                        // two sweeps per pass: its own tiling
         if (!pl.K2) return fail_arg("internal: two-sweep 3-D pass without its plan");
-        a.nstrip = pl.nsg2; a.njb = pl.nrb2;
+        a.nstrip = pl.nsg2; a.njb = pl.nrb2; a.joff = pl.joff2;
         a.nkc = std::max(1, pl.nkc2); a.KC = pl.KC2;
         a.force = force; a.no_ctl = no_ctl;
         a.sc_ = p.sc_; a.ctl = ws->ctl; a.stop = p.stop;

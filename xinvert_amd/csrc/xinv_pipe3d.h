@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256) void k_row_factor3d(RowFactor3Args a)
 // 1 / yc-2 where those are defined): the pre-pass of the pass's FIRST sweep is applied to the source buffer by k_extend
 // before this launch (idempotent; launch_fused3d) -- group 0 finds it in what it loads; the pre-pass of the SECOND sweep is
 // applied by group 1 to the plane it takes out of the ring, before anything reads it, out of the wavefront's own registers:
-// rows 0 / 1 always sit in one wavefront; the planner takes this variant only where rows yc-2 / yc-1 do too in every
-// cross-section that needs row yc-1 right (p3_extend_ok, xinv_launch.h: two row counts in three; the others keep the
-// one-sweep kernel).  (Round 5 loaded the partner rows from HBM; round 6 first read row yc-2 out of the neighbouring
+// rows 0 / 1 and rows yc-2 / yc-1 each have to sit in one wavefront of every cross-section that needs the boundary row
+// right: true for five row counts in eight as the blocks lie, for all of them with the blocks shifted up by two rows where
+// needed (Fused3Args::joff; p3_extend_joff, xinv_launch.h).  (Round 5 loaded the partner rows from HBM; round 6 first read row yc-2 out of the neighbouring
 // wavefront's ring slot where the pair is split: both bit-exact, both spilled 26-34 registers and ran at a third of the
 // rate -- the kernel has 128 registers and uses 123-126.)
 template <int G, int RR, bool AL, bool FMA = false, bool SEAM = false, bool EXT = false>
@@ -152,14 +152,14 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const unsigned long long okx64 = __builtin_amdgcn_ballot_w64(lc.ok_x) & ~rs.lanes, oky64 = __builtin_amdgcn_ballot_w64(lc.ok_y);
 
     // the RR rows of this wavefront (the same rows in both groups)
-    const int j0 = jb * RJ - H + gw * RR;
+    const int j0 = jb * RJ - H - a.joff + gw * RR;       // (joff: the 'extend' variant's tiling offset, 0 elsewhere)
     int jr[RR];
     bool row_use[RR];
 #pragma unroll
     for (int rr = 0; rr < RR; rr++) {
         const int j = j0 + rr;
         jr[rr] = j < 0 ? 0 : (j > yc - 1 ? yc - 1 : j);
-        row_use[rr] = (gw * RR + rr >= H) && (gw * RR + rr < NR - H) && (j < yc);
+        row_use[rr] = (gw * RR + rr >= H) && (gw * RR + rr < NR - H) && (j < yc) && (j >= 0);
     }
     // neighbouring wavefronts of the group (the first / last one reads itself: those rows are halo)
     const int wm = gw > 0 ? wave - 1 : wave, wp = gw < G - 1 ? wave + 1 : wave;

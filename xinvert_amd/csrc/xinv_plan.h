@@ -250,7 +250,7 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
         pl.K2 = false;
         const int k2_auto = XINV_ENV_INT("XINV_3D_K2", 1);
         const bool ext3 = (p.BCy == XINV_BC_EXTEND);      // ('extend': the EXT variant -- not with the seam or the contracted arithmetic)
-        if (p.kind == KIND_STD3D && pl.um == 7u && !(ext3 && (pl.seam || pl.fma || !p3_extend_ok(p.yc))) && !(pl.seam && (pl.fma || p.xc < 64)) &&
+        if (p.kind == KIND_STD3D && pl.um == 7u && !(ext3 && (pl.seam || pl.fma || p3_extend_joff(p.yc) < 0)) && !(pl.seam && (pl.fma || p.xc < 64)) &&
             (opt.sweeps_per_launch == 2 || (opt.sweeps_per_launch == 0 && k2_auto)) &&
             opt.rows_per_tile == 0 && p.stop.mxLoop >= 1 &&
             p.zc * p.yc * 64 < ((int64_t)1 << 31) &&                      // (32-bit offsets into the record table)
@@ -258,7 +258,8 @@ static int plan_fused3d(const Problem &p, const xinv_options &opt, Workspace *ws
             pl.K2 = true;
             pl.K = 2;
             pl.nsg2 = (int)cdiv(p.xc, pl.seam ? xinv_ring_uw(p.xc, 4) : 120);  // (odd-xc periodic seam: the ring variant's strips, xinv_tiles.h)
-            pl.nrb2 = (int)cdiv(p.yc, XINV_P3_G * XINV_P3_RR - 8);
+            pl.joff2 = ext3 ? p3_extend_joff(p.yc) : 0;
+            pl.nrb2 = (int)cdiv(p.yc + pl.joff2, XINV_P3_G * XINV_P3_RR - 8);
             {
                 // per-(plane, row) records of the x-uniform coefficients, relaxation factor and predicate: once per solve
                 const bool shared = (p.sc[0] == 0 && p.sc[1] == 0 && p.sc[2] == 0);
