@@ -734,6 +734,20 @@ def test_device_side_mask_scale_demask_equals_host_front_end(undef):
     Wd = xa.invert_omega(W, ['lev', 'lat', 'lon'], mParams=mP, iParams=iP)
     Wh = xa.invert_omega(W, ['lev', 'lat', 'lon'], mParams=mP, iParams=dict(iP, device_prep=False))
     assert _same(Wd.values, Wh.values) and np.abs(Wd.values[np.isfinite(Wd.values)]).max() > 0
+    # ... and as a ROLLING batch (round 6, xinv_hostptr.h: one launch chain over the volumes that have arrived; taken for
+    # large batches, here on request): six time steps, an odd sweep budget, float64 and float32 forcing -- the fields of the
+    # chunked pipeline, with the front-end passes (mask, cos(lat) scale, zero first guess, de-mask) on the device
+    frc6 = 1e-17 * rng.standard_normal((6, 9, 72, 144))
+    frc6[:, :3, land] = undef
+    frc6[4, 5:, 20:30, 40:60] = undef
+    for dt in (np.float64, np.float32):
+        W6 = xa.Field(frc6.astype(dt), ('time', 'lev', 'lat', 'lon'), {'lev': lev, 'lat': lat, 'lon': lon})
+        iP6 = dict(iP, mxLoop=22)
+        Wr = xa.invert_omega(W6, ['lev', 'lat', 'lon'], mParams=mP, iParams=dict(iP6, host_inflight=-1))
+        assert Wr.iParams['stats']['host_chunks'] == 6, Wr.iParams['stats']
+        Wc = xa.invert_omega(W6, ['lev', 'lat', 'lon'], mParams=mP, iParams=dict(iP6, host_chunk=2))
+        assert Wc.iParams['stats']['host_chunks'] == 3
+        assert _same(Wr.values, Wc.values) and np.array_equal(Wr.iParams['flags'][:, [0, 2]], Wc.iParams['flags'][:, [0, 2]])
 
 
 def test_invert_poisson_dataarray_in_dataarray_out():

@@ -402,6 +402,7 @@ def _solve(kind, coefs, F, S, dims, iParams):
                        sweeps_per_launch=int(iParams.get('sweeps_per_launch', 0)),
                        check_every=int(iParams.get('check_every', 0)), rowconst_mask=rowconst,
                        host_chunk=int(iParams.get('host_chunk', 0)),
+                       host_inflight=int(iParams.get('host_inflight', 0)),     # (chunk solves in flight; -1: the rolling batch of the 3-D form for any batch)
                        devices=_device_list(iParams, nbatch, sum(a.nbytes for a, st_ in zip(arrs, strides) if a is not None and st_)),
                        prep=prep,
                        f32_mask=f32_mask,                                        # bit 0: S; bit q + 1: coefficient q (the forcing last)
