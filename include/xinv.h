@@ -182,6 +182,9 @@ typedef struct xinv_stats {
     int32_t k_chunks;           /* two-sweep 3-D pass: chunks the plan cuts a tile's column into where it cuts (1: never)    */
     int32_t cut_tiles;          /* ... tiles of the solve's first sweep launch that were cut (the remainder of its last round
                                    of one workgroup per CU, or every tile of a small batch); the others march whole         */
+    int32_t rolling;            /* host-pointer entries: 1 = the batch ran as a rolling batch (one launch chain over the members
+                                   that had arrived and were not done: xinv_hostptr.h), 0 = chunk solves                    */
+    int32_t reserved_;
     double  launch_us_min, launch_us_avg, launch_us_max;   /* timing = 2: every sweep launch bracketed by its own pair
                                    of HIP events on the stream it runs on (one lane only): per-launch durations without
                                    a profiler's per-dispatch overhead                                                  */

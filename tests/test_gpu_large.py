@@ -152,7 +152,7 @@ def test_rolling_batch_3d_host_pointers(BCy, sweeps, tol, uni):
         q['S0'] = r['S0']
         ps.append(q)
     S, fl, st = util.run_hip_batched(ps, sweeps - 1, tol, shared=(0, 1, 2), host_inflight=-1)
-    assert st['path'] == 2 and st['host_chunks'] == nb, st
+    assert st['path'] == 2 and st['host_chunks'] == nb and st['rolling'] == 1, st
     loops = set()
     for m, q in enumerate(ps):
         So, flo = util.run_oracle(q, sweeps - 1, tol, 2)
@@ -164,3 +164,37 @@ def test_rolling_batch_3d_host_pointers(BCy, sweeps, tol, uni):
     # the chunked pipeline gives the same fields
     S2, fl2, st2 = util.run_hip_batched(ps, sweeps - 1, tol, shared=(0, 1, 2), host_chunk=2)
     assert np.array_equal(S, S2) and np.array_equal(fl[:, [0, 2]], fl2[:, [0, 2]])
+
+
+@pytest.mark.parametrize('kind', ['std2d', 'gen2d'])
+@pytest.mark.parametrize('sweeps,tol', [(40, 0.0), (41, 0.0), (600, 2e-3)])
+@pytest.mark.parametrize('masked_tiles', [0, 1])
+def test_rolling_batch_2d_host_pointers(kind, sweeps, tol, masked_tiles):
+    """The rolling batch for the 2-D 5-point forms with shared per-row coefficients (lat-lon Poisson / Gill-Matsuno batches):
+    the first chunk is planned alone; if it has no fully masked tile the batch is planned without tile lists and rolls (four
+    sweeps per pass on k_pipe2d, a shorter tail launch for a budget that is not whole passes, stops at any sweep of a pass);
+    if it has, the chunk scheme takes the call.  Bit for bit the oracle either way."""
+    from util import rand2d
+    nb = 6
+    yc, xc = 150, 460
+    base = rand2d(kind, yc, xc, 'fixed', 'periodic', 0, 0, seed=950)
+    ncu = 3 if kind == 'std2d' else 6
+    for q in range(ncu):
+        base['coefs'][q][:] = base['coefs'][q][:, :1]
+    ps = []
+    for m in range(nb):
+        r = rand2d(kind, yc, xc, 'fixed', 'periodic', 0, 1, seed=951 + m)
+        q = dict(base)
+        F = r['coefs'][-1] * 10.0 ** (-(m % 3))
+        F[r['coefs'][-1] == util.U] = util.U
+        if masked_tiles:
+            F[:, :130] = util.U                          # a strip of land: whole tiles to skip
+        q['coefs'] = list(base['coefs'][:ncu]) + [F]
+        q['S0'] = np.where(r['S0'] == util.U, 0.0, r['S0'])
+        ps.append(q)
+    S, fl, st = util.run_hip_batched(ps, sweeps - 1, tol, shared=tuple(range(ncu)), host_inflight=-1, force_tile_skip=1)
+    assert st['path'] == 2 and st['rolling'] == (0 if masked_tiles else 1), st
+    for m, q in enumerate(ps):
+        So, flo = util.run_oracle(q, sweeps - 1, tol, 2)
+        assert np.array_equal(S[m], So), 'member %d: %d points differ' % (m, (S[m] != So).sum())
+        assert fl[m][0] == flo[0] and fl[m][2] == flo[2], (m, fl[m], flo)

@@ -48,6 +48,7 @@ class XinvStats(ctypes.Structure):
                 ('recovered_members', ctypes.c_int32), ('lanes', ctypes.c_int32),
                 ('planned', ctypes.c_int32), ('point_factor', ctypes.c_int32), ('plan_ms', ctypes.c_double),
                 ('k_chunks', ctypes.c_int32), ('cut_tiles', ctypes.c_int32),
+                ('rolling', ctypes.c_int32), ('reserved_', ctypes.c_int32),
                 ('launch_us_min', ctypes.c_double), ('launch_us_avg', ctypes.c_double),
                 ('launch_us_max', ctypes.c_double)]
 

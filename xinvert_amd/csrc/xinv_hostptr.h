@@ -142,11 +142,17 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // yet, instead of one solve per chunk.  For the standard 3-D form with shared coefficient arrays (its plan reads nothing
     // of a member's own), on the streaming path, where the planner is left to itself.
     // (xinv_options.host_inflight = -1 takes it for any batch of two or more: the tests' small volumes)
-    bool rolling = p.kind == KIND_STD3D && opt.host_chunk == 0 && opt.host_inflight <= 0 &&
+    const bool roll2d = (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);     // (2-D: only where no tile is fully masked, see roll)
+    bool rolling = (p.kind == KIND_STD3D || roll2d) && opt.host_chunk == 0 && opt.host_inflight <= 0 &&
                    opt.path != XINV_PATH_COLOUR && !(p.BCx == XINV_BC_PERIODIC && (p.xc & 1) && p.xc < 64) &&
-                   ((p.nbatch >= 4 && (double)n * 16.0 * (double)p.nbatch >= 100663296.0) || (opt.host_inflight < 0 && p.nbatch >= 2));
-    for (int q = 0; q + 1 < p.ncoef; q++) rolling = rolling && p.c[q] && (p.nbatch == 1 || p.sc[q] == 0);
-    const std::vector<int64_t> chunks = rolling ? std::vector<int64_t>((size_t)p.nbatch, 1) : host_chunks(p, opt);
+                   ((!roll2d && p.nbatch >= 4 && (double)n * 16.0 * (double)p.nbatch >= 100663296.0) || (opt.host_inflight < 0 && p.nbatch >= 2));
+    // (2-D forms roll on request only -- host_inflight = -1 --: C4 x 8, 500 sweeps: 15.0 ms rolling against 13.4 in chunks of
+    //  two members, two chunk solves in flight (7.6 resident).  The 2-D tiling is chosen for the whole batch -- 240 workgroups
+    //  per member where the chip holds a thousand --, so a launch over two members of eight takes two thirds of the time of
+    //  one over all eight, there are no lanes, and the two plans cost a millisecond: profiles/r06_host_pipeline.txt)
+    for (int q = 0; q + 1 < p.ncoef; q++) rolling = rolling && (p.c[q] ? (p.nbatch == 1 || p.sc[q] == 0) : (roll2d && q == 1));
+    // (3-D: a volume per upload event; 2-D: the chunk scheme's chunks -- it takes over when the forcing has masked tiles)
+    const std::vector<int64_t> chunks = (rolling && !roll2d) ? std::vector<int64_t>((size_t)p.nbatch, 1) : host_chunks(p, opt);
     const int64_t nchunk = (int64_t)chunks.size();
     std::vector<int64_t> first((size_t)nchunk + 1, 0);
     for (int64_t c = 0; c < nchunk; c++) first[(size_t)c + 1] = first[(size_t)c] + chunks[(size_t)c];
@@ -485,7 +491,8 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // when the launch is about to run; a retired member's control block travels behind its last launch, its final state
     // is put into S as finalise() does (the redo of a pass the stop rule fired in: from that pass's source, intact since),
     // and the downloader takes it from there behind an event.
-    auto roll_3d = [&]() -> int {
+    constexpr int ROLL_FALLBACK = 0x7fff0001;            // (not an error: the chunk scheme takes the call)
+    auto roll = [&]() -> int {
         const int64_t nb = p.nbatch;
         {   // the plan needs the shared coefficient arrays: they travel ahead of member 0
             std::unique_lock<std::mutex> lk(act.mu);
@@ -499,9 +506,27 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         memset(&t_stats, 0, sizeof t_stats);
         const auto t_plan0 = std::chrono::steady_clock::now();
         Plan pl;
-        r = make_plan(d, o1, ws, scp, pl);
+        xinv_options oroll = o1;
+        if (roll2d) {
+            // 2-D: the plan of a batch reads every member's forcing (the lists of fully masked tiles) -- the rolling batch plans
+            // before they have arrived.  The first chunk is planned alone: if IT has masked tiles to skip, the chunk scheme
+            // takes the call; else the batch is planned without tile lists (a later member's masked tiles are swept like any
+            // other: the update leaves masked points alone, the result is the same).
+            Problem d1 = d;
+            d1.nbatch = chunks[0];
+            Plan pa;
+            r = make_plan(d1, o1, ws, scp, pa);
+            if (r) return r;
+            // (the point-factor stream of the general form with coefficients that vary along x folds the forcing's mask into the
+            //  factors: it reads every member's forcing too)
+            if (pa.path != XINV_PATH_FUSED || pa.skip || pa.pq) return ROLL_FALLBACK;
+            for (int q = 0; q < p.ncoef; q++)                // (what that plan found constant along x is not tested again)
+                if (d.c[q] && d.sc[q] == 0 && ((t_detected_um >> q) & 1u)) d.known_um |= 1u << q;
+            oroll.flags |= XINV_FLAG_NO_TILE_SKIP;
+        }
+        r = make_plan(d, oroll, ws, scp, pl);
         if (r) return r;
-        if (pl.path != XINV_PATH_FUSED) { t_err = "internal: rolling batch without a streaming kernel"; return XINV_ERR_HIP; }
+        if (pl.path != XINV_PATH_FUSED || pl.skip || pl.pq) return roll2d ? ROLL_FALLBACK : (t_err = "internal: rolling batch without a streaming kernel", XINV_ERR_HIP);
         const double plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
         // workspace (run_sweeps' own, without the lagged norm: never in 3-D)
         r = tail_wait(ws, scp);
@@ -527,7 +552,12 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         std::vector<int64_t> join((size_t)nb, -1);
         struct Retired { int64_t a, b; hipEvent_t ctl_done; };
         std::deque<Retired> fin;
-        constexpr int NQ = 4;
+        // How far the host runs ahead of the GPU: far enough that a wake-up of the pacing wait (20-50 us) never starves the
+        // queue -- ~400 us of launches, two at least (a 3-D launch is 0.1-1 ms, a 2-D one 30-60 us) --, not so far that a
+        // member that has just arrived waits long for the next join.
+        constexpr int NQ = 16;
+        const double est_launch_us = std::max(20.0, (double)nb * (double)n * pl.K / (pl.pipe ? 6.0e5 : (is3d(p.kind) ? 2.5e5 : 3.0e5)) * 0.6);
+        const int depth = (int)std::min(12.0, std::max(2.0, 400.0 / est_launch_us));
         hipEvent_t ev_l[NQ];
         for (int q = 0; q < NQ; q++) if ((r = ev.make(&ev_l[q], false))) return r;
         hipEvent_t ev_t0, ev_t1;
@@ -566,20 +596,23 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             if (rr) return rr;
             return finish_members(g.a, g.b - g.a, scp, after);
         };
-        int64_t lo = 0, hi = 0;
+        int64_t lo = 0, hi = 0, cj = 0;
         for (int64_t i = 0; lo < nb; i++) {
             if (!(i & 1)) {                                          // a join point: buffer 0 is the source of this launch
-                int64_t nh = hi;
+                int64_t cn = cj;                                     // (chunks cj .. cn-1 have arrived)
                 {
                     std::unique_lock<std::mutex> lk(act.mu);
-                    if (hi == lo && hi < nb)                         // nobody active: wait for the next arrival
-                        act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)hi] != 0 || act.abort; });
+                    if (hi == lo && cj < nchunk)                     // nobody active: wait for the next arrival
+                        act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)cj] != 0 || act.abort; });
                     if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
                     if (act.abort) { t_err = "host-pointer solve aborted"; return XINV_ERR_HIP; }
-                    while (nh < nb && act.chunk_ready[(size_t)nh]) nh++;
+                    while (cn < nchunk && act.chunk_ready[(size_t)cn]) cn++;
                 }
-                for (int64_t m = hi; m < nh; m++) { HIPCHK(hipStreamWaitEvent(scp, e_chunk[(size_t)m], 0)); join[(size_t)m] = i; }
-                hi = nh;
+                for (; cj < cn; cj++) {
+                    HIPCHK(hipStreamWaitEvent(scp, e_chunk[(size_t)cj], 0));
+                    for (int64_t m = first[(size_t)cj]; m < first[(size_t)cj + 1]; m++) join[(size_t)m] = i;
+                    hi = first[(size_t)cj + 1];
+                }
             }
             if (hi > lo) {
                 int64_t f = lo;                                      // [lo, f): their last launch (klast sweeps)
@@ -602,7 +635,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
                 }
             }
             HIPCHK(hipEventRecord(ev_l[i % NQ], scp));
-            if (i >= 2) HIPCHK(hipEventSynchronize(ev_l[(i - 2) % NQ]));     // two launches ahead of the GPU, no more
+            if (i >= depth) HIPCHK(hipEventSynchronize(ev_l[(i - depth) % NQ]));   // `depth` launches ahead of the GPU, no more
             while (!fin.empty() && hipEventQuery(fin.front().ctl_done) == hipSuccess) {
                 r = finish(fin.front()); if (r) return r;
                 fin.pop_front();
@@ -622,13 +655,18 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         t_stats.xuniform_mask = (int32_t)pl.um; t_stats.lanes = 1; t_stats.sweep_launches = nlaunch;
         t_stats.sweeps_max = sweeps_max; t_stats.sweep_ms = ms; t_stats.plan_ms = plan_ms;
         t_stats.k_chunks = pl.K2 ? std::max(1, pl.nkc2) : 0;
+        t_stats.pipelined = pl.pipe ? pl.npair : 0;
+        t_stats.rolling = 1;
         acc = t_stats; acc_set = true;
         return XINV_OK;
     };
+    bool rolled = false;
     if (rolling) {
-        rc = roll_3d();
-        if (rc) return rc;
-    } else {
+        rc = roll();
+        if (rc && rc != ROLL_FALLBACK) return rc;
+        rolled = (rc == XINV_OK);
+    }
+    if (!rolled) {
     for (int k = 1; k < ninfl; k++)
         act.solvers.emplace_back([&, k]() {
             int r = (hipSetDevice(device) == hipSuccess) ? XINV_OK : XINV_ERR_HIP;
