@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two processes on ONE GPU solving two C5 volumes each at the same time: are the fields those of a process alone?"""
 import os, sys, subprocess, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == 'worker':
     lo, hi, cus, sweeps, lanes = (int(v) for v in sys.argv[2:7])
