@@ -65,7 +65,11 @@ UPD_FLOPS = {'std2d': 16, 'gen2d': 25, 'std3d': 21, 'bih2d': 45}
 # first keys of `roofline`, in this order (the driver keeps 24)
 ROOF_FIRST = ['bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_GBps', 'traffic_frac_of_hbm_peak',
               'hbm_frac', 'executed_over_useful', 'parity_bitwise', 'avg_launch_ms', 'launches', 'ms_outside_launches',
-              'kernel', 'configs', 'hbm_variant', 'valu_frac', 'alg_frac', 'alg_GBps', 'alg_bytes_per_launch',
+              'kernel', 'valu_frac', 'frac_of_fma_datasheet_peak',
+              # (scalars of the other legs, so that they survive in the driver's record: VERDICT r5 items 4 and 5)
+              'sustained_value', 'sustained_launch_drift', 'e2e_c2_invert_poisson_ms', 'e2e_c5x15_ms',
+              'e2e_c5x15_vs_resident', 'e2e_c4x8_ms', 'src_sha',
+              'configs', 'hbm_variant', 'alg_frac', 'alg_GBps', 'alg_bytes_per_launch',
               'streamed_bytes_per_point_sweep', 'active_tile_share', 'in_infinity_cache']
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 # fp64 vector ALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T operations/s (the 78.6 TFLOP/s
@@ -883,6 +887,8 @@ def main():
             out['roofline']['parity_bitwise'] = bool(par['bitwise'] and par['loop_equal'] and same_cfg)
         if a.config == 'c2' and single and not a.no_configs:
             out['sustained'] = sustained_leg(rp, sweeps, opts, float(nb) * n, a.sustained_seconds)
+            out['roofline']['sustained_value'] = out['sustained']['value']
+            out['roofline']['sustained_launch_drift'] = out['sustained']['launch_drift']
         if a.config == 'c2' and single and a.mask == 'continents' and not a.no_configs:
             # mask sensitivity of the headline: the same solve with a coastline-scale mask
             # (few whole tiles to skip) and with tile skipping off
@@ -921,6 +927,9 @@ def main():
                                                                   'parity_bitwise')} for c in out['configs']]
         if a.config == 'c2' and single and not a.no_e2e and (a.ny, a.nx) == (1800, 3600) and a.mask == 'continents':
             out['end_to_end'] = end_to_end_leg(local, p, S_res500)
+            e2 = out['end_to_end']
+            out['roofline'].update({'e2e_c2_invert_poisson_ms': e2['C2_invert_Poisson']['wall_ms'], 'e2e_c5x15_ms': e2['C5x15']['wall_ms'],
+                                    'e2e_c5x15_vs_resident': e2['C5x15']['vs_resident'], 'e2e_c4x8_ms': e2['C4x8']['wall_ms']})
         if a.inproc and single:
             out['inproc'] = inproc_leg(a, a.gpus)
         if a.config == 'c2' and single and not a.no_cpu:
