@@ -889,6 +889,15 @@ def main():
             out['sustained'] = sustained_leg(rp, sweeps, opts, float(nb) * n, a.sustained_seconds)
             out['roofline']['sustained_value'] = out['sustained']['value']
             out['roofline']['sustained_launch_drift'] = out['sustained']['launch_drift']
+        if a.config == 'c2' and single and not a.no_configs:
+            # the same solve WITHOUT a resident plan (every call of xinv_<form>_f64_dev re-derives what a plan keeps: what
+            # rounds 1-4 timed) -- for continuity with their lines
+            rq = ResidentProblem(p, device=local, plan=False)
+            tq, mq, lq, sq, _ = time_resident(rq, sweeps, 5, 2, timing=1)
+            out['unplanned'] = {'value': float(nb) * n * sweeps * 5 / tq, 'unit': 'point-sweeps/s', 'ms_per_step': tq / 5 * 1e3,
+                                'avg_launch_us': mq / max(lq, 1) * 1e3, 'planned': int(sq.get('planned', 0)),
+                                'note': 'ResidentProblem(plan=False): detection passes, per-row records and tile lists rebuilt in every solve'}
+            del rq
         if a.config == 'c2' and single and a.mask == 'continents' and not a.no_configs:
             # mask sensitivity of the headline: the same solve with a coastline-scale mask
             # (few whole tiles to skip) and with tile skipping off
