@@ -991,7 +991,7 @@ def _medium_fuzz(chunk, seed0, odd, every_case_stops=False, runner=None):
 @pytest.mark.parametrize('shape', [(50, 40, 130), (37, 20, 250), (50, 41, 130), (50, 42, 130)])
 def test_pipe3d_tail_cut(BCy, BCx, nmem, cus, shape):
     """k_pipe3d runs one workgroup per CU; the tiles of a launch's last, partly filled round are cut into k chunks while the
-    others march the whole column (xinv_pipe3d.h, p3_whole_tiles).  With `cu_count` a small batch takes the mixed launch:
+    others march the whole column (xinv_pipe3d.h; xinv_tiles.h: xinv_p3_whole_tiles).  With `cu_count` a small batch takes the mixed launch:
     whole-column and cut tiles of one member, members of both kinds -- bit for bit the oracle, stop rule included."""
     # (BCy = 'extend': yc = 40 / 42 put rows yc-2, yc-1 into one wavefront; 41 splits them: the one-sweep kernel)
     ps = [_uniform3d(rand3d(shape[0], shape[1], shape[2], BCy, BCx, 1, seed=_seed(('tail', BCy, BCx, nmem, cus, shape, m))), None)

@@ -324,5 +324,5 @@ class xarray_standin:
 
 def p3_extend_ok(yc):
     """The two-sweep 3-D pass takes BCy = 'extend' at every row count since the row blocks may be shifted up by two rows
-    (xinv_launch.h: p3_extend_joff); kept for the tests that asked which counts it took before."""
+    (xinv_tiles.h: xinv_p3_extend_joff); kept for the tests that asked which counts it took before."""
     return True

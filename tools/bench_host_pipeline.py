@@ -17,8 +17,10 @@ ap.add_argument('--chunks', default='', help='comma list of host_chunk values to
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--lanes', type=int, default=0)
 ap.add_argument('--inflight', default='0', help='comma list of xinv_options.host_inflight values')
+ap.add_argument('--check-every', type=int, default=0, help='xinv_options.check_every: launches per host poll (0 = the engine chooses)')
 a = ap.parse_args()
-p = synthetic.omega_latlon(50, 360, 720, a.members) if a.config == 'c5' else synthetic.gill_matsuno(720, 1440, a.members)
+p = (synthetic.omega_latlon(50, 360, 720, a.members) if a.config == 'c5' else synthetic.poisson_latlon(1800, 3600, members=a.members) if a.config == 'c2'
+     else synthetic.gill_matsuno(720, 1440, a.members))
 L = _lib.require_gpu()
 nb = p['S0'].shape[0]; n = int(np.prod(p['S0'].shape[1:]))
 rp = ResidentProblem(p)
@@ -42,7 +44,7 @@ for chunk, infl in [(c_, i_) for c_ in ([int(v) for v in a.chunks.split(',')] if
     for rep in range(a.reps):
         S = arrs[0].copy()
         fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
-        o = _lib.options(host_chunk=chunk, host_inflight=infl, lanes=a.lanes)
+        o = _lib.options(host_chunk=chunk, host_inflight=infl, lanes=a.lanes, check_every=a.check_every)
         t = time.perf_counter()
         rc = getattr(L, FN[p['kind']] + '_batched')(_lib.hptr(S), *[_lib.hptr(x) for x in arrs[1:]], nb, _lib.strides_arg(strides),
                                                     *scalars(p), _lib.hptr(fl), a.sweeps - 1, 0.0, ctypes.byref(o))
@@ -50,6 +52,6 @@ for chunk, infl in [(c_, i_) for c_ in ([int(v) for v in a.chunks.split(',')] if
         _lib.check(rc)
         if dt < best:
             best, st = dt, _lib.last_stats()
-    print(json.dumps({'entry': 'host pointers', 'host_chunk': chunk, 'inflight': infl, 'chunks': st['host_chunks'], 'wall_ms': best * 1e3,
+    print(json.dumps({'entry': 'host pointers', 'host_chunk': chunk, 'inflight': infl, 'check_every': a.check_every, 'lanes': a.lanes, 'chunks': st['host_chunks'], 'wall_ms': best * 1e3,
                       'h2d_ms': st['h2d_ms'], 'd2h_ms': st['d2h_ms'], 'vs_dev': best / dev_s,
                       'point_sweeps_per_s': nb * n * a.sweeps / best}), flush=True)

@@ -48,7 +48,7 @@ struct Fused3Args {
     // a launch whose tile count is not a multiple of the compute units).  nfull == 0: every tile is cut.
     int64_t nfull;
     int joff;                  // k_pipe3d: rows the row blocks are shifted up by (0, or 2 with BCy = 'extend' where that puts rows
-                               // yc-2 / yc-1 into one wavefront: xinv_launch.h, p3_extend_joff); block jb owns rows [jb RJ - joff, ..)
+                               // yc-2 / yc-1 into one wavefront: xinv_tiles.h, xinv_p3_extend_joff); block jb owns rows [jb RJ - joff, ..)
 };
 
 // 7-point update with the mask folded into a select (numbas.py:146-169).

@@ -63,8 +63,11 @@ struct CopyPool {                                   // process-wide memcpy worke
         std::lock_guard<std::mutex> lk(mu);
         if (nworker) return;
         unsigned hc = std::thread::hardware_concurrency();
-        { const int e_ = XINV_ENV_INT("XINV_COPY_THREADS", 0); if (e_ > 0) hc = 2u * (unsigned)e_; }
-        nworker = (int)std::max(1u, std::min(8u, hc / 2u));
+        // (three workers + the caller.  Round 6, EPYC 9575F host, 3600 x 1800 host to host / C4 x 8 through host pointers, ms:
+        //  no worker 8.4 / 15.0, one 7.4-7.9 / 13.4-13.8, two 7.5 / 13.1, three 7.5 / 13.3, four 7.6 / 13.0, eight -- until
+        //  then -- 7.7 / 13.4, sixteen 7.9 / 13.4, twenty-four 8.0 / 14.4: one core moves ~25 GB/s, more hands only add wake-ups)
+        nworker = (int)std::max(1u, std::min(3u, hc / 2u));
+        { const int e_ = XINV_ENV_INT("XINV_COPY_THREADS", 0); if (e_ > 0) nworker = std::min(e_, 32); if (e_ < 0) nworker = 0; }
         for (int i = 0; i < nworker; i++)
             th.emplace_back([this] {
                 for (;;) {
@@ -86,7 +89,7 @@ struct CopyPool {                                   // process-wide memcpy worke
     // copy n bytes with the workers + the calling thread; returns when every byte has landed
     void copy(void *d, const void *s, size_t n)
     {
-        if (n < ((size_t)4 << 20) || nworker < 1) { memcpy(d, s, n); return; }
+        if (n < ((size_t)4 << 20) || nworker < 1 || th.empty()) { memcpy(d, s, n); return; }
         const int parts = nworker + 1;
         const size_t piece = ((n / parts) + 4095) & ~(size_t)4095;
         Batch b;
@@ -155,8 +158,16 @@ static int stage_h2d(StageRing &r, hipStream_t s, double *dev, const double *hos
     }
     int rc = r.ensure();
     if (rc) return rc;
-    for (size_t off = 0; off < bytes; off += StageRing::SLOT) {
-        const size_t n = std::min(StageRing::SLOT, bytes - off);
+    // An idle ring (the first array of a call): the DMA engine waits for the first slot's memcpy -- 32 MiB, half a
+    // millisecond nothing overlaps.  Start with short pieces (4, 8, 16 MiB), so that the engine starts after 4 MiB;
+    // a ring with copies in flight keeps whole slots (more, smaller DMAs cost a long batch a third: StageRing).
+    bool idle = true;
+    for (int k = 0; k < StageRing::NSLOT && idle; k++)
+        if (r.inflight[k]) { if (hipEventQuery(r.ev[k]) == hipSuccess) r.inflight[k] = false; else idle = false; }
+    (void)hipGetLastError();                         // (hipErrorNotReady of the query)
+    size_t piece = idle ? ((size_t)4 << 20) : StageRing::SLOT;
+    for (size_t off = 0; off < bytes; ) {
+        const size_t n = std::min(piece, bytes - off);
         const int k = r.next;
         if (r.inflight[k]) { HIPCHK(hipEventSynchronize(r.ev[k])); r.inflight[k] = false; }
         g_copy_pool.copy(r.buf[k], (const char *)host + off, n);
@@ -164,6 +175,8 @@ static int stage_h2d(StageRing &r, hipStream_t s, double *dev, const double *hos
         HIPCHK(hipEventRecord(r.ev[k], s));
         r.inflight[k] = true;
         r.next = (k + 1) % StageRing::NSLOT;
+        off += n;
+        piece = std::min(StageRing::SLOT, piece * 2);
     }
     return XINV_OK;
 }
@@ -254,7 +267,7 @@ static int bind_thread_to_device_node(int device)
 // Grown on demand, reused across solves (no hipMalloc in steady state).
 #define XINV_MAX_LANES 4
 #define XINV_MAX_INFLIGHT 6          /* host-pointer entries: chunk solves in flight on one device (workspace slots 0 .. 5) */
-#define XINV_DEFAULT_INFLIGHT 2
+#define XINV_DEFAULT_INFLIGHT 4          /* ... of the 2-D forms (three for the 3-D ones: xinv_hostptr.h) */
 struct Workspace {
     int device = -1;
     int cus = 0;                                        // the device's compute units (make_plan)

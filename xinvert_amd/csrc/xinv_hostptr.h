@@ -57,8 +57,8 @@ static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &op
     // upload / last download against the fixed cost of a chunk (~0.5 ms of planning, launches of few workgroups).
     // Measured (profiles/r05_host_pipeline.txt): C5, 15 volumes -- 1 chunk 212 ms, [4, 7, 4] (round 4's split) 172,
     // chunks of 2 volumes 161, of 1 volume 200; C4, 8 members -- 1 chunk 15.4 ms, chunks of 2 members 14.1, of 1: 17.2.
-    if (total < 100663296.0 || nb < 4) { out.push_back(nb); return out; }
     if (is3d(p.kind)) {
+        if (total < 100663296.0 || nb < 4) { out.push_back(nb); return out; }
         // Round 6 (profiles/r06_host_pipeline.txt; C5 x 15, ms): chunks of three volumes, THREE chunk solves in flight, each
         // one launch chain (no lanes inside a chunk): 148; chunks of two, two in flight -- round 5 -- 160-167; three
         // in flight 155; chunks of four 154-168; ramps 1, 2, 4, .. 163-173.  The remainder LAST.
@@ -66,9 +66,18 @@ static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &op
         for (int64_t m0 = 0; m0 < nb; m0 += per) out.push_back(std::min(per, nb - m0));
         return out;
     }
-    const int64_t nch = std::min<int64_t>(std::min<int64_t>(4, nb / 2), std::max<int64_t>(2, (int64_t)((total + 33554431.0) / 33554432.0)));
-    for (int64_t c = 0; c < nch; c++) out.push_back(nb / nch + (c < nb % nch ? 1 : 0));
-    return out;
+    // 2-D forms, end of round 6 (FOUR chunk solves in flight, the copy streams at high priority; wall ms of 500 sweeps,
+    // profiles/r06_host_pipeline.txt): 1440 x 720 general form x 3 members -- chunks of 1: 6.6, one chunk 7.1; x 6 -- 1: 11.4,
+    // 2: 14.5, 3: 13.0; x 8 -- 1: 13.5, 2: 13.1, 4: 14.7; x 12 -- 1: 18.8, 2: 17.7, 3: 22.4; x 16 -- 2: 21.6, 4: 27.1; x 32 --
+    // 2: 38.1, 4: 43.0, 8: 40.4; x 64 -- 4: 82.3, 8: 75.2, 16: 73.0.  3600 x 1800 standard form x 2 -- 1: 15.9, one chunk 17.6;
+    // x 3 -- 1: 22.2, one chunk 24.5; x 4 -- 1: 27.0, 2: 26.6; x 8 -- 1: 44.2, 2: 43.8.  Odd chunks lose (their two lanes are
+    // uneven); single members up to eight, pairs up to 32, four chunks beyond.
+    if (total < 50331648.0) { out.push_back(nb); return out; }
+    {
+        const int64_t per = nb < 8 ? 1 : (nb <= 32 ? 2 : (nb + 3) / 4);
+        for (int64_t m0 = 0; m0 < nb; m0 += per) out.push_back(std::min(per, nb - m0));
+        return out;
+    }
 }
 
 // One device: upload -> solve -> download, pipelined over member chunks by three actors:
@@ -106,6 +115,13 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
 {
     const bool may_register = (outer == nullptr);     // a per-device call of a multi-device solve uses the parent's registrations
     const auto wall0 = std::chrono::steady_clock::now();
+    // XINV_HOST_TRACE=1: host-side time stamps of the call's phases on stderr (ms since entry; diagnosis only)
+    static const bool trace_on = XINV_ENV_INT("XINV_HOST_TRACE", 0) != 0;
+    auto trace = [&](const char *what, long long k = -1) {
+        if (!trace_on) return;
+        fprintf(stderr, "[xinv host %8.3f ms] %s%s%lld\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count(),
+                what, k < 0 ? " " : " #", k);
+    };
     DeviceGuard dg;
     HIPCHK(dg.select(opt.device));
     int device = 0;
@@ -115,8 +131,19 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // upload -> solve -> download sequence
     Workspace *ws = get_ws(device);
     std::lock_guard<std::recursive_mutex> host_lock(ws->busy);
+    // The copy streams take the highest stream priority: the runtime keeps its hardware queues per priority, so the staged
+    // copies (blit kernels on this runtime) no longer queue behind a chunk solve's launch chain that happens to share
+    // their hardware queue -- C4 x 8 with four chunk solves in flight: 14.0 -> 12.8 ms, uploads no longer stretched to
+    // 8 ms (profiles/r06_host_pipeline.txt; XINV_COPY_PRIO=0 in a hooks build: the round-5 streams).
     for (hipStream_t *sp : { &ws->s_up, &ws->s_down, &ws->s_compute })
-        if (!*sp) HIPCHK(hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+        if (!*sp) {
+            if (sp != &ws->s_compute && XINV_ENV_INT("XINV_COPY_PRIO", 1)) {
+                int lo_ = 0, hi_ = 0;
+                HIPCHK(hipDeviceGetStreamPriorityRange(&lo_, &hi_));
+                HIPCHK(hipStreamCreateWithPriority(sp, hipStreamNonBlocking, hi_));
+            } else
+                HIPCHK(hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+        }
     hipStream_t sup = ws->s_up, sdn = ws->s_down, scp = ws->s_compute;
     DevPool *pool = get_pool(device);
     pool->reset();
@@ -317,6 +344,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             }
     }
 
+    trace("set up: device buffers, ops queued for the uploader");
     // ---- the actors -----------------------------------------------------------------------------
     HostActors act;
     act.streams = { sup, sdn, scp };
@@ -332,8 +360,10 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         };
         if (!r && hipEventRecord(e_up0, sup) != hipSuccess) r = XINV_ERR_HIP;
         if (!r) run(shared_ops);
+        trace("uploader: shared arrays queued");
         for (int64_t c = 0; c < nchunk; c++) {
             if (!r) run(chunk_ops[(size_t)c]);
+            trace("uploader: chunk queued", c);
             if (!r && hipEventRecord(e_chunk[(size_t)c], sup) != hipSuccess) r = XINV_ERR_HIP;
             if (!r && c == nchunk - 1 && hipEventRecord(e_up1, sup) != hipSuccess) r = XINV_ERR_HIP;
             { std::lock_guard<std::mutex> lk(act.mu); act.chunk_ready[(size_t)c] = 1; if (r) { act.u_rc = r; act.u_err = t_err; } }
@@ -355,10 +385,12 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             if (r) continue;
             if (first_job) { if (hipEventRecord(e_dn0, sdn) != hipSuccess) r = XINV_ERR_HIP; first_job = false; }
             if (!r) { try { r = job(); } catch (const std::exception &e) { t_err = e.what(); r = XINV_ERR_HIP; } }
+            trace("downloader: job queued / staged");
         }
         if (!r && first_job && hipEventRecord(e_dn0, sdn) != hipSuccess) r = XINV_ERR_HIP;
         if (!r && hipEventRecord(e_dn1, sdn) != hipSuccess) r = XINV_ERR_HIP;
         if (!r && hipStreamSynchronize(sdn) != hipSuccess) r = XINV_ERR_HIP;
+        trace("downloader: drained");
         std::lock_guard<std::mutex> lk(act.mu);
         act.d_rc = r; if (r) act.d_err = t_err;
     });
@@ -373,6 +405,12 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // (276 tiles on 256 CUs) ends in a tail during which only the OTHER chains' launches keep the CUs busy.  Two chains
     // (round 5) left the chip 1.68 launches deep on average -- C5 x 15: 160 ms of which the GPU is busy 160, at 107 us per
     // volume and launch against 77 for the resident batch (profiles/r06_host_pipeline.txt) --; three / four fill the tails.
+    // 2-D forms: FOUR (end of round 6, with the copy streams at high priority: C4 x 8 14.4 -> 13.3 ms, 3600 x 1800 x 8
+    // 47.6 -> 43.6; before, a third and fourth chain stretched the uploads behind them to 8 ms).  What is left against the
+    // resident batch (C4 x 8, 2000 sweeps: 37.1 ms against 28.4 + 5 of copies) is the price of chains issued by different
+    // host threads into the runtime's hardware queues: two chains alternating in ONE queue -- the lanes of a resident solve --
+    // overlap launch by launch, chains in different queues are arbitrated worse (GPU_MAX_HW_QUEUES=8 makes the resident
+    // two-lane solve itself 7.6 -> 11.7 ms).
     const int ninfl = (int)std::min<int64_t>(nchunk, std::max(1, opt.host_inflight > 0 ? std::min(opt.host_inflight, XINV_MAX_INFLIGHT)
                                                                                          : (is3d(p.kind) ? 3 : XINV_DEFAULT_INFLIGHT)));
     std::vector<Workspace *> wss((size_t)ninfl, nullptr);
@@ -456,6 +494,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             if (act.abort) { t_err = "host-pointer solve aborted"; return XINV_ERR_HIP; }
         }
         HIPCHK(hipStreamWaitEvent(cs, e_chunk[(size_t)c], 0));
+        trace("solver: chunk's upload queued, solve starts", c);
         Problem dc = d;
         { std::lock_guard<std::mutex> lk(act.mu); dc.known_um |= shared_um; }     // (what an earlier chunk's plan found out)
         dc.nbatch = nm;
@@ -464,6 +503,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             if (d.c[q] && d.sc[q] != 0) dc.c[q] = d.c[q] + m0 * d.sc[q];
         int r = solve_dev(dc, flags + 3 * m0, &o1, cs, slot);
         if (r) return r;
+        if (trace_on) { char b_[96]; snprintf(b_, sizeof b_, "solver: chunk solved (plan %.3f ms, sweeps %.3f ms)", t_stats.plan_ms, t_stats.sweep_ms); trace(b_, c); }
         {
             std::lock_guard<std::mutex> lk(act.mu);
             for (int q = 0; q < p.ncoef; q++)            // shared arrays found constant along x: the same for every chunk
@@ -682,9 +722,11 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     for (auto &t : act.solvers) if (t.joinable()) t.join();
     if (act.s2_rc) { t_err = act.s2_err; return act.s2_rc; }
     }
+    trace("solves done");
     act.close_downloads();
     act.up.join();
     act.down.join();
+    trace("uploader and downloader joined");
     if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
     if (act.d_rc) { t_err = act.d_err; return act.d_rc; }
     HIPCHK(hipStreamSynchronize(sup));

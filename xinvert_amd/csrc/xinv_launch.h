@@ -67,51 +67,18 @@ static inline int strip_uw(const Plan &pl, int K, bool pipe)
     return pipe ? XINV_PIPE_UW(pl.npair) : 128 - 4 * K;
 }
 
-// k_pipe3d runs ONE workgroup per compute unit.  A launch of `tiles` tiles (every member of the launch) therefore takes
-// ceil(tiles / cus) rounds of a whole march -- and when the last round holds only a few tiles (15 volumes of
-// 50 x 360 x 720 on 256 CUs: 2070 tiles, 8.09 rounds) they march alone while the other CUs idle.  The plan fixes a cut of
-// the column into nk chunks of KC planes (a member's partial slots are laid out for it); per launch this decides which
-// tiles are cut: none, all (small batches: more workgroups than tiles), or the remainder of the last round -- pieces that
-// start together when the whole-column rounds end and finish in a fraction of a march.  Costs in pipeline steps, as the
-// planner's: a whole march zc + 4, a chunk KC + 14 (four halo planes a side and the pipeline's fill).
-// Returns the number of tiles marched whole (they come first in the launch).
-static int64_t p3_whole_tiles(int64_t tiles, int nk, int64_t KC, int64_t zc, int cus_, double *cost_out = nullptr)
+// k_pipe3d's launch shape (which tiles of a launch march the whole column, which are cut into the plan's k chunks) and the
+// 'extend' variant's tiling offset: xinv_tiles.h (xinv_p3_whole_tiles, xinv_p3_extend_joff; checked on the CPU).
+static int64_t p3_whole_tiles(int64_t tiles, int nk, int64_t KC, int64_t zc, int cus, double *cost_out = nullptr)
 {
-    const bool no_rem = cus_ < 0;                        // (xinv_options.cu_count = -n: n compute units, never the remainder cut)
-    const int cus = cus_ < 0 ? -cus_ : cus_;
-    const double cf = (double)(zc + 4), cs = (double)(KC + 14);
-    double best = (double)cdiv(tiles, cus) * cf;
-    int64_t nfull = tiles;
-    if (nk > 1) {
-        const double call = (double)cdiv(tiles * nk, cus) * cs;
-        if (call < best * 0.97) { best = call; nfull = 0; }
-        const int64_t r = tiles % cus, R = tiles / cus;
-        if (r && R && !no_rem) {
-            const double crem = (double)R * cf + (double)cdiv(r * nk, cus) * cs;
-            if (crem < best * 0.985) { best = crem; nfull = tiles - r; }
-        }
-    }
-    if (cost_out) *cost_out = best;
-    return nfull;
+    return xinv_p3_whole_tiles(tiles, nk, KC, zc, cus, cost_out);
 }
 
-// k_pipe3d with BCy = 'extend' (xinv_pipe3d.h: EXT) applies the second sweep's pre-pass out of a wavefront's own registers:
-// rows 0 / 1 and rows yc-2 / yc-1 each have to sit in ONE wavefront (RR adjacent rows each; the cross-section of row block
-// jb starts at row jb * RJ - H - joff) -- the first pair in block 0, the second in the block that owns row yc-1 and in the
-// block before it when that one owns row yc-2 or yc-3, whose second sweep reads row yc-1 through row yc-2.  Returns the
-// shift of the row blocks that achieves it: 0 for five row counts in eight, 2 for the others (-1: none -- not reached).
-static bool p3_extend_ok(int64_t yc, int joff)
+static int p3_extend_joff(int64_t yc)
 {
-    const int RJ = XINV_P3_G * XINV_P3_RR - 8, H = 4, RR = XINV_P3_RR;
-    static_assert(XINV_P3_RR == 3 && XINV_P3_G * XINV_P3_RR - 8 > 0, "p3_extend_ok: three rows per wavefront");
-    if ((H + joff) % RR == RR - 1) return false;                   // row 0 would be a wavefront's last row
-    const int64_t jbo = (yc - 1 + joff) / RJ;                      // the block that owns row yc-1
-    auto together = [&](int64_t jb) { return ((yc - 2) - (jb * RJ - H - joff)) % RR != RR - 1; };   // row yc-2 is not a wavefront's last row
-    if (!together(jbo)) return false;
-    if (jbo > 0 && (yc - 1 + joff) - jbo * RJ <= 1 && !together(jbo - 1)) return false;
-    return true;
+    static_assert(XINV_P3_RR == 3 && XINV_P3_G * XINV_P3_RR - 8 > 0, "k_pipe3d: three rows per wavefront");
+    return xinv_p3_extend_joff(yc, XINV_P3_G * XINV_P3_RR - 8, 4, XINV_P3_RR);
 }
-static int p3_extend_joff(int64_t yc) { return p3_extend_ok(yc, 0) ? 0 : (p3_extend_ok(yc, 2) ? 2 : -1); }
 
 static int fused_dispatch(int kind, bool al, bool ext, unsigned um, int K, dim3 grid, dim3 block,
                           hipStream_t st, const FusedArgs &a, int *occ, bool seam = false, bool fma = false, bool pq = false)

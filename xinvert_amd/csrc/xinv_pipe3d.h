@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_row_factor3d(RowFactor3Args a)
 // applied by group 1 to the plane it takes out of the ring, before anything reads it, out of the wavefront's own registers:
 // rows 0 / 1 and rows yc-2 / yc-1 each have to sit in one wavefront of every cross-section that needs the boundary row
 // right: true for five row counts in eight as the blocks lie, for all of them with the blocks shifted up by two rows where
-// needed (Fused3Args::joff; p3_extend_joff, xinv_launch.h).  (Round 5 loaded the partner rows from HBM; round 6 first read row yc-2 out of the neighbouring
+// needed (Fused3Args::joff; xinv_p3_extend_joff, xinv_tiles.h).  (Round 5 loaded the partner rows from HBM; round 6 first read row yc-2 out of the neighbouring
 // wavefront's ring slot where the pair is split: both bit-exact, both spilled 26-34 registers and ran at a third of the
 // rate -- the kernel has 128 registers and uses 123-126.)
 template <int G, int RR, bool AL, bool FMA = false, bool SEAM = false, bool EXT = false>
@@ -101,36 +101,17 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
     const int NT = a.nstrip * a.njb;                     // tiles of a member
     const int NB = NT * a.nkc;                           // partial slots of a member
     const int L = (int)blockIdx.x, nfull = (int)a.nfull; // (a launch has fewer than 2^31 workgroups)
-    const bool whole = L < nfull;
-    int g;                                               // tile index in the launch, member-major
-    int kc = 0;
-    if (whole) g = L;
-    else { const int q = L - nfull; g = nfull + q / a.nkc; kc = q - (g - nfull) * a.nkc; }
+    const bool whole = L < nfull;                        // (slot -> tile, chunk, member: xinv_tiles.h, shared with the CPU suite's check)
+    int kc;
+    const int g = xinv_p3_slot_tile(L, nfull, a.nkc, kc);
     const int ml = g / NT;                               // member of the launch
     const int64_t m = a.member0 + ml;
     XinvCtl *ctl = a.ctl + m;
     if (!a.force && xinv_ctl_done(ctl)) return;
     const unsigned tag = xinv_ctl_seq(ctl);
     // the member's workgroup dispatched last reduces its norm (every other one is resident or finished by then)
-    bool reducer;
-    {
-        const int gl = (ml + 1) * NT - 1;                // the member's last tile
-        reducer = (gl < nfull) ? (L == gl) : (L == nfull + (gl - nfull) * a.nkc + a.nkc - 1);
-    }
-    int Tj;                                              // tile of the member
-    if (whole) {
-        // XCD-aware order: dispatch slot L lands on XCD L & 7; the member's workgroups of one XCD take a contiguous band of
-        // its tiles (rank of (L & 7, L) among the member's slots [L0, L0 + n): with L0 a multiple of 8 this is
-        // xcd * (n / 8) + min(xcd, n % 8) + (L - L0) / 8, the mapping of the 2-D grid this kernel used to have)
-        const int L0 = ml * NT;
-        const int n = (L0 + NT <= nfull) ? NT : (nfull - L0);                 // (the member's whole-column workgroups)
-        const int xcd = L & 7;
-        auto below = [](int e, int x) { return (e >> 3) * x + ((e & 7) < x ? (e & 7) : x); };       // v in [0, e): (v & 7) < x
-        auto same = [](int e, int x) { return e <= x ? 0 : ((e - x + 7) >> 3); };                   // v in [0, e): (v & 7) == x
-        Tj = (below(L0 + n, xcd) - below(L0, xcd)) + (same(L, xcd) - same(L0, xcd));
-    } else {
-        Tj = g - ml * NT;
-    }
+    const bool reducer = xinv_p3_slot_reduces(L, nfull, a.nkc, NT, ml);
+    const int Tj = xinv_p3_slot_member_tile(L, nfull, NT, ml, g);             // tile of the member (XCD-aware order)
     const int T = kc * NT + Tj;                          // the partial slot
     const int jb = Tj / a.nstrip, st = Tj - jb * a.nstrip;
     const int zc = (int)a.zc, yc = (int)a.yc;
@@ -352,7 +333,7 @@ __global__ __launch_bounds__(2 * G * 64) void k_pipe3d(Fused3Args a)
             if (r >= 1 && r <= zc - 2 && j0 <= yc - 1 && j0 + RR > yc - 1) {  // (... row yc-1)
                 xinv_unroll_steps([&](auto rtag) {
                     constexpr int rr = decltype(rtag)::value;
-                    if (j0 + rr == yc - 1) {                     // (rr > 0 wherever this row matters: p3_extend_ok)
+                    if (j0 + rr == yc - 1) {                     // (rr > 0 wherever this row matters: xinv_p3_extend_ok)
                         const double2 inner = sw[rr > 0 ? rr - 1 : 0][U];
                         ext_fix(sw[rr][U], inner);
                     }

@@ -71,3 +71,96 @@ __host__ __device__ inline int xinv_ring_hw(int64_t xc, int H, int strip)      /
 {
     return xinv_ring_asym(xc, H) ? (strip == 0 ? H + 2 : H) : H + 2;
 }
+
+// ---- k_pipe3d (xinv_pipe3d.h): a FLAT grid over the members of a launch, one workgroup per CU -----------------------------
+// Dispatch slot L of a launch -> which tile of which member, which planes.  With g the tile's index in the launch
+// (member-major; a member has NT tiles), the slots below nfull march tile g = L through the WHOLE column; the tiles behind
+// them are cut into nkc chunks: slot nfull + q marches chunk q % nkc of tile nfull + q / nkc.  `reducer`: the slot is the
+// member's last in dispatch order (it adds the member's norm partials: every other slot of the member is resident or
+// finished by then).  Whole-column slots take the member's tiles in an XCD-aware order: slot L lands on XCD L & 7, and the
+// member's slots of one XCD take a contiguous band of its tiles -- Tj = rank of (L & 7, L) among the member's whole-column
+// slots [L0, L0 + n) (with L0 a multiple of 8: xcd * (n / 8) + min(xcd, n % 8) + (L - L0) / 8).
+// (Three pieces, so that the kernel can place them around its early exit; xinv_p3_slot puts them together.)
+__host__ __device__ inline int xinv_p3_slot_tile(int L, int nfull, int nkc, int &kc)       // -> g; kc: the chunk (0 for a whole column)
+{
+    int g;                                               // tile index in the launch, member-major
+    kc = 0;
+    if (L < nfull) g = L;
+    else { const int q = L - nfull; g = nfull + q / nkc; kc = q - (g - nfull) * nkc; }
+    return g;
+}
+__host__ __device__ inline bool xinv_p3_slot_reduces(int L, int nfull, int nkc, int NT, int ml)
+{
+    const int gl = (ml + 1) * NT - 1;                    // the member's last tile
+    return (gl < nfull) ? (L == gl) : (L == nfull + (gl - nfull) * nkc + nkc - 1);
+}
+__host__ __device__ inline int xinv_p3_slot_member_tile(int L, int nfull, int NT, int ml, int g)
+{
+    if (L < nfull) {
+        const int L0 = ml * NT;
+        const int n = (L0 + NT <= nfull) ? NT : (nfull - L0);                 // (the member's whole-column slots)
+        const int xcd = L & 7;
+        auto below = [](int e, int x) { return (e >> 3) * x + ((e & 7) < x ? (e & 7) : x); };       // v in [0, e): (v & 7) < x
+        auto same = [](int e, int x) { return e <= x ? 0 : ((e - x + 7) >> 3); };                   // v in [0, e): (v & 7) == x
+        return (below(L0 + n, xcd) - below(L0, xcd)) + (same(L, xcd) - same(L0, xcd));
+    }
+    return g - ml * NT;
+}
+struct P3Slot { int ml, Tj, kc; bool whole, reducer; };
+__host__ __device__ inline P3Slot xinv_p3_slot(int L, int nfull, int nkc, int NT)
+{
+    P3Slot s;
+    s.whole = L < nfull;
+    const int g = xinv_p3_slot_tile(L, nfull, nkc, s.kc);
+    s.ml = g / NT;
+    s.reducer = xinv_p3_slot_reduces(L, nfull, nkc, NT, s.ml);
+    s.Tj = xinv_p3_slot_member_tile(L, nfull, NT, s.ml, g);
+    return s;
+}
+
+// How many tiles of a launch march the whole column (they come first).  One workgroup per CU: `tiles` tiles take
+// ceil(tiles / cus) rounds of a whole march -- and when the last round holds only a few tiles (15 volumes of 50 x 360 x 720 on
+// 256 CUs: 2070 tiles, 8.09 rounds) they march alone while the other CUs idle.  The plan fixes a cut of the column into nk
+// chunks of KC planes; per launch: none of the tiles is cut, all are (small batches: more workgroups than tiles), or the
+// remainder of the last round -- pieces that start together when the whole-column rounds end and finish in a fraction of a
+// march.  Costs in pipeline steps: a whole march zc + 4, a chunk KC + 14 (four halo planes a side and the pipeline's fill).
+// cus < 0: -cus compute units, never the remainder cut (xinv_options.cu_count = -1: A/B comparisons).
+__host__ inline int64_t xinv_p3_whole_tiles(int64_t tiles, int nk, int64_t KC, int64_t zc, int cus_, double *cost_out = nullptr)
+{
+    const bool no_rem = cus_ < 0;
+    const int64_t cus = cus_ < 0 ? -cus_ : cus_;
+    auto cdiv64 = [](int64_t a, int64_t b) { return (a + b - 1) / b; };
+    const double cf = (double)(zc + 4), cs = (double)(KC + 14);
+    double best = (double)cdiv64(tiles, cus) * cf;
+    int64_t nfull = tiles;
+    if (nk > 1) {
+        const double call = (double)cdiv64(tiles * nk, cus) * cs;
+        if (call < best * 0.97) { best = call; nfull = 0; }
+        const int64_t r = tiles % cus, R = tiles / cus;
+        if (r && R && !no_rem) {
+            const double crem = (double)R * cf + (double)cdiv64(r * nk, cus) * cs;
+            if (crem < best * 0.985) { best = crem; nfull = tiles - r; }
+        }
+    }
+    if (cost_out) *cost_out = best;
+    return nfull;
+}
+
+// BCy = 'extend' on k_pipe3d (EXT): the second sweep's pre-pass is applied out of a wavefront's own registers, so rows 0 / 1
+// and rows yc-2 / yc-1 each have to sit in ONE wavefront (RR adjacent rows each; the cross-section of row block jb starts at
+// row jb * RJ - H - joff) -- the first pair in block 0, the second in the block that owns row yc-1 and in the block before
+// it when that one owns row yc-2 or yc-3, whose second sweep reads row yc-1 through row yc-2.  xinv_p3_extend_joff: the
+// shift of the row blocks that achieves it -- 0 for five row counts in eight, 2 for the others (-1: none; not reached).
+__host__ __device__ inline bool xinv_p3_extend_ok(int64_t yc, int joff, int RJ, int H, int RR)
+{
+    if ((H + joff) % RR == RR - 1) return false;                   // row 0 would be a wavefront's last row
+    const int64_t jbo = (yc - 1 + joff) / RJ;                      // the block that owns row yc-1
+    auto together = [&](int64_t jb) { return ((yc - 2) - (jb * RJ - H - joff)) % RR != RR - 1; };   // row yc-2 is not a wavefront's last row
+    if (!together(jbo)) return false;
+    if (jbo > 0 && (yc - 1 + joff) - jbo * RJ <= 1 && !together(jbo - 1)) return false;
+    return true;
+}
+__host__ __device__ inline int xinv_p3_extend_joff(int64_t yc, int RJ, int H, int RR)
+{
+    return xinv_p3_extend_ok(yc, 0, RJ, H, RR) ? 0 : (xinv_p3_extend_ok(yc, 2, RJ, H, RR) ? 2 : -1);
+}
