@@ -192,9 +192,16 @@ def test_rolling_batch_2d_host_pointers(kind, sweeps, tol, masked_tiles):
         q['coefs'] = list(base['coefs'][:ncu]) + [F]
         q['S0'] = np.where(r['S0'] == util.U, 0.0, r['S0'])
         ps.append(q)
-    S, fl, st = util.run_hip_batched(ps, sweeps - 1, tol, shared=tuple(range(ncu)), host_inflight=-1, force_tile_skip=1)
-    assert st['path'] == 2 and st['rolling'] == (0 if masked_tiles else 1), st
-    for m, q in enumerate(ps):
-        So, flo = util.run_oracle(q, sweeps - 1, tol, 2)
-        assert np.array_equal(S[m], So), 'member %d: %d points differ' % (m, (S[m] != So).sum())
-        assert fl[m][0] == flo[0] and fl[m][2] == flo[2], (m, fl[m], flo)
+    ref = [util.run_oracle(q, sweeps - 1, tol, 2) for q in ps]
+    # one chunk (a batch this small): one rolling chain; chunks of two / of one member: TWO chains -- the lanes of the
+    # rolling batch, members 0-3 / 4-5 and 0-2 / 3-5 --, their launches issued alternately (xinv_hostptr.h)
+    for host_chunk in (0, 2, 1):
+        S, fl, st = util.run_hip_batched(ps, sweeps - 1, tol, shared=tuple(range(ncu)), host_inflight=-1, force_tile_skip=1,
+                                         host_chunk=host_chunk)
+        assert st['path'] == 2 and st['rolling'] == (0 if masked_tiles else 1), st
+        if not masked_tiles:
+            assert st['lanes'] == (2 if host_chunk else 1) and st['host_chunks'] == (nb // host_chunk if host_chunk else 1), st
+        for m, q in enumerate(ps):
+            So, flo = ref[m]
+            assert np.array_equal(S[m], So), 'chunks of %d, member %d: %d points differ' % (host_chunk, m, (S[m] != So).sum())
+            assert fl[m][0] == flo[0] and fl[m][2] == flo[2], (host_chunk, m, fl[m], flo)

@@ -170,7 +170,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // of a member's own), on the streaming path, where the planner is left to itself.
     // (xinv_options.host_inflight = -1 takes it for any batch of two or more: the tests' small volumes)
     const bool roll2d = (p.kind == KIND_STD2D || p.kind == KIND_GEN2D);     // (2-D: only where no tile is fully masked, see roll)
-    bool rolling = (p.kind == KIND_STD3D || roll2d) && opt.host_chunk == 0 && opt.host_inflight <= 0 &&
+    bool rolling = (p.kind == KIND_STD3D || roll2d) && (opt.host_chunk == 0 || opt.host_inflight < 0) && opt.host_inflight <= 0 &&
                    opt.path != XINV_PATH_COLOUR && !(p.BCx == XINV_BC_PERIODIC && (p.xc & 1) && p.xc < 64) &&
                    ((!roll2d && p.nbatch >= 4 && (double)n * 16.0 * (double)p.nbatch >= 100663296.0) || (opt.host_inflight < 0 && p.nbatch >= 2));
     // (2-D forms roll on request only -- host_inflight = -1 --: C4 x 8, 500 sweeps: 15.0 ms rolling against 13.4 in chunks of
@@ -590,7 +590,7 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         const int64_t L = (max_sweeps + Kf - 1) / Kf;               // launches of a member
         const int klast = (int)(max_sweeps - (L - 1) * Kf);           // sweeps of its last one
         std::vector<int64_t> join((size_t)nb, -1);
-        struct Retired { int64_t a, b; hipEvent_t ctl_done; };
+        struct Retired { int64_t a, b; hipEvent_t ctl_done; hipStream_t s; };
         std::deque<Retired> fin;
         // How far the host runs ahead of the GPU: far enough that a wake-up of the pacing wait (20-50 us) never starves the
         // queue -- ~400 us of launches, two at least (a 3-D launch is 0.1-1 ms, a 2-D one 30-60 us) --, not so far that a
@@ -598,6 +598,8 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         constexpr int NQ = 16;
         const double est_launch_us = std::max(20.0, (double)nb * (double)n * pl.K / (pl.pipe ? 6.0e5 : (is3d(p.kind) ? 2.5e5 : 3.0e5)) * 0.6);
         const int depth = (int)std::min(12.0, std::max(2.0, 400.0 / est_launch_us));
+        const int pstep = (roll2d && est_launch_us < 100.0) ? 4 : 1;   // launches per pacing event
+        const int dsteps = std::max(1, (depth + pstep - 1) / pstep);     // pacing events the host runs ahead
         hipEvent_t ev_l[NQ];
         for (int q = 0; q < NQ; q++) if ((r = ev.make(&ev_l[q], false))) return r;
         hipEvent_t ev_t0, ev_t1;
@@ -619,14 +621,14 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
                 else {                                              // stopped inside a pass: redo from its source, sweep by sweep
                     int cur = (int)((join[(size_t)m] + rl) & 1);
                     for (int64_t q = rl * Kf; q < sw; q++) {
-                        int rr = launch_planned(d, pl, ws, scp, 1, buf[cur], buf[cur ^ 1], m, 1, 1, 1);
+                        int rr = launch_planned(d, pl, ws, g.s, 1, buf[cur], buf[cur ^ 1], m, 1, 1, 1);
                         if (rr) return rr;
                         cur ^= 1;
                     }
                     where = cur;
                 }
                 if (where != 0)
-                    HIPCHK(hipMemcpyAsync(d.S + m * n, ws->S2 + m * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, scp));
+                    HIPCHK(hipMemcpyAsync(d.S + m * n, ws->S2 + m * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g.s));
                 if (c.overflow) flags[3 * m + 0] = 1.0;
                 if (c.wrote) { flags[3 * m + 1] = c.flag1; flags[3 * m + 2] = c.flag2; }
                 sweeps_max = std::max<int64_t>(sweeps_max, sw);
@@ -634,51 +636,92 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             hipEvent_t after;
             int rr = ev.make(&after, false);
             if (rr) return rr;
-            return finish_members(g.a, g.b - g.a, scp, after);
+            return finish_members(g.a, g.b - g.a, g.s, after);
         };
-        int64_t lo = 0, hi = 0, cj = 0;
-        for (int64_t i = 0; lo < nb; i++) {
+        // Lanes (2-D forms): the members are cut into two halves at a chunk boundary, each half a rolling chain of its own on
+        // its own stream, the two chains' launches issued alternately by this thread -- the lanes of a resident solve
+        // (run_sweeps): one chain's launch boundary is covered by the other's launch.  (Chains issued by DIFFERENT host
+        // threads -- the chunk scheme -- do not alternate in the runtime's hardware queues: C4 x 8, 2000 sweeps, 37 ms in
+        // chunks against 28.4 resident + 5 of copies.)  The 3-D form keeps one chain: its launches fill the chip in rounds.
+        struct Lane { int64_t lo, hi, cj, cend, mend; hipStream_t s; };
+        const int nl = (roll2d && nchunk >= 2 && ninfl >= 2) ? 2 : 1;
+        const int64_t csplit = nl == 2 ? (nchunk + 1) / 2 : nchunk;
+        Lane lanes[2] = { {0, 0, 0, csplit, first[(size_t)csplit], scp},
+                          {first[(size_t)csplit], first[(size_t)csplit], csplit, nchunk, nb, nl == 2 ? scps[1] : scp} };
+        if (nl == 2) {                                               // the second chain starts behind the plan and k_solve_init
+            hipEvent_t e_init;
+            if ((r = ev.make(&e_init, false))) return r;
+            HIPCHK(hipEventRecord(e_init, scp));
+            HIPCHK(hipStreamWaitEvent(lanes[1].s, e_init, 0));
+        }
+        hipEvent_t ev_l1[NQ];
+        if (nl == 2) for (int q = 0; q < NQ; q++) if ((r = ev.make(&ev_l1[q], false))) return r;
+        auto active = [&]() { for (int l = 0; l < nl; l++) if (lanes[l].lo < lanes[l].mend) return true; return false; };
+        for (int64_t i = 0; active(); i++) {
             if (!(i & 1)) {                                          // a join point: buffer 0 is the source of this launch
-                int64_t cn = cj;                                     // (chunks cj .. cn-1 have arrived)
-                {
-                    std::unique_lock<std::mutex> lk(act.mu);
-                    if (hi == lo && cj < nchunk)                     // nobody active: wait for the next arrival
-                        act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)cj] != 0 || act.abort; });
-                    if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
-                    if (act.abort) { t_err = "host-pointer solve aborted"; return XINV_ERR_HIP; }
-                    while (cn < nchunk && act.chunk_ready[(size_t)cn]) cn++;
+                std::unique_lock<std::mutex> lk(act.mu);
+                bool idle = true;
+                for (int l = 0; l < nl; l++) idle = idle && lanes[l].hi == lanes[l].lo;
+                if (idle) {                                          // nobody active: wait for the next arrival (uploads come in batch order)
+                    int64_t cw = -1;
+                    for (int l = nl - 1; l >= 0; l--) if (lanes[l].cj < lanes[l].cend) cw = lanes[l].cj;
+                    if (cw >= 0) act.cv.wait(lk, [&] { return act.chunk_ready[(size_t)cw] != 0 || act.abort; });
                 }
-                for (; cj < cn; cj++) {
-                    HIPCHK(hipStreamWaitEvent(scp, e_chunk[(size_t)cj], 0));
-                    for (int64_t m = first[(size_t)cj]; m < first[(size_t)cj + 1]; m++) join[(size_t)m] = i;
-                    hi = first[(size_t)cj + 1];
+                if (act.u_rc) { t_err = act.u_err; return act.u_rc; }
+                if (act.abort) { t_err = "host-pointer solve aborted"; return XINV_ERR_HIP; }
+                int64_t cn[2];
+                for (int l = 0; l < nl; l++) {                       // (chunks cj .. cn-1 of the lane have arrived)
+                    cn[l] = lanes[l].cj;
+                    while (cn[l] < lanes[l].cend && act.chunk_ready[(size_t)cn[l]]) cn[l]++;
                 }
-            }
-            if (hi > lo) {
-                int64_t f = lo;                                      // [lo, f): their last launch (klast sweeps)
-                while (f < hi && i - join[(size_t)f] == L - 1) f++;
-                const double *src = buf[i & 1];
-                double *dst = buf[(i + 1) & 1];
-                if (klast == Kf) {                                   // (a budget that is whole passes: one launch for everybody)
-                    r = launch_planned(d, pl, ws, scp, Kf, src, dst, lo, hi - lo, 0, 0); if (r) return r; nlaunch++;
-                } else {
-                    if (f > lo) { r = launch_planned(d, pl, ws, scp, klast, src, dst, lo, f - lo, 0, 0); if (r) return r; nlaunch++; }
-                    if (hi > f) { r = launch_planned(d, pl, ws, scp, Kf, src, dst, f, hi - f, 0, 0); if (r) return r; nlaunch++; }
-                }
-                if (f > lo) {
-                    HIPCHK(hipMemcpyAsync(hc + lo, ws->ctl + lo, (size_t)(f - lo) * sizeof(XinvCtl), hipMemcpyDeviceToHost, scp));
-                    Retired g{lo, f, nullptr};
-                    if ((r = ev.make(&g.ctl_done, false))) return r;
-                    HIPCHK(hipEventRecord(g.ctl_done, scp));
-                    fin.push_back(g);
-                    lo = f;
+                lk.unlock();
+                for (int l = 0; l < nl; l++) {
+                    Lane &ln = lanes[l];
+                    for (; ln.cj < cn[l]; ln.cj++) {
+                        HIPCHK(hipStreamWaitEvent(ln.s, e_chunk[(size_t)ln.cj], 0));
+                        for (int64_t m = first[(size_t)ln.cj]; m < first[(size_t)ln.cj + 1]; m++) join[(size_t)m] = i;
+                        ln.hi = first[(size_t)ln.cj + 1];
+                    }
                 }
             }
-            HIPCHK(hipEventRecord(ev_l[i % NQ], scp));
-            if (i >= depth) HIPCHK(hipEventSynchronize(ev_l[(i - depth) % NQ]));   // `depth` launches ahead of the GPU, no more
-            while (!fin.empty() && hipEventQuery(fin.front().ctl_done) == hipSuccess) {
-                r = finish(fin.front()); if (r) return r;
-                fin.pop_front();
+            for (int l = 0; l < nl; l++) {
+                Lane &ln = lanes[l];
+                const int64_t lo = ln.lo, hi = ln.hi;
+                if (hi > lo) {
+                    int64_t f = lo;                                  // [lo, f): their last launch (klast sweeps)
+                    while (f < hi && i - join[(size_t)f] == L - 1) f++;
+                    const double *src = buf[i & 1];
+                    double *dst = buf[(i + 1) & 1];
+                    if (klast == Kf) {                               // (a budget that is whole passes: one launch for everybody)
+                        r = launch_planned(d, pl, ws, ln.s, Kf, src, dst, lo, hi - lo, 0, 0); if (r) return r; nlaunch++;
+                    } else {
+                        if (f > lo) { r = launch_planned(d, pl, ws, ln.s, klast, src, dst, lo, f - lo, 0, 0); if (r) return r; nlaunch++; }
+                        if (hi > f) { r = launch_planned(d, pl, ws, ln.s, Kf, src, dst, f, hi - f, 0, 0); if (r) return r; nlaunch++; }
+                    }
+                    if (f > lo) {
+                        HIPCHK(hipMemcpyAsync(hc + lo, ws->ctl + lo, (size_t)(f - lo) * sizeof(XinvCtl), hipMemcpyDeviceToHost, ln.s));
+                        Retired g{lo, f, nullptr, ln.s};
+                        if ((r = ev.make(&g.ctl_done, false))) return r;
+                        HIPCHK(hipEventRecord(g.ctl_done, ln.s));
+                        fin.push_back(g);
+                        ln.lo = f;
+                    }
+                }
+                // `depth` launches ahead of the GPU, no more.  (An event behind EVERY launch of a 2-D chain -- 30-60 us -- holds the
+                //  next launch back by a few microseconds: the pacing events of those chains sit behind every fourth launch.)
+                if (i % pstep == 0) {
+                    hipEvent_t *evq = l ? ev_l1 : ev_l;
+                    const int64_t e = i / pstep;
+                    HIPCHK(hipEventRecord(evq[e % NQ], ln.s));
+                    if (e >= dsteps) HIPCHK(hipEventSynchronize(evq[(e - dsteps) % NQ]));
+                }
+            }
+            // (the retired groups of two chains do not finish in queue order: take whichever has arrived)
+            for (size_t q = 0; q < fin.size(); ) {
+                if (hipEventQuery(fin[q].ctl_done) == hipSuccess) {
+                    r = finish(fin[q]); if (r) return r;
+                    fin.erase(fin.begin() + (std::ptrdiff_t)q);
+                } else q++;
             }
             (void)hipGetLastError();                                 // (hipEventQuery: hipErrorNotReady is not an error)
         }
@@ -687,12 +730,13 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
             r = finish(fin.front()); if (r) return r;
             fin.pop_front();
         }
+        if (nl == 2) HIPCHK(hipStreamSynchronize(lanes[1].s));
         HIPCHK(hipEventRecord(ev_t1, scp));
         HIPCHK(hipStreamSynchronize(scp));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev_t0, ev_t1));
         t_stats.path = pl.path; t_stats.colours = pl.ncol; t_stats.sweeps_per_launch = Kf; t_stats.rows_per_tile = pl.RY;
-        t_stats.xuniform_mask = (int32_t)pl.um; t_stats.lanes = 1; t_stats.sweep_launches = nlaunch;
+        t_stats.xuniform_mask = (int32_t)pl.um; t_stats.lanes = nl; t_stats.sweep_launches = nlaunch;
         t_stats.sweeps_max = sweeps_max; t_stats.sweep_ms = ms; t_stats.plan_ms = plan_ms;
         t_stats.k_chunks = pl.K2 ? std::max(1, pl.nkc2) : 0;
         t_stats.pipelined = pl.pipe ? pl.npair : 0;
