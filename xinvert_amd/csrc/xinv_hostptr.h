@@ -119,8 +119,9 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     static const bool trace_on = XINV_ENV_INT("XINV_HOST_TRACE", 0) != 0;
     auto trace = [&](const char *what, long long k = -1) {
         if (!trace_on) return;
-        fprintf(stderr, "[xinv host %8.3f ms] %s%s%lld\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count(),
-                what, k < 0 ? " " : " #", k);
+        const double ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        if (k < 0) fprintf(stderr, "[xinv host %8.3f ms] %s\n", ms_, what);
+        else fprintf(stderr, "[xinv host %8.3f ms] %s #%lld\n", ms_, what, k);
     };
     DeviceGuard dg;
     HIPCHK(dg.select(opt.device));
@@ -139,8 +140,11 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
         if (!*sp) {
             if (sp != &ws->s_compute && XINV_ENV_INT("XINV_COPY_PRIO", 1)) {
                 int lo_ = 0, hi_ = 0;
-                HIPCHK(hipDeviceGetStreamPriorityRange(&lo_, &hi_));
-                HIPCHK(hipStreamCreateWithPriority(sp, hipStreamNonBlocking, hi_));
+                if (hipDeviceGetStreamPriorityRange(&lo_, &hi_) != hipSuccess || hipStreamCreateWithPriority(sp, hipStreamNonBlocking, hi_) != hipSuccess) {
+                    (void)hipGetLastError();             // (no priorities on this device / runtime: a plain stream)
+                    *sp = nullptr;
+                    HIPCHK(hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+                }
             } else
                 HIPCHK(hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
         }
