@@ -131,7 +131,7 @@ typedef struct xinv_options {
                                    small test problems take that path; it never changes a result.  -1: the device's count,
                                    without that cut (A/B comparisons); -n: n units, without it.                        */
     int32_t host_inflight;      /* host-pointer entries: chunk solves in flight on a device at a time (1 .. 6; 0 = the
-                                   library's choice -- four for the 2-D forms, three for the 3-D ones): every one is a chain of dependent launches on a stream and a
+                                   library's choice -- two for the 2-D forms, three for the 3-D ones): every one is a chain of dependent launches on a stream and a
                                    workspace of its own; their launches fill each other's tails.  The standard 3-D form with
                                    shared coefficient arrays runs a ROLLING batch instead where it is left at 0 (and
                                    host_chunk is): one chain of launches over the members that have arrived and are

@@ -267,7 +267,7 @@ static int bind_thread_to_device_node(int device)
 // Grown on demand, reused across solves (no hipMalloc in steady state).
 #define XINV_MAX_LANES 4
 #define XINV_MAX_INFLIGHT 6          /* host-pointer entries: chunk solves in flight on one device (workspace slots 0 .. 5) */
-#define XINV_DEFAULT_INFLIGHT 4          /* ... of the 2-D forms (three for the 3-D ones: xinv_hostptr.h) */
+#define XINV_DEFAULT_INFLIGHT 2          /* ... of the 2-D forms (three for the 3-D ones: xinv_hostptr.h) */
 struct Workspace {
     int device = -1;
     int cus = 0;                                        // the device's compute units (make_plan)

@@ -66,18 +66,22 @@ static std::vector<int64_t> host_chunks(const Problem &p, const xinv_options &op
         for (int64_t m0 = 0; m0 < nb; m0 += per) out.push_back(std::min(per, nb - m0));
         return out;
     }
-    // 2-D forms, end of round 6 (FOUR chunk solves in flight, the copy streams at high priority; wall ms of 500 sweeps,
-    // profiles/r06_host_pipeline.txt): 1440 x 720 general form x 3 members -- chunks of 1: 6.6, one chunk 7.1; x 6 -- 1: 11.4,
-    // 2: 14.5, 3: 13.0; x 8 -- 1: 13.5, 2: 13.1, 4: 14.7; x 12 -- 1: 18.8, 2: 17.7, 3: 22.4; x 16 -- 2: 21.6, 4: 27.1; x 32 --
-    // 2: 38.1, 4: 43.0, 8: 40.4; x 64 -- 4: 82.3, 8: 75.2, 16: 73.0.  3600 x 1800 standard form x 2 -- 1: 15.9, one chunk 17.6;
-    // x 3 -- 1: 22.2, one chunk 24.5; x 4 -- 1: 27.0, 2: 26.6; x 8 -- 1: 44.2, 2: 43.8.  Odd chunks lose (their two lanes are
-    // uneven); single members up to eight, pairs up to 32, four chunks beyond.
+    // 2-D forms, end of round 6 (TWO chunk solves in flight, the copy streams at high priority; wall ms of 500 sweeps,
+    // profiles/r06_host_pipeline.txt): 1440 x 720 general form (17 MB a member) x 3 members -- chunks of 1: 8.5, one chunk 7.5;
+    // x 6 -- 1: 13.3, 2: 12.0, 3: 12.9; x 8 -- 1: 17.2, 2: 14.0, 4: 15.9; x 12 -- 2: 19.0, 3: 22.4, 4: 20.2, 6: 19.3; x 16 --
+    // 2: 23.9, 4: 26.2, 8: 23.6; x 32 -- 2: 42.8, 4: 49.0, 8: 41.5, 16: 40.6; x 64 -- 8: 82.0, 16: 71.7, 32: 72.8.  3600 x 1800
+    // standard form (104 MB a member) x 2 -- 1: 16.7, one chunk 18.1; x 3 -- 1: 20.5, one chunk 25.1; x 8 -- 1: 43.7, 2: 45.8,
+    // 4: 48.4.  Odd chunks lose (their two lanes are uneven).  Large members travel one by one; small ones in pairs up to 16
+    // members, in four chunks beyond.  (FOUR chunk solves in flight are faster in a fresh process -- C4 x 8 13.1 against
+    // 13.7, x 16 21.6 --, but in a process that has run resident solves before -- bench.py -- every second process lands on
+    // 15-16 ms: the chains then share the runtime's hardware queues unevenly; two in flight give 12.8-13.1 every time.)
     if (total < 50331648.0) { out.push_back(nb); return out; }
-    {
-        const int64_t per = nb < 8 ? 1 : (nb <= 32 ? 2 : (nb + 3) / 4);
-        for (int64_t m0 = 0; m0 < nb; m0 += per) out.push_back(std::min(per, nb - m0));
-        return out;
-    }
+    int64_t per;
+    if (member_bytes >= 67108864.0) per = 1;
+    else if (nb < 4) { out.push_back(nb); return out; }
+    else per = nb <= 16 ? 2 : ((std::max<int64_t>(2, nb / 4) + 1) & ~(int64_t)1);
+    for (int64_t m0 = 0; m0 < nb; m0 += per) out.push_back(std::min(per, nb - m0));
+    return out;
 }
 
 // One device: upload -> solve -> download, pipelined over member chunks by three actors:
@@ -409,14 +413,15 @@ static int solve_host_one(Problem &p, double *flags, const xinv_options &opt, co
     // (276 tiles on 256 CUs) ends in a tail during which only the OTHER chains' launches keep the CUs busy.  Two chains
     // (round 5) left the chip 1.68 launches deep on average -- C5 x 15: 160 ms of which the GPU is busy 160, at 107 us per
     // volume and launch against 77 for the resident batch (profiles/r06_host_pipeline.txt) --; three / four fill the tails.
-    // 2-D forms: FOUR (end of round 6, with the copy streams at high priority: C4 x 8 14.4 -> 13.3 ms, 3600 x 1800 x 8
-    // 47.6 -> 43.6; before, a third and fourth chain stretched the uploads behind them to 8 ms).  What is left against the
-    // resident batch (C4 x 8, 2000 sweeps: 37.1 ms against 28.4 + 5 of copies) is the price of chains issued by different
-    // host threads into the runtime's hardware queues: two chains alternating in ONE queue -- the lanes of a resident solve --
-    // overlap launch by launch, chains in different queues are arbitrated worse (GPU_MAX_HW_QUEUES=8 makes the resident
-    // two-lane solve itself 7.6 -> 11.7 ms).
+    // 2-D forms: two.  (Four -- possible since the copy streams have queues of their own; before, a third and fourth chain
+    // stretched the uploads behind them to 8 ms -- are faster in a fresh process, C4 x 8 14.4 -> 13.3 ms, 3600 x 1800 x 8
+    // 47.6 -> 43.6, and bimodal in one that has run resident solves before: bench.py's end_to_end leg 12.3-12.9 or 14.7-16.1
+    // ms, process by process, against 12.8-13.1 with two; host_inflight = 4 asks for them.)  What is left against the
+    // resident batch (C4 x 8, 2000 sweeps: 37.1 ms against 28.4 + 5 of copies) is kernel time of small launches: four
+    // chains of two-member launches run 8.7 us per member and pass, the resident batch's two lanes of four 7.2
+    // (tools/kernel_groups.sh; GPU_MAX_HW_QUEUES=8 makes the resident two-lane solve itself 7.6 -> 11.7 ms).
     const int ninfl = (int)std::min<int64_t>(nchunk, std::max(1, opt.host_inflight > 0 ? std::min(opt.host_inflight, XINV_MAX_INFLIGHT)
-                                                                                         : (is3d(p.kind) ? 3 : XINV_DEFAULT_INFLIGHT)));
+                                                                                         : (is3d(p.kind) ? 3 : XINV_ENV_INT("XINV_INFLIGHT_2D", XINV_DEFAULT_INFLIGHT))));
     std::vector<Workspace *> wss((size_t)ninfl, nullptr);
     std::vector<hipStream_t> scps((size_t)ninfl, nullptr);
     wss[0] = ws; scps[0] = scp;
