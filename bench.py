@@ -686,11 +686,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ms_sweeps, launches = 0.0, 0
+    stamps = [t0]                                  # (host clock after every step: a stall inside the timed region shows in the line)
     for _ in range(a.steps):
         s, allf = step()
         ms_sweeps += s['sweep_ms']; launches += s['sweep_launches']
+        stamps.append(time.perf_counter())
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0              # this rank's own K steps (before it waits for the others)
+    step_ms = sorted((b_ - a_) * 1e3 for a_, b_ in zip(stamps[:-1], stamps[1:]))
     barrier()
     dt = time.perf_counter() - t0
     ranks_done, backend = 1, None
@@ -748,6 +751,7 @@ def main():
             'n_gpus': ranks_done, 'gpus_requested': a.gpus, 'rccl_ranks': ranks_done if backend == 'nccl' else 0,
             'collective_backend': backend, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': scaling,
+            'step_ms_min_median_max': [step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1]],      # rank 0's own steps (host clock)
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'rank_values': rank_values, 'n1_value': n1,
             'rank_spread': None if not rank_values else max(r['value'] for r in rank_values) / min(r['value'] for r in rank_values),
