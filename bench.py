@@ -683,6 +683,8 @@ def main():
         rp.reset()
         step()
     rp.reset()
+    import gc
+    gc.collect(); gc.disable()                     # (as timeit does: no collector pause inside the timed region)
     barrier()
     t0 = time.perf_counter()
     ms_sweeps, launches = 0.0, 0
@@ -693,6 +695,7 @@ def main():
         stamps.append(time.perf_counter())
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0              # this rank's own K steps (before it waits for the others)
+    gc.enable()
     step_ms = sorted((b_ - a_) * 1e3 for a_, b_ in zip(stamps[:-1], stamps[1:]))
     barrier()
     dt = time.perf_counter() - t0
