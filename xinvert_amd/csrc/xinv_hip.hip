@@ -38,7 +38,7 @@
 #define XINV_AUX_KERNELS            /* the detection / skip-norm helper kernels live in this unit */
 #include "xinv_dispatch.h"          /* argument structs + launchers of the sweep kernels (xinv_tu_*.hip) */
 
-#define XINV_VERSION 500
+#define XINV_VERSION 600
 #define XINV_MEMBER_CHUNK 32768     /* members per launch: grid.y / grid.z are limited to 65535 */
 
 // The shipped library reads NO environment variable: the planner's choices are overridden through xinv_options
