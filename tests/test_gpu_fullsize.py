@@ -138,6 +138,29 @@ def test_c4_gill_matsuno_member_1440x720_vs_oracle():
     assert st['xuniform_mask'] == 31
 
 
+@pytest.mark.parametrize('sweeps', [40, 41])
+def test_c4_gill_matsuno_batch_host_pointers_chunked_and_rolling_equal_resident(sweeps):
+    """One GPU's share of BASELINE configs[3] at full grid size through the host-pointer entry: the library's own chunks
+    (pairs of members, two chunk solves in flight), four chunk solves in flight, and the rolling batch in two lanes
+    (host_inflight = -1: members 0-3 / 4-5 as two chains whose launches alternate) give the fields of the
+    device-resident solve bit for bit; member 5 against the oracle."""
+    from xinvert_amd import synthetic
+    p = synthetic.gill_matsuno(720, 1440, 6)
+    ps = [synthetic.member(p, m) for m in range(6)]
+    shared = tuple(p['shared'])
+    Sr, flr, _ = util.run_hip_dev(ps, sweeps - 1, 0.0, shared=shared)
+    So, flo = run_oracle(ps[5], sweeps - 1, 0.0, COLOUR_2)
+    assert np.array_equal(Sr[5], So) and flr[5][2] == flo[2]
+    for opt, chunks, rolling in ((dict(), 3, 0), (dict(host_inflight=4), 3, 0), (dict(host_inflight=-1), 3, 1),
+                                 (dict(host_inflight=-1, host_chunk=1), 6, 1)):
+        S, fl, st = util.run_hip_batched(ps, sweeps - 1, 0.0, shared=shared, **opt)
+        assert st['host_chunks'] == chunks and st['rolling'] == rolling and st['path'] == 2, (opt, st)
+        if rolling:
+            assert st['lanes'] == 2, st
+        assert np.array_equal(S, Sr), (opt, int((S != Sr).sum()))
+        assert np.array_equal(fl[:, [0, 2]], flr[:, [0, 2]]), opt
+
+
 def test_c5_omega_volume_720x360x50_vs_oracle():
     """BASELINE configs[4]: one of the 120 volumes at full size (topography mask)."""
     from xinvert_amd import synthetic
