@@ -1,4 +1,9 @@
 #!/bin/bash
+# Sweeps of the host-pointer pipeline's knobs on one box (profiles/r06_host_pipeline.txt, sections (2)-(9), were made with
+# variants of this loop): tools/bench_host_pipeline.py <config> --members M --sweeps S --chunks a,b,c --inflight i,j [--lanes n]
+# [--check-every n]; the hooks build (XINV_SO=build/libxinv_hooks.so) additionally reads XINV_COPY_PRIO (0: plain copy streams),
+# XINV_COPY_THREADS (staging memcpy workers; -1: none), XINV_INFLIGHT_2D (default chunk solves in flight of the 2-D forms) and
+# XINV_HOST_TRACE (phase stamps on stderr).  As committed: chunk sizes with two chunk solves in flight.
 # chunk sizes with TWO chunk solves in flight (the stable setting in bench.py's process)
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$PWD/gpurun_out/host_trace; mkdir -p $out
