@@ -497,9 +497,11 @@ def sustained_leg(rp, sweeps, opts, n_all, seconds=5.0):
                     'back-to-back solves, not one queue of launches'}
 
 
-def host_pointer_solve(p, sweeps, reps=3, **opt):
+def host_pointer_solve(p, sweeps, reps=3, f32=False, **opt):
     """One C-ABI call on HOST arrays (the `_batched` entry): upload, sweeps, download -- what a caller of the reference's
-    API pays.  -> (best wall seconds, stats of that call, S, flags)"""
+    API pays.  -> (best wall seconds, stats of that call, S, flags).  f32: the first guess / solution and the forcing
+    travel as float32 (xinv_options.f32_mask; promoted / rounded on the device) -- the dtype of every dataset the
+    reference ships (tests/test_Poisson.py:14-24)."""
     import ctypes
     from xinvert_amd import _lib
     from xinvert_amd.resident import FN, scalars
@@ -518,13 +520,19 @@ def host_pointer_solve(p, sweeps, reps=3, **opt):
         else:
             arrs.append(np.ascontiguousarray(c, dtype=np.float64)); strides.append(0 if k in p['shared'] else n)
     q = {k: v for k, v in p.items() if k not in ('S0', 'coefs')}
+    f32_mask = 0
+    if f32:
+        arrs[0] = arrs[0].astype(np.float32)
+        arrs[-1] = arrs[-1].astype(np.float32)
+        f32_mask = 1 | (1 << (len(arrs) - 1))
+    isf = [bool((f32_mask >> k) & 1) for k in range(len(arrs))]
     best = None
     for _ in range(reps):
         S = arrs[0].copy()
         fl = np.tile(np.array([0., 1., 0.]), (nb, 1))
-        o = _lib.options(rowconst_mask=rowconst, **opt)
+        o = _lib.options(rowconst_mask=rowconst, f32_mask=f32_mask, **opt)
         t = time.perf_counter()
-        rc = getattr(L, FN[p['kind']] + '_batched')(_lib.hptr(S), *[_lib.hptr(x) for x in arrs[1:]], nb,
+        rc = getattr(L, FN[p['kind']] + '_batched')(_lib.hptr(S, f32=isf[0]), *[_lib.hptr(x, f32=isf[k + 1]) for k, x in enumerate(arrs[1:])], nb,
                                                     _lib.strides_arg(strides), *scalars(q), _lib.hptr(fl),
                                                     sweeps - 1, 0.0, ctypes.byref(o))
         dt = time.perf_counter() - t
@@ -579,6 +587,23 @@ def end_to_end_leg(local, p_c2, S_resident):
                      'host_chunks': st['host_chunks'], 'vs_resident': dt / tr,
                      'value_pcie_inclusive': n_all * sweeps / dt, 'unit': 'point-sweeps/s',
                      'bitwise_equal_to_resident': bool(np.array_equal(S, res))}
+        if name == 'C5x15':
+            # ... and as the reference's users hold their data: float32 forcing in, float32 solution out (half the bytes over
+            # PCIe; the sweeps are the same float64 arithmetic on the promoted values).  Checked against the resident solve of
+            # the float32-rounded forcing, rounded to float32.
+            p32 = dict(p)
+            p32['coefs'] = list(p['coefs'][:-1]) + [np.asarray(p['coefs'][-1]).astype(np.float32).astype(np.float64)]
+            p32['S0'] = np.asarray(p['S0']).astype(np.float32).astype(np.float64)
+            rp = ResidentProblem(p32, device=local)
+            rp.reset(); rp.solve(sweeps - 1, 0.0)
+            res32 = rp.result().astype(np.float32)
+            del rp
+            dt32, st32, S32, _ = host_pointer_solve(p32, sweeps, device=local, f32=True)
+            out[name + '_float32'] = {'wall_ms': dt32 * 1e3, 'h2d_ms': st32['h2d_ms'], 'd2h_ms': st32['d2h_ms'],
+                                      'host_chunks': st32['host_chunks'], 'vs_resident': dt32 / tr,
+                                      'value_pcie_inclusive': n_all * sweeps / dt32, 'unit': 'point-sweeps/s',
+                                      'note': 'first guess / solution and forcing as float32 host arrays (f32_mask), float64 sweeps',
+                                      'equal_to_resident_rounded_to_float32': bool(S32.dtype == np.float32 and np.array_equal(S32, res32))}
     return out
 
 
