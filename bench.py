@@ -707,10 +707,10 @@ def main():
     for _ in range(a.warmup):
         rp.reset()
         step()
-    rp.reset()
     import gc
-    gc.collect(); gc.disable()                     # (as timeit does: no collector pause inside the timed region)
-    barrier()
+    gc.disable()                                   # (as timeit does: no collector pause inside the timed region; no gc.collect()
+    rp.reset()                                     #  here -- 20 ms of idle GPU before t0 cost the first steps 10 %: the clocks
+    barrier()                                      #  ramp for ~30 ms after any idle gap, tools/step_time_vs_state.py)
     t0 = time.perf_counter()
     ms_sweeps, launches = 0.0, 0
     stamps = [t0]                                  # (host clock after every step: a stall inside the timed region shows in the line)
@@ -721,7 +721,8 @@ def main():
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0              # this rank's own K steps (before it waits for the others)
     gc.enable()
-    step_ms = sorted((b_ - a_) * 1e3 for a_, b_ in zip(stamps[:-1], stamps[1:]))
+    step_ms_order = [(b_ - a_) * 1e3 for a_, b_ in zip(stamps[:-1], stamps[1:])]
+    step_ms = sorted(step_ms_order)
     barrier()
     dt = time.perf_counter() - t0
     ranks_done, backend = 1, None
@@ -780,6 +781,7 @@ def main():
             'collective_backend': backend, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': scaling,
             'step_ms_min_median_max': [step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1]],      # rank 0's own steps (host clock)
+            'step_ms': [round(x, 3) for x in step_ms_order[:64]],                                   # ... in order (the first 64)
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'rank_values': rank_values, 'n1_value': n1,
             'rank_spread': None if not rank_values else max(r['value'] for r in rank_values) / min(r['value'] for r in rank_values),
